@@ -1,0 +1,387 @@
+"""Host-side mirror of the reference's API for the DLS path, over the C ABI (include/ikgpu.h).
+
+Names, argument meaning and outcome reporting follow dazzmo/ik so that the parity tests read
+like the reference's own (commented-out) tests (ik/test/dls.cpp:10-76):
+
+    reference (C++)                                   here (Python over libikgpu.so)
+    ------------------------------------------------  -----------------------------------------
+    pinocchio::urdf::buildModelFromXML  cassie.cpp:34  Model.from_urdf_xml(xml, free_flyer)
+    ik::InverseKinematicsProblem        problem.hpp:9  InverseKinematicsProblem(model, max_priority_level)
+    ik::FrameTask::create               frame.hpp:123  FrameTask.create(model, frame, type, reference_frame)
+    ik::KinematicType                   frame.hpp:20   KinematicType
+    ik::dls_parameters                  dls.hpp:24     dls_parameters
+    ik::inverse_kinematics_visitor      visitor.hpp:7  inverse_kinematics_visitor (one-parameter family)
+    ik::dls_data                        dls.hpp:34     dls_data(problem)  (owns the device handle)
+    ik::dls(problem, q0, data, v, p)    dls.hpp:111    dls(problem, q0, data, visitor, p)
+    --                                                 dls_batch(problem, Q0, targets, data, visitor, p)
+
+The C++ mirror of the same classes lives in ik_amd/csrc/host/ik/.  No arithmetic happens here.
+"""
+import ctypes as C
+import enum
+
+import numpy as np
+
+from . import capi
+
+
+class KinematicType(enum.IntEnum):  # reference ik/ik/frame.hpp:20
+    Position = 0
+    Orientation = 1
+    Full = 2
+
+
+class SE3:
+    """pinocchio::SE3 as the path uses it: a rotation matrix and a translation."""
+
+    def __init__(self, rotation=None, translation=None):
+        self.rotation = np.eye(3) if rotation is None else np.array(rotation, dtype=np.float64).reshape(3, 3)
+        self.translation = np.zeros(3) if translation is None else np.array(translation, dtype=np.float64).reshape(3)
+
+    @staticmethod
+    def Identity():
+        return SE3()
+
+    @staticmethod
+    def from12(v):
+        v = np.asarray(v, dtype=np.float64).reshape(12)
+        return SE3(v[:9].reshape(3, 3), v[9:])
+
+    def to12(self):
+        return np.concatenate([self.rotation.reshape(9), self.translation])
+
+
+class Model:
+    """What the path reads of pinocchio::Model (reference ik/ik/common.hpp:16)."""
+
+    def __init__(self, handle):
+        self._h = handle
+        L = capi.lib()
+        f = capi.FlatModel()
+        capi.check(L.ikgpu_model_get_flat(self._h, C.byref(f)))
+        self.njoints, self.nq, self.nv, self.nframes = f.njoints, f.nq, f.nv, f.nframes
+        self.names = [f.joint_names[i].decode() for i in range(f.njoints)]
+        self.frame_names = [f.frame_names[i].decode() for i in range(f.nframes)]
+        self.lowerPositionLimit = np.array(f.lower[:f.nq], dtype=np.float64)
+        self.upperPositionLimit = np.array(f.upper[:f.nq], dtype=np.float64)
+        self._flat = f
+
+    @staticmethod
+    def from_urdf_xml(xml, free_flyer=False):
+        """pinocchio::urdf::buildModelFromXML(xml, [JointModelFreeFlyer(),] model)."""
+        if isinstance(xml, str):
+            xml = xml.encode("utf-8")
+        h = C.c_void_p()
+        capi.check(capi.lib().ikgpu_model_from_urdf(xml, len(xml), capi.ROOT_FREEFLYER if free_flyer else capi.ROOT_FIXED,
+                                                    C.byref(h)))
+        return Model(h)
+
+    @staticmethod
+    def from_urdf_file(path, free_flyer=False):
+        with open(path, "rb") as fh:
+            return Model.from_urdf_xml(fh.read(), free_flyer)
+
+    def getFrameId(self, name):
+        return int(capi.lib().ikgpu_model_frame_id(self._h, name.encode()))
+
+    def getJointId(self, name):
+        return int(capi.lib().ikgpu_model_joint_id(self._h, name.encode()))
+
+    def existFrame(self, name):
+        return self.getFrameId(name) < self.nframes
+
+    def flat(self):
+        """numpy copies of the flat arrays (same keys as the oracle's model dict)."""
+        f, nj, nf = self._flat, self.njoints, self.nframes
+        return dict(
+            nq=self.nq, nv=self.nv,
+            jtype=np.array(f.joint_type[:nj], np.int32), parent=np.array(f.joint_parent[:nj], np.int32),
+            idx_q=np.array(f.joint_idx_q[:nj], np.int32), idx_v=np.array(f.joint_idx_v[:nj], np.int32),
+            placement=np.array(f.joint_placement[:12 * nj]).reshape(nj, 12),
+            axis=np.array(f.joint_axis[:3 * nj]).reshape(nj, 3),
+            lower=self.lowerPositionLimit.copy(), upper=self.upperPositionLimit.copy(),
+            frame_parent=np.array(f.frame_parent[:nf], np.int32),
+            frame_placement=np.array(f.frame_placement[:12 * nf]).reshape(nf, 12),
+            frame_names=list(self.frame_names), joint_names=list(self.names))
+
+    def __del__(self):
+        try:
+            if self._h:
+                capi.lib().ikgpu_model_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class FrameTask:
+    """ik::FrameTask (reference ik/ik/frame.hpp:78-200)."""
+
+    def __init__(self, model, frame, type=KinematicType.Full, reference_frame="universe"):
+        self.frame, self.reference_frame, self.type = frame, reference_frame, KinematicType(type)
+        self._frame_id, self._ref_id = model.getFrameId(frame), model.getFrameId(reference_frame)
+        if self._frame_id >= model.nframes:
+            raise ValueError("frame %r not found in model" % frame)
+        if self._ref_id >= model.nframes:
+            raise ValueError("reference frame %r not found in model" % reference_frame)
+        self._dimension = 6 if self.type == KinematicType.Full else 3  # frame.hpp:102-108
+        self._weighting = np.ones(self._dimension)                      # task.hpp:48-51
+        self.target = SE3.Identity()                                    # frame.hpp:189
+
+    @staticmethod
+    def create(model, frame, type=KinematicType.Full, reference_frame="universe"):
+        return FrameTask(model, frame, type, reference_frame)
+
+    def dimension(self):
+        return self._dimension
+
+    def weighting(self):
+        return self._weighting
+
+
+class InverseKinematicsProblem:
+    """ik::InverseKinematicsProblem (reference ik/ik/problem.hpp:9-206), frame tasks only --
+    the other task kinds are outside the accelerated path."""
+
+    def __init__(self, model, max_priority_level=0):
+        self._model = model
+        self._max_priority_level = int(max_priority_level)
+        self._tasks = [[] for _ in range(self._max_priority_level + 1)]
+        self._frame_tasks = []
+        self._frame_tasks_map = {}
+        self._generation = 0
+
+    def max_priority_level(self):
+        return self._max_priority_level
+
+    def model(self):
+        return self._model
+
+    def add_frame_task(self, name, task, priority=0):
+        if not 0 <= priority <= self._max_priority_level:
+            raise ValueError("Maximum priority level exceeded!")
+        self._frame_tasks_map.setdefault(name, len(self._frame_tasks))
+        self._frame_tasks.append(task)
+        self._tasks[priority].append(task)
+        self._generation += 1
+        return task
+
+    def get_frame_task(self, name):
+        return self._frame_tasks[self._frame_tasks_map[name]]
+
+    def get_all_tasks(self, priority):
+        return self._tasks[priority]
+
+    def get_all_constraints(self):
+        return []
+
+    def e_size(self, priority):
+        return sum(t.dimension() for t in self._tasks[priority])
+
+    def c_size(self):
+        return 0
+
+    def ordered_tasks(self):
+        """(task, priority) in the row order of the stacked system (reference ik/ik/dls.cpp:20-24)."""
+        return [(t, p) for p in range(self._max_priority_level + 1) for t in self._tasks[p]]
+
+
+class dls_parameters:
+    """ik::dls_parameters (reference ik/ik/dls.hpp:24-28, ik/ik/common.hpp:59-66)."""
+
+    def __init__(self, max_iterations=100, step_length=1.0, damping=1e-2, max_time=1.0, random_restart=False):
+        self.max_iterations = max_iterations
+        self.max_time = max_time              # unused by the reference loop
+        self.step_length = step_length
+        self.damping = damping
+        self.random_restart = random_restart  # unused by the reference loop
+
+
+class inverse_kinematics_visitor:
+    """ik::inverse_kinematics_visitor (reference ik/ik/visitor.hpp:7-22).  A C++ visitor cannot run
+    inside the kernel; the one-parameter family `||e[0]||^2 < tolerance` is what crosses the ABI.
+    tolerance < 0 is a visitor whose should_stop() always returns false."""
+
+    def __init__(self, tolerance=1e-4):
+        self.tolerance = tolerance
+
+
+class never_stop_visitor(inverse_kinematics_visitor):
+    def __init__(self):
+        super().__init__(-1.0)
+
+
+class dls_data:
+    """ik::dls_data (reference ik/ik/dls.hpp:34-65): the reusable workspace.  Here it owns the
+    device-side problem handle (constant tables in HBM) and reports the outcome of the last call."""
+
+    def __init__(self, problem, device=0):
+        self.success = False
+        self.iterations = 0
+        self.q = None
+        self._device = int(device)
+        self._h = None
+        self._generation = -1
+        self._bind(problem)
+
+    def _task_array(self, problem):
+        ordered = problem.ordered_tasks()
+        arr = (capi.Task * len(ordered))()
+        for i, (t, prio) in enumerate(ordered):
+            arr[i].frame, arr[i].reference, arr[i].type, arr[i].priority = t._frame_id, t._ref_id, int(t.type), prio
+            w = list(np.asarray(t.weighting(), dtype=np.float64)) + [1.0] * 6
+            for k in range(6):
+                arr[i].weight[k] = w[k]
+        return arr
+
+    def _bind(self, problem):
+        key = (problem._generation, tuple(tuple(t.weighting()) for t, _ in problem.ordered_tasks()))
+        if self._h is not None and key == self._generation:
+            return
+        self._release()
+        arr = self._task_array(problem)
+        h = C.c_void_p()
+        capi.check(capi.lib().ikgpu_problem_create(problem.model()._h, arr, len(arr), self._device, C.byref(h)))
+        self._h = h
+        self._generation = key
+        self.rows = int(capi.lib().ikgpu_problem_rows(h))
+        self.kernel = capi.lib().ikgpu_problem_kernel(h).decode()
+
+    def _release(self):
+        if self._h is not None:
+            capi.lib().ikgpu_problem_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+
+def plan(problem):
+    """Name of the kernel specialisation the problem maps to (host-only; raises IkgpuError when the
+    shape has no device kernel)."""
+    ordered = problem.ordered_tasks()
+    arr = (capi.Task * len(ordered))()
+    for i, (t, prio) in enumerate(ordered):
+        arr[i].frame, arr[i].reference, arr[i].type, arr[i].priority = t._frame_id, t._ref_id, int(t.type), prio
+        w = list(np.asarray(t.weighting(), dtype=np.float64)) + [1.0] * 6
+        for k in range(6):
+            arr[i].weight[k] = w[k]
+    buf = C.create_string_buffer(128)
+    capi.check(capi.lib().ikgpu_problem_plan(problem.model()._h, arr, len(arr), buf, len(buf)))
+    return buf.value.decode()
+
+
+def _params(visitor, p):
+    return capi.DlsParams(int(p.max_iterations), float(p.damping), float(p.step_length), float(visitor.tolerance))
+
+
+def dls(problem, q0, data, visitor=None, p=None):
+    """ik::dls (reference ik/ik/dls.hpp:111-114): one problem, targets taken from each task's
+    `target`; returns q and sets data.success exactly as reference ik/ik/dls.cpp:62-63,76-77.
+    Runs as a batch of one on the device."""
+    visitor = visitor or inverse_kinematics_visitor()
+    p = p or dls_parameters()
+    data._bind(problem)
+    model = problem.model()
+    q0 = np.ascontiguousarray(q0, dtype=np.float64).reshape(model.nq)
+    tg = np.ascontiguousarray(np.stack([t.target.to12() for t, _ in problem.ordered_tasks()]))
+    q = np.empty(model.nq)
+    ok = np.zeros(1, np.uint8)
+    it = np.zeros(1, np.int32)
+    prm = _params(visitor, p)
+    capi.check(capi.lib().ikgpu_dls_solve_batch_host(
+        data._h, 1, q0.ctypes.data, tg.ctypes.data, C.byref(prm), q.ctypes.data, ok.ctypes.data, it.ctypes.data, capi.AOS))
+    data.success, data.iterations, data.q = bool(ok[0]), int(it[0]), q
+    return q
+
+
+def dls_batch(problem, Q0, targets, data, visitor=None, p=None, layout="soa", out=None, stream=None):
+    """B independent ik::dls() calls in lockstep on the device.
+
+    torch CUDA tensors (float64, contiguous) go straight through as device pointers on the current
+    stream; numpy arrays take the host-pointer entry point (copy in / solve / copy out).
+      layout "soa": Q0 [nq, B], targets [ntasks, 12, B]   |   "aos": Q0 [B, nq], targets [B, ntasks, 12]
+    Returns (Q, success uint8 [B], iterations int32 [B]) in the same container type as Q0.
+    """
+    visitor = visitor or inverse_kinematics_visitor()
+    p = p or dls_parameters()
+    data._bind(problem)
+    model = problem.model()
+    ntasks = len(problem.ordered_tasks())
+    lay = {"soa": capi.SOA, "aos": capi.AOS}[layout]
+    prm = _params(visitor, p)
+    L = capi.lib()
+    if isinstance(Q0, np.ndarray):
+        Q0 = np.ascontiguousarray(Q0, dtype=np.float64)
+        targets = np.ascontiguousarray(targets, dtype=np.float64)
+        B = Q0.shape[1] if lay == capi.SOA else Q0.shape[0]
+        _check_shapes(Q0.shape, targets.shape, model.nq, ntasks, B, lay)
+        Q = np.empty_like(Q0)
+        ok = np.zeros(B, np.uint8)
+        it = np.zeros(B, np.int32)
+        capi.check(L.ikgpu_dls_solve_batch_host(data._h, B, Q0.ctypes.data, targets.ctypes.data, C.byref(prm),
+                                                Q.ctypes.data, ok.ctypes.data, it.ctypes.data, lay))
+        return Q, ok, it
+    import torch
+    if not (Q0.is_cuda and targets.is_cuda and Q0.dtype == torch.float64 and targets.dtype == torch.float64):
+        raise TypeError("dls_batch needs float64 CUDA tensors (or numpy arrays)")
+    if not (Q0.is_contiguous() and targets.is_contiguous()):
+        raise ValueError("dls_batch needs contiguous tensors")
+    if Q0.device.index != data._device:
+        raise ValueError("tensors live on cuda:%s but the problem was created on device %d" % (Q0.device.index, data._device))
+    B = Q0.shape[1] if lay == capi.SOA else Q0.shape[0]
+    _check_shapes(tuple(Q0.shape), tuple(targets.shape), model.nq, ntasks, B, lay)
+    if out is None:
+        Q = torch.empty_like(Q0)
+        ok = torch.empty(B, dtype=torch.uint8, device=Q0.device)
+        it = torch.empty(B, dtype=torch.int32, device=Q0.device)
+    else:
+        Q, ok, it = out
+    s = torch.cuda.current_stream(Q0.device).cuda_stream if stream is None else stream
+    capi.check(L.ikgpu_dls_solve_batch(data._h, B, Q0.data_ptr(), targets.data_ptr(), C.byref(prm), Q.data_ptr(),
+                                       ok.data_ptr(), it.data_ptr(), lay, C.c_void_p(s)))
+    return Q, ok, it
+
+
+def _check_shapes(qs, ts, nq, ntasks, B, lay):
+    want_q = (nq, B) if lay == capi.SOA else (B, nq)
+    want_t = (ntasks, 12, B) if lay == capi.SOA else (B, ntasks, 12)
+    if tuple(qs) != want_q:
+        raise ValueError("Q0 has shape %s, expected %s" % (tuple(qs), want_q))
+    if tuple(ts) != want_t:
+        raise ValueError("targets has shape %s, expected %s" % (tuple(ts), want_t))
+
+
+def evaluate_batch(problem, Q, targets, data, layout="soa", jacobian=True):
+    """evaluate_problem_data + stacking (reference ik/ik/data.cpp:25-58, ik/ik/dls.cpp:18-24) for a
+    batch, on the device: returns (e [M, B], J [M, nv, B]) for "soa" ([B, M], [B, M, nv] for "aos")."""
+    import torch
+    data._bind(problem)
+    model = problem.model()
+    lay = {"soa": capi.SOA, "aos": capi.AOS}[layout]
+    B = Q.shape[1] if lay == capi.SOA else Q.shape[0]
+    M = data.rows
+    e = torch.empty((M, B) if lay == capi.SOA else (B, M), dtype=torch.float64, device=Q.device)
+    J = None
+    if jacobian:
+        J = torch.empty((M, model.nv, B) if lay == capi.SOA else (B, M, model.nv), dtype=torch.float64, device=Q.device)
+    s = torch.cuda.current_stream(Q.device).cuda_stream
+    capi.check(capi.lib().ikgpu_evaluate_batch(data._h, B, Q.data_ptr(), targets.data_ptr(), e.data_ptr(),
+                                               J.data_ptr() if jacobian else None, lay, C.c_void_p(s)))
+    return e, J
+
+
+def task_frames_fk_batch(problem, Q, data, layout="soa"):
+    """World placements of the task frames (one entry of data.oMf per task, reference
+    ik/ik/data.cpp:28-29): [ntasks, 12, B] ("soa") or [B, ntasks, 12] ("aos")."""
+    import torch
+    data._bind(problem)
+    lay = {"soa": capi.SOA, "aos": capi.AOS}[layout]
+    B = Q.shape[1] if lay == capi.SOA else Q.shape[0]
+    nt = len(problem.ordered_tasks())
+    out = torch.empty((nt, 12, B) if lay == capi.SOA else (B, nt, 12), dtype=torch.float64, device=Q.device)
+    s = torch.cuda.current_stream(Q.device).cuda_stream
+    capi.check(capi.lib().ikgpu_task_frames_fk_batch(data._h, B, Q.data_ptr(), out.data_ptr(), lay, C.c_void_p(s)))
+    return out

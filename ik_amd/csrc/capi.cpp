@@ -1,0 +1,318 @@
+// capi.cpp -- implementation of include/ikgpu.h.  No exception crosses the boundary; every
+// solve runs the gfx950 kernels (kernels.hip) or fails with a message -- there is no CPU path.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <exception>
+#include <new>
+#include <stdexcept>
+#include <string>
+
+#include "ikgpu.h"
+#include "kernels.hpp"
+#include "model.hpp"
+#include "problem.hpp"
+
+struct ikgpu_problem {
+    ikgpu::ProblemHost host;
+    ikgpu::DeviceTables dev;
+    int device = 0;
+    int nframes = 0;
+};
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+
+int hip_fail(hipError_t e, const char *what) {
+    return fail(IKGPU_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+template <class F>
+int guarded(F &&f) {
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        return fail(IKGPU_ERR_INVALID, "out of host memory");
+    } catch (const std::exception &e) {
+        return fail(IKGPU_ERR_INVALID, e.what());
+    } catch (...) {
+        return fail(IKGPU_ERR_INVALID, "unknown C++ exception");
+    }
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+int check_params(const ikgpu_dls_params *p) {
+    if (!p) return fail(IKGPU_ERR_INVALID, "params is null");
+    if (p->max_iterations < 0) return fail(IKGPU_ERR_INVALID, "max_iterations must be >= 0");
+    if (!(p->damping > 0.0))
+        return fail(IKGPU_ERR_INVALID, "damping must be > 0: the device solves JJ^T + damping^2 I by Cholesky (SPD)");
+    return IKGPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ikgpu_abi_version(void) { return IKGPU_ABI_VERSION; }
+
+const char *ikgpu_last_error(void) { return g_last_error.c_str(); }
+
+void ikgpu_dls_params_default(ikgpu_dls_params *p) {
+    if (!p) return;
+    p->max_iterations = 100;  // reference ik/ik/common.hpp:61
+    p->damping = 1e-2;        // reference ik/ik/dls.hpp:25
+    p->step_length = 1.0;     // reference ik/ik/common.hpp:65
+    p->stop_sq_tol = 1e-4;    // reference ik/ik/visitor.hpp:19
+}
+
+int ikgpu_model_from_urdf(const char *xml, size_t len, int root_joint, ikgpu_model **out) {
+    if (!xml || !out) return fail(IKGPU_ERR_INVALID, "null argument");
+    if (root_joint != IKGPU_ROOT_FIXED && root_joint != IKGPU_ROOT_FREEFLYER)
+        return fail(IKGPU_ERR_INVALID, "root_joint must be IKGPU_ROOT_FIXED or IKGPU_ROOT_FREEFLYER");
+    *out = nullptr;
+    try {
+        auto *h = new ikgpu_model{ikgpu::Model::from_urdf(xml, len, root_joint == IKGPU_ROOT_FREEFLYER)};
+        h->m.finalize();  // name views must point into the final object
+        *out = h;
+        return IKGPU_OK;
+    } catch (const std::exception &e) {
+        return fail(IKGPU_ERR_PARSE, e.what());
+    } catch (...) {
+        return fail(IKGPU_ERR_PARSE, "unknown C++ exception");
+    }
+}
+
+int ikgpu_model_create(const ikgpu_flat_model *flat, ikgpu_model **out) {
+    if (!flat || !out) return fail(IKGPU_ERR_INVALID, "null argument");
+    *out = nullptr;
+    return guarded([&] {
+        auto *h = new ikgpu_model{ikgpu::Model::from_flat(*flat)};
+        h->m.finalize();
+        *out = h;
+        return static_cast<int>(IKGPU_OK);
+    });
+}
+
+void ikgpu_model_destroy(ikgpu_model *m) { delete m; }
+
+int ikgpu_model_get_flat(const ikgpu_model *h, ikgpu_flat_model *out) {
+    if (!h || !out) return fail(IKGPU_ERR_INVALID, "null argument");
+    const ikgpu::Model &m = h->m;
+    out->njoints = m.njoints();
+    out->nq = m.nq;
+    out->nv = m.nv;
+    out->nframes = m.nframes();
+    out->joint_type = m.joint_type.data();
+    out->joint_parent = m.joint_parent.data();
+    out->joint_idx_q = m.joint_idx_q.data();
+    out->joint_idx_v = m.joint_idx_v.data();
+    out->joint_placement = m.joint_placement.empty() ? nullptr : m.joint_placement[0].data();
+    out->joint_axis = m.joint_axis.empty() ? nullptr : m.joint_axis[0].data();
+    out->lower = m.lower.data();
+    out->upper = m.upper.data();
+    out->frame_parent = m.frame_parent.data();
+    out->frame_placement = m.frame_placement.empty() ? nullptr : m.frame_placement[0].data();
+    out->joint_names = m.joint_name_ptrs.data();
+    out->frame_names = m.frame_name_ptrs.data();
+    return IKGPU_OK;
+}
+
+int32_t ikgpu_model_frame_id(const ikgpu_model *h, const char *name) {
+    if (!h || !name) return -1;
+    return h->m.frame_id(name);
+}
+
+int32_t ikgpu_model_joint_id(const ikgpu_model *h, const char *name) {
+    if (!h || !name) return -1;
+    return h->m.joint_id(name);
+}
+
+int ikgpu_problem_create(const ikgpu_model *h, const ikgpu_task *tasks, int32_t ntasks, int32_t device,
+                         ikgpu_problem **out) {
+    if (!h || !tasks || !out) return fail(IKGPU_ERR_INVALID, "null argument");
+    *out = nullptr;
+    ikgpu::ProblemHost ph;
+    try {
+        ph = ikgpu::analyse_problem(h->m, tasks, ntasks);
+    } catch (const std::exception &e) {
+        const std::string msg = e.what();
+        return fail(msg.rfind("unsupported", 0) == 0 ? IKGPU_ERR_UNSUPPORTED : IKGPU_ERR_INVALID, msg);
+    }
+    if (!ikgpu::chain_shape_built(ph.chain.nj, ph.tasks[0].type))
+        return fail(IKGPU_ERR_UNSUPPORTED, "unsupported: no kernel instantiated for " + ph.kernel_name);
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) return fail(IKGPU_ERR_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(IKGPU_ERR_INVALID, "device ordinal out of range");
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return hip_fail(e, "hipGetDeviceProperties");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(IKGPU_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+
+    return guarded([&] {
+        DeviceGuard g(device);
+        if (!g.ok) return fail(IKGPU_ERR_DEVICE, "hipSetDevice failed");
+        auto *p = new ikgpu_problem;
+        p->host = std::move(ph);
+        p->device = device;
+        p->nframes = h->m.nframes();
+        const size_t nq = static_cast<size_t>(p->host.nq);
+        hipError_t err = hipSuccess;
+        auto up = [&](auto **dst, const void *src, size_t bytes) {
+            if (err != hipSuccess) return;
+            err = hipMalloc(reinterpret_cast<void **>(dst), bytes ? bytes : 8);
+            if (err == hipSuccess && bytes) err = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+        };
+        up(&p->dev.lower, p->host.lower.data(), nq * sizeof(double));
+        up(&p->dev.upper, p->host.upper.data(), nq * sizeof(double));
+        up(&p->dev.q_in_chain, p->host.q_in_chain.data(), nq);
+        const std::vector<double> desc = ikgpu::chain_desc_table(p->host);
+        up(&p->dev.chain_desc, desc.data(), desc.size() * sizeof(double));
+        if (err != hipSuccess) {
+            ikgpu_problem_destroy(p);
+            return hip_fail(err, "uploading problem tables");
+        }
+        *out = p;
+        return static_cast<int>(IKGPU_OK);
+    });
+}
+
+int ikgpu_problem_plan(const ikgpu_model *h, const ikgpu_task *tasks, int32_t ntasks, char *out, size_t cap) {
+    if (!h || !tasks) return fail(IKGPU_ERR_INVALID, "null argument");
+    try {
+        const ikgpu::ProblemHost ph = ikgpu::analyse_problem(h->m, tasks, ntasks);
+        if (!ikgpu::chain_shape_built(ph.chain.nj, ph.tasks[0].type))
+            return fail(IKGPU_ERR_UNSUPPORTED, "unsupported: no kernel instantiated for " + ph.kernel_name);
+        if (out && cap) {
+            std::strncpy(out, ph.kernel_name.c_str(), cap - 1);
+            out[cap - 1] = '\0';
+        }
+        return IKGPU_OK;
+    } catch (const std::exception &e) {
+        const std::string msg = e.what();
+        return fail(msg.rfind("unsupported", 0) == 0 ? IKGPU_ERR_UNSUPPORTED : IKGPU_ERR_INVALID, msg);
+    }
+}
+
+void ikgpu_problem_destroy(ikgpu_problem *p) {
+    if (!p) return;
+    DeviceGuard g(p->device);
+    (void)hipFree(p->dev.lower);
+    (void)hipFree(p->dev.upper);
+    (void)hipFree(p->dev.q_in_chain);
+    (void)hipFree(p->dev.chain_desc);
+    delete p;
+}
+
+int32_t ikgpu_problem_rows(const ikgpu_problem *p) { return p ? p->host.rows : -1; }
+
+const char *ikgpu_problem_kernel(const ikgpu_problem *p) { return p ? p->host.kernel_name.c_str() : ""; }
+
+int ikgpu_dls_solve_batch(const ikgpu_problem *p, int64_t B, const double *q0, const double *targets,
+                          const ikgpu_dls_params *params, double *q_out, uint8_t *success, int32_t *iters, int layout,
+                          void *stream) {
+    if (!p || !q0 || !targets || !q_out) return fail(IKGPU_ERR_INVALID, "null argument");
+    if (B < 0) return fail(IKGPU_ERR_INVALID, "negative batch size");
+    if (layout != IKGPU_SOA && layout != IKGPU_AOS) return fail(IKGPU_ERR_INVALID, "unknown layout");
+    if (int rc = check_params(params)) return rc;
+    if (B == 0) return IKGPU_OK;
+    if (B > (int64_t(1) << 31) * 32) return fail(IKGPU_ERR_INVALID, "batch too large for one launch");
+    return guarded([&] {
+        DeviceGuard g(p->device);
+        if (!g.ok) return fail(IKGPU_ERR_DEVICE, "hipSetDevice failed");
+        ikgpu::BatchIO io{B, q0, targets, q_out, success, iters, layout};
+        hipError_t e = ikgpu::launch_dls_chain(p->host, p->dev, io, *params, static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return hip_fail(e, "launching the DLS kernel");
+        return static_cast<int>(IKGPU_OK);
+    });
+}
+
+int ikgpu_dls_solve_batch_host(const ikgpu_problem *p, int64_t B, const double *q0, const double *targets,
+                               const ikgpu_dls_params *params, double *q_out, uint8_t *success, int32_t *iters,
+                               int layout) {
+    if (!p || !q0 || !targets || !q_out) return fail(IKGPU_ERR_INVALID, "null argument");
+    if (B < 0) return fail(IKGPU_ERR_INVALID, "negative batch size");
+    if (int rc = check_params(params)) return rc;
+    if (B == 0) return IKGPU_OK;
+    return guarded([&] {
+        DeviceGuard g(p->device);
+        if (!g.ok) return fail(IKGPU_ERR_DEVICE, "hipSetDevice failed");
+        const size_t nb_q = sizeof(double) * p->host.nq * B, nb_t = sizeof(double) * 12 * p->host.ntasks * B;
+        double *d_q0 = nullptr, *d_t = nullptr, *d_q = nullptr;
+        uint8_t *d_s = nullptr;
+        int32_t *d_i = nullptr;
+        hipError_t e = hipSuccess;
+        auto step = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+        step(hipMalloc(reinterpret_cast<void **>(&d_q0), nb_q));
+        step(hipMalloc(reinterpret_cast<void **>(&d_t), nb_t));
+        step(hipMalloc(reinterpret_cast<void **>(&d_q), nb_q));
+        step(hipMalloc(reinterpret_cast<void **>(&d_s), B));
+        step(hipMalloc(reinterpret_cast<void **>(&d_i), sizeof(int32_t) * B));
+        if (e == hipSuccess) step(hipMemcpy(d_q0, q0, nb_q, hipMemcpyHostToDevice));
+        if (e == hipSuccess) step(hipMemcpy(d_t, targets, nb_t, hipMemcpyHostToDevice));
+        int rc = IKGPU_OK;
+        if (e == hipSuccess) {
+            rc = ikgpu_dls_solve_batch(p, B, d_q0, d_t, params, d_q, d_s, d_i, layout, nullptr);
+            if (rc == IKGPU_OK) {
+                step(hipDeviceSynchronize());
+                step(hipMemcpy(q_out, d_q, nb_q, hipMemcpyDeviceToHost));
+                if (success) step(hipMemcpy(success, d_s, B, hipMemcpyDeviceToHost));
+                if (iters) step(hipMemcpy(iters, d_i, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
+            }
+        }
+        (void)hipFree(d_q0); (void)hipFree(d_t); (void)hipFree(d_q); (void)hipFree(d_s); (void)hipFree(d_i);
+        if (rc != IKGPU_OK) return rc;
+        if (e != hipSuccess) return hip_fail(e, "host-pointer solve");
+        return static_cast<int>(IKGPU_OK);
+    });
+}
+
+int ikgpu_evaluate_batch(const ikgpu_problem *p, int64_t B, const double *q, const double *targets, double *e_out,
+                         double *J_out, int layout, void *stream) {
+    if (!p || !q || !targets || !e_out) return fail(IKGPU_ERR_INVALID, "null argument");
+    if (B < 0) return fail(IKGPU_ERR_INVALID, "negative batch size");
+    if (layout != IKGPU_SOA && layout != IKGPU_AOS) return fail(IKGPU_ERR_INVALID, "unknown layout");
+    if (B == 0) return IKGPU_OK;
+    return guarded([&] {
+        DeviceGuard g(p->device);
+        if (!g.ok) return fail(IKGPU_ERR_DEVICE, "hipSetDevice failed");
+        hipError_t e = ikgpu::launch_eval_chain(p->host, p->dev, B, q, targets, e_out, J_out, layout, static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return hip_fail(e, "launching the evaluate kernel");
+        return static_cast<int>(IKGPU_OK);
+    });
+}
+
+int ikgpu_task_frames_fk_batch(const ikgpu_problem *p, int64_t B, const double *q, double *oMf_out, int layout,
+                               void *stream) {
+    if (!p || !q || !oMf_out) return fail(IKGPU_ERR_INVALID, "null argument");
+    if (B < 0) return fail(IKGPU_ERR_INVALID, "negative batch size");
+    if (layout != IKGPU_SOA && layout != IKGPU_AOS) return fail(IKGPU_ERR_INVALID, "unknown layout");
+    if (B == 0) return IKGPU_OK;
+    return guarded([&] {
+        DeviceGuard g(p->device);
+        if (!g.ok) return fail(IKGPU_ERR_DEVICE, "hipSetDevice failed");
+        hipError_t e = ikgpu::launch_fk_chain(p->host, p->dev, B, q, oMf_out, layout, static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return hip_fail(e, "launching the FK kernel");
+        return static_cast<int>(IKGPU_OK);
+    });
+}
+
+}  // extern "C"

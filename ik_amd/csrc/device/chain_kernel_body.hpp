@@ -1,0 +1,132 @@
+// chain_kernel_body.hpp -- what ONE lane of the chain kernels does around the lane solver:
+// load its problem from HBM, solve, store.  Shared by the __global__ wrappers (kernels.hip) and
+// by the CPU lane emulator under tests/ (which runs it in a plain loop over b).
+#pragma once
+#include <cstdint>
+
+#include "chain_solver.hpp"
+
+namespace ikdev {
+
+enum : int { LAYOUT_SOA = 0, LAYOUT_AOS = 1 };  // == ikgpu_layout
+
+template <int NJ>
+struct ChainKernelArgs {
+    const ChainDesc<NJ> *desc;  // HBM copy of the chain table (uploaded at problem creation)
+    LoopParams prm;
+    double ref_pl[12];          // world placement of the task's (world-fixed) reference frame
+    int qidx[NJ];               // index of each chain joint in q
+    int vidx[NJ];               // ... and in the tangent vector
+    int nq, nv, layout;
+    int64_t B;
+    const double *q0;
+    const double *targets;
+    double *q_out;
+    uint8_t *success;
+    int32_t *iters;
+    const double *lower, *upper;  // [nq]
+    const uint8_t *q_in_chain;    // [nq]
+    double *e_out, *J_out, *oMf_out;  // stage kernels
+};
+
+IKD_FN int64_t at(int layout, int64_t B, int ncomp, int c, int64_t b) {
+    return layout == LAYOUT_SOA ? static_cast<int64_t>(c) * B + b : b * ncomp + c;
+}
+
+// oMt = oMr * target (reference ik/ik/frame.hpp:48); oMr is constant for a world-fixed reference.
+template <int NJ>
+IKD_FN void load_target(const ChainKernelArgs<NJ> &a, int64_t b, double (&oMt)[12]) {
+    double t[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) t[k] = a.targets[at(a.layout, a.B, 12, k, b)];
+    const double *r = a.ref_pl;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            oMt[3 * i + j] = dfma(r[3 * i], t[j], dfma(r[3 * i + 1], t[3 + j], r[3 * i + 2] * t[6 + j]));
+        oMt[9 + i] = dfma(r[3 * i], t[9], dfma(r[3 * i + 1], t[10], dfma(r[3 * i + 2], t[11], r[9 + i])));
+    }
+}
+
+// B independent ik::dls() calls (reference ik/ik/dls.cpp:5-78), lane `gid`.
+template <int NJ, int KT, class AnyFn>
+IKD_FN void dls_chain_body(const ChainKernelArgs<NJ> &a, const ChainDesc<NJ> &d, int64_t gid, AnyFn any_active) {
+    const bool valid = gid < a.B;
+    const int64_t b = valid ? gid : a.B - 1;  // tail lanes shadow the last problem and store nothing
+
+    double q[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) q[j] = a.q0[at(a.layout, a.B, a.nq, a.qidx[j], b)];
+    double oMt[12];
+    load_target(a, b, oMt);
+
+    int iters;
+    bool success;
+    chain_dls<NJ, KT>(d, a.prm, q, oMt, iters, success, any_active);
+
+    if (!valid) return;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) a.q_out[at(a.layout, a.B, a.nq, a.qidx[j], b)] = q[j];
+    // Entries outside the task support: dq = 0 there, so the loop only ever clamps them
+    // (reference ik/ik/dls.cpp:71 clips the whole q after each step; no step is taken when iters == 0).
+    for (int i = 0; i < a.nq; ++i) {
+        if (a.q_in_chain[i]) continue;
+        const double v = a.q0[at(a.layout, a.B, a.nq, i, b)];
+        const double c = dmin(a.upper[i], dmax(v, a.lower[i]));
+        a.q_out[at(a.layout, a.B, a.nq, i, b)] = (iters > 0) ? c : v;
+    }
+    if (a.success) a.success[b] = success ? 1 : 0;
+    if (a.iters) a.iters[b] = iters;
+}
+
+// evaluate_problem_data + stacking (reference ik/ik/data.cpp:25-58, ik/ik/dls.cpp:18-24):
+// e [M x B], dense J [M x nv x B] (zero outside the support, as the reference's zero-initialised
+// frame Jacobian, ik/ik/frame.hpp:110).
+template <int NJ, int KT>
+IKD_FN void eval_chain_body(const ChainKernelArgs<NJ> &a, const ChainDesc<NJ> &d, int64_t b) {
+    constexpr int M = TaskDim<KT>::value;
+    if (b >= a.B) return;
+    double q[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) q[j] = a.q0[at(a.layout, a.B, a.nq, a.qidx[j], b)];
+    double oMt[12];
+    load_target(a, b, oMt);
+    double e[M], col[NJ][M], Rf[9], pf[3];
+    chain_evaluate<NJ, KT>(d, q, oMt, e, col, Rf, pf);
+#pragma unroll
+    for (int r = 0; r < M; ++r) a.e_out[at(a.layout, a.B, M, r, b)] = e[r];
+    if (a.J_out) {
+        for (int r = 0; r < M; ++r)
+            for (int c = 0; c < a.nv; ++c) a.J_out[at(a.layout, a.B, M * a.nv, r * a.nv + c, b)] = 0.0;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < M; ++r) a.J_out[at(a.layout, a.B, M * a.nv, r * a.nv + a.vidx[j], b)] = col[j][r];
+    }
+}
+
+// World placement of the task frame (reference ik/ik/data.cpp:28-29, one entry of data.oMf).
+template <int NJ>
+IKD_FN void fk_chain_body(const ChainKernelArgs<NJ> &a, const ChainDesc<NJ> &d, int64_t b) {
+    if (b >= a.B) return;
+    double R[9], p[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = d.pl[0][k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p[k] = d.pl[0][9 + k];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        if (j > 0) se3_compose_const(R, p, d.pl[j]);
+        double s, c;
+        dsincos(a.q0[at(a.layout, a.B, a.nq, a.qidx[j], b)], s, c);
+        rot_z_right(R, s, c);
+    }
+    se3_compose_const(R, p, d.frame_pl);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) a.oMf_out[at(a.layout, a.B, 12, k, b)] = R[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) a.oMf_out[at(a.layout, a.B, 12, 9 + k, b)] = p[k];
+}
+
+}  // namespace ikdev

@@ -1,0 +1,194 @@
+// chain_solver.hpp -- the whole ik::dls() loop for ONE problem whose task support is a serial
+// chain of NJ revolute joints hanging off a fixed base (shapes "S" and "U" of SURVEY.md section 8:
+// Cassie single leg NJ = 7, UR5 NJ = 6), executed by one wavefront lane entirely in registers.
+//
+// Reference path restated per iteration (file:line relative to the reference root):
+//   ik/ik/data.cpp:28-30    FK + joint Jacobians            -> chain FK, axis / origin per joint
+//   ik/ik/frame.hpp:37-62   e = log6(oMf^-1 oMr target)     -> log6_and_jlog6_inv
+//   ik/ik/frame.hpp:152-182 J = -Jlog6(tMf) J_local         -> per-column transform
+//   ik/ik/data.cpp:49-50    task weighting                  -> folded into the 6x6 blocks
+//   ik/ik/dls.cpp:39-41     JJ = Jt Jt^T + damping^2 I      -> symmetric rank-1 accumulation
+//   ik/ik/dls.cpp:52-53     dq = -Jt^T JJ^-1 et (N = I)     -> per-lane Cholesky
+//   ik/ik/dls.cpp:61-64     stop test before the step       -> lane freezes, wave goes on
+//   ik/ik/dls.cpp:67-71     integrate + joint clipping      -> q + step*dq, clamp
+//
+// Every joint is "revolute about local z": an arbitrary unit axis a is folded into the constant
+// placements on the host (pl' = P_prev^T pl P, P e_z = a), which leaves oMi * a and the joint
+// origin -- all the Jacobian needs -- unchanged.
+#pragma once
+#include "lane_math.hpp"
+
+namespace ikdev {
+
+enum : int { KT_POSITION = 0, KT_ORIENTATION = 1, KT_FULL = 2 };  // ik::KinematicType order
+
+template <int NJ>
+struct ChainDesc {
+    double pl[NJ][12];    // pl[0]: world -> joint-0 frame (all fixed transforms folded); pl[j]: joint j-1 -> j
+    double frame_pl[12];  // last joint frame -> task frame
+    double lo[NJ], hi[NJ];
+    double wgt[6];        // Task::weighting(), first `dimension` entries
+};  // all doubles: the kernels stage it from HBM into LDS as a flat table
+
+struct LoopParams {
+    int max_iterations;
+    double lam2;         // damping^2
+    double step_length;
+    double stop_sq_tol;  // < 0: never stop
+    int priority;        // priority level of the task (the stop test reads priority-0 rows only)
+};
+
+template <int KT>
+struct TaskDim {
+    static constexpr int value = (KT == KT_FULL) ? 6 : 3;
+};
+
+// Evaluate e (M), the M x NJ task Jacobian columns, for the chain at configuration q.
+// oMt: target placement in the world (reference frame fixed in the world), 12 doubles.
+template <int NJ, int KT>
+IKD_FN void chain_evaluate(const ChainDesc<NJ> &d, const double (&q)[NJ], const double (&oMt)[12],
+                           double (&e)[TaskDim<KT>::value], double (&col)[NJ][TaskDim<KT>::value],
+                           double (&Rf)[9], double (&pf)[3]) {
+    constexpr int M = TaskDim<KT>::value;
+    double zax[NJ][3], org[NJ][3];
+    double R[9], p[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = d.pl[0][k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p[k] = d.pl[0][9 + k];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        if (j > 0) se3_compose_const(R, p, d.pl[j]);
+        double s, c;
+        dsincos(q[j], s, c);
+        rot_z_right(R, s, c);
+        zax[j][0] = R[2]; zax[j][1] = R[5]; zax[j][2] = R[8];
+        org[j][0] = p[0]; org[j][1] = p[1]; org[j][2] = p[2];
+    }
+    se3_compose_const(R, p, d.frame_pl);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rf[k] = R[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pf[k] = p[k];
+
+    // fMt = oMf^-1 oMt
+    double Re[9], pe[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Re[3 * i + j] = dfma(R[i], oMt[j], dfma(R[3 + i], oMt[3 + j], R[6 + i] * oMt[6 + j]));
+    {
+        const double dp[3] = {oMt[9] - p[0], oMt[10] - p[1], oMt[11] - p[2]};
+        rotT_vec(R, dp, pe);
+    }
+    LogAndJlog lj;
+    log6_and_jlog6_inv(Re, pe, lj);
+
+    // K = -diag(w) * Jlog6(tMf) restricted to the task rows:  top rows [At | Bt], bottom rows [0 | Ab]
+    double At[9], Bt[9], Ab[9];
+    if (KT == KT_FULL || KT == KT_POSITION) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                At[3 * i + j] = -d.wgt[i] * lj.A[3 * i + j];
+                Bt[3 * i + j] = -d.wgt[i] * lj.Bm[3 * i + j];
+            }
+    }
+    if (KT == KT_FULL || KT == KT_ORIENTATION) {
+        constexpr int w0 = (KT == KT_FULL) ? 3 : 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) Ab[3 * i + j] = -d.wgt[w0 + i] * lj.A[3 * i + j];
+    }
+    if (KT == KT_FULL) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) e[i] = lj.e[i] * d.wgt[i];
+    } else if (KT == KT_POSITION) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) e[i] = lj.e[i] * d.wgt[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) e[i] = lj.e[3 + i] * d.wgt[i];
+    }
+
+    // columns: J_local(:, j) = [r x w' ; w'],  w' = Rf^T z_j,  r = Rf^T (o_j - p_f)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        double wl[3], r[3], vl[3];
+        rotT_vec(R, zax[j], wl);
+        const double dj[3] = {org[j][0] - p[0], org[j][1] - p[1], org[j][2] - p[2]};
+        rotT_vec(R, dj, r);
+        cross(r, wl, vl);
+        if (KT == KT_FULL || KT == KT_POSITION) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                col[j][i] = dfma(At[3 * i], vl[0], dfma(At[3 * i + 1], vl[1], dfma(At[3 * i + 2], vl[2],
+                            dfma(Bt[3 * i], wl[0], dfma(Bt[3 * i + 1], wl[1], Bt[3 * i + 2] * wl[2])))));
+        }
+        if (KT == KT_FULL || KT == KT_ORIENTATION) {
+            constexpr int r0 = (KT == KT_FULL) ? 3 : 0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                col[j][r0 + i] = dfma(Ab[3 * i], wl[0], dfma(Ab[3 * i + 1], wl[1], Ab[3 * i + 2] * wl[2]));
+        }
+    }
+    (void)M;
+}
+
+// One full solve. q: in = q0 (chain joints only), out = result. Returns iterations / success.
+// any_active(bool) must return a wave-uniform "some lane still iterating" (identity on the host).
+template <int NJ, int KT, class AnyFn>
+IKD_FN void chain_dls(const ChainDesc<NJ> &d, const LoopParams &prm, double (&q)[NJ], const double (&oMt)[12],
+                      int &iters_out, bool &success_out, AnyFn any_active) {
+    constexpr int M = TaskDim<KT>::value;
+    bool active = true;
+    bool success = false;
+    int iters = prm.max_iterations;
+#pragma unroll 1
+    for (int it = 0; it < prm.max_iterations; ++it) {
+        // The constant table `d` lives in LDS on the device: re-read it every iteration (broadcast
+        // ds_read, off the VALU) instead of letting the compiler hoist ~150 doubles into registers.
+        asm volatile("" ::: "memory");
+        double e[M], col[NJ][M], Rf[9], pf[3];
+        chain_evaluate<NJ, KT>(d, q, oMt, e, col, Rf, pf);
+
+        double G[M * M];
+#pragma unroll
+        for (int a = 0; a < M; ++a)
+#pragma unroll
+            for (int b = 0; b <= a; ++b) {
+                double s = (a == b) ? prm.lam2 : 0.0;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) s = dfma(col[j][a], col[j][b], s);
+                G[a * M + b] = s;
+            }
+        double y[M];
+        chol_solve<M>(G, e, y);
+
+        double e0sq = 0.0;
+        if (prm.priority == 0) {
+#pragma unroll
+            for (int a = 0; a < M; ++a) e0sq = dfma(e[a], e[a], e0sq);
+        }
+        const bool stop_now = active && (prm.stop_sq_tol >= 0.0) && (e0sq < prm.stop_sq_tol);
+        if (stop_now) { success = true; iters = it; }
+        active = active && !stop_now;
+
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int a = 0; a < M; ++a) s = dfma(col[j][a], y[a], s);
+            const double qn = dfma(prm.step_length, -s, q[j]);
+            const double qc = dmin(d.hi[j], dmax(qn, d.lo[j]));
+            q[j] = active ? qc : q[j];
+        }
+        if (!any_active(active)) break;
+    }
+    iters_out = iters;
+    success_out = success;
+}
+
+}  // namespace ikdev

@@ -1,0 +1,323 @@
+// lane_math.hpp -- per-lane FP64 building blocks of the batched DLS kernels.
+//
+// One IK problem lives in one wavefront lane; every function here is straight-line,
+// branch-free (selects, not divergent branches) scalar double code that hipcc keeps in VGPRs.
+// Uniform model constants arrive through the kernel-argument segment (SGPRs).
+//
+// The file also compiles as plain host C++ (g++) -- ONLY so that tests/ can run the exact
+// lane program on the CPU ("lane emulation") and compare it with the oracle before a GPU
+// is involved.  libikgpu.so never contains or calls a host build of this code.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define IKD_FN __host__ __device__ inline __attribute__((always_inline))
+#else
+#define IKD_FN inline __attribute__((always_inline))
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define IKD_ON_DEVICE 1
+#else
+#define IKD_ON_DEVICE 0
+#endif
+
+namespace ikdev {
+
+// TaylorSeriesExpansion<double>::precision<3>() = eps^(1/4)
+constexpr double kTaylorPrec3 = 1.220703125e-4;  // 2^-13 exactly == (2^-52)^(1/4)
+constexpr double kPi = 3.141592653589793238462643383279502884;
+
+IKD_FN double dfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+IKD_FN double dsel(bool c, double a, double b) { return c ? a : b; }
+IKD_FN double dmin(double a, double b) { return __builtin_fmin(a, b); }
+IKD_FN double dmax(double a, double b) { return __builtin_fmax(a, b); }
+
+// 1/x for normal-range x: v_rcp_f64 seed + two Newton steps (no div_scale/div_fixup sequence).
+IKD_FN double drcp(double x) {
+#if IKD_ON_DEVICE
+    double r = __builtin_amdgcn_rcp(x);
+    double e = dfma(-x, r, 1.0);
+    r = dfma(e, r, r);
+    e = dfma(-x, r, 1.0);
+    r = dfma(e, r, r);
+    return r;
+#else
+    return 1.0 / x;
+#endif
+}
+
+// 1/sqrt(x) for normal-range x > 0: v_rsq_f64 seed + two Newton steps.
+IKD_FN double drsqrt(double x) {
+#if IKD_ON_DEVICE
+    double y = __builtin_amdgcn_rsq(x);
+    double hx = 0.5 * x;
+    double e = dfma(-hx * y, y, 0.5);
+    y = dfma(y, e, y);
+    e = dfma(-hx * y, y, 0.5);
+    y = dfma(y, e, y);
+    return y;
+#else
+    return 1.0 / std::sqrt(x);
+#endif
+}
+
+IKD_FN double dsqrt(double x) { return __builtin_sqrt(x); }
+
+// sin and cos of one argument.  Cody-Waite reduction by pi/2 with an FMA'd two-constant split
+// (exact enough for |x| <~ 1e5; joint angles are clamped to their limits every iteration),
+// fdlibm kernel polynomials on [-pi/4, pi/4], quadrant fix-up by selects.  < 1.5 ulp.
+IKD_FN void dsincos(double x, double &s_out, double &c_out) {
+    constexpr double kTwoOverPi = 0.63661977236758134308;
+    constexpr double kPio2Hi = 1.57079632679489655800e+00;
+    constexpr double kPio2Lo = 6.12323399573676603587e-17;
+    const double k = __builtin_rint(x * kTwoOverPi);
+    double r = dfma(-k, kPio2Hi, x);
+    r = dfma(-k, kPio2Lo, r);
+    const int n = static_cast<int>(k);
+    const double z = r * r;
+    // sin(r) = r + r^3 (S1 + z (S2 + ...))
+    double ps = dfma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = dfma(z, ps, 2.75573137070700676789e-06);
+    ps = dfma(z, ps, -1.98412698298579493134e-04);
+    ps = dfma(z, ps, 8.33333333332248946124e-03);
+    ps = dfma(z, ps, -1.66666666666666324348e-01);
+    const double sr = dfma(z * r, ps, r);
+    // cos(r) = 1 - z/2 + z^2 (C1 + z (C2 + ...))
+    double pc = dfma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = dfma(z, pc, -2.75573143513906633035e-07);
+    pc = dfma(z, pc, 2.48015872894767294178e-05);
+    pc = dfma(z, pc, -1.38888888888741095749e-03);
+    pc = dfma(z, pc, 4.16666666666666019037e-02);
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    const double cr = w + (((1.0 - w) - hz) + z * z * pc);
+    const bool swap = (n & 1) != 0;
+    const double s0 = swap ? cr : sr;
+    const double c0 = swap ? sr : cr;
+    s_out = (n & 2) ? -s0 : s0;
+    c_out = ((n + 1) & 2) ? -c0 : c0;
+}
+
+// acos on [-1, 1] (fdlibm e_acos rational approximation, divisions by drcp).
+IKD_FN double dacos(double x) {
+    constexpr double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17;
+    constexpr double pS0 = 1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01,
+                     pS2 = 2.01212532134862925881e-01, pS3 = -4.00555345006794114027e-02,
+                     pS4 = 7.91534994289814532176e-04, pS5 = 3.47933107596021167570e-05;
+    constexpr double qS1 = -2.40339491173441421878e+00, qS2 = 2.02094576023350569471e+00,
+                     qS3 = -6.88283971605453293030e-01, qS4 = 7.70381505559019352791e-02;
+    const double ax = __builtin_fabs(x);
+    const bool small = ax < 0.5;
+    // small: z = x^2 ; large: z = (1-|x|)/2
+    const double z = small ? x * x : (1.0 - ax) * 0.5;
+    double p = dfma(z, pS5, pS4);
+    p = dfma(z, p, pS3);
+    p = dfma(z, p, pS2);
+    p = dfma(z, p, pS1);
+    p = dfma(z, p, pS0);
+    p = p * z;
+    double q = dfma(z, qS4, qS3);
+    q = dfma(z, q, qS2);
+    q = dfma(z, q, qS1);
+    q = dfma(z, q, 1.0);
+    const double r = p * drcp(q);
+    // |x| < 0.5: pi/2 - (x - (pio2_lo - x*r))
+    const double res_small = pio2_hi - (x - (pio2_lo - x * r));
+    // |x| >= 0.5: s = sqrt(z)
+    const double s = dsqrt(z);
+    // x >= 0.5: 2*(df + w) with df = s truncated, c = (z - df*df)/(s + df), w = r*s + c
+#if IKD_ON_DEVICE
+    const double df = __longlong_as_double(__double_as_longlong(s) & 0xFFFFFFFF00000000ll);
+#else
+    double df;
+    {
+        std::uint64_t u;
+        __builtin_memcpy(&u, &s, 8);
+        u &= 0xFFFFFFFF00000000ull;
+        __builtin_memcpy(&df, &u, 8);
+    }
+#endif
+    const double c = dfma(-df, df, z) * drcp(s + df);
+    const double res_pos = 2.0 * (df + dfma(r, s, c));
+    // x <= -0.5: pi - 2*(s + (r*s - pio2_lo))
+    const double res_neg = kPi - 2.0 * (s + dfma(r, s, -pio2_lo));
+    const double res_large = (x > 0.0) ? res_pos : res_neg;
+    double res = small ? res_small : res_large;
+    res = (ax >= 1.0) ? ((x > 0.0) ? 0.0 : kPi) : res;
+    return res;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SE(3) pieces.  A rotation is 9 doubles row-major; everything is fully unrolled.
+// ---------------------------------------------------------------------------------------------
+
+// (R, p) <- (R, p) * (Rc, pc)   with (Rc, pc) = c[0..11], uniform constants
+IKD_FN void se3_compose_const(double (&R)[9], double (&p)[3], const double *c) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double a = R[3 * i], b = R[3 * i + 1], d = R[3 * i + 2];
+        p[i] = dfma(a, c[9], dfma(b, c[10], dfma(d, c[11], p[i])));
+        R[3 * i] = dfma(a, c[0], dfma(b, c[3], d * c[6]));
+        R[3 * i + 1] = dfma(a, c[1], dfma(b, c[4], d * c[7]));
+        R[3 * i + 2] = dfma(a, c[2], dfma(b, c[5], d * c[8]));
+    }
+}
+
+// R <- R * Rz(angle) given (sin, cos)
+IKD_FN void rot_z_right(double (&R)[9], double s, double c) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double a = R[3 * i], b = R[3 * i + 1];
+        R[3 * i] = dfma(a, c, b * s);
+        R[3 * i + 1] = dfma(b, c, -(a * s));
+    }
+}
+
+// out = R^T v
+IKD_FN void rotT_vec(const double (&R)[9], const double (&v)[3], double (&out)[3]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out[i] = dfma(R[i], v[0], dfma(R[3 + i], v[1], R[6 + i] * v[2]));
+}
+
+IKD_FN void cross(const double (&a)[3], const double (&b)[3], double (&c)[3]) {
+    c[0] = dfma(a[1], b[2], -(a[2] * b[1]));
+    c[1] = dfma(a[2], b[0], -(a[0] * b[2]));
+    c[2] = dfma(a[0], b[1], -(a[1] * b[0]));
+}
+
+IKD_FN double dot(const double (&a)[3], const double (&b)[3]) { return dfma(a[0], b[0], dfma(a[1], b[1], a[2] * b[2])); }
+
+// Result of log6(fMt) and of -W * Jlog6(tMf) for tMf = fMt^-1, sharing one log3.
+// (reference ik/ik/frame.hpp:50-61 and :162-166; formulas SURVEY.md App. A.3)
+struct LogAndJlog {
+    double e[6];    // log6(fMt) = [v; w]
+    double A[9];    // Jlog3(theta, -w)
+    double Bm[9];   // C * A  (top-right block of Jlog6(tMf))
+};
+
+// Re, pe : rotation / translation of fMt.  any_near_pi: wave-uniform hint that some lane is in
+// the theta >= pi - 1e-2 regime (the alternative log3 formula is evaluated only then).
+IKD_FN void log6_and_jlog6_inv(const double (&Re)[9], const double (&pe)[3], LogAndJlog &o) {
+    const double tr = Re[0] + Re[4] + Re[8];
+    double x = (tr - 1.0) * 0.5;
+    x = dmin(1.0, dmax(-1.0, x));  // tr >= 3 -> theta = 0 ; tr <= -1 -> theta = pi
+    const double theta = dacos(x);
+    const double omc = 1.0 - x;                                 // 1 - cos(theta)
+    const double st = dsqrt(dmax(0.0, omc * (1.0 + x)));        // sin(theta), theta in [0, pi]
+    const bool small = theta < kTaylorPrec3;
+    const double inv_t = drcp(theta);
+    const double inv_omc = drcp(omc);
+    const double t2 = theta * theta;
+
+    // log3, regular branch
+    const double fac = 0.5 * dsel(theta > kTaylorPrec3, theta * drcp(st), 1.0);
+    double w[3] = {fac * (Re[7] - Re[5]), fac * (Re[2] - Re[6]), fac * (Re[3] - Re[1])};
+    // log3, theta >= pi - 1e-2
+    {
+        const bool near_pi = theta >= kPi - 1e-2;
+        const double cphi = -x;
+        const double beta_pi = t2 * drcp(1.0 + cphi);
+        const double t0 = (Re[0] + cphi) * beta_pi, t1 = (Re[4] + cphi) * beta_pi, t2v = (Re[8] + cphi) * beta_pi;
+        const double a0 = dsel(Re[7] > Re[5], 1.0, -1.0) * dsel(t0 > 0.0, dsqrt(dmax(t0, 0.0)), 0.0);
+        const double a1 = dsel(Re[2] > Re[6], 1.0, -1.0) * dsel(t1 > 0.0, dsqrt(dmax(t1, 0.0)), 0.0);
+        const double a2 = dsel(Re[3] > Re[1], 1.0, -1.0) * dsel(t2v > 0.0, dsqrt(dmax(t2v, 0.0)), 0.0);
+        w[0] = dsel(near_pi, a0, w[0]);
+        w[1] = dsel(near_pi, a1, w[1]);
+        w[2] = dsel(near_pi, a2, w[2]);
+    }
+
+    const double st_omc = st * inv_omc;  // sin / (1 - cos)
+    const double alpha = dsel(small, 1.0 - t2 * (1.0 / 12.0) - t2 * t2 * (1.0 / 720.0), theta * st_omc * 0.5);
+    const double beta = dsel(small, 1.0 / 12.0 + t2 * (1.0 / 720.0), dfma(-0.5 * inv_t, st_omc, inv_t * inv_t));
+    double wxp[3];
+    cross(w, pe, wxp);
+    const double bwp = beta * dot(w, pe);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        o.e[i] = dfma(alpha, pe[i], dfma(-0.5, wxp[i], bwp * w[i]));
+        o.e[3 + i] = w[i];
+    }
+
+    // Jlog6(tMf), tMf = (Re^T, -Re^T pe): log3 = -w, same theta.
+    const double u[3] = {-w[0], -w[1], -w[2]};
+    double pp[3];
+    rotT_vec(Re, pe, pp);
+    pp[0] = -pp[0]; pp[1] = -pp[1]; pp[2] = -pp[2];
+    const double a3 = beta;  // 1/t^2 - (st/(1-ct))/(2t) ; same Taylor expansion
+    const double diag = dsel(small, 0.5 * (2.0 - t2 * (1.0 / 6.0)), 0.5 * (theta * st_omc));
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) o.A[3 * i + j] = a3 * u[i] * u[j];
+    o.A[0] += diag; o.A[4] += diag; o.A[8] += diag;
+    // + skew(0.5 u)
+    o.A[1] -= 0.5 * u[2]; o.A[2] += 0.5 * u[1];
+    o.A[3] += 0.5 * u[2]; o.A[5] -= 0.5 * u[0];
+    o.A[6] -= 0.5 * u[1]; o.A[7] += 0.5 * u[0];
+
+    const double inv_t2 = inv_t * inv_t;
+    const double bdot = dsel(small, 1.0 / 360.0,
+                             dfma(-2.0 * inv_t2, inv_t2, (1.0 + st * inv_t) * inv_t2 * (0.5 * inv_omc)));
+    const double up = dot(u, pp);
+    const double k1 = bdot * up, k2 = dfma(t2, bdot, 2.0 * beta);
+    const double v3[3] = {dfma(k1, u[0], -(k2 * pp[0])), dfma(k1, u[1], -(k2 * pp[1])), dfma(k1, u[2], -(k2 * pp[2]))};
+    double C[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) C[3 * i + j] = dfma(v3[i], u[j], beta * u[i] * pp[j]);
+    const double ub = up * beta;
+    C[0] += ub; C[4] += ub; C[8] += ub;
+    C[1] -= 0.5 * pp[2]; C[2] += 0.5 * pp[1];
+    C[3] += 0.5 * pp[2]; C[5] -= 0.5 * pp[0];
+    C[6] -= 0.5 * pp[1]; C[7] += 0.5 * pp[0];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            o.Bm[3 * i + j] = dfma(C[3 * i], o.A[j], dfma(C[3 * i + 1], o.A[3 + j], C[3 * i + 2] * o.A[6 + j]));
+}
+
+// In-place Cholesky of the SPD matrix held in the lower triangle of G (row-major M x M, only
+// i >= j used), then solve G x = b.  Diagonal entries are replaced by 1/L_ii.
+// Stands in for `JJ.ldlt().solve(et)` (reference ik/ik/dls.cpp:53): JJ = J J^T + lambda^2 I is
+// SPD for lambda > 0, so an unpivoted factorisation solves the same system.
+template <int M>
+IKD_FN void chol_solve(double (&G)[M * M], const double (&b)[M], double (&x)[M]) {
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+        double d = G[k * M + k];
+#pragma unroll
+        for (int m = 0; m < k; ++m) d = dfma(-G[k * M + m], G[k * M + m], d);
+        const double inv = drsqrt(d);
+        G[k * M + k] = inv;
+#pragma unroll
+        for (int i = k + 1; i < M; ++i) {
+            double s = G[i * M + k];
+#pragma unroll
+            for (int m = 0; m < k; ++m) s = dfma(-G[i * M + m], G[k * M + m], s);
+            G[i * M + k] = s * inv;
+        }
+    }
+    double y[M];
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+        double s = b[k];
+#pragma unroll
+        for (int m = 0; m < k; ++m) s = dfma(-G[k * M + m], y[m], s);
+        y[k] = s * G[k * M + k];
+    }
+#pragma unroll
+    for (int k = M - 1; k >= 0; --k) {
+        double s = y[k];
+#pragma unroll
+        for (int m = k + 1; m < M; ++m) s = dfma(-G[m * M + k], x[m], s);
+        x[k] = s * G[k * M + k];
+    }
+}
+
+}  // namespace ikdev

@@ -1,0 +1,165 @@
+// kernels.hip -- gfx950 kernels of the batched DLS path: one IK problem per wavefront lane,
+// the whole iteration loop on-chip, HBM touched once on entry and once on exit; the shared
+// kinematic-chain table is staged HBM -> LDS once per workgroup and read by broadcast.
+//
+// Reference path: ik::dls (ik/ik/dls.cpp:5-78) and everything it calls per iteration; the lane
+// program is device/chain_solver.hpp, the per-lane load/solve/store is device/chain_kernel_body.hpp.
+#include "kernels.hpp"
+
+#include <stdexcept>
+#include <string>
+
+#include "device/chain_kernel_body.hpp"
+
+namespace ikgpu {
+namespace {
+
+constexpr int kBlock = 64;  // one wave64 per workgroup: 1024 workgroups at B = 65536 cover 256 CUs x 4 SIMDs
+
+using ikdev::ChainDesc;
+using ikdev::ChainKernelArgs;
+
+// Stage the chain table HBM -> LDS with coalesced loads; every lane then reads it by broadcast.
+template <int NJ>
+__device__ __forceinline__ const ChainDesc<NJ> &stage_desc(const ChainDesc<NJ> *src, double *lds) {
+    constexpr int kWords = sizeof(ChainDesc<NJ>) / sizeof(double);
+    const double *g = reinterpret_cast<const double *>(src);
+    for (int i = threadIdx.x; i < kWords; i += kBlock) lds[i] = g[i];
+    __syncthreads();
+    return *reinterpret_cast<const ChainDesc<NJ> *>(lds);
+}
+
+template <int NJ, int KT>
+__global__ __launch_bounds__(kBlock) void dls_chain_kernel(const ChainKernelArgs<NJ> a) {
+    __shared__ double lds_desc[sizeof(ChainDesc<NJ>) / sizeof(double)];
+    const ChainDesc<NJ> &d = stage_desc<NJ>(a.desc, lds_desc);
+    const int64_t gid = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    ikdev::dls_chain_body<NJ, KT>(a, d, gid, [](bool act) { return __any(act) != 0; });
+}
+
+template <int NJ, int KT>
+__global__ __launch_bounds__(kBlock) void eval_chain_kernel(const ChainKernelArgs<NJ> a) {
+    __shared__ double lds_desc[sizeof(ChainDesc<NJ>) / sizeof(double)];
+    const ChainDesc<NJ> &d = stage_desc<NJ>(a.desc, lds_desc);
+    ikdev::eval_chain_body<NJ, KT>(a, d, static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x);
+}
+
+template <int NJ>
+__global__ __launch_bounds__(kBlock) void fk_chain_kernel(const ChainKernelArgs<NJ> a) {
+    __shared__ double lds_desc[sizeof(ChainDesc<NJ>) / sizeof(double)];
+    const ChainDesc<NJ> &d = stage_desc<NJ>(a.desc, lds_desc);
+    ikdev::fk_chain_body<NJ>(a, d, static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x);
+}
+
+template <int NJ>
+ChainKernelArgs<NJ> make_args(const ProblemHost &ph, const DeviceTables &dt) {
+    ChainKernelArgs<NJ> a{};
+    fill_chain_args(ph, a.ref_pl, a.qidx, a.vidx, &a.nq, &a.nv, &a.prm.priority);
+    a.desc = reinterpret_cast<const ChainDesc<NJ> *>(dt.chain_desc);
+    a.lower = dt.lower;
+    a.upper = dt.upper;
+    a.q_in_chain = dt.q_in_chain;
+    return a;
+}
+
+inline dim3 grid_for(int64_t B) { return dim3(static_cast<unsigned>((B + kBlock - 1) / kBlock)); }
+
+template <int NJ, int KT>
+hipError_t run_dls(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const ikgpu_dls_params &prm,
+                   hipStream_t stream) {
+    ChainKernelArgs<NJ> a = make_args<NJ>(ph, dt);
+    a.prm.max_iterations = prm.max_iterations;
+    a.prm.lam2 = prm.damping * prm.damping;
+    a.prm.step_length = prm.step_length;
+    a.prm.stop_sq_tol = prm.stop_sq_tol;
+    a.layout = io.layout;
+    a.B = io.B;
+    a.q0 = io.q0;
+    a.targets = io.targets;
+    a.q_out = io.q_out;
+    a.success = io.success;
+    a.iters = io.iters;
+    hipLaunchKernelGGL((dls_chain_kernel<NJ, KT>), grid_for(io.B), dim3(kBlock), 0, stream, a);
+    return hipGetLastError();
+}
+
+template <int NJ, int KT>
+hipError_t run_eval(const ProblemHost &ph, const DeviceTables &dt, int64_t B, const double *q, const double *targets,
+                    double *e_out, double *J_out, int layout, hipStream_t stream) {
+    ChainKernelArgs<NJ> a = make_args<NJ>(ph, dt);
+    a.layout = layout;
+    a.B = B;
+    a.q0 = q;
+    a.targets = targets;
+    a.e_out = e_out;
+    a.J_out = J_out;
+    hipLaunchKernelGGL((eval_chain_kernel<NJ, KT>), grid_for(B), dim3(kBlock), 0, stream, a);
+    return hipGetLastError();
+}
+
+template <int NJ>
+hipError_t run_fk(const ProblemHost &ph, const DeviceTables &dt, int64_t B, const double *q, double *oMf_out,
+                  int layout, hipStream_t stream) {
+    ChainKernelArgs<NJ> a = make_args<NJ>(ph, dt);
+    a.layout = layout;
+    a.B = B;
+    a.q0 = q;
+    a.oMf_out = oMf_out;
+    hipLaunchKernelGGL((fk_chain_kernel<NJ>), grid_for(B), dim3(kBlock), 0, stream, a);
+    return hipGetLastError();
+}
+
+[[noreturn]] void not_built(int nj, int type) {
+    throw std::runtime_error("no kernel instantiated for chain length " + std::to_string(nj) + ", kinematic type " +
+                             std::to_string(type));
+}
+
+}  // namespace
+
+#define IKGPU_FOR_NJ(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
+
+bool chain_shape_built(int nj, int type) {
+    return nj >= 1 && nj <= kMaxChain && (type == IKGPU_FULL || type == IKGPU_POSITION || type == IKGPU_ORIENTATION);
+}
+
+hipError_t launch_dls_chain(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io,
+                            const ikgpu_dls_params &prm, hipStream_t stream) {
+    const int nj = ph.chain.nj, type = ph.tasks[0].type;
+#define X(N)                                                                                              \
+    if (nj == N) {                                                                                        \
+        if (type == IKGPU_FULL) return run_dls<N, ikdev::KT_FULL>(ph, dt, io, prm, stream);               \
+        if (type == IKGPU_POSITION) return run_dls<N, ikdev::KT_POSITION>(ph, dt, io, prm, stream);       \
+        if (type == IKGPU_ORIENTATION) return run_dls<N, ikdev::KT_ORIENTATION>(ph, dt, io, prm, stream); \
+    }
+    IKGPU_FOR_NJ(X)
+#undef X
+    not_built(nj, type);
+}
+
+hipError_t launch_eval_chain(const ProblemHost &ph, const DeviceTables &dt, int64_t B, const double *q,
+                             const double *targets, double *e_out, double *J_out, int layout, hipStream_t stream) {
+    const int nj = ph.chain.nj, type = ph.tasks[0].type;
+#define X(N)                                                                                                             \
+    if (nj == N) {                                                                                                       \
+        if (type == IKGPU_FULL) return run_eval<N, ikdev::KT_FULL>(ph, dt, B, q, targets, e_out, J_out, layout, stream); \
+        if (type == IKGPU_POSITION)                                                                                      \
+            return run_eval<N, ikdev::KT_POSITION>(ph, dt, B, q, targets, e_out, J_out, layout, stream);                 \
+        if (type == IKGPU_ORIENTATION)                                                                                   \
+            return run_eval<N, ikdev::KT_ORIENTATION>(ph, dt, B, q, targets, e_out, J_out, layout, stream);              \
+    }
+    IKGPU_FOR_NJ(X)
+#undef X
+    not_built(nj, type);
+}
+
+hipError_t launch_fk_chain(const ProblemHost &ph, const DeviceTables &dt, int64_t B, const double *q, double *oMf_out,
+                           int layout, hipStream_t stream) {
+    const int nj = ph.chain.nj;
+#define X(N) \
+    if (nj == N) return run_fk<N>(ph, dt, B, q, oMf_out, layout, stream);
+    IKGPU_FOR_NJ(X)
+#undef X
+    not_built(nj, 0);
+}
+
+}  // namespace ikgpu

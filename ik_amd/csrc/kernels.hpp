@@ -1,0 +1,37 @@
+// kernels.hpp -- host-visible launchers of the gfx950 kernels (defined in kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+#include "problem.hpp"
+
+namespace ikgpu {
+
+struct DeviceTables {  // per-problem constant arrays resident in HBM
+    double *lower = nullptr, *upper = nullptr;  // [nq]
+    uint8_t *q_in_chain = nullptr;              // [nq]
+    double *chain_desc = nullptr;               // ikdev::ChainDesc<NJ> as a flat array of doubles
+};
+
+struct BatchIO {
+    int64_t B;
+    const double *q0;       // [nq x B]
+    const double *targets;  // [ntasks x 12 x B]
+    double *q_out;          // [nq x B]
+    uint8_t *success;       // [B] or null
+    int32_t *iters;         // [B] or null
+    int layout;             // ikgpu_layout
+};
+
+// Returns hipSuccess or the launch error. Throws std::runtime_error for an un-instantiated shape.
+hipError_t launch_dls_chain(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io,
+                            const ikgpu_dls_params &prm, hipStream_t stream);
+hipError_t launch_eval_chain(const ProblemHost &ph, const DeviceTables &dt, int64_t B, const double *q, const double *targets,
+                             double *e_out, double *J_out, int layout, hipStream_t stream);
+hipError_t launch_fk_chain(const ProblemHost &ph, const DeviceTables &dt, int64_t B, const double *q, double *oMf_out, int layout,
+                           hipStream_t stream);
+bool chain_shape_built(int nj, int type);
+
+}  // namespace ikgpu

@@ -1,0 +1,161 @@
+/*
+ * ikgpu.h -- C ABI of the MI355X batched damped-least-squares IK path.
+ *
+ * This is the drop-in boundary for ONE path of dazzmo/ik: the iterative loop ik::dls()
+ * (reference ik/ik/dls.cpp:5-78) together with what it calls per iteration
+ * (ik/ik/data.cpp:25-58, ik/ik/frame.hpp:37-62,152-182, ik/ik/common.hpp:53-56,
+ * ik/ik/visitor.hpp:15-21).  The reference has no FFI of its own -- its boundary is the C++
+ * free function
+ *
+ *     vector_t dls(InverseKinematicsProblem&, const vector_t& q0, dls_data&,
+ *                  const inverse_kinematics_visitor&, const dls_parameters&);   // ik/ik/dls.hpp:111-114
+ *
+ * so each entry point below names the reference interface it stands in for.  The C++ mirror of
+ * the reference classes (ik_amd/csrc/host/ik/ *.hpp) and the Python ctypes binding (ik_amd/capi.py)
+ * are thin layers over exactly these symbols.  Plain pointers and sizes only; no C++ or torch
+ * types cross this boundary; nothing here ever throws.  There is NO CPU fallback: every solve
+ * entry point runs hand-written gfx950 kernels or returns an error.
+ *
+ * Conventions
+ *   - SE(3) values are 12 doubles: rotation row-major (9) then translation (3).
+ *   - Configuration vectors follow Pinocchio: revolute/prismatic joints one entry; a free-flyer
+ *     root is (x y z qx qy qz qw) in q and (v_lin, omega) body-frame in the tangent space.
+ *   - Batch layouts: IKGPU_SOA is component-major  [component][B]  (device-native, coalesced);
+ *     IKGPU_AOS is problem-major [B][component] (what a column-major nq x B Eigen matrix is).
+ *     targets: SOA [ntasks][12][B], AOS [B][ntasks][12].
+ *   - All functions return IKGPU_OK (0) or an ikgpu_status error; ikgpu_last_error() gives the
+ *     message of the calling thread's last failure.
+ */
+#ifndef IKGPU_H
+#define IKGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IKGPU_ABI_VERSION 1
+
+typedef enum {
+    IKGPU_OK = 0,
+    IKGPU_ERR_INVALID = 1,     /* bad argument (null pointer, size mismatch, unknown id) */
+    IKGPU_ERR_PARSE = 2,       /* URDF text could not be parsed */
+    IKGPU_ERR_UNSUPPORTED = 3, /* model / task set has no device kernel (stated in last_error) */
+    IKGPU_ERR_DEVICE = 4       /* HIP runtime failure, or no gfx950 device */
+} ikgpu_status;
+
+typedef enum { IKGPU_JOINT_UNIVERSE = 0, IKGPU_JOINT_REVOLUTE = 1, IKGPU_JOINT_PRISMATIC = 2, IKGPU_JOINT_FREEFLYER = 3 } ikgpu_joint_type;
+
+/* ik::KinematicType, reference ik/ik/frame.hpp:20 (same order). */
+typedef enum { IKGPU_POSITION = 0, IKGPU_ORIENTATION = 1, IKGPU_FULL = 2 } ikgpu_kinematic_type;
+
+typedef enum { IKGPU_SOA = 0, IKGPU_AOS = 1 } ikgpu_layout;
+
+typedef enum { IKGPU_ROOT_FIXED = 0, IKGPU_ROOT_FREEFLYER = 1 } ikgpu_root_joint;
+
+/* Flat kinematic model (what pinocchio::Model holds that the path reads: ik/ik/common.hpp:16).
+ * Joint 0 is "universe".  As an input every pointer is caller-owned; as an output of
+ * ikgpu_model_get_flat the pointers alias the model and live as long as it does. */
+typedef struct {
+    int32_t njoints, nq, nv, nframes;
+    const int32_t *joint_type;      /* [njoints] ikgpu_joint_type */
+    const int32_t *joint_parent;    /* [njoints] */
+    const int32_t *joint_idx_q;     /* [njoints] */
+    const int32_t *joint_idx_v;     /* [njoints] */
+    const double *joint_placement;  /* [njoints][12] parent joint frame -> joint frame */
+    const double *joint_axis;       /* [njoints][3]  unit axis (revolute / prismatic) */
+    const double *lower, *upper;    /* [nq] position limits (model.lowerPositionLimit / upper) */
+    const int32_t *frame_parent;    /* [nframes] parent joint */
+    const double *frame_placement;  /* [nframes][12] */
+    const char *const *joint_names; /* [njoints] */
+    const char *const *frame_names; /* [nframes] */
+} ikgpu_flat_model;
+
+/* One ik::FrameTask (reference ik/ik/frame.hpp:78-200) as the device sees it: frame and
+ * reference-frame ids (model.getFrameId), kinematic type, priority level
+ * (InverseKinematicsProblem::add_frame_task's third argument, ik/ik/problem.hpp:55-66) and the
+ * Task::weighting() vector (ik/ik/task.hpp:40; first `dimension` entries used, default ones).
+ * The task's `target` (frame.hpp:189) is per-problem data and is passed to the solve call. */
+typedef struct {
+    int32_t frame, reference, type, priority;
+    double weight[6];
+} ikgpu_task;
+
+/* ik::dls_parameters (reference ik/ik/dls.hpp:24-28, ik/ik/common.hpp:59-66) plus the stop rule
+ * of inverse_kinematics_visitor::should_stop (ik/ik/visitor.hpp:15-21) as a number: a problem
+ * stops, *before* stepping, when ||e[0]||^2 < stop_sq_tol (1e-4 in the reference).  A negative
+ * value means "a visitor that never stops": exactly max_iterations steps are taken.
+ * max_time and random_restart are unused by the reference loop and have no counterpart. */
+typedef struct {
+    int32_t max_iterations; /* default 100 */
+    double damping;         /* default 1e-2; damping^2 is added to the Gram diagonal (dls.cpp:41) */
+    double step_length;     /* default 1.0 */
+    double stop_sq_tol;     /* default 1e-4; < 0 never stops */
+} ikgpu_dls_params;
+
+typedef struct ikgpu_model ikgpu_model;     /* immutable host-side kinematic model */
+typedef struct ikgpu_problem ikgpu_problem; /* model + task table flattened onto one device */
+
+int ikgpu_abi_version(void);
+const char *ikgpu_last_error(void);
+void ikgpu_dls_params_default(ikgpu_dls_params *p);
+
+/* ---- model loading: stands in for pinocchio::urdf::buildModelFromXML as called at reference
+ * ik_ros/src/cassie.cpp:34-35 and ik_ros/src/rviz_model_loader.cpp:24-27.  Reproduces Pinocchio's
+ * conventions (joint order, idx_q/idx_v, fixed joints folded into placements, frame table). */
+int ikgpu_model_from_urdf(const char *xml, size_t len, int root_joint /* ikgpu_root_joint */, ikgpu_model **out);
+/* From arrays (the hook for a caller that already holds a pinocchio::Model). Deep-copies. */
+int ikgpu_model_create(const ikgpu_flat_model *flat, ikgpu_model **out);
+void ikgpu_model_destroy(ikgpu_model *m);
+int ikgpu_model_get_flat(const ikgpu_model *m, ikgpu_flat_model *out);
+/* model.getFrameId(name) (reference ik/ik/common.hpp:50): returns nframes when absent. */
+int32_t ikgpu_model_frame_id(const ikgpu_model *m, const char *name);
+int32_t ikgpu_model_joint_id(const ikgpu_model *m, const char *name);
+
+/* ---- problem: stands in for InverseKinematicsProblem + dls_data construction
+ * (reference ik/ik/problem.hpp:17-22, ik/ik/dls.hpp:36-52, ik/ik/data.cpp:8-23).  Analyses the
+ * support of every task, picks the kernel specialisation and uploads the constant tables.
+ * device: HIP device ordinal. */
+int ikgpu_problem_create(const ikgpu_model *m, const ikgpu_task *tasks, int32_t ntasks, int32_t device, ikgpu_problem **out);
+void ikgpu_problem_destroy(ikgpu_problem *p);
+/* Host-only dry run of the analysis ikgpu_problem_create performs: writes the name of the kernel
+ * specialisation that would run (NUL-terminated, truncated to cap) or fails with
+ * IKGPU_ERR_UNSUPPORTED / IKGPU_ERR_INVALID and the reason in ikgpu_last_error(). Touches no device. */
+int ikgpu_problem_plan(const ikgpu_model *m, const ikgpu_task *tasks, int32_t ntasks, char *out, size_t cap);
+int32_t ikgpu_problem_rows(const ikgpu_problem *p);        /* M = sum of task dimensions */
+const char *ikgpu_problem_kernel(const ikgpu_problem *p);  /* name of the chosen specialisation */
+
+/* ---- the hot path: B independent calls of ik::dls() (reference ik/ik/dls.cpp:5-78) in lockstep.
+ * All array arguments are DEVICE pointers on the problem's device:
+ *   q0      [nq x B]            initial configurations
+ *   targets [ntasks x 12 x B]   FrameTask::target per task, w.r.t. the task's reference frame
+ *   q_out   [nq x B]            returned configuration (dls.cpp:63 / :77)
+ *   success [B] (uint8, may be NULL)  data.success (dls.cpp:62 / :76)
+ *   iters   [B] (int32, may be NULL)  iteration index at which should_stop fired, else max_iterations
+ * stream: a hipStream_t (NULL = default stream).  Asynchronous; re-entrant per stream. */
+int ikgpu_dls_solve_batch(const ikgpu_problem *p, int64_t B, const double *q0, const double *targets,
+                          const ikgpu_dls_params *params, double *q_out, uint8_t *success, int32_t *iters,
+                          int layout /* ikgpu_layout */, void *stream);
+
+/* Same with HOST pointers: copies in, solves on the device, copies out, synchronises. This is what
+ * the single-problem ik::dls() shim calls with B = 1. */
+int ikgpu_dls_solve_batch_host(const ikgpu_problem *p, int64_t B, const double *q0, const double *targets,
+                               const ikgpu_dls_params *params, double *q_out, uint8_t *success, int32_t *iters,
+                               int layout);
+
+/* ---- stage kernels (device pointers), for stage-by-stage parity and for building targets:
+ * evaluate_problem_data + stacking (reference ik/ik/data.cpp:25-58, ik/ik/dls.cpp:18-24):
+ *   e_out [M x B], J_out [M x nv x B] (row-major M x nv per problem; J_out may be NULL). */
+int ikgpu_evaluate_batch(const ikgpu_problem *p, int64_t B, const double *q, const double *targets,
+                         double *e_out, double *J_out, int layout, void *stream);
+/* framesForwardKinematics restricted to the task frames (reference ik/ik/data.cpp:28-29):
+ *   oMf_out [ntasks x 12 x B] world placement of each task's frame. */
+int ikgpu_task_frames_fk_batch(const ikgpu_problem *p, int64_t B, const double *q, double *oMf_out,
+                               int layout, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IKGPU_H */

@@ -1,0 +1,586 @@
+/*
+ * ik_oracle.c -- plain-C CPU restatement of the reference IK hot path.
+ * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (see ik_oracle.h for the full statement).
+ *
+ * "Faithful" variant: same loop order, whole-tree FK, every frame placed, dense 6 x nv joint
+ * Jacobian, dense M x nv task Jacobian, dense M x M Gram, pivoted LDL^T, dense N = I mat-vec --
+ * i.e. the work the reference does, minus its string look-ups and per-iteration heap traffic.
+ *
+ * Follows (reference root relative):
+ *   ik/ik/dls.cpp:5-78, ik/ik/data.cpp:25-58, ik/ik/frame.hpp:37-62,152-182,
+ *   ik/ik/common.hpp:47-56, ik/ik/visitor.hpp:15-21, ik/ik/dls.hpp:24-65, ik/ik/task.hpp:48-51.
+ * Pinocchio / Eigen semantics: SURVEY.md Appendix A (third-party, not in the reference tree).
+ */
+#include "ik_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* TaylorSeriesExpansion<double>::precision<3>() = eps^(1/4) */
+static double taylor_prec3(void) { return sqrt(sqrt(DBL_EPSILON)); }
+
+/* ---------------------------------------------------------------- SE(3) as 12 doubles */
+#define R_(M, i, j) ((M)[3 * (i) + (j)])
+#define P_(M, i) ((M)[9 + (i)])
+
+static void se3_identity(double *M) {
+    memset(M, 0, 12 * sizeof(double));
+    R_(M, 0, 0) = R_(M, 1, 1) = R_(M, 2, 2) = 1.0;
+}
+
+/* C = A * B  (SE3::act) */
+static void se3_mul(const double *A, const double *B, double *C) {
+    double T[12];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j)
+            R_(T, i, j) = R_(A, i, 0) * R_(B, 0, j) + R_(A, i, 1) * R_(B, 1, j) + R_(A, i, 2) * R_(B, 2, j);
+        P_(T, i) = P_(A, i) + R_(A, i, 0) * P_(B, 0) + R_(A, i, 1) * P_(B, 1) + R_(A, i, 2) * P_(B, 2);
+    }
+    memcpy(C, T, sizeof T);
+}
+
+/* C = A^-1 * B  (SE3::actInv) */
+static void se3_inv_mul(const double *A, const double *B, double *C) {
+    double T[12], d[3];
+    for (int i = 0; i < 3; ++i) d[i] = P_(B, i) - P_(A, i);
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j)
+            R_(T, i, j) = R_(A, 0, i) * R_(B, 0, j) + R_(A, 1, i) * R_(B, 1, j) + R_(A, 2, i) * R_(B, 2, j);
+        P_(T, i) = R_(A, 0, i) * d[0] + R_(A, 1, i) * d[1] + R_(A, 2, i) * d[2];
+    }
+    memcpy(C, T, sizeof T);
+}
+
+static void cross3(const double *a, const double *b, double *c) {
+    double x = a[1] * b[2] - a[2] * b[1];
+    double y = a[2] * b[0] - a[0] * b[2];
+    double z = a[0] * b[1] - a[1] * b[0];
+    c[0] = x; c[1] = y; c[2] = z;
+}
+
+static double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+/* Eigen::Quaternion::toRotationMatrix, coefficients (x,y,z,w), not normalised */
+static void quat_to_R(const double *q, double *M) {
+    double x = q[0], y = q[1], z = q[2], w = q[3];
+    double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    double twx = tx * w, twy = ty * w, twz = tz * w;
+    double txx = tx * x, txy = ty * x, txz = tz * x;
+    double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R_(M, 0, 0) = 1 - (tyy + tzz); R_(M, 0, 1) = txy - twz;       R_(M, 0, 2) = txz + twy;
+    R_(M, 1, 0) = txy + twz;       R_(M, 1, 1) = 1 - (txx + tzz); R_(M, 1, 2) = tyz - twx;
+    R_(M, 2, 0) = txz - twy;       R_(M, 2, 1) = tyz + twx;       R_(M, 2, 2) = 1 - (txx + tyy);
+}
+
+/* Eigen rotation matrix -> quaternion (x,y,z,w) */
+static void R_to_quat(const double *M, double *q) {
+    double t = R_(M, 0, 0) + R_(M, 1, 1) + R_(M, 2, 2);
+    if (t > 0) {
+        t = sqrt(t + 1.0);
+        q[3] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (R_(M, 2, 1) - R_(M, 1, 2)) * t;
+        q[1] = (R_(M, 0, 2) - R_(M, 2, 0)) * t;
+        q[2] = (R_(M, 1, 0) - R_(M, 0, 1)) * t;
+    } else {
+        int i = 0;
+        if (R_(M, 1, 1) > R_(M, 0, 0)) i = 1;
+        if (R_(M, 2, 2) > R_(M, i, i)) i = 2;
+        int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(R_(M, i, i) - R_(M, j, j) - R_(M, k, k) + 1.0);
+        q[i] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (R_(M, k, j) - R_(M, j, k)) * t;
+        q[j] = (R_(M, j, i) + R_(M, i, j)) * t;
+        q[k] = (R_(M, k, i) + R_(M, i, k)) * t;
+    }
+}
+
+/* ---------------------------------------------------------------- Lie-group maps (App. A.3, A.5) */
+static void log3_(const double *M, double *w, double *theta_out) {
+    const double tr = R_(M, 0, 0) + R_(M, 1, 1) + R_(M, 2, 2);
+    double theta;
+    if (tr >= 3.0) theta = 0.0;
+    else if (tr <= -1.0) theta = M_PI;
+    else theta = acos((tr - 1.0) / 2.0);
+    if (theta >= M_PI - 1e-2) {
+        const double cphi = -(tr - 1.0) / 2.0;
+        const double beta = theta * theta / (1.0 + cphi);
+        const double t0 = (R_(M, 0, 0) + cphi) * beta, t1 = (R_(M, 1, 1) + cphi) * beta,
+                     t2 = (R_(M, 2, 2) + cphi) * beta;
+        w[0] = (R_(M, 2, 1) > R_(M, 1, 2) ? 1.0 : -1.0) * (t0 > 0 ? sqrt(t0) : 0.0);
+        w[1] = (R_(M, 0, 2) > R_(M, 2, 0) ? 1.0 : -1.0) * (t1 > 0 ? sqrt(t1) : 0.0);
+        w[2] = (R_(M, 1, 0) > R_(M, 0, 1) ? 1.0 : -1.0) * (t2 > 0 ? sqrt(t2) : 0.0);
+    } else {
+        const double t = ((theta > taylor_prec3()) ? theta / sin(theta) : 1.0) / 2.0;
+        w[0] = t * (R_(M, 2, 1) - R_(M, 1, 2));
+        w[1] = t * (R_(M, 0, 2) - R_(M, 2, 0));
+        w[2] = t * (R_(M, 1, 0) - R_(M, 0, 1));
+    }
+    *theta_out = theta;
+}
+
+void iko_log6(const double *M, double *out) {
+    double w[3], t, wxp[3];
+    const double *p = &P_(M, 0);
+    log3_(M, w, &t);
+    const double t2 = t * t;
+    double alpha, beta;
+    if (t < taylor_prec3()) {
+        alpha = 1.0 - t2 / 12.0 - t2 * t2 / 720.0;
+        beta = 1.0 / 12.0 + t2 / 720.0;
+    } else {
+        const double st = sin(t), ct = cos(t);
+        alpha = t * st / (2.0 * (1.0 - ct));
+        beta = 1.0 / t2 - st / (2.0 * t * (1.0 - ct));
+    }
+    cross3(w, p, wxp);
+    const double bwp = beta * dot3(w, p);
+    for (int i = 0; i < 3; ++i) {
+        out[i] = alpha * p[i] - 0.5 * wxp[i] + bwp * w[i];
+        out[3 + i] = w[i];
+    }
+}
+
+static void add_skew(const double *v, double *A /*3x3 row-major*/) {
+    A[1] -= v[2]; A[2] += v[1];
+    A[3] += v[2]; A[5] -= v[0];
+    A[6] -= v[1]; A[7] += v[0];
+}
+
+static void Jlog3_(double theta, const double *w, double *A) {
+    double alpha, diag;
+    if (theta < taylor_prec3()) {
+        alpha = 1.0 / 12.0 + theta * theta / 720.0;
+        diag = 0.5 * (2.0 - theta * theta / 6.0);
+    } else {
+        const double st = sin(theta), ct = cos(theta);
+        const double st_1mct = st / (1.0 - ct);
+        alpha = 1.0 / (theta * theta) - st_1mct / (2.0 * theta);
+        diag = 0.5 * (theta * st_1mct);
+    }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) A[3 * i + j] = alpha * w[i] * w[j];
+    A[0] += diag; A[4] += diag; A[8] += diag;
+    const double hw[3] = {0.5 * w[0], 0.5 * w[1], 0.5 * w[2]};
+    add_skew(hw, A);
+}
+
+void iko_Jlog6(const double *M, double *J /*6x6 row-major*/) {
+    double w[3], t, A[9], C[9], B[9];
+    const double *p = &P_(M, 0);
+    log3_(M, w, &t);
+    Jlog3_(t, w, A);
+    const double t2 = t * t;
+    double beta, bdot;
+    if (t < taylor_prec3()) {
+        beta = 1.0 / 12.0 + t2 / 720.0;
+        bdot = 1.0 / 360.0;
+    } else {
+        const double tinv = 1.0 / t, t2inv = tinv * tinv;
+        const double st = sin(t), ct = cos(t);
+        const double inv_2_2ct = 1.0 / (2.0 * (1.0 - ct));
+        beta = t2inv - st * tinv * inv_2_2ct;
+        bdot = -2.0 * t2inv * t2inv + (1.0 + st * tinv) * t2inv * inv_2_2ct;
+    }
+    const double wTp = dot3(w, p);
+    double v3[3];
+    for (int i = 0; i < 3; ++i) v3[i] = (bdot * wTp) * w[i] - (t2 * bdot + 2.0 * beta) * p[i];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) C[3 * i + j] = v3[i] * w[j] + beta * w[i] * p[j];
+    C[0] += wTp * beta; C[4] += wTp * beta; C[8] += wTp * beta;
+    const double hp[3] = {0.5 * p[0], 0.5 * p[1], 0.5 * p[2]};
+    add_skew(hp, C);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            B[3 * i + j] = C[3 * i] * A[j] + C[3 * i + 1] * A[3 + j] + C[3 * i + 2] * A[6 + j];
+    memset(J, 0, 36 * sizeof(double));
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            J[6 * i + j] = A[3 * i + j];
+            J[6 * i + 3 + j] = B[3 * i + j];
+            J[6 * (3 + i) + 3 + j] = A[3 * i + j];
+        }
+}
+
+void iko_exp6(const double *nu, double *M) {
+    const double *v = nu, *w = nu + 3;
+    const double t2 = dot3(w, w);
+    const double t = sqrt(t2);
+    double a_wxv, a_v, a_w, diag;
+    if (t < taylor_prec3()) {
+        a_wxv = 0.5 - t2 / 24.0;
+        a_v = 1.0 - t2 / 6.0;
+        a_w = 1.0 / 6.0 - t2 / 120.0;
+        diag = 1.0 - t2 / 2.0;
+    } else {
+        const double st = sin(t), ct = cos(t);
+        const double inv_t2 = 1.0 / t2;
+        a_wxv = (1.0 - ct) * inv_t2;
+        a_v = st / t;
+        a_w = (1.0 - a_v) * inv_t2;
+        diag = ct;
+    }
+    double wxv[3];
+    cross3(w, v, wxv);
+    const double awv = a_w * dot3(w, v);
+    for (int i = 0; i < 3; ++i) P_(M, i) = a_v * v[i] + awv * w[i] + a_wxv * wxv[i];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) R_(M, i, j) = a_wxv * w[i] * w[j];
+    const double av[3] = {a_v * w[0], a_v * w[1], a_v * w[2]};
+    add_skew(av, M);
+    R_(M, 0, 0) += diag; R_(M, 1, 1) += diag; R_(M, 2, 2) += diag;
+}
+
+/* ---------------------------------------------------------------- kinematics (App. A.2) */
+static void joint_transform(const iko_model *m, int j, const double *q, double *M) {
+    const int iq = m->idx_q[j];
+    const double *a = m->axis + 3 * j;
+    se3_identity(M);
+    switch (m->jtype[j]) {
+        case IKO_JOINT_REVOLUTE: {
+            const double c = cos(q[iq]), s = sin(q[iq]), k = 1.0 - c;
+            /* Rodrigues; for an aligned axis every entry is exact */
+            R_(M, 0, 0) = c + k * a[0] * a[0];
+            R_(M, 0, 1) = k * a[0] * a[1] - s * a[2];
+            R_(M, 0, 2) = k * a[0] * a[2] + s * a[1];
+            R_(M, 1, 0) = k * a[1] * a[0] + s * a[2];
+            R_(M, 1, 1) = c + k * a[1] * a[1];
+            R_(M, 1, 2) = k * a[1] * a[2] - s * a[0];
+            R_(M, 2, 0) = k * a[2] * a[0] - s * a[1];
+            R_(M, 2, 1) = k * a[2] * a[1] + s * a[0];
+            R_(M, 2, 2) = c + k * a[2] * a[2];
+        } break;
+        case IKO_JOINT_PRISMATIC:
+            for (int i = 0; i < 3; ++i) P_(M, i) = a[i] * q[iq];
+            break;
+        case IKO_JOINT_FREEFLYER:
+            quat_to_R(q + iq + 3, M);
+            for (int i = 0; i < 3; ++i) P_(M, i) = q[iq + i];
+            break;
+        default: break;
+    }
+}
+
+void iko_fk(const iko_model *m, const double *q, double *oMi_out, double *oMf_out) {
+    double *oMi = oMi_out ? oMi_out : (double *)malloc(sizeof(double) * 12 * m->njoints);
+    se3_identity(oMi);
+    for (int j = 1; j < m->njoints; ++j) {
+        double Mj[12], liMi[12];
+        joint_transform(m, j, q, Mj);
+        se3_mul(m->placement + 12 * j, Mj, liMi);
+        se3_mul(oMi + 12 * m->parent[j], liMi, oMi + 12 * j);
+    }
+    if (oMf_out)
+        for (int f = 0; f < m->nframes; ++f)
+            se3_mul(oMi + 12 * m->frame_parent[f], m->frame_placement + 12 * f, oMf_out + 12 * f);
+    if (!oMi_out) free(oMi);
+}
+
+/* computeJointJacobians: Jw[6][nv] row-major, columns [v; w] in the world frame */
+static void joint_jacobians_world(const iko_model *m, const double *oMi, double *Jw) {
+    const int nv = m->nv;
+    memset(Jw, 0, sizeof(double) * 6 * nv);
+    for (int j = 1; j < m->njoints; ++j) {
+        const double *M = oMi + 12 * j;
+        const double *a = m->axis + 3 * j;
+        const int iv = m->idx_v[j];
+        if (m->jtype[j] == IKO_JOINT_REVOLUTE || m->jtype[j] == IKO_JOINT_PRISMATIC) {
+            double Ra[3], v[3];
+            for (int i = 0; i < 3; ++i) Ra[i] = R_(M, i, 0) * a[0] + R_(M, i, 1) * a[1] + R_(M, i, 2) * a[2];
+            if (m->jtype[j] == IKO_JOINT_REVOLUTE) {
+                cross3(&P_(M, 0), Ra, v);
+                for (int i = 0; i < 3; ++i) { Jw[i * nv + iv] = v[i]; Jw[(3 + i) * nv + iv] = Ra[i]; }
+            } else {
+                for (int i = 0; i < 3; ++i) Jw[i * nv + iv] = Ra[i];
+            }
+        } else if (m->jtype[j] == IKO_JOINT_FREEFLYER) {
+            /* Ad(oM1) = [[R, [p]x R], [0, R]] */
+            for (int c = 0; c < 3; ++c) {
+                double Rc[3] = {R_(M, 0, c), R_(M, 1, c), R_(M, 2, c)}, pxRc[3];
+                cross3(&P_(M, 0), Rc, pxRc);
+                for (int i = 0; i < 3; ++i) {
+                    Jw[i * nv + iv + c] = Rc[i];
+                    Jw[i * nv + iv + 3 + c] = pxRc[i];
+                    Jw[(3 + i) * nv + iv + 3 + c] = Rc[i];
+                }
+            }
+        }
+    }
+}
+
+/* getFrameJacobian(LOCAL): writes only the columns in the support of `joint` into Jl[6][nv] */
+static void frame_jacobian_local(const iko_model *m, const double *Jw, const double *oMf, int joint,
+                                 double *Jl) {
+    const int nv = m->nv;
+    for (int j = joint; j > 0; j = m->parent[j]) {
+        const int n = (m->jtype[j] == IKO_JOINT_FREEFLYER) ? 6 : 1;
+        for (int c = m->idx_v[j]; c < m->idx_v[j] + n; ++c) {
+            double v[3] = {Jw[c], Jw[nv + c], Jw[2 * nv + c]};
+            double w[3] = {Jw[3 * nv + c], Jw[4 * nv + c], Jw[5 * nv + c]};
+            double pxw[3];
+            cross3(&P_(oMf, 0), w, pxw);
+            for (int i = 0; i < 3; ++i) v[i] -= pxw[i];
+            for (int i = 0; i < 3; ++i) {
+                Jl[i * nv + c] = R_(oMf, 0, i) * v[0] + R_(oMf, 1, i) * v[1] + R_(oMf, 2, i) * v[2];
+                Jl[(3 + i) * nv + c] = R_(oMf, 0, i) * w[0] + R_(oMf, 1, i) * w[1] + R_(oMf, 2, i) * w[2];
+            }
+        }
+    }
+}
+
+static int task_dim(const iko_task *t) { return t->type == IKO_FULL ? 6 : 3; }
+
+int iko_task_rows(const iko_task *tasks, int ntasks) {
+    int M = 0;
+    for (int i = 0; i < ntasks; ++i) M += task_dim(&tasks[i]);
+    return M;
+}
+
+typedef struct {
+    double *oMi, *oMf, *Jw, *Jl, *et, *Jt, *JJ, *y, *dq, *tmp, *q, *qn;
+    int *perm;
+    int M;
+} workspace;
+
+static workspace *ws_new(const iko_model *m, int M) {
+    workspace *w = (workspace *)calloc(1, sizeof *w);
+    w->M = M;
+    w->oMi = (double *)malloc(sizeof(double) * 12 * m->njoints);
+    w->oMf = (double *)malloc(sizeof(double) * 12 * m->nframes);
+    w->Jw = (double *)malloc(sizeof(double) * 6 * m->nv);
+    w->Jl = (double *)calloc(6 * m->nv, sizeof(double)); /* zeroed once: frame.hpp:110 */
+    w->et = (double *)malloc(sizeof(double) * M);
+    w->Jt = (double *)malloc(sizeof(double) * M * m->nv);
+    w->JJ = (double *)malloc(sizeof(double) * M * M);
+    w->y = (double *)malloc(sizeof(double) * M);
+    w->dq = (double *)malloc(sizeof(double) * m->nv);
+    w->tmp = (double *)malloc(sizeof(double) * (m->nv > M ? m->nv : M));
+    w->q = (double *)malloc(sizeof(double) * m->nq);
+    w->qn = (double *)malloc(sizeof(double) * m->nq);
+    w->perm = (int *)malloc(sizeof(int) * M);
+    return w;
+}
+
+static void ws_free(workspace *w) {
+    free(w->oMi); free(w->oMf); free(w->Jw); free(w->Jl); free(w->et); free(w->Jt); free(w->JJ);
+    free(w->y); free(w->dq); free(w->tmp); free(w->q); free(w->qn); free(w->perm); free(w);
+}
+
+/* evaluate_problem_data + stacking. Each task owns a frame-Jacobian scratch in the reference
+ * (frame.hpp:199, zeroed once); columns outside the support stay zero, so a shared scratch
+ * re-zeroed per task is equivalent. Returns ||e[0]||^2 of the priority-0 rows via *e0sq. */
+static void evaluate_ws(const iko_model *m, const iko_task *tasks, int ntasks, const double *targets,
+                        const double *q, workspace *w, double *e0sq) {
+    const int nv = m->nv;
+    iko_fk(m, q, w->oMi, w->oMf);                 /* data.cpp:28-29 */
+    joint_jacobians_world(m, w->oMi, w->Jw);      /* data.cpp:30 */
+    int maxp = 0;
+    for (int i = 0; i < ntasks; ++i) if (tasks[i].priority > maxp) maxp = tasks[i].priority;
+    int row = 0;
+    double acc0 = 0.0;
+    for (int p = 0; p <= maxp; ++p) {             /* data.cpp:38; dls.cpp:20-24 */
+        for (int ti = 0; ti < ntasks; ++ti) {
+            const iko_task *t = &tasks[ti];
+            if (t->priority != p) continue;
+            const double *oMf = w->oMf + 12 * t->frame, *oMr = w->oMf + 12 * t->reference;
+            double oMt[12], fMt[12], tMf[12], e6[6], Jlog[36];
+            se3_mul(oMr, targets + 12 * ti, oMt); /* frame.hpp:48 */
+            se3_inv_mul(oMf, oMt, fMt);           /* frame.hpp:50 */
+            iko_log6(fMt, e6);                    /* frame.hpp:53-61 */
+            se3_inv_mul(oMt, oMf, tMf);           /* frame.hpp:162 */
+            iko_Jlog6(tMf, Jlog);                 /* frame.hpp:165-166 */
+            memset(w->Jl, 0, sizeof(double) * 6 * nv);
+            frame_jacobian_local(m, w->Jw, oMf, m->frame_parent[t->frame], w->Jl); /* :169 */
+            const int d = task_dim(t);
+            const int r0 = (t->type == IKO_ORIENTATION) ? 3 : 0;
+            for (int r = 0; r < d; ++r) {         /* frame.hpp:173-181 */
+                const double wt = t->weight[r];   /* data.cpp:49-50 */
+                w->et[row + r] = e6[r0 + r] * wt;
+                if (p == 0) acc0 += w->et[row + r] * w->et[row + r];
+                for (int c = 0; c < nv; ++c) {
+                    double s = 0.0;
+                    for (int k = 0; k < 6; ++k) s += -Jlog[6 * (r0 + r) + k] * w->Jl[k * nv + c];
+                    w->Jt[(row + r) * nv + c] = wt * s;
+                }
+            }
+            row += d;
+        }
+    }
+    if (e0sq) *e0sq = acc0;
+}
+
+void iko_evaluate(const iko_model *m, const iko_task *tasks, int ntasks, const double *targets,
+                  const double *q, double *et, double *Jt) {
+    const int M = iko_task_rows(tasks, ntasks);
+    workspace *w = ws_new(m, M);
+    evaluate_ws(m, tasks, ntasks, targets, q, w, NULL);
+    memcpy(et, w->et, sizeof(double) * M);
+    memcpy(Jt, w->Jt, sizeof(double) * M * m->nv);
+    ws_free(w);
+}
+
+/* Eigen::LDLT restated: in-place lower LDL^T with symmetric pivoting on the largest |diagonal|,
+ * then solve (dls.cpp:53 `JJ.ldlt().solve(et)`). A is M x M row-major, destroyed. */
+static void ldlt_solve(double *A, int n, const double *b, double *x, int *perm, double *tmp) {
+    for (int k = 0; k < n; ++k) {
+        int piv = k;
+        double big = fabs(A[k * n + k]);
+        for (int i = k + 1; i < n; ++i)
+            if (fabs(A[i * n + i]) > big) { big = fabs(A[i * n + i]); piv = i; }
+        perm[k] = piv;
+        if (piv != k) { /* symmetric swap of rows/cols k and piv in the lower triangle */
+            for (int j = 0; j < k; ++j) { double t = A[k * n + j]; A[k * n + j] = A[piv * n + j]; A[piv * n + j] = t; }
+            for (int i = piv + 1; i < n; ++i) { double t = A[i * n + k]; A[i * n + k] = A[i * n + piv]; A[i * n + piv] = t; }
+            { double t = A[k * n + k]; A[k * n + k] = A[piv * n + piv]; A[piv * n + piv] = t; }
+            for (int i = k + 1; i < piv; ++i) { double t = A[i * n + k]; A[i * n + k] = A[piv * n + i]; A[piv * n + i] = t; }
+        }
+        /* A[k][k] -= sum_j L[k][j]^2 D[j];  column k below the diagonal likewise, then / D[k] */
+        for (int j = 0; j < k; ++j) tmp[j] = A[k * n + j] * A[j * n + j];
+        double d = A[k * n + k];
+        for (int j = 0; j < k; ++j) d -= A[k * n + j] * tmp[j];
+        A[k * n + k] = d;
+        for (int i = k + 1; i < n; ++i) {
+            double s = A[i * n + k];
+            for (int j = 0; j < k; ++j) s -= A[i * n + j] * tmp[j];
+            A[i * n + k] = (fabs(d) > DBL_MIN) ? s / d : s;
+        }
+    }
+    for (int i = 0; i < n; ++i) x[i] = b[i];
+    for (int k = 0; k < n; ++k) if (perm[k] != k) { double t = x[k]; x[k] = x[perm[k]]; x[perm[k]] = t; }
+    for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) x[i] -= A[i * n + j] * x[j];
+    for (int i = 0; i < n; ++i) x[i] = (fabs(A[i * n + i]) > DBL_MIN) ? x[i] / A[i * n + i] : 0.0;
+    for (int i = n - 1; i >= 0; --i) for (int j = i + 1; j < n; ++j) x[i] -= A[j * n + i] * x[j];
+    for (int k = n - 1; k >= 0; --k) if (perm[k] != k) { double t = x[k]; x[k] = x[perm[k]]; x[perm[k]] = t; }
+}
+
+/* pinocchio::integrate (App. A.5) */
+void iko_integrate(const iko_model *m, const double *q, const double *v, double *out) {
+    for (int j = 1; j < m->njoints; ++j) {
+        const int iq = m->idx_q[j], iv = m->idx_v[j];
+        if (m->jtype[j] == IKO_JOINT_FREEFLYER) {
+            double M0[12], E[12], M1[12], rq[4];
+            quat_to_R(q + iq + 3, M0);
+            for (int i = 0; i < 3; ++i) P_(M0, i) = q[iq + i];
+            iko_exp6(v + iv, E);
+            se3_mul(M0, E, M1);
+            for (int i = 0; i < 3; ++i) out[iq + i] = P_(M1, i);
+            R_to_quat(M1, rq);
+            double dot = 0.0;
+            for (int i = 0; i < 4; ++i) dot += rq[i] * q[iq + 3 + i];
+            if (dot < 0.0) for (int i = 0; i < 4; ++i) rq[i] = -rq[i];
+            double n2 = 0.0;
+            for (int i = 0; i < 4; ++i) n2 += rq[i] * rq[i];
+            const double al = (3.0 - n2) / 2.0;
+            for (int i = 0; i < 4; ++i) out[iq + 3 + i] = rq[i] * al;
+        } else {
+            out[iq] = q[iq] + v[iv];
+        }
+    }
+}
+
+static int dls_ws(const iko_model *m, const iko_task *tasks, int ntasks, const double *targets,
+                  const double *q0, const iko_params *p, double *q_out, int *success, int *iters,
+                  double *trace, workspace *w) {
+    const int nq = m->nq, nv = m->nv, M = w->M;
+    memcpy(w->q, q0, sizeof(double) * nq);                     /* dls.cpp:8 */
+    for (int it = 0; it < p->max_iterations; ++it) {           /* dls.cpp:14 */
+        double e0sq;
+        evaluate_ws(m, tasks, ntasks, targets, w->q, w, &e0sq); /* dls.cpp:16-24 */
+        for (int i = 0; i < M; ++i)                             /* dls.cpp:39 */
+            for (int j = 0; j < M; ++j) {
+                double s = 0.0;
+                for (int c = 0; c < nv; ++c) s += w->Jt[i * nv + c] * w->Jt[j * nv + c];
+                w->JJ[i * M + j] = s;
+            }
+        for (int i = 0; i < M; ++i) w->JJ[i * M + i] += p->damping * p->damping; /* dls.cpp:41 */
+        ldlt_solve(w->JJ, M, w->et, w->y, w->perm, w->tmp);    /* dls.cpp:53 */
+        for (int c = 0; c < nv; ++c) {                          /* dls.cpp:52-53, N = I */
+            double s = 0.0;
+            for (int i = 0; i < M; ++i) s += w->Jt[i * nv + c] * w->y[i];
+            w->dq[c] = -s;
+        }
+        if (trace) {
+            double *t = trace + (size_t)it * (nq + M + nv);
+            memcpy(t, w->q, sizeof(double) * nq);
+            memcpy(t + nq, w->et, sizeof(double) * M);
+            memcpy(t + nq + M, w->dq, sizeof(double) * nv);
+        }
+        if (p->stop_sq_tol >= 0.0 && e0sq < p->stop_sq_tol) {  /* visitor.hpp:19; dls.cpp:61-64 */
+            memcpy(q_out, w->q, sizeof(double) * nq);
+            *success = 1;
+            *iters = it;
+            return 0;
+        }
+        for (int c = 0; c < nv; ++c) w->tmp[c] = p->step_length * w->dq[c];
+        iko_integrate(m, w->q, w->tmp, w->qn);                  /* dls.cpp:67-68 */
+        for (int i = 0; i < nq; ++i) {                          /* common.hpp:53-56 */
+            const double lo_clamped = w->qn[i] > m->lower[i] ? w->qn[i] : m->lower[i]; /* cwiseMax */
+            w->q[i] = m->upper[i] < lo_clamped ? m->upper[i] : lo_clamped;             /* cwiseMin */
+        }
+    }
+    memcpy(q_out, w->q, sizeof(double) * nq);                   /* dls.cpp:76-77 */
+    *success = 0;
+    *iters = p->max_iterations;
+    return 0;
+}
+
+int iko_dls(const iko_model *m, const iko_task *tasks, int ntasks, const double *targets,
+            const double *q0, const iko_params *p, double *q_out, int *success, int *iters,
+            double *trace) {
+    workspace *w = ws_new(m, iko_task_rows(tasks, ntasks));
+    int rc = dls_ws(m, tasks, ntasks, targets, q0, p, q_out, success, iters, trace, w);
+    ws_free(w);
+    return rc;
+}
+
+typedef struct {
+    const iko_model *m; const iko_task *tasks; int ntasks; long b0, b1;
+    const double *targets, *q0; const iko_params *p; double *q_out; unsigned char *success; int *iters;
+} batch_job;
+
+static void *batch_worker(void *arg) {
+    batch_job *j = (batch_job *)arg;
+    workspace *w = ws_new(j->m, iko_task_rows(j->tasks, j->ntasks));
+    const int nq = j->m->nq;
+    for (long b = j->b0; b < j->b1; ++b) {
+        int ok = 0, it = 0;
+        dls_ws(j->m, j->tasks, j->ntasks, j->targets + (size_t)b * j->ntasks * 12, j->q0 + (size_t)b * nq,
+               j->p, j->q_out + (size_t)b * nq, &ok, &it, NULL, w);
+        if (j->success) j->success[b] = (unsigned char)ok;
+        if (j->iters) j->iters[b] = it;
+    }
+    ws_free(w);
+    return NULL;
+}
+
+int iko_dls_batch(const iko_model *m, const iko_task *tasks, int ntasks, long B, const double *targets,
+                  const double *q0, const iko_params *p, double *q_out, unsigned char *success,
+                  int *iters, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    pthread_t th[256];
+    batch_job jobs[256];
+    for (int t = 0; t < nthreads; ++t) {
+        batch_job j = {m, tasks, ntasks, B * t / nthreads, B * (t + 1) / nthreads, targets, q0, p, q_out, success, iters};
+        jobs[t] = j;
+    }
+    if (nthreads == 1) { batch_worker(&jobs[0]); return 0; }
+    for (int t = 0; t < nthreads; ++t) pthread_create(&th[t], NULL, batch_worker, &jobs[t]);
+    for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+    return 0;
+}
+
+void iko_fk_batch(const iko_model *m, long B, const double *q, const int *frames, int nsel, double *out) {
+    double *oMi = (double *)malloc(sizeof(double) * 12 * m->njoints);
+    double *oMf = (double *)malloc(sizeof(double) * 12 * m->nframes);
+    for (long b = 0; b < B; ++b) {
+        iko_fk(m, q + (size_t)b * m->nq, oMi, oMf);
+        for (int s = 0; s < nsel; ++s)
+            memcpy(out + ((size_t)b * nsel + s) * 12, oMf + 12 * frames[s], 12 * sizeof(double));
+    }
+    free(oMi); free(oMf);
+}

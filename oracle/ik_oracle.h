@@ -1,0 +1,89 @@
+/*
+ * ik_oracle.h -- CPU restatement of the reference IK hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * PARITY UNPINNED.  The reference (dazzmo/ik) cannot be built in this environment: its
+ * arithmetic lives in Pinocchio and Eigen, which are un-vendored, un-pinned
+ * (ik/ik/CMakeLists.txt:1-3 `find_package(... REQUIRED)`, no version, no lock file) and absent
+ * here, and its own tests pin no numbers (all TEST bodies in ik/test/{ik,dls,task}.cpp are
+ * commented out).  This oracle is therefore a faithful restatement of the reference loop with
+ * Pinocchio/Eigen semantics restated from their published algorithms,
+ * cross-checked against an independently written numpy twin (oracle/twin.py), analytic
+ * known-answer tests and the committed golden vectors (tests/golden/).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * Nothing under ik_amd/ or include/ links, imports or calls it.
+ */
+#ifndef IK_ORACLE_H
+#define IK_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { IKO_JOINT_UNIVERSE = 0, IKO_JOINT_REVOLUTE = 1, IKO_JOINT_PRISMATIC = 2, IKO_JOINT_FREEFLYER = 3 };
+/* ik::KinematicType, ik/ik/frame.hpp:20 */
+enum { IKO_POSITION = 0, IKO_ORIENTATION = 1, IKO_FULL = 2 };
+
+/* Flat kinematic model with Pinocchio's conventions (joint 0 = universe). SE(3) values are 12
+ * doubles: rotation row-major (9) then translation (3). */
+typedef struct {
+    int njoints, nq, nv, nframes;
+    const int *jtype, *parent, *idx_q, *idx_v; /* [njoints] */
+    const double *placement;                   /* [njoints][12] parent-joint frame -> joint frame */
+    const double *axis;                        /* [njoints][3]  */
+    const double *lower, *upper;               /* [nq] */
+    const int *frame_parent;                   /* [nframes] parent joint */
+    const double *frame_placement;             /* [nframes][12] */
+} iko_model;
+
+/* ik::FrameTask (ik/ik/frame.hpp:78-200): frame ids, kinematic type, priority level and the
+ * Task::weighting() vector (ik/ik/task.hpp:40). */
+typedef struct {
+    int frame, reference, type, priority;
+    double weight[6];
+} iko_task;
+
+/* ik::dls_parameters (ik/ik/dls.hpp:24-28) + the stop rule of ik/ik/visitor.hpp:19 as a number:
+ * stop when ||e[0]||^2 < stop_sq_tol; negative == a visitor whose should_stop() is always false. */
+typedef struct {
+    int max_iterations;
+    double damping, step_length, stop_sq_tol;
+} iko_params;
+
+int iko_task_rows(const iko_task *tasks, int ntasks);
+
+/* framesForwardKinematics: oMi[njoints][12], oMf[nframes][12] (either may be NULL). */
+void iko_fk(const iko_model *m, const double *q, double *oMi, double *oMf);
+
+/* evaluate_problem_data (ik/ik/data.cpp:25-58) + the stacking of ik/ik/dls.cpp:18-24:
+ * et[M], Jt[M][nv] row-major, rows ordered by priority then insertion. targets: [ntasks][12]. */
+void iko_evaluate(const iko_model *m, const iko_task *tasks, int ntasks, const double *targets,
+                  const double *q, double *et, double *Jt);
+
+/* ik::dls (ik/ik/dls.cpp:5-78) for one problem. Returns 0 on success (of the call, not of the
+ * solve). iters = index of the iteration at which should_stop fired, or max_iterations.
+ * trace (optional): per iteration [q(nq) | et(M) | dq(nv)] appended, for stage parity tests. */
+int iko_dls(const iko_model *m, const iko_task *tasks, int ntasks, const double *targets,
+            const double *q0, const iko_params *p, double *q_out, int *success, int *iters,
+            double *trace);
+
+/* Batch of independent problems, array-of-structures: q0[B][nq], targets[B][ntasks][12],
+ * q_out[B][nq]; nthreads worker threads split the batch in contiguous blocks. */
+int iko_dls_batch(const iko_model *m, const iko_task *tasks, int ntasks, long B,
+                  const double *targets, const double *q0, const iko_params *p, double *q_out,
+                  unsigned char *success, int *iters, int nthreads);
+
+/* Batch FK of selected frames: q[B][nq] -> out[B][nsel][12]. */
+void iko_fk_batch(const iko_model *m, long B, const double *q, const int *frames, int nsel,
+                  double *out);
+
+/* Lie-group maps exposed for analytic tests. M is 12 doubles (R row-major, p). */
+void iko_log6(const double *M, double *out6);
+void iko_Jlog6(const double *M, double *out36);
+void iko_exp6(const double *nu6, double *M);
+void iko_integrate(const iko_model *m, const double *q, const double *v, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
