@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py -- IK solves/s of the batched DLS path on MI355X (BASELINE.json's metric).
+
+A "step" is one pass of the hot path over one batch already resident in HBM: B independent
+50-iteration DLS solves (Cassie single-leg chain, cassie_fixed.urdf, LeftFootFront SE(3) task,
+lambda = 1e-2, step = 1.0, never-stop visitor) -- reference ik::dls, ik/ik/dls.cpp:5-78 -- plus,
+for N > 1, the RCCL all-gather of the solved configurations.  Weak scaling: B per GPU is fixed.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--iters I] [--no-cpu]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (see the key list in main()).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import ik_amd  # noqa: E402
+from ik_amd import distributed as ikdist  # noqa: E402
+from ik_amd import workload  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+FP64_VALU_PEAK_TF = 78.6    # 256 CU x 4 SIMD x 16 FP64 lanes x 2 (FMA) x 2.4 GHz
+BYTES_PER_SOLVE = {"cassie_leg": 8 * 16 + 96 * 1 + 8 * 16 + 1 + 4}  # 357 B
+
+
+def load_kernel_stats():
+    path = os.path.join(ROOT, "ik_amd", "kernel_stats.json")
+    if os.path.exists(path):
+        with open(path) as fh:
+            return json.load(fh)
+    return {}
+
+
+def cpu_baseline(model, q0_np, tg_np, iters, budget_s=12.0):
+    """The CPU oracle (oracle/ik_oracle.c, a port -- the reference itself cannot be built) timed on
+    this host's cores on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    om = O.OracleModel(model.flat())
+    fid = model.getFrameId("LeftFootFront")
+    tasks = O.make_tasks([(fid, 0, 2, 0, None)])
+    prm = O.params(iters, 1e-2, 1.0, -1.0)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    probe = min(256, q0_np.shape[0])
+    t = time.perf_counter()
+    O.dls_batch(om, tasks, tg_np[:probe], q0_np[:probe], prm, 1)
+    r1 = probe / (time.perf_counter() - t)
+    sample = int(min(q0_np.shape[0], max(probe, r1 * cores * budget_s)))
+    t = time.perf_counter()
+    q_ref, ok_ref, it_ref = O.dls_batch(om, tasks, tg_np[:sample], q0_np[:sample], prm, cores)
+    dt = time.perf_counter() - t
+    # which of the sampled problems converged on the CPU (SURVEY.md 8d parity bar): FK(q) reaches the target
+    reached = O.fk_batch(om, q_ref, [fid])
+    conv = np.abs(reached - tg_np[:sample]).reshape(sample, -1).max(axis=1) < 1e-8
+    return dict(value=sample / dt, unit="solves/s", cores=cores, kind="port",
+                sample="first %d problems of the batch, %d threads, %.1f s; 1-thread probe %.0f solves/s"
+                       % (sample, cores, dt, r1)), q_ref, sample, conv
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=65536, help="problems per GPU")
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs a torch.distributed.run launch (WORLD_SIZE=%d)" % (args.gpus, world))
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    B = args.batch
+    model = ik_amd.Model.from_urdf_file(os.path.join(workload.MODELS_DIR, "cassie_fixed.kin.urdf"))
+    problem = ik_amd.InverseKinematicsProblem(model)
+    problem.add_frame_task("lf", ik_amd.FrameTask.create(model, "LeftFootFront", ik_amd.KinematicType.Full))
+    data = ik_amd.dls_data(problem, device=local_rank)
+
+    # this rank's shard of the global synthetic batch (weak scaling: B problems per GPU)
+    lo, hi = ikdist.shard_range(B * world, rank, world)
+    idx = np.arange(lo, hi)
+    q0_np, qs_np = workload.chain_workload(model.lowerPositionLimit, model.upperPositionLimit,
+                                           workload.cassie_nominal(model.names), idx, seed=0, mode="uniform")
+    Q0 = torch.from_numpy(np.ascontiguousarray(q0_np.T)).to(dev)
+    QS = torch.from_numpy(np.ascontiguousarray(qs_np.T)).to(dev)
+    targets = ik_amd.task_frames_fk_batch(problem, QS, data)  # FK(q*) on the device: reachable targets
+    out = (torch.empty_like(Q0), torch.empty(B, dtype=torch.uint8, device=dev), torch.empty(B, dtype=torch.int32, device=dev))
+    bufs = ikdist.GatherBuffers(model.nq, B, world, dev) if distributed else None
+    visitor = ik_amd.never_stop_visitor()
+    prm = ik_amd.dls_parameters(max_iterations=args.iters, damping=1e-2, step_length=1.0)
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record()
+        ik_amd.dls_batch(problem, Q0, targets, data, visitor, prm, out=out)
+        if ev is not None:
+            ev[1].record()
+        if distributed:
+            ikdist.all_gather_solutions(out[0], out[1], out[2], bufs)
+
+    for _ in range(args.warmup):
+        step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+
+    if rank == 0:
+        total = B * world * args.steps
+        value = total / elapsed
+        bytes_solve = BYTES_PER_SOLVE["cassie_leg"]
+        achieved = bytes_solve * B / (kernel_ms * 1e-3) / 1e9
+        stats = load_kernel_stats().get("dls_chain<NJ=7,full>", {})
+        res = {
+            "metric": "IK solves/sec (50-iter DLS) at batch=65536",
+            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "Cassie single-leg chain (cassie_fixed.urdf, 7 support joints of nq=16), one SE(3) "
+                                   "LeftFootFront task, %d fixed DLS iterations, damping 1e-2, step 1.0, targets FK(q*) "
+                                   "with q* uniform in the joint limits" % args.iters,
+                       "batch_per_gpu": B, "global_batch": B * world, "iterations": args.iters,
+                       "kernel": data.kernel, "parallelism": "batch-sharded x%d + all-gather" % world if distributed else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": stats.get("hbm_traffic_bytes_per_launch"),
+                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_solve": bytes_solve,
+                         "note": "fused on-chip loop: the binding roof is FP64 VALU, see valu_roofline"},
+        }
+        if stats.get("flop_per_iteration"):
+            flops = stats["flop_per_iteration"] * args.iters
+            tf = flops * B / (kernel_ms * 1e-3) / 1e12
+            res["valu_roofline"] = {"bound": "fp64_valu", "achieved": tf, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+                                    "frac": tf / FP64_VALU_PEAK_TF, "flop_per_solve": flops,
+                                    "counting": "FP64 VALU instructions in the kernel's loop body (FMA = 2), static ISA count"}
+        if not args.no_cpu:
+            tg_np = targets.permute(2, 0, 1).contiguous().cpu().numpy()
+            cpu, q_ref, sample, conv = cpu_baseline(model, q0_np, tg_np, args.iters)
+            res["cpu_baseline"] = cpu
+            d = np.abs(out[0].cpu().numpy().T[:sample] - q_ref).max(axis=1)
+            res["parity_vs_cpu"] = {"problems": sample, "converged_on_cpu": int(conv.sum()),
+                                    "max_abs_dq_rad_converged": float(d[conv].max()) if conv.any() else None,
+                                    "max_abs_dq_rad_not_converged": float(d[~conv].max()) if (~conv).any() else None,
+                                    "bar_rad": 1e-6}
+        print(json.dumps(res))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

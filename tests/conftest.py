@@ -1,0 +1,31 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+MODELS = os.path.join(ROOT, "fixtures", "models")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def native_built():
+    """libikgpu.so and the oracle must exist; build them when this checkout has not been built yet."""
+    lib = os.path.join(ROOT, "ik_amd", "libikgpu.so")
+    if not os.path.exists(lib):
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "__graft_entry__.py")])
+    import oracle as O
+    O.lib()
+    return lib
+
+
+def urdf_path(name):
+    return os.path.join(MODELS, name + ".kin.urdf")

@@ -1,0 +1,191 @@
+"""CPU-side checks of the product's host logic: the C-ABI library loads and exports every symbol
+include/ikgpu.h declares, the URDF loader reproduces the golden model tables (Pinocchio's
+conventions), problem analysis picks / rejects kernels, errors are reported as the
+header promises.  No compute call is made (there is no GPU here and the product has no CPU path)."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import MODELS, ROOT, urdf_path
+
+import twin as T
+
+
+@pytest.fixture(scope="module")
+def ik(native_built):
+    import ik_amd
+    return ik_amd
+
+
+def test_library_exports_every_declared_symbol(native_built):
+    from ik_amd import capi
+    header = open(os.path.join(ROOT, "include", "ikgpu.h")).read()
+    declared = sorted(set(re.findall(r"\b(ikgpu_[a-z_0-9]+)\s*\(", header)))
+    assert declared, "no prototypes found"
+    lib = C.CDLL(native_built)
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, missing
+    assert sorted(capi.SYMBOLS) == declared
+    lib.ikgpu_abi_version.restype = C.c_int
+    assert lib.ikgpu_abi_version() == 1
+
+
+def test_default_parameters_are_the_reference_defaults(ik):
+    from ik_amd import capi
+    p = capi.DlsParams()
+    capi.lib().ikgpu_dls_params_default(C.byref(p))
+    # reference ik/ik/common.hpp:61,65; ik/ik/dls.hpp:25; ik/ik/visitor.hpp:19
+    assert (p.max_iterations, p.damping, p.step_length, p.stop_sq_tol) == (100, 1e-2, 1.0, 1e-4)
+    d = ik.dls_parameters()
+    assert (d.max_iterations, d.damping, d.step_length) == (100, 1e-2, 1.0)
+    assert ik.inverse_kinematics_visitor().tolerance == 1e-4
+
+
+@pytest.mark.parametrize("case", ["S_cassie_leg", "U_ur5", "F_cassie_full"])
+def test_urdf_loader_matches_golden_model_tables(ik, case):
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", case + ".json")))
+    m = ik.Model.from_urdf_file(os.path.join(MODELS, g["urdf"]), free_flyer=g["free_flyer"])
+    gm = g["model"]
+    assert (m.njoints, m.nq, m.nv, m.nframes) == (gm["njoints"], gm["nq"], gm["nv"], gm["nframes"])
+    assert m.names == gm["joint_names"] and m.frame_names == gm["frame_names"]
+    f = m.flat()
+    assert f["idx_q"].tolist() == gm["idx_q"] and f["idx_v"].tolist() == gm["idx_v"] and f["parent"].tolist() == gm["parent"]
+    assert np.array_equal(f["lower"], np.array(gm["lower"])) and np.array_equal(f["upper"], np.array(gm["upper"]))
+    assert np.array_equal(f["placement"], np.array(gm["joint_placement"]))          # bit-exact
+    assert np.array_equal(f["frame_placement"], np.array(gm["frame_placement"]))
+    assert f["frame_parent"].tolist() == gm["frame_parent"]
+    assert m.getFrameId("universe") == 0 and m.getFrameId("no_such_frame") == m.nframes  # as Model::getFrameId
+
+
+def test_loader_on_the_reference_urdfs_when_present(ik):
+    """The stripped fixtures and the reference's full URDFs (visual / inertial / transmission elements,
+    comments, nested <joint> inside <transmission>) give the identical model."""
+    ref = "/root/reference"
+    pairs = [("cassie-description/urdf/cassie.urdf", "cassie", True), ("cassie-description/urdf/cassie_fixed.urdf", "cassie_fixed", False),
+             ("ik/test/ur5.urdf", "ur5", False)]
+    if not os.path.isdir(ref):
+        pytest.skip("reference tree not present (GPU box)")
+    for rel, name, ff in pairs:
+        a = ik.Model.from_urdf_file(os.path.join(ref, rel), ff).flat()
+        b = ik.Model.from_urdf_file(urdf_path(name), ff).flat()
+        for k in a:
+            assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), (name, k)
+
+
+def test_model_roundtrip_through_flat_arrays(ik):
+    from ik_amd import capi
+    m = ik.Model.from_urdf_file(urdf_path("cassie"), free_flyer=True)
+    h = C.c_void_p()
+    capi.check(capi.lib().ikgpu_model_create(C.byref(m._flat), C.byref(h)))
+    m2 = ik.Model(h)
+    a, b = m.flat(), m2.flat()
+    for k in a:
+        assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+
+
+BAD = {
+    "not xml": (b"this is not xml", "XML parse error"),
+    "wrong root": (b"<model/>", "must be <robot>"),
+    "mismatched tag": (b"<robot><link name='a'></robot>", "mismatched end tag"),
+    "no links": (b"<robot name='r'/>", "no links"),
+    "continuous joint": (b"<robot><link name='a'/><link name='b'/><joint name='j' type='continuous'><parent link='a'/>"
+                         b"<child link='b'/><axis xyz='0 0 1'/></joint></robot>", "unsupported URDF joint type"),
+    "unknown link": (b"<robot><link name='a'/><joint name='j' type='fixed'><parent link='a'/><child link='zz'/></joint></robot>",
+                     "unknown link"),
+    "two roots": (b"<robot><link name='a'/><link name='b'/></robot>", "more than one root"),
+    "bad number": (b"<robot><link name='a'/><link name='b'/><joint name='j' type='revolute'><origin xyz='0 x 0'/>"
+                   b"<parent link='a'/><child link='b'/></joint></robot>", "cannot parse number"),
+}
+
+
+@pytest.mark.parametrize("label", sorted(BAD))
+def test_malformed_urdf_is_an_error_not_a_crash(ik, label):
+    from ik_amd import capi
+    xml, needle = BAD[label]
+    with pytest.raises(capi.IkgpuError) as ei:
+        ik.Model.from_urdf_xml(xml)
+    assert ei.value.code == capi.ERR_PARSE and needle in ei.value.message
+
+
+def test_xml_features_attributes_comments_entities(ik):
+    xml = b"""<?xml version="1.0"?><!DOCTYPE robot><!-- c --><robot name='r'>
+      <link name="a"><visual><geometry><mesh filename="x &amp; y.stl"/></geometry></visual></link><link name='b'/>
+      <!-- <joint name="ghost" type="revolute"/> -->
+      <transmission name="t"><joint name="j"><hardwareInterface>P</hardwareInterface></joint></transmission>
+      <joint name="j" type="revolute"><origin xyz="+1 2e-1 -.5" rpy="0 0 0"/><parent link="a"/><child link="b"/>
+        <axis xyz="0 1 0"/><limit lower="-1" upper="2" effort="1"/></joint></robot>"""
+    m = ik.Model.from_urdf_xml(xml)
+    assert m.names == ["universe", "j"] and m.nq == 1
+    f = m.flat()
+    assert f["placement"][1, 9:].tolist() == [1.0, 0.2, -0.5] and f["axis"][1].tolist() == [0, 1, 0]
+    assert (f["lower"][0], f["upper"][0]) == (-1.0, 2.0)
+
+
+def _problem(ik, name, frames, ff=False, types=None, reference="universe", max_prio=0, prios=None):
+    m = ik.Model.from_urdf_file(urdf_path(name), free_flyer=ff)
+    p = ik.InverseKinematicsProblem(m, max_prio)
+    for i, f in enumerate(frames):
+        t = ik.FrameTask.create(m, f, types[i] if types else ik.KinematicType.Full, reference)
+        p.add_frame_task("t%d" % i, t, prios[i] if prios else 0)
+    return m, p
+
+
+def test_plan_names_the_kernel_for_the_benchmark_shapes(ik):
+    assert ik.plan(_problem(ik, "cassie_fixed", ["LeftFootFront"])[1]) == "dls_chain<NJ=7,full>"
+    assert ik.plan(_problem(ik, "ur5", ["tool0"])[1]) == "dls_chain<NJ=6,full>"
+    assert ik.plan(_problem(ik, "cassie_fixed", ["RightFootFront"], types=[ik.KinematicType.Position])[1]) == "dls_chain<NJ=7,position>"
+    assert ik.plan(_problem(ik, "ur5", ["wrist_1_link"], types=[ik.KinematicType.Orientation])[1]) == "dls_chain<NJ=4,orientation>"
+
+
+def test_problem_api_mirrors_the_reference_container(ik):
+    m, p = _problem(ik, "cassie_fixed", ["LeftFootFront", "RightFootFront"], max_prio=1, prios=[1, 0],
+                    types=[ik.KinematicType.Full, ik.KinematicType.Position])
+    assert p.max_priority_level() == 1 and p.e_size(0) == 3 and p.e_size(1) == 6 and p.c_size() == 0
+    assert [t.frame for t, _ in p.ordered_tasks()] == ["RightFootFront", "LeftFootFront"]  # priority order (dls.cpp:20-24)
+    assert p.get_frame_task("t0").frame == "LeftFootFront" and p.model() is m
+    t = p.get_frame_task("t1")
+    assert t.dimension() == 3 and t.weighting().tolist() == [1, 1, 1] and np.array_equal(t.target.to12(), ik.SE3().to12())
+    with pytest.raises(ValueError):
+        ik.FrameTask.create(m, "nope")
+    with pytest.raises(ValueError):
+        p.add_frame_task("x", t, priority=2)
+
+
+def test_unsupported_shapes_say_so(ik):
+    from ik_amd import capi
+    m, p = _problem(ik, "ur5", ["tool0"], reference="wrist_1_link")
+    with pytest.raises(capi.IkgpuError) as ei:
+        ik.plan(p)
+    assert ei.value.code == capi.ERR_UNSUPPORTED and "reference frame" in ei.value.message
+    m, p = _problem(ik, "cassie_fixed", ["pelvis"])
+    with pytest.raises(capi.IkgpuError) as ei:
+        ik.plan(p)
+    assert "fixed in the world" in ei.value.message
+
+
+def test_no_gpu_means_a_loud_error_not_a_fallback(ik):
+    import torch
+    from ik_amd import capi
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    m, p = _problem(ik, "cassie_fixed", ["LeftFootFront"])
+    with pytest.raises(capi.IkgpuError) as ei:
+        ik.dls_data(p)
+    assert ei.value.code == capi.ERR_DEVICE and "no CPU path" in ei.value.message
+
+
+def test_workload_is_counter_based_and_shardable():
+    from ik_amd import workload
+    lo, hi, nom = -np.ones(5), np.ones(5), np.zeros(5)
+    q0, qs = workload.chain_workload(lo, hi, nom, np.arange(100), seed=7)
+    q0b, qsb = workload.chain_workload(lo, hi, nom, np.arange(40, 60), seed=7)
+    assert np.array_equal(q0[40:60], q0b) and np.array_equal(qs[40:60], qsb)      # any shard, same numbers
+    q0c, _ = workload.chain_workload(lo, hi, nom, np.arange(100), seed=8)
+    assert not np.array_equal(q0, q0c)
+    assert (np.abs(q0) <= 0.1).all() and (qs >= lo).all() and (qs <= hi).all()
+    u = workload.uniform01(0, np.arange(200000), np.arange(2))
+    assert abs(u.mean() - 0.5) < 2e-3 and abs(u.var() - 1 / 12) < 2e-3 and u.min() >= 0 and u.max() < 1

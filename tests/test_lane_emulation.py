@@ -1,0 +1,122 @@
+"""The exact per-lane program of the gfx950 chain kernels (ik_amd/csrc/device/*.hpp), compiled for the
+host by this test and run lane after lane, against the C oracle.  This is how the lane program and the
+host-side problem analysis are checked in the GPU-less build container; the -m gpu tests then check
+the same program on the device through the C ABI."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, urdf_path
+
+import oracle as O
+
+
+@pytest.fixture(scope="module")
+def emu(native_built):
+    src = os.path.join(ROOT, "tests", "lane_emu", "lane_emu.cpp")
+    out = os.path.join(ROOT, "tests", "lane_emu", "liblane_emu.so")
+    deps = [src] + [os.path.join(ROOT, "ik_amd", "csrc", f) for f in
+                    ("model.cpp", "problem.cpp", "model.hpp", "problem.hpp", "device/lane_math.hpp",
+                     "device/chain_solver.hpp", "device/chain_kernel_body.hpp")]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
+                               "-I" + os.path.join(ROOT, "ik_amd", "csrc"), "-o", out, src,
+                               os.path.join(ROOT, "ik_amd", "csrc", "model.cpp"), os.path.join(ROOT, "ik_amd", "csrc", "problem.cpp")])
+    L = C.CDLL(out)
+    L.lane_emu_last_error.restype = C.c_char_p
+    return L
+
+
+def run(L, urdf, task, mode, q0, tg, prm, nv, M, layout=1):
+    B, nq = (q0.shape[0], q0.shape[1]) if layout == 1 else (q0.shape[1], q0.shape[0])
+    qo = np.empty_like(q0)
+    ok, it = np.zeros(B, np.uint8), np.zeros(B, np.int32)
+    e, J, oMf = np.empty((B, M)), np.empty((B, M, nv)), np.empty((B, 1, 12))
+    p = lambda a: C.c_void_p(a.ctypes.data)
+    rc = L.lane_emu_run(urdf, C.c_size_t(len(urdf)), 0, C.byref(task), mode, C.c_int64(B), p(q0), p(tg),
+                        C.byref(prm) if prm is not None else None, p(qo), p(ok), p(it), p(e), p(J), p(oMf), layout)
+    assert rc == 0, L.lane_emu_last_error()
+    return qo, ok, it, e, J, oMf
+
+
+def setup(name, frame, ktype=2, weights=None, B=256, mode="near", narrow=None):
+    import ik_amd
+    from ik_amd import capi, workload
+    urdf = open(urdf_path(name), "rb").read()
+    model = ik_amd.Model.from_urdf_xml(urdf)
+    om = O.OracleModel(model.flat())
+    fid = model.getFrameId(frame)
+    nominal = workload.UR5_NOMINAL if name == "ur5" else workload.cassie_nominal(model.names)
+    q0, qs = workload.chain_workload(model.lowerPositionLimit, model.upperPositionLimit, nominal, np.arange(B), 0, mode, narrow)
+    tg = O.fk_batch(om, qs, [fid])
+    w = list(weights) + [1.0] * (6 - len(weights)) if weights is not None else [1.0] * 6
+    task = capi.Task(fid, 0, ktype, 0, (C.c_double * 6)(*w))
+    ot = O.make_tasks([(fid, 0, ktype, 0, weights)])
+    return urdf, model, om, task, ot, q0, qs, tg
+
+
+@pytest.mark.parametrize("name,frame", [("cassie_fixed", "LeftFootFront"), ("ur5", "tool0"), ("cassie_fixed", "RightFootBack")])
+def test_lane_program_stagewise(emu, name, frame):
+    from ik_amd import capi
+    urdf, model, om, task, ot, q0, qs, tg = setup(name, frame, B=200, mode="uniform", narrow=2.0 if name == "ur5" else None)
+    *_, oMf = run(emu, urdf, task, 2, qs, tg, None, model.nv, 6)
+    assert np.abs(oMf - tg).max() < 1e-14
+    _, _, _, e, J, _ = run(emu, urdf, task, 1, q0, tg, None, model.nv, 6)
+    for b in range(q0.shape[0]):
+        eo, Jo = O.evaluate(om, ot, tg[b], q0[b])
+        assert np.abs(e[b] - eo).max() < 1e-11 and np.abs(J[b] - Jo).max() < 1e-11
+
+
+@pytest.mark.parametrize("name,frame", [("cassie_fixed", "LeftFootFront"), ("ur5", "tool0")])
+@pytest.mark.parametrize("iters,tol", [(50, -1.0), (100, 1e-4), (1, -1.0), (0, 1e-4)])
+def test_lane_program_full_loop(emu, name, frame, iters, tol):
+    from ik_amd import capi
+    urdf, model, om, task, ot, q0, qs, tg = setup(name, frame, B=256, mode="near")
+    q0[:, -1] += 9.0  # an entry outside the support (Cassie) / inside it (UR5), beyond its limit
+    prm = capi.DlsParams(iters, 1e-2, 1.0, tol)
+    qo, ok, it, *_ = run(emu, urdf, task, 0, q0, tg, prm, model.nv, 6)
+    q_ref, ok_ref, it_ref = O.dls_batch(om, ot, tg, q0, O.params(iters, 1e-2, 1.0, tol))
+    assert np.array_equal(ok, ok_ref) and np.array_equal(it, it_ref)
+    assert np.abs(qo - q_ref).max() < 1e-9
+    # SoA gives the same bits
+    qo2, ok2, it2, *_ = run(emu, urdf, task, 0, np.ascontiguousarray(q0.T), np.ascontiguousarray(tg.transpose(1, 2, 0)),
+                            prm, model.nv, 6, layout=0)
+    assert np.array_equal(qo2.T, qo) and np.array_equal(ok2, ok) and np.array_equal(it2, it)
+
+
+@pytest.mark.parametrize("ktype,weights", [(0, None), (1, None), (2, [1.0, 2.0, 0.5, 1.5, 1.0, 3.0]), (1, [2.0, 1.0, 0.25])])
+def test_lane_program_types_and_weights(emu, ktype, weights):
+    from ik_amd import capi
+    urdf, model, om, task, ot, q0, qs, tg = setup("cassie_fixed", "LeftFootFront", ktype, weights, B=128)
+    M = 6 if ktype == 2 else 3
+    _, _, _, e, J, _ = run(emu, urdf, task, 1, q0, tg, None, model.nv, M)
+    eo, Jo = O.evaluate(om, ot, tg[5], q0[5])
+    assert np.abs(e[5] - eo).max() < 1e-12 and np.abs(J[5] - Jo).max() < 1e-12
+    for iters in (1, 25):
+        prm = capi.DlsParams(iters, 1e-2, 1.0, -1.0)
+        qo, *_ = run(emu, urdf, task, 0, q0, tg, prm, model.nv, M)
+        q_ref, _, _ = O.dls_batch(om, ot, tg, q0, O.params(iters, 1e-2, 1.0, -1.0))
+        assert np.abs(qo - q_ref).max() < 1e-8
+
+
+def test_lane_program_general_axis_and_far_targets_stepwise(emu):
+    """A joint about a non-aligned axis (folded into the placements on the host) and UR5 far targets,
+    where only step-wise parity is meaningful (the iteration is chaotic there)."""
+    from ik_amd import capi
+    import ik_amd
+    xml = open(urdf_path("ur5"), "rb").read().replace(b'<axis xyz="0 1 0"/>', b'<axis xyz="0.6 0.64 0.48"/>', 1)
+    model = ik_amd.Model.from_urdf_xml(xml)
+    om = O.OracleModel(model.flat())
+    fid = model.getFrameId("tool0")
+    rng = np.random.default_rng(0)
+    q0 = rng.uniform(-2, 2, (200, 6))
+    tg = O.fk_batch(om, rng.uniform(-2, 2, (200, 6)), [fid])
+    task = capi.Task(fid, 0, 2, 0, (C.c_double * 6)(*[1.0] * 6))
+    ot = O.make_tasks([(fid, 0, 2, 0, None)])
+    for iters, bar in ((1, 1e-9), (3, 1e-6)):
+        qo, *_ = run(emu, xml, task, 0, q0, tg, capi.DlsParams(iters, 1e-2, 1.0, -1.0), 6, 6)
+        q_ref, _, _ = O.dls_batch(om, ot, tg, q0, O.params(iters, 1e-2, 1.0, -1.0))
+        assert np.abs(qo - q_ref).max() < bar

@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Static statistics of the DLS kernels' iteration loop, from the gfx950 disassembly.
+
+Counting rule for the FP64-VALU roofline (bench.py `valu_roofline`): every FP64 VALU instruction in
+the loop body counts its arithmetic -- FMA/FMAC = 2 flop, MUL/ADD/MIN/MAX = 1, RCP/RSQ/RNDNE/LDEXP/
+conversions = 1 -- per lane; the count is of *executed* instructions (what the hardware must issue),
+not of an algorithmic minimum.  Writes ik_amd/kernel_stats.json.
+
+    python tools/kernel_stats.py
+"""
+import collections
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNELS = {  # display name -> mangled-name fragment
+    "dls_chain<NJ=7,full>": "dls_chain_kernelILi7ELi2E",
+    "dls_chain<NJ=6,full>": "dls_chain_kernelILi6ELi2E",
+}
+FLOPS = {"v_fma_f64": 2, "v_fmac_f64": 2, "v_mul_f64": 1, "v_add_f64": 1, "v_min_f64": 1, "v_max_f64": 1,
+         "v_rcp_f64": 1, "v_rsq_f64": 1, "v_rndne_f64": 1, "v_ldexp_f64": 1, "v_cvt_i32_f64": 1, "v_cvt_f64_i32": 1,
+         "v_sqrt_f64": 1, "v_fract_f64": 1, "v_trig_preop_f64": 1, "v_div_scale_f64": 1, "v_div_fmas_f64": 2,
+         "v_div_fixup_f64": 1, "v_frexp_mant_f64": 1}
+
+
+def main():
+    with tempfile.TemporaryDirectory() as td:
+        asm = os.path.join(td, "kernels.s")
+        cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
+               "-I" + os.path.join(ROOT, "ik_amd", "csrc"), "--offload-arch=gfx950", "-fno-fast-math", "-ffp-contract=on",
+               "-S", "--cuda-device-only", os.path.join(ROOT, "ik_amd", "csrc", "kernels.hip"), "-o", asm]
+        subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
+        text = open(asm).read()
+    out = {}
+    for disp, frag in KERNELS.items():
+        m = re.search(r"^(_Z\w*%s\w*):" % re.escape(frag), text, re.M)
+        if not m:
+            continue
+        name = m.group(1)
+        body = text[m.end():text.index(".Lfunc_end", m.end())].split("\n")
+        # Blocks carry "; =>This Inner Loop Header" / ";   in Loop: Header=BBn_m" comments: take the loop with
+        # the most instructions (the DLS iteration loop; the other one is the LDS staging loop).
+        loops = collections.defaultdict(collections.Counter)
+        cur = None
+        for l in body:
+            t = l.strip()
+            mlab = re.match(r"^\.?L?(BB\d+_\d+):", t)
+            if mlab or t.startswith("; %bb."):
+                if "Inner Loop Header" in t and mlab:
+                    cur = mlab.group(1)
+                else:
+                    mh = re.search(r"in Loop: Header=(BB\d+_\d+)", t)
+                    cur = mh.group(1) if mh else None
+                continue
+            if cur is None or not t or t.startswith((".", ";", "//")):
+                continue
+            loops[cur][re.sub(r"_e(32|64)$", "", t.split()[0])] += 1
+        if not loops:
+            continue
+        c = max(loops.values(), key=lambda cc: sum(cc.values()))
+        meta = text[text.index(name, text.index(".amdhsa_kernel")):]
+        def grab(key):
+            mm = re.search(r"%s\s+(\d+)" % key, meta)
+            return int(mm.group(1)) if mm else None
+        flops = sum(FLOPS.get(k, 0) * v for k, v in c.items())
+        out[disp] = {
+            "loop_instructions": sum(c.values()),
+            "fp64_valu_instructions": sum(v for k, v in c.items() if k.endswith("_f64")),
+            "fp64_fma_instructions": c["v_fma_f64"] + c["v_fmac_f64"],
+            "flop_per_iteration": flops,
+            "lds_reads": sum(v for k, v in c.items() if k.startswith("ds_read")),
+            "next_free_vgpr": grab(r"\.amdhsa_next_free_vgpr"),
+            "accum_offset": grab(r"\.amdhsa_accum_offset"),
+            "top_instructions": dict(c.most_common(12)),
+        }
+    path = os.path.join(ROOT, "ik_amd", "kernel_stats.json")
+    old = {}
+    if os.path.exists(path):
+        old = json.load(open(path))
+    for k, v in out.items():
+        if k in old and "hbm_traffic_bytes_per_launch" in old[k]:
+            v["hbm_traffic_bytes_per_launch"] = old[k]["hbm_traffic_bytes_per_launch"]
+    json.dump(out, open(path, "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    sys.exit(main())
