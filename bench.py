@@ -2,14 +2,16 @@
 """bench.py -- IK solves/s of the batched DLS path on MI355X (BASELINE.json's metric).
 
 A "step" is one pass of the hot path over one batch already resident in HBM: B independent
-50-iteration DLS solves (Cassie single-leg chain, cassie_fixed.urdf, LeftFootFront SE(3) task,
-lambda = 1e-2, step = 1.0, never-stop visitor) -- reference ik::dls, ik/ik/dls.cpp:5-78 -- plus,
-for N > 1, the RCCL all-gather of the solved configurations.  Weak scaling: B per GPU is fixed.
+fixed-iteration DLS solves (reference ik::dls, ik/ik/dls.cpp:5-78; lambda = 1e-2, step = 1.0,
+never-stop visitor) plus, for N > 1, the RCCL all-gather of the solved configurations.  Weak scaling:
+B per GPU is fixed.  Default workload = the one the metric is quoted on: Cassie single-leg chain,
+B = 65536, 50 iterations.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--iters I] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--iters I]
+                    [--workload cassie_leg|cassie_full_body|ur5] [--no-cpu]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line (see the key list in main()).
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -27,9 +29,24 @@ import ik_amd  # noqa: E402
 from ik_amd import distributed as ikdist  # noqa: E402
 from ik_amd import workload  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
-FP64_VALU_PEAK_TF = 78.6    # 256 CU x 4 SIMD x 16 FP64 lanes x 2 (FMA) x 2.4 GHz
-BYTES_PER_SOLVE = {"cassie_leg": 8 * 16 + 96 * 1 + 8 * 16 + 1 + 4}  # 357 B
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+FP64_VALU_PEAK_TF = 78.6  # 256 CU x 4 SIMD x 16 FP64 FMA lanes x 2 flop x 2.4 GHz
+
+# Algorithmic HBM bytes per solve: q0 in + targets in + q out + success + iters
+#   = 8 nq + 96 T + 8 nq + 1 + 4
+WORKLOADS = {
+    "cassie_leg": dict(urdf="cassie_fixed", free_flyer=False, frames=["LeftFootFront"], nq=16,
+                       text="Cassie single-leg chain (cassie_fixed.urdf, 7 support joints of nq=16), one SE(3) LeftFootFront task"),
+    "cassie_full_body": dict(urdf="cassie", free_flyer=True, frames=["LeftFootFront", "RightFootFront", "pelvis"], nq=23,
+                             text="Cassie full body (cassie.urdf + free-flyer, nq=23 / nv=22), SE(3) tasks on LeftFootFront, "
+                                  "RightFootFront and pelvis (M=18)"),
+    "ur5": dict(urdf="ur5", free_flyer=False, frames=["tool0"], nq=6,
+                text="UR5 arm (ur5.urdf, nq=6), one SE(3) tool0 task, targets within +-2 rad so the joint clamp is live"),
+}
+
+
+def bytes_per_solve(w):
+    return 8 * w["nq"] + 96 * len(w["frames"]) + 8 * w["nq"] + 1 + 4
 
 
 def load_kernel_stats():
@@ -40,14 +57,24 @@ def load_kernel_stats():
     return {}
 
 
-def cpu_baseline(model, q0_np, tg_np, iters, budget_s=12.0):
-    """The CPU oracle (oracle/ik_oracle.c, a port -- the reference itself cannot be built) timed on
+def make_inputs(name, model, idx):
+    w = WORKLOADS[name]
+    lo, hi = model.lowerPositionLimit, model.upperPositionLimit
+    if name == "cassie_full_body":
+        return workload.freeflyer_workload(lo, hi, workload.cassie_nominal(model.names), idx, seed=0, mode="near")
+    if name == "ur5":
+        return workload.chain_workload(lo, hi, workload.UR5_NOMINAL, idx, seed=0, mode="near")
+    return workload.chain_workload(lo, hi, workload.cassie_nominal(model.names), idx, seed=0, mode="uniform")
+
+
+def cpu_baseline(model, frames, q0_np, tg_np, iters, budget_s=12.0):
+    """The CPU oracle (oracle/ik_oracle.c, a port -- the reference itself cannot be built here) timed on
     this host's cores on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
     om = O.OracleModel(model.flat())
-    fid = model.getFrameId("LeftFootFront")
-    tasks = O.make_tasks([(fid, 0, 2, 0, None)])
+    fids = [model.getFrameId(f) for f in frames]
+    tasks = O.make_tasks([(f, 0, 2, 0, None) for f in fids])
     prm = O.params(iters, 1e-2, 1.0, -1.0)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     probe = min(256, q0_np.shape[0])
@@ -59,10 +86,10 @@ def cpu_baseline(model, q0_np, tg_np, iters, budget_s=12.0):
     q_ref, ok_ref, it_ref = O.dls_batch(om, tasks, tg_np[:sample], q0_np[:sample], prm, cores)
     dt = time.perf_counter() - t
     # which of the sampled problems converged on the CPU (SURVEY.md 8d parity bar): FK(q) reaches the target
-    reached = O.fk_batch(om, q_ref, [fid])
+    reached = O.fk_batch(om, q_ref, fids)
     conv = np.abs(reached - tg_np[:sample]).reshape(sample, -1).max(axis=1) < 1e-8
     return dict(value=sample / dt, unit="solves/s", cores=cores, kind="port",
-                sample="first %d problems of the batch, %d threads, %.1f s; 1-thread probe %.0f solves/s"
+                sample="first %d problems of the batch, %d threads, %.2f s wall; 1-thread probe %.0f solves/s"
                        % (sample, cores, dt, r1)), q_ref, sample, conv
 
 
@@ -73,6 +100,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=65536, help="problems per GPU")
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--workload", default="cassie_leg", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
 
@@ -92,16 +120,16 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     B = args.batch
-    model = ik_amd.Model.from_urdf_file(os.path.join(workload.MODELS_DIR, "cassie_fixed.kin.urdf"))
+    w = WORKLOADS[args.workload]
+    model = ik_amd.Model.from_urdf_file(os.path.join(workload.MODELS_DIR, w["urdf"] + ".kin.urdf"), free_flyer=w["free_flyer"])
     problem = ik_amd.InverseKinematicsProblem(model)
-    problem.add_frame_task("lf", ik_amd.FrameTask.create(model, "LeftFootFront", ik_amd.KinematicType.Full))
+    for f in w["frames"]:
+        problem.add_frame_task(f, ik_amd.FrameTask.create(model, f, ik_amd.KinematicType.Full))
     data = ik_amd.dls_data(problem, device=local_rank)
 
     # this rank's shard of the global synthetic batch (weak scaling: B problems per GPU)
     lo, hi = ikdist.shard_range(B * world, rank, world)
-    idx = np.arange(lo, hi)
-    q0_np, qs_np = workload.chain_workload(model.lowerPositionLimit, model.upperPositionLimit,
-                                           workload.cassie_nominal(model.names), idx, seed=0, mode="uniform")
+    q0_np, qs_np = make_inputs(args.workload, model, np.arange(lo, hi))
     Q0 = torch.from_numpy(np.ascontiguousarray(q0_np.T)).to(dev)
     QS = torch.from_numpy(np.ascontiguousarray(qs_np.T)).to(dev)
     targets = ik_amd.task_frames_fk_batch(problem, QS, data)  # FK(q*) on the device: reachable targets
@@ -140,25 +168,24 @@ def main():
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
 
     if rank == 0:
-        total = B * world * args.steps
-        value = total / elapsed
-        bytes_solve = BYTES_PER_SOLVE["cassie_leg"]
-        achieved = bytes_solve * B / (kernel_ms * 1e-3) / 1e9
-        stats = load_kernel_stats().get("dls_chain<NJ=7,full>", {})
+        value = B * world * args.steps / elapsed
+        bps = bytes_per_solve(w)
+        achieved = bps * B / (kernel_ms * 1e-3) / 1e9
+        stats = load_kernel_stats().get(data.kernel, {})
         res = {
             "metric": "IK solves/sec (50-iter DLS) at batch=65536",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "Cassie single-leg chain (cassie_fixed.urdf, 7 support joints of nq=16), one SE(3) "
-                                   "LeftFootFront task, %d fixed DLS iterations, damping 1e-2, step 1.0, targets FK(q*) "
-                                   "with q* uniform in the joint limits" % args.iters,
-                       "batch_per_gpu": B, "global_batch": B * world, "iterations": args.iters,
-                       "kernel": data.kernel, "parallelism": "batch-sharded x%d + all-gather" % world if distributed else "single GPU"},
+            "config": {"workload": "%s, %d fixed DLS iterations, damping 1e-2, step 1.0, reachable targets FK(q*)"
+                                   % (w["text"], args.iters),
+                       "name": args.workload, "batch_per_gpu": B, "global_batch": B * world, "iterations": args.iters,
+                       "kernel": data.kernel,
+                       "parallelism": "batch-sharded x%d + all-gather" % world if distributed else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": stats.get("hbm_traffic_bytes_per_launch"),
-                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_solve": bytes_solve,
-                         "note": "fused on-chip loop: the binding roof is FP64 VALU, see valu_roofline"},
+                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_solve": bps,
+                         "note": "fused on-chip loop: the binding roof is FP64 VALU issue, see valu_roofline"},
         }
         if stats.get("flop_per_iteration"):
             flops = stats["flop_per_iteration"] * args.iters
@@ -168,7 +195,7 @@ def main():
                                     "counting": "FP64 VALU instructions in the kernel's loop body (FMA = 2), static ISA count"}
         if not args.no_cpu:
             tg_np = targets.permute(2, 0, 1).contiguous().cpu().numpy()
-            cpu, q_ref, sample, conv = cpu_baseline(model, q0_np, tg_np, args.iters)
+            cpu, q_ref, sample, conv = cpu_baseline(model, w["frames"], q0_np, tg_np, args.iters)
             res["cpu_baseline"] = cpu
             d = np.abs(out[0].cpu().numpy().T[:sample] - q_ref).max(axis=1)
             res["parity_vs_cpu"] = {"problems": sample, "converged_on_cpu": int(conv.sum()),

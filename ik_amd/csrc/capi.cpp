@@ -24,6 +24,11 @@ namespace {
 
 thread_local std::string g_last_error;
 
+bool shape_built(const ikgpu::ProblemHost &ph) {
+    return ph.kind == ikgpu::KernelKind::Chain ? ikgpu::chain_shape_built(ph.chain.nj, ph.tasks[0].type)
+                                               : ikgpu::tree_shape_built(ph.chain.nj, ph.chainB.nj);
+}
+
 int fail(int code, const std::string &msg) {
     g_last_error = msg;
     return code;
@@ -155,7 +160,7 @@ int ikgpu_problem_create(const ikgpu_model *h, const ikgpu_task *tasks, int32_t 
         const std::string msg = e.what();
         return fail(msg.rfind("unsupported", 0) == 0 ? IKGPU_ERR_UNSUPPORTED : IKGPU_ERR_INVALID, msg);
     }
-    if (!ikgpu::chain_shape_built(ph.chain.nj, ph.tasks[0].type))
+    if (!shape_built(ph))
         return fail(IKGPU_ERR_UNSUPPORTED, "unsupported: no kernel instantiated for " + ph.kernel_name);
 
     int ndev = 0;
@@ -184,7 +189,8 @@ int ikgpu_problem_create(const ikgpu_model *h, const ikgpu_task *tasks, int32_t 
         up(&p->dev.lower, p->host.lower.data(), nq * sizeof(double));
         up(&p->dev.upper, p->host.upper.data(), nq * sizeof(double));
         up(&p->dev.q_in_chain, p->host.q_in_chain.data(), nq);
-        const std::vector<double> desc = ikgpu::chain_desc_table(p->host);
+        const std::vector<double> desc = p->host.kind == ikgpu::KernelKind::Chain ? ikgpu::chain_desc_table(p->host)
+                                                                                     : ikgpu::tree_desc_table(p->host);
         up(&p->dev.chain_desc, desc.data(), desc.size() * sizeof(double));
         if (err != hipSuccess) {
             ikgpu_problem_destroy(p);
@@ -199,7 +205,7 @@ int ikgpu_problem_plan(const ikgpu_model *h, const ikgpu_task *tasks, int32_t nt
     if (!h || !tasks) return fail(IKGPU_ERR_INVALID, "null argument");
     try {
         const ikgpu::ProblemHost ph = ikgpu::analyse_problem(h->m, tasks, ntasks);
-        if (!ikgpu::chain_shape_built(ph.chain.nj, ph.tasks[0].type))
+        if (!shape_built(ph))
             return fail(IKGPU_ERR_UNSUPPORTED, "unsupported: no kernel instantiated for " + ph.kernel_name);
         if (out && cap) {
             std::strncpy(out, ph.kernel_name.c_str(), cap - 1);
@@ -229,17 +235,20 @@ const char *ikgpu_problem_kernel(const ikgpu_problem *p) { return p ? p->host.ke
 int ikgpu_dls_solve_batch(const ikgpu_problem *p, int64_t B, const double *q0, const double *targets,
                           const ikgpu_dls_params *params, double *q_out, uint8_t *success, int32_t *iters, int layout,
                           void *stream) {
-    if (!p || !q0 || !targets || !q_out) return fail(IKGPU_ERR_INVALID, "null argument");
+    if (!p) return fail(IKGPU_ERR_INVALID, "null problem");
     if (B < 0) return fail(IKGPU_ERR_INVALID, "negative batch size");
     if (layout != IKGPU_SOA && layout != IKGPU_AOS) return fail(IKGPU_ERR_INVALID, "unknown layout");
     if (int rc = check_params(params)) return rc;
-    if (B == 0) return IKGPU_OK;
+    if (B == 0) return IKGPU_OK;  // an empty batch is a no-op (its pointers may be null)
+    if (!q0 || !targets || !q_out) return fail(IKGPU_ERR_INVALID, "null argument");
     if (B > (int64_t(1) << 31) * 32) return fail(IKGPU_ERR_INVALID, "batch too large for one launch");
     return guarded([&] {
         DeviceGuard g(p->device);
         if (!g.ok) return fail(IKGPU_ERR_DEVICE, "hipSetDevice failed");
         ikgpu::BatchIO io{B, q0, targets, q_out, success, iters, layout};
-        hipError_t e = ikgpu::launch_dls_chain(p->host, p->dev, io, *params, static_cast<hipStream_t>(stream));
+        hipError_t e = p->host.kind == ikgpu::KernelKind::Chain
+                           ? ikgpu::launch_dls_chain(p->host, p->dev, io, *params, static_cast<hipStream_t>(stream))
+                           : ikgpu::launch_dls_tree(p->host, p->dev, io, *params, static_cast<hipStream_t>(stream));
         if (e != hipSuccess) return hip_fail(e, "launching the DLS kernel");
         return static_cast<int>(IKGPU_OK);
     });
@@ -294,7 +303,9 @@ int ikgpu_evaluate_batch(const ikgpu_problem *p, int64_t B, const double *q, con
     return guarded([&] {
         DeviceGuard g(p->device);
         if (!g.ok) return fail(IKGPU_ERR_DEVICE, "hipSetDevice failed");
-        hipError_t e = ikgpu::launch_eval_chain(p->host, p->dev, B, q, targets, e_out, J_out, layout, static_cast<hipStream_t>(stream));
+        hipError_t e = p->host.kind == ikgpu::KernelKind::Chain
+                           ? ikgpu::launch_eval_chain(p->host, p->dev, B, q, targets, e_out, J_out, layout, static_cast<hipStream_t>(stream))
+                           : ikgpu::launch_eval_tree(p->host, p->dev, B, q, targets, e_out, J_out, nullptr, layout, static_cast<hipStream_t>(stream));
         if (e != hipSuccess) return hip_fail(e, "launching the evaluate kernel");
         return static_cast<int>(IKGPU_OK);
     });
@@ -309,7 +320,9 @@ int ikgpu_task_frames_fk_batch(const ikgpu_problem *p, int64_t B, const double *
     return guarded([&] {
         DeviceGuard g(p->device);
         if (!g.ok) return fail(IKGPU_ERR_DEVICE, "hipSetDevice failed");
-        hipError_t e = ikgpu::launch_fk_chain(p->host, p->dev, B, q, oMf_out, layout, static_cast<hipStream_t>(stream));
+        hipError_t e = p->host.kind == ikgpu::KernelKind::Chain
+                           ? ikgpu::launch_fk_chain(p->host, p->dev, B, q, oMf_out, layout, static_cast<hipStream_t>(stream))
+                           : ikgpu::launch_eval_tree(p->host, p->dev, B, q, q, nullptr, nullptr, oMf_out, layout, static_cast<hipStream_t>(stream));
         if (e != hipSuccess) return hip_fail(e, "launching the FK kernel");
         return static_cast<int>(IKGPU_OK);
     });

@@ -1,0 +1,460 @@
+// tree_solver.hpp -- the whole ik::dls() loop for ONE problem on a free-flyer model whose tasks
+// hang off the floating base: up to two serial chains of revolute joints, each ending in a frame
+// task, plus an optional frame task on the base link itself (shape "F" of SURVEY.md section 8:
+// Cassie full body, nq = 23 / nv = 22, LeftFootFront + RightFootFront + pelvis, M = 18).
+//
+// Reference path restated per iteration (file:line relative to the reference root):
+//   ik/ik/data.cpp:28-30     FK + joint Jacobians (free-flyer columns = Ad(oM1))
+//   ik/ik/frame.hpp:37-62    e_t = log6(oMf^-1 oMt)            per task
+//   ik/ik/frame.hpp:152-182  J_t = -Jlog6(tMf) J_local          per task
+//   ik/ik/data.cpp:49-50     weighting;  ik/ik/dls.cpp:18-24 stacking of all priority levels
+//   ik/ik/dls.cpp:39-53      dq = -Jt^T (Jt Jt^T + damping^2 I)^-1 et
+//   ik/ik/dls.cpp:61-71      stop test, pinocchio::integrate (SE(3) for the base), joint clipping
+//
+// The linear solve uses the identity  J^T (J J^T + l I)^-1 = (J^T J + l I)^-1 J^T : the 20 x 20
+// normal matrix H = J^T J + l I has an arrow structure (the two chains couple only through the six
+// base columns), so each chain is eliminated by a 7 x 7 Cholesky and the base by a 6 x 6 Schur
+// complement -- the same dq as the reference's dense 18 x 18 LDL^T up to rounding (cond(H) ~ 1e5),
+// with a third of its registers.  A Position / Orientation task is a Full task whose unused rows
+// carry weight zero: zero rows change neither H nor J^T e.
+#pragma once
+#include "chain_solver.hpp"
+
+namespace ikdev {
+
+template <int NA, int NB>
+struct TreeDesc {
+    double plA[NA > 0 ? NA : 1][12];  // plA[0]: base joint frame -> first joint of chain A (axis-folded)
+    double frA[12];                   // last joint of chain A -> task frame
+    double loA[NA > 0 ? NA : 1], hiA[NA > 0 ? NA : 1];
+    double plB[NB > 0 ? NB : 1][12];
+    double frB[12];
+    double loB[NB > 0 ? NB : 1], hiB[NB > 0 ? NB : 1];
+    double frP[12];                   // base joint frame -> frame of the base task
+    double wA[6], wB[6], wP[6];       // six-row weights (zeros on rows the task's kinematic type drops)
+};  // all doubles: staged HBM -> LDS as a flat table
+
+struct TreeParams {
+    int max_iterations;
+    double lam2, step_length, stop_sq_tol;
+    int prioA, prioB, prioP;  // priority level per task; the stop test sums priority-0 rows
+    int hasP;                 // a base task is present
+};
+
+// Packed lower-triangular index
+IKD_FN constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
+
+// Eigen::Quaternion::toRotationMatrix, coefficients (x, y, z, w), not normalised (App. A.2)
+IKD_FN void quat_to_R(const double (&qb)[7], double (&R)[9]) {
+    const double x = qb[3], y = qb[4], z = qb[5], w = qb[6];
+    const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w;
+    const double txx = tx * x, txy = ty * x, txz = tz * x;
+    const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1.0 - (tyy + tzz); R[1] = txy - twz;         R[2] = txz + twy;
+    R[3] = txy + twz;         R[4] = 1.0 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.0 - (txx + tyy);
+}
+
+// What one frame task contributes, given its frame placement (Rf, pf) in the world:
+// weighted error e (6), and K = -diag(w) Jlog6(tMf) as blocks: top rows [At | Bt], bottom rows [0 | Ab].
+struct TaskTerms {
+    double e[6];
+    double At[9], Bt[9], Ab[9];
+};
+
+IKD_FN void task_terms(const double (&Rf)[9], const double (&pf)[3], const double (&oMt)[12], const double *w6,
+                       TaskTerms &t) {
+    double Re[9], pe[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Re[3 * i + j] = dfma(Rf[i], oMt[j], dfma(Rf[3 + i], oMt[3 + j], Rf[6 + i] * oMt[6 + j]));
+    const double dp[3] = {oMt[9] - pf[0], oMt[10] - pf[1], oMt[11] - pf[2]};
+    rotT_vec(Rf, dp, pe);
+    LogAndJlog lj;
+    log6_and_jlog6_inv(Re, pe, lj);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double wt = w6[i], wb = w6[3 + i];
+        t.e[i] = lj.e[i] * wt;
+        t.e[3 + i] = lj.e[3 + i] * wb;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            t.At[3 * i + j] = -wt * lj.A[3 * i + j];
+            t.Bt[3 * i + j] = -wt * lj.Bm[3 * i + j];
+            t.Ab[3 * i + j] = -wb * lj.A[3 * i + j];
+        }
+    }
+}
+
+// Task Jacobian columns of the six free-flyer DoFs: J_local = Ad(oMf^-1 oM1) = [[Rb, [pb]x Rb], [0, Rb]].
+// JL[c] (c = 0..2, linear DoFs): only the top three rows are non-zero.  JA[c]: all six rows.
+IKD_FN void base_columns(const TaskTerms &t, const double (&Rf)[9], const double (&pf)[3], const double (&R1)[9],
+                         const double (&p1)[3], double (&JL)[3][3], double (&JA)[3][6]) {
+    double Rb[9], pb[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Rb[3 * i + j] = dfma(Rf[i], R1[j], dfma(Rf[3 + i], R1[3 + j], Rf[6 + i] * R1[6 + j]));
+    const double dp[3] = {p1[0] - pf[0], p1[1] - pf[1], p1[2] - pf[2]};
+    rotT_vec(Rf, dp, pb);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double rc[3] = {Rb[c], Rb[3 + c], Rb[6 + c]};
+        double pxr[3];
+        cross(pb, rc, pxr);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            JL[c][i] = dfma(t.At[3 * i], rc[0], dfma(t.At[3 * i + 1], rc[1], t.At[3 * i + 2] * rc[2]));
+            JA[c][i] = dfma(t.At[3 * i], pxr[0], dfma(t.At[3 * i + 1], pxr[1], dfma(t.At[3 * i + 2], pxr[2],
+                       dfma(t.Bt[3 * i], rc[0], dfma(t.Bt[3 * i + 1], rc[1], t.Bt[3 * i + 2] * rc[2])))));
+            JA[c][3 + i] = dfma(t.Ab[3 * i], rc[0], dfma(t.Ab[3 * i + 1], rc[1], t.Ab[3 * i + 2] * rc[2]));
+        }
+    }
+}
+
+// Hbb += Jb^T Jb, gb += Jb^T e  for the six base columns (Jb = [JL | JA])
+IKD_FN void accumulate_base(const double (&JL)[3][3], const double (&JA)[3][6], const double (&e)[6], double (&Hbb)[21],
+                            double (&gb)[6]) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int b = 0; b <= a; ++b)
+            Hbb[tri(a, b)] = dfma(JL[a][0], JL[b][0], dfma(JL[a][1], JL[b][1], dfma(JL[a][2], JL[b][2], Hbb[tri(a, b)])));
+        gb[a] = dfma(JL[a][0], e[0], dfma(JL[a][1], e[1], dfma(JL[a][2], e[2], gb[a])));
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+            Hbb[tri(3 + a, b)] = dfma(JA[a][0], JL[b][0], dfma(JA[a][1], JL[b][1], dfma(JA[a][2], JL[b][2], Hbb[tri(3 + a, b)])));
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+            double s = Hbb[tri(3 + a, 3 + b)];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) s = dfma(JA[a][r], JA[b][r], s);
+            Hbb[tri(3 + a, 3 + b)] = s;
+        }
+        double s = gb[3 + a];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) s = dfma(JA[a][r], e[r], s);
+        gb[3 + a] = s;
+    }
+}
+
+// Per-chain factorisation kept for the back-substitution: H_ll = L L^T (packed, diagonal holds
+// 1/L_ii), W = L^-1 H_lb (NJ x 6), u = L^-1 g_l.
+template <int NJ>
+struct LegFactor {
+    double L[NJ * (NJ + 1) / 2];
+    double W[NJ][6];
+    double u[NJ];
+};
+
+// Evaluate one chain task at the current configuration, add its base-block contributions to
+// (Hbb, gb), eliminate its NJ joint unknowns (Schur complement onto the base) and return the factor.
+template <int NJ>
+IKD_FN void leg_eval_factor(const double (&R1)[9], const double (&p1)[3], const double (*pl)[12], const double *frame_pl,
+                            const double *w6, const double (&q)[NJ], const double (&oMt)[12], double lam2, bool prio0,
+                            double (&Hbb)[21], double (&gb)[6], double &e0sq, LegFactor<NJ> &F) {
+    double zax[NJ][3], org[NJ][3];
+    double R[9], p[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = R1[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p[k] = p1[k];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        se3_compose_const(R, p, pl[j]);
+        double s, c;
+        dsincos(q[j], s, c);
+        rot_z_right(R, s, c);
+        zax[j][0] = R[2]; zax[j][1] = R[5]; zax[j][2] = R[8];
+        org[j][0] = p[0]; org[j][1] = p[1]; org[j][2] = p[2];
+    }
+    se3_compose_const(R, p, frame_pl);
+
+    TaskTerms t;
+    task_terms(R, p, oMt, w6, t);
+    if (prio0) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) e0sq = dfma(t.e[r], t.e[r], e0sq);
+    }
+    double JL[3][3], JA[3][6];
+    base_columns(t, R, p, R1, p1, JL, JA);
+    accumulate_base(JL, JA, t.e, Hbb, gb);
+
+    // chain columns
+    double col[NJ][6];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        double wl[3], r[3], vl[3];
+        rotT_vec(R, zax[j], wl);
+        const double dj[3] = {org[j][0] - p[0], org[j][1] - p[1], org[j][2] - p[2]};
+        rotT_vec(R, dj, r);
+        cross(r, wl, vl);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            col[j][i] = dfma(t.At[3 * i], vl[0], dfma(t.At[3 * i + 1], vl[1], dfma(t.At[3 * i + 2], vl[2],
+                        dfma(t.Bt[3 * i], wl[0], dfma(t.Bt[3 * i + 1], wl[1], t.Bt[3 * i + 2] * wl[2])))));
+            col[j][3 + i] = dfma(t.Ab[3 * i], wl[0], dfma(t.Ab[3 * i + 1], wl[1], t.Ab[3 * i + 2] * wl[2]));
+        }
+    }
+    // H_ll (packed), H_lb -> W, g_l -> u
+#pragma unroll
+    for (int a = 0; a < NJ; ++a) {
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+            double s = (a == b) ? lam2 : 0.0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) s = dfma(col[a][r], col[b][r], s);
+            F.L[tri(a, b)] = s;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            F.W[a][c] = dfma(col[a][0], JL[c][0], dfma(col[a][1], JL[c][1], col[a][2] * JL[c][2]));
+            double s = 0.0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) s = dfma(col[a][r], JA[c][r], s);
+            F.W[a][3 + c] = s;
+        }
+        double s = 0.0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) s = dfma(col[a][r], t.e[r], s);
+        F.u[a] = s;
+    }
+    // Cholesky of H_ll; forward-substitute the 6 + 1 right-hand sides alongside
+#pragma unroll
+    for (int k = 0; k < NJ; ++k) {
+        double d = F.L[tri(k, k)];
+#pragma unroll
+        for (int m = 0; m < k; ++m) d = dfma(-F.L[tri(k, m)], F.L[tri(k, m)], d);
+        const double inv = drsqrt(d);
+        F.L[tri(k, k)] = inv;
+#pragma unroll
+        for (int i = k + 1; i < NJ; ++i) {
+            double s = F.L[tri(i, k)];
+#pragma unroll
+            for (int m = 0; m < k; ++m) s = dfma(-F.L[tri(i, m)], F.L[tri(k, m)], s);
+            F.L[tri(i, k)] = s * inv;
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            double s = F.W[k][c];
+#pragma unroll
+            for (int m = 0; m < k; ++m) s = dfma(-F.L[tri(k, m)], F.W[m][c], s);
+            F.W[k][c] = s * inv;
+        }
+        double s = F.u[k];
+#pragma unroll
+        for (int m = 0; m < k; ++m) s = dfma(-F.L[tri(k, m)], F.u[m], s);
+        F.u[k] = s * inv;
+    }
+    // Schur complement onto the base: Hbb -= W^T W, gb -= W^T u
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+            double s = Hbb[tri(a, b)];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) s = dfma(-F.W[j][a], F.W[j][b], s);
+            Hbb[tri(a, b)] = s;
+        }
+        double s = gb[a];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) s = dfma(-F.W[j][a], F.u[j], s);
+        gb[a] = s;
+    }
+}
+
+// dq_l = -L^-T (u + W dq_b)
+template <int NJ>
+IKD_FN void leg_back_substitute(const LegFactor<NJ> &F, const double (&dqb)[6], double (&dql)[NJ]) {
+    double t[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        double s = F.u[j];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) s = dfma(F.W[j][c], dqb[c], s);
+        t[j] = s;
+    }
+#pragma unroll
+    for (int k = NJ - 1; k >= 0; --k) {
+        double s = t[k];
+#pragma unroll
+        for (int m = k + 1; m < NJ; ++m) s = dfma(-F.L[tri(m, k)], dql[m], s);
+        dql[k] = s * F.L[tri(k, k)];
+    }
+#pragma unroll
+    for (int k = 0; k < NJ; ++k) dql[k] = -dql[k];
+}
+
+// pinocchio::integrate for the free-flyer: q_b <- q_b (+) v, v = [v_lin; omega]
+IKD_FN void freeflyer_integrate(const double (&qb)[7], const double (&R1)[9], const double (&v)[6], double (&out)[7]) {
+    const double w[3] = {v[3], v[4], v[5]};
+    const double vl[3] = {v[0], v[1], v[2]};
+    const double t2 = dot(w, w);
+    const double t = dsqrt(t2);
+    double st, ct;
+    dsincos(t, st, ct);
+    const bool small = t < kTaylorPrec3;
+    const double inv_t2 = drcp(t2);
+    const double a_wxv = dsel(small, 0.5 - t2 * (1.0 / 24.0), (1.0 - ct) * inv_t2);
+    const double a_v = dsel(small, 1.0 - t2 * (1.0 / 6.0), st * drcp(t));
+    const double a_w = dsel(small, 1.0 / 6.0 - t2 * (1.0 / 120.0), (1.0 - a_v) * inv_t2);
+    const double diag = dsel(small, 1.0 - t2 * 0.5, ct);
+    double wxv[3];
+    cross(w, vl, wxv);
+    const double awv = a_w * dot(w, vl);
+    double tr[3], E[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tr[i] = dfma(a_v, vl[i], dfma(awv, w[i], a_wxv * wxv[i]));
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) E[3 * i + j] = a_wxv * w[i] * w[j];
+    E[1] -= a_v * w[2]; E[2] += a_v * w[1];
+    E[3] += a_v * w[2]; E[5] -= a_v * w[0];
+    E[6] -= a_v * w[1]; E[7] += a_v * w[0];
+    E[0] += diag; E[4] += diag; E[8] += diag;
+    // M1 = (R1, p) * (E, tr)
+    double M[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        out[i] = dfma(R1[3 * i], tr[0], dfma(R1[3 * i + 1], tr[1], dfma(R1[3 * i + 2], tr[2], qb[i])));
+#pragma unroll
+        for (int j = 0; j < 3; ++j) M[3 * i + j] = dfma(R1[3 * i], E[j], dfma(R1[3 * i + 1], E[3 + j], R1[3 * i + 2] * E[6 + j]));
+    }
+    // rotation matrix -> quaternion, Eigen's branch selection done with selects
+    const double trace = M[0] + M[4] + M[8];
+    const bool cw = trace > 0.0;
+    int i0 = 0;
+    i0 = (M[4] > M[0]) ? 1 : 0;
+    const double mii = (i0 == 1) ? M[4] : M[0];
+    i0 = (M[8] > mii) ? 2 : i0;
+    const bool cx = !cw && i0 == 0, cy = !cw && i0 == 1;
+    // t = sqrt(1 + trace)  or  sqrt(1 + M_ii - M_jj - M_kk)
+    const double arg = cw ? trace + 1.0 : (cx ? (M[0] - M[4] - M[8] + 1.0) : (cy ? (M[4] - M[8] - M[0] + 1.0) : (M[8] - M[0] - M[4] + 1.0)));
+    const double tq = dsqrt(arg);
+    const double half_t = 0.5 * tq;
+    const double s = 0.5 * drcp(tq);
+    const double d21 = M[7] - M[5], d02 = M[2] - M[6], d10 = M[3] - M[1];  // (R21-R12), (R02-R20), (R10-R01)
+    const double s01 = M[3] + M[1], s02 = M[6] + M[2], s12 = M[7] + M[5];
+    double rq[4];  // x y z w
+    rq[0] = cw ? d21 * s : (cx ? half_t : (cy ? s01 * s : s02 * s));
+    rq[1] = cw ? d02 * s : (cx ? s01 * s : (cy ? half_t : s12 * s));
+    rq[2] = cw ? d10 * s : (cx ? s02 * s : (cy ? s12 * s : half_t));
+    rq[3] = cw ? half_t : (cx ? d21 * s : (cy ? d02 * s : d10 * s));
+    const double dp = dfma(rq[0], qb[3], dfma(rq[1], qb[4], dfma(rq[2], qb[5], rq[3] * qb[6])));
+    const double sg = (dp < 0.0) ? -1.0 : 1.0;
+    const double n2 = dfma(rq[0], rq[0], dfma(rq[1], rq[1], dfma(rq[2], rq[2], rq[3] * rq[3])));
+    const double al = sg * ((3.0 - n2) * 0.5);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[3 + k] = rq[k] * al;
+}
+
+// Storage hooks for the first chain's factor while the second chain is processed: on the device
+// they park L and W in LDS ([entry][lane], conflict-free ds_write/read_b64); on the host they copy.
+template <int NA, int NB, class Park, class AnyFn>
+IKD_FN void tree_dls(const TreeDesc<NA, NB> &d, const TreeParams &prm, double (&qb)[7], double (&qa)[NA > 0 ? NA : 1],
+                     double (&qbj)[NB > 0 ? NB : 1], const double *targets_lane, int64_t tstride, const int (&tslot)[3],
+                     int &iters_out, bool &success_out, Park park, AnyFn any_active) {
+    bool active = true, success = false;
+    int iters = prm.max_iterations;
+#pragma unroll 1
+    for (int it = 0; it < prm.max_iterations; ++it) {
+        asm volatile("" ::: "memory");  // re-read the LDS table and the targets every iteration (see chain_solver.hpp)
+        double R1[9];
+        quat_to_R(qb, R1);
+        const double p1[3] = {qb[0], qb[1], qb[2]};
+        double Hbb[21], gb[6], e0sq = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+#pragma unroll
+            for (int j = 0; j <= i; ++j) Hbb[tri(i, j)] = (i == j) ? prm.lam2 : 0.0;
+            gb[i] = 0.0;
+        }
+        LegFactor<(NA > 0 ? NA : 1)> FA;
+        LegFactor<(NB > 0 ? NB : 1)> FB;
+        if (NA > 0) {
+            double oMt[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) oMt[k] = targets_lane[(tslot[0] * 12 + k) * tstride];
+            leg_eval_factor<(NA > 0 ? NA : 1)>(R1, p1, d.plA, d.frA, d.wA, qa, oMt, prm.lam2, prm.prioA == 0, Hbb, gb, e0sq, FA);
+            if (NB > 0) park.store(FA);
+        }
+        if (NB > 0) {
+            double oMt[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) oMt[k] = targets_lane[(tslot[1] * 12 + k) * tstride];
+            leg_eval_factor<(NB > 0 ? NB : 1)>(R1, p1, d.plB, d.frB, d.wB, qbj, oMt, prm.lam2, prm.prioB == 0, Hbb, gb, e0sq, FB);
+        }
+        if (prm.hasP) {
+            double oMt[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) oMt[k] = targets_lane[(tslot[2] * 12 + k) * tstride];
+            double Rf[9], pf[3];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Rf[k] = R1[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) pf[k] = p1[k];
+            se3_compose_const(Rf, pf, d.frP);
+            TaskTerms t;
+            task_terms(Rf, pf, oMt, d.wP, t);
+            if (prm.prioP == 0) {
+#pragma unroll
+                for (int r = 0; r < 6; ++r) e0sq = dfma(t.e[r], t.e[r], e0sq);
+            }
+            double JL[3][3], JA[3][6];
+            base_columns(t, Rf, pf, R1, p1, JL, JA);
+            accumulate_base(JL, JA, t.e, Hbb, gb);
+        }
+        // base: S dq_b = -g
+        double S[36], x[6], dqb[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) S[i * 6 + j] = Hbb[tri(i, j)];
+        chol_solve<6>(S, gb, x);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) dqb[i] = -x[i];
+
+        const bool stop_now = active && (prm.stop_sq_tol >= 0.0) && (e0sq < prm.stop_sq_tol);
+        if (stop_now) { success = true; iters = it; }
+        active = active && !stop_now;
+
+        if (NB > 0) {
+            double dql[NB > 0 ? NB : 1];
+            leg_back_substitute<(NB > 0 ? NB : 1)>(FB, dqb, dql);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const double qc = dmin(d.hiB[j], dmax(dfma(prm.step_length, dql[j], qbj[j]), d.loB[j]));
+                qbj[j] = active ? qc : qbj[j];
+            }
+        }
+        if (NA > 0) {
+            if (NB > 0) park.load(FA);
+            double dql[NA > 0 ? NA : 1];
+            leg_back_substitute<(NA > 0 ? NA : 1)>(FA, dqb, dql);
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                const double qc = dmin(d.hiA[j], dmax(dfma(prm.step_length, dql[j], qa[j]), d.loA[j]));
+                qa[j] = active ? qc : qa[j];
+            }
+        }
+        {
+            double v[6], qn[7];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) v[i] = prm.step_length * dqb[i];
+            freeflyer_integrate(qb, R1, v, qn);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) qb[i] = active ? qn[i] : qb[i];
+        }
+        if (!any_active(active)) break;
+    }
+    iters_out = iters;
+    success_out = success;
+}
+
+}  // namespace ikdev

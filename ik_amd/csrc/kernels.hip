@@ -10,6 +10,7 @@
 #include <string>
 
 #include "device/chain_kernel_body.hpp"
+#include "device/tree_kernel_body.hpp"
 
 namespace ikgpu {
 namespace {
@@ -160,6 +161,136 @@ hipError_t launch_fk_chain(const ProblemHost &ph, const DeviceTables &dt, int64_
     IKGPU_FOR_NJ(X)
 #undef X
     not_built(nj, 0);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Free-flyer tree kernels (shape F: Cassie full body, two foot chains + the pelvis task)
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+using ikdev::LegFactor;
+using ikdev::TreeDesc;
+using ikdev::TreeKernelArgs;
+
+// While chain B is evaluated, chain A's factor (L packed + W) is parked in LDS as [entry][lane]:
+// consecutive lanes hit consecutive 8-byte words, so every ds_write_b64 / ds_read_b64 is conflict-free.
+template <int NJ>
+struct LdsPark {
+    static constexpr int kL = NJ * (NJ + 1) / 2;
+    static constexpr int kEntries = kL + NJ * 6;
+    double (*buf)[kBlock];
+    int lane;
+    __device__ __forceinline__ void store(const LegFactor<NJ> &F) const {
+#pragma unroll
+        for (int e = 0; e < kL; ++e) buf[e][lane] = F.L[e];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) buf[kL + j * 6 + c][lane] = F.W[j][c];
+    }
+    __device__ __forceinline__ void load(LegFactor<NJ> &F) const {
+#pragma unroll
+        for (int e = 0; e < kL; ++e) F.L[e] = buf[e][lane];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) F.W[j][c] = buf[kL + j * 6 + c][lane];
+    }
+};
+
+template <int NA, int NB>
+__device__ __forceinline__ const TreeDesc<NA, NB> &stage_tree_desc(const TreeDesc<NA, NB> *src, double *lds) {
+    constexpr int kWords = sizeof(TreeDesc<NA, NB>) / sizeof(double);
+    const double *g = reinterpret_cast<const double *>(src);
+    for (int i = threadIdx.x; i < kWords; i += kBlock) lds[i] = g[i];
+    __syncthreads();
+    return *reinterpret_cast<const TreeDesc<NA, NB> *>(lds);
+}
+
+template <int NA, int NB>
+__global__ __launch_bounds__(kBlock) void dls_tree_kernel(const TreeKernelArgs<NA, NB> a) {
+    __shared__ double lds_desc[sizeof(TreeDesc<NA, NB>) / sizeof(double)];
+    __shared__ double lds_park[LdsPark<NA>::kEntries][kBlock];
+    const TreeDesc<NA, NB> &d = stage_tree_desc<NA, NB>(a.desc, lds_desc);
+    const int64_t gid = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    LdsPark<NA> park{lds_park, static_cast<int>(threadIdx.x)};
+    ikdev::dls_tree_body<NA, NB>(a, d, gid, park, [](bool act) { return __any(act) != 0; });
+}
+
+template <int NA, int NB>
+__global__ __launch_bounds__(kBlock) void eval_tree_kernel(const TreeKernelArgs<NA, NB> a) {
+    __shared__ double lds_desc[sizeof(TreeDesc<NA, NB>) / sizeof(double)];
+    const TreeDesc<NA, NB> &d = stage_tree_desc<NA, NB>(a.desc, lds_desc);
+    ikdev::eval_tree_body<NA, NB>(a, d, static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x);
+}
+
+template <int NA, int NB>
+TreeKernelArgs<NA, NB> make_tree_args(const ProblemHost &ph, const DeviceTables &dt) {
+    TreeKernelArgs<NA, NB> a{};
+    const TreeArgsHost h = tree_args(ph);
+    for (int j = 0; j < NA; ++j) { a.qidxA[j] = h.qidxA[j]; a.vidxA[j] = h.vidxA[j]; }
+    for (int j = 0; j < NB; ++j) { a.qidxB[j] = h.qidxB[j]; a.vidxB[j] = h.vidxB[j]; }
+    for (int s = 0; s < 3; ++s) { a.tslot[s] = h.tslot[s]; a.trow[s] = h.trow[s]; a.tdim[s] = h.tdim[s]; a.trow0[s] = h.trow0[s]; }
+    a.prm.prioA = h.prio[0]; a.prm.prioB = h.prio[1]; a.prm.prioP = h.prio[2];
+    a.prm.hasP = h.hasP;
+    a.desc = reinterpret_cast<const TreeDesc<NA, NB> *>(dt.chain_desc);
+    a.nq = ph.nq; a.nv = ph.nv; a.ntasks = ph.ntasks;
+    a.lower = dt.lower; a.upper = dt.upper; a.q_in_chain = dt.q_in_chain;
+    return a;
+}
+
+template <int NA, int NB>
+hipError_t run_dls_tree(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const ikgpu_dls_params &prm,
+                        hipStream_t stream) {
+    TreeKernelArgs<NA, NB> a = make_tree_args<NA, NB>(ph, dt);
+    a.prm.max_iterations = prm.max_iterations;
+    a.prm.lam2 = prm.damping * prm.damping;
+    a.prm.step_length = prm.step_length;
+    a.prm.stop_sq_tol = prm.stop_sq_tol;
+    a.layout = io.layout; a.B = io.B; a.q0 = io.q0; a.targets = io.targets;
+    a.q_out = io.q_out; a.success = io.success; a.iters = io.iters;
+    hipLaunchKernelGGL((dls_tree_kernel<NA, NB>), grid_for(io.B), dim3(kBlock), 0, stream, a);
+    return hipGetLastError();
+}
+
+template <int NA, int NB>
+hipError_t run_eval_tree(const ProblemHost &ph, const DeviceTables &dt, int64_t B, const double *q, const double *targets,
+                         double *e_out, double *J_out, double *oMf_out, int layout, hipStream_t stream) {
+    TreeKernelArgs<NA, NB> a = make_tree_args<NA, NB>(ph, dt);
+    a.layout = layout; a.B = B; a.q0 = q; a.targets = targets;
+    a.e_out = e_out; a.J_out = J_out; a.oMf_out = oMf_out;
+    hipLaunchKernelGGL((eval_tree_kernel<NA, NB>), grid_for(B), dim3(kBlock), 0, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+#define IKGPU_FOR_TREE(X) X(7, 7) X(7, 0)
+
+bool tree_shape_built(int na, int nb) {
+#define X(A, B_) if (na == A && nb == B_) return true;
+    IKGPU_FOR_TREE(X)
+#undef X
+    return false;
+}
+
+hipError_t launch_dls_tree(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const ikgpu_dls_params &prm,
+                           hipStream_t stream) {
+    const int na = ph.chain.nj, nb = ph.chainB.nj;
+#define X(A, B_) if (na == A && nb == B_) return run_dls_tree<A, B_>(ph, dt, io, prm, stream);
+    IKGPU_FOR_TREE(X)
+#undef X
+    not_built(na, nb);
+}
+
+hipError_t launch_eval_tree(const ProblemHost &ph, const DeviceTables &dt, int64_t B, const double *q, const double *targets,
+                            double *e_out, double *J_out, double *oMf_out, int layout, hipStream_t stream) {
+    const int na = ph.chain.nj, nb = ph.chainB.nj;
+#define X(A, B_) if (na == A && nb == B_) return run_eval_tree<A, B_>(ph, dt, B, q, targets, e_out, J_out, oMf_out, layout, stream);
+    IKGPU_FOR_TREE(X)
+#undef X
+    not_built(na, nb);
 }
 
 }  // namespace ikgpu

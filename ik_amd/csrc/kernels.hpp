@@ -35,3 +35,14 @@ hipError_t launch_fk_chain(const ProblemHost &ph, const DeviceTables &dt, int64_
 bool chain_shape_built(int nj, int type);
 
 }  // namespace ikgpu
+
+namespace ikgpu {
+// Free-flyer tree kernels (shape F).  dt.chain_desc holds ikdev::TreeDesc<NA, NB>.
+hipError_t launch_dls_tree(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io,
+                           const ikgpu_dls_params &prm, hipStream_t stream);
+// e_out / J_out / oMf_out: any may be null.
+hipError_t launch_eval_tree(const ProblemHost &ph, const DeviceTables &dt, int64_t B, const double *q,
+                            const double *targets, double *e_out, double *J_out, double *oMf_out, int layout,
+                            hipStream_t stream);
+bool tree_shape_built(int na, int nb);
+}  // namespace ikgpu

@@ -36,6 +36,48 @@ SE3 rot_only(const double *P, bool transpose) {
 
 int task_dim(const ikgpu_task &t) { return t.type == IKGPU_FULL ? 6 : 3; }
 
+bool is_identity(const SE3 &s) { return s == se3_identity(); }
+
+// Axis-folded table of the revolute joints `joints` (root first) ending in frame `frame`.
+// pl[0] is relative to the parent joint of joints[0] (the universe, or the free-flyer base).
+ChainHost build_chain(const Model &m, const std::vector<int> &joints, int frame, int task_index,
+                      std::vector<uint8_t> &q_in_chain) {
+    if (static_cast<int>(joints.size()) > kMaxChain)
+        throw std::runtime_error("unsupported on the device yet: support chain longer than " + std::to_string(kMaxChain) + " joints");
+    ChainHost c;
+    c.nj = static_cast<int>(joints.size());
+    c.task = task_index;
+    double Pprev[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int k = 0; k < c.nj; ++k) {
+        const int j = joints[k];
+        if (m.joint_type[j] != IKGPU_JOINT_REVOLUTE)
+            throw std::runtime_error("unsupported on the device yet: joint '" + m.joint_names[j] + "' in the task support is not revolute");
+        if (q_in_chain[m.joint_idx_q[j]])
+            throw std::runtime_error("unsupported on the device yet: joint '" + m.joint_names[j] + "' is in the support of two tasks");
+        double P[9];
+        axis_frame(m.joint_axis[j], P);
+        SE3 pl = se3_mul(se3_mul(rot_only(Pprev, true), m.joint_placement[j]), rot_only(P, false));
+        std::memcpy(c.pl[k], pl.data(), sizeof(double) * 12);
+        c.qidx[k] = m.joint_idx_q[j];
+        c.vidx[k] = m.joint_idx_v[j];
+        c.lo[k] = m.lower[m.joint_idx_q[j]];
+        c.hi[k] = m.upper[m.joint_idx_q[j]];
+        q_in_chain[m.joint_idx_q[j]] = 1;
+        std::memcpy(Pprev, P, sizeof P);
+    }
+    SE3 fpl = se3_mul(rot_only(Pprev, true), m.frame_placement[frame]);
+    std::memcpy(c.frame_pl, fpl.data(), sizeof(double) * 12);
+    return c;
+}
+
+// Six-row weights of a task: rows its kinematic type drops get weight zero.
+void weights6(const ikgpu_task &t, double *w6) {
+    for (int i = 0; i < 6; ++i) w6[i] = 0.0;
+    if (t.type == IKGPU_FULL) for (int i = 0; i < 6; ++i) w6[i] = t.weight[i];
+    if (t.type == IKGPU_POSITION) for (int i = 0; i < 3; ++i) w6[i] = t.weight[i];
+    if (t.type == IKGPU_ORIENTATION) for (int i = 0; i < 3; ++i) w6[3 + i] = t.weight[i];
+}
+
 }  // namespace
 
 ProblemHost analyse_problem(const Model &m, const ikgpu_task *tasks, int ntasks) {
@@ -47,6 +89,7 @@ ProblemHost analyse_problem(const Model &m, const ikgpu_task *tasks, int ntasks)
     ph.lower = m.lower;
     ph.upper = m.upper;
     ph.q_in_chain.assign(m.nq, 0);
+    int last_prio = 0;
     for (int i = 0; i < ntasks; ++i) {
         const ikgpu_task &t = tasks[i];
         if (t.frame < 0 || t.frame >= m.nframes()) throw std::runtime_error("task " + std::to_string(i) + ": frame id out of range");
@@ -54,51 +97,58 @@ ProblemHost analyse_problem(const Model &m, const ikgpu_task *tasks, int ntasks)
         if (t.type != IKGPU_POSITION && t.type != IKGPU_ORIENTATION && t.type != IKGPU_FULL)
             throw std::runtime_error("task " + std::to_string(i) + ": unknown kinematic type");
         if (t.priority < 0) throw std::runtime_error("task " + std::to_string(i) + ": negative priority");
+        if (t.priority < last_prio) throw std::runtime_error("tasks must be listed in stacking order (non-decreasing priority)");
+        last_prio = t.priority;
         ph.tasks.push_back(t);
+        ph.task_row.push_back(ph.rows);
         ph.rows += task_dim(t);
     }
-
-    if (ntasks != 1)
-        throw std::runtime_error("unsupported on the device yet: more than one task (multi-task kernels are not built in this round)");
-
-    const ikgpu_task &t = tasks[0];
-    if (m.frame_parent[t.reference] != 0)
-        throw std::runtime_error("unsupported on the device yet: reference frame '" + m.frame_names[t.reference] +
-                                 "' moves with the configuration (only world-fixed reference frames)");
-    std::memcpy(ph.ref_pl, m.frame_placement[t.reference].data(), sizeof(double) * 12);
-
-    // support chain, root first
-    std::vector<int> chain;
-    for (int j = m.frame_parent[t.frame]; j > 0; j = m.joint_parent[j]) chain.insert(chain.begin(), j);
-    if (chain.empty()) throw std::runtime_error("task frame '" + m.frame_names[t.frame] + "' is fixed in the world: nothing to solve");
-    if (static_cast<int>(chain.size()) > kMaxChain)
-        throw std::runtime_error("unsupported on the device yet: support chain longer than " + std::to_string(kMaxChain) + " joints");
-    for (int j : chain)
-        if (m.joint_type[j] != IKGPU_JOINT_REVOLUTE)
-            throw std::runtime_error("unsupported on the device yet: joint '" + m.joint_names[j] + "' in the task support is not revolute");
-
-    ChainHost &c = ph.chain;
-    c.nj = static_cast<int>(chain.size());
-    double Pprev[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    for (int k = 0; k < c.nj; ++k) {
-        const int j = chain[k];
-        double P[9];
-        axis_frame(m.joint_axis[j], P);
-        SE3 pl = se3_mul(se3_mul(rot_only(Pprev, true), m.joint_placement[j]), rot_only(P, false));
-        std::memcpy(c.pl[k], pl.data(), sizeof(double) * 12);
-        c.qidx[k] = m.joint_idx_q[j];
-        c.vidx[k] = m.joint_idx_v[j];
-        c.lo[k] = m.lower[m.joint_idx_q[j]];
-        c.hi[k] = m.upper[m.joint_idx_q[j]];
-        ph.q_in_chain[m.joint_idx_q[j]] = 1;
-        std::memcpy(Pprev, P, sizeof P);
-    }
-    SE3 fpl = se3_mul(rot_only(Pprev, true), m.frame_placement[t.frame]);
-    std::memcpy(c.frame_pl, fpl.data(), sizeof(double) * 12);
-
-    ph.kind = KernelKind::Chain;
     static const char *kt[] = {"position", "orientation", "full"};
-    ph.kernel_name = "dls_chain<NJ=" + std::to_string(c.nj) + "," + kt[t.type] + ">";
+    const bool free_flyer = m.njoints() > 1 && m.joint_type[1] == IKGPU_JOINT_FREEFLYER;
+
+    if (!free_flyer) {
+        if (ntasks != 1)
+            throw std::runtime_error("unsupported on the device yet: more than one task on a fixed-base model");
+        const ikgpu_task &t = tasks[0];
+        if (m.frame_parent[t.reference] != 0)
+            throw std::runtime_error("unsupported on the device yet: reference frame '" + m.frame_names[t.reference] +
+                                     "' moves with the configuration (only world-fixed reference frames)");
+        std::memcpy(ph.ref_pl, m.frame_placement[t.reference].data(), sizeof(double) * 12);
+        std::vector<int> joints;
+        for (int j = m.frame_parent[t.frame]; j > 0; j = m.joint_parent[j]) joints.insert(joints.begin(), j);
+        if (joints.empty()) throw std::runtime_error("task frame '" + m.frame_names[t.frame] + "' is fixed in the world: nothing to solve");
+        ph.chain = build_chain(m, joints, t.frame, 0, ph.q_in_chain);
+        ph.kind = KernelKind::Chain;
+        ph.kernel_name = "dls_chain<NJ=" + std::to_string(ph.chain.nj) + "," + kt[t.type] + ">";
+        return ph;
+    }
+
+    // free-flyer base: chains hang off joint 1
+    for (int k = 0; k < 7; ++k) ph.q_in_chain[k] = 1;
+    int nchains = 0;
+    for (int i = 0; i < ntasks; ++i) {
+        const ikgpu_task &t = tasks[i];
+        if (m.frame_parent[t.reference] != 0 || !is_identity(m.frame_placement[t.reference]))
+            throw std::runtime_error("unsupported on the device yet: reference frame '" + m.frame_names[t.reference] +
+                                     "' on a free-flyer model (only the universe frame)");
+        std::vector<int> joints;
+        for (int j = m.frame_parent[t.frame]; j > 1; j = m.joint_parent[j]) joints.insert(joints.begin(), j);
+        if (m.frame_parent[t.frame] == 0)
+            throw std::runtime_error("task frame '" + m.frame_names[t.frame] + "' is fixed in the world: nothing to solve");
+        if (joints.empty()) {
+            if (ph.base_task >= 0) throw std::runtime_error("unsupported on the device yet: two tasks on the floating base link");
+            ph.base_task = i;
+            std::memcpy(ph.base_frame_pl, m.frame_placement[t.frame].data(), sizeof(double) * 12);
+        } else {
+            if (nchains == 2) throw std::runtime_error("unsupported on the device yet: more than two chain tasks on a free-flyer model");
+            (nchains == 0 ? ph.chain : ph.chainB) = build_chain(m, joints, t.frame, i, ph.q_in_chain);
+            ++nchains;
+        }
+    }
+    if (nchains == 0) throw std::runtime_error("unsupported on the device yet: free-flyer problem without a chain task");
+    ph.kind = KernelKind::Tree;
+    ph.kernel_name = "dls_tree<NA=" + std::to_string(ph.chain.nj) + ",NB=" + std::to_string(ph.chainB.nj) +
+                     (ph.base_task >= 0 ? ",base_task>" : ">");
     return ph;
 }
 
@@ -113,6 +163,30 @@ std::vector<double> chain_desc_table(const ProblemHost &ph) {
     return t;
 }
 
+std::vector<double> tree_desc_table(const ProblemHost &ph) {
+    std::vector<double> t;
+    auto put_chain = [&](const ChainHost &c) {
+        const int n = c.nj > 0 ? c.nj : 1;  // TreeDesc keeps one dummy slot for an absent chain
+        for (int j = 0; j < n; ++j) t.insert(t.end(), c.pl[j], c.pl[j] + 12);
+        t.insert(t.end(), c.frame_pl, c.frame_pl + 12);
+        t.insert(t.end(), c.lo, c.lo + n);
+        t.insert(t.end(), c.hi, c.hi + n);
+    };
+    put_chain(ph.chain);
+    put_chain(ph.chainB);
+    t.insert(t.end(), ph.base_frame_pl, ph.base_frame_pl + 12);
+    double w6[6];
+    auto put_w = [&](int task) {
+        for (double &x : w6) x = 0.0;
+        if (task >= 0) weights6(ph.tasks[task], w6);
+        t.insert(t.end(), w6, w6 + 6);
+    };
+    put_w(ph.chain.task);
+    put_w(ph.chainB.nj > 0 ? ph.chainB.task : -1);
+    put_w(ph.base_task);
+    return t;
+}
+
 void fill_chain_args(const ProblemHost &ph, double *ref_pl12, int *qidx, int *vidx, int *nq, int *nv, int *priority) {
     const ChainHost &c = ph.chain;
     for (int j = 0; j < c.nj; ++j) {
@@ -123,6 +197,25 @@ void fill_chain_args(const ProblemHost &ph, double *ref_pl12, int *qidx, int *vi
     *nq = ph.nq;
     *nv = ph.nv;
     *priority = ph.tasks[0].priority;
+}
+
+TreeArgsHost tree_args(const ProblemHost &ph) {
+    TreeArgsHost a{};
+    for (int j = 0; j < kMaxChain; ++j) {
+        a.qidxA[j] = ph.chain.qidx[j]; a.vidxA[j] = ph.chain.vidx[j];
+        a.qidxB[j] = ph.chainB.qidx[j]; a.vidxB[j] = ph.chainB.vidx[j];
+    }
+    const int slot_task[3] = {ph.chain.task, ph.chainB.nj > 0 ? ph.chainB.task : -1, ph.base_task};
+    for (int s = 0; s < 3; ++s) {
+        const int ti = slot_task[s];
+        a.tslot[s] = ti >= 0 ? ti : 0;
+        a.trow[s] = ti >= 0 ? ph.task_row[ti] : 0;
+        a.tdim[s] = ti >= 0 ? task_dim(ph.tasks[ti]) : 0;
+        a.trow0[s] = (ti >= 0 && ph.tasks[ti].type == IKGPU_ORIENTATION) ? 3 : 0;
+        a.prio[s] = ti >= 0 ? ph.tasks[ti].priority : 1;
+    }
+    a.hasP = ph.base_task >= 0 ? 1 : 0;
+    return a;
 }
 
 }  // namespace ikgpu

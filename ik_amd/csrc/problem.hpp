@@ -13,12 +13,15 @@ namespace ikgpu {
 
 constexpr int kMaxChain = 8;
 
-enum class KernelKind { Chain };
+// Chain: fixed base, ONE task whose support is a serial chain of revolute joints (shapes S, U).
+// Tree:  free-flyer base, up to two chain tasks + at most one task on the base link (shape F).
+enum class KernelKind { Chain, Tree };
 
-// Host copy of one serial chain (support of one task), axis-folded: every joint rotates about
-// its local z.  Filled by analyse_chain().
+// Host copy of one serial chain (support of one task below its base), axis-folded: every joint
+// rotates about its local z.
 struct ChainHost {
     int nj = 0;
+    int task = -1;  // index of the task in the (priority-ordered) task list
     int qidx[kMaxChain] = {};
     int vidx[kMaxChain] = {};
     double pl[kMaxChain][12] = {};
@@ -30,20 +33,32 @@ struct ProblemHost {
     KernelKind kind = KernelKind::Chain;
     std::string kernel_name;
     int nq = 0, nv = 0, ntasks = 0, rows = 0;
-    std::vector<ikgpu_task> tasks;
-    // chain kernels (single task)
-    ChainHost chain;
-    double ref_pl[12] = {};  // world placement of the (fixed) reference frame
+    std::vector<ikgpu_task> tasks;    // in stacking order (priority, then insertion)
+    std::vector<int> task_row;        // first row of each task in the stacked system
+    ChainHost chain;                  // Chain kind: the chain; Tree kind: chain A
+    ChainHost chainB;                 // Tree kind: chain B (nj = 0 when absent)
+    int base_task = -1;               // Tree kind: index of the task on the base link, or -1
+    double base_frame_pl[12] = {};    // base joint frame -> frame of the base task
+    double ref_pl[12] = {};           // Chain kind: world placement of the (fixed) reference frame
     std::vector<uint8_t> q_in_chain;  // [nq] 1 if the entry is integrated by the kernel
     std::vector<double> lower, upper;
 };
 
-// Throws std::runtime_error (unsupported shapes say so explicitly).
+// Throws std::runtime_error (unsupported shapes say so explicitly, message starts with "unsupported").
 ProblemHost analyse_problem(const Model &m, const ikgpu_task *tasks, int ntasks);
 
-// ikdev::ChainDesc<nj> as the flat array of doubles the kernels stage into LDS.
+// ikdev::ChainDesc<nj> / ikdev::TreeDesc<na, nb> as the flat array of doubles the kernels stage into LDS.
 std::vector<double> chain_desc_table(const ProblemHost &ph);
+std::vector<double> tree_desc_table(const ProblemHost &ph);
 // The per-problem scalars of ikdev::ChainKernelArgs<nj>.
 void fill_chain_args(const ProblemHost &ph, double *ref_pl12, int *qidx, int *vidx, int *nq, int *nv, int *priority);
+// The per-problem scalars of ikdev::TreeKernelArgs<na, nb>.
+struct TreeArgsHost {
+    int qidxA[kMaxChain], qidxB[kMaxChain], vidxA[kMaxChain], vidxB[kMaxChain];
+    int tslot[3], trow[3], tdim[3], trow0[3];
+    int prio[3];
+    int hasP;
+};
+TreeArgsHost tree_args(const ProblemHost &ph);
 
 }  // namespace ikgpu

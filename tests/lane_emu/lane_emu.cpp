@@ -1,14 +1,15 @@
-// lane_emu.cpp -- TEST HARNESS ONLY.  Runs the exact per-lane program of the gfx950 chain
-// kernels (ik_amd/csrc/device/chain_kernel_body.hpp) on the CPU, one "lane" after another, so
-// that the lane program and the host-side problem analysis can be checked against the oracle in
-// the GPU-less build container.  It is compiled by tests/ with g++ into its own shared object;
-// libikgpu.so neither contains nor calls it (the product has no CPU path).
+// lane_emu.cpp -- TEST HARNESS ONLY.  Runs the exact per-lane programs of the gfx950 kernels
+// (ik_amd/csrc/device/*_kernel_body.hpp) on the CPU, one "lane" after another, so that the lane
+// programs and the host-side problem analysis can be checked against the oracle in the GPU-less
+// build container.  It is compiled by tests/ with g++ into its own shared object; libikgpu.so
+// neither contains nor calls it (the product has no CPU path).
 #include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
 
 #include "device/chain_kernel_body.hpp"
+#include "device/tree_kernel_body.hpp"
 #include "ikgpu.h"
 #include "model.hpp"
 #include "problem.hpp"
@@ -17,50 +18,76 @@ namespace {
 
 thread_local std::string g_err;
 
-template <int NJ>
-struct Ctx {
-    ikdev::ChainKernelArgs<NJ> a{};
-    ikdev::ChainDesc<NJ> d{};
+struct IO {
+    int mode;  // 0: dls, 1: evaluate (e, J), 2: task-frame FK
+    int64_t B;
+    const double *q0, *targets;
+    const ikgpu_dls_params *prm;
+    double *q_out;
+    uint8_t *success;
+    int32_t *iters;
+    double *e_out, *J_out, *oMf_out;
+    int layout;
 };
 
-template <int NJ>
-Ctx<NJ> make_ctx(const ikgpu::ProblemHost &ph) {
-    Ctx<NJ> c;
+template <int NJ, int KT>
+void run_chain(const ikgpu::ProblemHost &ph, const IO &io) {
+    ikdev::ChainKernelArgs<NJ> a{};
+    ikdev::ChainDesc<NJ> d{};
     const std::vector<double> t = ikgpu::chain_desc_table(ph);
-    if (t.size() * sizeof(double) != sizeof(ikdev::ChainDesc<NJ>)) throw std::runtime_error("desc table size mismatch");
-    std::memcpy(&c.d, t.data(), sizeof c.d);
-    ikgpu::fill_chain_args(ph, c.a.ref_pl, c.a.qidx, c.a.vidx, &c.a.nq, &c.a.nv, &c.a.prm.priority);
-    c.a.lower = ph.lower.data();
-    c.a.upper = ph.upper.data();
-    c.a.q_in_chain = ph.q_in_chain.data();
-    return c;
+    if (t.size() * sizeof(double) != sizeof d) throw std::runtime_error("chain desc table size mismatch");
+    std::memcpy(&d, t.data(), sizeof d);
+    ikgpu::fill_chain_args(ph, a.ref_pl, a.qidx, a.vidx, &a.nq, &a.nv, &a.prm.priority);
+    a.lower = ph.lower.data(); a.upper = ph.upper.data(); a.q_in_chain = ph.q_in_chain.data();
+    a.layout = io.layout; a.B = io.B; a.q0 = io.q0; a.targets = io.targets;
+    a.q_out = io.q_out; a.success = io.success; a.iters = io.iters;
+    a.e_out = io.e_out; a.J_out = io.J_out; a.oMf_out = io.oMf_out;
+    if (io.prm) {
+        a.prm.max_iterations = io.prm->max_iterations;
+        a.prm.lam2 = io.prm->damping * io.prm->damping;
+        a.prm.step_length = io.prm->step_length;
+        a.prm.stop_sq_tol = io.prm->stop_sq_tol;
+    }
+    for (int64_t b = 0; b < io.B; ++b) {
+        if (io.mode == 0) ikdev::dls_chain_body<NJ, KT>(a, d, b, [](bool act) { return act; });
+        else if (io.mode == 1) ikdev::eval_chain_body<NJ, KT>(a, d, b);
+        else ikdev::fk_chain_body<NJ>(a, d, b);
+    }
 }
 
-template <int NJ, int KT>
-void run(const ikgpu::ProblemHost &ph, int mode, int64_t B, const double *q0, const double *targets,
-         const ikgpu_dls_params *prm, double *q_out, uint8_t *success, int32_t *iters, double *e_out, double *J_out,
-         double *oMf_out, int layout) {
-    Ctx<NJ> c = make_ctx<NJ>(ph);
-    c.a.layout = layout;
-    c.a.B = B;
-    c.a.q0 = q0;
-    c.a.targets = targets;
-    c.a.q_out = q_out;
-    c.a.success = success;
-    c.a.iters = iters;
-    c.a.e_out = e_out;
-    c.a.J_out = J_out;
-    c.a.oMf_out = oMf_out;
-    if (prm) {
-        c.a.prm.max_iterations = prm->max_iterations;
-        c.a.prm.lam2 = prm->damping * prm->damping;
-        c.a.prm.step_length = prm->step_length;
-        c.a.prm.stop_sq_tol = prm->stop_sq_tol;
+template <int NJ>
+struct HostPark {  // the device parks chain A's factor in LDS; on the host it simply stays where it is
+    void store(const ikdev::LegFactor<NJ> &) const {}
+    void load(ikdev::LegFactor<NJ> &) const {}
+};
+
+template <int NA, int NB>
+void run_tree(const ikgpu::ProblemHost &ph, const IO &io) {
+    ikdev::TreeKernelArgs<NA, NB> a{};
+    ikdev::TreeDesc<NA, NB> d{};
+    const std::vector<double> t = ikgpu::tree_desc_table(ph);
+    if (t.size() * sizeof(double) != sizeof d) throw std::runtime_error("tree desc table size mismatch");
+    std::memcpy(&d, t.data(), sizeof d);
+    const ikgpu::TreeArgsHost h = ikgpu::tree_args(ph);
+    for (int j = 0; j < NA; ++j) { a.qidxA[j] = h.qidxA[j]; a.vidxA[j] = h.vidxA[j]; }
+    for (int j = 0; j < NB; ++j) { a.qidxB[j] = h.qidxB[j]; a.vidxB[j] = h.vidxB[j]; }
+    for (int s = 0; s < 3; ++s) { a.tslot[s] = h.tslot[s]; a.trow[s] = h.trow[s]; a.tdim[s] = h.tdim[s]; a.trow0[s] = h.trow0[s]; }
+    a.prm.prioA = h.prio[0]; a.prm.prioB = h.prio[1]; a.prm.prioP = h.prio[2]; a.prm.hasP = h.hasP;
+    a.nq = ph.nq; a.nv = ph.nv; a.ntasks = ph.ntasks;
+    a.lower = ph.lower.data(); a.upper = ph.upper.data(); a.q_in_chain = ph.q_in_chain.data();
+    a.layout = io.layout; a.B = io.B; a.q0 = io.q0; a.targets = io.targets;
+    a.q_out = io.q_out; a.success = io.success; a.iters = io.iters;
+    if (io.mode == 1) { a.e_out = io.e_out; a.J_out = io.J_out; }
+    if (io.mode == 2) { a.oMf_out = io.oMf_out; a.targets = io.q0; }
+    if (io.prm) {
+        a.prm.max_iterations = io.prm->max_iterations;
+        a.prm.lam2 = io.prm->damping * io.prm->damping;
+        a.prm.step_length = io.prm->step_length;
+        a.prm.stop_sq_tol = io.prm->stop_sq_tol;
     }
-    for (int64_t b = 0; b < B; ++b) {
-        if (mode == 0) ikdev::dls_chain_body<NJ, KT>(c.a, c.d, b, [](bool act) { return act; });
-        else if (mode == 1) ikdev::eval_chain_body<NJ, KT>(c.a, c.d, b);
-        else ikdev::fk_chain_body<NJ>(c.a, c.d, b);
+    for (int64_t b = 0; b < io.B; ++b) {
+        if (io.mode == 0) ikdev::dls_tree_body<NA, NB>(a, d, b, HostPark<NA>{}, [](bool act) { return act; });
+        else ikdev::eval_tree_body<NA, NB>(a, d, b);
     }
 }
 
@@ -70,24 +97,31 @@ extern "C" {
 
 const char *lane_emu_last_error(void) { return g_err.c_str(); }
 
-// mode 0: dls, 1: evaluate, 2: task-frame FK.  Host pointers, same layouts as include/ikgpu.h.
-int lane_emu_run(const char *urdf, size_t len, int root_joint, const ikgpu_task *task, int mode, int64_t B,
-                 const double *q0, const double *targets, const ikgpu_dls_params *prm, double *q_out,
-                 uint8_t *success, int32_t *iters, double *e_out, double *J_out, double *oMf_out, int layout) {
+// Host pointers, same layouts as include/ikgpu.h.  tasks must be in stacking order.
+int lane_emu_run(const char *urdf, size_t len, int root_joint, const ikgpu_task *tasks, int ntasks, int mode, int64_t B,
+                 const double *q0, const double *targets, const ikgpu_dls_params *prm, double *q_out, uint8_t *success,
+                 int32_t *iters, double *e_out, double *J_out, double *oMf_out, int layout) {
     try {
         ikgpu::Model m = ikgpu::Model::from_urdf(urdf, len, root_joint != 0);
-        ikgpu::ProblemHost ph = ikgpu::analyse_problem(m, task, 1);
-        const int nj = ph.chain.nj, kt = task->type;
-#define X(N)                                                                                                               \
-    if (nj == N) {                                                                                                         \
-        if (kt == 2) run<N, 2>(ph, mode, B, q0, targets, prm, q_out, success, iters, e_out, J_out, oMf_out, layout);       \
-        else if (kt == 0) run<N, 0>(ph, mode, B, q0, targets, prm, q_out, success, iters, e_out, J_out, oMf_out, layout);  \
-        else run<N, 1>(ph, mode, B, q0, targets, prm, q_out, success, iters, e_out, J_out, oMf_out, layout);               \
-        return 0;                                                                                                          \
+        ikgpu::ProblemHost ph = ikgpu::analyse_problem(m, tasks, ntasks);
+        const IO io{mode, B, q0, targets, prm, q_out, success, iters, e_out, J_out, oMf_out, layout};
+        if (ph.kind == ikgpu::KernelKind::Chain) {
+            const int nj = ph.chain.nj, kt = tasks[0].type;
+#define X(N)                                       \
+    if (nj == N) {                                 \
+        if (kt == 2) run_chain<N, 2>(ph, io);      \
+        else if (kt == 0) run_chain<N, 0>(ph, io); \
+        else run_chain<N, 1>(ph, io);              \
+        return 0;                                  \
     }
-        X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
+            X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
 #undef X
-        g_err = "chain length not instantiated";
+        } else {
+            const int na = ph.chain.nj, nb = ph.chainB.nj;
+            if (na == 7 && nb == 7) { run_tree<7, 7>(ph, io); return 0; }
+            if (na == 7 && nb == 0) { run_tree<7, 0>(ph, io); return 0; }
+        }
+        g_err = "shape not instantiated in the lane emulator: " + ph.kernel_name;
         return 1;
     } catch (const std::exception &e) {
         g_err = e.what();

@@ -233,3 +233,108 @@ def test_error_behaviour(torch_cuda):
     # B = 0 is a no-op
     Q, ok, it = ik_amd.dls_batch(problem, Q0[:, :0].contiguous(), T[:, :, :0].contiguous(), data)
     assert Q.shape == (16, 0)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Shape F (BASELINE.json configs[2]): Cassie full body, free-flyer base, nq = 23 / nv = 22,
+# LeftFootFront + RightFootFront + pelvis SE(3) tasks (M = 18)
+# ---------------------------------------------------------------------------------------------------
+def _setup_full_body(types=(2, 2, 2), weights=(None, None, None), prios=(0, 0, 0),
+                     frames=("LeftFootFront", "RightFootFront", "pelvis")):
+    import ik_amd
+    import oracle as O
+    model = ik_amd.Model.from_urdf_file(urdf_path("cassie"), free_flyer=True)
+    problem = ik_amd.InverseKinematicsProblem(model, max(prios))
+    spec = []
+    for i, f in enumerate(frames):
+        t = problem.add_frame_task("t%d" % i, ik_amd.FrameTask.create(model, f, ik_amd.KinematicType(types[i])), prios[i])
+        if weights[i] is not None:
+            t.weighting()[:] = weights[i]
+    for t, prio in problem.ordered_tasks():
+        w = None if np.all(t.weighting() == 1) else list(t.weighting())
+        spec.append((t._frame_id, 0, int(t.type), prio, w))
+    data = ik_amd.dls_data(problem, device=0)
+    om = O.OracleModel(model.flat())
+    return ik_amd, O, model, problem, data, om, O.make_tasks(spec), [s[0] for s in spec]
+
+
+def _full_body_inputs(model, B, mode="near", seed=0):
+    from ik_amd import workload
+    return workload.freeflyer_workload(model.lowerPositionLimit, model.upperPositionLimit,
+                                       workload.cassie_nominal(model.names), np.arange(B), seed=seed, mode=mode)
+
+
+def test_full_body_stages_match_oracle(torch_cuda):
+    torch = torch_cuda
+    ik_amd, O, model, problem, data, om, ot, fids = _setup_full_body()
+    assert data.kernel == "dls_tree<NA=7,NB=7,base_task>" and data.rows == 18
+    B = 200
+    q0, qs = _full_body_inputs(model, B)
+    got = ik_amd.task_frames_fk_batch(problem, _to_dev(torch, qs), data).permute(2, 0, 1).cpu().numpy()
+    tg = O.fk_batch(om, qs, fids)
+    assert np.abs(got - tg).max() < 1e-13
+    T = torch.from_numpy(np.ascontiguousarray(tg.transpose(1, 2, 0))).cuda()
+    e, J = ik_amd.evaluate_batch(problem, _to_dev(torch, q0), T, data)
+    e, J = e.cpu().numpy().T, J.permute(2, 0, 1).cpu().numpy()
+    for b in range(B):
+        eo, Jo = O.evaluate(om, ot, tg[b], q0[b])
+        assert np.abs(e[b] - eo).max() < 1e-10 and np.abs(J[b] - Jo).max() < 1e-10
+
+
+@pytest.mark.parametrize("mode,stop_tol,iters", [("near", -1.0, 50), ("near", 1e-4, 100), ("near", -1.0, 1), ("uniform", -1.0, 3)])
+def test_full_body_dls_matches_oracle(torch_cuda, mode, stop_tol, iters):
+    torch = torch_cuda
+    ik_amd, O, model, problem, data, om, ot, fids = _setup_full_body()
+    B = 2048
+    q0, qs = _full_body_inputs(model, B, mode)
+    tg = O.fk_batch(om, qs, fids)
+    T = torch.from_numpy(np.ascontiguousarray(tg.transpose(1, 2, 0))).cuda()
+    Q, ok, it = ik_amd.dls_batch(problem, _to_dev(torch, q0), T, data, ik_amd.inverse_kinematics_visitor(stop_tol),
+                                 ik_amd.dls_parameters(max_iterations=iters))
+    q_ref, ok_ref, it_ref = O.dls_batch(om, ot, tg, q0, O.params(iters, 1e-2, 1.0, stop_tol), os.cpu_count() or 1)
+    assert np.array_equal(ok.cpu().numpy(), ok_ref) and np.array_equal(it.cpu().numpy(), it_ref)
+    assert np.abs(Q.cpu().numpy().T - q_ref).max() <= TOL
+    # AoS gives the same bits
+    Qa, oka, ita = ik_amd.dls_batch(problem, torch.from_numpy(q0).cuda(), torch.from_numpy(tg).cuda(), data,
+                                    ik_amd.inverse_kinematics_visitor(stop_tol), ik_amd.dls_parameters(max_iterations=iters), layout="aos")
+    assert torch.equal(Q.T.contiguous(), Qa) and torch.equal(ok, oka) and torch.equal(it, ita)
+
+
+def test_full_body_types_weights_priorities(torch_cuda):
+    torch = torch_cuda
+    ik_amd, O, model, problem, data, om, ot, fids = _setup_full_body(
+        types=(0, 2, 1), weights=([2.0, 1.0, 0.5], [1, 1, 1, 0.3, 0.3, 0.3], None), prios=(0, 0, 1))
+    B = 512
+    q0, qs = _full_body_inputs(model, B)
+    tg = O.fk_batch(om, qs, fids)
+    T = torch.from_numpy(np.ascontiguousarray(tg.transpose(1, 2, 0))).cuda()
+    for iters, tol in ((1, -1.0), (30, 1e-4)):
+        Q, ok, it = ik_amd.dls_batch(problem, _to_dev(torch, q0), T, data, ik_amd.inverse_kinematics_visitor(tol),
+                                     ik_amd.dls_parameters(max_iterations=iters))
+        q_ref, ok_ref, it_ref = O.dls_batch(om, ot, tg, q0, O.params(iters, 1e-2, 1.0, tol))
+        assert np.array_equal(ok.cpu().numpy(), ok_ref) and np.array_equal(it.cpu().numpy(), it_ref)
+        assert np.abs(Q.cpu().numpy().T - q_ref).max() <= TOL
+
+
+def test_full_body_full_size_properties(torch_cuda):
+    """BASELINE.json configs[2] at its full batch (65536): round trip, idempotence, determinism, unit
+    quaternions, joint limits."""
+    torch = torch_cuda
+    ik_amd, O, model, problem, data, om, ot, fids = _setup_full_body()
+    B = 65536
+    q0, qs = _full_body_inputs(model, B)
+    Q0, QS = _to_dev(torch, q0), _to_dev(torch, qs)
+    T = ik_amd.task_frames_fk_batch(problem, QS, data)
+    v, p = ik_amd.never_stop_visitor(), ik_amd.dls_parameters(max_iterations=50)
+    Q1, _, _ = ik_amd.dls_batch(problem, Q0, T, data, v, p)
+    Q2, _, _ = ik_amd.dls_batch(problem, Q0, T, data, v, p)
+    assert torch.equal(Q1, Q2)
+    res = (ik_amd.task_frames_fk_batch(problem, Q1, data) - T).abs().amax(dim=(0, 1))
+    conv = res < 1e-9
+    assert conv.double().mean().item() > 0.95
+    Q3, _, _ = ik_amd.dls_batch(problem, Q1, T, data, v, ik_amd.dls_parameters(max_iterations=5))
+    assert (Q3 - Q1)[:, conv].abs().max().item() < 1e-8
+    assert ((Q1[3:7] ** 2).sum(0).sqrt() - 1).abs().max().item() < 1e-12
+    lo = torch.from_numpy(model.lowerPositionLimit).cuda()[7:, None]
+    hi = torch.from_numpy(model.upperPositionLimit).cuda()[7:, None]
+    assert bool(((Q1[7:] >= lo) & (Q1[7:] <= hi)).all())

@@ -20,7 +20,8 @@ def emu(native_built):
     out = os.path.join(ROOT, "tests", "lane_emu", "liblane_emu.so")
     deps = [src] + [os.path.join(ROOT, "ik_amd", "csrc", f) for f in
                     ("model.cpp", "problem.cpp", "model.hpp", "problem.hpp", "device/lane_math.hpp",
-                     "device/chain_solver.hpp", "device/chain_kernel_body.hpp")]
+                     "device/chain_solver.hpp", "device/chain_kernel_body.hpp", "device/tree_solver.hpp",
+                     "device/tree_kernel_body.hpp")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
                                "-I" + os.path.join(ROOT, "ik_amd", "csrc"), "-o", out, src,
@@ -30,13 +31,14 @@ def emu(native_built):
     return L
 
 
-def run(L, urdf, task, mode, q0, tg, prm, nv, M, layout=1):
+def run(L, urdf, task, mode, q0, tg, prm, nv, M, layout=1, root=0, ntasks=1):
     B, nq = (q0.shape[0], q0.shape[1]) if layout == 1 else (q0.shape[1], q0.shape[0])
     qo = np.empty_like(q0)
     ok, it = np.zeros(B, np.uint8), np.zeros(B, np.int32)
-    e, J, oMf = np.empty((B, M)), np.empty((B, M, nv)), np.empty((B, 1, 12))
+    e, J, oMf = np.empty((B, M)), np.empty((B, M, nv)), np.empty((B, ntasks, 12))
     p = lambda a: C.c_void_p(a.ctypes.data)
-    rc = L.lane_emu_run(urdf, C.c_size_t(len(urdf)), 0, C.byref(task), mode, C.c_int64(B), p(q0), p(tg),
+    tasks = task if ntasks > 1 else C.byref(task)
+    rc = L.lane_emu_run(urdf, C.c_size_t(len(urdf)), root, tasks, ntasks, mode, C.c_int64(B), p(q0), p(tg),
                         C.byref(prm) if prm is not None else None, p(qo), p(ok), p(it), p(e), p(J), p(oMf), layout)
     assert rc == 0, L.lane_emu_last_error()
     return qo, ok, it, e, J, oMf
@@ -120,3 +122,79 @@ def test_lane_program_general_axis_and_far_targets_stepwise(emu):
         qo, *_ = run(emu, xml, task, 0, q0, tg, capi.DlsParams(iters, 1e-2, 1.0, -1.0), 6, 6)
         q_ref, _, _ = O.dls_batch(om, ot, tg, q0, O.params(iters, 1e-2, 1.0, -1.0))
         assert np.abs(qo - q_ref).max() < bar
+
+
+# ---------------------------------------------------------------------------------------------------
+# free-flyer tree program (shape F: Cassie full body, LeftFootFront + RightFootFront + pelvis)
+# ---------------------------------------------------------------------------------------------------
+def setup_full_body(B, types=(2, 2, 2), weights=(None, None, None), prios=(0, 0, 0), frames=("LeftFootFront", "RightFootFront", "pelvis")):
+    import ik_amd
+    from ik_amd import capi, workload
+    urdf = open(urdf_path("cassie"), "rb").read()
+    model = ik_amd.Model.from_urdf_xml(urdf, free_flyer=True)
+    om = O.OracleModel(model.flat())
+    fids = [model.getFrameId(f) for f in frames]
+    q0, qs = workload.freeflyer_workload(model.lowerPositionLimit, model.upperPositionLimit,
+                                         workload.cassie_nominal(model.names), np.arange(B), seed=0,
+                                         integrate=lambda q, v: O.integrate(om, q, v))
+    tg = O.fk_batch(om, qs, fids)
+    tasks = (capi.Task * len(fids))()
+    spec = []
+    for i, f in enumerate(fids):
+        w = weights[i]
+        ww = list(w) + [1.0] * (6 - len(w)) if w is not None else [1.0] * 6
+        tasks[i] = capi.Task(f, 0, types[i], prios[i], (C.c_double * 6)(*ww))
+        spec.append((f, 0, types[i], prios[i], w))
+    return urdf, model, om, tasks, O.make_tasks(spec), q0, qs, tg, fids
+
+
+def test_tree_program_stagewise(emu):
+    urdf, model, om, tasks, ot, q0, qs, tg, fids = setup_full_body(48)
+    *_, oMf = run(emu, urdf, tasks, 2, qs, tg, None, model.nv, 18, root=1, ntasks=3)
+    assert np.abs(oMf - tg).max() < 1e-14
+    _, _, _, e, J, _ = run(emu, urdf, tasks, 1, q0, tg, None, model.nv, 18, root=1, ntasks=3)
+    for b in range(q0.shape[0]):
+        eo, Jo = O.evaluate(om, ot, tg[b], q0[b])
+        assert np.abs(e[b] - eo).max() < 1e-12 and np.abs(J[b] - Jo).max() < 1e-12
+
+
+@pytest.mark.parametrize("iters,tol", [(1, -1.0), (3, -1.0), (50, -1.0), (100, 1e-4), (0, 1e-4)])
+def test_tree_program_full_loop(emu, iters, tol):
+    """The arrow-structured primal solve (7x7 Cholesky per chain + 6x6 Schur complement on the base) returns
+    the dq of the reference's dense 18x18 dual solve; the base moves by SE(3) integration (App. A.5)."""
+    from ik_amd import capi
+    urdf, model, om, tasks, ot, q0, qs, tg, fids = setup_full_body(64)
+    q0[:, 13] += 4.0  # LeftAchillesSpring: outside every support, beyond its limit -> clamped iff a step is taken
+    prm = capi.DlsParams(iters, 1e-2, 1.0, tol)
+    qo, ok, it, *_ = run(emu, urdf, tasks, 0, q0, tg, prm, model.nv, 18, root=1, ntasks=3)
+    q_ref, ok_ref, it_ref = O.dls_batch(om, ot, tg, q0, O.params(iters, 1e-2, 1.0, tol))
+    assert np.array_equal(ok, ok_ref) and np.array_equal(it, it_ref)
+    assert np.abs(qo - q_ref).max() < 1e-9
+    assert np.abs(np.linalg.norm(qo[:, 3:7], axis=1) - 1).max() < 1e-12
+
+
+def test_tree_program_types_weights_priorities(emu):
+    """Position / Orientation tasks are Full tasks with zero-weight rows in the primal form; the stop test
+    reads priority-0 rows only (reference ik/ik/visitor.hpp:19)."""
+    from ik_amd import capi
+    urdf, model, om, tasks, ot, q0, qs, tg, fids = setup_full_body(
+        32, types=(0, 2, 1), weights=([2.0, 1.0, 0.5], [1, 1, 1, 0.3, 0.3, 0.3], None), prios=(0, 0, 1))
+    M = 3 + 6 + 3
+    _, _, _, e, J, _ = run(emu, urdf, tasks, 1, q0, tg, None, model.nv, M, root=1, ntasks=3)
+    eo, Jo = O.evaluate(om, ot, tg[3], q0[3])
+    assert np.abs(e[3] - eo).max() < 1e-12 and np.abs(J[3] - Jo).max() < 1e-12
+    for iters, tol in ((1, -1.0), (30, 1e-4)):
+        prm = capi.DlsParams(iters, 1e-2, 1.0, tol)
+        qo, ok, it, *_ = run(emu, urdf, tasks, 0, q0, tg, prm, model.nv, M, root=1, ntasks=3)
+        q_ref, ok_ref, it_ref = O.dls_batch(om, ot, tg, q0, O.params(iters, 1e-2, 1.0, tol))
+        assert np.array_equal(ok, ok_ref) and np.array_equal(it, it_ref) and np.abs(qo - q_ref).max() < 1e-8
+
+
+def test_tree_program_single_chain_plus_base_task(emu):
+    from ik_amd import capi
+    urdf, model, om, tasks, ot, q0, qs, tg, fids = setup_full_body(32, types=(2, 2), weights=(None, None), prios=(0, 0),
+                                                                     frames=("RightFootBack", "pelvis"))
+    prm = capi.DlsParams(20, 1e-2, 1.0, -1.0)
+    qo, ok, it, *_ = run(emu, urdf, tasks, 0, q0, tg, prm, model.nv, 12, root=1, ntasks=2)
+    q_ref, _, _ = O.dls_batch(om, ot, tg, q0, O.params(20, 1e-2, 1.0, -1.0))
+    assert np.abs(qo - q_ref).max() < 1e-9
