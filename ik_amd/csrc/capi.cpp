@@ -26,7 +26,7 @@ thread_local std::string g_last_error;
 
 bool shape_built(const ikgpu::ProblemHost &ph) {
     return ph.kind == ikgpu::KernelKind::Chain ? ikgpu::chain_shape_built(ph.chain.nj, ph.tasks[0].type)
-                                               : ikgpu::tree_shape_built(ph.chain.nj, ph.chainB.nj);
+                                               : ikgpu::tree_shape_built(ph.chain.nj, ph.chainB.nj > 0 ? 2 : 1);
 }
 
 int fail(int code, const std::string &msg) {

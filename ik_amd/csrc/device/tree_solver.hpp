@@ -22,23 +22,27 @@
 
 namespace ikdev {
 
-template <int NA, int NB>
+// Constant table of one chain (axis-folded, see chain_solver.hpp) and of the whole problem.
+template <int NJ>
+struct ChainTable {
+    double pl[NJ][12];  // pl[0]: base joint frame -> first joint of the chain; pl[j]: joint j-1 -> j
+    double fr[12];      // last joint -> task frame
+    double lo[NJ], hi[NJ];
+    double w[6];        // six-row weights (zeros on rows the task's kinematic type drops)
+};
+
+template <int NJ, int NCH>
 struct TreeDesc {
-    double plA[NA > 0 ? NA : 1][12];  // plA[0]: base joint frame -> first joint of chain A (axis-folded)
-    double frA[12];                   // last joint of chain A -> task frame
-    double loA[NA > 0 ? NA : 1], hiA[NA > 0 ? NA : 1];
-    double plB[NB > 0 ? NB : 1][12];
-    double frB[12];
-    double loB[NB > 0 ? NB : 1], hiB[NB > 0 ? NB : 1];
-    double frP[12];                   // base joint frame -> frame of the base task
-    double wA[6], wB[6], wP[6];       // six-row weights (zeros on rows the task's kinematic type drops)
+    ChainTable<NJ> chain[NCH];
+    double frP[12];  // base joint frame -> frame of the base task
+    double wP[6];
 };  // all doubles: staged HBM -> LDS as a flat table
 
 struct TreeParams {
     int max_iterations;
     double lam2, step_length, stop_sq_tol;
-    int prioA, prioB, prioP;  // priority level per task; the stop test sums priority-0 rows
-    int hasP;                 // a base task is present
+    int prio[2], prioP;  // priority level per task; the stop test sums priority-0 rows
+    int hasP;            // a base task is present
 };
 
 // Packed lower-triangular index
@@ -354,12 +358,14 @@ IKD_FN void freeflyer_integrate(const double (&qb)[7], const double (&R1)[9], co
     for (int k = 0; k < 4; ++k) out[3 + k] = rq[k] * al;
 }
 
-// Storage hooks for the first chain's factor while the second chain is processed: on the device
-// they park L and W in LDS ([entry][lane], conflict-free ds_write/read_b64); on the host they copy.
-template <int NA, int NB, class Park, class AnyFn>
-IKD_FN void tree_dls(const TreeDesc<NA, NB> &d, const TreeParams &prm, double (&qb)[7], double (&qa)[NA > 0 ? NA : 1],
-                     double (&qbj)[NB > 0 ? NB : 1], const double *targets_lane, int64_t tstride, const int (&tslot)[3],
-                     int &iters_out, bool &success_out, Park park, AnyFn any_active) {
+// One full solve.  The chains share ONE copy of the evaluation / factorisation code (a rolled 2-trip
+// loop: the unrolled body of one chain is ~3000 instructions, two inlined copies overflow the
+// instruction cache).  Chain 0's factor (L, W) is parked while chain 1 is processed -- `park` stores /
+// reloads it: LDS [entry][lane] on the device (conflict-free ds_write/read_b64), a plain copy on the host.
+template <int NJ, int NCH, class Park, class AnyFn>
+IKD_FN void tree_dls(const TreeDesc<NJ, NCH> &d, const TreeParams &prm, double (&qb)[7], double (&qj)[NCH][NJ],
+                     const double *targets_lane, int64_t tstride, const int (&tslot)[3], int &iters_out,
+                     bool &success_out, Park park, AnyFn any_active) {
     bool active = true, success = false;
     int iters = prm.max_iterations;
 #pragma unroll 1
@@ -375,20 +381,22 @@ IKD_FN void tree_dls(const TreeDesc<NA, NB> &d, const TreeParams &prm, double (&
             for (int j = 0; j <= i; ++j) Hbb[tri(i, j)] = (i == j) ? prm.lam2 : 0.0;
             gb[i] = 0.0;
         }
-        LegFactor<(NA > 0 ? NA : 1)> FA;
-        LegFactor<(NB > 0 ? NB : 1)> FB;
-        if (NA > 0) {
-            double oMt[12];
+        LegFactor<NJ> F;
+        double u0[NJ];
+#pragma unroll 1
+        for (int c = 0; c < NCH; ++c) {
+            const ChainTable<NJ> &ct = d.chain[c];
+            double q[NJ], oMt[12];
 #pragma unroll
-            for (int k = 0; k < 12; ++k) oMt[k] = targets_lane[(tslot[0] * 12 + k) * tstride];
-            leg_eval_factor<(NA > 0 ? NA : 1)>(R1, p1, d.plA, d.frA, d.wA, qa, oMt, prm.lam2, prm.prioA == 0, Hbb, gb, e0sq, FA);
-            if (NB > 0) park.store(FA);
-        }
-        if (NB > 0) {
-            double oMt[12];
+            for (int j = 0; j < NJ; ++j) q[j] = (NCH > 1 && c == 1) ? qj[NCH - 1][j] : qj[0][j];
 #pragma unroll
-            for (int k = 0; k < 12; ++k) oMt[k] = targets_lane[(tslot[1] * 12 + k) * tstride];
-            leg_eval_factor<(NB > 0 ? NB : 1)>(R1, p1, d.plB, d.frB, d.wB, qbj, oMt, prm.lam2, prm.prioB == 0, Hbb, gb, e0sq, FB);
+            for (int k = 0; k < 12; ++k) oMt[k] = targets_lane[(tslot[c] * 12 + k) * tstride];
+            leg_eval_factor<NJ>(R1, p1, ct.pl, ct.fr, ct.w, q, oMt, prm.lam2, prm.prio[c] == 0, Hbb, gb, e0sq, F);
+            if (NCH > 1 && c == 0) {
+                park.store(F);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) u0[j] = F.u[j];
+            }
         }
         if (prm.hasP) {
             double oMt[12];
@@ -424,23 +432,22 @@ IKD_FN void tree_dls(const TreeDesc<NA, NB> &d, const TreeParams &prm, double (&
         if (stop_now) { success = true; iters = it; }
         active = active && !stop_now;
 
-        if (NB > 0) {
-            double dql[NB > 0 ? NB : 1];
-            leg_back_substitute<(NB > 0 ? NB : 1)>(FB, dqb, dql);
+#pragma unroll 1
+        for (int c = NCH - 1; c >= 0; --c) {
+            const ChainTable<NJ> &ct = d.chain[c];
+            if (NCH > 1 && c == 0) {
+                park.load(F);
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const double qc = dmin(d.hiB[j], dmax(dfma(prm.step_length, dql[j], qbj[j]), d.loB[j]));
-                qbj[j] = active ? qc : qbj[j];
+                for (int j = 0; j < NJ; ++j) F.u[j] = u0[j];
             }
-        }
-        if (NA > 0) {
-            if (NB > 0) park.load(FA);
-            double dql[NA > 0 ? NA : 1];
-            leg_back_substitute<(NA > 0 ? NA : 1)>(FA, dqb, dql);
+            double dql[NJ];
+            leg_back_substitute<NJ>(F, dqb, dql);
 #pragma unroll
-            for (int j = 0; j < NA; ++j) {
-                const double qc = dmin(d.hiA[j], dmax(dfma(prm.step_length, dql[j], qa[j]), d.loA[j]));
-                qa[j] = active ? qc : qa[j];
+            for (int j = 0; j < NJ; ++j) {
+                const double qold = (NCH > 1 && c == 1) ? qj[NCH - 1][j] : qj[0][j];
+                const double qc = dmin(ct.hi[j], dmax(dfma(prm.step_length, dql[j], qold), ct.lo[j]));
+                const double qn = active ? qc : qold;
+                if (NCH > 1 && c == 1) qj[NCH - 1][j] = qn; else qj[0][j] = qn;
             }
         }
         {

@@ -1,0 +1,415 @@
+// ik_gpu.hpp -- C++ host-side mirror of the reference's API for the DLS path, header-only over the
+// C ABI (include/ikgpu.h, libikgpu.so).  A caller of dazzmo/ik keeps its code:
+//
+//     ik::model_t model;
+//     ik::urdf::buildModelFromXML(xml, ik::JointModelFreeFlyer(), model);      // ik_ros/src/cassie.cpp:34-35
+//     ik::InverseKinematicsProblem problem(model, 1);                           // ik/ik/problem.hpp:17
+//     auto foot = ik::FrameTask::create(model, "LeftFootFront", ik::KinematicType::Full);   // ik/ik/frame.hpp:123
+//     problem.add_frame_task("fl", foot);                                       // ik/ik/problem.hpp:55
+//     ik::dls_data data(problem);                                               // ik/ik/dls.hpp:36
+//     foot->target.translation() << 0.0, 0.1, -0.6;                             // ik_ros/src/cassie.cpp:95
+//     ik::dls_parameters p;  p.damping = 1e-2;                                  // ik/ik/dls.hpp:24
+//     q = ik::dls(problem, q, data, ik::inverse_kinematics_visitor(), p);       // ik/ik/dls.hpp:111
+//
+// and gains ik::dls_batch(...) for B problems in lockstep on one MI355X.  Pinocchio and Eigen are not
+// needed: the few value types the path touches (vector_t, se3_t, model_t) are provided here with the
+// member names the reference code uses.  No arithmetic of the solve happens on the host.
+//
+// Differences that cannot be hidden, by design of a device path:
+//   * a C++ visitor cannot run inside a kernel: inverse_kinematics_visitor carries the one-parameter
+//     family of ik/ik/visitor.hpp:19 (`||e[0]||^2 < tolerance`); override stop_tolerance(), not should_stop();
+//   * only FrameTask is accelerated (SURVEY.md section 8f lists the rest as "next");
+//   * failures of the device call throw std::runtime_error (the reference has no failure channel).
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <fstream>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#include "ikgpu.h"
+
+namespace ik {
+
+typedef int int_t;
+typedef std::size_t index_t;
+typedef double number_t;
+typedef std::string string_t;
+
+// ---- the slice of Eigen::VectorXd the path uses (ik/ik/common.hpp:31) -----------------------------
+class vector_t {
+   public:
+    vector_t() = default;
+    explicit vector_t(index_t n, number_t v = 0.0) : d_(n, v) {}
+    vector_t(std::initializer_list<number_t> l) : d_(l) {}
+    static vector_t Zero(index_t n) { return vector_t(n, 0.0); }
+    static vector_t Ones(index_t n) { return vector_t(n, 1.0); }
+    static vector_t Constant(index_t n, number_t v) { return vector_t(n, v); }
+    index_t size() const { return d_.size(); }
+    index_t rows() const { return d_.size(); }
+    number_t &operator[](index_t i) { return d_[i]; }
+    const number_t &operator[](index_t i) const { return d_[i]; }
+    number_t &operator()(index_t i) { return d_[i]; }
+    const number_t &operator()(index_t i) const { return d_[i]; }
+    number_t *data() { return d_.data(); }
+    const number_t *data() const { return d_.data(); }
+    void setZero() { for (auto &x : d_) x = 0.0; }
+    void setOnes() { for (auto &x : d_) x = 1.0; }
+    void setConstant(number_t v) { for (auto &x : d_) x = v; }
+    number_t squaredNorm() const { number_t s = 0; for (auto x : d_) s += x * x; return s; }
+    bool operator==(const vector_t &o) const { return d_ == o.d_; }
+
+   private:
+    std::vector<number_t> d_;
+};
+
+// Eigen-style comma initialiser for the fixed-size accessors below: v << a, b, c;
+class comma_init {
+   public:
+    comma_init(number_t *p, int n, number_t first) : p_(p), n_(n), k_(0) { put(first); }
+    comma_init &operator,(number_t v) { put(v); return *this; }
+
+   private:
+    void put(number_t v) { if (k_ >= n_) throw std::out_of_range("too many coefficients in comma initialiser"); p_[k_++] = v; }
+    number_t *p_;
+    int n_, k_;
+};
+
+class vector3_ref {
+   public:
+    explicit vector3_ref(number_t *p) : p_(p) {}
+    number_t &operator[](int i) { return p_[i]; }
+    number_t &operator()(int i) { return p_[i]; }
+    comma_init operator<<(number_t v) { return comma_init(p_, 3, v); }
+    void setZero() { p_[0] = p_[1] = p_[2] = 0.0; }
+
+   private:
+    number_t *p_;
+};
+
+class matrix3_ref {  // row-major 3 x 3
+   public:
+    explicit matrix3_ref(number_t *p) : p_(p) {}
+    number_t &operator()(int i, int j) { return p_[3 * i + j]; }
+    comma_init operator<<(number_t v) { return comma_init(p_, 9, v); }  // row by row, as Eigen
+    void setIdentity() { for (int i = 0; i < 9; ++i) p_[i] = (i % 4 == 0) ? 1.0 : 0.0; }
+
+   private:
+    number_t *p_;
+};
+
+// ---- pinocchio::SE3 as the path uses it (ik/ik/common.hpp:19; ik/ik/frame.hpp:189) ---------------
+class se3_t {
+   public:
+    se3_t() { setIdentity(); }
+    static se3_t Identity() { return se3_t(); }
+    void setIdentity() { for (int i = 0; i < 12; ++i) m_[i] = (i < 9 && i % 4 == 0) ? 1.0 : 0.0; }
+    matrix3_ref rotation() { return matrix3_ref(m_); }
+    vector3_ref translation() { return vector3_ref(m_ + 9); }
+    const number_t *data() const { return m_; }  // rotation row-major (9) + translation (3): the ABI's SE(3)
+    number_t *data() { return m_; }
+
+   private:
+    number_t m_[12];
+};
+
+// ---- pinocchio::Model as the path reads it (ik/ik/common.hpp:16) --------------------------------
+struct JointModelFreeFlyer {};
+
+class model_t {
+   public:
+    model_t() = default;
+    int nq = 0, nv = 0, njoints = 0, nframes = 0;
+    std::vector<string_t> names;        // joint names, "universe" first
+    std::vector<string_t> frame_names;
+    vector_t lowerPositionLimit, upperPositionLimit;
+
+    index_t getFrameId(const string_t &name) const { return static_cast<index_t>(ikgpu_model_frame_id(h_.get(), name.c_str())); }
+    index_t getJointId(const string_t &name) const { return static_cast<index_t>(ikgpu_model_joint_id(h_.get(), name.c_str())); }
+    bool existFrame(const string_t &name) const { return getFrameId(name) < static_cast<index_t>(nframes); }
+    const ikgpu_model *handle() const { return h_.get(); }
+
+    void adopt(ikgpu_model *h) {
+        h_ = std::shared_ptr<ikgpu_model>(h, ikgpu_model_destroy);
+        ikgpu_flat_model f;
+        if (ikgpu_model_get_flat(h, &f) != IKGPU_OK) throw std::runtime_error(ikgpu_last_error());
+        nq = f.nq; nv = f.nv; njoints = f.njoints; nframes = f.nframes;
+        names.assign(f.joint_names, f.joint_names + f.njoints);
+        frame_names.assign(f.frame_names, f.frame_names + f.nframes);
+        lowerPositionLimit = vector_t(f.nq);
+        upperPositionLimit = vector_t(f.nq);
+        for (int i = 0; i < f.nq; ++i) { lowerPositionLimit[i] = f.lower[i]; upperPositionLimit[i] = f.upper[i]; }
+    }
+
+   private:
+    std::shared_ptr<ikgpu_model> h_;
+};
+
+namespace urdf {  // pinocchio::urdf::buildModel* as called at ik_ros/src/cassie.cpp:34-35, ik/test/dls.cpp:13
+inline model_t &buildModelFromXML(const string_t &xml, model_t &model) {
+    ikgpu_model *h = nullptr;
+    if (ikgpu_model_from_urdf(xml.data(), xml.size(), IKGPU_ROOT_FIXED, &h) != IKGPU_OK) throw std::invalid_argument(ikgpu_last_error());
+    model.adopt(h);
+    return model;
+}
+inline model_t &buildModelFromXML(const string_t &xml, const JointModelFreeFlyer &, model_t &model) {
+    ikgpu_model *h = nullptr;
+    if (ikgpu_model_from_urdf(xml.data(), xml.size(), IKGPU_ROOT_FREEFLYER, &h) != IKGPU_OK) throw std::invalid_argument(ikgpu_last_error());
+    model.adopt(h);
+    return model;
+}
+inline string_t read_file(const string_t &filename) {
+    std::ifstream in(filename, std::ios::binary);
+    if (!in) throw std::invalid_argument("cannot open URDF file " + filename);
+    std::ostringstream ss;
+    ss << in.rdbuf();
+    return ss.str();
+}
+inline model_t &buildModel(const string_t &filename, model_t &model) { return buildModelFromXML(read_file(filename), model); }
+inline model_t &buildModel(const string_t &filename, const JointModelFreeFlyer &ff, model_t &model) {
+    return buildModelFromXML(read_file(filename), ff, model);
+}
+}  // namespace urdf
+
+// ---- ik::Task (ik/ik/task.hpp:19-57) ------------------------------------------------------------
+class Task {
+   public:
+    Task() : dimension_(0) {}
+    virtual ~Task() = default;
+    index_t dimension() const { return dimension_; }
+    vector_t &weighting() { return weighting_; }
+    const vector_t &weighting() const { return weighting_; }
+
+   protected:
+    void set_dimension(const index_t &dimension) {
+        dimension_ = dimension;
+        weighting_ = vector_t::Ones(dimension);
+    }
+
+   private:
+    index_t dimension_;
+    vector_t weighting_;
+};
+
+enum class KinematicType { Position, Orientation, Full };  // ik/ik/frame.hpp:20
+
+// ---- ik::FrameTask (ik/ik/frame.hpp:78-200) -----------------------------------------------------
+class FrameTask : public Task {
+   public:
+    FrameTask(const model_t &model, const string_t &frame, const KinematicType &type = KinematicType::Full,
+              const string_t &reference_frame = "universe")
+        : Task(), target(se3_t::Identity()), type_(type), frame_(frame), reference_frame_(reference_frame) {
+        frame_id_ = model.getFrameId(frame);
+        reference_id_ = model.getFrameId(reference_frame);
+        if (frame_id_ >= static_cast<index_t>(model.nframes)) throw std::invalid_argument("Frame not found in model: " + frame);
+        if (reference_id_ >= static_cast<index_t>(model.nframes))
+            throw std::invalid_argument("Reference frame not found in model: " + reference_frame);
+        set_dimension(type == KinematicType::Full ? 6 : 3);
+    }
+    static std::shared_ptr<FrameTask> create(const model_t &model, const string_t &frame,
+                                             const KinematicType &type = KinematicType::Full,
+                                             const string_t &reference_frame = "universe") {
+        return std::make_shared<FrameTask>(model, frame, type, reference_frame);
+    }
+    se3_t target;  // w.r.t. the reference frame; the caller edits it between solves (cassie.cpp:95-99)
+
+    KinematicType type() const { return type_; }
+    const string_t &frame() const { return frame_; }
+    const string_t &reference_frame() const { return reference_frame_; }
+    index_t frame_id() const { return frame_id_; }
+    index_t reference_id() const { return reference_id_; }
+
+   protected:
+    KinematicType type_;
+    string_t frame_, reference_frame_;
+    index_t frame_id_ = 0, reference_id_ = 0;
+};
+
+// ---- ik::InverseKinematicsProblem (ik/ik/problem.hpp:9-206), frame tasks --------------------------
+class InverseKinematicsProblem {
+   public:
+    InverseKinematicsProblem(const model_t &model, const std::size_t &max_priority_level = 0)
+        : model_(model), max_priority_level_(max_priority_level), tasks_(max_priority_level + 1) {}
+
+    const std::size_t &max_priority_level() const { return max_priority_level_; }
+    std::size_t e_size(const std::size_t &priority) const {
+        std::size_t sz = 0;
+        for (const auto &task : get_all_tasks(priority)) sz += task->dimension();
+        return sz;
+    }
+    std::size_t c_size() const { return 0; }
+
+    std::shared_ptr<FrameTask> add_frame_task(const string_t &name, const std::shared_ptr<FrameTask> &task,
+                                              const std::size_t &priority = 0) {
+        if (priority > max_priority_level_) throw std::out_of_range("Maximum priority level exceeded!");
+        frame_tasks_map_.insert({name, frame_tasks_.size()});
+        frame_tasks_.push_back(task);
+        tasks_[priority].push_back(task);
+        ++generation_;
+        return frame_tasks_.back();
+    }
+    std::shared_ptr<FrameTask> get_frame_task(const string_t &name) { return frame_tasks_.at(get_frame_task_index(name)); }
+    std::size_t get_frame_task_index(const string_t &name) {
+        auto it = frame_tasks_map_.find(name);
+        if (it == frame_tasks_map_.end()) throw std::out_of_range("Frame task does not exist: " + name);
+        return it->second;
+    }
+    const std::vector<std::shared_ptr<FrameTask>> &get_all_tasks(const std::size_t &priority) const { return tasks_.at(priority); }
+    const model_t &model() const { return model_; }
+    std::size_t generation() const { return generation_; }
+
+   private:
+    model_t model_;  // a copy, as the reference keeps (problem.hpp:183); the handle inside is shared
+    std::size_t max_priority_level_;
+    std::vector<std::vector<std::shared_ptr<FrameTask>>> tasks_;
+    std::vector<std::shared_ptr<FrameTask>> frame_tasks_;
+    std::unordered_map<string_t, std::size_t> frame_tasks_map_;
+    std::size_t generation_ = 0;
+};
+
+// ---- parameters and the stop rule ---------------------------------------------------------------
+struct default_solver_parameters {  // ik/ik/common.hpp:59-66
+    index_t max_iterations = 100;
+    number_t max_time = 1.0;  // unused by the reference loop
+    number_t step_length = 1.0;
+};
+struct dls_parameters : public default_solver_parameters {  // ik/ik/dls.hpp:24-28
+    number_t damping = 1e-2;
+    bool random_restart = false;  // unused by the reference loop
+};
+
+class inverse_kinematics_visitor {  // ik/ik/visitor.hpp:7-22
+   public:
+    inverse_kinematics_visitor() = default;
+    virtual ~inverse_kinematics_visitor() = default;
+    // should_stop(ik, e, dq) := e[0].squaredNorm() < stop_tolerance(); negative: never stop
+    virtual number_t stop_tolerance() const { return 1e-4; }
+};
+class default_inverse_kinematics_visitor : public inverse_kinematics_visitor {};
+class never_stop_visitor : public inverse_kinematics_visitor {
+   public:
+    number_t stop_tolerance() const override { return -1.0; }
+};
+
+// ---- ik::dls_data (ik/ik/dls.hpp:34-65; ik/ik/data.hpp:8-29) ------------------------------------
+class dls_data {
+   public:
+    explicit dls_data(const InverseKinematicsProblem &problem, int device = 0) : device_(device) { bind(problem); }
+    dls_data(const dls_data &) = delete;
+    dls_data &operator=(const dls_data &) = delete;
+
+    bool success = false;  // data.success (ik/ik/data.hpp:18)
+    index_t iterations = 0;
+    vector_t q, dq;
+
+    const ikgpu_problem *handle() const { return h_.get(); }
+    const char *kernel() const { return ikgpu_problem_kernel(h_.get()); }
+
+    // (Re)builds the device-side tables when tasks were added or weights changed since the last call.
+    void bind(const InverseKinematicsProblem &problem) {
+        std::vector<ikgpu_task> tasks;
+        for (std::size_t p = 0; p <= problem.max_priority_level(); ++p)  // stacking order of ik/ik/dls.cpp:20-24
+            for (const auto &t : problem.get_all_tasks(p)) {
+                ikgpu_task k;
+                k.frame = static_cast<int32_t>(t->frame_id());
+                k.reference = static_cast<int32_t>(t->reference_id());
+                k.type = t->type() == KinematicType::Position ? IKGPU_POSITION
+                         : t->type() == KinematicType::Orientation ? IKGPU_ORIENTATION : IKGPU_FULL;
+                k.priority = static_cast<int32_t>(p);
+                for (int i = 0; i < 6; ++i) k.weight[i] = i < static_cast<int>(t->dimension()) ? t->weighting()[i] : 1.0;
+                tasks.push_back(k);
+            }
+        if (h_ && same(tasks)) return;
+        ikgpu_problem *h = nullptr;
+        if (ikgpu_problem_create(problem.model().handle(), tasks.data(), static_cast<int32_t>(tasks.size()), device_, &h) != IKGPU_OK)
+            throw std::runtime_error(ikgpu_last_error());
+        h_ = std::shared_ptr<ikgpu_problem>(h, ikgpu_problem_destroy);
+        tasks_ = tasks;
+        q = vector_t::Zero(problem.model().nq);
+        dq = vector_t::Zero(problem.model().nv);
+    }
+
+   private:
+    bool same(const std::vector<ikgpu_task> &t) const {
+        if (t.size() != tasks_.size()) return false;
+        for (std::size_t i = 0; i < t.size(); ++i) {
+            const ikgpu_task &a = t[i], &b = tasks_[i];
+            if (a.frame != b.frame || a.reference != b.reference || a.type != b.type || a.priority != b.priority) return false;
+            for (int k = 0; k < 6; ++k)
+                if (a.weight[k] != b.weight[k]) return false;
+        }
+        return true;
+    }
+    int device_;
+    std::shared_ptr<ikgpu_problem> h_;
+    std::vector<ikgpu_task> tasks_;
+};
+
+namespace detail {
+inline ikgpu_dls_params to_abi(const inverse_kinematics_visitor &visitor, const dls_parameters &p) {
+    ikgpu_dls_params a;
+    a.max_iterations = static_cast<int32_t>(p.max_iterations);
+    a.damping = p.damping;
+    a.step_length = p.step_length;
+    a.stop_sq_tol = visitor.stop_tolerance();
+    return a;
+}
+inline std::vector<number_t> gather_targets(const InverseKinematicsProblem &problem) {
+    std::vector<number_t> t;
+    for (std::size_t p = 0; p <= problem.max_priority_level(); ++p)
+        for (const auto &task : problem.get_all_tasks(p)) t.insert(t.end(), task->target.data(), task->target.data() + 12);
+    return t;
+}
+}  // namespace detail
+
+// ---- ik::dls (ik/ik/dls.hpp:111-114; ik/ik/dls.cpp:5-78): one problem, a batch of one on the device
+inline vector_t dls(InverseKinematicsProblem &problem, const vector_t &q0, dls_data &data,
+                    const inverse_kinematics_visitor &visitor = inverse_kinematics_visitor(),
+                    const dls_parameters &p = dls_parameters()) {
+    data.bind(problem);
+    if (q0.size() != static_cast<index_t>(problem.model().nq)) throw std::invalid_argument("q0 has the wrong size");
+    const std::vector<number_t> targets = detail::gather_targets(problem);
+    const ikgpu_dls_params prm = detail::to_abi(visitor, p);
+    vector_t q(q0.size());
+    uint8_t ok = 0;
+    int32_t it = 0;
+    if (ikgpu_dls_solve_batch_host(data.handle(), 1, q0.data(), targets.data(), &prm, q.data(), &ok, &it, IKGPU_AOS) != IKGPU_OK)
+        throw std::runtime_error(ikgpu_last_error());
+    data.success = ok != 0;
+    data.iterations = static_cast<index_t>(it);
+    data.q = q;
+    return q;
+}
+
+// B problems in lockstep, HOST buffers: Q0 is nq x B column-major (problem b's q contiguous, as an
+// Eigen::MatrixXd of that shape), targets B x ntasks x 12 in the stacking order of the tasks, Q likewise
+// nq x B; success / iterations may be null.
+inline void dls_batch(InverseKinematicsProblem &problem, std::int64_t B, const number_t *Q0, const number_t *targets,
+                      dls_data &data, number_t *Q, std::uint8_t *success, std::int32_t *iterations,
+                      const inverse_kinematics_visitor &visitor = inverse_kinematics_visitor(),
+                      const dls_parameters &p = dls_parameters()) {
+    data.bind(problem);
+    const ikgpu_dls_params prm = detail::to_abi(visitor, p);
+    if (ikgpu_dls_solve_batch_host(data.handle(), B, Q0, targets, &prm, Q, success, iterations, IKGPU_AOS) != IKGPU_OK)
+        throw std::runtime_error(ikgpu_last_error());
+}
+
+// The same with DEVICE buffers on the problem's device (component-major: Q0 [nq][B], targets
+// [ntasks][12][B]) and a hipStream_t; asynchronous.
+inline void dls_batch_device(InverseKinematicsProblem &problem, std::int64_t B, const number_t *Q0, const number_t *targets,
+                             dls_data &data, number_t *Q, std::uint8_t *success, std::int32_t *iterations, void *stream,
+                             const inverse_kinematics_visitor &visitor = inverse_kinematics_visitor(),
+                             const dls_parameters &p = dls_parameters()) {
+    data.bind(problem);
+    const ikgpu_dls_params prm = detail::to_abi(visitor, p);
+    if (ikgpu_dls_solve_batch(data.handle(), B, Q0, targets, &prm, Q, success, iterations, IKGPU_SOA, stream) != IKGPU_OK)
+        throw std::runtime_error(ikgpu_last_error());
+}
+
+}  // namespace ik

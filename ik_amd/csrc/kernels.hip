@@ -173,7 +173,7 @@ using ikdev::LegFactor;
 using ikdev::TreeDesc;
 using ikdev::TreeKernelArgs;
 
-// While chain B is evaluated, chain A's factor (L packed + W) is parked in LDS as [entry][lane]:
+// While chain 1 is evaluated, chain 0's factor (L packed + W) is parked in LDS as [entry][lane]:
 // consecutive lanes hit consecutive 8-byte words, so every ds_write_b64 / ds_read_b64 is conflict-free.
 template <int NJ>
 struct LdsPark {
@@ -199,77 +199,78 @@ struct LdsPark {
     }
 };
 
-template <int NA, int NB>
-__device__ __forceinline__ const TreeDesc<NA, NB> &stage_tree_desc(const TreeDesc<NA, NB> *src, double *lds) {
-    constexpr int kWords = sizeof(TreeDesc<NA, NB>) / sizeof(double);
+template <int NJ, int NCH>
+__device__ __forceinline__ const TreeDesc<NJ, NCH> &stage_tree_desc(const TreeDesc<NJ, NCH> *src, double *lds) {
+    constexpr int kWords = sizeof(TreeDesc<NJ, NCH>) / sizeof(double);
     const double *g = reinterpret_cast<const double *>(src);
     for (int i = threadIdx.x; i < kWords; i += kBlock) lds[i] = g[i];
     __syncthreads();
-    return *reinterpret_cast<const TreeDesc<NA, NB> *>(lds);
+    return *reinterpret_cast<const TreeDesc<NJ, NCH> *>(lds);
 }
 
-template <int NA, int NB>
-__global__ __launch_bounds__(kBlock) void dls_tree_kernel(const TreeKernelArgs<NA, NB> a) {
-    __shared__ double lds_desc[sizeof(TreeDesc<NA, NB>) / sizeof(double)];
-    __shared__ double lds_park[LdsPark<NA>::kEntries][kBlock];
-    const TreeDesc<NA, NB> &d = stage_tree_desc<NA, NB>(a.desc, lds_desc);
+template <int NJ, int NCH>
+__global__ __launch_bounds__(kBlock) void dls_tree_kernel(const TreeKernelArgs<NJ, NCH> a) {
+    __shared__ double lds_desc[sizeof(TreeDesc<NJ, NCH>) / sizeof(double)];
+    __shared__ double lds_park[NCH > 1 ? LdsPark<NJ>::kEntries : 1][kBlock];
+    const TreeDesc<NJ, NCH> &d = stage_tree_desc<NJ, NCH>(a.desc, lds_desc);
     const int64_t gid = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-    LdsPark<NA> park{lds_park, static_cast<int>(threadIdx.x)};
-    ikdev::dls_tree_body<NA, NB>(a, d, gid, park, [](bool act) { return __any(act) != 0; });
+    LdsPark<NJ> park{lds_park, static_cast<int>(threadIdx.x)};
+    ikdev::dls_tree_body<NJ, NCH>(a, d, gid, park, [](bool act) { return __any(act) != 0; });
 }
 
-template <int NA, int NB>
-__global__ __launch_bounds__(kBlock) void eval_tree_kernel(const TreeKernelArgs<NA, NB> a) {
-    __shared__ double lds_desc[sizeof(TreeDesc<NA, NB>) / sizeof(double)];
-    const TreeDesc<NA, NB> &d = stage_tree_desc<NA, NB>(a.desc, lds_desc);
-    ikdev::eval_tree_body<NA, NB>(a, d, static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x);
+template <int NJ, int NCH>
+__global__ __launch_bounds__(kBlock) void eval_tree_kernel(const TreeKernelArgs<NJ, NCH> a) {
+    __shared__ double lds_desc[sizeof(TreeDesc<NJ, NCH>) / sizeof(double)];
+    const TreeDesc<NJ, NCH> &d = stage_tree_desc<NJ, NCH>(a.desc, lds_desc);
+    ikdev::eval_tree_body<NJ, NCH>(a, d, static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x);
 }
 
-template <int NA, int NB>
-TreeKernelArgs<NA, NB> make_tree_args(const ProblemHost &ph, const DeviceTables &dt) {
-    TreeKernelArgs<NA, NB> a{};
+template <int NJ, int NCH>
+TreeKernelArgs<NJ, NCH> make_tree_args(const ProblemHost &ph, const DeviceTables &dt) {
+    TreeKernelArgs<NJ, NCH> a{};
     const TreeArgsHost h = tree_args(ph);
-    for (int j = 0; j < NA; ++j) { a.qidxA[j] = h.qidxA[j]; a.vidxA[j] = h.vidxA[j]; }
-    for (int j = 0; j < NB; ++j) { a.qidxB[j] = h.qidxB[j]; a.vidxB[j] = h.vidxB[j]; }
+    for (int c = 0; c < NCH; ++c)
+        for (int j = 0; j < NJ; ++j) { a.qidx[c][j] = h.qidx[c][j]; a.vidx[c][j] = h.vidx[c][j]; }
     for (int s = 0; s < 3; ++s) { a.tslot[s] = h.tslot[s]; a.trow[s] = h.trow[s]; a.tdim[s] = h.tdim[s]; a.trow0[s] = h.trow0[s]; }
-    a.prm.prioA = h.prio[0]; a.prm.prioB = h.prio[1]; a.prm.prioP = h.prio[2];
+    a.prm.prio[0] = h.prio[0]; a.prm.prio[1] = h.prio[1]; a.prm.prioP = h.prio[2];
     a.prm.hasP = h.hasP;
-    a.desc = reinterpret_cast<const TreeDesc<NA, NB> *>(dt.chain_desc);
+    a.desc = reinterpret_cast<const TreeDesc<NJ, NCH> *>(dt.chain_desc);
     a.nq = ph.nq; a.nv = ph.nv; a.ntasks = ph.ntasks;
     a.lower = dt.lower; a.upper = dt.upper; a.q_in_chain = dt.q_in_chain;
     return a;
 }
 
-template <int NA, int NB>
+template <int NJ, int NCH>
 hipError_t run_dls_tree(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const ikgpu_dls_params &prm,
                         hipStream_t stream) {
-    TreeKernelArgs<NA, NB> a = make_tree_args<NA, NB>(ph, dt);
+    TreeKernelArgs<NJ, NCH> a = make_tree_args<NJ, NCH>(ph, dt);
     a.prm.max_iterations = prm.max_iterations;
     a.prm.lam2 = prm.damping * prm.damping;
     a.prm.step_length = prm.step_length;
     a.prm.stop_sq_tol = prm.stop_sq_tol;
     a.layout = io.layout; a.B = io.B; a.q0 = io.q0; a.targets = io.targets;
     a.q_out = io.q_out; a.success = io.success; a.iters = io.iters;
-    hipLaunchKernelGGL((dls_tree_kernel<NA, NB>), grid_for(io.B), dim3(kBlock), 0, stream, a);
+    hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH>), grid_for(io.B), dim3(kBlock), 0, stream, a);
     return hipGetLastError();
 }
 
-template <int NA, int NB>
+template <int NJ, int NCH>
 hipError_t run_eval_tree(const ProblemHost &ph, const DeviceTables &dt, int64_t B, const double *q, const double *targets,
                          double *e_out, double *J_out, double *oMf_out, int layout, hipStream_t stream) {
-    TreeKernelArgs<NA, NB> a = make_tree_args<NA, NB>(ph, dt);
+    TreeKernelArgs<NJ, NCH> a = make_tree_args<NJ, NCH>(ph, dt);
     a.layout = layout; a.B = B; a.q0 = q; a.targets = targets;
     a.e_out = e_out; a.J_out = J_out; a.oMf_out = oMf_out;
-    hipLaunchKernelGGL((eval_tree_kernel<NA, NB>), grid_for(B), dim3(kBlock), 0, stream, a);
+    hipLaunchKernelGGL((eval_tree_kernel<NJ, NCH>), grid_for(B), dim3(kBlock), 0, stream, a);
     return hipGetLastError();
 }
 
 }  // namespace
 
-#define IKGPU_FOR_TREE(X) X(7, 7) X(7, 0)
+// (chain length, number of chains) pairs with a compiled kernel
+#define IKGPU_FOR_TREE(X) X(7, 2) X(7, 1) X(6, 2) X(6, 1)
 
-bool tree_shape_built(int na, int nb) {
-#define X(A, B_) if (na == A && nb == B_) return true;
+bool tree_shape_built(int nj, int nch) {
+#define X(N, C) if (nj == N && nch == C) return true;
     IKGPU_FOR_TREE(X)
 #undef X
     return false;
@@ -277,20 +278,20 @@ bool tree_shape_built(int na, int nb) {
 
 hipError_t launch_dls_tree(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const ikgpu_dls_params &prm,
                            hipStream_t stream) {
-    const int na = ph.chain.nj, nb = ph.chainB.nj;
-#define X(A, B_) if (na == A && nb == B_) return run_dls_tree<A, B_>(ph, dt, io, prm, stream);
+    const int nj = ph.chain.nj, nch = ph.chainB.nj > 0 ? 2 : 1;
+#define X(N, C) if (nj == N && nch == C) return run_dls_tree<N, C>(ph, dt, io, prm, stream);
     IKGPU_FOR_TREE(X)
 #undef X
-    not_built(na, nb);
+    not_built(nj, nch);
 }
 
 hipError_t launch_eval_tree(const ProblemHost &ph, const DeviceTables &dt, int64_t B, const double *q, const double *targets,
                             double *e_out, double *J_out, double *oMf_out, int layout, hipStream_t stream) {
-    const int na = ph.chain.nj, nb = ph.chainB.nj;
-#define X(A, B_) if (na == A && nb == B_) return run_eval_tree<A, B_>(ph, dt, B, q, targets, e_out, J_out, oMf_out, layout, stream);
+    const int nj = ph.chain.nj, nch = ph.chainB.nj > 0 ? 2 : 1;
+#define X(N, C) if (nj == N && nch == C) return run_eval_tree<N, C>(ph, dt, B, q, targets, e_out, J_out, oMf_out, layout, stream);
     IKGPU_FOR_TREE(X)
 #undef X
-    not_built(na, nb);
+    not_built(nj, nch);
 }
 
 }  // namespace ikgpu

@@ -44,5 +44,5 @@ hipError_t launch_dls_tree(const ProblemHost &ph, const DeviceTables &dt, const 
 hipError_t launch_eval_tree(const ProblemHost &ph, const DeviceTables &dt, int64_t B, const double *q,
                             const double *targets, double *e_out, double *J_out, double *oMf_out, int layout,
                             hipStream_t stream);
-bool tree_shape_built(int na, int nb);
+bool tree_shape_built(int nj, int nch);
 }  // namespace ikgpu

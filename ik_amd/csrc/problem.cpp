@@ -146,8 +146,11 @@ ProblemHost analyse_problem(const Model &m, const ikgpu_task *tasks, int ntasks)
         }
     }
     if (nchains == 0) throw std::runtime_error("unsupported on the device yet: free-flyer problem without a chain task");
+    if (nchains == 2 && ph.chain.nj != ph.chainB.nj)
+        throw std::runtime_error("unsupported on the device yet: the two chains of a free-flyer problem differ in length (" +
+                                 std::to_string(ph.chain.nj) + " vs " + std::to_string(ph.chainB.nj) + " joints)");
     ph.kind = KernelKind::Tree;
-    ph.kernel_name = "dls_tree<NA=" + std::to_string(ph.chain.nj) + ",NB=" + std::to_string(ph.chainB.nj) +
+    ph.kernel_name = "dls_tree<NJ=" + std::to_string(ph.chain.nj) + ",chains=" + std::to_string(nchains) +
                      (ph.base_task >= 0 ? ",base_task>" : ">");
     return ph;
 }
@@ -164,26 +167,23 @@ std::vector<double> chain_desc_table(const ProblemHost &ph) {
 }
 
 std::vector<double> tree_desc_table(const ProblemHost &ph) {
+    // ikdev::TreeDesc<NJ, NCH>: ChainTable chain[NCH] {pl, fr, lo, hi, w}, frP, wP
     std::vector<double> t;
-    auto put_chain = [&](const ChainHost &c) {
-        const int n = c.nj > 0 ? c.nj : 1;  // TreeDesc keeps one dummy slot for an absent chain
-        for (int j = 0; j < n; ++j) t.insert(t.end(), c.pl[j], c.pl[j] + 12);
-        t.insert(t.end(), c.frame_pl, c.frame_pl + 12);
-        t.insert(t.end(), c.lo, c.lo + n);
-        t.insert(t.end(), c.hi, c.hi + n);
-    };
-    put_chain(ph.chain);
-    put_chain(ph.chainB);
-    t.insert(t.end(), ph.base_frame_pl, ph.base_frame_pl + 12);
     double w6[6];
-    auto put_w = [&](int task) {
-        for (double &x : w6) x = 0.0;
-        if (task >= 0) weights6(ph.tasks[task], w6);
+    auto put_chain = [&](const ChainHost &c) {
+        for (int j = 0; j < c.nj; ++j) t.insert(t.end(), c.pl[j], c.pl[j] + 12);
+        t.insert(t.end(), c.frame_pl, c.frame_pl + 12);
+        t.insert(t.end(), c.lo, c.lo + c.nj);
+        t.insert(t.end(), c.hi, c.hi + c.nj);
+        weights6(ph.tasks[c.task], w6);
         t.insert(t.end(), w6, w6 + 6);
     };
-    put_w(ph.chain.task);
-    put_w(ph.chainB.nj > 0 ? ph.chainB.task : -1);
-    put_w(ph.base_task);
+    put_chain(ph.chain);
+    if (ph.chainB.nj > 0) put_chain(ph.chainB);
+    t.insert(t.end(), ph.base_frame_pl, ph.base_frame_pl + 12);
+    for (double &x : w6) x = 0.0;
+    if (ph.base_task >= 0) weights6(ph.tasks[ph.base_task], w6);
+    t.insert(t.end(), w6, w6 + 6);
     return t;
 }
 
@@ -202,8 +202,8 @@ void fill_chain_args(const ProblemHost &ph, double *ref_pl12, int *qidx, int *vi
 TreeArgsHost tree_args(const ProblemHost &ph) {
     TreeArgsHost a{};
     for (int j = 0; j < kMaxChain; ++j) {
-        a.qidxA[j] = ph.chain.qidx[j]; a.vidxA[j] = ph.chain.vidx[j];
-        a.qidxB[j] = ph.chainB.qidx[j]; a.vidxB[j] = ph.chainB.vidx[j];
+        a.qidx[0][j] = ph.chain.qidx[j]; a.vidx[0][j] = ph.chain.vidx[j];
+        a.qidx[1][j] = ph.chainB.qidx[j]; a.vidx[1][j] = ph.chainB.vidx[j];
     }
     const int slot_task[3] = {ph.chain.task, ph.chainB.nj > 0 ? ph.chainB.task : -1, ph.base_task};
     for (int s = 0; s < 3; ++s) {
@@ -215,6 +215,7 @@ TreeArgsHost tree_args(const ProblemHost &ph) {
         a.prio[s] = ti >= 0 ? ph.tasks[ti].priority : 1;
     }
     a.hasP = ph.base_task >= 0 ? 1 : 0;
+    a.nch = ph.chainB.nj > 0 ? 2 : 1;
     return a;
 }
 

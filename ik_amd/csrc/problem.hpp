@@ -54,10 +54,10 @@ std::vector<double> tree_desc_table(const ProblemHost &ph);
 void fill_chain_args(const ProblemHost &ph, double *ref_pl12, int *qidx, int *vidx, int *nq, int *nv, int *priority);
 // The per-problem scalars of ikdev::TreeKernelArgs<na, nb>.
 struct TreeArgsHost {
-    int qidxA[kMaxChain], qidxB[kMaxChain], vidxA[kMaxChain], vidxB[kMaxChain];
+    int qidx[2][kMaxChain], vidx[2][kMaxChain];
     int tslot[3], trow[3], tdim[3], trow0[3];
     int prio[3];
-    int hasP;
+    int hasP, nch;
 };
 TreeArgsHost tree_args(const ProblemHost &ph);
 

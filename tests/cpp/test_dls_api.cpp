@@ -1,0 +1,88 @@
+// test_dls_api.cpp -- exercises the C++ mirror of the reference API (ik_amd/csrc/host/ik/) the way the
+// reference's own (commented-out) tests do (reference ik/test/dls.cpp:10-76, ik/test/ik.cpp:9-20):
+// load a model, create FrameTasks, add them to an InverseKinematicsProblem, set targets, call ik::dls.
+// Driven by tests/test_gpu_parity.py, which compares the printed solution with the CPU oracle.
+//
+//   test_dls_api <urdf> <free_flyer 0|1> <max_it> <damping> <step> <tol> <ntasks>
+//                { <frame> <type 0|1|2> <priority> <12 target numbers> } x ntasks   <nq numbers of q0>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "ik/dls.hpp"
+#include "ik/problem.hpp"
+
+int main(int argc, char **argv) {
+    try {
+        int a = 1;
+        auto next = [&]() -> std::string {
+            if (a >= argc) throw std::runtime_error("not enough arguments");
+            return argv[a++];
+        };
+        const std::string urdf_filename = next();
+        const bool free_flyer = std::atoi(next().c_str()) != 0;
+        ik::dls_parameters p;
+        p.max_iterations = std::atoi(next().c_str());
+        p.damping = std::atof(next().c_str());
+        p.step_length = std::atof(next().c_str());
+        const double tol = std::atof(next().c_str());
+        const int ntasks = std::atoi(next().c_str());
+
+        // Load a model
+        ik::model_t model;
+        if (free_flyer) ik::urdf::buildModel(urdf_filename, ik::JointModelFreeFlyer(), model);
+        else ik::urdf::buildModel(urdf_filename, model);
+
+        std::size_t max_priority = 0;
+        struct Spec { std::string frame; int type; std::size_t prio; double target[12]; };
+        std::vector<Spec> specs(ntasks);
+        for (auto &s : specs) {
+            s.frame = next();
+            s.type = std::atoi(next().c_str());
+            s.prio = std::atoi(next().c_str());
+            for (double &x : s.target) x = std::atof(next().c_str());
+            if (s.prio > max_priority) max_priority = s.prio;
+        }
+        ik::InverseKinematicsProblem problem(model, max_priority);
+        int k = 0;
+        for (auto &s : specs) {
+            const ik::KinematicType type = s.type == 0 ? ik::KinematicType::Position
+                                           : s.type == 1 ? ik::KinematicType::Orientation : ik::KinematicType::Full;
+            auto task = ik::FrameTask::create(model, s.frame, type, "universe");
+            problem.add_frame_task("task" + std::to_string(k++), task, s.prio);
+        }
+        k = 0;
+        for (auto &s : specs) {  // targets are edited after registration, as the demo does (cassie.cpp:95-99)
+            auto task = problem.get_frame_task("task" + std::to_string(k++));
+            task->target.rotation() << s.target[0], s.target[1], s.target[2], s.target[3], s.target[4], s.target[5],
+                s.target[6], s.target[7], s.target[8];
+            task->target.translation() << s.target[9], s.target[10], s.target[11];
+        }
+        ik::vector_t q0 = ik::vector_t::Zero(model.nq);
+        for (int i = 0; i < model.nq; ++i) q0[i] = std::atof(next().c_str());
+
+        ik::dls_data data(problem);
+        struct tol_visitor : ik::inverse_kinematics_visitor {
+            double t;
+            explicit tol_visitor(double t_) : t(t_) {}
+            double stop_tolerance() const override { return t; }
+        } visitor(tol);
+
+        // Solve
+        ik::vector_t q = ik::dls(problem, q0, data, visitor, p);
+        // and once more through the same data object (warm start from the result, as cassie.cpp:112 does)
+        ik::vector_t q2 = ik::dls(problem, q, data, visitor, p);
+
+        std::printf("{\"kernel\": \"%s\", \"success\": %d, \"iterations\": %zu, \"q\": [", data.kernel(), data.success ? 1 : 0,
+                    data.iterations);
+        for (ik::index_t i = 0; i < q2.size(); ++i) std::printf("%s%.17g", i ? ", " : "", q2[i]);
+        std::printf("], \"q_first\": [");
+        for (ik::index_t i = 0; i < q.size(); ++i) std::printf("%s%.17g", i ? ", " : "", q[i]);
+        std::printf("]}\n");
+        return 0;
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+}

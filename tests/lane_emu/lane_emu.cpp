@@ -56,23 +56,28 @@ void run_chain(const ikgpu::ProblemHost &ph, const IO &io) {
 }
 
 template <int NJ>
-struct HostPark {  // the device parks chain A's factor in LDS; on the host it simply stays where it is
-    void store(const ikdev::LegFactor<NJ> &) const {}
-    void load(ikdev::LegFactor<NJ> &) const {}
+struct HostPark {  // the device parks chain 0's factor in LDS; the host keeps a copy
+    mutable ikdev::LegFactor<NJ> saved;
+    void store(const ikdev::LegFactor<NJ> &F) const { saved = F; }
+    void load(ikdev::LegFactor<NJ> &F) const {
+        for (int e = 0; e < NJ * (NJ + 1) / 2; ++e) F.L[e] = saved.L[e];
+        for (int j = 0; j < NJ; ++j)
+            for (int c = 0; c < 6; ++c) F.W[j][c] = saved.W[j][c];
+    }
 };
 
-template <int NA, int NB>
+template <int NJ, int NCH>
 void run_tree(const ikgpu::ProblemHost &ph, const IO &io) {
-    ikdev::TreeKernelArgs<NA, NB> a{};
-    ikdev::TreeDesc<NA, NB> d{};
+    ikdev::TreeKernelArgs<NJ, NCH> a{};
+    ikdev::TreeDesc<NJ, NCH> d{};
     const std::vector<double> t = ikgpu::tree_desc_table(ph);
     if (t.size() * sizeof(double) != sizeof d) throw std::runtime_error("tree desc table size mismatch");
     std::memcpy(&d, t.data(), sizeof d);
     const ikgpu::TreeArgsHost h = ikgpu::tree_args(ph);
-    for (int j = 0; j < NA; ++j) { a.qidxA[j] = h.qidxA[j]; a.vidxA[j] = h.vidxA[j]; }
-    for (int j = 0; j < NB; ++j) { a.qidxB[j] = h.qidxB[j]; a.vidxB[j] = h.vidxB[j]; }
+    for (int c = 0; c < NCH; ++c)
+        for (int j = 0; j < NJ; ++j) { a.qidx[c][j] = h.qidx[c][j]; a.vidx[c][j] = h.vidx[c][j]; }
     for (int s = 0; s < 3; ++s) { a.tslot[s] = h.tslot[s]; a.trow[s] = h.trow[s]; a.tdim[s] = h.tdim[s]; a.trow0[s] = h.trow0[s]; }
-    a.prm.prioA = h.prio[0]; a.prm.prioB = h.prio[1]; a.prm.prioP = h.prio[2]; a.prm.hasP = h.hasP;
+    a.prm.prio[0] = h.prio[0]; a.prm.prio[1] = h.prio[1]; a.prm.prioP = h.prio[2]; a.prm.hasP = h.hasP;
     a.nq = ph.nq; a.nv = ph.nv; a.ntasks = ph.ntasks;
     a.lower = ph.lower.data(); a.upper = ph.upper.data(); a.q_in_chain = ph.q_in_chain.data();
     a.layout = io.layout; a.B = io.B; a.q0 = io.q0; a.targets = io.targets;
@@ -86,8 +91,8 @@ void run_tree(const ikgpu::ProblemHost &ph, const IO &io) {
         a.prm.stop_sq_tol = io.prm->stop_sq_tol;
     }
     for (int64_t b = 0; b < io.B; ++b) {
-        if (io.mode == 0) ikdev::dls_tree_body<NA, NB>(a, d, b, HostPark<NA>{}, [](bool act) { return act; });
-        else ikdev::eval_tree_body<NA, NB>(a, d, b);
+        if (io.mode == 0) ikdev::dls_tree_body<NJ, NCH>(a, d, b, HostPark<NJ>{}, [](bool act) { return act; });
+        else ikdev::eval_tree_body<NJ, NCH>(a, d, b);
     }
 }
 
@@ -117,9 +122,9 @@ int lane_emu_run(const char *urdf, size_t len, int root_joint, const ikgpu_task 
             X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
 #undef X
         } else {
-            const int na = ph.chain.nj, nb = ph.chainB.nj;
-            if (na == 7 && nb == 7) { run_tree<7, 7>(ph, io); return 0; }
-            if (na == 7 && nb == 0) { run_tree<7, 0>(ph, io); return 0; }
+            const int nj = ph.chain.nj, nch = ph.chainB.nj > 0 ? 2 : 1;
+            if (nj == 7 && nch == 2) { run_tree<7, 2>(ph, io); return 0; }
+            if (nj == 7 && nch == 1) { run_tree<7, 1>(ph, io); return 0; }
         }
         g_err = "shape not instantiated in the lane emulator: " + ph.kernel_name;
         return 1;

@@ -267,7 +267,7 @@ def _full_body_inputs(model, B, mode="near", seed=0):
 def test_full_body_stages_match_oracle(torch_cuda):
     torch = torch_cuda
     ik_amd, O, model, problem, data, om, ot, fids = _setup_full_body()
-    assert data.kernel == "dls_tree<NA=7,NB=7,base_task>" and data.rows == 18
+    assert data.kernel == "dls_tree<NJ=7,chains=2,base_task>" and data.rows == 18
     B = 200
     q0, qs = _full_body_inputs(model, B)
     got = ik_amd.task_frames_fk_batch(problem, _to_dev(torch, qs), data).permute(2, 0, 1).cpu().numpy()
@@ -338,3 +338,53 @@ def test_full_body_full_size_properties(torch_cuda):
     lo = torch.from_numpy(model.lowerPositionLimit).cuda()[7:, None]
     hi = torch.from_numpy(model.upperPositionLimit).cuda()[7:, None]
     assert bool(((Q1[7:] >= lo) & (Q1[7:] <= hi)).all())
+
+
+# ---------------------------------------------------------------------------------------------------
+# The C++ mirror of the reference API (ik_amd/csrc/host/ik/*.hpp) through a program written like the
+# reference's own tests (tests/cpp/test_dls_api.cpp ~ reference ik/test/dls.cpp:10-76)
+# ---------------------------------------------------------------------------------------------------
+def _cpp_binary():
+    import subprocess
+    from conftest import ROOT
+    src = os.path.join(ROOT, "tests", "cpp", "test_dls_api.cpp")
+    exe = os.path.join(ROOT, "tests", "cpp", "test_dls_api")
+    hdr = os.path.join(ROOT, "ik_amd", "csrc", "host", "ik", "ik_gpu.hpp")
+    if not os.path.exists(exe) or max(os.path.getmtime(src), os.path.getmtime(hdr)) > os.path.getmtime(exe):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                               "-I" + os.path.join(ROOT, "ik_amd", "csrc", "host"), "-o", exe, src,
+                               "-L" + os.path.join(ROOT, "ik_amd"), "-likgpu", "-Wl,-rpath," + os.path.join(ROOT, "ik_amd")])
+    return exe
+
+
+@pytest.mark.parametrize("name,ff,frames,types,prios", [
+    ("ur5", False, ["ee_fixed_joint"], [2], [0]),
+    ("cassie_fixed", False, ["LeftFootFront"], [0], [0]),
+    ("cassie", True, ["LeftFootFront", "RightFootFront", "pelvis"], [2, 2, 2], [0, 0, 0]),
+])
+def test_cpp_api_program_matches_oracle(torch_cuda, name, ff, frames, types, prios):
+    import json
+    import subprocess
+    import ik_amd
+    import oracle as O
+    from ik_amd import workload
+    model = ik_amd.Model.from_urdf_file(urdf_path(name), free_flyer=ff)
+    om = O.OracleModel(model.flat())
+    fids = [model.getFrameId(f) for f in frames]
+    if ff:
+        q0, qs = _full_body_inputs(model, 4, seed=5)
+    else:
+        q0, qs = _inputs(model, name, 4, "near", seed=5)
+    q0, tg = q0[3], O.fk_batch(om, qs, fids)[3]
+    ot = O.make_tasks([(f, 0, t, p, None) for f, t, p in zip(fids, types, prios)])
+    args = [_cpp_binary(), urdf_path(name), "1" if ff else "0", "30", "0.01", "1.0", "1e-4", str(len(frames))]
+    for f, t, p, target in zip(frames, types, prios, tg):
+        args += [f, str(t), str(p)] + ["%.17g" % x for x in target]
+    args += ["%.17g" % x for x in q0]
+    # a standalone C++ process uses the system ROCm runtime (no torch in that process)
+    out = json.loads(subprocess.check_output(args, text=True))
+    q1, ok1, it1 = O.dls(om, ot, tg, q0, O.params(30, 0.01, 1.0, 1e-4))
+    q2, ok2, it2 = O.dls(om, ot, tg, q1, O.params(30, 0.01, 1.0, 1e-4))
+    assert np.abs(np.array(out["q_first"]) - q1).max() <= TOL
+    assert np.abs(np.array(out["q"]) - q2).max() <= TOL
+    assert out["success"] == int(ok2) and out["iterations"] == it2
