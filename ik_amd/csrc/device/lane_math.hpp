@@ -25,6 +25,15 @@
 #define IKD_ON_DEVICE 0
 #endif
 
+// Scheduling fence between the phases of a long unrolled lane program: keeps the machine scheduler from
+// hoisting a later phase's LDS / global loads (and their destination registers) across an earlier phase,
+// which is what pushes the big kernels over the 512-register budget.  No instruction is emitted.
+#if IKD_ON_DEVICE
+#define IKD_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define IKD_SCHED_FENCE() ((void)0)
+#endif
+
 namespace ikdev {
 
 // TaylorSeriesExpansion<double>::precision<3>() = eps^(1/4)
@@ -36,36 +45,41 @@ IKD_FN double dsel(bool c, double a, double b) { return c ? a : b; }
 IKD_FN double dmin(double a, double b) { return __builtin_fmin(a, b); }
 IKD_FN double dmax(double a, double b) { return __builtin_fmax(a, b); }
 
-// 1/x for normal-range x: v_rcp_f64 seed + two Newton steps (no div_scale/div_fixup sequence).
+// 1/x for normal-range x: v_rcp_f64 seed (measured 24.4 bits on gfx950, tools/seed_probe.hip) + one
+// second-order Newton step: r (1 + e + e^2), e = 1 - x r  ->  relative error e^3 ~ 1e-22, i.e. rounding-limited
+// (no div_scale / div_fmas / div_fixup sequence; denormal and huge inputs are outside the path's range).
 IKD_FN double drcp(double x) {
 #if IKD_ON_DEVICE
-    double r = __builtin_amdgcn_rcp(x);
-    double e = dfma(-x, r, 1.0);
-    r = dfma(e, r, r);
-    e = dfma(-x, r, 1.0);
-    r = dfma(e, r, r);
-    return r;
+    const double r = __builtin_amdgcn_rcp(x);
+    const double e = dfma(-x, r, 1.0);
+    return dfma(dfma(e, e, e), r, r);
 #else
     return 1.0 / x;
 #endif
 }
 
-// 1/sqrt(x) for normal-range x > 0: v_rsq_f64 seed + two Newton steps.
+// 1/sqrt(x) for normal-range x > 0: v_rsq_f64 seed (24.2 bits) + one third-order (Halley) step:
+// y (1 + e/2 + 3 e^2/8), e = 1 - x y^2  ->  relative error ~e^3, rounding-limited.
 IKD_FN double drsqrt(double x) {
 #if IKD_ON_DEVICE
-    double y = __builtin_amdgcn_rsq(x);
-    double hx = 0.5 * x;
-    double e = dfma(-hx * y, y, 0.5);
-    y = dfma(y, e, y);
-    e = dfma(-hx * y, y, 0.5);
-    y = dfma(y, e, y);
-    return y;
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = dfma(-x * y, y, 1.0);
+    return dfma(y * e, dfma(e, 0.375, 0.5), y);
 #else
     return 1.0 / std::sqrt(x);
 #endif
 }
 
-IKD_FN double dsqrt(double x) { return __builtin_sqrt(x); }
+// sqrt(x) for x >= 0 in the normal range (0 maps to 0): x * rsqrt(x) with one correction step.
+IKD_FN double dsqrt(double x) {
+#if IKD_ON_DEVICE
+    const double y = drsqrt(dmax(x, 1e-300));
+    const double s = x * y;
+    return dfma(dfma(-s, s, x), 0.5 * y, s);
+#else
+    return __builtin_sqrt(x);
+#endif
+}
 
 // sin and cos of one argument.  Cody-Waite reduction by pi/2 with an FMA'd two-constant split
 // (exact enough for |x| <~ 1e5; joint angles are clamped to their limits every iteration),

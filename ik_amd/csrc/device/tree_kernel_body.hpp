@@ -35,27 +35,29 @@ IKD_FN void dls_tree_body(const TreeKernelArgs<NJ, NCH> &a, const TreeDesc<NJ, N
                           AnyFn any_active) {
     const bool valid = gid < a.B;
     const int64_t b = valid ? gid : a.B - 1;
-    double qb[7], qj[NCH][NJ];
+    double qb[7], qj0[NJ], qj1[NJ];  // chain 1's angles stay unused (zero) when NCH == 1
 #pragma unroll
     for (int k = 0; k < 7; ++k) qb[k] = a.q0[at(a.layout, a.B, a.nq, k, b)];  // free-flyer: idx_q = 0
 #pragma unroll
-    for (int c = 0; c < NCH; ++c)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) qj[c][j] = a.q0[at(a.layout, a.B, a.nq, a.qidx[c][j], b)];
+    for (int j = 0; j < NJ; ++j) {
+        qj0[j] = a.q0[at(a.layout, a.B, a.nq, a.qidx[0][j], b)];
+        qj1[j] = NCH > 1 ? a.q0[at(a.layout, a.B, a.nq, a.qidx[NCH - 1][j], b)] : 0.0;
+    }
     const double *tl = a.layout == LAYOUT_SOA ? a.targets + b : a.targets + b * a.ntasks * 12;
     const int64_t ts = a.layout == LAYOUT_SOA ? a.B : 1;
 
     int iters;
     bool success;
-    tree_dls<NJ, NCH>(d, a.prm, qb, qj, tl, ts, a.tslot, iters, success, park, any_active);
+    tree_dls<NJ, NCH>(d, a.prm, qb, qj0, qj1, tl, ts, a.tslot, iters, success, park, any_active);
 
     if (!valid) return;
 #pragma unroll
     for (int k = 0; k < 7; ++k) a.q_out[at(a.layout, a.B, a.nq, k, b)] = qb[k];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) a.q_out[at(a.layout, a.B, a.nq, a.qidx[c][j], b)] = qj[c][j];
+    for (int j = 0; j < NJ; ++j) {
+        a.q_out[at(a.layout, a.B, a.nq, a.qidx[0][j], b)] = qj0[j];
+        if (NCH > 1) a.q_out[at(a.layout, a.B, a.nq, a.qidx[NCH - 1][j], b)] = qj1[j];
+    }
     for (int i = 0; i < a.nq; ++i) {  // entries outside every task support: only ever clamped
         if (a.q_in_chain[i]) continue;
         const double v = a.q0[at(a.layout, a.B, a.nq, i, b)];

@@ -179,6 +179,7 @@ IKD_FN void leg_eval_factor(const double (&R1)[9], const double (&p1)[3], const 
     }
     se3_compose_const(R, p, frame_pl);
 
+    IKD_SCHED_FENCE();
     TaskTerms t;
     task_terms(R, p, oMt, w6, t);
     if (prio0) {
@@ -189,6 +190,7 @@ IKD_FN void leg_eval_factor(const double (&R1)[9], const double (&p1)[3], const 
     base_columns(t, R, p, R1, p1, JL, JA);
     accumulate_base(JL, JA, t.e, Hbb, gb);
 
+    IKD_SCHED_FENCE();
     // chain columns
     double col[NJ][6];
 #pragma unroll
@@ -205,6 +207,7 @@ IKD_FN void leg_eval_factor(const double (&R1)[9], const double (&p1)[3], const 
             col[j][3 + i] = dfma(t.Ab[3 * i], wl[0], dfma(t.Ab[3 * i + 1], wl[1], t.Ab[3 * i + 2] * wl[2]));
         }
     }
+    IKD_SCHED_FENCE();
     // H_ll (packed), H_lb -> W, g_l -> u
 #pragma unroll
     for (int a = 0; a < NJ; ++a) {
@@ -228,6 +231,7 @@ IKD_FN void leg_eval_factor(const double (&R1)[9], const double (&p1)[3], const 
         for (int r = 0; r < 6; ++r) s = dfma(col[a][r], t.e[r], s);
         F.u[a] = s;
     }
+    IKD_SCHED_FENCE();
     // Cholesky of H_ll; forward-substitute the 6 + 1 right-hand sides alongside
 #pragma unroll
     for (int k = 0; k < NJ; ++k) {
@@ -360,10 +364,10 @@ IKD_FN void freeflyer_integrate(const double (&qb)[7], const double (&R1)[9], co
 
 // One full solve.  The chains share ONE copy of the evaluation / factorisation code (a rolled 2-trip
 // loop: the unrolled body of one chain is ~3000 instructions, two inlined copies overflow the
-// instruction cache).  Chain 0's factor (L, W) is parked while chain 1 is processed -- `park` stores /
+// instruction cache).  Chain 0's factor (L, W, u) is parked while chain 1 is processed -- `park` stores /
 // reloads it: LDS [entry][lane] on the device (conflict-free ds_write/read_b64), a plain copy on the host.
 template <int NJ, int NCH, class Park, class AnyFn>
-IKD_FN void tree_dls(const TreeDesc<NJ, NCH> &d, const TreeParams &prm, double (&qb)[7], double (&qj)[NCH][NJ],
+IKD_FN void tree_dls(const TreeDesc<NJ, NCH> &d, const TreeParams &prm, double (&qb)[7], double (&qj0)[NJ], double (&qj1)[NJ],
                      const double *targets_lane, int64_t tstride, const int (&tslot)[3], int &iters_out,
                      bool &success_out, Park park, AnyFn any_active) {
     bool active = true, success = false;
@@ -371,8 +375,8 @@ IKD_FN void tree_dls(const TreeDesc<NJ, NCH> &d, const TreeParams &prm, double (
 #pragma unroll 1
     for (int it = 0; it < prm.max_iterations; ++it) {
         asm volatile("" ::: "memory");  // re-read the LDS table and the targets every iteration (see chain_solver.hpp)
-        double R1[9];
-        quat_to_R(qb, R1);
+        // R1 = R(quaternion) is recomputed where it is needed (24 instructions) instead of being kept live
+        // across the chain bodies: nine doubles less at the register-pressure peak.
         const double p1[3] = {qb[0], qb[1], qb[2]};
         double Hbb[21], gb[6], e0sq = 0.0;
 #pragma unroll
@@ -382,27 +386,24 @@ IKD_FN void tree_dls(const TreeDesc<NJ, NCH> &d, const TreeParams &prm, double (
             gb[i] = 0.0;
         }
         LegFactor<NJ> F;
-        double u0[NJ];
 #pragma unroll 1
         for (int c = 0; c < NCH; ++c) {
             const ChainTable<NJ> &ct = d.chain[c];
-            double q[NJ], oMt[12];
+            double q[NJ], oMt[12], R1[9];
+            quat_to_R(qb, R1);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) q[j] = (NCH > 1 && c == 1) ? qj[NCH - 1][j] : qj[0][j];
+            for (int j = 0; j < NJ; ++j) q[j] = (NCH > 1 && c == 1) ? qj1[j] : qj0[j];
 #pragma unroll
             for (int k = 0; k < 12; ++k) oMt[k] = targets_lane[(tslot[c] * 12 + k) * tstride];
             leg_eval_factor<NJ>(R1, p1, ct.pl, ct.fr, ct.w, q, oMt, prm.lam2, prm.prio[c] == 0, Hbb, gb, e0sq, F);
-            if (NCH > 1 && c == 0) {
-                park.store(F);
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) u0[j] = F.u[j];
-            }
+            if (NCH > 1 && c == 0) park.store(F);
         }
         if (prm.hasP) {
             double oMt[12];
 #pragma unroll
             for (int k = 0; k < 12; ++k) oMt[k] = targets_lane[(tslot[2] * 12 + k) * tstride];
-            double Rf[9], pf[3];
+            double Rf[9], pf[3], R1[9];
+            quat_to_R(qb, R1);
 #pragma unroll
             for (int k = 0; k < 9; ++k) Rf[k] = R1[k];
 #pragma unroll
@@ -435,23 +436,23 @@ IKD_FN void tree_dls(const TreeDesc<NJ, NCH> &d, const TreeParams &prm, double (
 #pragma unroll 1
         for (int c = NCH - 1; c >= 0; --c) {
             const ChainTable<NJ> &ct = d.chain[c];
-            if (NCH > 1 && c == 0) {
-                park.load(F);
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) F.u[j] = u0[j];
-            }
+            if (NCH > 1 && c == 0) park.load(F);
             double dql[NJ];
             leg_back_substitute<NJ>(F, dqb, dql);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const double qold = (NCH > 1 && c == 1) ? qj[NCH - 1][j] : qj[0][j];
+                const double qold = (NCH > 1 && c == 1) ? qj1[j] : qj0[j];
                 const double qc = dmin(ct.hi[j], dmax(dfma(prm.step_length, dql[j], qold), ct.lo[j]));
                 const double qn = active ? qc : qold;
-                if (NCH > 1 && c == 1) qj[NCH - 1][j] = qn; else qj[0][j] = qn;
+                // two separate arrays updated through selects: anything indexed by the runtime chain
+                // number `c` would be demoted from registers to scratch memory
+                qj1[j] = (NCH > 1 && c == 1) ? qn : qj1[j];
+                qj0[j] = (NCH > 1 && c == 1) ? qj0[j] : qn;
             }
         }
         {
-            double v[6], qn[7];
+            double v[6], qn[7], R1[9];
+            quat_to_R(qb, R1);
 #pragma unroll
             for (int i = 0; i < 6; ++i) v[i] = prm.step_length * dqb[i];
             freeflyer_integrate(qb, R1, v, qn);

@@ -173,55 +173,64 @@ using ikdev::LegFactor;
 using ikdev::TreeDesc;
 using ikdev::TreeKernelArgs;
 
-// While chain 1 is evaluated, chain 0's factor (L packed + W) is parked in LDS as [entry][lane]:
-// consecutive lanes hit consecutive 8-byte words, so every ds_write_b64 / ds_read_b64 is conflict-free.
+// While chain 1 is evaluated, chain 0's factor (L packed, W, u: 77 doubles for NJ = 7) is parked in LDS as
+// [entry][lane]: consecutive lanes hit consecutive 8-byte words, so every ds_write_b64 / ds_read_b64 is
+// conflict-free.  77 x 512 B = 38.5 KB per wave: two waves share a workgroup (and one copy of the constant
+// table) so that four waves -- one per SIMD -- fit the CU's 160 KB of LDS.
+constexpr int kTreeWaves = 2;
+constexpr int kTreeBlock = 64 * kTreeWaves;
+
 template <int NJ>
 struct LdsPark {
     static constexpr int kL = NJ * (NJ + 1) / 2;
-    static constexpr int kEntries = kL + NJ * 6;
-    double (*buf)[kBlock];
+    static constexpr int kEntries = kL + NJ * 6 + NJ;
+    double (*buf)[64];
     int lane;
     __device__ __forceinline__ void store(const LegFactor<NJ> &F) const {
 #pragma unroll
         for (int e = 0; e < kL; ++e) buf[e][lane] = F.L[e];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+        for (int j = 0; j < NJ; ++j) {
 #pragma unroll
             for (int c = 0; c < 6; ++c) buf[kL + j * 6 + c][lane] = F.W[j][c];
+            buf[kL + NJ * 6 + j][lane] = F.u[j];
+        }
     }
     __device__ __forceinline__ void load(LegFactor<NJ> &F) const {
 #pragma unroll
         for (int e = 0; e < kL; ++e) F.L[e] = buf[e][lane];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+        for (int j = 0; j < NJ; ++j) {
 #pragma unroll
             for (int c = 0; c < 6; ++c) F.W[j][c] = buf[kL + j * 6 + c][lane];
+            F.u[j] = buf[kL + NJ * 6 + j][lane];
+        }
     }
 };
 
 template <int NJ, int NCH>
-__device__ __forceinline__ const TreeDesc<NJ, NCH> &stage_tree_desc(const TreeDesc<NJ, NCH> *src, double *lds) {
+__device__ __forceinline__ const TreeDesc<NJ, NCH> &stage_tree_desc(const TreeDesc<NJ, NCH> *src, double *lds, int nthreads) {
     constexpr int kWords = sizeof(TreeDesc<NJ, NCH>) / sizeof(double);
     const double *g = reinterpret_cast<const double *>(src);
-    for (int i = threadIdx.x; i < kWords; i += kBlock) lds[i] = g[i];
+    for (int i = threadIdx.x; i < kWords; i += nthreads) lds[i] = g[i];
     __syncthreads();
     return *reinterpret_cast<const TreeDesc<NJ, NCH> *>(lds);
 }
 
 template <int NJ, int NCH>
-__global__ __launch_bounds__(kBlock) void dls_tree_kernel(const TreeKernelArgs<NJ, NCH> a) {
+__global__ __launch_bounds__(kTreeBlock) void dls_tree_kernel(const TreeKernelArgs<NJ, NCH> a) {
     __shared__ double lds_desc[sizeof(TreeDesc<NJ, NCH>) / sizeof(double)];
-    __shared__ double lds_park[NCH > 1 ? LdsPark<NJ>::kEntries : 1][kBlock];
-    const TreeDesc<NJ, NCH> &d = stage_tree_desc<NJ, NCH>(a.desc, lds_desc);
-    const int64_t gid = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-    LdsPark<NJ> park{lds_park, static_cast<int>(threadIdx.x)};
+    __shared__ double lds_park[kTreeWaves][NCH > 1 ? LdsPark<NJ>::kEntries : 1][64];
+    const TreeDesc<NJ, NCH> &d = stage_tree_desc<NJ, NCH>(a.desc, lds_desc, kTreeBlock);
+    const int64_t gid = static_cast<int64_t>(blockIdx.x) * kTreeBlock + threadIdx.x;
+    LdsPark<NJ> park{lds_park[threadIdx.x / 64], static_cast<int>(threadIdx.x % 64)};
     ikdev::dls_tree_body<NJ, NCH>(a, d, gid, park, [](bool act) { return __any(act) != 0; });
 }
 
 template <int NJ, int NCH>
 __global__ __launch_bounds__(kBlock) void eval_tree_kernel(const TreeKernelArgs<NJ, NCH> a) {
     __shared__ double lds_desc[sizeof(TreeDesc<NJ, NCH>) / sizeof(double)];
-    const TreeDesc<NJ, NCH> &d = stage_tree_desc<NJ, NCH>(a.desc, lds_desc);
+    const TreeDesc<NJ, NCH> &d = stage_tree_desc<NJ, NCH>(a.desc, lds_desc, kBlock);
     ikdev::eval_tree_body<NJ, NCH>(a, d, static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x);
 }
 
@@ -250,7 +259,8 @@ hipError_t run_dls_tree(const ProblemHost &ph, const DeviceTables &dt, const Bat
     a.prm.stop_sq_tol = prm.stop_sq_tol;
     a.layout = io.layout; a.B = io.B; a.q0 = io.q0; a.targets = io.targets;
     a.q_out = io.q_out; a.success = io.success; a.iters = io.iters;
-    hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH>), grid_for(io.B), dim3(kBlock), 0, stream, a);
+    hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH>), dim3(static_cast<unsigned>((io.B + kTreeBlock - 1) / kTreeBlock)), dim3(kTreeBlock), 0,
+                       stream, a);
     return hipGetLastError();
 }
 

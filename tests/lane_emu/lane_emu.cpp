@@ -61,8 +61,10 @@ struct HostPark {  // the device parks chain 0's factor in LDS; the host keeps a
     void store(const ikdev::LegFactor<NJ> &F) const { saved = F; }
     void load(ikdev::LegFactor<NJ> &F) const {
         for (int e = 0; e < NJ * (NJ + 1) / 2; ++e) F.L[e] = saved.L[e];
-        for (int j = 0; j < NJ; ++j)
+        for (int j = 0; j < NJ; ++j) {
             for (int c = 0; c < 6; ++c) F.W[j][c] = saved.W[j][c];
+            F.u[j] = saved.u[j];
+        }
     }
 };
 

@@ -1,0 +1,13 @@
+#!/usr/bin/env bash
+# PMC passes for one bench workload (separate rocprofv3 runs, --pmc only with --kernel-trace):
+#   tools/pmc_session.sh <workload> <outdir-under-gpurun_out>
+set -u
+W="$1"; OUT="$GRAFT_REPO_ROOT/gpurun_out/$2"; mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+run() { name="$1"; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 5 --warmup 2 --no-cpu --workload "$W" > "$OUT/$name.log" 2>&1 || echo "pass $name failed"; }
+run fetch FETCH_SIZE
+run write WRITE_SIZE
+run lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS
+run sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES
+run grbm GRBM_GUI_ACTIVE
+find "$OUT" -name "*counter_collection.csv" | head
