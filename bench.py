@@ -172,6 +172,11 @@ def main():
         bps = bytes_per_solve(w)
         achieved = bps * B / (kernel_ms * 1e-3) / 1e9
         stats = load_kernel_stats().get(data.kernel, {})
+        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+        # separate runs, gfx950 correction applied: tools/pmc_to_stats.py); measured at B = 65536, linear in B.
+        traffic = None
+        if stats.get("hbm_traffic_bytes_per_launch") and stats.get("pmc", {}).get("batch"):
+            traffic = stats["hbm_traffic_bytes_per_launch"] * B / stats["pmc"]["batch"]
         res = {
             "metric": "IK solves/sec (50-iter DLS) at batch=65536",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -183,7 +188,7 @@ def main():
                        "kernel": data.kernel,
                        "parallelism": "batch-sharded x%d + all-gather" % world if distributed else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": stats.get("hbm_traffic_bytes_per_launch"),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_solve": bps,
                          "note": "fused on-chip loop: the binding roof is FP64 VALU issue, see valu_roofline"},
         }

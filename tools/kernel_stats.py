@@ -17,9 +17,10 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = {  # display name -> mangled-name fragment
-    "dls_chain<NJ=7,full>": "dls_chain_kernelILi7ELi2E",
-    "dls_chain<NJ=6,full>": "dls_chain_kernelILi6ELi2E",
+KERNELS = {  # display name -> (mangled-name fragment, trip count of loops nested in the iteration loop)
+    "dls_chain<NJ=7,full>": ("dls_chain_kernelILi7ELi2E", 1),
+    "dls_chain<NJ=6,full>": ("dls_chain_kernelILi6ELi2E", 1),
+    "dls_tree<NJ=7,chains=2,base_task>": ("dls_tree_kernelILi7ELi2E", 2),
 }
 FLOPS = {"v_fma_f64": 2, "v_fmac_f64": 2, "v_mul_f64": 1, "v_add_f64": 1, "v_min_f64": 1, "v_max_f64": 1,
          "v_rcp_f64": 1, "v_rsq_f64": 1, "v_rndne_f64": 1, "v_ldexp_f64": 1, "v_cvt_i32_f64": 1, "v_cvt_f64_i32": 1,
@@ -36,32 +37,58 @@ def main():
         subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
         text = open(asm).read()
     out = {}
-    for disp, frag in KERNELS.items():
+    for disp, (frag, trips) in KERNELS.items():
         m = re.search(r"^(_Z\w*%s\w*):" % re.escape(frag), text, re.M)
         if not m:
             continue
         name = m.group(1)
         body = text[m.end():text.index(".Lfunc_end", m.end())].split("\n")
-        # Blocks carry "; =>This Inner Loop Header" / ";   in Loop: Header=BBn_m" comments: take the loop with
-        # the most instructions (the DLS iteration loop; the other one is the LDS staging loop).
-        loops = collections.defaultdict(collections.Counter)
+        # Blocks carry "; =>This Inner Loop Header" / "; =>This Loop Header" / ";   in Loop: Header=BBn_m Depth=d"
+        # comments.  The DLS iteration loop is the depth-1 loop with the most instructions (the LDS staging loop is
+        # the other one); blocks of loops nested inside it (the rolled 2-trip chain loops of the tree kernel) are
+        # weighted by their trip count.
+        per_header = collections.defaultdict(collections.Counter)   # header label -> instruction counts of its own blocks
+        depth_of, parent_of = {}, {}
         cur = None
         for l in body:
             t = l.strip()
             mlab = re.match(r"^\.?L?(BB\d+_\d+):", t)
             if mlab or t.startswith("; %bb."):
-                if "Inner Loop Header" in t and mlab:
+                mh = re.search(r"in Loop: Header=(BB\d+_\d+) Depth=(\d+)", t)
+                if mlab and ("Loop Header: Depth=" in t):
                     cur = mlab.group(1)
+                    depth_of[cur] = int(re.search(r"Loop Header: Depth=(\d+)", t).group(1))
+                elif mh:
+                    cur = mh.group(1)
+                    depth_of.setdefault(cur, int(mh.group(2)))
                 else:
-                    mh = re.search(r"in Loop: Header=(BB\d+_\d+)", t)
-                    cur = mh.group(1) if mh else None
+                    cur = None
+                continue
+            mp = re.search(r"Parent Loop (BB\d+_\d+) Depth=(\d+)", t)
+            if mp and cur is not None and t.startswith(";"):
+                parent_of[cur] = mp.group(1)
                 continue
             if cur is None or not t or t.startswith((".", ";", "//")):
                 continue
-            loops[cur][re.sub(r"_e(32|64)$", "", t.split()[0])] += 1
-        if not loops:
+            per_header[cur][re.sub(r"_e(32|64)$", "", t.split()[0])] += 1
+        if not per_header:
             continue
-        c = max(loops.values(), key=lambda cc: sum(cc.values()))
+        # children: loops whose header block says "Parent Loop X"; blocks "in Loop: Header=H" belong to H
+        for h in list(per_header):
+            if h not in parent_of and depth_of.get(h, 1) > 1:
+                # a nested loop whose header line lacked the Parent comment: attach to the largest depth-1 loop
+                parent_of[h] = None
+        tops = [h for h in per_header if depth_of.get(h, 1) == 1]
+        def total(h):
+            c = collections.Counter(per_header[h])
+            for k, par in parent_of.items():
+                if par == h or (par is None and h == main):
+                    sub = total(k)
+                    for kk, vv in sub.items():
+                        c[kk] += vv * trips
+            return c
+        main = max(tops, key=lambda h: sum(per_header[h].values()) + sum(sum(per_header[k].values()) for k in per_header if depth_of.get(k, 1) > 1))
+        c = total(main)
         meta = text[text.index(name, text.index(".amdhsa_kernel")):]
         def grab(key):
             mm = re.search(r"%s\s+(\d+)" % key, meta)
