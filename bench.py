@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--workload", default="cassie_leg", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--gather", action="store_true", help="run the all-gather step even at N = 1 (rehearsal)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,8 +114,12 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    distributed = world > 1
-    if distributed:
+    # Under torch.distributed.run (RANK / WORLD_SIZE set) the process group is always created, also for N = 1,
+    # so that a one-GPU rehearsal (`python -m torch.distributed.run --nproc-per-node 1 bench.py --gather`) runs the
+    # very same RCCL code path the N > 1 launch takes.
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    distributed = world > 1 or (launched and args.gather)
+    if launched:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
@@ -133,35 +138,49 @@ def main():
     Q0 = torch.from_numpy(np.ascontiguousarray(q0_np.T)).to(dev)
     QS = torch.from_numpy(np.ascontiguousarray(qs_np.T)).to(dev)
     targets = ik_amd.task_frames_fk_batch(problem, QS, data)  # FK(q*) on the device: reachable targets
-    out = (torch.empty_like(Q0), torch.empty(B, dtype=torch.uint8, device=dev), torch.empty(B, dtype=torch.int32, device=dev))
-    bufs = ikdist.GatherBuffers(model.nq, B, world, dev) if distributed else None
+    # two buffer sets alternate so that the all-gather of step k overlaps the solve of step k + 1
+    bufs = [ikdist.ShardBuffers(model.nq, B, world, dev) for _ in range(2)]
+    out = bufs[0].out()
     visitor = ik_amd.never_stop_visitor()
     prm = ik_amd.dls_parameters(max_iterations=args.iters, damping=1e-2, step_length=1.0)
 
+    state = {"k": 0}
+
     def step(ev=None):
+        buf = bufs[state["k"] % 2]
+        state["k"] += 1
+        if distributed:
+            buf.wait()  # the gather issued two steps ago must have drained this buffer set
         if ev is not None:
             ev[0].record()
-        ik_amd.dls_batch(problem, Q0, targets, data, visitor, prm, out=out)
+        ik_amd.dls_batch(problem, Q0, targets, data, visitor, prm, out=buf.out())
         if ev is not None:
             ev[1].record()
         if distributed:
-            ikdist.all_gather_solutions(out[0], out[1], out[2], bufs)
+            buf.all_gather(async_op=True)
+
+    def drain():
+        for buf in bufs:
+            buf.wait()
 
     for _ in range(args.warmup):
         step()
+    drain()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if distributed:
+    if launched:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(events[k])
+    drain()
+    out = bufs[(state["k"] - 1) % 2].out()
     torch.cuda.synchronize()
-    if distributed:
+    if launched:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if distributed:
+    if launched:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -186,7 +205,7 @@ def main():
                                    % (w["text"], args.iters),
                        "name": args.workload, "batch_per_gpu": B, "global_batch": B * world, "iterations": args.iters,
                        "kernel": data.kernel,
-                       "parallelism": "batch-sharded x%d + all-gather" % world if distributed else "single GPU"},
+                       "parallelism": "batch-sharded x%d + RCCL all-gather" % world if distributed else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_solve": bps,
@@ -208,7 +227,7 @@ def main():
                                     "max_abs_dq_rad_not_converged": float(d[~conv].max()) if (~conv).any() else None,
                                     "bar_rad": 1e-6}
         print(json.dumps(res))
-    if distributed:
+    if launched:
         dist.barrier()
         dist.destroy_process_group()
 

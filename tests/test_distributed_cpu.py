@@ -1,6 +1,6 @@
 """World-size-2 `gloo` test of the multi-GPU path's host logic: contiguous sharding of the
-batch, per-rank generation of exactly its own shard, ONE all-gather of the solutions into the
-[world][nq][B/world] layout.  On CPU the per-rank solver is the oracle (the device kernels need a GPU);
+batch, per-rank generation of exactly its own shard, ONE all-gather of each rank's packed
+(q | iterations | success) block into the [world][nq][B/world] layout.  On CPU the per-rank solver is the oracle (the device kernels need a GPU);
 the collective code is the same function bench.py runs over RCCL."""
 import os
 import socket
@@ -42,10 +42,16 @@ def _worker(rank, world, port, total, outdir):
                                          workload.cassie_nominal(model.names), np.arange(lo, hi), seed=0, mode="near")
         tg = O.fk_batch(om, qs, [fid])
         q, ok, it = O.dls_batch(om, tasks, tg, q0, O.params(20, 1e-2, 1.0, 1e-4))
-        bufs = ikdist.GatherBuffers(model.nq, hi - lo, world, torch.device("cpu"))
-        Q, OK, IT = ikdist.all_gather_solutions(torch.from_numpy(np.ascontiguousarray(q.T)), torch.from_numpy(ok),
-                                                torch.from_numpy(it), bufs)
-        np.savez(os.path.join(outdir, "rank%d.npz" % rank), Q=Q.numpy(), OK=OK.numpy(), IT=IT.numpy())
+        bufs = ikdist.ShardBuffers(model.nq, hi - lo, world, torch.device("cpu"))
+        Q, OK, IT = bufs.out()                     # the views a device solve writes into
+        Q.copy_(torch.from_numpy(np.ascontiguousarray(q.T)))
+        OK.copy_(torch.from_numpy(ok))
+        IT.copy_(torch.from_numpy(it))
+        bufs.all_gather(async_op=True)             # the same call bench.py issues over RCCL
+        bufs.wait()
+        Qs, OKs, ITs = bufs.gathered()
+        np.savez(os.path.join(outdir, "rank%d.npz" % rank), Q=np.stack([x.numpy() for x in Qs]),
+                 OK=np.stack([x.numpy() for x in OKs]), IT=np.stack([x.numpy() for x in ITs]))
     finally:
         dist.destroy_process_group()
 
