@@ -211,12 +211,13 @@ def main():
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_solve": bps,
                          "note": "fused on-chip loop: the binding roof is FP64 VALU issue, see valu_roofline"},
         }
-        if stats.get("flop_per_iteration"):
-            flops = stats["flop_per_iteration"] * args.iters
+        if stats.get("flop_per_solve_measured") and args.iters == 50:
+            flops = stats["flop_per_solve_measured"]
             tf = flops * B / (kernel_ms * 1e-3) / 1e12
             res["valu_roofline"] = {"bound": "fp64_valu", "achieved": tf, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
                                     "frac": tf / FP64_VALU_PEAK_TF, "flop_per_solve": flops,
-                                    "counting": "FP64 VALU instructions in the kernel's loop body (FMA = 2), static ISA count"}
+                                    "counting": "executed FP64 VALU instructions per launch from the SQ_INSTS_VALU_{FMA,MUL,ADD,"
+                                                "TRANS}_F64 counters (x 64 lanes, FMA = 2), 50 iterations; profiles/r01_pmc"}
         if not args.no_cpu:
             tg_np = targets.permute(2, 0, 1).contiguous().cpu().numpy()
             cpu, q_ref, sample, conv = cpu_baseline(model, w["frames"], q0_np, tg_np, args.iters)

@@ -93,7 +93,7 @@ IKD_FN void eval_chain_body(const ChainKernelArgs<NJ> &a, const ChainDesc<NJ> &d
     double oMt[12];
     load_target(a, b, oMt);
     double e[M], col[NJ][M], Rf[9], pf[3];
-    chain_evaluate<NJ, KT>(d, q, oMt, e, col, Rf, pf);
+    chain_evaluate<NJ, KT>(d, q, oMt, a.prm.idmask, a.prm.unit_weights != 0, e, col, Rf, pf);
 #pragma unroll
     for (int r = 0; r < M; ++r) a.e_out[at(a.layout, a.B, M, r, b)] = e[r];
     if (a.J_out) {
@@ -102,7 +102,7 @@ IKD_FN void eval_chain_body(const ChainKernelArgs<NJ> &a, const ChainDesc<NJ> &d
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int r = 0; r < M; ++r) a.J_out[at(a.layout, a.B, M * a.nv, r * a.nv + a.vidx[j], b)] = col[j][r];
+            for (int r = 0; r < M; ++r) a.J_out[at(a.layout, a.B, M * a.nv, r * a.nv + a.vidx[j], b)] = -col[j][r];
     }
 }
 
@@ -117,12 +117,12 @@ IKD_FN void fk_chain_body(const ChainKernelArgs<NJ> &a, const ChainDesc<NJ> &d, 
     for (int k = 0; k < 3; ++k) p[k] = d.pl[0][9 + k];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        if (j > 0) se3_compose_const(R, p, d.pl[j]);
+        if (j > 0) se3_compose_const(R, p, d.pl[j], (a.prm.idmask >> j) & 1);
         double s, c;
         dsincos(a.q0[at(a.layout, a.B, a.nq, a.qidx[j], b)], s, c);
         rot_z_right(R, s, c);
     }
-    se3_compose_const(R, p, d.frame_pl);
+    se3_compose_const(R, p, d.frame_pl, (a.prm.idmask >> NJ) & 1);
 #pragma unroll
     for (int k = 0; k < 9; ++k) a.oMf_out[at(a.layout, a.B, 12, k, b)] = R[k];
 #pragma unroll

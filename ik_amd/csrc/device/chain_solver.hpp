@@ -36,6 +36,8 @@ struct LoopParams {
     double step_length;
     double stop_sq_tol;  // < 0: never stop
     int priority;        // priority level of the task (the stop test reads priority-0 rows only)
+    int idmask;          // bit j: placement pl[j] has an exactly-identity rotation; bit NJ: frame_pl has
+    int unit_weights;    // every Task::weighting() entry is exactly 1
 };
 
 template <int KT>
@@ -43,11 +45,12 @@ struct TaskDim {
     static constexpr int value = (KT == KT_FULL) ? 6 : 3;
 };
 
-// Evaluate e (M), the M x NJ task Jacobian columns, for the chain at configuration q.
+// Evaluate e (M) and the NEGATED M x NJ task Jacobian columns (col = -J_task(:, j) = +W Jlog6(tMf) J_local(:, j):
+// the minus sign of reference ik/ik/frame.hpp:173-181 is folded into the step, dq = +col^T y) at configuration q.
 // oMt: target placement in the world (reference frame fixed in the world), 12 doubles.
 template <int NJ, int KT>
-IKD_FN void chain_evaluate(const ChainDesc<NJ> &d, const double (&q)[NJ], const double (&oMt)[12],
-                           double (&e)[TaskDim<KT>::value], double (&col)[NJ][TaskDim<KT>::value],
+IKD_FN void chain_evaluate(const ChainDesc<NJ> &d, const double (&q)[NJ], const double (&oMt)[12], int idmask,
+                           bool unit_weights, double (&e)[TaskDim<KT>::value], double (&col)[NJ][TaskDim<KT>::value],
                            double (&Rf)[9], double (&pf)[3]) {
     constexpr int M = TaskDim<KT>::value;
     double zax[NJ][3], org[NJ][3];
@@ -58,14 +61,14 @@ IKD_FN void chain_evaluate(const ChainDesc<NJ> &d, const double (&q)[NJ], const 
     for (int k = 0; k < 3; ++k) p[k] = d.pl[0][9 + k];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        if (j > 0) se3_compose_const(R, p, d.pl[j]);
+        if (j > 0) se3_compose_const(R, p, d.pl[j], (idmask >> j) & 1);
         double s, c;
         dsincos(q[j], s, c);
         rot_z_right(R, s, c);
         zax[j][0] = R[2]; zax[j][1] = R[5]; zax[j][2] = R[8];
         org[j][0] = p[0]; org[j][1] = p[1]; org[j][2] = p[2];
     }
-    se3_compose_const(R, p, d.frame_pl);
+    se3_compose_const(R, p, d.frame_pl, (idmask >> NJ) & 1);
 #pragma unroll
     for (int k = 0; k < 9; ++k) Rf[k] = R[k];
 #pragma unroll
@@ -84,33 +87,45 @@ IKD_FN void chain_evaluate(const ChainDesc<NJ> &d, const double (&q)[NJ], const 
     LogAndJlog lj;
     log6_and_jlog6_inv(Re, pe, lj);
 
-    // K = -diag(w) * Jlog6(tMf) restricted to the task rows:  top rows [At | Bt], bottom rows [0 | Ab]
+    // K' = +diag(w) * Jlog6(tMf) restricted to the task rows:  top rows [At | Bt], bottom rows [0 | Ab]
     double At[9], Bt[9], Ab[9];
-    if (KT == KT_FULL || KT == KT_POSITION) {
+    constexpr int w0 = (KT == KT_FULL) ? 3 : 0;
+    if (unit_weights) {  // wave-uniform
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < 9; ++k) { At[k] = lj.A[k]; Bt[k] = lj.Bm[k]; Ab[k] = lj.A[k]; }
+        if (KT == KT_FULL) {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                At[3 * i + j] = -d.wgt[i] * lj.A[3 * i + j];
-                Bt[3 * i + j] = -d.wgt[i] * lj.Bm[3 * i + j];
-            }
-    }
-    if (KT == KT_FULL || KT == KT_ORIENTATION) {
-        constexpr int w0 = (KT == KT_FULL) ? 3 : 0;
+            for (int i = 0; i < 6; ++i) e[i] = lj.e[i];
+        } else {
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) Ab[3 * i + j] = -d.wgt[w0 + i] * lj.A[3 * i + j];
-    }
-    if (KT == KT_FULL) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) e[i] = lj.e[i] * d.wgt[i];
-    } else if (KT == KT_POSITION) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) e[i] = lj.e[i] * d.wgt[i];
+            for (int i = 0; i < 3; ++i) e[i] = lj.e[(KT == KT_ORIENTATION ? 3 : 0) + i];
+        }
     } else {
+        if (KT == KT_FULL || KT == KT_POSITION) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) e[i] = lj.e[3 + i] * d.wgt[i];
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    At[3 * i + j] = d.wgt[i] * lj.A[3 * i + j];
+                    Bt[3 * i + j] = d.wgt[i] * lj.Bm[3 * i + j];
+                }
+        }
+        if (KT == KT_FULL || KT == KT_ORIENTATION) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) Ab[3 * i + j] = d.wgt[w0 + i] * lj.A[3 * i + j];
+        }
+        if (KT == KT_FULL) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) e[i] = lj.e[i] * d.wgt[i];
+        } else if (KT == KT_POSITION) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) e[i] = lj.e[i] * d.wgt[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) e[i] = lj.e[3 + i] * d.wgt[i];
+        }
     }
 
     // columns: J_local(:, j) = [r x w' ; w'],  w' = Rf^T z_j,  r = Rf^T (o_j - p_f)
@@ -152,7 +167,7 @@ IKD_FN void chain_dls(const ChainDesc<NJ> &d, const LoopParams &prm, double (&q)
         // ds_read, off the VALU) instead of letting the compiler hoist ~150 doubles into registers.
         asm volatile("" ::: "memory");
         double e[M], col[NJ][M], Rf[9], pf[3];
-        chain_evaluate<NJ, KT>(d, q, oMt, e, col, Rf, pf);
+        chain_evaluate<NJ, KT>(d, q, oMt, prm.idmask, prm.unit_weights != 0, e, col, Rf, pf);
 
         double G[M * M];
 #pragma unroll
@@ -181,7 +196,7 @@ IKD_FN void chain_dls(const ChainDesc<NJ> &d, const LoopParams &prm, double (&q)
             double s = 0.0;
 #pragma unroll
             for (int a = 0; a < M; ++a) s = dfma(col[j][a], y[a], s);
-            const double qn = dfma(prm.step_length, -s, q[j]);
+            const double qn = dfma(prm.step_length, s, q[j]);  // dq_j = -J_task(:, j)^T y = +col_j^T y
             const double qc = dmin(d.hi[j], dmax(qn, d.lo[j]));
             q[j] = active ? qc : q[j];
         }

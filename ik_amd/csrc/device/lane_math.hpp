@@ -30,8 +30,10 @@
 // which is what pushes the big kernels over the 512-register budget.  No instruction is emitted.
 #if IKD_ON_DEVICE
 #define IKD_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define IKD_ANY(pred) (__any(pred) != 0)  // true in every lane when the predicate holds in some lane of the wave
 #else
 #define IKD_SCHED_FENCE() ((void)0)
+#define IKD_ANY(pred) (pred)
 #endif
 
 namespace ikdev {
@@ -169,8 +171,15 @@ IKD_FN double dacos(double x) {
 // SE(3) pieces.  A rotation is 9 doubles row-major; everything is fully unrolled.
 // ---------------------------------------------------------------------------------------------
 
-// (R, p) <- (R, p) * (Rc, pc)   with (Rc, pc) = c[0..11], uniform constants
-IKD_FN void se3_compose_const(double (&R)[9], double (&p)[3], const double *c) {
+// (R, p) <- (R, p) * (Rc, pc)   with (Rc, pc) = c[0..11], uniform constants.
+// rot_identity is wave-uniform (a bit of the problem's placement mask, computed on the host): when Rc is
+// exactly the identity the 27 rotation FMAs are skipped -- multiplying by exact ones and zeros changes no bit.
+IKD_FN void se3_compose_const(double (&R)[9], double (&p)[3], const double *c, bool rot_identity = false) {
+    if (rot_identity) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) p[i] = dfma(R[3 * i], c[9], dfma(R[3 * i + 1], c[10], dfma(R[3 * i + 2], c[11], p[i])));
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const double a = R[3 * i], b = R[3 * i + 1], d = R[3 * i + 2];
@@ -230,9 +239,9 @@ IKD_FN void log6_and_jlog6_inv(const double (&Re)[9], const double (&pe)[3], Log
     // log3, regular branch
     const double fac = 0.5 * dsel(theta > kTaylorPrec3, theta * drcp(st), 1.0);
     double w[3] = {fac * (Re[7] - Re[5]), fac * (Re[2] - Re[6]), fac * (Re[3] - Re[1])};
-    // log3, theta >= pi - 1e-2
-    {
-        const bool near_pi = theta >= kPi - 1e-2;
+    // log3, theta >= pi - 1e-2: evaluated only when some lane of the wave is there (wave-uniform branch)
+    const bool near_pi = theta >= kPi - 1e-2;
+    if (IKD_ANY(near_pi)) {
         const double cphi = -x;
         const double beta_pi = t2 * drcp(1.0 + cphi);
         const double t0 = (Re[0] + cphi) * beta_pi, t1 = (Re[4] + cphi) * beta_pi, t2v = (Re[8] + cphi) * beta_pi;

@@ -95,14 +95,14 @@ IKD_FN void eval_tree_body(const TreeKernelArgs<NJ, NCH> &a, const TreeDesc<NJ, 
         for (int k = 0; k < 9; ++k) R[k] = R1[k];
         for (int k = 0; k < 3; ++k) p[k] = p1[k];
         for (int j = 0; j < nj; ++j) {
-            se3_compose_const(R, p, ct.pl[j]);
+            se3_compose_const(R, p, ct.pl[j], (a.prm.idmask[c] >> j) & 1);
             double s, cs;
             dsincos(a.q0[at(a.layout, a.B, a.nq, a.qidx[c][j], b)], s, cs);
             rot_z_right(R, s, cs);
             zax[j][0] = R[2]; zax[j][1] = R[5]; zax[j][2] = R[8];
             org[j][0] = p[0]; org[j][1] = p[1]; org[j][2] = p[2];
         }
-        se3_compose_const(R, p, is_chain ? ct.fr : d.frP);
+        se3_compose_const(R, p, is_chain ? ct.fr : d.frP, is_chain ? ((a.prm.idmask[c] >> NJ) & 1) : (a.prm.idmaskP & 1));
         if (a.oMf_out) {
             for (int k = 0; k < 9; ++k) a.oMf_out[at(a.layout, a.B, a.ntasks * 12, a.tslot[slot] * 12 + k, b)] = R[k];
             for (int k = 0; k < 3; ++k) a.oMf_out[at(a.layout, a.B, a.ntasks * 12, a.tslot[slot] * 12 + 9 + k, b)] = p[k];
@@ -111,7 +111,7 @@ IKD_FN void eval_tree_body(const TreeKernelArgs<NJ, NCH> &a, const TreeDesc<NJ, 
         double oMt[12];
         for (int k = 0; k < 12; ++k) oMt[k] = tl[(a.tslot[slot] * 12 + k) * ts];
         TaskTerms t;
-        task_terms(R, p, oMt, is_chain ? ct.w : d.wP, t);
+        task_terms(R, p, oMt, is_chain ? ct.w : d.wP, (is_chain ? a.prm.unit[c] : a.prm.unitP) != 0, t);
         double JL[3][3], JA[3][6], col[NJ][6];
         base_columns(t, R, p, R1, p1, JL, JA);
         for (int j = 0; j < nj; ++j) {
@@ -132,10 +132,10 @@ IKD_FN void eval_tree_body(const TreeKernelArgs<NJ, NCH> &a, const TreeDesc<NJ, 
             if (a.J_out) {
                 for (int cc = 0; cc < a.nv; ++cc) a.J_out[at(a.layout, a.B, Mtot * a.nv, row * a.nv + cc, b)] = 0.0;
                 for (int cc = 0; cc < 3; ++cc) {
-                    a.J_out[at(a.layout, a.B, Mtot * a.nv, row * a.nv + cc, b)] = lr < 3 ? JL[cc][lr] : 0.0;
-                    a.J_out[at(a.layout, a.B, Mtot * a.nv, row * a.nv + 3 + cc, b)] = JA[cc][lr];
+                    a.J_out[at(a.layout, a.B, Mtot * a.nv, row * a.nv + cc, b)] = lr < 3 ? -JL[cc][lr] : 0.0;
+                    a.J_out[at(a.layout, a.B, Mtot * a.nv, row * a.nv + 3 + cc, b)] = -JA[cc][lr];
                 }
-                for (int j = 0; j < nj; ++j) a.J_out[at(a.layout, a.B, Mtot * a.nv, row * a.nv + a.vidx[c][j], b)] = col[j][lr];
+                for (int j = 0; j < nj; ++j) a.J_out[at(a.layout, a.B, Mtot * a.nv, row * a.nv + a.vidx[c][j], b)] = -col[j][lr];
             }
         }
     }

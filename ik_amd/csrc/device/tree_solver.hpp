@@ -43,6 +43,8 @@ struct TreeParams {
     double lam2, step_length, stop_sq_tol;
     int prio[2], prioP;  // priority level per task; the stop test sums priority-0 rows
     int hasP;            // a base task is present
+    int idmask[2], idmaskP;  // identity-rotation placement masks (see chain_solver.hpp LoopParams::idmask)
+    int unit[2], unitP;      // the task is Full with all-ones weights
 };
 
 // Packed lower-triangular index
@@ -61,13 +63,13 @@ IKD_FN void quat_to_R(const double (&qb)[7], double (&R)[9]) {
 }
 
 // What one frame task contributes, given its frame placement (Rf, pf) in the world:
-// weighted error e (6), and K = -diag(w) Jlog6(tMf) as blocks: top rows [At | Bt], bottom rows [0 | Ab].
+// weighted error e (6), and K' = +diag(w) Jlog6(tMf) as blocks: top rows [At | Bt], bottom rows [0 | Ab].
 struct TaskTerms {
     double e[6];
     double At[9], Bt[9], Ab[9];
 };
 
-IKD_FN void task_terms(const double (&Rf)[9], const double (&pf)[3], const double (&oMt)[12], const double *w6,
+IKD_FN void task_terms(const double (&Rf)[9], const double (&pf)[3], const double (&oMt)[12], const double *w6, bool unit,
                        TaskTerms &t) {
     double Re[9], pe[3];
 #pragma unroll
@@ -78,6 +80,15 @@ IKD_FN void task_terms(const double (&Rf)[9], const double (&pf)[3], const doubl
     rotT_vec(Rf, dp, pe);
     LogAndJlog lj;
     log6_and_jlog6_inv(Re, pe, lj);
+    // K' = +diag(w) Jlog6(tMf): the task Jacobian is carried NEGATED (J' = -J_task); H = J'^T J' is unchanged and
+    // the right-hand side becomes g' = J'^T e = -J_task^T e, so the system solved is H dq = g'.
+    if (unit) {  // wave-uniform: Full task, all weights exactly 1
+#pragma unroll
+        for (int k = 0; k < 6; ++k) t.e[k] = lj.e[k];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { t.At[k] = lj.A[k]; t.Bt[k] = lj.Bm[k]; t.Ab[k] = lj.A[k]; }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const double wt = w6[i], wb = w6[3 + i];
@@ -85,9 +96,9 @@ IKD_FN void task_terms(const double (&Rf)[9], const double (&pf)[3], const doubl
         t.e[3 + i] = lj.e[3 + i] * wb;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            t.At[3 * i + j] = -wt * lj.A[3 * i + j];
-            t.Bt[3 * i + j] = -wt * lj.Bm[3 * i + j];
-            t.Ab[3 * i + j] = -wb * lj.A[3 * i + j];
+            t.At[3 * i + j] = wt * lj.A[3 * i + j];
+            t.Bt[3 * i + j] = wt * lj.Bm[3 * i + j];
+            t.Ab[3 * i + j] = wb * lj.A[3 * i + j];
         }
     }
 }
@@ -160,8 +171,8 @@ struct LegFactor {
 // (Hbb, gb), eliminate its NJ joint unknowns (Schur complement onto the base) and return the factor.
 template <int NJ>
 IKD_FN void leg_eval_factor(const double (&R1)[9], const double (&p1)[3], const double (*pl)[12], const double *frame_pl,
-                            const double *w6, const double (&q)[NJ], const double (&oMt)[12], double lam2, bool prio0,
-                            double (&Hbb)[21], double (&gb)[6], double &e0sq, LegFactor<NJ> &F) {
+                            const double *w6, int idmask, bool unit, const double (&q)[NJ], const double (&oMt)[12],
+                            double lam2, bool prio0, double (&Hbb)[21], double (&gb)[6], double &e0sq, LegFactor<NJ> &F) {
     double zax[NJ][3], org[NJ][3];
     double R[9], p[3];
 #pragma unroll
@@ -170,18 +181,18 @@ IKD_FN void leg_eval_factor(const double (&R1)[9], const double (&p1)[3], const 
     for (int k = 0; k < 3; ++k) p[k] = p1[k];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        se3_compose_const(R, p, pl[j]);
+        se3_compose_const(R, p, pl[j], (idmask >> j) & 1);
         double s, c;
         dsincos(q[j], s, c);
         rot_z_right(R, s, c);
         zax[j][0] = R[2]; zax[j][1] = R[5]; zax[j][2] = R[8];
         org[j][0] = p[0]; org[j][1] = p[1]; org[j][2] = p[2];
     }
-    se3_compose_const(R, p, frame_pl);
+    se3_compose_const(R, p, frame_pl, (idmask >> NJ) & 1);
 
     IKD_SCHED_FENCE();
     TaskTerms t;
-    task_terms(R, p, oMt, w6, t);
+    task_terms(R, p, oMt, w6, unit, t);
     if (prio0) {
 #pragma unroll
         for (int r = 0; r < 6; ++r) e0sq = dfma(t.e[r], t.e[r], e0sq);
@@ -276,7 +287,7 @@ IKD_FN void leg_eval_factor(const double (&R1)[9], const double (&p1)[3], const 
     }
 }
 
-// dq_l = -L^-T (u + W dq_b)
+// dq_l = L^-T (u' - W dq_b)   (u' = L^-1 g'_l with the negated Jacobian convention of task_terms)
 template <int NJ>
 IKD_FN void leg_back_substitute(const LegFactor<NJ> &F, const double (&dqb)[6], double (&dql)[NJ]) {
     double t[NJ];
@@ -284,7 +295,7 @@ IKD_FN void leg_back_substitute(const LegFactor<NJ> &F, const double (&dqb)[6], 
     for (int j = 0; j < NJ; ++j) {
         double s = F.u[j];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) s = dfma(F.W[j][c], dqb[c], s);
+        for (int c = 0; c < 6; ++c) s = dfma(-F.W[j][c], dqb[c], s);
         t[j] = s;
     }
 #pragma unroll
@@ -294,8 +305,6 @@ IKD_FN void leg_back_substitute(const LegFactor<NJ> &F, const double (&dqb)[6], 
         for (int m = k + 1; m < NJ; ++m) s = dfma(-F.L[tri(m, k)], dql[m], s);
         dql[k] = s * F.L[tri(k, k)];
     }
-#pragma unroll
-    for (int k = 0; k < NJ; ++k) dql[k] = -dql[k];
 }
 
 // pinocchio::integrate for the free-flyer: q_b <- q_b (+) v, v = [v_lin; omega]
@@ -395,7 +404,8 @@ IKD_FN void tree_dls(const TreeDesc<NJ, NCH> &d, const TreeParams &prm, double (
             for (int j = 0; j < NJ; ++j) q[j] = (NCH > 1 && c == 1) ? qj1[j] : qj0[j];
 #pragma unroll
             for (int k = 0; k < 12; ++k) oMt[k] = targets_lane[(tslot[c] * 12 + k) * tstride];
-            leg_eval_factor<NJ>(R1, p1, ct.pl, ct.fr, ct.w, q, oMt, prm.lam2, prm.prio[c] == 0, Hbb, gb, e0sq, F);
+            leg_eval_factor<NJ>(R1, p1, ct.pl, ct.fr, ct.w, prm.idmask[c], prm.unit[c] != 0, q, oMt, prm.lam2, prm.prio[c] == 0, Hbb,
+                                gb, e0sq, F);
             if (NCH > 1 && c == 0) park.store(F);
         }
         if (prm.hasP) {
@@ -408,9 +418,9 @@ IKD_FN void tree_dls(const TreeDesc<NJ, NCH> &d, const TreeParams &prm, double (
             for (int k = 0; k < 9; ++k) Rf[k] = R1[k];
 #pragma unroll
             for (int k = 0; k < 3; ++k) pf[k] = p1[k];
-            se3_compose_const(Rf, pf, d.frP);
+            se3_compose_const(Rf, pf, d.frP, prm.idmaskP & 1);
             TaskTerms t;
-            task_terms(Rf, pf, oMt, d.wP, t);
+            task_terms(Rf, pf, oMt, d.wP, prm.unitP != 0, t);
             if (prm.prioP == 0) {
 #pragma unroll
                 for (int r = 0; r < 6; ++r) e0sq = dfma(t.e[r], t.e[r], e0sq);
@@ -419,15 +429,13 @@ IKD_FN void tree_dls(const TreeDesc<NJ, NCH> &d, const TreeParams &prm, double (
             base_columns(t, Rf, pf, R1, p1, JL, JA);
             accumulate_base(JL, JA, t.e, Hbb, gb);
         }
-        // base: S dq_b = -g
-        double S[36], x[6], dqb[6];
+        // base: S dq_b = g'
+        double S[36], dqb[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i)
 #pragma unroll
             for (int j = 0; j <= i; ++j) S[i * 6 + j] = Hbb[tri(i, j)];
-        chol_solve<6>(S, gb, x);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) dqb[i] = -x[i];
+        chol_solve<6>(S, gb, dqb);
 
         const bool stop_now = active && (prm.stop_sq_tol >= 0.0) && (e0sq < prm.stop_sq_tol);
         if (stop_now) { success = true; iters = it; }

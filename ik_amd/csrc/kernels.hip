@@ -55,7 +55,7 @@ __global__ __launch_bounds__(kBlock) void fk_chain_kernel(const ChainKernelArgs<
 template <int NJ>
 ChainKernelArgs<NJ> make_args(const ProblemHost &ph, const DeviceTables &dt) {
     ChainKernelArgs<NJ> a{};
-    fill_chain_args(ph, a.ref_pl, a.qidx, a.vidx, &a.nq, &a.nv, &a.prm.priority);
+    fill_chain_args(ph, a.ref_pl, a.qidx, a.vidx, &a.nq, &a.nv, &a.prm.priority, &a.prm.idmask, &a.prm.unit_weights);
     a.desc = reinterpret_cast<const ChainDesc<NJ> *>(dt.chain_desc);
     a.lower = dt.lower;
     a.upper = dt.upper;
@@ -243,6 +243,8 @@ TreeKernelArgs<NJ, NCH> make_tree_args(const ProblemHost &ph, const DeviceTables
     for (int s = 0; s < 3; ++s) { a.tslot[s] = h.tslot[s]; a.trow[s] = h.trow[s]; a.tdim[s] = h.tdim[s]; a.trow0[s] = h.trow0[s]; }
     a.prm.prio[0] = h.prio[0]; a.prm.prio[1] = h.prio[1]; a.prm.prioP = h.prio[2];
     a.prm.hasP = h.hasP;
+    a.prm.idmask[0] = h.idmask[0]; a.prm.idmask[1] = h.idmask[1]; a.prm.idmaskP = h.idmaskP;
+    a.prm.unit[0] = h.unit[0]; a.prm.unit[1] = h.unit[1]; a.prm.unitP = h.unit[2];
     a.desc = reinterpret_cast<const TreeDesc<NJ, NCH> *>(dt.chain_desc);
     a.nq = ph.nq; a.nv = ph.nv; a.ntasks = ph.ntasks;
     a.lower = dt.lower; a.upper = dt.upper; a.q_in_chain = dt.q_in_chain;

@@ -187,7 +187,31 @@ std::vector<double> tree_desc_table(const ProblemHost &ph) {
     return t;
 }
 
-void fill_chain_args(const ProblemHost &ph, double *ref_pl12, int *qidx, int *vidx, int *nq, int *nv, int *priority) {
+namespace {
+bool rot_is_identity(const double *pl) {
+    static const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int k = 0; k < 9; ++k)
+        if (pl[k] != I[k]) return false;
+    return true;
+}
+}  // namespace
+
+int chain_identity_mask(const ChainHost &c) {
+    int m = 0;
+    for (int j = 0; j < c.nj; ++j)
+        if (rot_is_identity(c.pl[j])) m |= 1 << j;
+    if (rot_is_identity(c.frame_pl)) m |= 1 << c.nj;
+    return m;
+}
+
+bool task_has_unit_weights(const ikgpu_task &t) {
+    for (int i = 0; i < task_dim(t); ++i)
+        if (t.weight[i] != 1.0) return false;
+    return true;
+}
+
+void fill_chain_args(const ProblemHost &ph, double *ref_pl12, int *qidx, int *vidx, int *nq, int *nv, int *priority,
+                     int *idmask, int *unit_weights) {
     const ChainHost &c = ph.chain;
     for (int j = 0; j < c.nj; ++j) {
         qidx[j] = c.qidx[j];
@@ -197,6 +221,8 @@ void fill_chain_args(const ProblemHost &ph, double *ref_pl12, int *qidx, int *vi
     *nq = ph.nq;
     *nv = ph.nv;
     *priority = ph.tasks[0].priority;
+    *idmask = chain_identity_mask(c);
+    *unit_weights = task_has_unit_weights(ph.tasks[0]) ? 1 : 0;
 }
 
 TreeArgsHost tree_args(const ProblemHost &ph) {
@@ -216,6 +242,15 @@ TreeArgsHost tree_args(const ProblemHost &ph) {
     }
     a.hasP = ph.base_task >= 0 ? 1 : 0;
     a.nch = ph.chainB.nj > 0 ? 2 : 1;
+    a.idmask[0] = chain_identity_mask(ph.chain);
+    a.idmask[1] = ph.chainB.nj > 0 ? chain_identity_mask(ph.chainB) : 0;
+    a.idmaskP = rot_is_identity(ph.base_frame_pl) ? 1 : 0;
+    for (int s = 0; s < 3; ++s) {
+        // only a Full task with all-ones weights takes the unit path: a Position / Orientation task is a Full
+        // task with zero-weight rows in the tree kernels
+        const int ti = slot_task[s];
+        a.unit[s] = (ti >= 0 && ph.tasks[ti].type == IKGPU_FULL && task_has_unit_weights(ph.tasks[ti])) ? 1 : 0;
+    }
     return a;
 }
 

@@ -51,13 +51,18 @@ ProblemHost analyse_problem(const Model &m, const ikgpu_task *tasks, int ntasks)
 std::vector<double> chain_desc_table(const ProblemHost &ph);
 std::vector<double> tree_desc_table(const ProblemHost &ph);
 // The per-problem scalars of ikdev::ChainKernelArgs<nj>.
-void fill_chain_args(const ProblemHost &ph, double *ref_pl12, int *qidx, int *vidx, int *nq, int *nv, int *priority);
+void fill_chain_args(const ProblemHost &ph, double *ref_pl12, int *qidx, int *vidx, int *nq, int *nv, int *priority,
+                     int *idmask, int *unit_weights);
+// Bit j set when placement j of the chain has an exactly-identity rotation; bit nj for the frame placement.
+int chain_identity_mask(const ChainHost &c);
+bool task_has_unit_weights(const ikgpu_task &t);
 // The per-problem scalars of ikdev::TreeKernelArgs<na, nb>.
 struct TreeArgsHost {
     int qidx[2][kMaxChain], vidx[2][kMaxChain];
     int tslot[3], trow[3], tdim[3], trow0[3];
     int prio[3];
     int hasP, nch;
+    int idmask[2], idmaskP, unit[3];
 };
 TreeArgsHost tree_args(const ProblemHost &ph);
 

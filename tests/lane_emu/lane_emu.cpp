@@ -37,7 +37,7 @@ void run_chain(const ikgpu::ProblemHost &ph, const IO &io) {
     const std::vector<double> t = ikgpu::chain_desc_table(ph);
     if (t.size() * sizeof(double) != sizeof d) throw std::runtime_error("chain desc table size mismatch");
     std::memcpy(&d, t.data(), sizeof d);
-    ikgpu::fill_chain_args(ph, a.ref_pl, a.qidx, a.vidx, &a.nq, &a.nv, &a.prm.priority);
+    ikgpu::fill_chain_args(ph, a.ref_pl, a.qidx, a.vidx, &a.nq, &a.nv, &a.prm.priority, &a.prm.idmask, &a.prm.unit_weights);
     a.lower = ph.lower.data(); a.upper = ph.upper.data(); a.q_in_chain = ph.q_in_chain.data();
     a.layout = io.layout; a.B = io.B; a.q0 = io.q0; a.targets = io.targets;
     a.q_out = io.q_out; a.success = io.success; a.iters = io.iters;
@@ -80,6 +80,8 @@ void run_tree(const ikgpu::ProblemHost &ph, const IO &io) {
         for (int j = 0; j < NJ; ++j) { a.qidx[c][j] = h.qidx[c][j]; a.vidx[c][j] = h.vidx[c][j]; }
     for (int s = 0; s < 3; ++s) { a.tslot[s] = h.tslot[s]; a.trow[s] = h.trow[s]; a.tdim[s] = h.tdim[s]; a.trow0[s] = h.trow0[s]; }
     a.prm.prio[0] = h.prio[0]; a.prm.prio[1] = h.prio[1]; a.prm.prioP = h.prio[2]; a.prm.hasP = h.hasP;
+    a.prm.idmask[0] = h.idmask[0]; a.prm.idmask[1] = h.idmask[1]; a.prm.idmaskP = h.idmaskP;
+    a.prm.unit[0] = h.unit[0]; a.prm.unit[1] = h.unit[1]; a.prm.unitP = h.unit[2];
     a.nq = ph.nq; a.nv = ph.nv; a.ntasks = ph.ntasks;
     a.lower = ph.lower.data(); a.upper = ph.upper.data(); a.q_in_chain = ph.q_in_chain.data();
     a.layout = io.layout; a.B = io.B; a.q0 = io.q0; a.targets = io.targets;

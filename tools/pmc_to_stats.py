@@ -46,6 +46,13 @@ def main(src, kernel, dst, tag):
                 "SQ_LDS_IDX_ACTIVE": mean.get("SQ_LDS_IDX_ACTIVE"), "SQ_INSTS_VALU": mean.get("SQ_INSTS_VALU"),
                 "SQ_ACTIVE_INST_VALU": mean.get("SQ_ACTIVE_INST_VALU"), "SQ_WAVE_CYCLES": mean.get("SQ_WAVE_CYCLES"),
                 "SQ_WAIT_ANY": mean.get("SQ_WAIT_ANY"), "GRBM_GUI_ACTIVE": mean.get("GRBM_GUI_ACTIVE")}
+    if "SQ_INSTS_VALU_FMA_F64" in mean and e["pmc"]["batch"]:
+        # executed FP64 flops per launch, from the hardware instruction counters (wave instructions x 64 lanes, FMA = 2)
+        fl = 64.0 * (2.0 * mean["SQ_INSTS_VALU_FMA_F64"] + mean.get("SQ_INSTS_VALU_MUL_F64", 0.0) +
+                     mean.get("SQ_INSTS_VALU_ADD_F64", 0.0) + mean.get("SQ_INSTS_VALU_TRANS_F64", 0.0))
+        e["flop_per_solve_measured"] = fl / e["pmc"]["batch"]
+        e["pmc"].update({k: mean[k] for k in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64",
+                                              "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_SALU", "SQ_INSTS_VMEM") if k in mean})
     json.dump(stats, open(path, "w"), indent=1)
     print(kernel, json.dumps(e["pmc"]), "traffic MB", traffic / 1e6)
 
