@@ -311,35 +311,32 @@ IKD_FN void log6_and_jlog6_inv(const double (&Re)[9], const double (&pe)[3], Log
 // SPD for lambda > 0, so an unpivoted factorisation solves the same system.
 template <int M>
 IKD_FN void chol_solve(double (&G)[M * M], const double (&b)[M], double (&x)[M]) {
-#pragma unroll
-    for (int k = 0; k < M; ++k) {
-        double d = G[k * M + k];
-#pragma unroll
-        for (int m = 0; m < k; ++m) d = dfma(-G[k * M + m], G[k * M + m], d);
-        const double inv = drsqrt(d);
-        G[k * M + k] = inv;
-#pragma unroll
-        for (int i = k + 1; i < M; ++i) {
-            double s = G[i * M + k];
-#pragma unroll
-            for (int m = 0; m < k; ++m) s = dfma(-G[i * M + m], G[k * M + m], s);
-            G[i * M + k] = s * inv;
-        }
-    }
+    // Right-looking (outer-product) form with the right-hand side carried as an extra row: after column k is
+    // scaled, every trailing update is an independent FMA, so the 1/sqrt of the next pivot overlaps them instead
+    // of waiting behind a dependent dot-product chain (the kernels run one wave per SIMD: latency is exposed).
     double y[M];
 #pragma unroll
-    for (int k = 0; k < M; ++k) {
-        double s = b[k];
+    for (int k = 0; k < M; ++k) y[k] = b[k];
 #pragma unroll
-        for (int m = 0; m < k; ++m) s = dfma(-G[k * M + m], y[m], s);
-        y[k] = s * G[k * M + k];
+    for (int k = 0; k < M; ++k) {
+        const double inv = drsqrt(G[k * M + k]);
+        G[k * M + k] = inv;
+        y[k] = y[k] * inv;
+#pragma unroll
+        for (int i = k + 1; i < M; ++i) G[i * M + k] = G[i * M + k] * inv;
+#pragma unroll
+        for (int i = k + 1; i < M; ++i) {
+#pragma unroll
+            for (int j = k + 1; j <= i; ++j) G[i * M + j] = dfma(-G[i * M + k], G[j * M + k], G[i * M + j]);
+            y[i] = dfma(-G[i * M + k], y[k], y[i]);
+        }
     }
+    // back substitution, column-oriented: once x_k is known every remaining y_m is updated independently
 #pragma unroll
     for (int k = M - 1; k >= 0; --k) {
-        double s = y[k];
+        x[k] = y[k] * G[k * M + k];
 #pragma unroll
-        for (int m = k + 1; m < M; ++m) s = dfma(-G[m * M + k], x[m], s);
-        x[k] = s * G[k * M + k];
+        for (int m = 0; m < k; ++m) y[m] = dfma(-G[k * M + m], x[k], y[m]);
     }
 }
 

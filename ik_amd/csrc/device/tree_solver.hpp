@@ -243,32 +243,26 @@ IKD_FN void leg_eval_factor(const double (&R1)[9], const double (&p1)[3], const 
         F.u[a] = s;
     }
     IKD_SCHED_FENCE();
-    // Cholesky of H_ll; forward-substitute the 6 + 1 right-hand sides alongside
+    // Cholesky of H_ll, right-looking, with the 6 + 1 right-hand sides (W, u) carried as extra rows: every
+    // trailing update is an independent FMA (see chol_solve in lane_math.hpp)
 #pragma unroll
     for (int k = 0; k < NJ; ++k) {
-        double d = F.L[tri(k, k)];
-#pragma unroll
-        for (int m = 0; m < k; ++m) d = dfma(-F.L[tri(k, m)], F.L[tri(k, m)], d);
-        const double inv = drsqrt(d);
+        const double inv = drsqrt(F.L[tri(k, k)]);
         F.L[tri(k, k)] = inv;
 #pragma unroll
+        for (int c = 0; c < 6; ++c) F.W[k][c] = F.W[k][c] * inv;
+        F.u[k] = F.u[k] * inv;
+#pragma unroll
+        for (int i = k + 1; i < NJ; ++i) F.L[tri(i, k)] = F.L[tri(i, k)] * inv;
+#pragma unroll
         for (int i = k + 1; i < NJ; ++i) {
-            double s = F.L[tri(i, k)];
+            const double lik = F.L[tri(i, k)];
 #pragma unroll
-            for (int m = 0; m < k; ++m) s = dfma(-F.L[tri(i, m)], F.L[tri(k, m)], s);
-            F.L[tri(i, k)] = s * inv;
+            for (int jj = k + 1; jj <= i; ++jj) F.L[tri(i, jj)] = dfma(-lik, F.L[tri(jj, k)], F.L[tri(i, jj)]);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) F.W[i][c] = dfma(-lik, F.W[k][c], F.W[i][c]);
+            F.u[i] = dfma(-lik, F.u[k], F.u[i]);
         }
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            double s = F.W[k][c];
-#pragma unroll
-            for (int m = 0; m < k; ++m) s = dfma(-F.L[tri(k, m)], F.W[m][c], s);
-            F.W[k][c] = s * inv;
-        }
-        double s = F.u[k];
-#pragma unroll
-        for (int m = 0; m < k; ++m) s = dfma(-F.L[tri(k, m)], F.u[m], s);
-        F.u[k] = s * inv;
     }
     // Schur complement onto the base: Hbb -= W^T W, gb -= W^T u
 #pragma unroll
@@ -300,10 +294,9 @@ IKD_FN void leg_back_substitute(const LegFactor<NJ> &F, const double (&dqb)[6], 
     }
 #pragma unroll
     for (int k = NJ - 1; k >= 0; --k) {
-        double s = t[k];
+        dql[k] = t[k] * F.L[tri(k, k)];
 #pragma unroll
-        for (int m = k + 1; m < NJ; ++m) s = dfma(-F.L[tri(m, k)], dql[m], s);
-        dql[k] = s * F.L[tri(k, k)];
+        for (int m = 0; m < k; ++m) t[m] = dfma(-F.L[tri(k, m)], dql[k], t[m]);
     }
 }
 
