@@ -10,6 +10,7 @@ like the reference's own (commented-out) tests (ik/test/dls.cpp:10-76):
     ik::FrameTask::create               frame.hpp:123  FrameTask.create(model, frame, type, reference_frame)
     ik::KinematicType                   frame.hpp:20   KinematicType
     ik::dls_parameters                  dls.hpp:24     dls_parameters
+    ik::AlignAxisTask::create           frame.hpp:245  AlignAxisTask.create(model, frame, axis, reference_frame)
     ik::inverse_kinematics_visitor      visitor.hpp:7  inverse_kinematics_visitor (one-parameter family)
     ik::dls_data                        dls.hpp:34     dls_data(problem)  (owns the device handle)
     ik::dls(problem, q0, data, v, p)    dls.hpp:111    dls(problem, q0, data, visitor, p)
@@ -29,6 +30,12 @@ class KinematicType(enum.IntEnum):  # reference ik/ik/frame.hpp:20
     Position = 0
     Orientation = 1
     Full = 2
+
+
+class AlignAxisType(enum.IntEnum):  # reference ik/ik/frame.hpp:202
+    AxisX = 0
+    AxisY = 1
+    AxisZ = 2
 
 
 class SE3:
@@ -138,6 +145,41 @@ class FrameTask:
         return self._weighting
 
 
+class AlignAxisTask:
+    """ik::AlignAxisTask (reference ik/ik/frame.hpp:210-319): one row, e = 1 - axis . target/|target| with the
+    frame's chosen axis expressed in the reference frame.  Runs on the generic kernel."""
+
+    def __init__(self, model, frame, axis, reference_frame="universe"):
+        self.frame, self.reference_frame, self.axis = frame, reference_frame, AlignAxisType(axis)
+        self._frame_id, self._ref_id = model.getFrameId(frame), model.getFrameId(reference_frame)
+        if self._frame_id >= model.nframes:
+            raise ValueError("frame %r not found in model" % frame)
+        if self._ref_id >= model.nframes:
+            raise ValueError("reference frame %r not found in model" % reference_frame)
+        self._weighting = np.ones(1)
+        self.target = np.array([1.0, 0.0, 0.0])  # frame.hpp:307 (uninitialised in the reference)
+
+    @staticmethod
+    def create(model, frame, axis, reference_frame="universe"):
+        return AlignAxisTask(model, frame, axis, reference_frame)
+
+    def dimension(self):
+        return 1
+
+    def weighting(self):
+        return self._weighting
+
+
+def _abi_type(task):
+    return 3 + int(task.axis) if isinstance(task, AlignAxisTask) else int(task.type)
+
+
+def _target12(task):
+    if isinstance(task, AlignAxisTask):
+        return np.concatenate([np.eye(3).reshape(9), np.asarray(task.target, dtype=np.float64).reshape(3)])
+    return task.target.to12()
+
+
 class InverseKinematicsProblem:
     """ik::InverseKinematicsProblem (reference ik/ik/problem.hpp:9-206), frame tasks only --
     the other task kinds are outside the accelerated path."""
@@ -148,6 +190,8 @@ class InverseKinematicsProblem:
         self._tasks = [[] for _ in range(self._max_priority_level + 1)]
         self._frame_tasks = []
         self._frame_tasks_map = {}
+        self._axis_tasks = []
+        self._axis_tasks_map = {}
         self._generation = 0
 
     def max_priority_level(self):
@@ -167,6 +211,18 @@ class InverseKinematicsProblem:
 
     def get_frame_task(self, name):
         return self._frame_tasks[self._frame_tasks_map[name]]
+
+    def add_align_axis_task(self, name, task, priority=0):  # reference ik/ik/problem.hpp:94-105
+        if not 0 <= priority <= self._max_priority_level:
+            raise ValueError("Maximum priority level exceeded!")
+        self._axis_tasks_map.setdefault(name, len(self._axis_tasks))
+        self._axis_tasks.append(task)
+        self._tasks[priority].append(task)
+        self._generation += 1
+        return task
+
+    def get_align_axis_task(self, name):
+        return self._axis_tasks[self._axis_tasks_map[name]]
 
     def get_all_tasks(self, priority):
         return self._tasks[priority]
@@ -227,7 +283,7 @@ class dls_data:
         ordered = problem.ordered_tasks()
         arr = (capi.Task * len(ordered))()
         for i, (t, prio) in enumerate(ordered):
-            arr[i].frame, arr[i].reference, arr[i].type, arr[i].priority = t._frame_id, t._ref_id, int(t.type), prio
+            arr[i].frame, arr[i].reference, arr[i].type, arr[i].priority = t._frame_id, t._ref_id, _abi_type(t), prio
             w = list(np.asarray(t.weighting(), dtype=np.float64)) + [1.0] * 6
             for k in range(6):
                 arr[i].weight[k] = w[k]
@@ -264,7 +320,7 @@ def plan(problem):
     ordered = problem.ordered_tasks()
     arr = (capi.Task * len(ordered))()
     for i, (t, prio) in enumerate(ordered):
-        arr[i].frame, arr[i].reference, arr[i].type, arr[i].priority = t._frame_id, t._ref_id, int(t.type), prio
+        arr[i].frame, arr[i].reference, arr[i].type, arr[i].priority = t._frame_id, t._ref_id, _abi_type(t), prio
         w = list(np.asarray(t.weighting(), dtype=np.float64)) + [1.0] * 6
         for k in range(6):
             arr[i].weight[k] = w[k]
@@ -286,7 +342,7 @@ def dls(problem, q0, data, visitor=None, p=None):
     data._bind(problem)
     model = problem.model()
     q0 = np.ascontiguousarray(q0, dtype=np.float64).reshape(model.nq)
-    tg = np.ascontiguousarray(np.stack([t.target.to12() for t, _ in problem.ordered_tasks()]))
+    tg = np.ascontiguousarray(np.stack([_target12(t) for t, _ in problem.ordered_tasks()]))
     q = np.empty(model.nq)
     ok = np.zeros(1, np.uint8)
     it = np.zeros(1, np.int32)

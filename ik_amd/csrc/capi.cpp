@@ -25,8 +25,17 @@ namespace {
 thread_local std::string g_last_error;
 
 bool shape_built(const ikgpu::ProblemHost &ph) {
+    if (ph.kind == ikgpu::KernelKind::Generic) return true;
     return ph.kind == ikgpu::KernelKind::Chain ? ikgpu::chain_shape_built(ph.chain.nj, ph.tasks[0].type)
                                                : ikgpu::tree_shape_built(ph.chain.nj, ph.chainB.nj > 0 ? 2 : 1);
+}
+
+// Analysis + the "is this specialisation compiled" check; a specialised shape without an instantiation
+// falls back to the generic kernel.  Throws std::runtime_error on invalid input.
+ikgpu::ProblemHost analyse(const ikgpu::Model &m, const ikgpu_task *tasks, int32_t ntasks) {
+    ikgpu::ProblemHost ph = ikgpu::analyse_problem(m, tasks, ntasks);
+    if (!shape_built(ph)) ph = ikgpu::analyse_problem(m, tasks, ntasks, /*force_generic=*/true);
+    return ph;
 }
 
 int fail(int code, const std::string &msg) {
@@ -155,13 +164,10 @@ int ikgpu_problem_create(const ikgpu_model *h, const ikgpu_task *tasks, int32_t 
     *out = nullptr;
     ikgpu::ProblemHost ph;
     try {
-        ph = ikgpu::analyse_problem(h->m, tasks, ntasks);
+        ph = analyse(h->m, tasks, ntasks);
     } catch (const std::exception &e) {
-        const std::string msg = e.what();
-        return fail(msg.rfind("unsupported", 0) == 0 ? IKGPU_ERR_UNSUPPORTED : IKGPU_ERR_INVALID, msg);
+        return fail(IKGPU_ERR_INVALID, e.what());
     }
-    if (!shape_built(ph))
-        return fail(IKGPU_ERR_UNSUPPORTED, "unsupported: no kernel instantiated for " + ph.kernel_name);
 
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -189,9 +195,14 @@ int ikgpu_problem_create(const ikgpu_model *h, const ikgpu_task *tasks, int32_t 
         up(&p->dev.lower, p->host.lower.data(), nq * sizeof(double));
         up(&p->dev.upper, p->host.upper.data(), nq * sizeof(double));
         up(&p->dev.q_in_chain, p->host.q_in_chain.data(), nq);
-        const std::vector<double> desc = p->host.kind == ikgpu::KernelKind::Chain ? ikgpu::chain_desc_table(p->host)
+        if (p->host.kind == ikgpu::KernelKind::Generic) {
+            up(&p->dev.g_ints, p->host.generic.ints.data(), p->host.generic.ints.size() * sizeof(int32_t));
+            up(&p->dev.g_dbls, p->host.generic.dbls.data(), p->host.generic.dbls.size() * sizeof(double));
+        } else {
+            const std::vector<double> desc = p->host.kind == ikgpu::KernelKind::Chain ? ikgpu::chain_desc_table(p->host)
                                                                                      : ikgpu::tree_desc_table(p->host);
-        up(&p->dev.chain_desc, desc.data(), desc.size() * sizeof(double));
+            up(&p->dev.chain_desc, desc.data(), desc.size() * sizeof(double));
+        }
         if (err != hipSuccess) {
             ikgpu_problem_destroy(p);
             return hip_fail(err, "uploading problem tables");
@@ -204,17 +215,14 @@ int ikgpu_problem_create(const ikgpu_model *h, const ikgpu_task *tasks, int32_t 
 int ikgpu_problem_plan(const ikgpu_model *h, const ikgpu_task *tasks, int32_t ntasks, char *out, size_t cap) {
     if (!h || !tasks) return fail(IKGPU_ERR_INVALID, "null argument");
     try {
-        const ikgpu::ProblemHost ph = ikgpu::analyse_problem(h->m, tasks, ntasks);
-        if (!shape_built(ph))
-            return fail(IKGPU_ERR_UNSUPPORTED, "unsupported: no kernel instantiated for " + ph.kernel_name);
+        const ikgpu::ProblemHost ph = analyse(h->m, tasks, ntasks);
         if (out && cap) {
             std::strncpy(out, ph.kernel_name.c_str(), cap - 1);
             out[cap - 1] = '\0';
         }
         return IKGPU_OK;
     } catch (const std::exception &e) {
-        const std::string msg = e.what();
-        return fail(msg.rfind("unsupported", 0) == 0 ? IKGPU_ERR_UNSUPPORTED : IKGPU_ERR_INVALID, msg);
+        return fail(IKGPU_ERR_INVALID, e.what());
     }
 }
 
@@ -225,6 +233,8 @@ void ikgpu_problem_destroy(ikgpu_problem *p) {
     (void)hipFree(p->dev.upper);
     (void)hipFree(p->dev.q_in_chain);
     (void)hipFree(p->dev.chain_desc);
+    (void)hipFree(p->dev.g_ints);
+    (void)hipFree(p->dev.g_dbls);
     delete p;
 }
 
@@ -246,9 +256,10 @@ int ikgpu_dls_solve_batch(const ikgpu_problem *p, int64_t B, const double *q0, c
         DeviceGuard g(p->device);
         if (!g.ok) return fail(IKGPU_ERR_DEVICE, "hipSetDevice failed");
         ikgpu::BatchIO io{B, q0, targets, q_out, success, iters, layout};
-        hipError_t e = p->host.kind == ikgpu::KernelKind::Chain
-                           ? ikgpu::launch_dls_chain(p->host, p->dev, io, *params, static_cast<hipStream_t>(stream))
-                           : ikgpu::launch_dls_tree(p->host, p->dev, io, *params, static_cast<hipStream_t>(stream));
+        const hipStream_t st = static_cast<hipStream_t>(stream);
+        hipError_t e = p->host.kind == ikgpu::KernelKind::Chain  ? ikgpu::launch_dls_chain(p->host, p->dev, io, *params, st)
+                       : p->host.kind == ikgpu::KernelKind::Tree ? ikgpu::launch_dls_tree(p->host, p->dev, io, *params, st)
+                                                                 : ikgpu::launch_dls_generic(p->host, p->dev, io, *params, st);
         if (e != hipSuccess) return hip_fail(e, "launching the DLS kernel");
         return static_cast<int>(IKGPU_OK);
     });
@@ -303,9 +314,10 @@ int ikgpu_evaluate_batch(const ikgpu_problem *p, int64_t B, const double *q, con
     return guarded([&] {
         DeviceGuard g(p->device);
         if (!g.ok) return fail(IKGPU_ERR_DEVICE, "hipSetDevice failed");
-        hipError_t e = p->host.kind == ikgpu::KernelKind::Chain
-                           ? ikgpu::launch_eval_chain(p->host, p->dev, B, q, targets, e_out, J_out, layout, static_cast<hipStream_t>(stream))
-                           : ikgpu::launch_eval_tree(p->host, p->dev, B, q, targets, e_out, J_out, nullptr, layout, static_cast<hipStream_t>(stream));
+        const hipStream_t st = static_cast<hipStream_t>(stream);
+        hipError_t e = p->host.kind == ikgpu::KernelKind::Chain  ? ikgpu::launch_eval_chain(p->host, p->dev, B, q, targets, e_out, J_out, layout, st)
+                       : p->host.kind == ikgpu::KernelKind::Tree ? ikgpu::launch_eval_tree(p->host, p->dev, B, q, targets, e_out, J_out, nullptr, layout, st)
+                                                                 : ikgpu::launch_eval_generic(p->host, p->dev, B, q, targets, e_out, J_out, nullptr, layout, st);
         if (e != hipSuccess) return hip_fail(e, "launching the evaluate kernel");
         return static_cast<int>(IKGPU_OK);
     });
@@ -320,9 +332,10 @@ int ikgpu_task_frames_fk_batch(const ikgpu_problem *p, int64_t B, const double *
     return guarded([&] {
         DeviceGuard g(p->device);
         if (!g.ok) return fail(IKGPU_ERR_DEVICE, "hipSetDevice failed");
-        hipError_t e = p->host.kind == ikgpu::KernelKind::Chain
-                           ? ikgpu::launch_fk_chain(p->host, p->dev, B, q, oMf_out, layout, static_cast<hipStream_t>(stream))
-                           : ikgpu::launch_eval_tree(p->host, p->dev, B, q, q, nullptr, nullptr, oMf_out, layout, static_cast<hipStream_t>(stream));
+        const hipStream_t st = static_cast<hipStream_t>(stream);
+        hipError_t e = p->host.kind == ikgpu::KernelKind::Chain  ? ikgpu::launch_fk_chain(p->host, p->dev, B, q, oMf_out, layout, st)
+                       : p->host.kind == ikgpu::KernelKind::Tree ? ikgpu::launch_eval_tree(p->host, p->dev, B, q, q, nullptr, nullptr, oMf_out, layout, st)
+                                                                 : ikgpu::launch_eval_generic(p->host, p->dev, B, q, q, nullptr, nullptr, oMf_out, layout, st);
         if (e != hipSuccess) return hip_fail(e, "launching the FK kernel");
         return static_cast<int>(IKGPU_OK);
     });

@@ -1,0 +1,332 @@
+// generic_solver.hpp -- ik::dls() for ANY model tree and task list the path can express, one problem per
+// lane, as a straight SIMT rendering of the reference loop (reference ik/ik/dls.cpp:5-78, ik/ik/data.cpp:25-58,
+// ik/ik/frame.hpp:37-62,152-182 and :257-301): whole-tree FK, world joint Jacobian, per-task error and dense
+// M x nv Jacobian rows, dense Gram, Cholesky, step, SE(3)/vector integrate, clamp.
+//
+// It is the FALLBACK behind the register-resident specialisations (chain_solver.hpp, tree_solver.hpp): those
+// cover the benchmark shapes; this one covers everything else -- fixed-base multi-task problems, chains that
+// share joints, reference frames that move with q (the reference's Jacobian ignores that motion,
+// ik/ik/frame.hpp:152-182, and so does this), prismatic joints, AlignAxisTask rows -- at memory-bound speed.
+// Every lane runs the same control flow (model and task table are shared), so there is no divergence; the
+// per-lane workspace lives in HBM as [word][lane], which makes every access of a wave a coalesced 512-byte
+// transaction.  Sizes are runtime values; nothing here is unrolled.
+#pragma once
+#include <cstdint>
+
+#include "chain_solver.hpp"
+#include "tree_solver.hpp"
+
+namespace ikdev {
+
+enum : int { GJ_UNIVERSE = 0, GJ_REVOLUTE = 1, GJ_PRISMATIC = 2, GJ_FREEFLYER = 3 };  // == ikgpu_joint_type
+enum : int { GT_POSITION = 0, GT_ORIENTATION = 1, GT_FULL = 2, GT_ALIGN_X = 3 };       // == ikgpu_kinematic_type
+
+// Read-only tables shared by all lanes (device global memory; host memory in the lane emulator).
+struct GenericTables {
+    int njoints, nq, nv, ntasks, M;
+    const int *jtype, *parent, *idx_q, *idx_v;  // [njoints]
+    const double *placement;                    // [njoints][12]
+    const double *axis;                         // [njoints][3]
+    const double *lower, *upper;                // [nq]
+    const int *t_type, *t_fjoint, *t_rjoint, *t_row, *t_dim, *t_prio;  // [ntasks]
+    const double *t_fpl, *t_rpl;                // [ntasks][12] frame / reference placement on their joints
+    const double *t_w;                          // [ntasks][6]
+    // workspace layout, in doubles per lane
+    int off_q, off_oMi, off_Jw, off_e, off_J, off_G, off_y, off_dq, ws_words;
+};
+
+struct Ws {  // word w of this lane
+    double *base;
+    int64_t stride;
+    IKD_FN double &operator[](int w) const { return base[static_cast<int64_t>(w) * stride]; }
+};
+
+IKD_FN void g_se3_mul(const double *A, const double *B, double *C) {  // C = A * B, C may not alias
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) C[3 * i + j] = dfma(A[3 * i], B[j], dfma(A[3 * i + 1], B[3 + j], A[3 * i + 2] * B[6 + j]));
+        C[9 + i] = dfma(A[3 * i], B[9], dfma(A[3 * i + 1], B[10], dfma(A[3 * i + 2], B[11], A[9 + i])));
+    }
+}
+
+IKD_FN void g_se3_inv_mul(const double *A, const double *B, double *C) {  // C = A^-1 * B
+    const double d[3] = {B[9] - A[9], B[10] - A[10], B[11] - A[11]};
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) C[3 * i + j] = dfma(A[i], B[j], dfma(A[3 + i], B[3 + j], A[6 + i] * B[6 + j]));
+        C[9 + i] = dfma(A[i], d[0], dfma(A[3 + i], d[1], A[6 + i] * d[2]));
+    }
+}
+
+// framesForwardKinematics (joints) + computeJointJacobians (ik/ik/data.cpp:28-30) into the workspace: q -> oMi, Jw.
+IKD_FN void generic_fk(const GenericTables &T, const Ws &ws) {
+    {
+        const double I[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+        for (int k = 0; k < 12; ++k) ws[T.off_oMi + k] = I[k];
+    }
+    for (int j = 1; j < T.njoints; ++j) {
+        double Mj[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0}, li[12], oP[12], oM[12];
+        const int iq = T.idx_q[j], iv = T.idx_v[j], jt = T.jtype[j];
+        const double *a = T.axis + 3 * j;
+        if (jt == GJ_REVOLUTE) {
+            double s, c;
+            dsincos(ws[T.off_q + iq], s, c);
+            const double k = 1.0 - c;  // Rodrigues; exact entries for an aligned axis
+            Mj[0] = c + k * a[0] * a[0];        Mj[1] = k * a[0] * a[1] - s * a[2]; Mj[2] = k * a[0] * a[2] + s * a[1];
+            Mj[3] = k * a[1] * a[0] + s * a[2]; Mj[4] = c + k * a[1] * a[1];        Mj[5] = k * a[1] * a[2] - s * a[0];
+            Mj[6] = k * a[2] * a[0] - s * a[1]; Mj[7] = k * a[2] * a[1] + s * a[0]; Mj[8] = c + k * a[2] * a[2];
+        } else if (jt == GJ_PRISMATIC) {
+            const double v = ws[T.off_q + iq];
+            Mj[9] = a[0] * v; Mj[10] = a[1] * v; Mj[11] = a[2] * v;
+        } else if (jt == GJ_FREEFLYER) {
+            double qb[7];
+            for (int k = 0; k < 7; ++k) qb[k] = ws[T.off_q + iq + k];
+            double R[9];
+            quat_to_R(qb, R);
+            for (int k = 0; k < 9; ++k) Mj[k] = R[k];
+            Mj[9] = qb[0]; Mj[10] = qb[1]; Mj[11] = qb[2];
+        }
+        g_se3_mul(T.placement + 12 * j, Mj, li);
+        for (int k = 0; k < 12; ++k) oP[k] = ws[T.off_oMi + 12 * T.parent[j] + k];
+        g_se3_mul(oP, li, oM);
+        for (int k = 0; k < 12; ++k) ws[T.off_oMi + 12 * j + k] = oM[k];
+        // world Jacobian columns [v; w]
+        if (jt == GJ_REVOLUTE || jt == GJ_PRISMATIC) {
+            const double Ra[3] = {dfma(oM[0], a[0], dfma(oM[1], a[1], oM[2] * a[2])), dfma(oM[3], a[0], dfma(oM[4], a[1], oM[5] * a[2])),
+                                  dfma(oM[6], a[0], dfma(oM[7], a[1], oM[8] * a[2]))};
+            const double p[3] = {oM[9], oM[10], oM[11]};
+            double v[3] = {Ra[0], Ra[1], Ra[2]}, w[3] = {0, 0, 0};
+            if (jt == GJ_REVOLUTE) {
+                cross(p, Ra, v);
+                w[0] = Ra[0]; w[1] = Ra[1]; w[2] = Ra[2];
+            }
+            for (int r = 0; r < 3; ++r) { ws[T.off_Jw + r * T.nv + iv] = v[r]; ws[T.off_Jw + (3 + r) * T.nv + iv] = w[r]; }
+        } else if (jt == GJ_FREEFLYER) {  // Ad(oM1) = [[R, [p]x R], [0, R]]
+            const double p[3] = {oM[9], oM[10], oM[11]};
+            for (int c = 0; c < 3; ++c) {
+                const double Rc[3] = {oM[c], oM[3 + c], oM[6 + c]};
+                double pxR[3];
+                cross(p, Rc, pxR);
+                for (int r = 0; r < 3; ++r) {
+                    ws[T.off_Jw + r * T.nv + iv + c] = Rc[r];
+                    ws[T.off_Jw + (3 + r) * T.nv + iv + c] = 0.0;
+                    ws[T.off_Jw + r * T.nv + iv + 3 + c] = pxR[r];
+                    ws[T.off_Jw + (3 + r) * T.nv + iv + 3 + c] = Rc[r];
+                }
+            }
+        }
+    }
+}
+
+// evaluate_problem_data (ik/ik/data.cpp:25-58) into the workspace: q -> oMi, Jw, et, Jt.  Returns ||e[0]||^2.
+IKD_FN double generic_evaluate(const GenericTables &T, const Ws &ws, const double *targets_lane, int64_t tstride) {
+    generic_fk(T, ws);
+    double e0sq = 0.0;
+    for (int t = 0; t < T.ntasks; ++t) {
+        const int fj = T.t_fjoint[t], rj = T.t_rjoint[t], type = T.t_type[t], row = T.t_row[t], dim = T.t_dim[t];
+        const double *w6 = T.t_w + 6 * t;
+        double oJ[12], oMf[12], oMr[12], tg[12];
+        for (int k = 0; k < 12; ++k) oJ[k] = ws[T.off_oMi + 12 * fj + k];
+        g_se3_mul(oJ, T.t_fpl + 12 * t, oMf);
+        for (int k = 0; k < 12; ++k) oJ[k] = ws[T.off_oMi + 12 * rj + k];
+        g_se3_mul(oJ, T.t_rpl + 12 * t, oMr);
+        for (int k = 0; k < 12; ++k) tg[k] = targets_lane[(t * 12 + k) * tstride];
+        for (int r = 0; r < dim; ++r)
+            for (int c = 0; c < T.nv; ++c) ws[T.off_J + (row + r) * T.nv + c] = 0.0;  // frame.hpp:110: zero outside the support
+        const double Rf[9] = {oMf[0], oMf[1], oMf[2], oMf[3], oMf[4], oMf[5], oMf[6], oMf[7], oMf[8]};
+        const double pf[3] = {oMf[9], oMf[10], oMf[11]};
+        if (type >= GT_ALIGN_X) {  // AlignAxisTask, ik/ik/frame.hpp:257-301
+            double rMf[12];
+            g_se3_inv_mul(oMr, oMf, rMf);
+            const int ax = type - GT_ALIGN_X;
+            const double r[3] = {rMf[ax], rMf[3 + ax], rMf[6 + ax]};
+            const double inv = drsqrt(dfma(tg[9], tg[9], dfma(tg[10], tg[10], tg[11] * tg[11])));
+            const double tn[3] = {tg[9] * inv, tg[10] * inv, tg[11] * inv};
+            double rxt[3];
+            cross(r, tn, rxt);
+            const double g[3] = {dfma(rxt[0], rMf[0], dfma(rxt[1], rMf[3], rxt[2] * rMf[6])),
+                                 dfma(rxt[0], rMf[1], dfma(rxt[1], rMf[4], rxt[2] * rMf[7])),
+                                 dfma(rxt[0], rMf[2], dfma(rxt[1], rMf[5], rxt[2] * rMf[8]))};
+            const double e = (1.0 - dot(r, tn)) * w6[0];
+            ws[T.off_e + row] = e;
+            if (T.t_prio[t] == 0) e0sq = dfma(e, e, e0sq);
+            for (int j = fj; j > 0; j = T.parent[j]) {
+                const int n = T.jtype[j] == GJ_FREEFLYER ? 6 : 1;
+                for (int c = T.idx_v[j]; c < T.idx_v[j] + n; ++c) {
+                    const double w[3] = {ws[T.off_Jw + 3 * T.nv + c], ws[T.off_Jw + 4 * T.nv + c], ws[T.off_Jw + 5 * T.nv + c]};
+                    double wl[3];
+                    rotT_vec(Rf, w, wl);
+                    ws[T.off_J + row * T.nv + c] = -w6[0] * dot(g, wl);
+                }
+            }
+            continue;
+        }
+        double oMt[12], Re[9], pe[3];
+        g_se3_mul(oMr, tg, oMt);                        // frame.hpp:48
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) Re[3 * i + j] = dfma(Rf[i], oMt[j], dfma(Rf[3 + i], oMt[3 + j], Rf[6 + i] * oMt[6 + j]));
+        {
+            const double dp[3] = {oMt[9] - pf[0], oMt[10] - pf[1], oMt[11] - pf[2]};
+            rotT_vec(Rf, dp, pe);
+        }
+        LogAndJlog lj;
+        log6_and_jlog6_inv(Re, pe, lj);                 // frame.hpp:50-61, :162-166
+        const int r0 = (type == GT_ORIENTATION) ? 3 : 0;
+        for (int r = 0; r < dim; ++r) {
+            const double e = lj.e[r0 + r] * w6[r];
+            ws[T.off_e + row + r] = e;
+            if (T.t_prio[t] == 0) e0sq = dfma(e, e, e0sq);
+        }
+        for (int j = fj; j > 0; j = T.parent[j]) {      // support of the frame's joint (getFrameJacobian, LOCAL)
+            const int n = T.jtype[j] == GJ_FREEFLYER ? 6 : 1;
+            for (int c = T.idx_v[j]; c < T.idx_v[j] + n; ++c) {
+                double v[3] = {ws[T.off_Jw + c], ws[T.off_Jw + T.nv + c], ws[T.off_Jw + 2 * T.nv + c]};
+                const double w[3] = {ws[T.off_Jw + 3 * T.nv + c], ws[T.off_Jw + 4 * T.nv + c], ws[T.off_Jw + 5 * T.nv + c]};
+                double pxw[3], vl[3], wl[3];
+                cross(pf, w, pxw);
+                v[0] -= pxw[0]; v[1] -= pxw[1]; v[2] -= pxw[2];
+                rotT_vec(Rf, v, vl);
+                rotT_vec(Rf, w, wl);
+                double out[6];
+                for (int i = 0; i < 3; ++i) {
+                    out[i] = -dfma(lj.A[3 * i], vl[0], dfma(lj.A[3 * i + 1], vl[1], dfma(lj.A[3 * i + 2], vl[2],
+                              dfma(lj.Bm[3 * i], wl[0], dfma(lj.Bm[3 * i + 1], wl[1], lj.Bm[3 * i + 2] * wl[2])))));
+                    out[3 + i] = -dfma(lj.A[3 * i], wl[0], dfma(lj.A[3 * i + 1], wl[1], lj.A[3 * i + 2] * wl[2]));
+                }
+                for (int r = 0; r < dim; ++r) ws[T.off_J + (row + r) * T.nv + c] = w6[r] * out[r0 + r];
+            }
+        }
+    }
+    return e0sq;
+}
+
+// One full solve on the workspace (q already stored at off_q).
+template <class AnyFn>
+IKD_FN void generic_dls(const GenericTables &T, const LoopParams &prm, const Ws &ws, const double *targets_lane,
+                        int64_t tstride, int &iters_out, bool &success_out, AnyFn any_active) {
+    bool active = true, success = false;
+    int iters = prm.max_iterations;
+    const int M = T.M, nv = T.nv;
+    for (int it = 0; it < prm.max_iterations; ++it) {
+        const double e0sq = generic_evaluate(T, ws, targets_lane, tstride);
+        // JJ = Jt Jt^T + damping^2 I (lower triangle, packed), ik/ik/dls.cpp:39-41
+        for (int i = 0; i < M; ++i)
+            for (int j = 0; j <= i; ++j) {
+                double s = (i == j) ? prm.lam2 : 0.0;
+                for (int c = 0; c < nv; ++c) s = dfma(ws[T.off_J + i * nv + c], ws[T.off_J + j * nv + c], s);
+                ws[T.off_G + tri(i, j)] = s;
+            }
+        // Cholesky in place (diagonal holds 1/L_ii), forward and backward substitution: y = JJ^-1 et
+        for (int k = 0; k < M; ++k) {
+            double d = ws[T.off_G + tri(k, k)];
+            for (int m = 0; m < k; ++m) { const double l = ws[T.off_G + tri(k, m)]; d = dfma(-l, l, d); }
+            const double inv = drsqrt(d);
+            ws[T.off_G + tri(k, k)] = inv;
+            for (int i = k + 1; i < M; ++i) {
+                double s = ws[T.off_G + tri(i, k)];
+                for (int m = 0; m < k; ++m) s = dfma(-ws[T.off_G + tri(i, m)], ws[T.off_G + tri(k, m)], s);
+                ws[T.off_G + tri(i, k)] = s * inv;
+            }
+        }
+        for (int k = 0; k < M; ++k) {
+            double s = ws[T.off_e + k];
+            for (int m = 0; m < k; ++m) s = dfma(-ws[T.off_G + tri(k, m)], ws[T.off_y + m], s);
+            ws[T.off_y + k] = s * ws[T.off_G + tri(k, k)];
+        }
+        for (int k = M - 1; k >= 0; --k) {
+            double s = ws[T.off_y + k];
+            for (int m = k + 1; m < M; ++m) s = dfma(-ws[T.off_G + tri(m, k)], ws[T.off_y + m], s);
+            ws[T.off_y + k] = s * ws[T.off_G + tri(k, k)];
+        }
+        for (int c = 0; c < nv; ++c) {  // dq = -Jt^T y, ik/ik/dls.cpp:52-53 (N = I)
+            double s = 0.0;
+            for (int r = 0; r < M; ++r) s = dfma(ws[T.off_J + r * nv + c], ws[T.off_y + r], s);
+            ws[T.off_dq + c] = -s;
+        }
+        const bool stop_now = active && (prm.stop_sq_tol >= 0.0) && (e0sq < prm.stop_sq_tol);
+        if (stop_now) { success = true; iters = it; }
+        active = active && !stop_now;
+        // integrate + clip (ik/ik/dls.cpp:67-71)
+        for (int j = 1; j < T.njoints; ++j) {
+            const int iq = T.idx_q[j], iv = T.idx_v[j];
+            if (T.jtype[j] == GJ_FREEFLYER) {
+                double qb[7], v[6], qn[7], R1[9];
+                for (int k = 0; k < 7; ++k) qb[k] = ws[T.off_q + iq + k];
+                for (int k = 0; k < 6; ++k) v[k] = prm.step_length * ws[T.off_dq + iv + k];
+                quat_to_R(qb, R1);
+                freeflyer_integrate(qb, R1, v, qn);
+                for (int k = 0; k < 7; ++k) {
+                    const double c = dmin(T.upper[iq + k], dmax(qn[k], T.lower[iq + k]));
+                    ws[T.off_q + iq + k] = active ? c : qb[k];
+                }
+            } else {
+                const double qo = ws[T.off_q + iq];
+                const double c = dmin(T.upper[iq], dmax(dfma(prm.step_length, ws[T.off_dq + iv], qo), T.lower[iq]));
+                ws[T.off_q + iq] = active ? c : qo;
+            }
+        }
+        if (!any_active(active)) break;
+    }
+    iters_out = iters;
+    success_out = success;
+}
+
+// What one lane of the generic kernels does (shared by kernels.hip and the lane emulator).
+struct GenericKernelArgs {
+    GenericTables T;
+    LoopParams prm;
+    int layout;
+    int64_t B;
+    const double *q0, *targets;
+    double *q_out;
+    uint8_t *success;
+    int32_t *iters;
+    double *ws;          // [ws_words][ws_stride]
+    int64_t ws_stride;   // >= B
+    double *e_out, *J_out, *oMf_out;  // stage kernel
+};
+
+template <class AnyFn>
+IKD_FN void dls_generic_body(const GenericKernelArgs &a, int64_t gid, AnyFn any_active) {
+    const bool valid = gid < a.B;
+    const int64_t b = valid ? gid : a.B - 1;
+    const Ws ws{a.ws + gid, a.ws_stride};  // tail lanes own (padding) workspace columns too: ws_stride is a multiple of 64
+    for (int i = 0; i < a.T.nq; ++i) ws[a.T.off_q + i] = a.q0[at(a.layout, a.B, a.T.nq, i, b)];
+    const double *tl = a.layout == LAYOUT_SOA ? a.targets + b : a.targets + b * a.T.ntasks * 12;
+    const int64_t ts = a.layout == LAYOUT_SOA ? a.B : 1;
+    int iters;
+    bool success;
+    generic_dls(a.T, a.prm, ws, tl, ts, iters, success, any_active);
+    if (!valid) return;
+    for (int i = 0; i < a.T.nq; ++i) a.q_out[at(a.layout, a.B, a.T.nq, i, b)] = ws[a.T.off_q + i];
+    if (a.success) a.success[b] = success ? 1 : 0;
+    if (a.iters) a.iters[b] = iters;
+}
+
+// Stage kernel: e, dense J and the world placement of each task frame.
+IKD_FN void eval_generic_body(const GenericKernelArgs &a, int64_t gid) {
+    if (gid >= a.B) return;
+    const int64_t b = gid;
+    const Ws ws{a.ws + gid, a.ws_stride};
+    for (int i = 0; i < a.T.nq; ++i) ws[a.T.off_q + i] = a.q0[at(a.layout, a.B, a.T.nq, i, b)];
+    const int M = a.T.M, nv = a.T.nv;
+    if (a.e_out || a.J_out) {
+        const double *tl = a.layout == LAYOUT_SOA ? a.targets + b : a.targets + b * a.T.ntasks * 12;
+        const int64_t ts = a.layout == LAYOUT_SOA ? a.B : 1;
+        generic_evaluate(a.T, ws, tl, ts);
+    } else {
+        generic_fk(a.T, ws);  // task-frame FK only: no targets are read
+    }
+    if (a.e_out)
+        for (int r = 0; r < M; ++r) a.e_out[at(a.layout, a.B, M, r, b)] = ws[a.T.off_e + r];
+    if (a.J_out)
+        for (int r = 0; r < M; ++r)
+            for (int c = 0; c < nv; ++c) a.J_out[at(a.layout, a.B, M * nv, r * nv + c, b)] = ws[a.T.off_J + r * nv + c];
+    if (a.oMf_out)
+        for (int t = 0; t < a.T.ntasks; ++t) {
+            double oJ[12], oMf[12];
+            for (int k = 0; k < 12; ++k) oJ[k] = ws[a.T.off_oMi + 12 * a.T.t_fjoint[t] + k];
+            g_se3_mul(oJ, a.T.t_fpl + 12 * t, oMf);
+            for (int k = 0; k < 12; ++k) a.oMf_out[at(a.layout, a.B, a.T.ntasks * 12, t * 12 + k, b)] = oMf[k];
+        }
+}
+
+}  // namespace ikdev

@@ -1,0 +1,24 @@
+// generic_tables.hpp -- binds the packed host tables of the generic kernel (problem.hpp: GenericHost) to the
+// pointer struct its lane program reads (device/generic_solver.hpp: GenericTables), for base pointers that live
+// either on the device (kernels.hip) or on the host (the lane emulator under tests/).
+#pragma once
+#include "device/generic_solver.hpp"
+#include "problem.hpp"
+
+namespace ikgpu {
+
+inline ikdev::GenericTables bind_generic_tables(const ProblemHost &ph, const int32_t *ibase, const double *dbase) {
+    const GenericHost &g = ph.generic;
+    ikdev::GenericTables T{};
+    T.njoints = g.njoints; T.nq = ph.nq; T.nv = ph.nv; T.ntasks = ph.ntasks; T.M = ph.rows;
+    T.jtype = ibase + g.o_jtype; T.parent = ibase + g.o_parent; T.idx_q = ibase + g.o_idx_q; T.idx_v = ibase + g.o_idx_v;
+    T.placement = dbase + g.o_placement; T.axis = dbase + g.o_axis; T.lower = dbase + g.o_lower; T.upper = dbase + g.o_upper;
+    T.t_type = ibase + g.o_ttype; T.t_fjoint = ibase + g.o_tfjoint; T.t_rjoint = ibase + g.o_trjoint;
+    T.t_row = ibase + g.o_trow; T.t_dim = ibase + g.o_tdim; T.t_prio = ibase + g.o_tprio;
+    T.t_fpl = dbase + g.o_tfpl; T.t_rpl = dbase + g.o_trpl; T.t_w = dbase + g.o_tw;
+    T.off_q = g.off_q; T.off_oMi = g.off_oMi; T.off_Jw = g.off_Jw; T.off_e = g.off_e; T.off_J = g.off_J;
+    T.off_G = g.off_G; T.off_y = g.off_y; T.off_dq = g.off_dq; T.ws_words = g.ws_words;
+    return T;
+}
+
+}  // namespace ikgpu

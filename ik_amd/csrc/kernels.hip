@@ -11,6 +11,7 @@
 
 #include "device/chain_kernel_body.hpp"
 #include "device/tree_kernel_body.hpp"
+#include "generic_tables.hpp"
 
 namespace ikgpu {
 namespace {
@@ -304,6 +305,59 @@ hipError_t launch_eval_tree(const ProblemHost &ph, const DeviceTables &dt, int64
     IKGPU_FOR_TREE(X)
 #undef X
     not_built(nj, nch);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Generic fallback kernel: any tree, any task list; workspace in HBM as [word][lane]
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(kBlock) void dls_generic_kernel(const ikdev::GenericKernelArgs a) {
+    ikdev::dls_generic_body(a, static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x, [](bool act) { return __any(act) != 0; });
+}
+
+__global__ __launch_bounds__(kBlock) void eval_generic_kernel(const ikdev::GenericKernelArgs a) {
+    ikdev::eval_generic_body(a, static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x);
+}
+
+hipError_t with_workspace(const ProblemHost &ph, const DeviceTables &dt, ikdev::GenericKernelArgs &a, int64_t B, hipStream_t stream,
+                          bool solve) {
+    a.T = bind_generic_tables(ph, dt.g_ints, dt.g_dbls);
+    a.B = B;
+    a.ws_stride = (B + kBlock - 1) / kBlock * kBlock;
+    const size_t bytes = sizeof(double) * static_cast<size_t>(ph.generic.ws_words) * static_cast<size_t>(a.ws_stride);
+    void *ws = nullptr;
+    hipError_t e = hipMallocAsync(&ws, bytes, stream);
+    if (e != hipSuccess) return e;
+    a.ws = static_cast<double *>(ws);
+    if (solve) hipLaunchKernelGGL(dls_generic_kernel, grid_for(B), dim3(kBlock), 0, stream, a);
+    else hipLaunchKernelGGL(eval_generic_kernel, grid_for(B), dim3(kBlock), 0, stream, a);
+    e = hipGetLastError();
+    const hipError_t f = hipFreeAsync(ws, stream);
+    return e != hipSuccess ? e : f;
+}
+
+}  // namespace
+
+hipError_t launch_dls_generic(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const ikgpu_dls_params &prm,
+                              hipStream_t stream) {
+    ikdev::GenericKernelArgs a{};
+    a.prm.max_iterations = prm.max_iterations;
+    a.prm.lam2 = prm.damping * prm.damping;
+    a.prm.step_length = prm.step_length;
+    a.prm.stop_sq_tol = prm.stop_sq_tol;
+    a.layout = io.layout; a.q0 = io.q0; a.targets = io.targets;
+    a.q_out = io.q_out; a.success = io.success; a.iters = io.iters;
+    return with_workspace(ph, dt, a, io.B, stream, true);
+}
+
+hipError_t launch_eval_generic(const ProblemHost &ph, const DeviceTables &dt, int64_t B, const double *q, const double *targets,
+                               double *e_out, double *J_out, double *oMf_out, int layout, hipStream_t stream) {
+    ikdev::GenericKernelArgs a{};
+    a.layout = layout; a.q0 = q; a.targets = targets;
+    a.e_out = e_out; a.J_out = J_out; a.oMf_out = oMf_out;
+    return with_workspace(ph, dt, a, B, stream, false);
 }
 
 }  // namespace ikgpu

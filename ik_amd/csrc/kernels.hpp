@@ -12,7 +12,9 @@ namespace ikgpu {
 struct DeviceTables {  // per-problem constant arrays resident in HBM
     double *lower = nullptr, *upper = nullptr;  // [nq]
     uint8_t *q_in_chain = nullptr;              // [nq]
-    double *chain_desc = nullptr;               // ikdev::ChainDesc<NJ> as a flat array of doubles
+    double *chain_desc = nullptr;               // ikdev::ChainDesc<NJ> / TreeDesc as a flat array of doubles
+    int32_t *g_ints = nullptr;                  // generic kernel: packed int tables
+    double *g_dbls = nullptr;                   // generic kernel: packed double tables
 };
 
 struct BatchIO {
@@ -45,4 +47,11 @@ hipError_t launch_eval_tree(const ProblemHost &ph, const DeviceTables &dt, int64
                             const double *targets, double *e_out, double *J_out, double *oMf_out, int layout,
                             hipStream_t stream);
 bool tree_shape_built(int nj, int nch);
+// Generic fallback kernel.  The per-lane workspace (ws_words doubles x roundup(B, 64) lanes) is allocated and
+// freed in stream order (hipMallocAsync / hipFreeAsync), so the call stays asynchronous and re-entrant.
+hipError_t launch_dls_generic(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io,
+                              const ikgpu_dls_params &prm, hipStream_t stream);
+hipError_t launch_eval_generic(const ProblemHost &ph, const DeviceTables &dt, int64_t B, const double *q,
+                               const double *targets, double *e_out, double *J_out, double *oMf_out, int layout,
+                               hipStream_t stream);
 }  // namespace ikgpu

@@ -34,7 +34,7 @@ SE3 rot_only(const double *P, bool transpose) {
     return s;
 }
 
-int task_dim(const ikgpu_task &t) { return t.type == IKGPU_FULL ? 6 : 3; }
+int task_dim(const ikgpu_task &t) { return t.type == IKGPU_FULL ? 6 : (t.type >= IKGPU_ALIGN_AXIS_X ? 1 : 3); }
 
 bool is_identity(const SE3 &s) { return s == se3_identity(); }
 
@@ -80,7 +80,126 @@ void weights6(const ikgpu_task &t, double *w6) {
 
 }  // namespace
 
-ProblemHost analyse_problem(const Model &m, const ikgpu_task *tasks, int ntasks) {
+namespace {
+
+struct Unsupported : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+// Chain / Tree specialisations; throws Unsupported when the problem does not have that shape.
+void specialise(ProblemHost &ph, const Model &m) {
+    static const char *kt[] = {"position", "orientation", "full"};
+    const int ntasks = ph.ntasks;
+    for (const ikgpu_task &t : ph.tasks)
+        if (t.type > IKGPU_FULL) throw Unsupported("AlignAxisTask rows run on the generic kernel");
+    const bool free_flyer = m.njoints() > 1 && m.joint_type[1] == IKGPU_JOINT_FREEFLYER;
+    std::vector<uint8_t> in_chain(m.nq, 0);
+
+    auto chain_of = [&](const std::vector<int> &joints, int frame, int task_index) {
+        if (static_cast<int>(joints.size()) > kMaxChain) throw Unsupported("support chain longer than the specialised kernels take");
+        for (int j : joints) {
+            if (m.joint_type[j] != IKGPU_JOINT_REVOLUTE) throw Unsupported("non-revolute joint in a task support");
+            if (in_chain[m.joint_idx_q[j]]) throw Unsupported("a joint is in the support of two tasks");
+        }
+        return build_chain(m, joints, frame, task_index, in_chain);
+    };
+
+    if (!free_flyer) {
+        if (ntasks != 1) throw Unsupported("more than one task on a fixed-base model");
+        const ikgpu_task &t = ph.tasks[0];
+        if (m.frame_parent[t.reference] != 0) throw Unsupported("reference frame moves with the configuration");
+        std::memcpy(ph.ref_pl, m.frame_placement[t.reference].data(), sizeof(double) * 12);
+        std::vector<int> joints;
+        for (int j = m.frame_parent[t.frame]; j > 0; j = m.joint_parent[j]) joints.insert(joints.begin(), j);
+        if (joints.empty()) throw Unsupported("task frame fixed in the world");
+        ph.chain = chain_of(joints, t.frame, 0);
+        ph.kind = KernelKind::Chain;
+        ph.kernel_name = "dls_chain<NJ=" + std::to_string(ph.chain.nj) + "," + kt[t.type] + ">";
+        ph.q_in_chain = in_chain;
+        return;
+    }
+    // free-flyer base: chains hang off joint 1
+    for (int k = 0; k < 7; ++k) in_chain[k] = 1;
+    int nchains = 0;
+    for (int i = 0; i < ntasks; ++i) {
+        const ikgpu_task &t = ph.tasks[i];
+        if (m.frame_parent[t.reference] != 0 || !is_identity(m.frame_placement[t.reference]))
+            throw Unsupported("reference frame other than the universe on a free-flyer model");
+        if (m.frame_parent[t.frame] == 0) throw Unsupported("task frame fixed in the world");
+        std::vector<int> joints;
+        for (int j = m.frame_parent[t.frame]; j > 1; j = m.joint_parent[j]) joints.insert(joints.begin(), j);
+        if (joints.empty()) {
+            if (ph.base_task >= 0) throw Unsupported("two tasks on the floating base link");
+            ph.base_task = i;
+            std::memcpy(ph.base_frame_pl, m.frame_placement[t.frame].data(), sizeof(double) * 12);
+        } else {
+            if (nchains == 2) throw Unsupported("more than two chain tasks on a free-flyer model");
+            (nchains == 0 ? ph.chain : ph.chainB) = chain_of(joints, t.frame, i);
+            ++nchains;
+        }
+    }
+    if (nchains == 0) throw Unsupported("free-flyer problem without a chain task");
+    if (nchains == 2 && ph.chain.nj != ph.chainB.nj) throw Unsupported("the two chains differ in length");
+    ph.kind = KernelKind::Tree;
+    ph.kernel_name = "dls_tree<NJ=" + std::to_string(ph.chain.nj) + ",chains=" + std::to_string(nchains) +
+                     (ph.base_task >= 0 ? ",base_task>" : ">");
+    ph.q_in_chain = in_chain;
+}
+
+void build_generic(ProblemHost &ph, const Model &m) {
+    GenericHost &g = ph.generic;
+    g = GenericHost();
+    const int nj = m.njoints(), nt = ph.ntasks;
+    g.njoints = nj;
+    auto put_i = [&](const std::vector<int32_t> &v) { int o = static_cast<int>(g.ints.size()); g.ints.insert(g.ints.end(), v.begin(), v.end()); return o; };
+    g.o_jtype = put_i(m.joint_type);
+    g.o_parent = put_i(m.joint_parent);
+    g.o_idx_q = put_i(m.joint_idx_q);
+    g.o_idx_v = put_i(m.joint_idx_v);
+    std::vector<int32_t> ttype, tfj, trj, trow, tdim, tprio;
+    for (int i = 0; i < nt; ++i) {
+        const ikgpu_task &t = ph.tasks[i];
+        ttype.push_back(t.type);
+        tfj.push_back(m.frame_parent[t.frame]);
+        trj.push_back(m.frame_parent[t.reference]);
+        trow.push_back(ph.task_row[i]);
+        tdim.push_back(task_dim(t));
+        tprio.push_back(t.priority);
+    }
+    g.o_ttype = put_i(ttype); g.o_tfjoint = put_i(tfj); g.o_trjoint = put_i(trj);
+    g.o_trow = put_i(trow); g.o_tdim = put_i(tdim); g.o_tprio = put_i(tprio);
+    auto put_d = [&](const double *p, size_t n) { int o = static_cast<int>(g.dbls.size()); g.dbls.insert(g.dbls.end(), p, p + n); return o; };
+    g.o_placement = static_cast<int>(g.dbls.size());
+    for (int j = 0; j < nj; ++j) put_d(m.joint_placement[j].data(), 12);
+    g.o_axis = static_cast<int>(g.dbls.size());
+    for (int j = 0; j < nj; ++j) put_d(m.joint_axis[j].data(), 3);
+    g.o_lower = put_d(m.lower.data(), m.lower.size());
+    g.o_upper = put_d(m.upper.data(), m.upper.size());
+    g.o_tfpl = static_cast<int>(g.dbls.size());
+    for (int i = 0; i < nt; ++i) put_d(m.frame_placement[ph.tasks[i].frame].data(), 12);
+    g.o_trpl = static_cast<int>(g.dbls.size());
+    for (int i = 0; i < nt; ++i) put_d(m.frame_placement[ph.tasks[i].reference].data(), 12);
+    g.o_tw = static_cast<int>(g.dbls.size());
+    for (int i = 0; i < nt; ++i) put_d(ph.tasks[i].weight, 6);
+    const int M = ph.rows, nv = m.nv;
+    int o = 0;
+    g.off_q = o; o += m.nq;
+    g.off_oMi = o; o += 12 * nj;
+    g.off_Jw = o; o += 6 * nv;
+    g.off_e = o; o += M;
+    g.off_J = o; o += M * nv;
+    g.off_G = o; o += M * (M + 1) / 2;
+    g.off_y = o; o += M;
+    g.off_dq = o; o += nv;
+    g.ws_words = o;
+    ph.kind = KernelKind::Generic;
+    ph.kernel_name = "dls_generic<M=" + std::to_string(M) + ",nv=" + std::to_string(nv) + ",joints=" + std::to_string(nj - 1) + ">";
+    ph.q_in_chain.assign(m.nq, 1);
+}
+
+}  // namespace
+
+ProblemHost analyse_problem(const Model &m, const ikgpu_task *tasks, int ntasks, bool force_generic) {
     if (ntasks < 1) throw std::runtime_error("a problem needs at least one task");
     ProblemHost ph;
     ph.nq = m.nq;
@@ -94,8 +213,7 @@ ProblemHost analyse_problem(const Model &m, const ikgpu_task *tasks, int ntasks)
         const ikgpu_task &t = tasks[i];
         if (t.frame < 0 || t.frame >= m.nframes()) throw std::runtime_error("task " + std::to_string(i) + ": frame id out of range");
         if (t.reference < 0 || t.reference >= m.nframes()) throw std::runtime_error("task " + std::to_string(i) + ": reference frame id out of range");
-        if (t.type != IKGPU_POSITION && t.type != IKGPU_ORIENTATION && t.type != IKGPU_FULL)
-            throw std::runtime_error("task " + std::to_string(i) + ": unknown kinematic type");
+        if (t.type < IKGPU_POSITION || t.type > IKGPU_ALIGN_AXIS_Z) throw std::runtime_error("task " + std::to_string(i) + ": unknown kinematic type");
         if (t.priority < 0) throw std::runtime_error("task " + std::to_string(i) + ": negative priority");
         if (t.priority < last_prio) throw std::runtime_error("tasks must be listed in stacking order (non-decreasing priority)");
         last_prio = t.priority;
@@ -103,55 +221,15 @@ ProblemHost analyse_problem(const Model &m, const ikgpu_task *tasks, int ntasks)
         ph.task_row.push_back(ph.rows);
         ph.rows += task_dim(t);
     }
-    static const char *kt[] = {"position", "orientation", "full"};
-    const bool free_flyer = m.njoints() > 1 && m.joint_type[1] == IKGPU_JOINT_FREEFLYER;
-
-    if (!free_flyer) {
-        if (ntasks != 1)
-            throw std::runtime_error("unsupported on the device yet: more than one task on a fixed-base model");
-        const ikgpu_task &t = tasks[0];
-        if (m.frame_parent[t.reference] != 0)
-            throw std::runtime_error("unsupported on the device yet: reference frame '" + m.frame_names[t.reference] +
-                                     "' moves with the configuration (only world-fixed reference frames)");
-        std::memcpy(ph.ref_pl, m.frame_placement[t.reference].data(), sizeof(double) * 12);
-        std::vector<int> joints;
-        for (int j = m.frame_parent[t.frame]; j > 0; j = m.joint_parent[j]) joints.insert(joints.begin(), j);
-        if (joints.empty()) throw std::runtime_error("task frame '" + m.frame_names[t.frame] + "' is fixed in the world: nothing to solve");
-        ph.chain = build_chain(m, joints, t.frame, 0, ph.q_in_chain);
-        ph.kind = KernelKind::Chain;
-        ph.kernel_name = "dls_chain<NJ=" + std::to_string(ph.chain.nj) + "," + kt[t.type] + ">";
-        return ph;
-    }
-
-    // free-flyer base: chains hang off joint 1
-    for (int k = 0; k < 7; ++k) ph.q_in_chain[k] = 1;
-    int nchains = 0;
-    for (int i = 0; i < ntasks; ++i) {
-        const ikgpu_task &t = tasks[i];
-        if (m.frame_parent[t.reference] != 0 || !is_identity(m.frame_placement[t.reference]))
-            throw std::runtime_error("unsupported on the device yet: reference frame '" + m.frame_names[t.reference] +
-                                     "' on a free-flyer model (only the universe frame)");
-        std::vector<int> joints;
-        for (int j = m.frame_parent[t.frame]; j > 1; j = m.joint_parent[j]) joints.insert(joints.begin(), j);
-        if (m.frame_parent[t.frame] == 0)
-            throw std::runtime_error("task frame '" + m.frame_names[t.frame] + "' is fixed in the world: nothing to solve");
-        if (joints.empty()) {
-            if (ph.base_task >= 0) throw std::runtime_error("unsupported on the device yet: two tasks on the floating base link");
-            ph.base_task = i;
-            std::memcpy(ph.base_frame_pl, m.frame_placement[t.frame].data(), sizeof(double) * 12);
-        } else {
-            if (nchains == 2) throw std::runtime_error("unsupported on the device yet: more than two chain tasks on a free-flyer model");
-            (nchains == 0 ? ph.chain : ph.chainB) = build_chain(m, joints, t.frame, i, ph.q_in_chain);
-            ++nchains;
+    if (!force_generic) {
+        try {
+            ProblemHost sp = ph;
+            specialise(sp, m);
+            return sp;
+        } catch (const Unsupported &) {
         }
     }
-    if (nchains == 0) throw std::runtime_error("unsupported on the device yet: free-flyer problem without a chain task");
-    if (nchains == 2 && ph.chain.nj != ph.chainB.nj)
-        throw std::runtime_error("unsupported on the device yet: the two chains of a free-flyer problem differ in length (" +
-                                 std::to_string(ph.chain.nj) + " vs " + std::to_string(ph.chainB.nj) + " joints)");
-    ph.kind = KernelKind::Tree;
-    ph.kernel_name = "dls_tree<NJ=" + std::to_string(ph.chain.nj) + ",chains=" + std::to_string(nchains) +
-                     (ph.base_task >= 0 ? ",base_task>" : ">");
+    build_generic(ph, m);
     return ph;
 }
 

@@ -13,9 +13,22 @@ namespace ikgpu {
 
 constexpr int kMaxChain = 8;
 
-// Chain: fixed base, ONE task whose support is a serial chain of revolute joints (shapes S, U).
-// Tree:  free-flyer base, up to two chain tasks + at most one task on the base link (shape F).
-enum class KernelKind { Chain, Tree };
+// Chain:   fixed base, ONE FrameTask whose support is a serial chain of revolute joints (shapes S, U).
+// Tree:    free-flyer base, up to two chain FrameTasks + at most one on the base link (shape F).
+// Generic: everything else the path can express (any tree, any task list incl. AlignAxisTask rows, moving
+//          reference frames, prismatic joints): the memory-resident fallback kernel.
+enum class KernelKind { Chain, Tree, Generic };
+
+// Packed tables of the generic kernel: one int buffer and one double buffer, with the offsets of each table.
+struct GenericHost {
+    std::vector<int32_t> ints;
+    std::vector<double> dbls;
+    int o_jtype = 0, o_parent = 0, o_idx_q = 0, o_idx_v = 0;                       // into ints
+    int o_ttype = 0, o_tfjoint = 0, o_trjoint = 0, o_trow = 0, o_tdim = 0, o_tprio = 0;
+    int o_placement = 0, o_axis = 0, o_lower = 0, o_upper = 0, o_tfpl = 0, o_trpl = 0, o_tw = 0;  // into dbls
+    int njoints = 0;
+    int off_q = 0, off_oMi = 0, off_Jw = 0, off_e = 0, off_J = 0, off_G = 0, off_y = 0, off_dq = 0, ws_words = 0;
+};
 
 // Host copy of one serial chain (support of one task below its base), axis-folded: every joint
 // rotates about its local z.
@@ -40,12 +53,14 @@ struct ProblemHost {
     int base_task = -1;               // Tree kind: index of the task on the base link, or -1
     double base_frame_pl[12] = {};    // base joint frame -> frame of the base task
     double ref_pl[12] = {};           // Chain kind: world placement of the (fixed) reference frame
+    GenericHost generic;              // Generic kind
     std::vector<uint8_t> q_in_chain;  // [nq] 1 if the entry is integrated by the kernel
     std::vector<double> lower, upper;
 };
 
-// Throws std::runtime_error (unsupported shapes say so explicitly, message starts with "unsupported").
-ProblemHost analyse_problem(const Model &m, const ikgpu_task *tasks, int ntasks);
+// Picks the kernel kind from the shape of the problem; force_generic skips the specialisations (used when a
+// specialised shape has no compiled instantiation).  Throws std::runtime_error on invalid input.
+ProblemHost analyse_problem(const Model &m, const ikgpu_task *tasks, int ntasks, bool force_generic = false);
 
 // ikdev::ChainDesc<nj> / ikdev::TreeDesc<na, nb> as the flat array of doubles the kernels stage into LDS.
 std::vector<double> chain_desc_table(const ProblemHost &ph);

@@ -49,7 +49,13 @@ typedef enum {
 typedef enum { IKGPU_JOINT_UNIVERSE = 0, IKGPU_JOINT_REVOLUTE = 1, IKGPU_JOINT_PRISMATIC = 2, IKGPU_JOINT_FREEFLYER = 3 } ikgpu_joint_type;
 
 /* ik::KinematicType, reference ik/ik/frame.hpp:20 (same order). */
-typedef enum { IKGPU_POSITION = 0, IKGPU_ORIENTATION = 1, IKGPU_FULL = 2 } ikgpu_kinematic_type;
+typedef enum {
+    IKGPU_POSITION = 0, IKGPU_ORIENTATION = 1, IKGPU_FULL = 2,
+    /* ik::AlignAxisTask with AlignAxisType::AxisX / AxisY / AxisZ (reference ik/ik/frame.hpp:202-319): one row,
+     * e = 1 - axis . target/|target|.  Its target direction (frame.hpp:307) rides in the translation part
+     * (doubles 9..11) of the task's 12-double target slot; the rotation part is ignored. */
+    IKGPU_ALIGN_AXIS_X = 3, IKGPU_ALIGN_AXIS_Y = 4, IKGPU_ALIGN_AXIS_Z = 5
+} ikgpu_kinematic_type;
 
 typedef enum { IKGPU_SOA = 0, IKGPU_AOS = 1 } ikgpu_layout;
 

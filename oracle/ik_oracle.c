@@ -332,7 +332,7 @@ static void frame_jacobian_local(const iko_model *m, const double *Jw, const dou
     }
 }
 
-static int task_dim(const iko_task *t) { return t->type == IKO_FULL ? 6 : 3; }
+static int task_dim(const iko_task *t) { return t->type == IKO_FULL ? 6 : (t->type >= IKO_ALIGN_X ? 1 : 3); }
 
 int iko_task_rows(const iko_task *tasks, int ntasks) {
     int M = 0;
@@ -388,14 +388,32 @@ static void evaluate_ws(const iko_model *m, const iko_task *tasks, int ntasks, c
             if (t->priority != p) continue;
             const double *oMf = w->oMf + 12 * t->frame, *oMr = w->oMf + 12 * t->reference;
             double oMt[12], fMt[12], tMf[12], e6[6], Jlog[36];
+            const int d = task_dim(t);
+            memset(w->Jl, 0, sizeof(double) * 6 * nv);
+            frame_jacobian_local(m, w->Jw, oMf, m->frame_parent[t->frame], w->Jl); /* frame.hpp:169 / :291 */
+            if (t->type >= IKO_ALIGN_X) {
+                /* AlignAxisTask (frame.hpp:257-301): e = 1 - r . t_hat, J = -(r x t_hat)^T R(rMf) J_local(angular) */
+                double rMf[12], r[3], tn[3], rxt[3], g[3];
+                const int ax = t->type - IKO_ALIGN_X;
+                const double *tg = targets + 12 * ti + 9; /* the direction rides in the translation part */
+                const double nrm = sqrt(tg[0] * tg[0] + tg[1] * tg[1] + tg[2] * tg[2]);
+                se3_inv_mul(oMr, oMf, rMf);
+                for (int i = 0; i < 3; ++i) { r[i] = R_(rMf, i, ax); tn[i] = tg[i] / nrm; }
+                cross3(r, tn, rxt);
+                for (int k = 0; k < 3; ++k) g[k] = rxt[0] * R_(rMf, 0, k) + rxt[1] * R_(rMf, 1, k) + rxt[2] * R_(rMf, 2, k);
+                const double wt = t->weight[0];
+                w->et[row] = (1.0 - dot3(r, tn)) * wt;
+                if (p == 0) acc0 += w->et[row] * w->et[row];
+                for (int c = 0; c < nv; ++c)
+                    w->Jt[row * nv + c] = wt * -(g[0] * w->Jl[3 * nv + c] + g[1] * w->Jl[4 * nv + c] + g[2] * w->Jl[5 * nv + c]);
+                row += d;
+                continue;
+            }
             se3_mul(oMr, targets + 12 * ti, oMt); /* frame.hpp:48 */
             se3_inv_mul(oMf, oMt, fMt);           /* frame.hpp:50 */
             iko_log6(fMt, e6);                    /* frame.hpp:53-61 */
             se3_inv_mul(oMt, oMf, tMf);           /* frame.hpp:162 */
             iko_Jlog6(tMf, Jlog);                 /* frame.hpp:165-166 */
-            memset(w->Jl, 0, sizeof(double) * 6 * nv);
-            frame_jacobian_local(m, w->Jw, oMf, m->frame_parent[t->frame], w->Jl); /* :169 */
-            const int d = task_dim(t);
             const int r0 = (t->type == IKO_ORIENTATION) ? 3 : 0;
             for (int r = 0; r < d; ++r) {         /* frame.hpp:173-181 */
                 const double wt = t->weight[r];   /* data.cpp:49-50 */

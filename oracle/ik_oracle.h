@@ -22,7 +22,10 @@ extern "C" {
 
 enum { IKO_JOINT_UNIVERSE = 0, IKO_JOINT_REVOLUTE = 1, IKO_JOINT_PRISMATIC = 2, IKO_JOINT_FREEFLYER = 3 };
 /* ik::KinematicType, ik/ik/frame.hpp:20 */
-enum { IKO_POSITION = 0, IKO_ORIENTATION = 1, IKO_FULL = 2 };
+enum { IKO_POSITION = 0, IKO_ORIENTATION = 1, IKO_FULL = 2,
+       /* ik::AlignAxisTask with AlignAxisType X / Y / Z (ik/ik/frame.hpp:202-319): one row; its target direction
+        * is the translation part (doubles 9..11) of the task's 12-double target slot, the rotation part is ignored */
+       IKO_ALIGN_X = 3, IKO_ALIGN_Y = 4, IKO_ALIGN_Z = 5 };
 
 /* Flat kinematic model with Pinocchio's conventions (joint 0 = universe). SE(3) values are 12
  * doubles: rotation row-major (9) then translation (3). */

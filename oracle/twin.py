@@ -29,6 +29,7 @@ TAYLOR_PREC3 = float(np.finfo(np.float64).eps) ** 0.25  # TaylorSeriesExpansion<
 DBL_MAX = float(np.finfo(np.float64).max)
 
 POSITION, ORIENTATION, FULL = 0, 1, 2  # ik::KinematicType (ik/ik/frame.hpp:20)
+ALIGN_X, ALIGN_Y, ALIGN_Z = 3, 4, 5     # ik::AlignAxisTask, AlignAxisType X / Y / Z (ik/ik/frame.hpp:202)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -454,7 +455,7 @@ class FrameTask:
         self.frame = frame_id(m, frame)
         self.reference = frame_id(m, reference)
         self.type = ktype
-        self.dim = 6 if ktype == FULL else 3
+        self.dim = 6 if ktype == FULL else (1 if ktype >= ALIGN_X else 3)
         self.target = np.eye(4) if target is None else np.array(target, float)
         self.w = np.ones(self.dim) if weights is None else np.array(weights, float)
 
@@ -468,6 +469,14 @@ def evaluate(m, tasks, q):
     Jw = joint_jacobians_world(m, oMi)
     es, Js = [], []
     for t in tasks:
+        if t.type >= ALIGN_X:  # AlignAxisTask (ik/ik/frame.hpp:257-301); target direction = t.target[:3, 3]
+            rMf = se3_inv(oMf[t.reference]) @ oMf[t.frame]
+            r = rMf[:3, t.type - ALIGN_X]
+            tn = t.target[:3, 3] / np.linalg.norm(t.target[:3, 3])
+            Jl = frame_jacobian_local(m, Jw, oMf[t.frame], m.frames[t.frame]["parent"])
+            es.append(np.array([1.0 - r @ tn]) * t.w)
+            Js.append(t.w[:, None] * (-(np.cross(r, tn)[None, :] @ rMf[:3, :3] @ Jl[3:, :])))
+            continue
         oMt = oMf[t.reference] @ t.target
         fMt = se3_inv(oMf[t.frame]) @ oMt
         e = log6(fMt)[t.rows()]

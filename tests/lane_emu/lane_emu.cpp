@@ -10,6 +10,7 @@
 
 #include "device/chain_kernel_body.hpp"
 #include "device/tree_kernel_body.hpp"
+#include "generic_tables.hpp"
 #include "ikgpu.h"
 #include "model.hpp"
 #include "problem.hpp"
@@ -100,6 +101,28 @@ void run_tree(const ikgpu::ProblemHost &ph, const IO &io) {
     }
 }
 
+void run_generic(const ikgpu::ProblemHost &ph, const IO &io) {
+    ikdev::GenericKernelArgs a{};
+    a.T = ikgpu::bind_generic_tables(ph, ph.generic.ints.data(), ph.generic.dbls.data());
+    a.layout = io.layout; a.B = io.B; a.q0 = io.q0; a.targets = io.targets;
+    a.q_out = io.q_out; a.success = io.success; a.iters = io.iters;
+    if (io.mode == 1) { a.e_out = io.e_out; a.J_out = io.J_out; }
+    if (io.mode == 2) { a.oMf_out = io.oMf_out; a.targets = io.q0; }
+    if (io.prm) {
+        a.prm.max_iterations = io.prm->max_iterations;
+        a.prm.lam2 = io.prm->damping * io.prm->damping;
+        a.prm.step_length = io.prm->step_length;
+        a.prm.stop_sq_tol = io.prm->stop_sq_tol;
+    }
+    a.ws_stride = (io.B + 63) / 64 * 64;
+    std::vector<double> ws(static_cast<size_t>(ph.generic.ws_words) * a.ws_stride, 0.0);
+    a.ws = ws.data();
+    for (int64_t b = 0; b < io.B; ++b) {
+        if (io.mode == 0) ikdev::dls_generic_body(a, b, [](bool act) { return act; });
+        else ikdev::eval_generic_body(a, b);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -111,9 +134,14 @@ int lane_emu_run(const char *urdf, size_t len, int root_joint, const ikgpu_task 
                  const double *q0, const double *targets, const ikgpu_dls_params *prm, double *q_out, uint8_t *success,
                  int32_t *iters, double *e_out, double *J_out, double *oMf_out, int layout) {
     try {
-        ikgpu::Model m = ikgpu::Model::from_urdf(urdf, len, root_joint != 0);
-        ikgpu::ProblemHost ph = ikgpu::analyse_problem(m, tasks, ntasks);
+        // root_joint bit 1 forces the generic kernel (to test it on shapes the specialisations also take)
+        ikgpu::Model m = ikgpu::Model::from_urdf(urdf, len, (root_joint & 1) != 0);
+        ikgpu::ProblemHost ph = ikgpu::analyse_problem(m, tasks, ntasks, (root_joint & 2) != 0);
         const IO io{mode, B, q0, targets, prm, q_out, success, iters, e_out, J_out, oMf_out, layout};
+        if (ph.kind == ikgpu::KernelKind::Generic) {
+            run_generic(ph, io);
+            return 0;
+        }
         if (ph.kind == ikgpu::KernelKind::Chain) {
             const int nj = ph.chain.nj, kt = tasks[0].type;
 #define X(N)                                       \

@@ -155,16 +155,28 @@ def test_problem_api_mirrors_the_reference_container(ik):
         p.add_frame_task("x", t, priority=2)
 
 
-def test_unsupported_shapes_say_so(ik):
+def test_every_other_shape_maps_to_the_generic_kernel(ik):
+    """Shapes without a register-resident specialisation run on the memory-resident generic kernel -- on the
+    device, never on a CPU path."""
+    m, p = _problem(ik, "ur5", ["tool0"], reference="wrist_1_link")          # reference frame moves with q
+    assert ik.plan(p) == "dls_generic<M=6,nv=6,joints=6>"
+    m, p = _problem(ik, "cassie_fixed", ["LeftFootFront", "RightFootFront"])  # fixed base, two tasks
+    assert ik.plan(p) == "dls_generic<M=12,nv=16,joints=16>"
+    m, p = _problem(ik, "cassie", ["LeftFootFront", "pelvis"], ff=True)
+    p.add_align_axis_task("align", ik.AlignAxisTask.create(m, "LeftFootFront", ik.AlignAxisType.AxisY))
+    assert ik.plan(p) == "dls_generic<M=13,nv=22,joints=17>"                  # the demo's task kinds (cassie.cpp:45-81)
+    assert p.get_align_axis_task("align").dimension() == 1
+
+
+def test_invalid_task_tables_are_errors(ik):
     from ik_amd import capi
-    m, p = _problem(ik, "ur5", ["tool0"], reference="wrist_1_link")
-    with pytest.raises(capi.IkgpuError) as ei:
-        ik.plan(p)
-    assert ei.value.code == capi.ERR_UNSUPPORTED and "reference frame" in ei.value.message
-    m, p = _problem(ik, "cassie_fixed", ["pelvis"])
-    with pytest.raises(capi.IkgpuError) as ei:
-        ik.plan(p)
-    assert "fixed in the world" in ei.value.message
+    m = ik.Model.from_urdf_file(urdf_path("ur5"))
+    bad = (capi.Task * 1)(capi.Task(m.nframes + 3, 0, 2, 0, (C.c_double * 6)(*[1.0] * 6)))
+    buf = C.create_string_buffer(64)
+    rc = capi.lib().ikgpu_problem_plan(m._h, bad, 1, buf, 64)
+    assert rc == capi.ERR_INVALID and b"frame id out of range" in capi.lib().ikgpu_last_error()
+    bad[0].frame, bad[0].type = 1, 9
+    assert capi.lib().ikgpu_problem_plan(m._h, bad, 1, buf, 64) == capi.ERR_INVALID
 
 
 def test_no_gpu_means_a_loud_error_not_a_fallback(ik):

@@ -198,3 +198,107 @@ def test_tree_program_single_chain_plus_base_task(emu):
     qo, ok, it, *_ = run(emu, urdf, tasks, 0, q0, tg, prm, model.nv, 12, root=1, ntasks=2)
     q_ref, _, _ = O.dls_batch(om, ot, tg, q0, O.params(20, 1e-2, 1.0, -1.0))
     assert np.abs(qo - q_ref).max() < 1e-9
+
+
+# ---------------------------------------------------------------------------------------------------
+# generic fallback program: any tree, any task list (incl. AlignAxisTask rows, moving reference frames,
+# prismatic joints), workspace in memory
+# ---------------------------------------------------------------------------------------------------
+def _generic_case(name, ff, specs, B, seed=0, xml_edit=None):
+    """specs: list of (frame, reference, type, priority, weights)."""
+    import ik_amd
+    from ik_amd import capi, workload
+    urdf = open(urdf_path(name), "rb").read()
+    if xml_edit:
+        urdf = xml_edit(urdf)
+    model = ik_amd.Model.from_urdf_xml(urdf, free_flyer=ff)
+    om = O.OracleModel(model.flat())
+    rng = np.random.default_rng(seed)
+    lo, hi = np.maximum(model.lowerPositionLimit, -2.5), np.minimum(model.upperPositionLimit, 2.5)
+    if ff:
+        nom = workload.cassie_nominal(model.names)
+        q0, qs = workload.freeflyer_workload(model.lowerPositionLimit, model.upperPositionLimit, nom, np.arange(B), seed=seed)
+    else:
+        mid = 0.5 * (lo + hi)
+        q0 = np.clip(mid + rng.uniform(-0.2, 0.2, (B, model.nq)), lo, hi)
+        qs = np.clip(q0 + rng.uniform(-0.15, 0.15, (B, model.nq)), lo, hi)
+    tasks = (capi.Task * len(specs))()
+    ospec, fids, rids = [], [], []
+    for i, (f, r, t, p, w) in enumerate(specs):
+        fid, rid = model.getFrameId(f), model.getFrameId(r)
+        ww = list(w) + [1.0] * (6 - len(w)) if w is not None else [1.0] * 6
+        tasks[i] = capi.Task(fid, rid, t, p, (C.c_double * 6)(*ww))
+        ospec.append((fid, rid, t, p, w))
+        fids.append(fid)
+        rids.append(rid)
+    # targets: pose of the frame at q* expressed in the reference frame at q* (reachable); direction for align rows
+    tg = np.zeros((B, len(specs), 12))
+    for b in range(B):
+        _, oMf = O.fk(om, qs[b])
+        for i, (f, r, t, p, w) in enumerate(specs):
+            if t >= 3:
+                tg[b, i, 9:] = rng.normal(size=3)
+                tg[b, i, :9] = np.eye(3).ravel()
+            else:
+                Mr, Mf = T4(oMf[rids[i]]), T4(oMf[fids[i]])
+                rel = np.linalg.inv(Mr) @ Mf
+                tg[b, i] = np.concatenate([rel[:3, :3].ravel(), rel[:3, 3]])
+    M = sum(6 if t == 2 else (1 if t >= 3 else 3) for _, _, t, _, _ in specs)
+    return urdf, model, om, tasks, O.make_tasks(ospec), q0, tg, M
+
+
+def T4(m12):
+    M = np.eye(4)
+    M[:3, :3] = np.asarray(m12[:9]).reshape(3, 3)
+    M[:3, 3] = m12[9:]
+    return M
+
+
+def _prismatic_elbow(xml):
+    return xml.replace(b'<joint name="elbow_joint" type="revolute">', b'<joint name="elbow_joint" type="prismatic">', 1) \
+              .replace(b'lower="-3.14159265359" upper="3.14159265359"', b'lower="-0.2" upper="0.2"', 1)
+
+
+GENERIC_CASES = {
+    "leg_forced": ("cassie_fixed", False, [("LeftFootFront", "universe", 2, 0, None)], 2, None),
+    "full_body_forced": ("cassie", True, [("LeftFootFront", "universe", 2, 0, None), ("RightFootFront", "universe", 2, 0, None),
+                                          ("pelvis", "universe", 2, 0, None)], 3, None),
+    # the demo's own task set (reference ik_ros/src/cassie.cpp:45-81): foot position w.r.t. the moving pelvis,
+    # pelvis pose in the world, foot Y axis aligned with a direction
+    "demo": ("cassie", True, [("LeftFootFront", "pelvis", 0, 0, None), ("pelvis", "universe", 2, 0, None),
+                              ("LeftFootFront", "universe", 4, 0, None)], 1, None),
+    "fixed_two_feet_prio": ("cassie_fixed", False, [("LeftFootFront", "universe", 2, 0, None),
+                                                    ("RightFootBack", "universe", 0, 1, [2.0, 1.0, 0.5])], 0, None),
+    "shared_joints": ("ur5", False, [("tool0", "universe", 0, 0, None), ("forearm_link", "universe", 1, 0, None)], 0, None),
+    "moving_reference_prismatic": ("ur5", False, [("tool0", "upper_arm_link", 2, 0, None)], 0, _prismatic_elbow),
+}
+
+
+@pytest.mark.parametrize("case", sorted(GENERIC_CASES))
+def test_generic_program_matches_oracle(emu, case):
+    from ik_amd import capi
+    name, ff, specs, root, edit = GENERIC_CASES[case]
+    B = 24
+    urdf, model, om, tasks, ot, q0, tg, M = _generic_case(name, ff, specs, B, xml_edit=edit)
+    nt = len(specs)
+    tk = tasks if nt > 1 else tasks[0]
+    _, _, _, e, J, _ = run(emu, urdf, tk, 1, q0, tg, None, model.nv, M, root=root | 2 if "forced" in case else root, ntasks=nt)
+    for b in range(B):
+        eo, Jo = O.evaluate(om, ot, tg[b], q0[b])
+        assert np.abs(e[b] - eo).max() < 1e-11 and np.abs(J[b] - Jo).max() < 1e-11
+    for iters, damping, step, tol in ((1, 1e-2, 1.0, -1.0), (3, 1e-2, 1.0, -1.0), (40, 1e-1, 0.5, 1e-6)):
+        prm = capi.DlsParams(iters, damping, step, tol)
+        qo, ok, it, *_ = run(emu, urdf, tk, 0, q0, tg, prm, model.nv, M, root=root | 2 if "forced" in case else root, ntasks=nt)
+        q_ref, ok_ref, it_ref = O.dls_batch(om, ot, tg, q0, O.params(iters, damping, step, tol))
+        assert np.array_equal(ok, ok_ref) and np.array_equal(it, it_ref)
+        assert np.abs(qo - q_ref).max() < 1e-8, (case, iters, np.abs(qo - q_ref).max())
+
+
+def test_generic_and_specialised_programs_agree(emu):
+    """The same problem through the register-resident chain program and through the generic one."""
+    from ik_amd import capi
+    urdf, model, om, task, ot, q0, qs, tg = setup("cassie_fixed", "LeftFootFront", B=64)
+    prm = capi.DlsParams(50, 1e-2, 1.0, -1.0)
+    qa, *_ = run(emu, urdf, task, 0, q0, tg, prm, model.nv, 6)
+    qb, *_ = run(emu, urdf, task, 0, q0, tg, prm, model.nv, 6, root=2)
+    assert np.abs(qa - qb).max() < 1e-9
