@@ -42,6 +42,12 @@ WORKLOADS = {
                                   "RightFootFront and pelvis (M=18)"),
     "ur5": dict(urdf="ur5", free_flyer=False, frames=["tool0"], nq=6,
                 text="UR5 arm (ur5.urdf, nq=6), one SE(3) tool0 task, targets within +-2 rad so the joint clamp is live"),
+    # the demo's own task set (reference ik_ros/src/cassie.cpp:45-81) on the generic fallback kernel
+    "cassie_demo": dict(urdf="cassie", free_flyer=True, frames=["LeftFootFront", "pelvis", "LeftFootFront"], nq=23,
+                        tasks=[("frame", "LeftFootFront", 0, "pelvis"), ("frame", "pelvis", 2, "universe"),
+                               ("align", "LeftFootFront", 1, "universe")],
+                        text="Cassie demo task set (cassie.urdf + free-flyer): LeftFootFront position w.r.t. the pelvis, pelvis "
+                             "SE(3) pose, LeftFootFront Y-axis alignment (M=10), generic kernel"),
 }
 
 
@@ -60,21 +66,27 @@ def load_kernel_stats():
 def make_inputs(name, model, idx):
     w = WORKLOADS[name]
     lo, hi = model.lowerPositionLimit, model.upperPositionLimit
-    if name == "cassie_full_body":
+    if name in ("cassie_full_body", "cassie_demo"):
         return workload.freeflyer_workload(lo, hi, workload.cassie_nominal(model.names), idx, seed=0, mode="near")
     if name == "ur5":
         return workload.chain_workload(lo, hi, workload.UR5_NOMINAL, idx, seed=0, mode="near")
     return workload.chain_workload(lo, hi, workload.cassie_nominal(model.names), idx, seed=0, mode="uniform")
 
 
-def cpu_baseline(model, frames, q0_np, tg_np, iters, budget_s=12.0):
+def task_specs(w):
+    return w.get("tasks") or [("frame", f, 2, "universe") for f in w["frames"]]
+
+
+def cpu_baseline(model, w, q0_np, tg_np, iters, budget_s=12.0):
     """The CPU oracle (oracle/ik_oracle.c, a port -- the reference itself cannot be built here) timed on
     this host's cores on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
     om = O.OracleModel(model.flat())
-    fids = [model.getFrameId(f) for f in frames]
-    tasks = O.make_tasks([(f, 0, 2, 0, None) for f in fids])
+    specs = task_specs(w)
+    fids = [model.getFrameId(f) for _, f, _, _ in specs]
+    tasks = O.make_tasks([(model.getFrameId(f), model.getFrameId(r), (3 + t) if kind == "align" else t, 0, None)
+                          for kind, f, t, r in specs])
     prm = O.params(iters, 1e-2, 1.0, -1.0)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     probe = min(256, q0_np.shape[0])
@@ -85,9 +97,13 @@ def cpu_baseline(model, frames, q0_np, tg_np, iters, budget_s=12.0):
     t = time.perf_counter()
     q_ref, ok_ref, it_ref = O.dls_batch(om, tasks, tg_np[:sample], q0_np[:sample], prm, cores)
     dt = time.perf_counter() - t
-    # which of the sampled problems converged on the CPU (SURVEY.md 8d parity bar): FK(q) reaches the target
-    reached = O.fk_batch(om, q_ref, fids)
-    conv = np.abs(reached - tg_np[:sample]).reshape(sample, -1).max(axis=1) < 1e-8
+    # which of the sampled problems converged on the CPU (SURVEY.md 8d parity bar): the stacked error vanishes
+    if w.get("tasks"):
+        conv = np.array([np.abs(O.evaluate(om, tasks, tg_np[b], q_ref[b])[0]).max() < 1e-8 for b in range(min(sample, 2048))])
+        conv = np.concatenate([conv, np.zeros(sample - conv.size, dtype=bool)])
+    else:
+        reached = O.fk_batch(om, q_ref, fids)
+        conv = np.abs(reached - tg_np[:sample]).reshape(sample, -1).max(axis=1) < 1e-8
     return dict(value=sample / dt, unit="solves/s", cores=cores, kind="port",
                 sample="first %d problems of the batch, %d threads, %.2f s wall; 1-thread probe %.0f solves/s"
                        % (sample, cores, dt, r1)), q_ref, sample, conv
@@ -128,8 +144,11 @@ def main():
     w = WORKLOADS[args.workload]
     model = ik_amd.Model.from_urdf_file(os.path.join(workload.MODELS_DIR, w["urdf"] + ".kin.urdf"), free_flyer=w["free_flyer"])
     problem = ik_amd.InverseKinematicsProblem(model)
-    for f in w["frames"]:
-        problem.add_frame_task(f, ik_amd.FrameTask.create(model, f, ik_amd.KinematicType.Full))
+    for i, (kind, f, t, r) in enumerate(task_specs(w)):
+        if kind == "align":
+            problem.add_align_axis_task("t%d" % i, ik_amd.AlignAxisTask.create(model, f, ik_amd.AlignAxisType(t), r))
+        else:
+            problem.add_frame_task("t%d" % i, ik_amd.FrameTask.create(model, f, ik_amd.KinematicType(t), r))
     data = ik_amd.dls_data(problem, device=local_rank)
 
     # this rank's shard of the global synthetic batch (weak scaling: B problems per GPU)
@@ -138,6 +157,15 @@ def main():
     Q0 = torch.from_numpy(np.ascontiguousarray(q0_np.T)).to(dev)
     QS = torch.from_numpy(np.ascontiguousarray(qs_np.T)).to(dev)
     targets = ik_amd.task_frames_fk_batch(problem, QS, data)  # FK(q*) on the device: reachable targets
+    if w.get("tasks"):
+        # express each frame target in its reference frame (here: the pelvis, task 1's frame) and give the align row a
+        # direction: world x axis
+        Rp, pp = targets[1, :9].reshape(3, 3, B), targets[1, 9:]
+        Rf, pf = targets[0, :9].reshape(3, 3, B), targets[0, 9:]
+        targets[0, :9] = torch.einsum("kib,kjb->ijb", Rp, Rf).reshape(9, B)
+        targets[0, 9:] = torch.einsum("kib,kb->ib", Rp, pf - pp)
+        targets[2, :9] = torch.eye(3, dtype=torch.float64, device=dev).reshape(9, 1)
+        targets[2, 9:] = torch.tensor([1.0, 0.0, 0.0], dtype=torch.float64, device=dev).reshape(3, 1)
     # two buffer sets alternate so that the all-gather of step k overlaps the solve of step k + 1
     bufs = [ikdist.ShardBuffers(model.nq, B, world, dev) for _ in range(2)]
     out = bufs[0].out()
@@ -220,7 +248,7 @@ def main():
                                                 "TRANS}_F64 counters (x 64 lanes, FMA = 2), 50 iterations; profiles/r01_pmc"}
         if not args.no_cpu:
             tg_np = targets.permute(2, 0, 1).contiguous().cpu().numpy()
-            cpu, q_ref, sample, conv = cpu_baseline(model, w["frames"], q0_np, tg_np, args.iters)
+            cpu, q_ref, sample, conv = cpu_baseline(model, w, q0_np, tg_np, args.iters)
             res["cpu_baseline"] = cpu
             d = np.abs(out[0].cpu().numpy().T[:sample] - q_ref).max(axis=1)
             res["parity_vs_cpu"] = {"problems": sample, "converged_on_cpu": int(conv.sum()),

@@ -18,7 +18,7 @@
 // Differences that cannot be hidden, by design of a device path:
 //   * a C++ visitor cannot run inside a kernel: inverse_kinematics_visitor carries the one-parameter
 //     family of ik/ik/visitor.hpp:19 (`||e[0]||^2 < tolerance`); override stop_tolerance(), not should_stop();
-//   * only FrameTask is accelerated (SURVEY.md section 8f lists the rest as "next");
+//   * FrameTask and AlignAxisTask are accelerated (SURVEY.md section 8f lists the other task kinds as "next");
 //   * failures of the device call throw std::runtime_error (the reference has no failure channel).
 #pragma once
 
@@ -199,17 +199,32 @@ class Task {
 
 enum class KinematicType { Position, Orientation, Full };  // ik/ik/frame.hpp:20
 
-// ---- ik::FrameTask (ik/ik/frame.hpp:78-200) -----------------------------------------------------
-class FrameTask : public Task {
+// A task row set as the device sees it; FrameTask and AlignAxisTask both provide it.
+class DeviceTask : public Task {
    public:
-    FrameTask(const model_t &model, const string_t &frame, const KinematicType &type = KinematicType::Full,
-              const string_t &reference_frame = "universe")
-        : Task(), target(se3_t::Identity()), type_(type), frame_(frame), reference_frame_(reference_frame) {
+    virtual int32_t abi_type() const = 0;                 // ikgpu_kinematic_type
+    virtual void abi_target(number_t *out12) const = 0;   // the 12-double target slot
+    index_t frame_id() const { return frame_id_; }
+    index_t reference_id() const { return reference_id_; }
+
+   protected:
+    void resolve(const model_t &model, const string_t &frame, const string_t &reference_frame) {
         frame_id_ = model.getFrameId(frame);
         reference_id_ = model.getFrameId(reference_frame);
         if (frame_id_ >= static_cast<index_t>(model.nframes)) throw std::invalid_argument("Frame not found in model: " + frame);
         if (reference_id_ >= static_cast<index_t>(model.nframes))
             throw std::invalid_argument("Reference frame not found in model: " + reference_frame);
+    }
+    index_t frame_id_ = 0, reference_id_ = 0;
+};
+
+// ---- ik::FrameTask (ik/ik/frame.hpp:78-200) -----------------------------------------------------
+class FrameTask : public DeviceTask {
+   public:
+    FrameTask(const model_t &model, const string_t &frame, const KinematicType &type = KinematicType::Full,
+              const string_t &reference_frame = "universe")
+        : target(se3_t::Identity()), type_(type), frame_(frame), reference_frame_(reference_frame) {
+        resolve(model, frame, reference_frame);
         set_dimension(type == KinematicType::Full ? 6 : 3);
     }
     static std::shared_ptr<FrameTask> create(const model_t &model, const string_t &frame,
@@ -222,16 +237,61 @@ class FrameTask : public Task {
     KinematicType type() const { return type_; }
     const string_t &frame() const { return frame_; }
     const string_t &reference_frame() const { return reference_frame_; }
-    index_t frame_id() const { return frame_id_; }
-    index_t reference_id() const { return reference_id_; }
+    int32_t abi_type() const override {
+        return type_ == KinematicType::Position ? IKGPU_POSITION : type_ == KinematicType::Orientation ? IKGPU_ORIENTATION : IKGPU_FULL;
+    }
+    void abi_target(number_t *o) const override {
+        for (int i = 0; i < 12; ++i) o[i] = target.data()[i];
+    }
 
    protected:
     KinematicType type_;
     string_t frame_, reference_frame_;
-    index_t frame_id_ = 0, reference_id_ = 0;
 };
 
-// ---- ik::InverseKinematicsProblem (ik/ik/problem.hpp:9-206), frame tasks --------------------------
+// ---- ik::AlignAxisTask (ik/ik/frame.hpp:202-319) ------------------------------------------------
+enum class AlignAxisType { AxisX = 0, AxisY = 1, AxisZ = 2 };
+
+class vector3_t {  // the slice of Eigen::Vector3d the task uses: target << x, y, z;  target[i]
+   public:
+    vector3_t() : d_{1.0, 0.0, 0.0} {}
+    number_t &operator[](int i) { return d_[i]; }
+    const number_t &operator[](int i) const { return d_[i]; }
+    comma_init operator<<(number_t v) { return comma_init(d_, 3, v); }
+    static vector3_t UnitX() { vector3_t v; v.d_[0] = 1; v.d_[1] = 0; v.d_[2] = 0; return v; }
+    static vector3_t UnitY() { vector3_t v; v.d_[0] = 0; v.d_[1] = 1; v.d_[2] = 0; return v; }
+    static vector3_t UnitZ() { vector3_t v; v.d_[0] = 0; v.d_[1] = 0; v.d_[2] = 1; return v; }
+
+   private:
+    number_t d_[3];
+};
+
+class AlignAxisTask : public DeviceTask {
+   public:
+    AlignAxisTask(const model_t &model, const string_t &frame, const AlignAxisType &axis,
+                  const string_t &reference_frame = "universe")
+        : axis_(axis), frame_(frame), reference_frame_(reference_frame) {
+        resolve(model, frame, reference_frame);
+        set_dimension(index_t(1));
+    }
+    static std::shared_ptr<AlignAxisTask> create(const model_t &model, const string_t &frame, const AlignAxisType &axis,
+                                                 const string_t &reference_frame = "universe") {
+        return std::make_shared<AlignAxisTask>(model, frame, axis, reference_frame);
+    }
+    vector3_t target;  // desired direction of the frame's axis (frame.hpp:307)
+
+    int32_t abi_type() const override { return IKGPU_ALIGN_AXIS_X + static_cast<int32_t>(axis_); }
+    void abi_target(number_t *o) const override {
+        for (int i = 0; i < 9; ++i) o[i] = (i % 4 == 0) ? 1.0 : 0.0;
+        for (int i = 0; i < 3; ++i) o[9 + i] = target[i];
+    }
+
+   protected:
+    AlignAxisType axis_;
+    string_t frame_, reference_frame_;
+};
+
+// ---- ik::InverseKinematicsProblem (ik/ik/problem.hpp:9-206), frame + align-axis tasks ---------------
 class InverseKinematicsProblem {
    public:
     InverseKinematicsProblem(const model_t &model, const std::size_t &max_priority_level = 0)
@@ -260,16 +320,32 @@ class InverseKinematicsProblem {
         if (it == frame_tasks_map_.end()) throw std::out_of_range("Frame task does not exist: " + name);
         return it->second;
     }
-    const std::vector<std::shared_ptr<FrameTask>> &get_all_tasks(const std::size_t &priority) const { return tasks_.at(priority); }
+    std::shared_ptr<AlignAxisTask> add_align_axis_task(const string_t &name, const std::shared_ptr<AlignAxisTask> &task,
+                                                       const std::size_t &priority = 0) {  // problem.hpp:94-105
+        if (priority > max_priority_level_) throw std::out_of_range("Maximum priority level exceeded!");
+        axis_tasks_map_.insert({name, axis_tasks_.size()});
+        axis_tasks_.push_back(task);
+        tasks_[priority].push_back(task);
+        ++generation_;
+        return axis_tasks_.back();
+    }
+    std::shared_ptr<AlignAxisTask> get_align_axis_task(const string_t &name) {
+        auto it = axis_tasks_map_.find(name);  // (the reference looks the name up in the frame-task map: problem.hpp:109)
+        if (it == axis_tasks_map_.end()) throw std::out_of_range("Align-axis task does not exist: " + name);
+        return axis_tasks_.at(it->second);
+    }
+    const std::vector<std::shared_ptr<DeviceTask>> &get_all_tasks(const std::size_t &priority) const { return tasks_.at(priority); }
     const model_t &model() const { return model_; }
     std::size_t generation() const { return generation_; }
 
    private:
     model_t model_;  // a copy, as the reference keeps (problem.hpp:183); the handle inside is shared
     std::size_t max_priority_level_;
-    std::vector<std::vector<std::shared_ptr<FrameTask>>> tasks_;
+    std::vector<std::vector<std::shared_ptr<DeviceTask>>> tasks_;
     std::vector<std::shared_ptr<FrameTask>> frame_tasks_;
     std::unordered_map<string_t, std::size_t> frame_tasks_map_;
+    std::vector<std::shared_ptr<AlignAxisTask>> axis_tasks_;
+    std::unordered_map<string_t, std::size_t> axis_tasks_map_;
     std::size_t generation_ = 0;
 };
 
@@ -319,8 +395,7 @@ class dls_data {
                 ikgpu_task k;
                 k.frame = static_cast<int32_t>(t->frame_id());
                 k.reference = static_cast<int32_t>(t->reference_id());
-                k.type = t->type() == KinematicType::Position ? IKGPU_POSITION
-                         : t->type() == KinematicType::Orientation ? IKGPU_ORIENTATION : IKGPU_FULL;
+                k.type = t->abi_type();
                 k.priority = static_cast<int32_t>(p);
                 for (int i = 0; i < 6; ++i) k.weight[i] = i < static_cast<int>(t->dimension()) ? t->weighting()[i] : 1.0;
                 tasks.push_back(k);
@@ -363,7 +438,11 @@ inline ikgpu_dls_params to_abi(const inverse_kinematics_visitor &visitor, const 
 inline std::vector<number_t> gather_targets(const InverseKinematicsProblem &problem) {
     std::vector<number_t> t;
     for (std::size_t p = 0; p <= problem.max_priority_level(); ++p)
-        for (const auto &task : problem.get_all_tasks(p)) t.insert(t.end(), task->target.data(), task->target.data() + 12);
+        for (const auto &task : problem.get_all_tasks(p)) {
+            number_t slot[12];
+            task->abi_target(slot);
+            t.insert(t.end(), slot, slot + 12);
+        }
     return t;
 }
 }  // namespace detail

@@ -151,3 +151,33 @@ def test_single_problem_demo_loop(torch_cuda):
         q_ref, ok_ref, it_ref = O.dls(om, ot, tg, q_ref, O.params(200, 1e-1, 1e-1, 1e-4))
         assert data.success == ok_ref and data.iterations == it_ref
         assert np.abs(q - q_ref).max() <= TOL
+
+
+def test_cpp_demo_program_matches_oracle(torch_cuda):
+    """tests/cpp/test_demo_loop.cpp is the reference's demo (ik_ros/src/cassie.cpp) on the C++ mirror."""
+    import json
+    import subprocess
+    import ik_amd
+    import oracle as O
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tests", "cpp", "test_demo_loop")
+    src = exe + ".cpp"
+    if not os.path.exists(exe) or os.path.getmtime(src) > os.path.getmtime(exe):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                               "-I" + os.path.join(ROOT, "ik_amd", "csrc", "host"), "-o", exe, src,
+                               "-L" + os.path.join(ROOT, "ik_amd"), "-likgpu", "-Wl,-rpath," + os.path.join(ROOT, "ik_amd")])
+    out = json.loads(subprocess.check_output([exe, urdf_path("cassie"), "4"], text=True))
+    assert out["kernel"].startswith("dls_generic<M=10,nv=22")
+    model = ik_amd.Model.from_urdf_file(urdf_path("cassie"), free_flyer=True)
+    om = O.OracleModel(model.flat())
+    lf, pe = model.getFrameId("LeftFootFront"), model.getFrameId("pelvis")
+    ot = O.make_tasks([(lf, pe, 0, 0, None), (pe, 0, 2, 0, None), (lf, 0, 4, 0, None)])
+    q = np.zeros(model.nq)
+    q[6] = 1.0
+    I9 = np.eye(3).ravel()
+    for k, tick in enumerate(out["ticks"]):
+        tg = np.stack([np.concatenate([I9, [0.0, 0.1, -0.6 + 0.2 * np.sin(0.5 * k)]]), np.concatenate([I9, np.zeros(3)]),
+                       np.concatenate([I9, [1.0, 0.0, 0.0]])])
+        q, ok, it = O.dls(om, ot, tg, q, O.params(200, 1e-1, 1e-1, 1e-4))
+        assert tick["success"] == int(ok) and tick["iterations"] == it
+        assert np.abs(np.array(tick["q"]) - q).max() <= TOL
