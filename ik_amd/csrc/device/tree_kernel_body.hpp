@@ -113,17 +113,15 @@ IKD_FN void eval_tree_body(const TreeKernelArgs<NJ, NCH> &a, const TreeDesc<NJ, 
         TaskTerms t;
         task_terms(R, p, oMt, is_chain ? ct.w : d.wP, (is_chain ? a.prm.unit[c] : a.prm.unitP) != 0, t);
         double JL[3][3], JA[3][6], col[NJ][6];
-        base_columns(t, R, p, R1, p1, JL, JA);
+        base_columns(t, p, R1, p1, JL, JA);
         for (int j = 0; j < nj; ++j) {
-            double wl[3], r[3], vl[3];
-            rotT_vec(R, zax[j], wl);
             const double dj[3] = {org[j][0] - p[0], org[j][1] - p[1], org[j][2] - p[2]};
-            rotT_vec(R, dj, r);
-            cross(r, wl, vl);
+            double vw[3];
+            cross(dj, zax[j], vw);
             for (int i = 0; i < 3; ++i) {
-                col[j][i] = dfma(t.At[3 * i], vl[0], dfma(t.At[3 * i + 1], vl[1], dfma(t.At[3 * i + 2], vl[2],
-                            dfma(t.Bt[3 * i], wl[0], dfma(t.Bt[3 * i + 1], wl[1], t.Bt[3 * i + 2] * wl[2])))));
-                col[j][3 + i] = dfma(t.Ab[3 * i], wl[0], dfma(t.Ab[3 * i + 1], wl[1], t.Ab[3 * i + 2] * wl[2]));
+                col[j][i] = dfma(t.At[3 * i], vw[0], dfma(t.At[3 * i + 1], vw[1], dfma(t.At[3 * i + 2], vw[2],
+                            dfma(t.Bt[3 * i], zax[j][0], dfma(t.Bt[3 * i + 1], zax[j][1], t.Bt[3 * i + 2] * zax[j][2])))));
+                col[j][3 + i] = dfma(t.Ab[3 * i], zax[j][0], dfma(t.Ab[3 * i + 1], zax[j][1], t.Ab[3 * i + 2] * zax[j][2]));
             }
         }
         for (int r = 0; r < a.tdim[slot]; ++r) {

@@ -62,12 +62,22 @@ IKD_FN void quat_to_R(const double (&qb)[7], double (&R)[9]) {
     R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.0 - (txx + tyy);
 }
 
-// What one frame task contributes, given its frame placement (Rf, pf) in the world:
-// weighted error e (6), and K' = +diag(w) Jlog6(tMf) as blocks: top rows [At | Bt], bottom rows [0 | Ab].
+// What one frame task contributes, given its frame placement (Rf, pf) in the world: weighted error e (6), and
+// K' = +diag(w) Jlog6(tMf) as blocks -- top rows [At | Bt], bottom rows [0 | Ab] -- each already multiplied by Rf^T
+// on the right, so that they act on WORLD-frame twists taken about the frame origin:
+//   -J_task(:, c) = [At (d x w) + Bt w ; Ab w],  (v, w) the world Jacobian column, d = origin_of_the_joint - p_f.
 struct TaskTerms {
     double e[6];
     double At[9], Bt[9], Ab[9];
 };
+
+// out = X * R^T
+IKD_FN void mul_RT(const double (&X)[9], const double (&R)[9], double (&out)[9]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) out[3 * i + k] = dfma(X[3 * i], R[3 * k], dfma(X[3 * i + 1], R[3 * k + 1], X[3 * i + 2] * R[3 * k + 2]));
+}
 
 IKD_FN void task_terms(const double (&Rf)[9], const double (&pf)[3], const double (&oMt)[12], const double *w6, bool unit,
                        TaskTerms &t) {
@@ -85,10 +95,13 @@ IKD_FN void task_terms(const double (&Rf)[9], const double (&pf)[3], const doubl
     if (unit) {  // wave-uniform: Full task, all weights exactly 1
 #pragma unroll
         for (int k = 0; k < 6; ++k) t.e[k] = lj.e[k];
+        mul_RT(lj.A, Rf, t.At);
+        mul_RT(lj.Bm, Rf, t.Bt);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) { t.At[k] = lj.A[k]; t.Bt[k] = lj.Bm[k]; t.Ab[k] = lj.A[k]; }
+        for (int k = 0; k < 9; ++k) t.Ab[k] = t.At[k];
         return;
     }
+    double A_t[9], B_t[9], A_b[9];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const double wt = w6[i], wb = w6[3 + i];
@@ -96,29 +109,28 @@ IKD_FN void task_terms(const double (&Rf)[9], const double (&pf)[3], const doubl
         t.e[3 + i] = lj.e[3 + i] * wb;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            t.At[3 * i + j] = wt * lj.A[3 * i + j];
-            t.Bt[3 * i + j] = wt * lj.Bm[3 * i + j];
-            t.Ab[3 * i + j] = wb * lj.A[3 * i + j];
+            A_t[3 * i + j] = wt * lj.A[3 * i + j];
+            B_t[3 * i + j] = wt * lj.Bm[3 * i + j];
+            A_b[3 * i + j] = wb * lj.A[3 * i + j];
         }
     }
+    mul_RT(A_t, Rf, t.At);
+    mul_RT(B_t, Rf, t.Bt);
+    mul_RT(A_b, Rf, t.Ab);
 }
 
-// Task Jacobian columns of the six free-flyer DoFs: J_local = Ad(oMf^-1 oM1) = [[Rb, [pb]x Rb], [0, Rb]].
+// (Negated) task Jacobian columns of the six free-flyer DoFs: J_local = Ad(oMf^-1 oM1).
 // JL[c] (c = 0..2, linear DoFs): only the top three rows are non-zero.  JA[c]: all six rows.
-IKD_FN void base_columns(const TaskTerms &t, const double (&Rf)[9], const double (&pf)[3], const double (&R1)[9],
-                         const double (&p1)[3], double (&JL)[3][3], double (&JA)[3][6]) {
-    double Rb[9], pb[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) Rb[3 * i + j] = dfma(Rf[i], R1[j], dfma(Rf[3 + i], R1[3 + j], Rf[6 + i] * R1[6 + j]));
+IKD_FN void base_columns(const TaskTerms &t, const double (&pf)[3], const double (&R1)[9], const double (&p1)[3],
+                         double (&JL)[3][3], double (&JA)[3][6]) {
+    // world columns of the free-flyer: linear DoF c: (R1 e_c, 0); angular DoF c: (p1 x R1 e_c, R1 e_c) about the world
+    // origin, i.e. ((p1 - pf) x R1 e_c, R1 e_c) about the frame origin
     const double dp[3] = {p1[0] - pf[0], p1[1] - pf[1], p1[2] - pf[2]};
-    rotT_vec(Rf, dp, pb);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const double rc[3] = {Rb[c], Rb[3 + c], Rb[6 + c]};
+        const double rc[3] = {R1[c], R1[3 + c], R1[6 + c]};
         double pxr[3];
-        cross(pb, rc, pxr);
+        cross(dp, rc, pxr);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             JL[c][i] = dfma(t.At[3 * i], rc[0], dfma(t.At[3 * i + 1], rc[1], t.At[3 * i + 2] * rc[2]));
@@ -198,24 +210,22 @@ IKD_FN void leg_eval_factor(const double (&R1)[9], const double (&p1)[3], const 
         for (int r = 0; r < 6; ++r) e0sq = dfma(t.e[r], t.e[r], e0sq);
     }
     double JL[3][3], JA[3][6];
-    base_columns(t, R, p, R1, p1, JL, JA);
+    base_columns(t, p, R1, p1, JL, JA);
     accumulate_base(JL, JA, t.e, Hbb, gb);
 
     IKD_SCHED_FENCE();
-    // chain columns
+    // chain columns (world-frame twist about the frame origin, see TaskTerms)
     double col[NJ][6];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        double wl[3], r[3], vl[3];
-        rotT_vec(R, zax[j], wl);
         const double dj[3] = {org[j][0] - p[0], org[j][1] - p[1], org[j][2] - p[2]};
-        rotT_vec(R, dj, r);
-        cross(r, wl, vl);
+        double vw[3];
+        cross(dj, zax[j], vw);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            col[j][i] = dfma(t.At[3 * i], vl[0], dfma(t.At[3 * i + 1], vl[1], dfma(t.At[3 * i + 2], vl[2],
-                        dfma(t.Bt[3 * i], wl[0], dfma(t.Bt[3 * i + 1], wl[1], t.Bt[3 * i + 2] * wl[2])))));
-            col[j][3 + i] = dfma(t.Ab[3 * i], wl[0], dfma(t.Ab[3 * i + 1], wl[1], t.Ab[3 * i + 2] * wl[2]));
+            col[j][i] = dfma(t.At[3 * i], vw[0], dfma(t.At[3 * i + 1], vw[1], dfma(t.At[3 * i + 2], vw[2],
+                        dfma(t.Bt[3 * i], zax[j][0], dfma(t.Bt[3 * i + 1], zax[j][1], t.Bt[3 * i + 2] * zax[j][2])))));
+            col[j][3 + i] = dfma(t.Ab[3 * i], zax[j][0], dfma(t.Ab[3 * i + 1], zax[j][1], t.Ab[3 * i + 2] * zax[j][2]));
         }
     }
     IKD_SCHED_FENCE();
@@ -419,7 +429,7 @@ IKD_FN void tree_dls(const TreeDesc<NJ, NCH> &d, const TreeParams &prm, double (
                 for (int r = 0; r < 6; ++r) e0sq = dfma(t.e[r], t.e[r], e0sq);
             }
             double JL[3][3], JA[3][6];
-            base_columns(t, Rf, pf, R1, p1, JL, JA);
+            base_columns(t, pf, R1, p1, JL, JA);
             accumulate_base(JL, JA, t.e, Hbb, gb);
         }
         // base: S dq_b = g'
