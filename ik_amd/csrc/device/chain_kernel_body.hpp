@@ -50,7 +50,7 @@ IKD_FN void load_target(const ChainKernelArgs<NJ> &a, int64_t b, double (&oMt)[1
 }
 
 // B independent ik::dls() calls (reference ik/ik/dls.cpp:5-78), lane `gid`.
-template <int NJ, int KT, class AnyFn>
+template <int NJ, int KT, int SMASK = -1, class AnyFn>
 IKD_FN void dls_chain_body(const ChainKernelArgs<NJ> &a, const ChainDesc<NJ> &d, int64_t gid, AnyFn any_active) {
     const bool valid = gid < a.B;
     const int64_t b = valid ? gid : a.B - 1;  // tail lanes shadow the last problem and store nothing
@@ -63,7 +63,7 @@ IKD_FN void dls_chain_body(const ChainKernelArgs<NJ> &a, const ChainDesc<NJ> &d,
 
     int iters;
     bool success;
-    chain_dls<NJ, KT>(d, a.prm, q, oMt, iters, success, any_active);
+    chain_dls<NJ, KT, SMASK>(d, a.prm, q, oMt, iters, success, any_active);
 
     if (!valid) return;
 #pragma unroll

@@ -40,6 +40,8 @@ struct LoopParams {
     int unit_weights;    // every Task::weighting() entry is exactly 1
 };
 
+constexpr int kSpecUnit = 30;
+
 template <int KT>
 struct TaskDim {
     static constexpr int value = (KT == KT_FULL) ? 6 : 3;
@@ -48,7 +50,12 @@ struct TaskDim {
 // Evaluate e (M) and the NEGATED M x NJ task Jacobian columns (col = -J_task(:, j) = +W Jlog6(tMf) J_local(:, j):
 // the minus sign of reference ik/ik/frame.hpp:173-181 is folded into the step, dq = +col^T y) at configuration q.
 // oMt: target placement in the world (reference frame fixed in the world), 12 doubles.
-template <int NJ, int KT>
+// SMASK >= 0: specialisation known at compile time -- bits 0..NJ: identity-rotation placement mask (must be a subset
+// of the problem's mask), bit kSpecUnit: every weight is exactly 1.  SMASK = -1: take the wave-uniform runtime values
+// `idmask` / `unit_weights`.  A compile-time value keeps the whole iteration one basic block, so the scheduler can
+// hoist the LDS reads of the constant table far ahead of their use -- with one wave per SIMD nothing else hides that
+// latency (measured: s_waitcnt stalls were 17 % of wave cycles with runtime branches; +18 % solves/s without them).
+template <int NJ, int KT, int SMASK = -1>
 IKD_FN void chain_evaluate(const ChainDesc<NJ> &d, const double (&q)[NJ], const double (&oMt)[12], int idmask,
                            bool unit_weights, double (&e)[TaskDim<KT>::value], double (&col)[NJ][TaskDim<KT>::value],
                            double (&Rf)[9], double (&pf)[3]) {
@@ -61,14 +68,14 @@ IKD_FN void chain_evaluate(const ChainDesc<NJ> &d, const double (&q)[NJ], const 
     for (int k = 0; k < 3; ++k) p[k] = d.pl[0][9 + k];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        if (j > 0) se3_compose_const(R, p, d.pl[j], (idmask >> j) & 1);
+        if (j > 0) se3_compose_const(R, p, d.pl[j], SMASK >= 0 ? ((SMASK >> j) & 1) != 0 : ((idmask >> j) & 1) != 0);
         double s, c;
         dsincos(q[j], s, c);
         rot_z_right(R, s, c);
         zax[j][0] = R[2]; zax[j][1] = R[5]; zax[j][2] = R[8];
         org[j][0] = p[0]; org[j][1] = p[1]; org[j][2] = p[2];
     }
-    se3_compose_const(R, p, d.frame_pl, (idmask >> NJ) & 1);
+    se3_compose_const(R, p, d.frame_pl, SMASK >= 0 ? ((SMASK >> NJ) & 1) != 0 : ((idmask >> NJ) & 1) != 0);
 #pragma unroll
     for (int k = 0; k < 9; ++k) Rf[k] = R[k];
 #pragma unroll
@@ -90,7 +97,8 @@ IKD_FN void chain_evaluate(const ChainDesc<NJ> &d, const double (&q)[NJ], const 
     // K' = +diag(w) * Jlog6(tMf) restricted to the task rows:  top rows [At | Bt], bottom rows [0 | Ab]
     double At[9], Bt[9], Ab[9];
     constexpr int w0 = (KT == KT_FULL) ? 3 : 0;
-    if (unit_weights) {  // wave-uniform
+    const bool unit = SMASK >= 0 ? ((SMASK >> kSpecUnit) & 1) != 0 : unit_weights;
+    if (unit) {  // compile-time, or wave-uniform
 #pragma unroll
         for (int k = 0; k < 9; ++k) { At[k] = lj.A[k]; Bt[k] = lj.Bm[k]; Ab[k] = lj.A[k]; }
         if (KT == KT_FULL) {
@@ -141,7 +149,7 @@ IKD_FN void chain_evaluate(const ChainDesc<NJ> &d, const double (&q)[NJ], const 
                 BtR[3 * i + k] = dfma(Bt[3 * i], R[3 * k], dfma(Bt[3 * i + 1], R[3 * k + 1], Bt[3 * i + 2] * R[3 * k + 2]));
             }
         }
-    if (KT == KT_FULL && unit_weights) {  // Ab == At
+    if (KT == KT_FULL && unit) {  // Ab == At
 #pragma unroll
         for (int k = 0; k < 9; ++k) AbR[k] = AtR[k];
     } else if (KT == KT_FULL || KT == KT_ORIENTATION) {
@@ -174,7 +182,7 @@ IKD_FN void chain_evaluate(const ChainDesc<NJ> &d, const double (&q)[NJ], const 
 
 // One full solve. q: in = q0 (chain joints only), out = result. Returns iterations / success.
 // any_active(bool) must return a wave-uniform "some lane still iterating" (identity on the host).
-template <int NJ, int KT, class AnyFn>
+template <int NJ, int KT, int SMASK = -1, class AnyFn>
 IKD_FN void chain_dls(const ChainDesc<NJ> &d, const LoopParams &prm, double (&q)[NJ], const double (&oMt)[12],
                       int &iters_out, bool &success_out, AnyFn any_active) {
     constexpr int M = TaskDim<KT>::value;
@@ -187,7 +195,7 @@ IKD_FN void chain_dls(const ChainDesc<NJ> &d, const LoopParams &prm, double (&q)
         // ds_read, off the VALU) instead of letting the compiler hoist ~150 doubles into registers.
         asm volatile("" ::: "memory");
         double e[M], col[NJ][M], Rf[9], pf[3];
-        chain_evaluate<NJ, KT>(d, q, oMt, prm.idmask, prm.unit_weights != 0, e, col, Rf, pf);
+        chain_evaluate<NJ, KT, SMASK>(d, q, oMt, prm.idmask, prm.unit_weights != 0, e, col, Rf, pf);
 
         double G[M * M];
 #pragma unroll

@@ -36,6 +36,14 @@
 #define IKD_ANY(pred) (pred)
 #endif
 
+// The theta -> pi formula of log3 is either gated by a wave-uniform branch (skipped unless some lane needs it)
+// or always evaluated and selected per lane (no branch: the iteration stays one basic block).
+#ifdef IKD_NEAR_PI_BRANCHLESS
+#define IKD_NEAR_PI_GATE(pred) true
+#else
+#define IKD_NEAR_PI_GATE(pred) IKD_ANY(pred)
+#endif
+
 namespace ikdev {
 
 // TaylorSeriesExpansion<double>::precision<3>() = eps^(1/4)
@@ -241,7 +249,7 @@ IKD_FN void log6_and_jlog6_inv(const double (&Re)[9], const double (&pe)[3], Log
     double w[3] = {fac * (Re[7] - Re[5]), fac * (Re[2] - Re[6]), fac * (Re[3] - Re[1])};
     // log3, theta >= pi - 1e-2: evaluated only when some lane of the wave is there (wave-uniform branch)
     const bool near_pi = theta >= kPi - 1e-2;
-    if (IKD_ANY(near_pi)) {
+    if (IKD_NEAR_PI_GATE(near_pi)) {
         const double cphi = -x;
         const double beta_pi = t2 * drcp(1.0 + cphi);
         const double t0 = (Re[0] + cphi) * beta_pi, t1 = (Re[4] + cphi) * beta_pi, t2v = (Re[8] + cphi) * beta_pi;

@@ -30,7 +30,7 @@ struct TreeKernelArgs {
 };
 
 // B independent ik::dls() calls (reference ik/ik/dls.cpp:5-78) on a free-flyer model, lane `gid`.
-template <int NJ, int NCH, class Park, class AnyFn>
+template <int NJ, int NCH, int SPEC = -1, class Park, class AnyFn>
 IKD_FN void dls_tree_body(const TreeKernelArgs<NJ, NCH> &a, const TreeDesc<NJ, NCH> &d, int64_t gid, Park park,
                           AnyFn any_active) {
     const bool valid = gid < a.B;
@@ -48,7 +48,7 @@ IKD_FN void dls_tree_body(const TreeKernelArgs<NJ, NCH> &a, const TreeDesc<NJ, N
 
     int iters;
     bool success;
-    tree_dls<NJ, NCH>(d, a.prm, qb, qj0, qj1, tl, ts, a.tslot, iters, success, park, any_active);
+    tree_dls<NJ, NCH, SPEC>(d, a.prm, qb, qj0, qj1, tl, ts, a.tslot, iters, success, park, any_active);
 
     if (!valid) return;
 #pragma unroll

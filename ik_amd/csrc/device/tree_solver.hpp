@@ -378,7 +378,12 @@ IKD_FN void freeflyer_integrate(const double (&qb)[7], const double (&R1)[9], co
 // loop: the unrolled body of one chain is ~3000 instructions, two inlined copies overflow the
 // instruction cache).  Chain 0's factor (L, W, u) is parked while chain 1 is processed -- `park` stores /
 // reloads it: LDS [entry][lane] on the device (conflict-free ds_write/read_b64), a plain copy on the host.
-template <int NJ, int NCH, class Park, class AnyFn>
+// SPEC >= 0: compile-time specialisation (see chain_solver.hpp) -- bits 0..NJ: identity-rotation placement mask shared
+// by the chains, bit kSpecUnit: the chain tasks are Full with unit weights, bit kSpecUnitP / kSpecIdP: the base task is
+// Full with unit weights / its frame placement is a pure translation.  SPEC = -1: runtime (wave-uniform) values.
+constexpr int kSpecUnitP = 29, kSpecIdP = 28;
+
+template <int NJ, int NCH, int SPEC = -1, class Park, class AnyFn>
 IKD_FN void tree_dls(const TreeDesc<NJ, NCH> &d, const TreeParams &prm, double (&qb)[7], double (&qj0)[NJ], double (&qj1)[NJ],
                      const double *targets_lane, int64_t tstride, const int (&tslot)[3], int &iters_out,
                      bool &success_out, Park park, AnyFn any_active) {
@@ -407,7 +412,8 @@ IKD_FN void tree_dls(const TreeDesc<NJ, NCH> &d, const TreeParams &prm, double (
             for (int j = 0; j < NJ; ++j) q[j] = (NCH > 1 && c == 1) ? qj1[j] : qj0[j];
 #pragma unroll
             for (int k = 0; k < 12; ++k) oMt[k] = targets_lane[(tslot[c] * 12 + k) * tstride];
-            leg_eval_factor<NJ>(R1, p1, ct.pl, ct.fr, ct.w, prm.idmask[c], prm.unit[c] != 0, q, oMt, prm.lam2, prm.prio[c] == 0, Hbb,
+            leg_eval_factor<NJ>(R1, p1, ct.pl, ct.fr, ct.w, SPEC >= 0 ? (SPEC & ((2 << NJ) - 1)) : prm.idmask[c],
+                                SPEC >= 0 ? ((SPEC >> kSpecUnit) & 1) != 0 : prm.unit[c] != 0, q, oMt, prm.lam2, prm.prio[c] == 0, Hbb,
                                 gb, e0sq, F);
             if (NCH > 1 && c == 0) park.store(F);
         }
@@ -421,9 +427,9 @@ IKD_FN void tree_dls(const TreeDesc<NJ, NCH> &d, const TreeParams &prm, double (
             for (int k = 0; k < 9; ++k) Rf[k] = R1[k];
 #pragma unroll
             for (int k = 0; k < 3; ++k) pf[k] = p1[k];
-            se3_compose_const(Rf, pf, d.frP, prm.idmaskP & 1);
+            se3_compose_const(Rf, pf, d.frP, SPEC >= 0 ? ((SPEC >> kSpecIdP) & 1) != 0 : (prm.idmaskP & 1) != 0);
             TaskTerms t;
-            task_terms(Rf, pf, oMt, d.wP, prm.unitP != 0, t);
+            task_terms(Rf, pf, oMt, d.wP, SPEC >= 0 ? ((SPEC >> kSpecUnitP) & 1) != 0 : prm.unitP != 0, t);
             if (prm.prioP == 0) {
 #pragma unroll
                 for (int r = 0; r < 6; ++r) e0sq = dfma(t.e[r], t.e[r], e0sq);

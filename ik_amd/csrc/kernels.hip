@@ -31,13 +31,20 @@ __device__ __forceinline__ const ChainDesc<NJ> &stage_desc(const ChainDesc<NJ> *
     return *reinterpret_cast<const ChainDesc<NJ> *>(lds);
 }
 
-template <int NJ, int KT>
+// SMASK: compile-time identity-rotation placement mask (0: skip nothing), see device/chain_solver.hpp
+template <int NJ, int KT, int SMASK>
 __global__ __launch_bounds__(kBlock) void dls_chain_kernel(const ChainKernelArgs<NJ> a) {
     __shared__ double lds_desc[sizeof(ChainDesc<NJ>) / sizeof(double)];
     const ChainDesc<NJ> &d = stage_desc<NJ>(a.desc, lds_desc);
     const int64_t gid = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-    ikdev::dls_chain_body<NJ, KT>(a, d, gid, [](bool act) { return __any(act) != 0; });
+    ikdev::dls_chain_body<NJ, KT, SMASK>(a, d, gid, [](bool act) { return __any(act) != 0; });
 }
+
+// Placement masks with a dedicated instantiation: the Cassie leg chains (knee, shin, tarsus, foot and the foot frame
+// are pure translations: 0xf8) and the UR5 arm (0x05).  Any other model runs the SMASK = 0 build.
+template <int NJ> struct HotMask { static constexpr int value = 0; };
+template <> struct HotMask<7> { static constexpr int value = 0xf8; };
+template <> struct HotMask<6> { static constexpr int value = 0x05; };
 
 template <int NJ, int KT>
 __global__ __launch_bounds__(kBlock) void eval_chain_kernel(const ChainKernelArgs<NJ> a) {
@@ -81,7 +88,13 @@ hipError_t run_dls(const ProblemHost &ph, const DeviceTables &dt, const BatchIO 
     a.q_out = io.q_out;
     a.success = io.success;
     a.iters = io.iters;
-    hipLaunchKernelGGL((dls_chain_kernel<NJ, KT>), grid_for(io.B), dim3(kBlock), 0, stream, a);
+    // two builds per shape: the hot one (known placement mask + unit weights, all folded at compile time) and the
+    // general one (nothing skipped, weights always applied); neither has a branch inside the iteration
+    constexpr int kHot = HotMask<NJ>::value | (1 << ikdev::kSpecUnit);
+    if (HotMask<NJ>::value != 0 && (a.prm.idmask & HotMask<NJ>::value) == HotMask<NJ>::value && a.prm.unit_weights)
+        hipLaunchKernelGGL((dls_chain_kernel<NJ, KT, kHot>), grid_for(io.B), dim3(kBlock), 0, stream, a);
+    else
+        hipLaunchKernelGGL((dls_chain_kernel<NJ, KT, 0>), grid_for(io.B), dim3(kBlock), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -218,14 +231,14 @@ __device__ __forceinline__ const TreeDesc<NJ, NCH> &stage_tree_desc(const TreeDe
     return *reinterpret_cast<const TreeDesc<NJ, NCH> *>(lds);
 }
 
-template <int NJ, int NCH>
+template <int NJ, int NCH, int SPEC>
 __global__ __launch_bounds__(kTreeBlock) void dls_tree_kernel(const TreeKernelArgs<NJ, NCH> a) {
     __shared__ double lds_desc[sizeof(TreeDesc<NJ, NCH>) / sizeof(double)];
     __shared__ double lds_park[kTreeWaves][NCH > 1 ? LdsPark<NJ>::kEntries : 1][64];
     const TreeDesc<NJ, NCH> &d = stage_tree_desc<NJ, NCH>(a.desc, lds_desc, kTreeBlock);
     const int64_t gid = static_cast<int64_t>(blockIdx.x) * kTreeBlock + threadIdx.x;
     LdsPark<NJ> park{lds_park[threadIdx.x / 64], static_cast<int>(threadIdx.x % 64)};
-    ikdev::dls_tree_body<NJ, NCH>(a, d, gid, park, [](bool act) { return __any(act) != 0; });
+    ikdev::dls_tree_body<NJ, NCH, SPEC>(a, d, gid, park, [](bool act) { return __any(act) != 0; });
 }
 
 template <int NJ, int NCH>
@@ -262,8 +275,15 @@ hipError_t run_dls_tree(const ProblemHost &ph, const DeviceTables &dt, const Bat
     a.prm.stop_sq_tol = prm.stop_sq_tol;
     a.layout = io.layout; a.B = io.B; a.q0 = io.q0; a.targets = io.targets;
     a.q_out = io.q_out; a.success = io.success; a.iters = io.iters;
-    hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH>), dim3(static_cast<unsigned>((io.B + kTreeBlock - 1) / kTreeBlock)), dim3(kTreeBlock), 0,
-                       stream, a);
+    // hot build: both chains carry the shape's known placement mask, every task is Full with unit weights and the base
+    // task sits at a pure translation from the base joint -- all folded at compile time; otherwise the general build
+    constexpr int kMask = HotMask<NJ>::value;
+    constexpr int kHot = kMask | (1 << ikdev::kSpecUnit) | (1 << ikdev::kSpecUnitP) | (1 << ikdev::kSpecIdP);
+    const bool hot = kMask != 0 && (a.prm.idmask[0] & kMask) == kMask && (NCH == 1 || (a.prm.idmask[1] & kMask) == kMask) &&
+                     a.prm.unit[0] && (NCH == 1 || a.prm.unit[1]) && (!a.prm.hasP || (a.prm.unitP && (a.prm.idmaskP & 1)));
+    const dim3 grid(static_cast<unsigned>((io.B + kTreeBlock - 1) / kTreeBlock));
+    if (hot) hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, kHot>), grid, dim3(kTreeBlock), 0, stream, a);
+    else hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, 0>), grid, dim3(kTreeBlock), 0, stream, a);
     return hipGetLastError();
 }
 

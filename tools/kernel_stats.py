@@ -4,7 +4,8 @@
 Counting rule for the FP64-VALU roofline (bench.py `valu_roofline`): every FP64 VALU instruction in
 the loop body counts its arithmetic -- FMA/FMAC = 2 flop, MUL/ADD/MIN/MAX = 1, RCP/RSQ/RNDNE/LDEXP/
 conversions = 1 -- per lane; the count is of *executed* instructions (what the hardware must issue),
-not of an algorithmic minimum.  Writes ik_amd/kernel_stats.json.
+not of an algorithmic minimum.  Both sides of wave-uniform branches are counted, so these static_* numbers are upper
+bounds; the flop count bench.py uses is the measured one (tools/pmc_to_stats.py).  Merges into ik_amd/kernel_stats.json.
 
     python tools/kernel_stats.py
 """
@@ -108,9 +109,14 @@ def main():
     old = {}
     if os.path.exists(path):
         old = json.load(open(path))
-    for k, v in out.items():
-        if k in old and "hbm_traffic_bytes_per_launch" in old[k]:
-            v["hbm_traffic_bytes_per_launch"] = old[k]["hbm_traffic_bytes_per_launch"]
+    for k, v in out.items():  # keep what tools/pmc_to_stats.py measured (traffic, flop counts, raw counters)
+        merged = dict(old.get(k, {}))
+        merged.update({"static_" + kk if kk in ("flop_per_iteration", "loop_instructions", "fp64_valu_instructions",
+                                                  "fp64_fma_instructions", "lds_reads", "top_instructions") else kk: vv
+                       for kk, vv in v.items()})
+        out[k] = merged
+    for k, v in old.items():
+        out.setdefault(k, v)
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
