@@ -31,7 +31,12 @@
 #if IKD_ON_DEVICE
 #define IKD_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define IKD_ANY(pred) (__any(pred) != 0)  // true in every lane when the predicate holds in some lane of the wave
+// Pins a value in a VGPR at this point: keeps hipcc from sinking its computation into one arm of a later select and
+// turning that select into a divergent branch (a branch splits the iteration's basic block and strands the LDS /
+// global loads behind it: with one wave per SIMD their latency is then fully exposed).
+#define IKD_PIN(x) asm volatile("" : "+v"(x))
 #else
+#define IKD_PIN(x) ((void)0)
 #define IKD_SCHED_FENCE() ((void)0)
 #define IKD_ANY(pred) (pred)
 #endif
@@ -151,7 +156,8 @@ IKD_FN double dacos(double x) {
     const double r = p * drcp(q);
     // |x| < 0.5: pi/2 - (x - (pio2_lo - x*r))
     const double res_small = pio2_hi - (x - (pio2_lo - x * r));
-    // |x| >= 0.5: s = sqrt(z)
+    // |x| >= 0.5: s = sqrt(z)   (hipcc turns the final selects into a branch around this arm: measured faster than
+    // pinning both arms, because near convergence every lane of a wave takes the same one)
     const double s = dsqrt(z);
     // x >= 0.5: 2*(df + w) with df = s truncated, c = (z - df*df)/(s + df), w = r*s + c
 #if IKD_ON_DEVICE
