@@ -174,16 +174,12 @@ def main():
 
     state = {"k": 0}
 
-    def step(ev=None):
+    def step():
         buf = bufs[state["k"] % 2]
         state["k"] += 1
         if distributed:
             buf.wait()  # the gather issued two steps ago must have drained this buffer set
-        if ev is not None:
-            ev[0].record()
         ik_amd.dls_batch(problem, Q0, targets, data, visitor, prm, out=buf.out())
-        if ev is not None:
-            ev[1].record()
         if distributed:
             buf.all_gather(async_op=True)
 
@@ -194,13 +190,19 @@ def main():
     for _ in range(args.warmup):
         step()
     drain()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # HIP events on the stream the kernels are launched on (torch's current stream is the one handed to the C ABI).
+    # N = 1: one pair around the K back-to-back launches -> average launch duration incl. the ~1-2 us launch boundary
+    # (agrees with rocprofv3 --kernel-trace within 1 %); N > 1: the collective shares the region, so each rank also
+    # times ONE isolated launch after the timed region.
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     if launched:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    ev0.record()
     for k in range(args.steps):
-        step(events[k])
+        step()
+    ev1.record()
     drain()
     out = bufs[(state["k"] - 1) % 2].out()
     torch.cuda.synchronize()
@@ -212,7 +214,14 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+    if distributed:
+        ev0.record()
+        ik_amd.dls_batch(problem, Q0, targets, data, visitor, prm, out=bufs[0].out())
+        ev1.record()
+        torch.cuda.synchronize()
+        kernel_ms = float(ev0.elapsed_time(ev1))
+    else:
+        kernel_ms = float(ev0.elapsed_time(ev1)) / args.steps
 
     if rank == 0:
         value = B * world * args.steps / elapsed
