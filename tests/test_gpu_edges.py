@@ -1,0 +1,114 @@
+"""GPU edge cases of the hot path through the C ABI: batch sizes around the wave width, one problem, zero
+iterations, huge but finite angles, unreachable targets, large damping, streams, and HIP-graph capture of the
+launch (the solve entry point allocates nothing and never synchronises, so it can be captured and replayed)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import urdf_path
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def ctx(native_built):
+    import torch
+    import ik_amd
+    import oracle as O
+    from ik_amd import workload
+    assert torch.cuda.is_available()
+    model = ik_amd.Model.from_urdf_file(urdf_path("cassie_fixed"))
+    problem = ik_amd.InverseKinematicsProblem(model)
+    problem.add_frame_task("lf", ik_amd.FrameTask.create(model, "LeftFootFront"))
+    data = ik_amd.dls_data(problem)
+    om = O.OracleModel(model.flat())
+    fid = model.getFrameId("LeftFootFront")
+    ot = O.make_tasks([(fid, 0, 2, 0, None)])
+
+    def inputs(B, mode="near", seed=0):
+        q0, qs = workload.chain_workload(model.lowerPositionLimit, model.upperPositionLimit,
+                                         workload.cassie_nominal(model.names), np.arange(B), seed, mode)
+        return q0, O.fk_batch(om, qs, [fid])
+
+    def dev(q0, tg):
+        return (torch.from_numpy(np.ascontiguousarray(q0.T)).cuda(), torch.from_numpy(np.ascontiguousarray(tg.transpose(1, 2, 0))).cuda())
+    return dict(torch=torch, ik=ik_amd, O=O, model=model, problem=problem, data=data, om=om, ot=ot, inputs=inputs, dev=dev)
+
+
+@pytest.mark.parametrize("B", [1, 2, 63, 64, 65, 127, 129, 4095])
+def test_batch_sizes_around_the_wave_width(ctx, B):
+    ik, O = ctx["ik"], ctx["O"]
+    q0, tg = ctx["inputs"](B)
+    Q0, T = ctx["dev"](q0, tg)
+    Q, ok, it = ik.dls_batch(ctx["problem"], Q0, T, ctx["data"])
+    q_ref, ok_ref, it_ref = O.dls_batch(ctx["om"], ctx["ot"], tg, q0, O.params())
+    assert np.array_equal(ok.cpu().numpy(), ok_ref) and np.array_equal(it.cpu().numpy(), it_ref)
+    assert np.abs(Q.cpu().numpy().T - q_ref).max() <= TOL
+
+
+def test_zero_iterations_returns_q0_untouched(ctx):
+    ik = ctx["ik"]
+    q0, tg = ctx["inputs"](100)
+    q0[:, 9] += 7.0  # outside its limit: must come back unclipped (reference ik/ik/dls.cpp:14,76-77 with no iteration)
+    Q0, T = ctx["dev"](q0, tg)
+    Q, ok, it = ik.dls_batch(ctx["problem"], Q0, T, ctx["data"], p=ik.dls_parameters(max_iterations=0))
+    assert ctx["torch"].equal(Q, Q0) and not ok.any() and not it.any()
+
+
+def test_large_angles_unreachable_targets_large_damping(ctx):
+    ik, O = ctx["ik"], ctx["O"]
+    q0, tg = ctx["inputs"](512, "uniform", seed=4)
+    q0[:, :8] += 2.0 * np.pi * np.arange(512)[:, None] % 37      # winds up to ~230 rad: the sincos range reduction
+    tg[::2, 0, 9:] += [3.0, -2.0, 4.0]                            # far outside the workspace
+    Q0, T = ctx["dev"](q0, tg)
+    for iters, damping, step in ((1, 1e-2, 1.0), (2, 5.0, 0.3), (1, 1e-3, 1.0)):
+        Q, ok, it = ik.dls_batch(ctx["problem"], Q0, T, ctx["data"], ik.never_stop_visitor(),
+                                 ik.dls_parameters(max_iterations=iters, damping=damping, step_length=step))
+        q_ref, _, _ = O.dls_batch(ctx["om"], ctx["ot"], tg, q0, O.params(iters, damping, step, -1.0))
+        assert np.isfinite(Q.cpu().numpy()).all()
+        assert np.abs(Q.cpu().numpy().T - q_ref).max() <= TOL
+    # a vanishing damping makes JJ^T + damping^2 I numerically singular for unreachable targets: the step is then
+    # dominated by rounding on both sides (Eigen's pivoted LDL^T in the reference, Cholesky here); it must stay finite
+    Q, _, _ = ik.dls_batch(ctx["problem"], Q0, T, ctx["data"], ik.never_stop_visitor(), ik.dls_parameters(max_iterations=3, damping=1e-6))
+    assert np.isfinite(Q.cpu().numpy()).all()
+
+
+def test_concurrent_streams_share_one_problem_handle(ctx):
+    torch, ik = ctx["torch"], ctx["ik"]
+    q0, tg = ctx["inputs"](8192)
+    Q0, T = ctx["dev"](q0, tg)
+    ref, _, _ = ik.dls_batch(ctx["problem"], Q0, T, ctx["data"])
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    outs = []
+    for s in streams:
+        with torch.cuda.stream(s):
+            outs.append(ik.dls_batch(ctx["problem"], Q0, T, ctx["data"])[0])
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, ref) for o in outs)
+
+
+def test_hip_graph_capture_and_replay(ctx):
+    """The chain / tree solve entry points are graph-capturable: one capture, many replays, same bits."""
+    torch, ik = ctx["torch"], ctx["ik"]
+    q0, tg = ctx["inputs"](4096)                                   # BASELINE.json configs[1]: a launch-bound size
+    Q0, T = ctx["dev"](q0, tg)
+    ref, ok_ref, it_ref = ik.dls_batch(ctx["problem"], Q0, T, ctx["data"])
+    out = (torch.empty_like(Q0), torch.empty(4096, dtype=torch.uint8, device="cuda"), torch.empty(4096, dtype=torch.int32, device="cuda"))
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(8):
+            ik.dls_batch(ctx["problem"], Q0, T, ctx["data"], out=out)
+    out[0].zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], ref) and torch.equal(out[1], ok_ref) and torch.equal(out[2], it_ref)
+    T2 = T.clone()
+    T.copy_(torch.roll(T2, 1, dims=2))                             # new targets in the captured buffers
+    g.replay()
+    torch.cuda.synchronize()
+    ref2, _, _ = ik.dls_batch(ctx["problem"], Q0, T, ctx["data"])
+    assert torch.equal(out[0], ref2)
