@@ -5,7 +5,7 @@ kernels behind a C ABI (include/ikgpu.h, ik_amd/libikgpu.so).  This package is t
 mirror of the reference API for that path plus the ctypes plumbing; it fails loudly when the
 native library is missing and has no CPU fallback.
 """
-from .api import (AlignAxisTask, AlignAxisType, FrameTask, InverseKinematicsProblem, KinematicType, Model, SE3, dls, dls_batch, dls_data,  # noqa: F401
+from .api import (AlignAxisTask, AlignAxisType, FrameTask, PostureTask, InverseKinematicsProblem, KinematicType, Model, SE3, dls, dls_batch, dls_data,  # noqa: F401
                   dls_parameters, evaluate_batch, inverse_kinematics_visitor, never_stop_visitor, plan,
                   task_frames_fk_batch)
 from .capi import IkgpuError  # noqa: F401

@@ -170,14 +170,60 @@ class AlignAxisTask:
         return self._weighting
 
 
-def _abi_type(task):
-    return 3 + int(task.axis) if isinstance(task, AlignAxisTask) else int(task.type)
+class PostureTask:
+    """ik::PostureTask (reference ik/ik/posture.hpp:17-85): e = (q.tail(nj) - target) * mask, J.rightCols(nj) = I
+    (the reference does not apply the mask to J).  Crosses the ABI as nj one-row tasks (IKGPU_POSTURE_ROW) and
+    runs on the generic kernel."""
+
+    def __init__(self, model, nj):
+        if not 0 < nj <= min(model.nq, model.nv):
+            raise ValueError("PostureTask over %d joints on a model with nv = %d" % (nj, model.nv))
+        self.nj = int(nj)
+        self._q0, self._v0 = model.nq - self.nj, model.nv - self.nj
+        self.target = np.zeros(self.nj)   # posture.hpp:75
+        self.mask = np.ones(self.nj)      # posture.hpp:82
+        self._weighting = np.ones(self.nj)
+
+    @staticmethod
+    def create(model, nj):
+        return PostureTask(model, nj)
+
+    def dimension(self):
+        return self.nj
+
+    def weighting(self):
+        return self._weighting
 
 
-def _target12(task):
+def _abi_rows(task, prio):
+    """The rows a task contributes to the ABI's task table: (frame, reference, type, priority, weight[6])."""
+    if isinstance(task, PostureTask):
+        return [(task._v0 + k, task._q0 + k, capi.POSTURE_ROW, prio, [float(task._weighting[k]), float(task.mask[k]), 1, 1, 1, 1])
+                for k in range(task.nj)]
+    w = list(np.asarray(task.weighting(), dtype=np.float64)) + [1.0] * 6
+    typ = 3 + int(task.axis) if isinstance(task, AlignAxisTask) else int(task.type)
+    return [(task._frame_id, task._ref_id, typ, prio, w[:6])]
+
+
+def _target_slots(task):
+    """The 12-double target slots of a task, one per ABI row."""
+    if isinstance(task, PostureTask):
+        out = np.zeros((task.nj, 12))
+        out[:, 9] = np.asarray(task.target, dtype=np.float64)
+        return out
     if isinstance(task, AlignAxisTask):
-        return np.concatenate([np.eye(3).reshape(9), np.asarray(task.target, dtype=np.float64).reshape(3)])
-    return task.target.to12()
+        return np.concatenate([np.eye(3).reshape(9), np.asarray(task.target, dtype=np.float64).reshape(3)])[None, :]
+    return task.target.to12()[None, :]
+
+
+def _task_table(problem):
+    rows = [r for t, prio in problem.ordered_tasks() for r in _abi_rows(t, prio)]
+    arr = (capi.Task * len(rows))()
+    for i, (f, r, typ, prio, w) in enumerate(rows):
+        arr[i].frame, arr[i].reference, arr[i].type, arr[i].priority = f, r, typ, prio
+        for k in range(6):
+            arr[i].weight[k] = w[k]
+    return arr
 
 
 class InverseKinematicsProblem:
@@ -192,6 +238,8 @@ class InverseKinematicsProblem:
         self._frame_tasks_map = {}
         self._axis_tasks = []
         self._axis_tasks_map = {}
+        self._posture_tasks = []
+        self._posture_tasks_map = {}
         self._generation = 0
 
     def max_priority_level(self):
@@ -240,6 +288,23 @@ class InverseKinematicsProblem:
         """(task, priority) in the row order of the stacked system (reference ik/ik/dls.cpp:20-24)."""
         return [(t, p) for p in range(self._max_priority_level + 1) for t in self._tasks[p]]
 
+    def target_slots(self):
+        """Number of 12-double target slots a batch call takes per problem: one per frame / axis task, one per
+        joint of a posture task (value in double 9 of its slot)."""
+        return sum(t.nj if isinstance(t, PostureTask) else 1 for t, _ in self.ordered_tasks())
+
+    def add_posture_task(self, name, task, priority=0):  # reference ik/ik/problem.hpp:134-145
+        if not 0 <= priority <= self._max_priority_level:
+            raise ValueError("Maximum priority level exceeded!")
+        self._posture_tasks_map.setdefault(name, len(self._posture_tasks))
+        self._posture_tasks.append(task)
+        self._tasks[priority].append(task)
+        self._generation += 1
+        return task
+
+    def get_posture_task(self, name):
+        return self._posture_tasks[self._posture_tasks_map[name]]
+
 
 class dls_parameters:
     """ik::dls_parameters (reference ik/ik/dls.hpp:24-28, ik/ik/common.hpp:59-66)."""
@@ -279,22 +344,12 @@ class dls_data:
         self._generation = -1
         self._bind(problem)
 
-    def _task_array(self, problem):
-        ordered = problem.ordered_tasks()
-        arr = (capi.Task * len(ordered))()
-        for i, (t, prio) in enumerate(ordered):
-            arr[i].frame, arr[i].reference, arr[i].type, arr[i].priority = t._frame_id, t._ref_id, _abi_type(t), prio
-            w = list(np.asarray(t.weighting(), dtype=np.float64)) + [1.0] * 6
-            for k in range(6):
-                arr[i].weight[k] = w[k]
-        return arr
-
     def _bind(self, problem):
-        key = (problem._generation, tuple(tuple(t.weighting()) for t, _ in problem.ordered_tasks()))
+        key = (problem._generation, tuple(tuple(r[4]) for t, p in problem.ordered_tasks() for r in _abi_rows(t, p)))
         if self._h is not None and key == self._generation:
             return
         self._release()
-        arr = self._task_array(problem)
+        arr = _task_table(problem)
         h = C.c_void_p()
         capi.check(capi.lib().ikgpu_problem_create(problem.model()._h, arr, len(arr), self._device, C.byref(h)))
         self._h = h
@@ -317,13 +372,7 @@ class dls_data:
 def plan(problem):
     """Name of the kernel specialisation the problem maps to (host-only; raises IkgpuError when the
     shape has no device kernel)."""
-    ordered = problem.ordered_tasks()
-    arr = (capi.Task * len(ordered))()
-    for i, (t, prio) in enumerate(ordered):
-        arr[i].frame, arr[i].reference, arr[i].type, arr[i].priority = t._frame_id, t._ref_id, _abi_type(t), prio
-        w = list(np.asarray(t.weighting(), dtype=np.float64)) + [1.0] * 6
-        for k in range(6):
-            arr[i].weight[k] = w[k]
+    arr = _task_table(problem)
     buf = C.create_string_buffer(128)
     capi.check(capi.lib().ikgpu_problem_plan(problem.model()._h, arr, len(arr), buf, len(buf)))
     return buf.value.decode()
@@ -342,7 +391,7 @@ def dls(problem, q0, data, visitor=None, p=None):
     data._bind(problem)
     model = problem.model()
     q0 = np.ascontiguousarray(q0, dtype=np.float64).reshape(model.nq)
-    tg = np.ascontiguousarray(np.stack([_target12(t) for t, _ in problem.ordered_tasks()]))
+    tg = np.ascontiguousarray(np.concatenate([_target_slots(t) for t, _ in problem.ordered_tasks()]))
     q = np.empty(model.nq)
     ok = np.zeros(1, np.uint8)
     it = np.zeros(1, np.int32)
@@ -365,8 +414,8 @@ def dls_batch(problem, Q0, targets, data, visitor=None, p=None, layout="soa", ou
     p = p or dls_parameters()
     data._bind(problem)
     model = problem.model()
-    ntasks = len(problem.ordered_tasks())
-    lay = {"soa": capi.SOA, "aos": capi.AOS}[layout]
+    ntasks = problem.target_slots()
+    lay ={"soa": capi.SOA, "aos": capi.AOS}[layout]
     prm = _params(visitor, p)
     L = capi.lib()
     if isinstance(Q0, np.ndarray):
@@ -436,7 +485,7 @@ def task_frames_fk_batch(problem, Q, data, layout="soa"):
     data._bind(problem)
     lay = {"soa": capi.SOA, "aos": capi.AOS}[layout]
     B = Q.shape[1] if lay == capi.SOA else Q.shape[0]
-    nt = len(problem.ordered_tasks())
+    nt = problem.target_slots()
     out = torch.empty((nt, 12, B) if lay == capi.SOA else (B, nt, 12), dtype=torch.float64, device=Q.device)
     s = torch.cuda.current_stream(Q.device).cuda_stream
     capi.check(capi.lib().ikgpu_task_frames_fk_batch(data._h, B, Q.data_ptr(), out.data_ptr(), lay, C.c_void_p(s)))

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libikgpu.so")
 OK, ERR_INVALID, ERR_PARSE, ERR_UNSUPPORTED, ERR_DEVICE = 0, 1, 2, 3, 4
 JOINT_UNIVERSE, JOINT_REVOLUTE, JOINT_PRISMATIC, JOINT_FREEFLYER = 0, 1, 2, 3
 POSITION, ORIENTATION, FULL = 0, 1, 2
+ALIGN_AXIS_X, ALIGN_AXIS_Y, ALIGN_AXIS_Z, POSTURE_ROW = 3, 4, 5, 6
 SOA, AOS = 0, 1
 ROOT_FIXED, ROOT_FREEFLYER = 0, 1
 

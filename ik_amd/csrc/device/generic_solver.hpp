@@ -19,7 +19,7 @@
 namespace ikdev {
 
 enum : int { GJ_UNIVERSE = 0, GJ_REVOLUTE = 1, GJ_PRISMATIC = 2, GJ_FREEFLYER = 3 };  // == ikgpu_joint_type
-enum : int { GT_POSITION = 0, GT_ORIENTATION = 1, GT_FULL = 2, GT_ALIGN_X = 3 };       // == ikgpu_kinematic_type
+enum : int { GT_POSITION = 0, GT_ORIENTATION = 1, GT_FULL = 2, GT_ALIGN_X = 3, GT_POSTURE_ROW = 6 };  // == ikgpu_kinematic_type
 
 // Read-only tables shared by all lanes (device global memory; host memory in the lane emulator).
 struct GenericTables {
@@ -123,6 +123,13 @@ IKD_FN double generic_evaluate(const GenericTables &T, const Ws &ws, const doubl
     for (int t = 0; t < T.ntasks; ++t) {
         const int fj = T.t_fjoint[t], rj = T.t_rjoint[t], type = T.t_type[t], row = T.t_row[t], dim = T.t_dim[t];
         const double *w6 = T.t_w + 6 * t;
+        if (type == GT_POSTURE_ROW) {  // one row of ik::PostureTask, ik/ik/posture.hpp:51-68 (fjoint = tangent column, rjoint = q index)
+            const double e = (ws[T.off_q + rj] - targets_lane[(t * 12 + 9) * tstride]) * w6[1] * w6[0];
+            ws[T.off_e + row] = e;
+            if (T.t_prio[t] == 0) e0sq = dfma(e, e, e0sq);
+            for (int c = 0; c < T.nv; ++c) ws[T.off_J + row * T.nv + c] = (c == fj) ? w6[0] : 0.0;
+            continue;
+        }
         double oJ[12], oMf[12], oMr[12], tg[12];
         for (int k = 0; k < 12; ++k) oJ[k] = ws[T.off_oMi + 12 * fj + k];
         g_se3_mul(oJ, T.t_fpl + 12 * t, oMf);
@@ -323,6 +330,10 @@ IKD_FN void eval_generic_body(const GenericKernelArgs &a, int64_t gid) {
     if (a.oMf_out)
         for (int t = 0; t < a.T.ntasks; ++t) {
             double oJ[12], oMf[12];
+            if (a.T.t_type[t] == GT_POSTURE_ROW) {  // no frame: report the identity
+                for (int k = 0; k < 12; ++k) a.oMf_out[at(a.layout, a.B, a.T.ntasks * 12, t * 12 + k, b)] = (k < 9 && k % 4 == 0) ? 1.0 : 0.0;
+                continue;
+            }
             for (int k = 0; k < 12; ++k) oJ[k] = ws[a.T.off_oMi + 12 * a.T.t_fjoint[t] + k];
             g_se3_mul(oJ, a.T.t_fpl + 12 * t, oMf);
             for (int k = 0; k < 12; ++k) a.oMf_out[at(a.layout, a.B, a.T.ntasks * 12, t * 12 + k, b)] = oMf[k];

@@ -18,7 +18,7 @@
 // Differences that cannot be hidden, by design of a device path:
 //   * a C++ visitor cannot run inside a kernel: inverse_kinematics_visitor carries the one-parameter
 //     family of ik/ik/visitor.hpp:19 (`||e[0]||^2 < tolerance`); override stop_tolerance(), not should_stop();
-//   * FrameTask and AlignAxisTask are accelerated (SURVEY.md section 8f lists the other task kinds as "next");
+//   * FrameTask, AlignAxisTask and PostureTask are accelerated (SURVEY.md section 8f lists the other kinds as "next");
 //   * failures of the device call throw std::runtime_error (the reference has no failure channel).
 #pragma once
 
@@ -199,13 +199,34 @@ class Task {
 
 enum class KinematicType { Position, Orientation, Full };  // ik/ik/frame.hpp:20
 
-// A task row set as the device sees it; FrameTask and AlignAxisTask both provide it.
+// A task as the device sees it: the ikgpu_task rows it contributes and one 12-double target slot per row.
 class DeviceTask : public Task {
+   public:
+    virtual void abi_rows(int32_t priority, std::vector<ikgpu_task> &out) const = 0;
+    virtual void abi_targets(std::vector<number_t> &out) const = 0;
+};
+
+// FrameTask and AlignAxisTask: one ABI row whose frame / reference are model frames.
+class SingleRowTask : public DeviceTask {
    public:
     virtual int32_t abi_type() const = 0;                 // ikgpu_kinematic_type
     virtual void abi_target(number_t *out12) const = 0;   // the 12-double target slot
     index_t frame_id() const { return frame_id_; }
     index_t reference_id() const { return reference_id_; }
+    void abi_rows(int32_t priority, std::vector<ikgpu_task> &out) const override {
+        ikgpu_task k;
+        k.frame = static_cast<int32_t>(frame_id_);
+        k.reference = static_cast<int32_t>(reference_id_);
+        k.type = abi_type();
+        k.priority = priority;
+        for (int i = 0; i < 6; ++i) k.weight[i] = i < static_cast<int>(dimension()) ? weighting()[i] : 1.0;
+        out.push_back(k);
+    }
+    void abi_targets(std::vector<number_t> &out) const override {
+        number_t slot[12];
+        abi_target(slot);
+        out.insert(out.end(), slot, slot + 12);
+    }
 
    protected:
     void resolve(const model_t &model, const string_t &frame, const string_t &reference_frame) {
@@ -219,7 +240,7 @@ class DeviceTask : public Task {
 };
 
 // ---- ik::FrameTask (ik/ik/frame.hpp:78-200) -----------------------------------------------------
-class FrameTask : public DeviceTask {
+class FrameTask : public SingleRowTask {
    public:
     FrameTask(const model_t &model, const string_t &frame, const KinematicType &type = KinematicType::Full,
               const string_t &reference_frame = "universe")
@@ -266,7 +287,7 @@ class vector3_t {  // the slice of Eigen::Vector3d the task uses: target << x, y
     number_t d_[3];
 };
 
-class AlignAxisTask : public DeviceTask {
+class AlignAxisTask : public SingleRowTask {
    public:
     AlignAxisTask(const model_t &model, const string_t &frame, const AlignAxisType &axis,
                   const string_t &reference_frame = "universe")
@@ -291,7 +312,49 @@ class AlignAxisTask : public DeviceTask {
     string_t frame_, reference_frame_;
 };
 
-// ---- ik::InverseKinematicsProblem (ik/ik/problem.hpp:9-206), frame + align-axis tasks ---------------
+// ---- ik::PostureTask (ik/ik/posture.hpp:17-85) --------------------------------------------------
+// e = (q.bottomRows(nj) - target) .* mask, J.rightCols(nj) = I (the reference leaves the mask out of J).  Crosses the
+// ABI as nj one-row tasks of type IKGPU_POSTURE_ROW; runs on the generic device kernel.
+class PostureTask : public DeviceTask {
+   public:
+    PostureTask(const model_t &model, const index_t &nj)
+        : target(vector_t::Zero(nj)), mask(vector_t::Ones(nj)), nj_(nj), q0_(model.nq - nj), v0_(model.nv - nj) {
+        if (nj == 0 || nj > static_cast<index_t>(model.nv) || nj > static_cast<index_t>(model.nq))
+            throw std::invalid_argument("PostureTask: nj out of range for this model");
+        set_dimension(nj);
+    }
+    static std::shared_ptr<PostureTask> create(const model_t &model, const index_t &nj) {
+        return std::make_shared<PostureTask>(model, nj);
+    }
+    vector_t target;  // posture.hpp:75
+    vector_t mask;    // posture.hpp:82
+
+    void abi_rows(int32_t priority, std::vector<ikgpu_task> &out) const override {
+        for (index_t k = 0; k < nj_; ++k) {
+            ikgpu_task r;
+            r.frame = static_cast<int32_t>(v0_ + k);      // tangent column
+            r.reference = static_cast<int32_t>(q0_ + k);  // index in q
+            r.type = IKGPU_POSTURE_ROW;
+            r.priority = priority;
+            r.weight[0] = weighting()[k];
+            r.weight[1] = mask[k];
+            for (int i = 2; i < 6; ++i) r.weight[i] = 1.0;
+            out.push_back(r);
+        }
+    }
+    void abi_targets(std::vector<number_t> &out) const override {
+        for (index_t k = 0; k < nj_; ++k) {
+            number_t slot[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            slot[9] = target[k];
+            out.insert(out.end(), slot, slot + 12);
+        }
+    }
+
+   protected:
+    index_t nj_, q0_, v0_;
+};
+
+// ---- ik::InverseKinematicsProblem (ik/ik/problem.hpp:9-206), frame + align-axis + posture tasks ------
 class InverseKinematicsProblem {
    public:
     InverseKinematicsProblem(const model_t &model, const std::size_t &max_priority_level = 0)
@@ -334,6 +397,20 @@ class InverseKinematicsProblem {
         if (it == axis_tasks_map_.end()) throw std::out_of_range("Align-axis task does not exist: " + name);
         return axis_tasks_.at(it->second);
     }
+    std::shared_ptr<PostureTask> add_posture_task(const string_t &name, const std::shared_ptr<PostureTask> &task,
+                                                  const std::size_t &priority = 0) {  // problem.hpp:134-145
+        if (priority > max_priority_level_) throw std::out_of_range("Maximum priority level exceeded!");
+        posture_tasks_map_.insert({name, posture_tasks_.size()});
+        posture_tasks_.push_back(task);
+        tasks_[priority].push_back(task);
+        ++generation_;
+        return posture_tasks_.back();
+    }
+    std::shared_ptr<PostureTask> get_posture_task(const string_t &name) {  // problem.hpp:147-149
+        auto it = posture_tasks_map_.find(name);
+        if (it == posture_tasks_map_.end()) throw std::out_of_range("Posture task does not exist: " + name);
+        return posture_tasks_.at(it->second);
+    }
     const std::vector<std::shared_ptr<DeviceTask>> &get_all_tasks(const std::size_t &priority) const { return tasks_.at(priority); }
     const model_t &model() const { return model_; }
     std::size_t generation() const { return generation_; }
@@ -346,6 +423,8 @@ class InverseKinematicsProblem {
     std::unordered_map<string_t, std::size_t> frame_tasks_map_;
     std::vector<std::shared_ptr<AlignAxisTask>> axis_tasks_;
     std::unordered_map<string_t, std::size_t> axis_tasks_map_;
+    std::vector<std::shared_ptr<PostureTask>> posture_tasks_;
+    std::unordered_map<string_t, std::size_t> posture_tasks_map_;
     std::size_t generation_ = 0;
 };
 
@@ -391,15 +470,7 @@ class dls_data {
     void bind(const InverseKinematicsProblem &problem) {
         std::vector<ikgpu_task> tasks;
         for (std::size_t p = 0; p <= problem.max_priority_level(); ++p)  // stacking order of ik/ik/dls.cpp:20-24
-            for (const auto &t : problem.get_all_tasks(p)) {
-                ikgpu_task k;
-                k.frame = static_cast<int32_t>(t->frame_id());
-                k.reference = static_cast<int32_t>(t->reference_id());
-                k.type = t->abi_type();
-                k.priority = static_cast<int32_t>(p);
-                for (int i = 0; i < 6; ++i) k.weight[i] = i < static_cast<int>(t->dimension()) ? t->weighting()[i] : 1.0;
-                tasks.push_back(k);
-            }
+            for (const auto &t : problem.get_all_tasks(p)) t->abi_rows(static_cast<int32_t>(p), tasks);
         if (h_ && same(tasks)) return;
         ikgpu_problem *h = nullptr;
         if (ikgpu_problem_create(problem.model().handle(), tasks.data(), static_cast<int32_t>(tasks.size()), device_, &h) != IKGPU_OK)
@@ -438,11 +509,7 @@ inline ikgpu_dls_params to_abi(const inverse_kinematics_visitor &visitor, const 
 inline std::vector<number_t> gather_targets(const InverseKinematicsProblem &problem) {
     std::vector<number_t> t;
     for (std::size_t p = 0; p <= problem.max_priority_level(); ++p)
-        for (const auto &task : problem.get_all_tasks(p)) {
-            number_t slot[12];
-            task->abi_target(slot);
-            t.insert(t.end(), slot, slot + 12);
-        }
+        for (const auto &task : problem.get_all_tasks(p)) task->abi_targets(t);
     return t;
 }
 }  // namespace detail

@@ -91,7 +91,7 @@ void specialise(ProblemHost &ph, const Model &m) {
     static const char *kt[] = {"position", "orientation", "full"};
     const int ntasks = ph.ntasks;
     for (const ikgpu_task &t : ph.tasks)
-        if (t.type > IKGPU_FULL) throw Unsupported("AlignAxisTask rows run on the generic kernel");
+        if (t.type > IKGPU_FULL) throw Unsupported("AlignAxisTask / PostureTask rows run on the generic kernel");
     const bool free_flyer = m.njoints() > 1 && m.joint_type[1] == IKGPU_JOINT_FREEFLYER;
     std::vector<uint8_t> in_chain(m.nq, 0);
 
@@ -160,8 +160,9 @@ void build_generic(ProblemHost &ph, const Model &m) {
     for (int i = 0; i < nt; ++i) {
         const ikgpu_task &t = ph.tasks[i];
         ttype.push_back(t.type);
-        tfj.push_back(m.frame_parent[t.frame]);
-        trj.push_back(m.frame_parent[t.reference]);
+        const bool posture = t.type == IKGPU_POSTURE_ROW;  // frame / reference are then tangent / configuration indices
+        tfj.push_back(posture ? t.frame : m.frame_parent[t.frame]);
+        trj.push_back(posture ? t.reference : m.frame_parent[t.reference]);
         trow.push_back(ph.task_row[i]);
         tdim.push_back(task_dim(t));
         tprio.push_back(t.priority);
@@ -176,9 +177,12 @@ void build_generic(ProblemHost &ph, const Model &m) {
     g.o_lower = put_d(m.lower.data(), m.lower.size());
     g.o_upper = put_d(m.upper.data(), m.upper.size());
     g.o_tfpl = static_cast<int>(g.dbls.size());
-    for (int i = 0; i < nt; ++i) put_d(m.frame_placement[ph.tasks[i].frame].data(), 12);
+    const SE3 ident = se3_identity();
+    for (int i = 0; i < nt; ++i)
+        put_d(ph.tasks[i].type == IKGPU_POSTURE_ROW ? ident.data() : m.frame_placement[ph.tasks[i].frame].data(), 12);
     g.o_trpl = static_cast<int>(g.dbls.size());
-    for (int i = 0; i < nt; ++i) put_d(m.frame_placement[ph.tasks[i].reference].data(), 12);
+    for (int i = 0; i < nt; ++i)
+        put_d(ph.tasks[i].type == IKGPU_POSTURE_ROW ? ident.data() : m.frame_placement[ph.tasks[i].reference].data(), 12);
     g.o_tw = static_cast<int>(g.dbls.size());
     for (int i = 0; i < nt; ++i) put_d(ph.tasks[i].weight, 6);
     const int M = ph.rows, nv = m.nv;
@@ -211,9 +215,14 @@ ProblemHost analyse_problem(const Model &m, const ikgpu_task *tasks, int ntasks,
     int last_prio = 0;
     for (int i = 0; i < ntasks; ++i) {
         const ikgpu_task &t = tasks[i];
-        if (t.frame < 0 || t.frame >= m.nframes()) throw std::runtime_error("task " + std::to_string(i) + ": frame id out of range");
-        if (t.reference < 0 || t.reference >= m.nframes()) throw std::runtime_error("task " + std::to_string(i) + ": reference frame id out of range");
-        if (t.type < IKGPU_POSITION || t.type > IKGPU_ALIGN_AXIS_Z) throw std::runtime_error("task " + std::to_string(i) + ": unknown kinematic type");
+        if (t.type == IKGPU_POSTURE_ROW) {
+            if (t.frame < 0 || t.frame >= m.nv) throw std::runtime_error("task " + std::to_string(i) + ": posture row tangent index out of range");
+            if (t.reference < 0 || t.reference >= m.nq) throw std::runtime_error("task " + std::to_string(i) + ": posture row configuration index out of range");
+        } else {
+            if (t.frame < 0 || t.frame >= m.nframes()) throw std::runtime_error("task " + std::to_string(i) + ": frame id out of range");
+            if (t.reference < 0 || t.reference >= m.nframes()) throw std::runtime_error("task " + std::to_string(i) + ": reference frame id out of range");
+        }
+        if (t.type < IKGPU_POSITION || t.type > IKGPU_POSTURE_ROW) throw std::runtime_error("task " + std::to_string(i) + ": unknown kinematic type");
         if (t.priority < 0) throw std::runtime_error("task " + std::to_string(i) + ": negative priority");
         if (t.priority < last_prio) throw std::runtime_error("tasks must be listed in stacking order (non-decreasing priority)");
         last_prio = t.priority;

@@ -54,7 +54,12 @@ typedef enum {
     /* ik::AlignAxisTask with AlignAxisType::AxisX / AxisY / AxisZ (reference ik/ik/frame.hpp:202-319): one row,
      * e = 1 - axis . target/|target|.  Its target direction (frame.hpp:307) rides in the translation part
      * (doubles 9..11) of the task's 12-double target slot; the rotation part is ignored. */
-    IKGPU_ALIGN_AXIS_X = 3, IKGPU_ALIGN_AXIS_Y = 4, IKGPU_ALIGN_AXIS_Z = 5
+    IKGPU_ALIGN_AXIS_X = 3, IKGPU_ALIGN_AXIS_Y = 4, IKGPU_ALIGN_AXIS_Z = 5,
+    /* ONE row of ik::PostureTask (reference ik/ik/posture.hpp:17-85; a task over nj joints is nj consecutive rows):
+     * e = (q[reference] - target) * mask, J = unit row at tangent column `frame` (the reference does not apply the mask
+     * to J), both times the weight.  Here `frame` is the tangent index, `reference` the index in q, weight[0] the
+     * Task::weighting() entry, weight[1] the mask entry; the target value rides in double 9 of the row's 12-double slot. */
+    IKGPU_POSTURE_ROW = 6
 } ikgpu_kinematic_type;
 
 typedef enum { IKGPU_SOA = 0, IKGPU_AOS = 1 } ikgpu_layout;

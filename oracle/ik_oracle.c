@@ -332,7 +332,7 @@ static void frame_jacobian_local(const iko_model *m, const double *Jw, const dou
     }
 }
 
-static int task_dim(const iko_task *t) { return t->type == IKO_FULL ? 6 : (t->type >= IKO_ALIGN_X ? 1 : 3); }
+static int task_dim(const iko_task *t) { return t->type == IKO_FULL ? 6 : (t->type >= IKO_ALIGN_X ? 1 : 3); } /* align / posture rows: 1 */
 
 int iko_task_rows(const iko_task *tasks, int ntasks) {
     int M = 0;
@@ -386,6 +386,19 @@ static void evaluate_ws(const iko_model *m, const iko_task *tasks, int ntasks, c
         for (int ti = 0; ti < ntasks; ++ti) {
             const iko_task *t = &tasks[ti];
             if (t->priority != p) continue;
+            if (t->type == IKO_POSTURE_ROW) {
+                /* one row of ik::PostureTask (posture.hpp:51-68): e = (q_k - target_k) * mask_k, J = e_k^T (the mask is
+                 * not applied to J: "todo - incorporate mask"), then the task weight on both (data.cpp:49-50).
+                 * frame = column in the tangent vector, reference = index in q, weight[0] = w_k, weight[1] = mask_k,
+                 * target_k rides in double 9 of the slot. */
+                const double wt = t->weight[0];
+                w->et[row] = (q[t->reference] - targets[12 * ti + 9]) * t->weight[1] * wt;
+                if (p == 0) acc0 += w->et[row] * w->et[row];
+                for (int c = 0; c < nv; ++c) w->Jt[row * nv + c] = 0.0;
+                w->Jt[row * nv + t->frame] = wt;
+                row += 1;
+                continue;
+            }
             const double *oMf = w->oMf + 12 * t->frame, *oMr = w->oMf + 12 * t->reference;
             double oMt[12], fMt[12], tMf[12], e6[6], Jlog[36];
             const int d = task_dim(t);

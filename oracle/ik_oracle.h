@@ -25,7 +25,10 @@ enum { IKO_JOINT_UNIVERSE = 0, IKO_JOINT_REVOLUTE = 1, IKO_JOINT_PRISMATIC = 2, 
 enum { IKO_POSITION = 0, IKO_ORIENTATION = 1, IKO_FULL = 2,
        /* ik::AlignAxisTask with AlignAxisType X / Y / Z (ik/ik/frame.hpp:202-319): one row; its target direction
         * is the translation part (doubles 9..11) of the task's 12-double target slot, the rotation part is ignored */
-       IKO_ALIGN_X = 3, IKO_ALIGN_Y = 4, IKO_ALIGN_Z = 5 };
+       IKO_ALIGN_X = 3, IKO_ALIGN_Y = 4, IKO_ALIGN_Z = 5,
+       /* one row of ik::PostureTask (ik/ik/posture.hpp:17-85): frame = tangent column, reference = index in q,
+        * weight[0] = task weight, weight[1] = mask entry, target value in double 9 of the slot */
+       IKO_POSTURE_ROW = 6 };
 
 /* Flat kinematic model with Pinocchio's conventions (joint 0 = universe). SE(3) values are 12
  * doubles: rotation row-major (9) then translation (3). */

@@ -32,6 +32,17 @@ POSITION, ORIENTATION, FULL = 0, 1, 2  # ik::KinematicType (ik/ik/frame.hpp:20)
 ALIGN_X, ALIGN_Y, ALIGN_Z = 3, 4, 5     # ik::AlignAxisTask, AlignAxisType X / Y / Z (ik/ik/frame.hpp:202)
 
 
+class PostureTask:
+    """ik::PostureTask (ik/ik/posture.hpp:17-85): e = (q.tail(nj) - target) * mask, J.rightCols(nj) = I (mask not applied)."""
+
+    def __init__(self, m, nj, target=None, mask=None, weights=None):
+        self.nj = nj
+        self.dim = nj
+        self.target = np.zeros(nj) if target is None else np.array(target, float)
+        self.mask = np.ones(nj) if mask is None else np.array(mask, float)
+        self.w = np.ones(nj) if weights is None else np.array(weights, float)
+
+
 # ----------------------------------------------------------------------------------------------
 # SE(3) helpers on 4x4 homogeneous matrices
 # ----------------------------------------------------------------------------------------------
@@ -469,6 +480,12 @@ def evaluate(m, tasks, q):
     Jw = joint_jacobians_world(m, oMi)
     es, Js = [], []
     for t in tasks:
+        if isinstance(t, PostureTask):
+            J = np.zeros((t.nj, m.nv))
+            J[:, m.nv - t.nj:] = np.eye(t.nj)
+            es.append((q[m.nq - t.nj:] - t.target) * t.mask * t.w)
+            Js.append(t.w[:, None] * J)
+            continue
         if t.type >= ALIGN_X:  # AlignAxisTask (ik/ik/frame.hpp:257-301); target direction = t.target[:3, 3]
             rMf = se3_inv(oMf[t.reference]) @ oMf[t.frame]
             r = rMf[:3, t.type - ALIGN_X]

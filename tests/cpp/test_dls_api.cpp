@@ -5,12 +5,14 @@
 //
 //   test_dls_api <urdf> <free_flyer 0|1> <max_it> <damping> <step> <tol> <ntasks>
 //                { <frame> <type 0|1|2> <priority> <12 target numbers> } x ntasks   <nq numbers of q0>
+//                [ posture <nj> <priority> <weight> <nj target numbers> ]
 #include <cstdio>
 #include <cstdlib>
 #include <string>
 #include <vector>
 
 #include "ik/dls.hpp"
+#include "ik/posture.hpp"
 #include "ik/problem.hpp"
 
 int main(int argc, char **argv) {
@@ -44,6 +46,19 @@ int main(int argc, char **argv) {
             for (double &x : s.target) x = std::atof(next().c_str());
             if (s.prio > max_priority) max_priority = s.prio;
         }
+        ik::vector_t q0 = ik::vector_t::Zero(model.nq);
+        for (int i = 0; i < model.nq; ++i) q0[i] = std::atof(next().c_str());
+        std::size_t posture_nj = 0, posture_prio = 0;
+        double posture_weight = 1.0;
+        std::vector<double> posture_target;
+        if (a < argc && next() == "posture") {
+            posture_nj = std::atoi(next().c_str());
+            posture_prio = std::atoi(next().c_str());
+            posture_weight = std::atof(next().c_str());
+            for (std::size_t i = 0; i < posture_nj; ++i) posture_target.push_back(std::atof(next().c_str()));
+            if (posture_prio > max_priority) max_priority = posture_prio;
+        }
+
         ik::InverseKinematicsProblem problem(model, max_priority);
         int k = 0;
         for (auto &s : specs) {
@@ -59,8 +74,12 @@ int main(int argc, char **argv) {
                 s.target[6], s.target[7], s.target[8];
             task->target.translation() << s.target[9], s.target[10], s.target[11];
         }
-        ik::vector_t q0 = ik::vector_t::Zero(model.nq);
-        for (int i = 0; i < model.nq; ++i) q0[i] = std::atof(next().c_str());
+        if (posture_nj) {  // a posture regulariser (reference ik/ik/posture.hpp:17-85; problem.hpp:134-145)
+            auto posture = ik::PostureTask::create(model, posture_nj);
+            problem.add_posture_task("posture", posture, posture_prio);
+            for (std::size_t i = 0; i < posture_nj; ++i) problem.get_posture_task("posture")->target[i] = posture_target[i];
+            posture->weighting().setConstant(posture_weight);
+        }
 
         ik::dls_data data(problem);
         struct tol_visitor : ik::inverse_kinematics_visitor {

@@ -39,6 +39,10 @@ def build(name, ff, specs, B, seed=0, xml_edit=None):
     model = ik_amd.Model.from_urdf_xml(xml, free_flyer=ff)
     problem = ik_amd.InverseKinematicsProblem(model, max(s[4] for s in specs))
     for i, (kind, f, r, t, p, w) in enumerate(specs):
+        if kind == "posture":   # f = nj, w = (weights, mask)
+            task = problem.add_posture_task("t%d" % i, ik_amd.PostureTask.create(model, f), p)
+            task.weighting()[:], task.mask[:] = w
+            continue
         if kind == "align":
             task = problem.add_align_axis_task("t%d" % i, ik_amd.AlignAxisTask.create(model, f, ik_amd.AlignAxisType(t), r), p)
         else:
@@ -50,6 +54,9 @@ def build(name, ff, specs, B, seed=0, xml_edit=None):
     ordered = problem.ordered_tasks()
     ospec = []
     for t, prio in ordered:
+        if isinstance(t, ik_amd.PostureTask):   # nj rows: (tangent column, q index, IKGPU_POSTURE_ROW, priority, [weight, mask])
+            ospec += [(model.nv - t.nj + k, model.nq - t.nj + k, 6, prio, [t.weighting()[k], t.mask[k]]) for k in range(t.nj)]
+            continue
         w = None if np.all(t.weighting() == 1) else list(t.weighting())
         ospec.append((t._frame_id, t._ref_id, 3 + int(t.axis) if isinstance(t, ik_amd.AlignAxisTask) else int(t.type), prio, w))
     rng = np.random.default_rng(seed)
@@ -64,7 +71,9 @@ def build(name, ff, specs, B, seed=0, xml_edit=None):
     for b in range(B):
         _, oMf = O.fk(om, qs[b])
         for i, (fid, rid, typ, _, _) in enumerate(ospec):
-            if typ >= 3:
+            if typ == 6:
+                tg[b, i, 9] = qs[b, rid]
+            elif typ >= 3:
                 tg[b, i, :9] = np.eye(3).ravel()
                 tg[b, i, 9:] = rng.normal(size=3)
             else:
@@ -87,6 +96,12 @@ CASES = {
     "moving_reference_prismatic": ("ur5", False, [("frame", "tool0", "upper_arm_link", 2, 0, None)], _prismatic_elbow),
     "three_feet_frames": ("cassie", True, [("frame", "LeftFootFront", "universe", 0, 0, None), ("frame", "LeftFootBack", "universe", 0, 0, None),
                                            ("frame", "RightFootFront", "universe", 2, 0, None), ("frame", "pelvis", "universe", 1, 1, None)], None),
+    # ik::PostureTask (reference ik/ik/posture.hpp:17-85) regularising two pose tasks, with weights and a mask with holes
+    "posture_regulariser": ("cassie", True, [("frame", "LeftFootFront", "universe", 2, 0, None), ("frame", "pelvis", "universe", 2, 0, None),
+                                             ("posture", 16, None, None, 1, ([0.1 + 0.05 * k for k in range(16)],
+                                                                             [0.0 if k in (3, 9) else 1.0 for k in range(16)]))], None),
+    "posture_first_level": ("ur5", False, [("posture", 4, None, None, 0, ([1.0] * 4, [1.0] * 4)),
+                                           ("frame", "tool0", "universe", 0, 0, None)], None),
 }
 
 
@@ -151,6 +166,73 @@ def test_single_problem_demo_loop(torch_cuda):
         q_ref, ok_ref, it_ref = O.dls(om, ot, tg, q_ref, O.params(200, 1e-1, 1e-1, 1e-4))
         assert data.success == ok_ref and data.iterations == it_ref
         assert np.abs(q - q_ref).max() <= TOL
+
+
+def test_single_problem_with_posture_task(torch_cuda):
+    """dls() with a PostureTask whose `target` / `mask` / weighting() are edited between solves, as a caller of the
+    reference would (ik/ik/posture.hpp:75-82)."""
+    import ik_amd
+    import oracle as O
+    from ik_amd import workload
+    model = ik_amd.Model.from_urdf_file(urdf_path("cassie"), free_flyer=True)
+    problem = ik_amd.InverseKinematicsProblem(model, 1)
+    foot = problem.add_frame_task("fl", ik_amd.FrameTask.create(model, "LeftFootFront", ik_amd.KinematicType.Full))
+    posture = problem.add_posture_task("posture", ik_amd.PostureTask.create(model, 16), 1)
+    assert problem.get_posture_task("posture") is posture and problem.e_size(1) == 16 and problem.target_slots() == 17
+    data = ik_amd.dls_data(problem)
+    assert data.rows == 22 and data.kernel.startswith("dls_generic<")
+    om = O.OracleModel(model.flat())
+    nom = workload.cassie_nominal(model.names)
+    q0, qs = workload.freeflyer_workload(model.lowerPositionLimit, model.upperPositionLimit, nom, np.arange(1), seed=5)
+    _, oMf = O.fk(om, qs[0])
+    foot.target = ik_amd.SE3.from12(oMf[model.getFrameId("LeftFootFront")])
+    p = ik_amd.dls_parameters(max_iterations=30, damping=1e-2, step_length=0.5)
+    q = q_ref = q0[0]
+    for round_, (w, hole) in enumerate(((0.05, None), (0.5, 4))):
+        posture.target[:] = nom + 0.01 * round_
+        posture.weighting()[:] = w
+        posture.mask[:] = 1.0
+        if hole is not None:
+            posture.mask[hole] = 0.0
+        ot = O.make_tasks([(model.getFrameId("LeftFootFront"), 0, 2, 0, None)] +
+                          [(model.nv - 16 + k, model.nq - 16 + k, 6, 1, [w, posture.mask[k]]) for k in range(16)])
+        tg = np.zeros((17, 12))
+        tg[0] = foot.target.to12()
+        tg[1:, 9] = posture.target
+        q = ik_amd.dls(problem, q, data, ik_amd.inverse_kinematics_visitor(1e-8), p)
+        q_ref, ok_ref, it_ref = O.dls(om, ot, tg, q_ref, O.params(30, 1e-2, 0.5, 1e-8))
+        assert data.success == ok_ref and data.iterations == it_ref
+        assert np.abs(q - q_ref).max() <= TOL
+
+
+def test_cpp_api_program_with_posture_task(torch_cuda):
+    """ik::PostureTask through the C++ mirror (tests/cpp/test_dls_api.cpp's `posture` option)."""
+    import json
+    import subprocess
+    import ik_amd
+    import oracle as O
+    from ik_amd import workload
+    from test_gpu_parity import _cpp_binary
+    model = ik_amd.Model.from_urdf_file(urdf_path("cassie"), free_flyer=True)
+    om = O.OracleModel(model.flat())
+    nom = workload.cassie_nominal(model.names)
+    q0, qs = workload.freeflyer_workload(model.lowerPositionLimit, model.upperPositionLimit, nom, np.arange(3), seed=9)
+    q0, qs = q0[2], qs[2]
+    fid = model.getFrameId("RightFootFront")
+    tg = np.zeros((17, 12))
+    tg[0] = O.fk(om, qs)[1][fid]
+    tg[1:, 9] = nom
+    ot = O.make_tasks([(fid, 0, 2, 0, None)] + [(model.nv - 16 + k, model.nq - 16 + k, 6, 1, [0.25, 1.0]) for k in range(16)])
+    args = [_cpp_binary(), urdf_path("cassie"), "1", "30", "0.01", "1.0", "1e-6", "1", "RightFootFront", "2", "0"]
+    args += ["%.17g" % x for x in tg[0]] + ["%.17g" % x for x in q0]
+    args += ["posture", "16", "1", "0.25"] + ["%.17g" % x for x in nom]
+    out = json.loads(subprocess.check_output(args, text=True))
+    assert out["kernel"].startswith("dls_generic<M=22")
+    q1, ok1, it1 = O.dls(om, ot, tg, q0, O.params(30, 0.01, 1.0, 1e-6))
+    q2, ok2, it2 = O.dls(om, ot, tg, q1, O.params(30, 0.01, 1.0, 1e-6))
+    assert np.abs(np.array(out["q_first"]) - q1).max() <= TOL
+    assert np.abs(np.array(out["q"]) - q2).max() <= TOL
+    assert out["success"] == int(ok2) and out["iterations"] == it2
 
 
 def test_cpp_demo_program_matches_oracle(torch_cuda):

@@ -177,6 +177,36 @@ def test_invalid_task_tables_are_errors(ik):
     assert rc == capi.ERR_INVALID and b"frame id out of range" in capi.lib().ikgpu_last_error()
     bad[0].frame, bad[0].type = 1, 9
     assert capi.lib().ikgpu_problem_plan(m._h, bad, 1, buf, 64) == capi.ERR_INVALID
+    # posture rows index the tangent vector and q directly
+    bad[0].frame, bad[0].reference, bad[0].type = m.nv, 0, capi.POSTURE_ROW
+    assert capi.lib().ikgpu_problem_plan(m._h, bad, 1, buf, 64) == capi.ERR_INVALID
+    bad[0].frame, bad[0].reference = 0, m.nq
+    assert capi.lib().ikgpu_problem_plan(m._h, bad, 1, buf, 64) == capi.ERR_INVALID
+
+
+def test_posture_task_expands_to_one_row_per_joint(ik):
+    """ik::PostureTask (reference ik/ik/posture.hpp:17-85) crosses the ABI as nj IKGPU_POSTURE_ROW tasks."""
+    from ik_amd import api, capi
+    m = ik.Model.from_urdf_file(urdf_path("cassie"), free_flyer=True)
+    p = ik.InverseKinematicsProblem(m, 1)
+    p.add_frame_task("fl", ik.FrameTask.create(m, "LeftFootFront"))
+    t = p.add_posture_task("posture", ik.PostureTask.create(m, 16), 1)
+    assert t.dimension() == 16 and (t.target == 0).all() and (t.mask == 1).all() and (t.weighting() == 1).all()
+    t.weighting()[:] = np.arange(16) + 1.0
+    t.mask[5] = 0.0
+    t.target[:] = np.linspace(-1, 1, 16)
+    rows = api._abi_rows(t, 1)
+    assert [r[0] for r in rows] == list(range(6, 22)) and [r[1] for r in rows] == list(range(7, 23))
+    assert all(r[2] == capi.POSTURE_ROW and r[3] == 1 for r in rows)
+    assert [r[4][0] for r in rows] == list(np.arange(16) + 1.0) and [r[4][1] for r in rows] == [0.0 if k == 5 else 1.0 for k in range(16)]
+    slots = api._target_slots(t)
+    assert slots.shape == (16, 12) and np.array_equal(slots[:, 9], t.target) and np.count_nonzero(slots) == np.count_nonzero(t.target)
+    assert p.e_size(0) == 6 and p.e_size(1) == 16 and p.target_slots() == 17
+    assert ik.plan(p) == "dls_generic<M=22,nv=22,joints=17>"
+    with pytest.raises(ValueError):
+        ik.PostureTask(m, 40)
+    with pytest.raises(ValueError):
+        p.add_posture_task("again", t, 2)
 
 
 def test_no_gpu_means_a_loud_error_not_a_fallback(ik):

@@ -222,10 +222,11 @@ def _generic_case(name, ff, specs, B, seed=0, xml_edit=None):
         mid = 0.5 * (lo + hi)
         q0 = np.clip(mid + rng.uniform(-0.2, 0.2, (B, model.nq)), lo, hi)
         qs = np.clip(q0 + rng.uniform(-0.15, 0.15, (B, model.nq)), lo, hi)
+    specs = expand_posture(specs, model.nq, model.nv)
     tasks = (capi.Task * len(specs))()
     ospec, fids, rids = [], [], []
     for i, (f, r, t, p, w) in enumerate(specs):
-        fid, rid = model.getFrameId(f), model.getFrameId(r)
+        fid, rid = (f, r) if t == 6 else (model.getFrameId(f), model.getFrameId(r))
         ww = list(w) + [1.0] * (6 - len(w)) if w is not None else [1.0] * 6
         tasks[i] = capi.Task(fid, rid, t, p, (C.c_double * 6)(*ww))
         ospec.append((fid, rid, t, p, w))
@@ -236,7 +237,9 @@ def _generic_case(name, ff, specs, B, seed=0, xml_edit=None):
     for b in range(B):
         _, oMf = O.fk(om, qs[b])
         for i, (f, r, t, p, w) in enumerate(specs):
-            if t >= 3:
+            if t == 6:
+                tg[b, i, 9] = qs[b, rids[i]]
+            elif t >= 3:
                 tg[b, i, 9:] = rng.normal(size=3)
                 tg[b, i, :9] = np.eye(3).ravel()
             else:
@@ -245,6 +248,17 @@ def _generic_case(name, ff, specs, B, seed=0, xml_edit=None):
                 tg[b, i] = np.concatenate([rel[:3, :3].ravel(), rel[:3, 3]])
     M = sum(6 if t == 2 else (1 if t >= 3 else 3) for _, _, t, _, _ in specs)
     return urdf, model, om, tasks, O.make_tasks(ospec), q0, tg, M
+
+
+def expand_posture(specs, nq, nv):
+    """("@posture", nj, 6, priority, (weights[nj], mask[nj])) -> nj IKGPU_POSTURE_ROW specs (tangent column, q index)."""
+    out = []
+    for f, r, t, p, w in specs:
+        if f == "@posture":
+            out += [(nv - r + k, nq - r + k, 6, p, [w[0][k], w[1][k]]) for k in range(r)]
+        else:
+            out.append((f, r, t, p, w))
+    return out
 
 
 def T4(m12):
@@ -271,6 +285,11 @@ GENERIC_CASES = {
                                                     ("RightFootBack", "universe", 0, 1, [2.0, 1.0, 0.5])], 0, None),
     "shared_joints": ("ur5", False, [("tool0", "universe", 0, 0, None), ("forearm_link", "universe", 1, 0, None)], 0, None),
     "moving_reference_prismatic": ("ur5", False, [("tool0", "upper_arm_link", 2, 0, None)], 0, _prismatic_elbow),
+    # ik::PostureTask (reference ik/ik/posture.hpp:17-85) as a regulariser at priority 1, weights and a mask with a hole
+    "posture_regulariser": ("cassie", True, [("LeftFootFront", "universe", 2, 0, None), ("pelvis", "universe", 2, 0, None),
+                                             ("@posture", 16, 6, 1, ([0.1 + 0.05 * k for k in range(16)],
+                                                                     [0.0 if k in (3, 9) else 1.0 for k in range(16)]))], 1, None),
+    "posture_only_arm": ("ur5", False, [("@posture", 4, 6, 0, ([1.0] * 4, [1.0] * 4)), ("tool0", "universe", 0, 0, None)], 0, None),
 }
 
 
@@ -280,7 +299,7 @@ def test_generic_program_matches_oracle(emu, case):
     name, ff, specs, root, edit = GENERIC_CASES[case]
     B = 24
     urdf, model, om, tasks, ot, q0, tg, M = _generic_case(name, ff, specs, B, xml_edit=edit)
-    nt = len(specs)
+    nt = len(tasks)
     tk = tasks if nt > 1 else tasks[0]
     _, _, _, e, J, _ = run(emu, urdf, tk, 1, q0, tg, None, model.nv, M, root=root | 2 if "forced" in case else root, ntasks=nt)
     for b in range(B):
