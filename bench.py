@@ -8,7 +8,7 @@ B per GPU is fixed.  Default workload = the one the metric is quoted on: Cassie 
 B = 65536, 50 iterations.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--iters I]
-                    [--workload cassie_leg|cassie_full_body|ur5] [--no-cpu]
+                    [--workload cassie_leg|cassie_full_body|ur5|cassie_demo|cassie_demo_pik] [--no-cpu]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line.
@@ -48,6 +48,14 @@ WORKLOADS = {
                                ("align", "LeftFootFront", 1, "universe")],
                         text="Cassie demo task set (cassie.urdf + free-flyer): LeftFootFront position w.r.t. the pelvis, pelvis "
                              "SE(3) pose, LeftFootFront Y-axis alignment (M=10), generic kernel"),
+    # the same tasks through the reference's other solver, ik::pik (reference ik/ik/pik.cpp:31-103): the alignment row at
+    # priority 1, solved in the null space of the two pose tasks; damping factor 0.1 per level
+    "cassie_demo_pik": dict(urdf="cassie", free_flyer=True, frames=["LeftFootFront", "pelvis", "LeftFootFront"], nq=23,
+                            tasks=[("frame", "LeftFootFront", 0, "pelvis"), ("frame", "pelvis", 2, "universe"),
+                                   ("align", "LeftFootFront", 1, "universe")],
+                            prios=[0, 0, 1], solver="pik", lam=[0.1, 0.1],
+                            text="Cassie demo task set as two priority levels (foot position w.r.t. the pelvis + pelvis SE(3) pose; "
+                                 "then foot Y-axis alignment), ik::pik with lambda 0.1 per level, generic kernel"),
 }
 
 
@@ -66,7 +74,7 @@ def load_kernel_stats():
 def make_inputs(name, model, idx):
     w = WORKLOADS[name]
     lo, hi = model.lowerPositionLimit, model.upperPositionLimit
-    if name in ("cassie_full_body", "cassie_demo"):
+    if name in ("cassie_full_body", "cassie_demo", "cassie_demo_pik"):
         return workload.freeflyer_workload(lo, hi, workload.cassie_nominal(model.names), idx, seed=0, mode="near")
     if name == "ur5":
         return workload.chain_workload(lo, hi, workload.UR5_NOMINAL, idx, seed=0, mode="near")
@@ -85,17 +93,23 @@ def cpu_baseline(model, w, q0_np, tg_np, iters, budget_s=12.0):
     om = O.OracleModel(model.flat())
     specs = task_specs(w)
     fids = [model.getFrameId(f) for _, f, _, _ in specs]
-    tasks = O.make_tasks([(model.getFrameId(f), model.getFrameId(r), (3 + t) if kind == "align" else t, 0, None)
-                          for kind, f, t, r in specs])
-    prm = O.params(iters, 1e-2, 1.0, -1.0)
+    prios = w.get("prios") or [0] * len(specs)
+    tasks = O.make_tasks([(model.getFrameId(f), model.getFrameId(r), (3 + t) if kind == "align" else t, p, None)
+                          for (kind, f, t, r), p in zip(specs, prios)])
+    if w.get("solver") == "pik":
+        prm = O.pik_params(iters, 1.0, -1.0, w["lam"])
+        solve = O.pik_batch
+    else:
+        prm = O.params(iters, 1e-2, 1.0, -1.0)
+        solve = O.dls_batch
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     probe = min(256, q0_np.shape[0])
     t = time.perf_counter()
-    O.dls_batch(om, tasks, tg_np[:probe], q0_np[:probe], prm, 1)
+    solve(om, tasks, tg_np[:probe], q0_np[:probe], prm, 1)
     r1 = probe / (time.perf_counter() - t)
     sample = int(min(q0_np.shape[0], max(probe, r1 * cores * budget_s)))
     t = time.perf_counter()
-    q_ref, ok_ref, it_ref = O.dls_batch(om, tasks, tg_np[:sample], q0_np[:sample], prm, cores)
+    q_ref, ok_ref, it_ref = solve(om, tasks, tg_np[:sample], q0_np[:sample], prm, cores)
     dt = time.perf_counter() - t
     # which of the sampled problems converged on the CPU (SURVEY.md 8d parity bar): the stacked error vanishes
     if w.get("tasks"):
@@ -143,13 +157,19 @@ def main():
     B = args.batch
     w = WORKLOADS[args.workload]
     model = ik_amd.Model.from_urdf_file(os.path.join(workload.MODELS_DIR, w["urdf"] + ".kin.urdf"), free_flyer=w["free_flyer"])
-    problem = ik_amd.InverseKinematicsProblem(model)
-    for i, (kind, f, t, r) in enumerate(task_specs(w)):
+    prios = w.get("prios") or [0] * len(task_specs(w))
+    problem = ik_amd.InverseKinematicsProblem(model, max(prios))
+    for i, ((kind, f, t, r), prio) in enumerate(zip(task_specs(w), prios)):
         if kind == "align":
-            problem.add_align_axis_task("t%d" % i, ik_amd.AlignAxisTask.create(model, f, ik_amd.AlignAxisType(t), r))
+            problem.add_align_axis_task("t%d" % i, ik_amd.AlignAxisTask.create(model, f, ik_amd.AlignAxisType(t), r), prio)
         else:
-            problem.add_frame_task("t%d" % i, ik_amd.FrameTask.create(model, f, ik_amd.KinematicType(t), r))
-    data = ik_amd.dls_data(problem, device=local_rank)
+            problem.add_frame_task("t%d" % i, ik_amd.FrameTask.create(model, f, ik_amd.KinematicType(t), r), prio)
+    use_pik = w.get("solver") == "pik"
+    if use_pik:
+        data = ik_amd.pik_data(problem, device=local_rank)
+        data.lambda_ = list(w["lam"])
+    else:
+        data = ik_amd.dls_data(problem, device=local_rank)
 
     # this rank's shard of the global synthetic batch (weak scaling: B problems per GPU)
     lo, hi = ikdist.shard_range(B * world, rank, world)
@@ -170,7 +190,12 @@ def main():
     bufs = [ikdist.ShardBuffers(model.nq, B, world, dev) for _ in range(2)]
     out = bufs[0].out()
     visitor = ik_amd.never_stop_visitor()
-    prm = ik_amd.dls_parameters(max_iterations=args.iters, damping=1e-2, step_length=1.0)
+    if use_pik:
+        prm = ik_amd.pik_parameters(max_iterations=args.iters, step_length=1.0)
+        solve_batch = ik_amd.pik_batch
+    else:
+        prm = ik_amd.dls_parameters(max_iterations=args.iters, damping=1e-2, step_length=1.0)
+        solve_batch = ik_amd.dls_batch
 
     state = {"k": 0}
 
@@ -179,7 +204,7 @@ def main():
         state["k"] += 1
         if distributed:
             buf.wait()  # the gather issued two steps ago must have drained this buffer set
-        ik_amd.dls_batch(problem, Q0, targets, data, visitor, prm, out=buf.out())
+        solve_batch(problem, Q0, targets, data, visitor, prm, out=buf.out())
         if distributed:
             buf.all_gather(async_op=True)
 
@@ -216,7 +241,7 @@ def main():
         elapsed = float(t.item())
     if distributed:
         ev0.record()
-        ik_amd.dls_batch(problem, Q0, targets, data, visitor, prm, out=bufs[0].out())
+        solve_batch(problem, Q0, targets, data, visitor, prm, out=bufs[0].out())
         ev1.record()
         torch.cuda.synchronize()
         kernel_ms = float(ev0.elapsed_time(ev1))
@@ -234,11 +259,12 @@ def main():
         if stats.get("hbm_traffic_bytes_per_launch") and stats.get("pmc", {}).get("batch"):
             traffic = stats["hbm_traffic_bytes_per_launch"] * B / stats["pmc"]["batch"]
         res = {
-            "metric": "IK solves/sec (50-iter DLS) at batch=65536",
+            "metric": "IK solves/sec (50-iter %s) at batch=65536" % ("PIK" if use_pik else "DLS"),
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s, %d fixed DLS iterations, damping 1e-2, step 1.0, reachable targets FK(q*)"
+            "config": {"workload": ("%s, %d fixed PIK iterations, step 1.0, reachable targets FK(q*)" if use_pik else
+                                    "%s, %d fixed DLS iterations, damping 1e-2, step 1.0, reachable targets FK(q*)")
                                    % (w["text"], args.iters),
                        "name": args.workload, "batch_per_gpu": B, "global_batch": B * world, "iterations": args.iters,
                        "kernel": data.kernel,

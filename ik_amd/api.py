@@ -459,6 +459,119 @@ def _check_shapes(qs, ts, nq, ntasks, B, lay):
         raise ValueError("targets has shape %s, expected %s" % (tuple(ts), want_t))
 
 
+class pik_parameters:
+    """ik::pik_parameters (reference ik/ik/pik.hpp:11-16).  `damping` and `max_time` are carried for source
+    compatibility: the reference loop reads neither (the damping factors live in pik_data.lambda_)."""
+
+    def __init__(self, max_iterations=100, damping=1e-2, step_length=1.0, max_time=1.0):
+        self.max_iterations = max_iterations
+        self.damping = damping
+        self.step_length = step_length
+        self.max_time = max_time
+
+
+class pik_data(dls_data):
+    """ik::pik_data (reference ik/ik/pik.hpp:21-50): the workspace of ik::pik.  `lambda_` holds the damping factor of
+    each priority level (`lambda` in the reference, 1.0 each) and `da` the secondary step projected into the null
+    space of all levels (zero); both are read at every call."""
+
+    def __init__(self, problem, device=0):
+        super().__init__(problem, device)
+        self.lambda_ = [1.0] * (problem.max_priority_level() + 1)
+        self.da = np.zeros(problem.model().nv)
+
+    def _bind(self, problem):
+        before = self._generation
+        super()._bind(problem)
+        if self._generation != before:
+            self.kernel = "pik_generic<" + plan_generic(problem).split("<", 1)[1]
+
+    def _params(self, visitor, p):
+        prm = capi.PikParams()
+        prm.max_iterations, prm.step_length, prm.stop_sq_tol = int(p.max_iterations), float(p.step_length), float(visitor.tolerance)
+        prm.num_levels = len(self.lambda_)
+        if prm.num_levels > capi.MAX_PIK_LEVELS:
+            raise ValueError("ik::pik on the device takes at most %d priority levels" % capi.MAX_PIK_LEVELS)
+        for i, l in enumerate(self.lambda_):
+            prm.lam[i] = float(l)
+        da = np.ascontiguousarray(self.da, dtype=np.float64)
+        if da.any():
+            prm._da_keepalive = da
+            prm.da = da.ctypes.data_as(C.POINTER(C.c_double))
+        return prm
+
+
+def plan_generic(problem):
+    """Name of the generic kernel instance of the problem (what ik::pik runs on)."""
+    name = plan(problem)
+    if name.startswith("dls_generic<"):
+        return name
+    rows = sum(t.dimension() for t, _ in problem.ordered_tasks())
+    m = problem.model()
+    return "dls_generic<M=%d,nv=%d,joints=%d>" % (rows, m.nv, m.njoints - 1)
+
+
+def pik(problem, q0, data, visitor=None, p=None):
+    """ik::pik (reference ik/ik/pik.hpp:56-59, ik/ik/pik.cpp:31-103): one problem, targets from each task's `target`;
+    returns q and sets data.success as the reference does.  A batch of one on the device."""
+    visitor = visitor or inverse_kinematics_visitor()
+    p = p or pik_parameters()
+    data._bind(problem)
+    model = problem.model()
+    q0 = np.ascontiguousarray(q0, dtype=np.float64).reshape(model.nq)
+    tg = np.ascontiguousarray(np.concatenate([_target_slots(t) for t, _ in problem.ordered_tasks()]))
+    q = np.empty(model.nq)
+    ok = np.zeros(1, np.uint8)
+    it = np.zeros(1, np.int32)
+    prm = data._params(visitor, p)
+    capi.check(capi.lib().ikgpu_pik_solve_batch_host(
+        data._h, 1, q0.ctypes.data, tg.ctypes.data, C.byref(prm), q.ctypes.data, ok.ctypes.data, it.ctypes.data, capi.AOS))
+    data.success, data.iterations, data.q = bool(ok[0]), int(it[0]), q
+    return q
+
+
+def pik_batch(problem, Q0, targets, data, visitor=None, p=None, layout="soa", out=None, stream=None):
+    """B independent ik::pik() calls in lockstep on the device; arguments and return value as dls_batch."""
+    visitor = visitor or inverse_kinematics_visitor()
+    p = p or pik_parameters()
+    data._bind(problem)
+    model = problem.model()
+    ntasks = problem.target_slots()
+    lay = {"soa": capi.SOA, "aos": capi.AOS}[layout]
+    prm = data._params(visitor, p)
+    L = capi.lib()
+    if isinstance(Q0, np.ndarray):
+        Q0 = np.ascontiguousarray(Q0, dtype=np.float64)
+        targets = np.ascontiguousarray(targets, dtype=np.float64)
+        B = Q0.shape[1] if lay == capi.SOA else Q0.shape[0]
+        _check_shapes(Q0.shape, targets.shape, model.nq, ntasks, B, lay)
+        Q = np.empty_like(Q0)
+        ok = np.zeros(B, np.uint8)
+        it = np.zeros(B, np.int32)
+        capi.check(L.ikgpu_pik_solve_batch_host(data._h, B, Q0.ctypes.data, targets.ctypes.data, C.byref(prm),
+                                                Q.ctypes.data, ok.ctypes.data, it.ctypes.data, lay))
+        return Q, ok, it
+    import torch
+    if not (Q0.is_cuda and targets.is_cuda and Q0.dtype == torch.float64 and targets.dtype == torch.float64):
+        raise TypeError("pik_batch needs float64 CUDA tensors (or numpy arrays)")
+    if not (Q0.is_contiguous() and targets.is_contiguous()):
+        raise ValueError("pik_batch needs contiguous tensors")
+    if Q0.device.index != data._device:
+        raise ValueError("tensors live on cuda:%s but the problem was created on device %d" % (Q0.device.index, data._device))
+    B = Q0.shape[1] if lay == capi.SOA else Q0.shape[0]
+    _check_shapes(tuple(Q0.shape), tuple(targets.shape), model.nq, ntasks, B, lay)
+    if out is None:
+        Q = torch.empty_like(Q0)
+        ok = torch.empty(B, dtype=torch.uint8, device=Q0.device)
+        it = torch.empty(B, dtype=torch.int32, device=Q0.device)
+    else:
+        Q, ok, it = out
+    s = torch.cuda.current_stream(Q0.device).cuda_stream if stream is None else stream
+    capi.check(L.ikgpu_pik_solve_batch(data._h, B, Q0.data_ptr(), targets.data_ptr(), C.byref(prm), Q.data_ptr(),
+                                       ok.data_ptr(), it.data_ptr(), lay, C.c_void_p(s)))
+    return Q, ok, it
+
+
 def evaluate_batch(problem, Q, targets, data, layout="soa", jacobian=True):
     """evaluate_problem_data + stacking (reference ik/ik/data.cpp:25-58, ik/ik/dls.cpp:18-24) for a
     batch, on the device: returns (e [M, B], J [M, nv, B]) for "soa" ([B, M], [B, M, nv] for "aos")."""

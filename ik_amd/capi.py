@@ -24,7 +24,9 @@ SYMBOLS = [
     "ikgpu_problem_create", "ikgpu_problem_destroy", "ikgpu_problem_rows", "ikgpu_problem_kernel",
     "ikgpu_problem_plan",
     "ikgpu_dls_solve_batch", "ikgpu_dls_solve_batch_host", "ikgpu_evaluate_batch", "ikgpu_task_frames_fk_batch",
+    "ikgpu_pik_params_default", "ikgpu_pik_solve_batch", "ikgpu_pik_solve_batch_host",
 ]
+MAX_PIK_LEVELS, MAX_PIK_DA = 8, 128
 
 
 class FlatModel(C.Structure):
@@ -45,6 +47,11 @@ class Task(C.Structure):
 class DlsParams(C.Structure):
     _fields_ = [("max_iterations", C.c_int32), ("damping", C.c_double), ("step_length", C.c_double),
                 ("stop_sq_tol", C.c_double)]
+
+
+class PikParams(C.Structure):
+    _fields_ = [("max_iterations", C.c_int32), ("step_length", C.c_double), ("stop_sq_tol", C.c_double),
+                ("num_levels", C.c_int32), ("lam", C.c_double * MAX_PIK_LEVELS), ("da", C.POINTER(C.c_double))]
 
 
 class IkgpuError(RuntimeError):
@@ -95,11 +102,15 @@ def lib():
     L.ikgpu_problem_plan.argtypes = [vp, C.POINTER(Task), i32, C.c_char_p, sz]
     L.ikgpu_dls_solve_batch.argtypes = [vp, i64, vp, vp, C.POINTER(DlsParams), vp, vp, vp, C.c_int, vp]
     L.ikgpu_dls_solve_batch_host.argtypes = [vp, i64, vp, vp, C.POINTER(DlsParams), vp, vp, vp, C.c_int]
+    L.ikgpu_pik_params_default.argtypes = [C.POINTER(PikParams), i32]
+    L.ikgpu_pik_params_default.restype = None
+    L.ikgpu_pik_solve_batch.argtypes = [vp, i64, vp, vp, C.POINTER(PikParams), vp, vp, vp, C.c_int, vp]
+    L.ikgpu_pik_solve_batch_host.argtypes = [vp, i64, vp, vp, C.POINTER(PikParams), vp, vp, vp, C.c_int]
     L.ikgpu_evaluate_batch.argtypes = [vp, i64, vp, vp, vp, vp, C.c_int, vp]
     L.ikgpu_task_frames_fk_batch.argtypes = [vp, i64, vp, vp, C.c_int, vp]
     for name in ("ikgpu_model_from_urdf", "ikgpu_model_create", "ikgpu_model_get_flat", "ikgpu_problem_create",
                  "ikgpu_problem_plan", "ikgpu_dls_solve_batch", "ikgpu_dls_solve_batch_host", "ikgpu_evaluate_batch",
-                 "ikgpu_task_frames_fk_batch"):
+                 "ikgpu_task_frames_fk_batch", "ikgpu_pik_solve_batch", "ikgpu_pik_solve_batch_host"):
         getattr(L, name).restype = C.c_int
     if L.ikgpu_abi_version() != 1:
         raise ImportError("libikgpu.so ABI version mismatch")

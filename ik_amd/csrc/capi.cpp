@@ -15,6 +15,7 @@
 
 struct ikgpu_problem {
     ikgpu::ProblemHost host;
+    ikgpu::ProblemHost gen;  // the same problem analysed for the generic lane program (what ik::pik runs on)
     ikgpu::DeviceTables dev;
     int device = 0;
     int nframes = 0;
@@ -78,6 +79,61 @@ int check_params(const ikgpu_dls_params *p) {
     if (!(p->damping > 0.0))
         return fail(IKGPU_ERR_INVALID, "damping must be > 0: the device solves JJ^T + damping^2 I by Cholesky (SPD)");
     return IKGPU_OK;
+}
+
+int check_pik_params(const ikgpu_problem *p, const ikgpu_pik_params *prm) {
+    if (!prm) return fail(IKGPU_ERR_INVALID, "params is null");
+    if (!p) return fail(IKGPU_ERR_INVALID, "null problem");
+    if (prm->max_iterations < 0) return fail(IKGPU_ERR_INVALID, "max_iterations must be >= 0");
+    const int levels = p->gen.generic.nlevels;
+    if (levels > IKGPU_MAX_PIK_LEVELS)
+        return fail(IKGPU_ERR_UNSUPPORTED, "the problem has " + std::to_string(levels) + " priority levels, ik::pik on the device takes at most " +
+                                               std::to_string(IKGPU_MAX_PIK_LEVELS));
+    if (prm->num_levels != levels)
+        return fail(IKGPU_ERR_INVALID, "num_levels is " + std::to_string(prm->num_levels) + " but the problem has " + std::to_string(levels) +
+                                           " priority levels");
+    for (int l = 0; l < levels; ++l)
+        if (!(prm->lambda[l] >= 0.0)) return fail(IKGPU_ERR_INVALID, "lambda[" + std::to_string(l) + "] must be >= 0");
+    if (prm->da && p->gen.nv > IKGPU_MAX_PIK_DA)
+        return fail(IKGPU_ERR_UNSUPPORTED, "da is carried by value for nv <= " + std::to_string(IKGPU_MAX_PIK_DA));
+    return IKGPU_OK;
+}
+
+// Host-pointer form of a batched solve: copy in, run `launch` on device buffers, synchronise, copy out.
+template <class Launch>
+int host_solve(const ikgpu_problem *p, int64_t B, const double *q0, const double *targets, double *q_out, uint8_t *success,
+               int32_t *iters, Launch &&launch) {
+    return guarded([&] {
+        DeviceGuard g(p->device);
+        if (!g.ok) return fail(IKGPU_ERR_DEVICE, "hipSetDevice failed");
+        const size_t nb_q = sizeof(double) * p->host.nq * B, nb_t = sizeof(double) * 12 * p->host.ntasks * B;
+        double *d_q0 = nullptr, *d_t = nullptr, *d_q = nullptr;
+        uint8_t *d_s = nullptr;
+        int32_t *d_i = nullptr;
+        hipError_t e = hipSuccess;
+        auto step = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+        step(hipMalloc(reinterpret_cast<void **>(&d_q0), nb_q));
+        step(hipMalloc(reinterpret_cast<void **>(&d_t), nb_t));
+        step(hipMalloc(reinterpret_cast<void **>(&d_q), nb_q));
+        step(hipMalloc(reinterpret_cast<void **>(&d_s), B));
+        step(hipMalloc(reinterpret_cast<void **>(&d_i), sizeof(int32_t) * B));
+        if (e == hipSuccess) step(hipMemcpy(d_q0, q0, nb_q, hipMemcpyHostToDevice));
+        if (e == hipSuccess) step(hipMemcpy(d_t, targets, nb_t, hipMemcpyHostToDevice));
+        int rc = IKGPU_OK;
+        if (e == hipSuccess) {
+            rc = launch(d_q0, d_t, d_q, d_s, d_i);
+            if (rc == IKGPU_OK) {
+                step(hipDeviceSynchronize());
+                step(hipMemcpy(q_out, d_q, nb_q, hipMemcpyDeviceToHost));
+                if (success) step(hipMemcpy(success, d_s, B, hipMemcpyDeviceToHost));
+                if (iters) step(hipMemcpy(iters, d_i, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
+            }
+        }
+        (void)hipFree(d_q0); (void)hipFree(d_t); (void)hipFree(d_q); (void)hipFree(d_s); (void)hipFree(d_i);
+        if (rc != IKGPU_OK) return rc;
+        if (e != hipSuccess) return hip_fail(e, "host-pointer solve");
+        return static_cast<int>(IKGPU_OK);
+    });
 }
 
 }  // namespace
@@ -162,9 +218,10 @@ int ikgpu_problem_create(const ikgpu_model *h, const ikgpu_task *tasks, int32_t 
                          ikgpu_problem **out) {
     if (!h || !tasks || !out) return fail(IKGPU_ERR_INVALID, "null argument");
     *out = nullptr;
-    ikgpu::ProblemHost ph;
+    ikgpu::ProblemHost ph, gen;
     try {
         ph = analyse(h->m, tasks, ntasks);
+        gen = ph.kind == ikgpu::KernelKind::Generic ? ph : ikgpu::analyse_problem(h->m, tasks, ntasks, /*force_generic=*/true);
     } catch (const std::exception &e) {
         return fail(IKGPU_ERR_INVALID, e.what());
     }
@@ -183,6 +240,7 @@ int ikgpu_problem_create(const ikgpu_model *h, const ikgpu_task *tasks, int32_t 
         if (!g.ok) return fail(IKGPU_ERR_DEVICE, "hipSetDevice failed");
         auto *p = new ikgpu_problem;
         p->host = std::move(ph);
+        p->gen = std::move(gen);
         p->device = device;
         p->nframes = h->m.nframes();
         const size_t nq = static_cast<size_t>(p->host.nq);
@@ -195,10 +253,9 @@ int ikgpu_problem_create(const ikgpu_model *h, const ikgpu_task *tasks, int32_t 
         up(&p->dev.lower, p->host.lower.data(), nq * sizeof(double));
         up(&p->dev.upper, p->host.upper.data(), nq * sizeof(double));
         up(&p->dev.q_in_chain, p->host.q_in_chain.data(), nq);
-        if (p->host.kind == ikgpu::KernelKind::Generic) {
-            up(&p->dev.g_ints, p->host.generic.ints.data(), p->host.generic.ints.size() * sizeof(int32_t));
-            up(&p->dev.g_dbls, p->host.generic.dbls.data(), p->host.generic.dbls.size() * sizeof(double));
-        } else {
+        up(&p->dev.g_ints, p->gen.generic.ints.data(), p->gen.generic.ints.size() * sizeof(int32_t));
+        up(&p->dev.g_dbls, p->gen.generic.dbls.data(), p->gen.generic.dbls.size() * sizeof(double));
+        if (p->host.kind != ikgpu::KernelKind::Generic) {
             const std::vector<double> desc = p->host.kind == ikgpu::KernelKind::Chain ? ikgpu::chain_desc_table(p->host)
                                                                                      : ikgpu::tree_desc_table(p->host);
             up(&p->dev.chain_desc, desc.data(), desc.size() * sizeof(double));
@@ -268,40 +325,56 @@ int ikgpu_dls_solve_batch(const ikgpu_problem *p, int64_t B, const double *q0, c
 int ikgpu_dls_solve_batch_host(const ikgpu_problem *p, int64_t B, const double *q0, const double *targets,
                                const ikgpu_dls_params *params, double *q_out, uint8_t *success, int32_t *iters,
                                int layout) {
-    if (!p || !q0 || !targets || !q_out) return fail(IKGPU_ERR_INVALID, "null argument");
+    if (!p) return fail(IKGPU_ERR_INVALID, "null problem");
     if (B < 0) return fail(IKGPU_ERR_INVALID, "negative batch size");
     if (int rc = check_params(params)) return rc;
+    if (B == 0) return IKGPU_OK;  // an empty batch is a no-op (its pointers may be null)
+    if (!q0 || !targets || !q_out) return fail(IKGPU_ERR_INVALID, "null argument");
+    return host_solve(p, B, q0, targets, q_out, success, iters, [&](const double *d_q0, const double *d_t, double *d_q, uint8_t *d_s, int32_t *d_i) {
+        return ikgpu_dls_solve_batch(p, B, d_q0, d_t, params, d_q, d_s, d_i, layout, nullptr);
+    });
+}
+
+void ikgpu_pik_params_default(ikgpu_pik_params *p, int32_t num_levels) {
+    if (!p) return;
+    p->max_iterations = 100;  // reference ik/ik/pik.hpp:12
+    p->step_length = 1.0;     // reference ik/ik/pik.hpp:14
+    p->stop_sq_tol = 1e-4;    // reference ik/ik/visitor.hpp:19
+    p->num_levels = num_levels;
+    for (double &l : p->lambda) l = 1.0;  // reference ik/ik/pik.hpp:24
+    p->da = nullptr;                      // reference ik/ik/pik.hpp:26
+}
+
+int ikgpu_pik_solve_batch(const ikgpu_problem *p, int64_t B, const double *q0, const double *targets,
+                          const ikgpu_pik_params *params, double *q_out, uint8_t *success, int32_t *iters, int layout,
+                          void *stream) {
+    if (!p) return fail(IKGPU_ERR_INVALID, "null problem");
+    if (B < 0) return fail(IKGPU_ERR_INVALID, "negative batch size");
+    if (layout != IKGPU_SOA && layout != IKGPU_AOS) return fail(IKGPU_ERR_INVALID, "unknown layout");
+    if (int rc = check_pik_params(p, params)) return rc;
     if (B == 0) return IKGPU_OK;
+    if (!q0 || !targets || !q_out) return fail(IKGPU_ERR_INVALID, "null argument");
+    if (B > (int64_t(1) << 31) * 32) return fail(IKGPU_ERR_INVALID, "batch too large for one launch");
     return guarded([&] {
         DeviceGuard g(p->device);
         if (!g.ok) return fail(IKGPU_ERR_DEVICE, "hipSetDevice failed");
-        const size_t nb_q = sizeof(double) * p->host.nq * B, nb_t = sizeof(double) * 12 * p->host.ntasks * B;
-        double *d_q0 = nullptr, *d_t = nullptr, *d_q = nullptr;
-        uint8_t *d_s = nullptr;
-        int32_t *d_i = nullptr;
-        hipError_t e = hipSuccess;
-        auto step = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-        step(hipMalloc(reinterpret_cast<void **>(&d_q0), nb_q));
-        step(hipMalloc(reinterpret_cast<void **>(&d_t), nb_t));
-        step(hipMalloc(reinterpret_cast<void **>(&d_q), nb_q));
-        step(hipMalloc(reinterpret_cast<void **>(&d_s), B));
-        step(hipMalloc(reinterpret_cast<void **>(&d_i), sizeof(int32_t) * B));
-        if (e == hipSuccess) step(hipMemcpy(d_q0, q0, nb_q, hipMemcpyHostToDevice));
-        if (e == hipSuccess) step(hipMemcpy(d_t, targets, nb_t, hipMemcpyHostToDevice));
-        int rc = IKGPU_OK;
-        if (e == hipSuccess) {
-            rc = ikgpu_dls_solve_batch(p, B, d_q0, d_t, params, d_q, d_s, d_i, layout, nullptr);
-            if (rc == IKGPU_OK) {
-                step(hipDeviceSynchronize());
-                step(hipMemcpy(q_out, d_q, nb_q, hipMemcpyDeviceToHost));
-                if (success) step(hipMemcpy(success, d_s, B, hipMemcpyDeviceToHost));
-                if (iters) step(hipMemcpy(iters, d_i, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
-            }
-        }
-        (void)hipFree(d_q0); (void)hipFree(d_t); (void)hipFree(d_q); (void)hipFree(d_s); (void)hipFree(d_i);
-        if (rc != IKGPU_OK) return rc;
-        if (e != hipSuccess) return hip_fail(e, "host-pointer solve");
+        ikgpu::BatchIO io{B, q0, targets, q_out, success, iters, layout};
+        const hipError_t e = ikgpu::launch_pik_generic(p->gen, p->dev, io, *params, static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return hip_fail(e, "launching the PIK kernel");
         return static_cast<int>(IKGPU_OK);
+    });
+}
+
+int ikgpu_pik_solve_batch_host(const ikgpu_problem *p, int64_t B, const double *q0, const double *targets,
+                               const ikgpu_pik_params *params, double *q_out, uint8_t *success, int32_t *iters,
+                               int layout) {
+    if (!p) return fail(IKGPU_ERR_INVALID, "null problem");
+    if (B < 0) return fail(IKGPU_ERR_INVALID, "negative batch size");
+    if (int rc = check_pik_params(p, params)) return rc;
+    if (B == 0) return IKGPU_OK;
+    if (!q0 || !targets || !q_out) return fail(IKGPU_ERR_INVALID, "null argument");
+    return host_solve(p, B, q0, targets, q_out, success, iters, [&](const double *d_q0, const double *d_t, double *d_q, uint8_t *d_s, int32_t *d_i) {
+        return ikgpu_pik_solve_batch(p, B, d_q0, d_t, params, d_q, d_s, d_i, layout, nullptr);
     });
 }
 

@@ -33,6 +33,10 @@ struct GenericTables {
     const double *t_w;                          // [ntasks][6]
     // workspace layout, in doubles per lane
     int off_q, off_oMi, off_Jw, off_e, off_J, off_G, off_y, off_dq, ws_words;
+    // prioritised IK (pik_solver.hpp): rows of level l are [lvl_row0[l], lvl_row0[l + 1]); its workspace extends the one above
+    int nlevels;
+    const int *lvl_row0;                        // [nlevels + 1]
+    int off_P, off_Jb, off_de, ws_words_pik;
 };
 
 struct Ws {  // word w of this lane
@@ -205,6 +209,29 @@ IKD_FN double generic_evaluate(const GenericTables &T, const Ws &ws, const doubl
     return e0sq;
 }
 
+// q <- clip(integrate(q, step * dq)) on the workspace (pinocchio::integrate + apply_joint_clipping,
+// ik/ik/common.hpp:53-56); a lane that is no longer active keeps its q.
+IKD_FN void generic_integrate_clip(const GenericTables &T, const Ws &ws, double step_length, bool active) {
+    for (int j = 1; j < T.njoints; ++j) {
+        const int iq = T.idx_q[j], iv = T.idx_v[j];
+        if (T.jtype[j] == GJ_FREEFLYER) {
+            double qb[7], v[6], qn[7], R1[9];
+            for (int k = 0; k < 7; ++k) qb[k] = ws[T.off_q + iq + k];
+            for (int k = 0; k < 6; ++k) v[k] = step_length * ws[T.off_dq + iv + k];
+            quat_to_R(qb, R1);
+            freeflyer_integrate(qb, R1, v, qn);
+            for (int k = 0; k < 7; ++k) {
+                const double c = dmin(T.upper[iq + k], dmax(qn[k], T.lower[iq + k]));
+                ws[T.off_q + iq + k] = active ? c : qb[k];
+            }
+        } else {
+            const double qo = ws[T.off_q + iq];
+            const double c = dmin(T.upper[iq], dmax(dfma(step_length, ws[T.off_dq + iv], qo), T.lower[iq]));
+            ws[T.off_q + iq] = active ? c : qo;
+        }
+    }
+}
+
 // One full solve on the workspace (q already stored at off_q).
 template <class AnyFn>
 IKD_FN void generic_dls(const GenericTables &T, const LoopParams &prm, const Ws &ws, const double *targets_lane,
@@ -251,25 +278,7 @@ IKD_FN void generic_dls(const GenericTables &T, const LoopParams &prm, const Ws 
         const bool stop_now = active && (prm.stop_sq_tol >= 0.0) && (e0sq < prm.stop_sq_tol);
         if (stop_now) { success = true; iters = it; }
         active = active && !stop_now;
-        // integrate + clip (ik/ik/dls.cpp:67-71)
-        for (int j = 1; j < T.njoints; ++j) {
-            const int iq = T.idx_q[j], iv = T.idx_v[j];
-            if (T.jtype[j] == GJ_FREEFLYER) {
-                double qb[7], v[6], qn[7], R1[9];
-                for (int k = 0; k < 7; ++k) qb[k] = ws[T.off_q + iq + k];
-                for (int k = 0; k < 6; ++k) v[k] = prm.step_length * ws[T.off_dq + iv + k];
-                quat_to_R(qb, R1);
-                freeflyer_integrate(qb, R1, v, qn);
-                for (int k = 0; k < 7; ++k) {
-                    const double c = dmin(T.upper[iq + k], dmax(qn[k], T.lower[iq + k]));
-                    ws[T.off_q + iq + k] = active ? c : qb[k];
-                }
-            } else {
-                const double qo = ws[T.off_q + iq];
-                const double c = dmin(T.upper[iq], dmax(dfma(prm.step_length, ws[T.off_dq + iv], qo), T.lower[iq]));
-                ws[T.off_q + iq] = active ? c : qo;
-            }
-        }
+        generic_integrate_clip(T, ws, prm.step_length, active);  // ik/ik/dls.cpp:67-71
         if (!any_active(active)) break;
     }
     iters_out = iters;

@@ -558,4 +558,76 @@ inline void dls_batch_device(InverseKinematicsProblem &problem, std::int64_t B, 
         throw std::runtime_error(ikgpu_last_error());
 }
 
+// ---- ik::pik, the prioritised solver (ik/ik/pik.hpp:11-59; ik/ik/pik.cpp:31-103) ---------------------
+struct pik_parameters {  // ik/ik/pik.hpp:11-16; the reference loop reads neither damping nor max_time
+    int max_iterations = 100;
+    double damping = 1e-2;
+    double step_length = 1.0;
+    double max_time = 1.0;
+};
+
+class pik_data : public dls_data {  // ik/ik/pik.hpp:21-50
+   public:
+    explicit pik_data(const InverseKinematicsProblem &problem, int device = 0)
+        : dls_data(problem, device), da(vector_t::Zero(problem.model().nv)) {
+        lambda.assign(problem.max_priority_level() + 1, 1.0);  // pik.hpp:24
+    }
+    vector_t da;                  // secondary step, projected into the null space of every level (pik.cpp:65)
+    std::vector<double> lambda;   // damping factor of each priority level (pik.cpp:54-55)
+};
+
+namespace detail {
+inline ikgpu_pik_params to_abi(const inverse_kinematics_visitor &visitor, const pik_parameters &p, const pik_data &data) {
+    ikgpu_pik_params a;
+    ikgpu_pik_params_default(&a, static_cast<int32_t>(data.lambda.size()));
+    if (data.lambda.size() > IKGPU_MAX_PIK_LEVELS) throw std::invalid_argument("ik::pik on the device takes at most 8 priority levels");
+    a.max_iterations = static_cast<int32_t>(p.max_iterations);
+    a.step_length = p.step_length;
+    a.stop_sq_tol = visitor.stop_tolerance();
+    for (std::size_t l = 0; l < data.lambda.size(); ++l) a.lambda[l] = data.lambda[l];
+    a.da = data.da.squaredNorm() > 0.0 ? data.da.data() : nullptr;
+    return a;
+}
+}  // namespace detail
+
+inline vector_t pik(InverseKinematicsProblem &problem, const vector_t &q0, pik_data &data,
+                    const inverse_kinematics_visitor &visitor = inverse_kinematics_visitor(),
+                    const pik_parameters &p = pik_parameters()) {
+    data.bind(problem);
+    if (q0.size() != static_cast<index_t>(problem.model().nq)) throw std::invalid_argument("q0 has the wrong size");
+    const std::vector<number_t> targets = detail::gather_targets(problem);
+    const ikgpu_pik_params prm = detail::to_abi(visitor, p, data);
+    vector_t q(q0.size());
+    uint8_t ok = 0;
+    int32_t it = 0;
+    if (ikgpu_pik_solve_batch_host(data.handle(), 1, q0.data(), targets.data(), &prm, q.data(), &ok, &it, IKGPU_AOS) != IKGPU_OK)
+        throw std::runtime_error(ikgpu_last_error());
+    data.success = ok != 0;
+    data.iterations = static_cast<index_t>(it);
+    data.q = q;
+    return q;
+}
+
+// B problems in lockstep, HOST buffers laid out as for dls_batch.
+inline void pik_batch(InverseKinematicsProblem &problem, std::int64_t B, const number_t *Q0, const number_t *targets,
+                      pik_data &data, number_t *Q, std::uint8_t *success, std::int32_t *iterations,
+                      const inverse_kinematics_visitor &visitor = inverse_kinematics_visitor(),
+                      const pik_parameters &p = pik_parameters()) {
+    data.bind(problem);
+    const ikgpu_pik_params prm = detail::to_abi(visitor, p, data);
+    if (ikgpu_pik_solve_batch_host(data.handle(), B, Q0, targets, &prm, Q, success, iterations, IKGPU_AOS) != IKGPU_OK)
+        throw std::runtime_error(ikgpu_last_error());
+}
+
+// DEVICE buffers (component-major) and a hipStream_t; asynchronous.
+inline void pik_batch_device(InverseKinematicsProblem &problem, std::int64_t B, const number_t *Q0, const number_t *targets,
+                             pik_data &data, number_t *Q, std::uint8_t *success, std::int32_t *iterations, void *stream,
+                             const inverse_kinematics_visitor &visitor = inverse_kinematics_visitor(),
+                             const pik_parameters &p = pik_parameters()) {
+    data.bind(problem);
+    const ikgpu_pik_params prm = detail::to_abi(visitor, p, data);
+    if (ikgpu_pik_solve_batch(data.handle(), B, Q0, targets, &prm, Q, success, iterations, IKGPU_SOA, stream) != IKGPU_OK)
+        throw std::runtime_error(ikgpu_last_error());
+}
+
 }  // namespace ik

@@ -10,6 +10,7 @@
 #include <string>
 
 #include "device/chain_kernel_body.hpp"
+#include "device/pik_solver.hpp"
 #include "device/tree_kernel_body.hpp"
 #include "generic_tables.hpp"
 
@@ -358,7 +359,40 @@ hipError_t with_workspace(const ProblemHost &ph, const DeviceTables &dt, ikdev::
     return e != hipSuccess ? e : f;
 }
 
+__global__ __launch_bounds__(kBlock) void pik_generic_kernel(const ikdev::PikKernelArgs a) {
+    ikdev::pik_generic_body(a, static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x, [](bool act) { return __any(act) != 0; });
+}
+
 }  // namespace
+
+// ik::pik (reference ik/ik/pik.cpp:31-103) on the generic lane program; `gen` is the problem's generic analysis.
+hipError_t launch_pik_generic(const ProblemHost &gen, const DeviceTables &dt, const BatchIO &io, const ikgpu_pik_params &prm,
+                              hipStream_t stream) {
+    ikdev::PikKernelArgs a{};
+    a.T = bind_generic_tables(gen, dt.g_ints, dt.g_dbls);
+    a.prm.max_iterations = prm.max_iterations;
+    a.prm.step_length = prm.step_length;
+    a.prm.stop_sq_tol = prm.stop_sq_tol;
+    for (int l = 0; l < ikdev::kMaxPikLevels; ++l) a.prm.lam2[l] = l < prm.num_levels ? prm.lambda[l] * prm.lambda[l] : 1.0;
+    a.prm.has_da = 0;
+    if (prm.da)
+        for (int k = 0; k < gen.nv; ++k) {
+            a.prm.da[k] = prm.da[k];
+            if (prm.da[k] != 0.0) a.prm.has_da = 1;
+        }
+    a.layout = io.layout; a.B = io.B; a.q0 = io.q0; a.targets = io.targets;
+    a.q_out = io.q_out; a.success = io.success; a.iters = io.iters;
+    a.ws_stride = (io.B + kBlock - 1) / kBlock * kBlock;
+    const size_t bytes = sizeof(double) * static_cast<size_t>(gen.generic.ws_words_pik) * static_cast<size_t>(a.ws_stride);
+    void *ws = nullptr;
+    hipError_t e = hipMallocAsync(&ws, bytes, stream);
+    if (e != hipSuccess) return e;
+    a.ws = static_cast<double *>(ws);
+    hipLaunchKernelGGL(pik_generic_kernel, grid_for(io.B), dim3(kBlock), 0, stream, a);
+    e = hipGetLastError();
+    const hipError_t f = hipFreeAsync(ws, stream);
+    return e != hipSuccess ? e : f;
+}
 
 hipError_t launch_dls_generic(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const ikgpu_dls_params &prm,
                               hipStream_t stream) {

@@ -51,6 +51,10 @@ bool tree_shape_built(int nj, int nch);
 // freed in stream order (hipMallocAsync / hipFreeAsync), so the call stays asynchronous and re-entrant.
 hipError_t launch_dls_generic(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io,
                               const ikgpu_dls_params &prm, hipStream_t stream);
+// ik::pik (reference ik/ik/pik.cpp:31-103): always the generic lane program; `gen` must be a Generic-kind analysis and
+// dt.g_ints / dt.g_dbls its uploaded tables.
+hipError_t launch_pik_generic(const ProblemHost &gen, const DeviceTables &dt, const BatchIO &io, const ikgpu_pik_params &prm,
+                              hipStream_t stream);
 hipError_t launch_eval_generic(const ProblemHost &ph, const DeviceTables &dt, int64_t B, const double *q,
                                const double *targets, double *e_out, double *J_out, double *oMf_out, int layout,
                                hipStream_t stream);

@@ -1,6 +1,7 @@
 // problem.cpp -- analyse the support of each task and build the kernel tables.
 #include "problem.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <stdexcept>
@@ -169,6 +170,16 @@ void build_generic(ProblemHost &ph, const Model &m) {
     }
     g.o_ttype = put_i(ttype); g.o_tfjoint = put_i(tfj); g.o_trjoint = put_i(trj);
     g.o_trow = put_i(trow); g.o_tdim = put_i(tdim); g.o_tprio = put_i(tprio);
+    // prioritised IK: first row of each priority level (tasks are listed in non-decreasing priority)
+    g.nlevels = nt > 0 ? ph.tasks[nt - 1].priority + 1 : 1;
+    std::vector<int32_t> lvl(g.nlevels + 1, 0);
+    for (int i = 0; i < nt; ++i) lvl[ph.tasks[i].priority + 1] += task_dim(ph.tasks[i]);
+    int mmax = 0;
+    for (int l = 0; l < g.nlevels; ++l) {
+        mmax = std::max(mmax, lvl[l + 1]);
+        lvl[l + 1] += lvl[l];
+    }
+    g.o_lvlrow0 = put_i(lvl);
     auto put_d = [&](const double *p, size_t n) { int o = static_cast<int>(g.dbls.size()); g.dbls.insert(g.dbls.end(), p, p + n); return o; };
     g.o_placement = static_cast<int>(g.dbls.size());
     for (int j = 0; j < nj; ++j) put_d(m.joint_placement[j].data(), 12);
@@ -196,6 +207,10 @@ void build_generic(ProblemHost &ph, const Model &m) {
     g.off_y = o; o += M;
     g.off_dq = o; o += nv;
     g.ws_words = o;
+    g.off_P = o; o += nv * nv;
+    g.off_Jb = o; o += mmax * nv;
+    g.off_de = o; o += mmax;
+    g.ws_words_pik = o;
     ph.kind = KernelKind::Generic;
     ph.kernel_name = "dls_generic<M=" + std::to_string(M) + ",nv=" + std::to_string(nv) + ",joints=" + std::to_string(nj - 1) + ">";
     ph.q_in_chain.assign(m.nq, 1);

@@ -28,6 +28,8 @@ struct GenericHost {
     int o_placement = 0, o_axis = 0, o_lower = 0, o_upper = 0, o_tfpl = 0, o_trpl = 0, o_tw = 0;  // into dbls
     int njoints = 0;
     int off_q = 0, off_oMi = 0, off_Jw = 0, off_e = 0, off_J = 0, off_G = 0, off_y = 0, off_dq = 0, ws_words = 0;
+    int nlevels = 1, o_lvlrow0 = 0;                               // prioritised IK: level -> first row (into ints)
+    int off_P = 0, off_Jb = 0, off_de = 0, ws_words_pik = 0;      // and its extra workspace
 };
 
 // Host copy of one serial chain (support of one task below its base), axis-folded: every joint

@@ -156,6 +156,32 @@ int ikgpu_dls_solve_batch_host(const ikgpu_problem *p, int64_t B, const double *
                                const ikgpu_dls_params *params, double *q_out, uint8_t *success, int32_t *iters,
                                int layout);
 
+/* ---- the other solver of the reference: B independent calls of ik::pik(), prioritised IK (reference
+ * ik/ik/pik.cpp:31-103, declared ik/ik/pik.hpp:56-59), in lockstep.  Arguments as ikgpu_dls_solve_batch.  Every priority
+ * level l of the task table is solved in the null space of the levels before it, with the damped pseudo-inverse of
+ * pik.cpp:5-22 (damping factor lambda[l]) and the projector update of pik.cpp:58-61.  Runs on the generic device kernel
+ * for every problem shape (`pik_generic<...>`). */
+#define IKGPU_MAX_PIK_LEVELS 8
+#define IKGPU_MAX_PIK_DA 128
+/* ik::pik_parameters (reference ik/ik/pik.hpp:11-16; its `damping` and `max_time` are never read by the loop) + the stop
+ * rule as in ikgpu_dls_params + the two members of ik::pik_data a caller sets before the call (ik/ik/pik.hpp:41-44). */
+typedef struct {
+    int32_t max_iterations;               /* default 100 */
+    double step_length;                   /* default 1.0 */
+    double stop_sq_tol;                   /* default 1e-4; < 0 never stops */
+    int32_t num_levels;                   /* must equal the problem's max priority + 1, <= IKGPU_MAX_PIK_LEVELS */
+    double lambda[IKGPU_MAX_PIK_LEVELS];  /* pik_data::lambda, default 1.0 each (pik.hpp:24) */
+    const double *da;                     /* pik_data::da, HOST pointer to nv doubles, or NULL for zero (the default);
+                                           * read during the call; nv <= IKGPU_MAX_PIK_DA when not NULL */
+} ikgpu_pik_params;
+void ikgpu_pik_params_default(ikgpu_pik_params *p, int32_t num_levels);
+int ikgpu_pik_solve_batch(const ikgpu_problem *p, int64_t B, const double *q0, const double *targets,
+                          const ikgpu_pik_params *params, double *q_out, uint8_t *success, int32_t *iters,
+                          int layout /* ikgpu_layout */, void *stream);
+int ikgpu_pik_solve_batch_host(const ikgpu_problem *p, int64_t B, const double *q0, const double *targets,
+                               const ikgpu_pik_params *params, double *q_out, uint8_t *success, int32_t *iters,
+                               int layout);
+
 /* ---- stage kernels (device pointers), for stage-by-stage parity and for building targets:
  * evaluate_problem_data + stacking (reference ik/ik/data.cpp:25-58, ik/ik/dls.cpp:18-24):
  *   e_out [M x B], J_out [M x nv x B] (row-major M x nv per problem; J_out may be NULL). */

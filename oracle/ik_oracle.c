@@ -605,6 +605,287 @@ int iko_dls_batch(const iko_model *m, const iko_task *tasks, int ntasks, long B,
     return 0;
 }
 
+/* ---------------------------------------------------------------------------------------------------
+ * ik::pik -- prioritised IK (ik/ik/pik.cpp:5-103)
+ * ------------------------------------------------------------------------------------------------- */
+
+/* Thin SVD by one-sided Jacobi (Hestenes): A (m x n, row-major) = U diag(s) V^T with k = min(m, n) columns.
+ * Stands in for Eigen::JacobiSVD(ComputeThinU | ComputeThinV) at pik.cpp:8-9: singular values are unique and the
+ * sum pik.cpp:12-19 forms from the triplets is invariant under the freedom left in the vectors. */
+static void svd_thin(const double *A, int m, int n, double *U, double *s, double *V) {
+    const int big = m >= n ? m : n, k = m >= n ? n : m;
+    double *W = (double *)malloc(sizeof(double) * big * k); /* column j = W[j*big ..] */
+    double *R = (double *)calloc((size_t)k * k, sizeof(double));
+    for (int j = 0; j < k; ++j) {
+        for (int i = 0; i < big; ++i) W[j * big + i] = (m >= n) ? A[i * n + j] : A[j * n + i];
+        R[j * k + j] = 1.0; /* column j of the accumulated right rotations = R[j*k ..] */
+    }
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        int rotated = 0;
+        for (int a = 0; a < k - 1; ++a)
+            for (int b = a + 1; b < k; ++b) {
+                double al = 0, be = 0, ga = 0;
+                for (int i = 0; i < big; ++i) {
+                    al += W[a * big + i] * W[a * big + i];
+                    be += W[b * big + i] * W[b * big + i];
+                    ga += W[a * big + i] * W[b * big + i];
+                }
+                if (ga == 0.0 || fabs(ga) <= DBL_EPSILON * sqrt(al * be)) continue;
+                rotated = 1;
+                const double zeta = (be - al) / (2.0 * ga);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                for (int i = 0; i < big; ++i) {
+                    const double x = W[a * big + i], y = W[b * big + i];
+                    W[a * big + i] = c * x - sn * y;
+                    W[b * big + i] = sn * x + c * y;
+                }
+                for (int i = 0; i < k; ++i) {
+                    const double x = R[a * k + i], y = R[b * k + i];
+                    R[a * k + i] = c * x - sn * y;
+                    R[b * k + i] = sn * x + c * y;
+                }
+            }
+        if (!rotated) break;
+    }
+    for (int j = 0; j < k; ++j) {
+        double nn = 0;
+        for (int i = 0; i < big; ++i) nn += W[j * big + i] * W[j * big + i];
+        s[j] = sqrt(nn);
+        for (int i = 0; i < big; ++i) {
+            const double w = s[j] > 0 ? W[j * big + i] / s[j] : 0.0;
+            if (m >= n) U[i * k + j] = w; else V[i * k + j] = w;
+        }
+        for (int i = 0; i < k; ++i) {
+            if (m >= n) V[i * k + j] = R[j * k + i]; else U[i * k + j] = R[j * k + i];
+        }
+    }
+    free(W); free(R);
+}
+
+/* damp_pseudoinverse (pik.cpp:5-22): res (n x m) = sum_i sigma_i / (lambda^2 + sigma_i^2) v_i u_i^T */
+static void damp_pseudoinverse(const double *A, int m, int n, double lambda, double *res) {
+    const int k = m >= n ? n : m;
+    double *U = (double *)malloc(sizeof(double) * m * k), *V = (double *)malloc(sizeof(double) * n * k);
+    double *s = (double *)malloc(sizeof(double) * k);
+    svd_thin(A, m, n, U, s, V);
+    for (int i = 0; i < n * m; ++i) res[i] = 0.0;
+    for (int i = 0; i < k; ++i) {
+        const double f = s[i] / (lambda * lambda + s[i] * s[i]);
+        for (int r = 0; r < n; ++r)
+            for (int c = 0; c < m; ++c) res[r * m + c] += f * V[r * k + i] * U[c * k + i];
+    }
+    free(U); free(V); free(s);
+}
+
+/* Jbar.completeOrthogonalDecomposition().pseudoInverse() * Jbar (pik.cpp:59-61): the orthogonal projector onto the
+ * row space of A, with the numerical rank Eigen's COD would find -- column-pivoted Householder QR
+ * (ColPivHouseholderQR), pivots with |R_kk| > eps * min(m, n) * max|R_kk| counted, and Eigen's early "the rest is
+ * exactly zero" cut on the remaining column norms.  Pr is n x n. */
+static void rowspace_projector(const double *A, int m, int n, double *Pr) {
+    const int k = m >= n ? n : m;
+    double *Q = (double *)malloc(sizeof(double) * m * n);
+    int *perm = (int *)malloc(sizeof(int) * n);
+    double *diag = (double *)malloc(sizeof(double) * (k > 0 ? k : 1));
+    memcpy(Q, A, sizeof(double) * m * n);
+    for (int j = 0; j < n; ++j) perm[j] = j;
+    double maxcol = 0.0;
+    for (int j = 0; j < n; ++j) {
+        double nn = 0;
+        for (int i = 0; i < m; ++i) nn += Q[i * n + j] * Q[i * n + j];
+        if (sqrt(nn) > maxcol) maxcol = sqrt(nn);
+    }
+    const double helper = (maxcol * DBL_EPSILON) * (maxcol * DBL_EPSILON) / (double)(m > 0 ? m : 1);
+    int nonzero = k;
+    double maxpivot = 0.0;
+    for (int c = 0; c < k; ++c) {
+        int piv = c;
+        double best = -1.0;
+        for (int j = c; j < n; ++j) {
+            double nn = 0;
+            for (int i = c; i < m; ++i) nn += Q[i * n + j] * Q[i * n + j];
+            if (nn > best) { best = nn; piv = j; }
+        }
+        if (nonzero == k && best < helper * (double)(m - c)) nonzero = c;
+        if (piv != c) {
+            for (int i = 0; i < m; ++i) { const double t = Q[i * n + c]; Q[i * n + c] = Q[i * n + piv]; Q[i * n + piv] = t; }
+            const int t = perm[c]; perm[c] = perm[piv]; perm[piv] = t;
+        }
+        /* Householder reflector on rows c.. of column c */
+        double nn = 0;
+        for (int i = c; i < m; ++i) nn += Q[i * n + c] * Q[i * n + c];
+        const double nrm = sqrt(nn), x0 = Q[c * n + c];
+        const double beta = x0 >= 0 ? -nrm : nrm;
+        diag[c] = beta;
+        if (fabs(beta) > maxpivot) maxpivot = fabs(beta);
+        if (nrm > 0) {
+            const double v0 = x0 - beta;
+            double vv = v0 * v0;
+            for (int i = c + 1; i < m; ++i) vv += Q[i * n + c] * Q[i * n + c];
+            if (vv > 0)
+                for (int j = c + 1; j < n; ++j) {
+                    double d = v0 * Q[c * n + j];
+                    for (int i = c + 1; i < m; ++i) d += Q[i * n + c] * Q[i * n + j];
+                    const double f = 2.0 * d / vv;
+                    Q[c * n + j] -= f * v0;
+                    for (int i = c + 1; i < m; ++i) Q[i * n + j] -= f * Q[i * n + c];
+                }
+        }
+        Q[c * n + c] = beta;
+        for (int i = c + 1; i < m; ++i) Q[i * n + c] = 0.0; /* (the reflector is not needed afterwards) */
+    }
+    int rank = 0;
+    for (int c = 0; c < nonzero; ++c)
+        if (fabs(diag[c]) > maxpivot * DBL_EPSILON * (double)k) ++rank;
+    /* rows 0..rank-1 of R, columns un-permuted, orthonormalised (modified Gram-Schmidt, applied twice) */
+    double *Z = (double *)calloc((size_t)(rank > 0 ? rank : 1) * n, sizeof(double));
+    for (int r = 0; r < rank; ++r)
+        for (int j = r; j < n; ++j) Z[r * n + perm[j]] = Q[r * n + j];
+    for (int r = 0; r < rank; ++r) {
+        for (int pass = 0; pass < 2; ++pass)
+            for (int q = 0; q < r; ++q) {
+                double d = 0;
+                for (int j = 0; j < n; ++j) d += Z[r * n + j] * Z[q * n + j];
+                for (int j = 0; j < n; ++j) Z[r * n + j] -= d * Z[q * n + j];
+            }
+        double nn = 0;
+        for (int j = 0; j < n; ++j) nn += Z[r * n + j] * Z[r * n + j];
+        nn = sqrt(nn);
+        for (int j = 0; j < n; ++j) Z[r * n + j] /= nn;
+    }
+    for (int i = 0; i < n * n; ++i) Pr[i] = 0.0;
+    for (int r = 0; r < rank; ++r)
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) Pr[i * n + j] += Z[r * n + i] * Z[r * n + j];
+    free(Q); free(perm); free(diag); free(Z);
+}
+
+void iko_damp_pseudoinverse(const double *A, int m, int n, double lambda, double *res) { damp_pseudoinverse(A, m, n, lambda, res); }
+void iko_rowspace_projector(const double *A, int m, int n, double *Pr) { rowspace_projector(A, m, n, Pr); }
+
+static int pik_ws(const iko_model *m, const iko_task *tasks, int ntasks, const double *targets, const double *q0,
+                  const iko_pik_params *p, double *q_out, int *success, int *iters, double *trace, workspace *w) {
+    const int nq = m->nq, nv = m->nv, M = w->M;
+    int maxp = 0;
+    for (int i = 0; i < ntasks; ++i) if (tasks[i].priority > maxp) maxp = tasks[i].priority;
+    if (p->nlevels != maxp + 1) return -1;
+    int *row0 = (int *)calloc((size_t)maxp + 2, sizeof(int));
+    for (int i = 0; i < ntasks; ++i) row0[tasks[i].priority + 1] += task_dim(&tasks[i]);
+    for (int l = 0; l <= maxp; ++l) row0[l + 1] += row0[l];
+    double *P = (double *)malloc(sizeof(double) * nv * nv), *Pr = (double *)malloc(sizeof(double) * nv * nv);
+    double *Jbar = (double *)malloc(sizeof(double) * (M > 0 ? M : 1) * nv), *pinv = (double *)malloc(sizeof(double) * (M > 0 ? M : 1) * nv);
+    double *de = (double *)malloc(sizeof(double) * (M > 0 ? M : 1));
+    int rc = 0, done = 0;
+    memcpy(w->q, q0, sizeof(double) * nq);                      /* pik.cpp:34 */
+    for (int it = 0; it < p->max_iterations && !done; ++it) {   /* pik.cpp:39 */
+        double e0sq;
+        evaluate_ws(m, tasks, ntasks, targets, w->q, w, &e0sq); /* pik.cpp:41 */
+        for (int i = 0; i < nv * nv; ++i) P[i] = 0.0;           /* pik.cpp:44-45 */
+        for (int i = 0; i < nv; ++i) { P[i * nv + i] = 1.0; w->dq[i] = 0.0; }
+        for (int l = 0; l <= maxp; ++l) {                       /* pik.cpp:47 */
+            const int r0 = row0[l], ml = row0[l + 1] - row0[l];
+            if (ml == 0) continue;
+            const double *Jl = w->Jt + (size_t)r0 * nv;
+            for (int r = 0; r < ml; ++r) {                      /* pik.cpp:49-51 */
+                double s = w->et[r0 + r];
+                for (int c = 0; c < nv; ++c) s -= Jl[r * nv + c] * w->dq[c];
+                de[r] = s;
+                for (int c = 0; c < nv; ++c) {
+                    double a = 0.0;
+                    for (int k = 0; k < nv; ++k) a += Jl[r * nv + k] * P[k * nv + c];
+                    Jbar[r * nv + c] = a;
+                }
+            }
+            damp_pseudoinverse(Jbar, ml, nv, p->lambda[l], pinv); /* pik.cpp:54-55 */
+            for (int c = 0; c < nv; ++c) {
+                double s = 0.0;
+                for (int r = 0; r < ml; ++r) s += pinv[c * ml + r] * de[r];
+                w->dq[c] -= s;
+            }
+            rowspace_projector(Jbar, ml, nv, Pr);               /* pik.cpp:58-61 */
+            for (int i = 0; i < nv * nv; ++i) P[i] -= Pr[i];
+        }
+        if (p->da)                                              /* pik.cpp:65 */
+            for (int c = 0; c < nv; ++c) {
+                double s = 0.0;
+                for (int k = 0; k < nv; ++k) s += P[c * nv + k] * p->da[k];
+                w->dq[c] += s;
+            }
+        if (trace) {
+            double *t = trace + (size_t)it * (nq + M + nv);
+            memcpy(t, w->q, sizeof(double) * nq);
+            memcpy(t + nq, w->et, sizeof(double) * M);
+            memcpy(t + nq + M, w->dq, sizeof(double) * nv);
+        }
+        if (p->stop_sq_tol >= 0.0 && e0sq < p->stop_sq_tol) {   /* visitor.hpp:19; pik.cpp:67-70 */
+            memcpy(q_out, w->q, sizeof(double) * nq);
+            *success = 1;
+            *iters = it;
+            done = 1;
+            break;
+        }
+        for (int c = 0; c < nv; ++c) w->tmp[c] = p->step_length * w->dq[c];
+        iko_integrate(m, w->q, w->tmp, w->qn);                   /* pik.cpp:73-74 */
+        for (int i = 0; i < nq; ++i) {                           /* pik.cpp:77 */
+            const double lo_clamped = w->qn[i] > m->lower[i] ? w->qn[i] : m->lower[i];
+            w->q[i] = m->upper[i] < lo_clamped ? m->upper[i] : lo_clamped;
+        }
+    }
+    if (!done) {
+        memcpy(q_out, w->q, sizeof(double) * nq);                /* pik.cpp:99-100 */
+        *success = 0;
+        *iters = p->max_iterations;
+    }
+    free(row0); free(P); free(Pr); free(Jbar); free(pinv); free(de);
+    return rc;
+}
+
+int iko_pik(const iko_model *m, const iko_task *tasks, int ntasks, const double *targets, const double *q0,
+            const iko_pik_params *p, double *q_out, int *success, int *iters, double *trace) {
+    const int M = iko_task_rows(tasks, ntasks);
+    workspace *w = ws_new(m, M);
+    int rc = pik_ws(m, tasks, ntasks, targets, q0, p, q_out, success, iters, trace, w);
+    ws_free(w);
+    return rc;
+}
+
+typedef struct {
+    const iko_model *m; const iko_task *tasks; int ntasks; long b0, b1;
+    const double *targets, *q0; const iko_pik_params *p; double *q_out; unsigned char *success; int *iters; int rc;
+} pik_job;
+
+static void *pik_worker(void *arg) {
+    pik_job *j = (pik_job *)arg;
+    workspace *w = ws_new(j->m, iko_task_rows(j->tasks, j->ntasks));
+    const int nq = j->m->nq;
+    for (long b = j->b0; b < j->b1; ++b) {
+        int ok = 0, it = 0;
+        if (pik_ws(j->m, j->tasks, j->ntasks, j->targets + (size_t)b * j->ntasks * 12, j->q0 + (size_t)b * nq, j->p,
+                   j->q_out + (size_t)b * nq, &ok, &it, NULL, w) != 0) { j->rc = -1; break; }
+        if (j->success) j->success[b] = (unsigned char)ok;
+        if (j->iters) j->iters[b] = it;
+    }
+    ws_free(w);
+    return NULL;
+}
+
+int iko_pik_batch(const iko_model *m, const iko_task *tasks, int ntasks, long B, const double *targets, const double *q0,
+                  const iko_pik_params *p, double *q_out, unsigned char *success, int *iters, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    pthread_t th[256];
+    pik_job jobs[256];
+    for (int t = 0; t < nthreads; ++t) {
+        pik_job j = {m, tasks, ntasks, B * t / nthreads, B * (t + 1) / nthreads, targets, q0, p, q_out, success, iters, 0};
+        jobs[t] = j;
+    }
+    if (nthreads == 1) { pik_worker(&jobs[0]); return jobs[0].rc; }
+    for (int t = 0; t < nthreads; ++t) pthread_create(&th[t], NULL, pik_worker, &jobs[t]);
+    int rc = 0;
+    for (int t = 0; t < nthreads; ++t) { pthread_join(th[t], NULL); if (jobs[t].rc) rc = jobs[t].rc; }
+    return rc;
+}
+
 void iko_fk_batch(const iko_model *m, long B, const double *q, const int *frames, int nsel, double *out) {
     double *oMi = (double *)malloc(sizeof(double) * 12 * m->njoints);
     double *oMf = (double *)malloc(sizeof(double) * 12 * m->nframes);

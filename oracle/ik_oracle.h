@@ -79,6 +79,28 @@ int iko_dls_batch(const iko_model *m, const iko_task *tasks, int ntasks, long B,
                   const double *targets, const double *q0, const iko_params *p, double *q_out,
                   unsigned char *success, int *iters, int nthreads);
 
+/* ik::pik_parameters (ik/ik/pik.hpp:11-16; `damping` there is never read) + the stop rule as above + the two members
+ * of ik::pik_data a caller sets (ik/ik/pik.hpp:41,44): lambda[level] (default 1.0 each, pik.hpp:24) and da (default
+ * zero; NULL == zero).  nlevels must be max priority + 1. */
+typedef struct {
+    int max_iterations;
+    double step_length, stop_sq_tol;
+    int nlevels;
+    const double *lambda; /* [nlevels] */
+    const double *da;     /* [nv] or NULL */
+} iko_pik_params;
+
+/* ik::pik (ik/ik/pik.cpp:31-103) for one problem; same outputs and trace format as iko_dls. Returns -1 when
+ * nlevels does not match the task table. */
+int iko_pik(const iko_model *m, const iko_task *tasks, int ntasks, const double *targets, const double *q0,
+            const iko_pik_params *p, double *q_out, int *success, int *iters, double *trace);
+int iko_pik_batch(const iko_model *m, const iko_task *tasks, int ntasks, long B, const double *targets, const double *q0,
+                  const iko_pik_params *p, double *q_out, unsigned char *success, int *iters, int nthreads);
+/* The two matrix functions of the PIK step, exposed for tests: damp_pseudoinverse (pik.cpp:5-22; res is n x m) and
+ * pinv(A) * A as Eigen's completeOrthogonalDecomposition would give it (pik.cpp:59-61; Pr is n x n). A is m x n. */
+void iko_damp_pseudoinverse(const double *A, int m, int n, double lambda, double *res);
+void iko_rowspace_projector(const double *A, int m, int n, double *Pr);
+
 /* Batch FK of selected frames: q[B][nq] -> out[B][nsel][12]. */
 void iko_fk_batch(const iko_model *m, long B, const double *q, const int *frames, int nsel,
                   double *out);

@@ -47,6 +47,11 @@ class _Params(C.Structure):
                 ("stop_sq_tol", C.c_double)]
 
 
+class _PikParams(C.Structure):
+    _fields_ = [("max_iterations", C.c_int), ("step_length", C.c_double), ("stop_sq_tol", C.c_double),
+                ("nlevels", C.c_int), ("lam", C.POINTER(C.c_double)), ("da", C.POINTER(C.c_double))]
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
@@ -148,6 +153,64 @@ def dls_batch(model, tasks, targets, q0, prm, nthreads=1):
     lib().iko_dls_batch(C.byref(model.c), tasks, C.c_int(len(tasks)), C.c_long(B), _p(targets), _p(q0),
                         C.byref(prm), _p(q), _p(ok), _p(it), C.c_int(nthreads))
     return q, ok, it
+
+
+def pik_params(max_iterations=100, step_length=1.0, stop_sq_tol=1e-4, lam=(1.0,), da=None):
+    """ik::pik_parameters + pik_data::lambda / da (reference ik/ik/pik.hpp:11-16,41-44).  Keeps the arrays alive."""
+    prm = _PikParams()
+    prm.max_iterations, prm.step_length, prm.stop_sq_tol, prm.nlevels = max_iterations, step_length, stop_sq_tol, len(lam)
+    prm._lam = (C.c_double * len(lam))(*lam)
+    prm.lam = C.cast(prm._lam, C.POINTER(C.c_double))
+    if da is not None:
+        prm._da = (C.c_double * len(da))(*da)
+        prm.da = C.cast(prm._da, C.POINTER(C.c_double))
+    return prm
+
+
+def pik(model, tasks, targets, q0, prm, trace=False):
+    targets = np.ascontiguousarray(targets, dtype=np.float64)
+    q0 = np.ascontiguousarray(q0, dtype=np.float64)
+    q = np.empty(model.nq)
+    ok, it = C.c_int(0), C.c_int(0)
+    M = task_rows(tasks)
+    tr = np.full((prm.max_iterations, model.nq + M + model.nv), np.nan) if trace else None
+    rc = lib().iko_pik(C.byref(model.c), tasks, C.c_int(len(tasks)), _p(targets), _p(q0), C.byref(prm), _p(q),
+                       C.byref(ok), C.byref(it), _p(tr) if trace else None)
+    if rc != 0:
+        raise ValueError("iko_pik: nlevels does not match the task table")
+    if trace:
+        return q, bool(ok.value), it.value, tr
+    return q, bool(ok.value), it.value
+
+
+def pik_batch(model, tasks, targets, q0, prm, nthreads=1):
+    """targets [B, ntasks, 12], q0 [B, nq] (array-of-structures)."""
+    targets = np.ascontiguousarray(targets, dtype=np.float64)
+    q0 = np.ascontiguousarray(q0, dtype=np.float64)
+    B = q0.shape[0]
+    assert targets.shape == (B, len(tasks), 12) and q0.shape == (B, model.nq)
+    q = np.empty_like(q0)
+    ok = np.zeros(B, dtype=np.uint8)
+    it = np.zeros(B, dtype=np.int32)
+    rc = lib().iko_pik_batch(C.byref(model.c), tasks, C.c_int(len(tasks)), C.c_long(B), _p(targets), _p(q0),
+                             C.byref(prm), _p(q), _p(ok), _p(it), C.c_int(nthreads))
+    if rc != 0:
+        raise ValueError("iko_pik_batch: nlevels does not match the task table")
+    return q, ok, it
+
+
+def damp_pseudoinverse(A, lam):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    res = np.empty((A.shape[1], A.shape[0]))
+    lib().iko_damp_pseudoinverse(_p(A), C.c_int(A.shape[0]), C.c_int(A.shape[1]), C.c_double(lam), _p(res))
+    return res
+
+
+def rowspace_projector(A):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    res = np.empty((A.shape[1], A.shape[1]))
+    lib().iko_rowspace_projector(_p(A), C.c_int(A.shape[0]), C.c_int(A.shape[1]), _p(res))
+    return res
 
 
 def log6(M12):

@@ -524,3 +524,60 @@ def dls(m, tasks, q0, max_iterations=100, damping=1e-2, step_length=1.0, stop_sq
             return q, True, i
         q = clamp(m, integrate(m, q, step_length * dq))
     return q, False, max_iterations
+
+
+def damp_pseudoinverse(M, lam):
+    """damp_pseudoinverse (ik/ik/pik.cpp:5-22)."""
+    U, s, Vt = np.linalg.svd(M, full_matrices=False)
+    res = np.zeros((M.shape[1], M.shape[0]))
+    for i in range(s.size):
+        res += (s[i] / (lam ** 2 + s[i] ** 2)) * np.outer(Vt[i], U[:, i])
+    return res
+
+
+def cod_rank(A):
+    """Numerical rank as Eigen's CompleteOrthogonalDecomposition decides it: column-pivoted QR, pivots above
+    eps * min(m, n) * max|pivot| (ColPivHouseholderQR::rank with the default threshold)."""
+    import scipy.linalg
+    if min(A.shape) == 0:
+        return 0
+    R = scipy.linalg.qr(A, mode="r", pivoting=True)[0]
+    d = np.abs(np.diag(R))
+    if d.max() == 0.0:
+        return 0
+    return int(np.sum(d > d.max() * np.finfo(float).eps * min(A.shape)))
+
+
+def rowspace_projector(A):
+    """Jbar.completeOrthogonalDecomposition().pseudoInverse() * Jbar (ik/ik/pik.cpp:59-61)."""
+    r = cod_rank(A)
+    Vt = np.linalg.svd(A, full_matrices=False)[2]
+    return Vt[:r].T @ Vt[:r]
+
+
+def pik(m, levels, q0, max_iterations=100, step_length=1.0, stop_sq_tol=1e-4, lam=None, da=None, trace=None):
+    """ik::pik (ik/ik/pik.cpp:31-103).  levels: one task list per priority level; lam: damping factor per level
+    (ik::pik_data::lambda, default 1.0 each, ik/ik/pik.hpp:24); da: ik::pik_data::da (default zero).
+    Returns (q, success, iterations-before-exit)."""
+    q = np.array(q0, dtype=float)
+    lam = [1.0] * len(levels) if lam is None else list(lam)
+    da = np.zeros(m.nv) if da is None else np.asarray(da, float)
+    for it in range(max_iterations):
+        eJ = [evaluate(m, lv, q) if lv else (np.zeros(0), np.zeros((0, m.nv))) for lv in levels]
+        P = np.eye(m.nv)
+        dq = np.zeros(m.nv)
+        for (e, J), l in zip(eJ, lam):
+            if e.size == 0:
+                continue
+            de_bar = e - J @ dq
+            Jbar = J @ P
+            dq = dq - damp_pseudoinverse(Jbar, l) @ de_bar
+            P = P - rowspace_projector(Jbar)
+        dq = dq + P @ da
+        if trace is not None:
+            trace.append(dict(q=q.copy(), e=np.concatenate([e for e, _ in eJ]), dq=dq.copy()))
+        e0 = eJ[0][0]
+        if stop_sq_tol >= 0.0 and float(np.dot(e0, e0)) < stop_sq_tol:
+            return q, True, it
+        q = clamp(m, integrate(m, q, step_length * dq))
+    return q, False, max_iterations

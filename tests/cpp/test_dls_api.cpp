@@ -5,13 +5,14 @@
 //
 //   test_dls_api <urdf> <free_flyer 0|1> <max_it> <damping> <step> <tol> <ntasks>
 //                { <frame> <type 0|1|2> <priority> <12 target numbers> } x ntasks   <nq numbers of q0>
-//                [ posture <nj> <priority> <weight> <nj target numbers> ]
+//                [ posture <nj> <priority> <weight> <nj target numbers> ]  [ pik <lambda per level ...> ]
 #include <cstdio>
 #include <cstdlib>
 #include <string>
 #include <vector>
 
 #include "ik/dls.hpp"
+#include "ik/pik.hpp"
 #include "ik/posture.hpp"
 #include "ik/problem.hpp"
 
@@ -51,12 +52,22 @@ int main(int argc, char **argv) {
         std::size_t posture_nj = 0, posture_prio = 0;
         double posture_weight = 1.0;
         std::vector<double> posture_target;
-        if (a < argc && next() == "posture") {
-            posture_nj = std::atoi(next().c_str());
-            posture_prio = std::atoi(next().c_str());
-            posture_weight = std::atof(next().c_str());
-            for (std::size_t i = 0; i < posture_nj; ++i) posture_target.push_back(std::atof(next().c_str()));
-            if (posture_prio > max_priority) max_priority = posture_prio;
+        bool use_pik = false;
+        std::vector<double> pik_lambda;
+        while (a < argc) {
+            const std::string opt = next();
+            if (opt == "posture") {
+                posture_nj = std::atoi(next().c_str());
+                posture_prio = std::atoi(next().c_str());
+                posture_weight = std::atof(next().c_str());
+                for (std::size_t i = 0; i < posture_nj; ++i) posture_target.push_back(std::atof(next().c_str()));
+                if (posture_prio > max_priority) max_priority = posture_prio;
+            } else if (opt == "pik") {  // solve with ik::pik; the rest of the line is lambda per level
+                use_pik = true;
+                while (a < argc) pik_lambda.push_back(std::atof(next().c_str()));
+            } else {
+                throw std::runtime_error("unknown option " + opt);
+            }
         }
 
         ik::InverseKinematicsProblem problem(model, max_priority);
@@ -81,20 +92,35 @@ int main(int argc, char **argv) {
             posture->weighting().setConstant(posture_weight);
         }
 
-        ik::dls_data data(problem);
         struct tol_visitor : ik::inverse_kinematics_visitor {
             double t;
             explicit tol_visitor(double t_) : t(t_) {}
             double stop_tolerance() const override { return t; }
         } visitor(tol);
 
-        // Solve
-        ik::vector_t q = ik::dls(problem, q0, data, visitor, p);
-        // and once more through the same data object (warm start from the result, as cassie.cpp:112 does)
-        ik::vector_t q2 = ik::dls(problem, q, data, visitor, p);
+        // Solve, and once more through the same data object (warm start from the result, as cassie.cpp:112 does)
+        ik::vector_t q, q2;
+        bool success = false;
+        std::size_t iterations = 0;
+        std::string kernel;
+        if (use_pik) {  // reference ik/ik/pik.hpp:56-59
+            ik::pik_data data(problem);
+            ik::pik_parameters pp;
+            pp.max_iterations = static_cast<int>(p.max_iterations);
+            pp.step_length = p.step_length;
+            if (pik_lambda.size() != data.lambda.size()) throw std::runtime_error("one lambda per priority level, please");
+            data.lambda = pik_lambda;
+            q = ik::pik(problem, q0, data, visitor, pp);
+            q2 = ik::pik(problem, q, data, visitor, pp);
+            success = data.success; iterations = data.iterations; kernel = data.kernel();
+        } else {
+            ik::dls_data data(problem);
+            q = ik::dls(problem, q0, data, visitor, p);
+            q2 = ik::dls(problem, q, data, visitor, p);
+            success = data.success; iterations = data.iterations; kernel = data.kernel();
+        }
 
-        std::printf("{\"kernel\": \"%s\", \"success\": %d, \"iterations\": %zu, \"q\": [", data.kernel(), data.success ? 1 : 0,
-                    data.iterations);
+        std::printf("{\"kernel\": \"%s\", \"success\": %d, \"iterations\": %zu, \"q\": [", kernel.c_str(), success ? 1 : 0, iterations);
         for (ik::index_t i = 0; i < q2.size(); ++i) std::printf("%s%.17g", i ? ", " : "", q2[i]);
         std::printf("], \"q_first\": [");
         for (ik::index_t i = 0; i < q.size(); ++i) std::printf("%s%.17g", i ? ", " : "", q[i]);

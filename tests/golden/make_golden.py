@@ -96,6 +96,57 @@ def lie_vectors(seed):
     return rows
 
 
+def pik_cases(seed):
+    """ik::pik (reference ik/ik/pik.cpp:31-103) vectors from the twin: task levels, lambda per level, q after 1 / 4 / 30
+    iterations and with the default stop rule.  Only cases whose result does not hinge on a noise-level rank decision."""
+    rng = np.random.default_rng(seed)
+    out = []
+    specs = [
+        ("ur5_pos_then_ori", "ur5.kin.urdf", False, [[("tool0", "universe", T.POSITION)], [("tool0", "universe", T.ORIENTATION)]], [0.1, 0.1]),
+        ("cassie_fixed_two_feet", "cassie_fixed.kin.urdf", False,
+         [[("LeftFootFront", "universe", T.FULL)], [("RightFootFront", "universe", T.POSITION)]], [0.05, 0.2]),
+        ("cassie_demo_levels", "cassie.kin.urdf", True,
+         [[("LeftFootFront", "pelvis", T.POSITION), ("pelvis", "universe", T.FULL)], [("LeftFootFront", "universe", T.ALIGN_X + 1)]], [0.1, 0.1]),
+    ]
+    for name, urdf, ff, levels, lam in specs:
+        m = T.load_urdf(os.path.join(MODELS, urdf), ff)
+        nj0 = 7 if ff else 0
+        names = m.names[2:] if ff else m.names[1:]
+        nominal = np.array([NOMINAL[x] for x in names]) if "cassie" in urdf else np.array([0.0, -np.pi / 2, np.pi / 2, 0.0, np.pi / 2, 0.0])
+        problems = []
+        for _ in range(4):
+            q0 = T.neutral(m)
+            q0[nj0:] = np.clip(nominal + rng.uniform(-0.1, 0.1, nominal.size), m.lower[nj0:], m.upper[nj0:])
+            qs = q0.copy()
+            qs[nj0:] = np.clip(q0[nj0:] + rng.uniform(-0.15, 0.15, nominal.size), m.lower[nj0:], m.upper[nj0:])
+            if ff:
+                q0[:3] = [0.0, 0.0, 1.0]
+                qs = T.integrate(m, qs, np.concatenate([rng.uniform(-0.05, 0.05, 3), rng.uniform(-0.1, 0.1, 3), np.zeros(m.nv - 6)]))
+            oMf = T.fk(m, qs)[1]
+            tl = []
+            for lv in levels:
+                row = []
+                for f, r, typ in lv:
+                    t = T.FrameTask(m, f, typ, r)
+                    if typ >= T.ALIGN_X:
+                        t.target = np.eye(4)
+                        t.target[:3, 3] = rng.normal(size=3)
+                    else:
+                        t.target = T.se3_inv(oMf[t.reference]) @ oMf[t.frame]
+                    row.append(t)
+                tl.append(row)
+            q1 = T.pik(m, tl, q0, 1, 1.0, -1.0, lam)[0]
+            q4 = T.pik(m, tl, q0, 4, 1.0, -1.0, lam)[0]
+            q30 = T.pik(m, tl, q0, 30, 0.5, -1.0, lam)[0]
+            qd, okd, itd = T.pik(m, tl, q0, 100, 1.0, 1e-4, lam)
+            problems.append(dict(q0=q0.tolist(), targets=[m12(t.target) for lv in tl for t in lv],
+                                 q_after_1=q1.tolist(), q_after_4=q4.tolist(), q_after_30_half_step=q30.tolist(),
+                                 default_stop=dict(q=qd.tolist(), success=bool(okd), iterations=int(itd))))
+        out.append(dict(name=name, urdf=urdf, free_flyer=ff, lam=lam,
+                        levels=[[dict(frame=f, reference=r, type=int(typ)) for f, r, typ in lv] for lv in levels], problems=problems))
+    return out
+
+
 if __name__ == "__main__":
     cases = [
         case("S_cassie_leg", "cassie_fixed.kin.urdf", False, ["LeftFootFront"], 8, 11),
@@ -108,3 +159,5 @@ if __name__ == "__main__":
         print(c["name"], len(c["problems"]), "problems; final errors", ["%.1e" % p["final_error_norm"] for p in c["problems"]])
     with open(os.path.join(HERE, "lie_maps.json"), "w") as fh:
         json.dump(lie_vectors(14), fh)
+    with open(os.path.join(HERE, "P_pik.json"), "w") as fh:
+        json.dump(pik_cases(15), fh)

@@ -10,6 +10,7 @@
 
 #include "device/chain_kernel_body.hpp"
 #include "device/tree_kernel_body.hpp"
+#include "device/pik_solver.hpp"
 #include "generic_tables.hpp"
 #include "ikgpu.h"
 #include "model.hpp"
@@ -160,6 +161,37 @@ int lane_emu_run(const char *urdf, size_t len, int root_joint, const ikgpu_task 
         }
         g_err = "shape not instantiated in the lane emulator: " + ph.kernel_name;
         return 1;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return 1;
+    }
+}
+
+// ik::pik (reference ik/ik/pik.cpp:31-103) through the device lane program (device/pik_solver.hpp), one lane at a time.
+int lane_emu_pik(const char *urdf, size_t len, int root_joint, const ikgpu_task *tasks, int ntasks, int64_t B, const double *q0,
+                 const double *targets, const ikgpu_pik_params *prm, double *q_out, uint8_t *success, int32_t *iters, int layout) {
+    try {
+        ikgpu::Model m = ikgpu::Model::from_urdf(urdf, len, (root_joint & 1) != 0);
+        const ikgpu::ProblemHost ph = ikgpu::analyse_problem(m, tasks, ntasks, /*force_generic=*/true);
+        if (prm->num_levels != ph.generic.nlevels) { g_err = "num_levels does not match the task table"; return 1; }
+        ikdev::PikKernelArgs a{};
+        a.T = ikgpu::bind_generic_tables(ph, ph.generic.ints.data(), ph.generic.dbls.data());
+        a.prm.max_iterations = prm->max_iterations;
+        a.prm.step_length = prm->step_length;
+        a.prm.stop_sq_tol = prm->stop_sq_tol;
+        for (int l = 0; l < ikdev::kMaxPikLevels; ++l) a.prm.lam2[l] = l < prm->num_levels ? prm->lambda[l] * prm->lambda[l] : 1.0;
+        if (prm->da)
+            for (int k = 0; k < ph.nv; ++k) {
+                a.prm.da[k] = prm->da[k];
+                if (prm->da[k] != 0.0) a.prm.has_da = 1;
+            }
+        a.layout = layout; a.B = B; a.q0 = q0; a.targets = targets;
+        a.q_out = q_out; a.success = success; a.iters = iters;
+        a.ws_stride = (B + 63) / 64 * 64;
+        std::vector<double> ws(static_cast<size_t>(ph.generic.ws_words_pik) * a.ws_stride, 0.0);
+        a.ws = ws.data();
+        for (int64_t b = 0; b < B; ++b) ikdev::pik_generic_body(a, b, [](bool act) { return act; });
+        return 0;
     } catch (const std::exception &e) {
         g_err = e.what();
         return 1;

@@ -1,0 +1,169 @@
+"""ik::pik (reference ik/ik/pik.cpp:31-103) on the MI355X through the C ABI (ikgpu_pik_solve_batch) against the CPU oracle
+(oracle/ik_oracle.c: iko_pik).  Tolerance: 1e-6 rad on q, as BASELINE.json's north_star states for the solvers; measured
+differences are ~1e-12.  Cases whose final projector hinges on a noise-level rank decision (see tests/test_lane_emulation.py,
+PIK_CASES) are compared with da = 0, where the result does not depend on it."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import urdf_path
+from test_gpu_generic import build
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def torch_cuda(native_built):
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+PIK_CASES = {
+    "ur5_pos_then_ori": ("ur5", False, [("frame", "tool0", "universe", 0, 0, None), ("frame", "tool0", "universe", 1, 1, None)], None, True),
+    "ur5_full_then_elbow": ("ur5", False, [("frame", "tool0", "universe", 2, 0, None), ("frame", "forearm_link", "universe", 0, 1, None)], None, False),
+    "fixed_two_feet": ("cassie_fixed", False, [("frame", "LeftFootFront", "universe", 2, 0, None),
+                                               ("frame", "RightFootFront", "universe", 0, 1, [1.0, 2.0, 0.5])], None, True),
+    "demo_three_levels": ("cassie", True, [("frame", "LeftFootFront", "pelvis", 0, 0, None), ("frame", "pelvis", "universe", 2, 0, None),
+                                           ("align", "LeftFootFront", "universe", 1, 1, None),
+                                           ("posture", 16, None, None, 2, ([0.5] * 16, [1.0] * 16))], None, False),
+    "feet_then_pelvis": ("cassie", True, [("frame", "LeftFootFront", "universe", 2, 0, None), ("frame", "RightFootFront", "universe", 2, 0, None),
+                                          ("frame", "pelvis", "universe", 2, 1, None)], None, False),
+    "single_level_leg": ("cassie_fixed", False, [("frame", "LeftFootFront", "universe", 2, 0, None)], None, True),
+}
+
+
+def _pik_data(ik_amd, problem, lam, da=None):
+    data = ik_amd.pik_data(problem, device=0)
+    data.lambda_ = list(lam)
+    if da is not None:
+        data.da = np.asarray(da, float)
+    return data
+
+
+@pytest.mark.parametrize("case", sorted(PIK_CASES))
+def test_pik_kernel_matches_oracle(torch_cuda, case):
+    torch = torch_cuda
+    name, ff, specs, edit, projector_determined = PIK_CASES[case]
+    B = 300  # not a multiple of 64
+    ik_amd, O, model, problem, _, om, ot, q0, tg = build(name, ff, specs, B, seed=4, xml_edit=edit)
+    levels = problem.max_priority_level() + 1
+    Q0 = torch.from_numpy(np.ascontiguousarray(q0.T)).cuda()
+    T = torch.from_numpy(np.ascontiguousarray(tg.transpose(1, 2, 0))).cuda()
+    for iters, step, tol, lam, da in ((1, 1.0, -1.0, [1.0] * levels, None),
+                                      (4, 1.0, -1.0, [0.1] * levels, None),
+                                      (30, 0.5, 1e-8, [0.05, 0.1, 0.2][:levels], None),
+                                      (6, 1.0, -1.0, [0.1] * levels, 0.01 * np.cos(np.arange(model.nv)))):
+        if da is not None and not projector_determined:
+            continue
+        data = _pik_data(ik_amd, problem, lam, da)
+        assert data.kernel.startswith("pik_generic<")
+        p = ik_amd.pik_parameters(max_iterations=iters, step_length=step)
+        visitor = ik_amd.inverse_kinematics_visitor(tol)
+        Q, ok, it = ik_amd.pik_batch(problem, Q0, T, data, visitor, p)
+        q_ref, ok_ref, it_ref = O.pik_batch(om, ot, tg, q0, O.pik_params(iters, step, tol, lam, None if da is None else list(da)), os.cpu_count() or 1)
+        assert np.array_equal(ok.cpu().numpy(), ok_ref) and np.array_equal(it.cpu().numpy(), it_ref), (case, iters)
+        assert np.abs(Q.cpu().numpy().T - q_ref).max() <= TOL, (case, iters)
+    # array-of-structures input gives the same bits; so does the host-pointer entry point
+    Qa, oka, ita = ik_amd.pik_batch(problem, torch.from_numpy(q0).cuda(), torch.from_numpy(tg).cuda(), data, visitor, p, layout="aos")
+    assert torch.equal(Q.T.contiguous(), Qa) and torch.equal(ok, oka) and torch.equal(it, ita)
+    Qh, okh, ith = ik_amd.pik_batch(problem, q0, tg, data, visitor, p, layout="aos")
+    assert np.array_equal(Qh, Qa.cpu().numpy()) and np.array_equal(okh, oka.cpu().numpy()) and np.array_equal(ith, ita.cpu().numpy())
+
+
+def test_pik_with_one_level_is_dls_with_damping_lambda(torch_cuda):
+    """One priority level: pik's step is -J^T (J J^T + lambda^2 I)^-1 e, i.e. ik::dls with damping = lambda -- here the
+    register-resident DLS kernel and the generic PIK kernel, on the same problem handle."""
+    torch = torch_cuda
+    ik_amd, O, model, problem, _, om, ot, q0, tg = build("cassie_fixed", False, [("frame", "LeftFootFront", "universe", 2, 0, None)], 512, seed=6)
+    data = _pik_data(ik_amd, problem, [1e-2])
+    Q0 = torch.from_numpy(np.ascontiguousarray(q0.T)).cuda()
+    T = torch.from_numpy(np.ascontiguousarray(tg.transpose(1, 2, 0))).cuda()
+    v = ik_amd.inverse_kinematics_visitor(1e-10)
+    Qp, okp, itp = ik_amd.pik_batch(problem, Q0, T, data, v, ik_amd.pik_parameters(max_iterations=25))
+    Qd, okd, itd = ik_amd.dls_batch(problem, Q0, T, data, v, ik_amd.dls_parameters(max_iterations=25, damping=1e-2))
+    assert torch.equal(okp, okd) and torch.equal(itp, itd)
+    assert (Qp - Qd).abs().max().item() < 1e-8
+
+
+def test_single_problem_pik_with_edited_lambda_and_da(torch_cuda):
+    """ik::pik() as a caller of the reference would use it: pik_data owns lambda and da and both are read at every call."""
+    import ik_amd
+    import oracle as O
+    model = ik_amd.Model.from_urdf_file(urdf_path("cassie_fixed"))
+    problem = ik_amd.InverseKinematicsProblem(model, 1)
+    left = problem.add_frame_task("left", ik_amd.FrameTask.create(model, "LeftFootFront", ik_amd.KinematicType.Full))
+    right = problem.add_frame_task("right", ik_amd.FrameTask.create(model, "RightFootFront", ik_amd.KinematicType.Position), 1)
+    data = ik_amd.pik_data(problem)
+    assert data.lambda_ == [1.0, 1.0] and not data.da.any()
+    om = O.OracleModel(model.flat())
+    rng = np.random.default_rng(8)
+    q = q_ref = np.clip(rng.uniform(-0.2, 0.2, model.nq), model.lowerPositionLimit, model.upperPositionLimit)
+    qs = np.clip(q + rng.uniform(-0.15, 0.15, model.nq), model.lowerPositionLimit, model.upperPositionLimit)
+    oMf = O.fk(om, qs)[1]
+    left.target = ik_amd.SE3.from12(oMf[model.getFrameId("LeftFootFront")])
+    right.target = ik_amd.SE3.from12(oMf[model.getFrameId("RightFootFront")])
+    ot = O.make_tasks([(model.getFrameId("LeftFootFront"), 0, 2, 0, None), (model.getFrameId("RightFootFront"), 0, 0, 1, None)])
+    tg = np.stack([left.target.to12(), right.target.to12()])
+    p = ik_amd.pik_parameters(max_iterations=20, step_length=0.7)
+    for lam, da in (([1.0, 1.0], None), ([0.05, 0.3], None), ([0.05, 0.3], 0.02 * np.sin(np.arange(model.nv)))):
+        data.lambda_ = lam
+        data.da = np.zeros(model.nv) if da is None else da
+        q = ik_amd.pik(problem, q, data, ik_amd.inverse_kinematics_visitor(1e-9), p)
+        q_ref, ok_ref, it_ref = O.pik(om, ot, tg, q_ref, O.pik_params(20, 0.7, 1e-9, lam, None if da is None else list(da)))
+        assert data.success == ok_ref and data.iterations == it_ref
+        assert np.abs(q - q_ref).max() <= TOL
+
+
+def test_pik_argument_errors(torch_cuda):
+    import ik_amd
+    from ik_amd import capi
+    model = ik_amd.Model.from_urdf_file(urdf_path("ur5"))
+    problem = ik_amd.InverseKinematicsProblem(model, 1)
+    problem.add_frame_task("a", ik_amd.FrameTask.create(model, "tool0", ik_amd.KinematicType.Position))
+    problem.add_frame_task("b", ik_amd.FrameTask.create(model, "tool0", ik_amd.KinematicType.Orientation), 1)
+    data = ik_amd.pik_data(problem)
+    q0, tg = np.zeros((1, model.nq)), np.zeros((1, 2, 12))
+    tg[:, :, [0, 4, 8]] = 1.0
+    data.lambda_ = [1.0]                       # one level short
+    with pytest.raises(capi.IkgpuError) as ei:
+        ik_amd.pik_batch(problem, q0, tg, data, layout="aos")
+    assert ei.value.code == capi.ERR_INVALID and "priority levels" in ei.value.message
+    data.lambda_ = [1.0, -0.5]
+    with pytest.raises(capi.IkgpuError):
+        ik_amd.pik_batch(problem, q0, tg, data, layout="aos")
+    data.lambda_ = [1.0, 1.0]
+    Q, ok, it = ik_amd.pik_batch(problem, np.zeros((0, model.nq)), np.zeros((0, 2, 12)), data, layout="aos")   # empty batch
+    assert Q.shape == (0, model.nq)
+    p = ik_amd.pik_parameters(max_iterations=0)
+    Q, ok, it = ik_amd.pik_batch(problem, q0 + 0.3, tg, data, p=p, layout="aos")
+    assert np.array_equal(Q, q0 + 0.3) and ok[0] == 0 and it[0] == 0
+
+
+def test_cpp_api_program_with_pik(torch_cuda):
+    """ik::pik through the C++ mirror (tests/cpp/test_dls_api.cpp's `pik` option)."""
+    import json
+    import subprocess
+    import ik_amd
+    import oracle as O
+    from test_gpu_parity import _cpp_binary
+    model = ik_amd.Model.from_urdf_file(urdf_path("ur5"))
+    om = O.OracleModel(model.flat())
+    rng = np.random.default_rng(12)
+    q0 = np.array([0.1, -1.4, 1.5, 0.1, 1.4, 0.05]) + rng.uniform(-0.1, 0.1, 6)
+    qs = q0 + rng.uniform(-0.15, 0.15, 6)
+    fid = model.getFrameId("tool0")
+    tg = np.stack([O.fk(om, qs)[1][fid]] * 2)
+    ot = O.make_tasks([(fid, 0, 0, 0, None), (fid, 0, 1, 1, None)])
+    args = [_cpp_binary(), urdf_path("ur5"), "0", "30", "0.01", "1.0", "1e-10", "2"]
+    for typ, prio in ((0, 0), (1, 1)):
+        args += ["tool0", str(typ), str(prio)] + ["%.17g" % x for x in tg[0]]
+    args += ["%.17g" % x for x in q0] + ["pik", "0.05", "0.1"]
+    out = json.loads(subprocess.check_output(args, text=True))
+    q1, ok1, it1 = O.pik(om, ot, tg, q0, O.pik_params(30, 1.0, 1e-10, [0.05, 0.1]))
+    q2, ok2, it2 = O.pik(om, ot, tg, q1, O.pik_params(30, 1.0, 1e-10, [0.05, 0.1]))
+    assert np.abs(np.array(out["q_first"]) - q1).max() <= TOL and np.abs(np.array(out["q"]) - q2).max() <= TOL
+    assert out["success"] == int(ok2) and out["iterations"] == it2

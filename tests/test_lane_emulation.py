@@ -21,7 +21,7 @@ def emu(native_built):
     deps = [src] + [os.path.join(ROOT, "ik_amd", "csrc", f) for f in
                     ("model.cpp", "problem.cpp", "model.hpp", "problem.hpp", "device/lane_math.hpp",
                      "device/chain_solver.hpp", "device/chain_kernel_body.hpp", "device/tree_solver.hpp",
-                     "device/tree_kernel_body.hpp")]
+                     "device/tree_kernel_body.hpp", "device/generic_solver.hpp", "device/pik_solver.hpp", "generic_tables.hpp")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
                                "-I" + os.path.join(ROOT, "ik_amd", "csrc"), "-o", out, src,
@@ -320,4 +320,80 @@ def test_generic_and_specialised_programs_agree(emu):
     prm = capi.DlsParams(50, 1e-2, 1.0, -1.0)
     qa, *_ = run(emu, urdf, task, 0, q0, tg, prm, model.nv, 6)
     qb, *_ = run(emu, urdf, task, 0, q0, tg, prm, model.nv, 6, root=2)
+    assert np.abs(qa - qb).max() < 1e-9
+
+
+# ---------------------------------------------------------------------------------------------------
+# ik::pik -- prioritised IK on the generic lane program (device/pik_solver.hpp vs oracle iko_pik)
+# ---------------------------------------------------------------------------------------------------
+def run_pik(L, urdf, tasks, q0, tg, prm, root=0):
+    B = q0.shape[0]
+    qo = np.empty_like(q0)
+    ok, it = np.zeros(B, np.uint8), np.zeros(B, np.int32)
+    p = lambda a: C.c_void_p(a.ctypes.data)
+    rc = L.lane_emu_pik(urdf, C.c_size_t(len(urdf)), root, tasks, len(tasks), C.c_int64(B), p(q0), p(tg), C.byref(prm), p(qo), p(ok), p(it), 1)
+    assert rc == 0, L.lane_emu_last_error()
+    return qo, ok, it
+
+
+def pik_prm(iters, step, tol, lam, da=None):
+    from ik_amd import capi
+    prm = capi.PikParams()
+    prm.max_iterations, prm.step_length, prm.stop_sq_tol, prm.num_levels = iters, step, tol, len(lam)
+    for i, l in enumerate(lam):
+        prm.lam[i] = l
+    if da is not None:
+        prm._da = (C.c_double * len(da))(*da)
+        prm.da = C.cast(prm._da, C.POINTER(C.c_double))
+    return prm
+
+
+# Last field: is the projector left by the LAST level well determined?  When the projected Jacobian of a level is exactly
+# rank deficient, its surplus singular values are rounding noise of a few eps * cond(previous levels), the same size as the
+# rank threshold the reference inherits from Eigen (eps * min(rows, cols)): whether a noise direction is removed from P is
+# then decided by rounding, in the reference as much as here.  dq before `P da` does not depend on it (a noise direction
+# carries a factor sigma / (lambda^2 + sigma^2) ~ 1e-13), so those cases are compared with da = 0 only.
+PIK_CASES = {
+    # position first, orientation in its null space (6-DoF arm: level 1 gets the 3 remaining dof)
+    "ur5_pos_then_ori": ("ur5", False, [("tool0", "universe", 0, 0, None), ("tool0", "universe", 1, 1, None)], 0, None, True),
+    # a full pose exhausts the arm: level 1 sees a numerically-zero projected Jacobian
+    "ur5_full_then_elbow": ("ur5", False, [("tool0", "universe", 2, 0, None), ("forearm_link", "universe", 0, 1, None)], 0, None, False),
+    "fixed_two_feet": ("cassie_fixed", False, [("LeftFootFront", "universe", 2, 0, None),
+                                               ("RightFootFront", "universe", 0, 1, [1.0, 2.0, 0.5])], 0, None, True),
+    # the demo's tasks split over two levels, then a posture regulariser at the third
+    "demo_three_levels": ("cassie", True, [("LeftFootFront", "pelvis", 0, 0, None), ("pelvis", "universe", 2, 0, None),
+                                           ("LeftFootFront", "universe", 4, 1, None),
+                                           ("@posture", 16, 6, 2, ([0.5] * 16, [1.0] * 16))], 1, None, False),
+    "feet_then_pelvis": ("cassie", True, [("LeftFootFront", "universe", 2, 0, None), ("RightFootFront", "universe", 2, 0, None),
+                                          ("pelvis", "universe", 2, 1, None)], 1, None, False),
+    "single_level_prismatic": ("ur5", False, [("tool0", "upper_arm_link", 2, 0, None)], 0, _prismatic_elbow, True),
+}
+
+
+@pytest.mark.parametrize("case", sorted(PIK_CASES))
+def test_pik_program_matches_oracle(emu, case):
+    name, ff, specs, root, edit, projector_determined = PIK_CASES[case]
+    B = 16
+    urdf, model, om, tasks, ot, q0, tg, M = _generic_case(name, ff, specs, B, seed=3, xml_edit=edit)
+    levels = max(t.priority for t in tasks) + 1
+    for iters, step, tol, lam, da in ((1, 1.0, -1.0, [1.0] * levels, None),
+                                      (4, 1.0, -1.0, [0.1] * levels, None),
+                                      (30, 0.5, 1e-8, [0.05, 0.1, 0.2][:levels], None),
+                                      (6, 1.0, -1.0, [0.1] * levels, list(0.01 * np.cos(np.arange(model.nv))))):
+        if da is not None and not projector_determined:
+            continue
+        qo, ok, it = run_pik(emu, urdf, tasks, q0, tg, pik_prm(iters, step, tol, lam, da), root=root)
+        q_ref, ok_ref, it_ref = O.pik_batch(om, ot, tg, q0, O.pik_params(iters, step, tol, lam, da))
+        assert np.array_equal(ok, ok_ref) and np.array_equal(it, it_ref), (case, iters)
+        assert np.abs(qo - q_ref).max() < 1e-8, (case, iters, np.abs(qo - q_ref).max())
+
+
+def test_pik_with_one_level_and_small_lambda_is_dls(emu):
+    """With one priority level pik's step is J^T (J J^T + lambda^2 I)^-1 e -- ik::dls with damping = lambda."""
+    from ik_amd import capi
+    urdf, model, om, task, ot, q0, qs, tg = setup("cassie_fixed", "LeftFootFront", B=32)
+    tasks = (capi.Task * 1)(task)
+    qa, oka, ita = run_pik(emu, urdf, tasks, q0, tg, pik_prm(25, 1.0, 1e-10, [1e-2]))
+    qb, okb, itb, *_ = run(emu, urdf, task, 0, q0, tg, capi.DlsParams(25, 1e-2, 1.0, 1e-10), model.nv, 6)
+    assert np.array_equal(oka, okb) and np.array_equal(ita, itb)
     assert np.abs(qa - qb).max() < 1e-9
