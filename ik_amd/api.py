@@ -195,6 +195,38 @@ class PostureTask:
         return self._weighting
 
 
+class FrameConstraint:
+    """ik::FrameConstraint (reference ik/ik/frame.hpp:325-449): the frame may not move relative to its reference frame in
+    the selected coordinates.  ik::dls keeps its step in the null space of the constraint Jacobian (reference
+    ik/ik/dls.cpp:26-34,43-53); `target` is carried for source compatibility -- the loop never reads it."""
+
+    def __init__(self, model, frame, type=KinematicType.Full, reference_frame="universe"):
+        self.frame, self.reference_frame, self.type = frame, reference_frame, KinematicType(type)
+        self._frame_id, self._ref_id = model.getFrameId(frame), model.getFrameId(reference_frame)
+        if self._frame_id >= model.nframes:
+            raise ValueError("Frame not found in model: %s" % frame)
+        if self._ref_id >= model.nframes:
+            raise ValueError("Reference frame not found in model: %s" % reference_frame)
+        self.target = SE3.Identity()
+
+    @staticmethod
+    def create(model, frame, type=KinematicType.Full, reference_frame="universe"):
+        return FrameConstraint(model, frame, type, reference_frame)
+
+    def dimension(self):
+        return 6 if self.type == KinematicType.Full else 3
+
+
+def _constraint_table(problem):
+    cons = problem.get_all_constraints()
+    arr = (capi.Task * max(1, len(cons)))()
+    for i, c in enumerate(cons):
+        arr[i].frame, arr[i].reference, arr[i].type, arr[i].priority = c._frame_id, c._ref_id, int(c.type), 0
+        for k in range(6):
+            arr[i].weight[k] = 1.0
+    return arr, len(cons)
+
+
 def _abi_rows(task, prio):
     """The rows a task contributes to the ABI's task table: (frame, reference, type, priority, weight[6])."""
     if isinstance(task, PostureTask):
@@ -240,6 +272,8 @@ class InverseKinematicsProblem:
         self._axis_tasks_map = {}
         self._posture_tasks = []
         self._posture_tasks_map = {}
+        self._frame_constraints = []
+        self._frame_constraints_map = {}
         self._generation = 0
 
     def max_priority_level(self):
@@ -275,14 +309,23 @@ class InverseKinematicsProblem:
     def get_all_tasks(self, priority):
         return self._tasks[priority]
 
-    def get_all_constraints(self):
-        return []
+    def add_frame_constraint(self, name, constraint):  # reference ik/ik/problem.hpp:68-77
+        self._frame_constraints_map.setdefault(name, len(self._frame_constraints))
+        self._frame_constraints.append(constraint)
+        self._generation += 1
+        return constraint
+
+    def get_frame_constraint(self, name):
+        return self._frame_constraints[self._frame_constraints_map[name]]
+
+    def get_all_constraints(self):  # reference ik/ik/problem.hpp:167-173
+        return list(self._frame_constraints)
 
     def e_size(self, priority):
         return sum(t.dimension() for t in self._tasks[priority])
 
-    def c_size(self):
-        return 0
+    def c_size(self):  # reference ik/ik/problem.hpp:47-53
+        return sum(c.dimension() for c in self._frame_constraints)
 
     def ordered_tasks(self):
         """(task, priority) in the row order of the stacked system (reference ik/ik/dls.cpp:20-24)."""
@@ -350,8 +393,9 @@ class dls_data:
             return
         self._release()
         arr = _task_table(problem)
+        cons, ncons = _constraint_table(problem)
         h = C.c_void_p()
-        capi.check(capi.lib().ikgpu_problem_create(problem.model()._h, arr, len(arr), self._device, C.byref(h)))
+        capi.check(capi.lib().ikgpu_problem_create_constrained(problem.model()._h, arr, len(arr), cons, ncons, self._device, C.byref(h)))
         self._h = h
         self._generation = key
         self.rows = int(capi.lib().ikgpu_problem_rows(h))
@@ -373,8 +417,9 @@ def plan(problem):
     """Name of the kernel specialisation the problem maps to (host-only; raises IkgpuError when the
     shape has no device kernel)."""
     arr = _task_table(problem)
-    buf = C.create_string_buffer(128)
-    capi.check(capi.lib().ikgpu_problem_plan(problem.model()._h, arr, len(arr), buf, len(buf)))
+    cons, ncons = _constraint_table(problem)
+    buf = C.create_string_buffer(160)
+    capi.check(capi.lib().ikgpu_problem_plan_constrained(problem.model()._h, arr, len(arr), cons, ncons, buf, len(buf)))
     return buf.value.decode()
 
 

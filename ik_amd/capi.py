@@ -25,6 +25,7 @@ SYMBOLS = [
     "ikgpu_problem_plan",
     "ikgpu_dls_solve_batch", "ikgpu_dls_solve_batch_host", "ikgpu_evaluate_batch", "ikgpu_task_frames_fk_batch",
     "ikgpu_pik_params_default", "ikgpu_pik_solve_batch", "ikgpu_pik_solve_batch_host",
+    "ikgpu_problem_create_constrained", "ikgpu_problem_plan_constrained",
 ]
 MAX_PIK_LEVELS, MAX_PIK_DA = 8, 128
 
@@ -100,6 +101,8 @@ def lib():
     L.ikgpu_problem_kernel.argtypes = [vp]
     L.ikgpu_problem_kernel.restype = C.c_char_p
     L.ikgpu_problem_plan.argtypes = [vp, C.POINTER(Task), i32, C.c_char_p, sz]
+    L.ikgpu_problem_create_constrained.argtypes = [vp, C.POINTER(Task), i32, C.POINTER(Task), i32, i32, C.POINTER(vp)]
+    L.ikgpu_problem_plan_constrained.argtypes = [vp, C.POINTER(Task), i32, C.POINTER(Task), i32, C.c_char_p, sz]
     L.ikgpu_dls_solve_batch.argtypes = [vp, i64, vp, vp, C.POINTER(DlsParams), vp, vp, vp, C.c_int, vp]
     L.ikgpu_dls_solve_batch_host.argtypes = [vp, i64, vp, vp, C.POINTER(DlsParams), vp, vp, vp, C.c_int]
     L.ikgpu_pik_params_default.argtypes = [C.POINTER(PikParams), i32]
@@ -110,7 +113,8 @@ def lib():
     L.ikgpu_task_frames_fk_batch.argtypes = [vp, i64, vp, vp, C.c_int, vp]
     for name in ("ikgpu_model_from_urdf", "ikgpu_model_create", "ikgpu_model_get_flat", "ikgpu_problem_create",
                  "ikgpu_problem_plan", "ikgpu_dls_solve_batch", "ikgpu_dls_solve_batch_host", "ikgpu_evaluate_batch",
-                 "ikgpu_task_frames_fk_batch", "ikgpu_pik_solve_batch", "ikgpu_pik_solve_batch_host"):
+                 "ikgpu_task_frames_fk_batch", "ikgpu_pik_solve_batch", "ikgpu_pik_solve_batch_host",
+                 "ikgpu_problem_create_constrained", "ikgpu_problem_plan_constrained"):
         getattr(L, name).restype = C.c_int
     if L.ikgpu_abi_version() != 1:
         raise ImportError("libikgpu.so ABI version mismatch")

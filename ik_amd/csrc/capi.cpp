@@ -33,9 +33,10 @@ bool shape_built(const ikgpu::ProblemHost &ph) {
 
 // Analysis + the "is this specialisation compiled" check; a specialised shape without an instantiation
 // falls back to the generic kernel.  Throws std::runtime_error on invalid input.
-ikgpu::ProblemHost analyse(const ikgpu::Model &m, const ikgpu_task *tasks, int32_t ntasks) {
-    ikgpu::ProblemHost ph = ikgpu::analyse_problem(m, tasks, ntasks);
-    if (!shape_built(ph)) ph = ikgpu::analyse_problem(m, tasks, ntasks, /*force_generic=*/true);
+ikgpu::ProblemHost analyse(const ikgpu::Model &m, const ikgpu_task *tasks, int32_t ntasks, const ikgpu_task *cons = nullptr,
+                           int32_t ncons = 0) {
+    ikgpu::ProblemHost ph = ikgpu::analyse_problem(m, tasks, ntasks, false, cons, ncons);
+    if (!shape_built(ph)) ph = ikgpu::analyse_problem(m, tasks, ntasks, /*force_generic=*/true, cons, ncons);
     return ph;
 }
 
@@ -216,12 +217,20 @@ int32_t ikgpu_model_joint_id(const ikgpu_model *h, const char *name) {
 
 int ikgpu_problem_create(const ikgpu_model *h, const ikgpu_task *tasks, int32_t ntasks, int32_t device,
                          ikgpu_problem **out) {
-    if (!h || !tasks || !out) return fail(IKGPU_ERR_INVALID, "null argument");
+    return ikgpu_problem_create_constrained(h, tasks, ntasks, nullptr, 0, device, out);
+}
+
+int ikgpu_problem_create_constrained(const ikgpu_model *h, const ikgpu_task *tasks, int32_t ntasks, const ikgpu_task *constraints,
+                                     int32_t nconstraints, int32_t device, ikgpu_problem **out) {
+    if (!h || !tasks || !out || (nconstraints > 0 && !constraints)) return fail(IKGPU_ERR_INVALID, "null argument");
+    if (nconstraints < 0) return fail(IKGPU_ERR_INVALID, "negative constraint count");
     *out = nullptr;
     ikgpu::ProblemHost ph, gen;
     try {
-        ph = analyse(h->m, tasks, ntasks);
-        gen = ph.kind == ikgpu::KernelKind::Generic ? ph : ikgpu::analyse_problem(h->m, tasks, ntasks, /*force_generic=*/true);
+        ph = analyse(h->m, tasks, ntasks, constraints, nconstraints);
+        gen = ph.kind == ikgpu::KernelKind::Generic
+                  ? ph
+                  : ikgpu::analyse_problem(h->m, tasks, ntasks, /*force_generic=*/true, constraints, nconstraints);
     } catch (const std::exception &e) {
         return fail(IKGPU_ERR_INVALID, e.what());
     }
@@ -270,9 +279,15 @@ int ikgpu_problem_create(const ikgpu_model *h, const ikgpu_task *tasks, int32_t 
 }
 
 int ikgpu_problem_plan(const ikgpu_model *h, const ikgpu_task *tasks, int32_t ntasks, char *out, size_t cap) {
-    if (!h || !tasks) return fail(IKGPU_ERR_INVALID, "null argument");
+    return ikgpu_problem_plan_constrained(h, tasks, ntasks, nullptr, 0, out, cap);
+}
+
+int ikgpu_problem_plan_constrained(const ikgpu_model *h, const ikgpu_task *tasks, int32_t ntasks, const ikgpu_task *constraints,
+                                   int32_t nconstraints, char *out, size_t cap) {
+    if (!h || !tasks || (nconstraints > 0 && !constraints)) return fail(IKGPU_ERR_INVALID, "null argument");
+    if (nconstraints < 0) return fail(IKGPU_ERR_INVALID, "negative constraint count");
     try {
-        const ikgpu::ProblemHost ph = analyse(h->m, tasks, ntasks);
+        const ikgpu::ProblemHost ph = analyse(h->m, tasks, ntasks, constraints, nconstraints);
         if (out && cap) {
             std::strncpy(out, ph.kernel_name.c_str(), cap - 1);
             out[cap - 1] = '\0';

@@ -37,6 +37,11 @@ struct GenericTables {
     int nlevels;
     const int *lvl_row0;                        // [nlevels + 1]
     int off_P, off_Jb, off_de, ws_words_pik;
+    // ik::FrameConstraint rows (ik/ik/frame.hpp:325-449), projected out of the DLS step (ik/ik/dls.cpp:26-34,43-53)
+    int ncons, Mc;
+    const int *c_type, *c_fjoint, *c_rjoint, *c_row, *c_dim;  // [ncons]
+    const double *c_fpl, *c_rpl;                               // [ncons][12]
+    int off_Jc;                                                // Mc x nv, inside the first ws_words words
 };
 
 struct Ws {  // word w of this lane
@@ -209,6 +214,131 @@ IKD_FN double generic_evaluate(const GenericTables &T, const Ws &ws, const doubl
     return e0sq;
 }
 
+// Column c of pinocchio::getFrameJacobian(..., LOCAL) for a frame placed at (Rf, pf) in the world, from the world joint
+// Jacobian in the workspace: linear part vl, angular part wl.
+IKD_FN void local_column(const GenericTables &T, const Ws &ws, int c, const double (&Rf)[9], const double (&pf)[3], double (&vl)[3],
+                         double (&wl)[3]) {
+    double v[3] = {ws[T.off_Jw + c], ws[T.off_Jw + T.nv + c], ws[T.off_Jw + 2 * T.nv + c]};
+    const double w[3] = {ws[T.off_Jw + 3 * T.nv + c], ws[T.off_Jw + 4 * T.nv + c], ws[T.off_Jw + 5 * T.nv + c]};
+    double pxw[3];
+    cross(pf, w, pxw);
+    v[0] -= pxw[0]; v[1] -= pxw[1]; v[2] -= pxw[2];
+    rotT_vec(Rf, v, vl);
+    rotT_vec(Rf, w, wl);
+}
+
+// Cyclic one-sided Jacobi on the m rows (length nv) stored at off_rows: plane rotations from the left until the rows are
+// mutually orthogonal, U^T A = diag(sigma) V^T, so that row i ends as sigma_i v_i^T.  A companion column at off_col
+// (length m; pass a negative offset for none) is rotated along and ends as U^T col.  Every lane of a wave runs the same
+// sweeps: a lane whose pair is already orthogonal applies the identity rotation, and the wave leaves on a uniform vote.
+template <class AnyFn>
+IKD_FN void jacobi_rows(const Ws &ws, int off_rows, int off_col, int m, int nv, AnyFn any_lane) {
+    const double eps = 2.220446049250313e-16;
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        bool rotated = false;
+        for (int a = 0; a < m - 1; ++a)
+            for (int b = a + 1; b < m; ++b) {
+                double al = 0.0, be = 0.0, ga = 0.0;
+                for (int c = 0; c < nv; ++c) {
+                    const double x = ws[off_rows + a * nv + c], y = ws[off_rows + b * nv + c];
+                    al = dfma(x, x, al);
+                    be = dfma(y, y, be);
+                    ga = dfma(x, y, ga);
+                }
+                const bool rot = __builtin_fabs(ga) > eps * __builtin_sqrt(al * be);
+                if (!any_lane(rot)) continue;
+                const double zeta = (be - al) / (2.0 * ga);
+                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (__builtin_fabs(zeta) + __builtin_sqrt(dfma(zeta, zeta, 1.0)));
+                const double c0 = 1.0 / __builtin_sqrt(dfma(t, t, 1.0));
+                const double cs = dsel(rot, c0, 1.0), sn = dsel(rot, c0 * t, 0.0);
+                for (int c = 0; c < nv; ++c) {
+                    const double x = ws[off_rows + a * nv + c], y = ws[off_rows + b * nv + c];
+                    ws[off_rows + a * nv + c] = dfma(cs, x, -sn * y);
+                    ws[off_rows + b * nv + c] = dfma(sn, x, cs * y);
+                }
+                if (off_col >= 0) {
+                    const double x = ws[off_col + a], y = ws[off_col + b];
+                    ws[off_col + a] = dfma(cs, x, -sn * y);
+                    ws[off_col + b] = dfma(sn, x, cs * y);
+                }
+                rotated = rotated || rot;
+            }
+        if (!any_lane(rotated)) break;
+    }
+}
+
+// ik::FrameConstraint::compute_jacobian (ik/ik/frame.hpp:413-449) for every constraint, into the workspace (Jc, Mc x nv):
+// the velocity of the frame relative to its reference frame, in the frame's local coordinates:
+//   Jc = J_frame(LOCAL) - Ad(fMr) J_reference(LOCAL),  rows by kinematic type.   Needs oMi and Jw (generic_fk).
+IKD_FN void generic_constraint_jacobian(const GenericTables &T, const Ws &ws) {
+    for (int k = 0; k < T.ncons; ++k) {
+        const int fj = T.c_fjoint[k], rj = T.c_rjoint[k], row = T.c_row[k], dim = T.c_dim[k];
+        const int r0 = (T.c_type[k] == GT_ORIENTATION) ? 3 : 0;
+        double oJ[12], oMf[12], oMr[12], fMr[12];
+        for (int i = 0; i < 12; ++i) oJ[i] = ws[T.off_oMi + 12 * fj + i];
+        g_se3_mul(oJ, T.c_fpl + 12 * k, oMf);
+        for (int i = 0; i < 12; ++i) oJ[i] = ws[T.off_oMi + 12 * rj + i];
+        g_se3_mul(oJ, T.c_rpl + 12 * k, oMr);
+        g_se3_inv_mul(oMf, oMr, fMr);
+        for (int r = 0; r < dim; ++r)
+            for (int c = 0; c < T.nv; ++c) ws[T.off_Jc + (row + r) * T.nv + c] = 0.0;
+        const double Rf[9] = {oMf[0], oMf[1], oMf[2], oMf[3], oMf[4], oMf[5], oMf[6], oMf[7], oMf[8]};
+        const double pf[3] = {oMf[9], oMf[10], oMf[11]};
+        for (int j = fj; j > 0; j = T.parent[j]) {
+            const int n = T.jtype[j] == GJ_FREEFLYER ? 6 : 1;
+            for (int c = T.idx_v[j]; c < T.idx_v[j] + n; ++c) {
+                double vl[3], wl[3];
+                local_column(T, ws, c, Rf, pf, vl, wl);
+                const double out[6] = {vl[0], vl[1], vl[2], wl[0], wl[1], wl[2]};
+                for (int r = 0; r < dim; ++r) ws[T.off_Jc + (row + r) * T.nv + c] = out[r0 + r];
+            }
+        }
+        const double Rr[9] = {oMr[0], oMr[1], oMr[2], oMr[3], oMr[4], oMr[5], oMr[6], oMr[7], oMr[8]};
+        const double pr[3] = {oMr[9], oMr[10], oMr[11]};
+        const double Rx[9] = {fMr[0], fMr[1], fMr[2], fMr[3], fMr[4], fMr[5], fMr[6], fMr[7], fMr[8]};
+        const double px[3] = {fMr[9], fMr[10], fMr[11]};
+        for (int j = rj; j > 0; j = T.parent[j]) {
+            const int n = T.jtype[j] == GJ_FREEFLYER ? 6 : 1;
+            for (int c = T.idx_v[j]; c < T.idx_v[j] + n; ++c) {
+                double vr[3], wr[3], Rv[3], Rw[3], pxRw[3];
+                local_column(T, ws, c, Rr, pr, vr, wr);
+                for (int i = 0; i < 3; ++i) {   // Ad(fMr) [v; w] = [R v + p x (R w); R w]
+                    Rv[i] = dfma(Rx[3 * i], vr[0], dfma(Rx[3 * i + 1], vr[1], Rx[3 * i + 2] * vr[2]));
+                    Rw[i] = dfma(Rx[3 * i], wr[0], dfma(Rx[3 * i + 1], wr[1], Rx[3 * i + 2] * wr[2]));
+                }
+                cross(px, Rw, pxRw);
+                const double out[6] = {Rv[0] + pxRw[0], Rv[1] + pxRw[1], Rv[2] + pxRw[2], Rw[0], Rw[1], Rw[2]};
+                for (int r = 0; r < dim; ++r) ws[T.off_Jc + (row + r) * T.nv + c] -= out[r0 + r];
+            }
+        }
+    }
+}
+
+// v <- (I - pinv(A) A) v for the m x nv matrix stored at off_rows (destroyed): ik/ik/dls.cpp:43-53's N applied to a vector.
+// Rank as Eigen's COD counts it, relative to the largest value: sigma_i > eps * min(m, nv) * sigma_max (see pik_solver.hpp).
+template <class AnyFn>
+IKD_FN void project_out_rowspace(const Ws &ws, int off_rows, int m, int nv, int off_vec, AnyFn any_lane) {
+    jacobi_rows(ws, off_rows, -1, m, nv, any_lane);
+    double smax2 = 0.0;
+    for (int i = 0; i < m; ++i) {
+        double s2 = 0.0;
+        for (int c = 0; c < nv; ++c) { const double x = ws[off_rows + i * nv + c]; s2 = dfma(x, x, s2); }
+        smax2 = dmax(smax2, s2);
+    }
+    const double kk = 2.220446049250313e-16 * static_cast<double>(m < nv ? m : nv);
+    const double thr2 = kk * kk * smax2;
+    for (int i = 0; i < m; ++i) {
+        double s2 = 0.0, d = 0.0;
+        for (int c = 0; c < nv; ++c) {
+            const double x = ws[off_rows + i * nv + c];
+            s2 = dfma(x, x, s2);
+            d = dfma(x, ws[off_vec + c], d);
+        }
+        const double f = dsel(s2 > thr2, d / s2, 0.0);
+        for (int c = 0; c < nv; ++c) ws[off_vec + c] = dfma(-f, ws[off_rows + i * nv + c], ws[off_vec + c]);
+    }
+}
+
 // q <- clip(integrate(q, step * dq)) on the workspace (pinocchio::integrate + apply_joint_clipping,
 // ik/ik/common.hpp:53-56); a lane that is no longer active keeps its q.
 IKD_FN void generic_integrate_clip(const GenericTables &T, const Ws &ws, double step_length, bool active) {
@@ -274,6 +404,10 @@ IKD_FN void generic_dls(const GenericTables &T, const LoopParams &prm, const Ws 
             double s = 0.0;
             for (int r = 0; r < M; ++r) s = dfma(ws[T.off_J + r * nv + c], ws[T.off_y + r], s);
             ws[T.off_dq + c] = -s;
+        }
+        if (T.Mc > 0) {  // dq <- N dq, N = I - pinv(Jc) Jc: the step stays in the null space of the constraints (dls.cpp:26-34,43-53)
+            generic_constraint_jacobian(T, ws);
+            project_out_rowspace(ws, T.off_Jc, T.Mc, nv, T.off_dq, any_active);
         }
         const bool stop_now = active && (prm.stop_sq_tol >= 0.0) && (e0sq < prm.stop_sq_tol);
         if (stop_now) { success = true; iters = it; }

@@ -25,7 +25,6 @@ namespace ikdev {
 
 constexpr int kMaxPikLevels = 8;    // == IKGPU_MAX_PIK_LEVELS
 constexpr int kMaxPikDa = 128;      // == IKGPU_MAX_PIK_DA: longest da carried by value in the kernel arguments
-constexpr int kPikMaxSweeps = 40;
 
 struct PikParams {
     int max_iterations;
@@ -34,8 +33,6 @@ struct PikParams {
     int has_da;
     double da[kMaxPikDa];
 };
-
-IKD_FN double pik_abs(double x) { return __builtin_fabs(x); }
 
 // One priority level on the workspace: rows [r0, r0 + ml) of (e, J).  Updates dq and, when asked, P.
 template <class AnyFn>
@@ -52,36 +49,7 @@ IKD_FN void pik_level(const GenericTables &T, const Ws &ws, int r0, int ml, doub
             ws[T.off_Jb + r * nv + c] = a;
         }
     }
-    // cyclic one-sided Jacobi on the rows of [Jb | de]
-    for (int sweep = 0; sweep < kPikMaxSweeps; ++sweep) {
-        bool rotated = false;
-        for (int a = 0; a < ml - 1; ++a)
-            for (int b = a + 1; b < ml; ++b) {
-                double al = 0.0, be = 0.0, ga = 0.0;
-                for (int c = 0; c < nv; ++c) {
-                    const double x = ws[T.off_Jb + a * nv + c], y = ws[T.off_Jb + b * nv + c];
-                    al = dfma(x, x, al);
-                    be = dfma(y, y, be);
-                    ga = dfma(x, y, ga);
-                }
-                const bool rot = pik_abs(ga) > eps * __builtin_sqrt(al * be);
-                if (!any_lane(rot)) continue;
-                const double zeta = (be - al) / (2.0 * ga);
-                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (pik_abs(zeta) + __builtin_sqrt(dfma(zeta, zeta, 1.0)));
-                const double c0 = 1.0 / __builtin_sqrt(dfma(t, t, 1.0));
-                const double cs = dsel(rot, c0, 1.0), sn = dsel(rot, c0 * t, 0.0);
-                for (int c = 0; c < nv; ++c) {
-                    const double x = ws[T.off_Jb + a * nv + c], y = ws[T.off_Jb + b * nv + c];
-                    ws[T.off_Jb + a * nv + c] = dfma(cs, x, -sn * y);
-                    ws[T.off_Jb + b * nv + c] = dfma(sn, x, cs * y);
-                }
-                const double x = ws[T.off_de + a], y = ws[T.off_de + b];
-                ws[T.off_de + a] = dfma(cs, x, -sn * y);
-                ws[T.off_de + b] = dfma(sn, x, cs * y);
-                rotated = rotated || rot;
-            }
-        if (!any_lane(rotated)) break;
-    }
+    jacobi_rows(ws, T.off_Jb, T.off_de, ml, nv, any_lane);  // rows of [Jb | de]
     // sigma_i^2 = |row_i|^2, recomputed where it is used (the rows are short)
     double smax2 = 0.0;
     for (int i = 0; i < ml; ++i) {

@@ -19,6 +19,10 @@ inline ikdev::GenericTables bind_generic_tables(const ProblemHost &ph, const int
     T.off_q = g.off_q; T.off_oMi = g.off_oMi; T.off_Jw = g.off_Jw; T.off_e = g.off_e; T.off_J = g.off_J;
     T.off_G = g.off_G; T.off_y = g.off_y; T.off_dq = g.off_dq; T.ws_words = g.ws_words;
     T.nlevels = g.nlevels; T.lvl_row0 = ibase + g.o_lvlrow0;
+    T.ncons = static_cast<int>(ph.constraints.size()); T.Mc = ph.crows;
+    T.c_type = ibase + g.o_ctype; T.c_fjoint = ibase + g.o_cfjoint; T.c_rjoint = ibase + g.o_crjoint;
+    T.c_row = ibase + g.o_crow; T.c_dim = ibase + g.o_cdim;
+    T.c_fpl = dbase + g.o_cfpl; T.c_rpl = dbase + g.o_crpl; T.off_Jc = g.off_Jc;
     T.off_P = g.off_P; T.off_Jb = g.off_Jb; T.off_de = g.off_de; T.ws_words_pik = g.ws_words_pik;
     return T;
 }

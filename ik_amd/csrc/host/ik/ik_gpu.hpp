@@ -312,6 +312,57 @@ class AlignAxisTask : public SingleRowTask {
     string_t frame_, reference_frame_;
 };
 
+// ---- ik::Constraint / ik::FrameConstraint (ik/ik/constraint.hpp; ik/ik/frame.hpp:325-449) -------------
+// The frame may not move relative to its reference frame in the selected coordinates: ik::dls keeps its step in the
+// null space of the stacked constraint Jacobian (ik/ik/dls.cpp:26-34,43-53).  `target` is never read by the loop.
+class Constraint {
+   public:
+    virtual ~Constraint() = default;
+    index_t dimension() const { return dimension_; }
+    virtual ikgpu_task abi_record() const = 0;
+
+   protected:
+    void set_dimension(const index_t &dimension) { dimension_ = dimension; }
+
+   private:
+    index_t dimension_ = 0;
+};
+
+class FrameConstraint : public Constraint {
+   public:
+    FrameConstraint(const model_t &model, const string_t &frame, const KinematicType &type = KinematicType::Full,
+                    const string_t &reference_frame = "universe")
+        : target(se3_t::Identity()), type_(type), frame_(frame), reference_frame_(reference_frame) {
+        frame_id_ = model.getFrameId(frame);
+        reference_id_ = model.getFrameId(reference_frame);
+        if (frame_id_ >= static_cast<index_t>(model.nframes)) throw std::invalid_argument("Frame not found in model: " + frame);
+        if (reference_id_ >= static_cast<index_t>(model.nframes))
+            throw std::invalid_argument("Reference frame not found in model: " + reference_frame);
+        set_dimension(type == KinematicType::Full ? 6 : 3);
+    }
+    static std::shared_ptr<FrameConstraint> create(const model_t &model, const string_t &frame,
+                                                   const KinematicType &type = KinematicType::Full,
+                                                   const string_t &reference_frame = "universe") {
+        return std::make_shared<FrameConstraint>(model, frame, type, reference_frame);
+    }
+    se3_t target;
+
+    ikgpu_task abi_record() const override {
+        ikgpu_task k;
+        k.frame = static_cast<int32_t>(frame_id_);
+        k.reference = static_cast<int32_t>(reference_id_);
+        k.type = type_ == KinematicType::Position ? IKGPU_POSITION : type_ == KinematicType::Orientation ? IKGPU_ORIENTATION : IKGPU_FULL;
+        k.priority = 0;
+        for (double &w : k.weight) w = 1.0;
+        return k;
+    }
+
+   protected:
+    KinematicType type_;
+    string_t frame_, reference_frame_;
+    index_t frame_id_ = 0, reference_id_ = 0;
+};
+
 // ---- ik::PostureTask (ik/ik/posture.hpp:17-85) --------------------------------------------------
 // e = (q.bottomRows(nj) - target) .* mask, J.rightCols(nj) = I (the reference leaves the mask out of J).  Crosses the
 // ABI as nj one-row tasks of type IKGPU_POSTURE_ROW; runs on the generic device kernel.
@@ -366,7 +417,25 @@ class InverseKinematicsProblem {
         for (const auto &task : get_all_tasks(priority)) sz += task->dimension();
         return sz;
     }
-    std::size_t c_size() const { return 0; }
+    std::size_t c_size() const {  // problem.hpp:47-53
+        std::size_t sz = 0;
+        for (const auto &c : frame_constraints_) sz += c->dimension();
+        return sz;
+    }
+    std::shared_ptr<FrameConstraint> add_frame_constraint(const string_t &name, const std::shared_ptr<FrameConstraint> &constraint) {
+        frame_constraints_map_.insert({name, frame_constraints_.size()});  // problem.hpp:68-77
+        frame_constraints_.push_back(constraint);
+        ++generation_;
+        return frame_constraints_.back();
+    }
+    std::shared_ptr<FrameConstraint> get_frame_constraint(const string_t &name) {
+        auto it = frame_constraints_map_.find(name);
+        if (it == frame_constraints_map_.end()) throw std::out_of_range("Frame constraint does not exist: " + name);
+        return frame_constraints_.at(it->second);
+    }
+    std::vector<std::shared_ptr<Constraint>> get_all_constraints() const {  // problem.hpp:167-173
+        return std::vector<std::shared_ptr<Constraint>>(frame_constraints_.begin(), frame_constraints_.end());
+    }
 
     std::shared_ptr<FrameTask> add_frame_task(const string_t &name, const std::shared_ptr<FrameTask> &task,
                                               const std::size_t &priority = 0) {
@@ -425,6 +494,8 @@ class InverseKinematicsProblem {
     std::unordered_map<string_t, std::size_t> axis_tasks_map_;
     std::vector<std::shared_ptr<PostureTask>> posture_tasks_;
     std::unordered_map<string_t, std::size_t> posture_tasks_map_;
+    std::vector<std::shared_ptr<FrameConstraint>> frame_constraints_;
+    std::unordered_map<string_t, std::size_t> frame_constraints_map_;
     std::size_t generation_ = 0;
 };
 
@@ -471,21 +542,25 @@ class dls_data {
         std::vector<ikgpu_task> tasks;
         for (std::size_t p = 0; p <= problem.max_priority_level(); ++p)  // stacking order of ik/ik/dls.cpp:20-24
             for (const auto &t : problem.get_all_tasks(p)) t->abi_rows(static_cast<int32_t>(p), tasks);
-        if (h_ && same(tasks)) return;
+        std::vector<ikgpu_task> constraints;
+        for (const auto &c : problem.get_all_constraints()) constraints.push_back(c->abi_record());
+        if (h_ && same(tasks, tasks_) && same(constraints, constraints_)) return;
         ikgpu_problem *h = nullptr;
-        if (ikgpu_problem_create(problem.model().handle(), tasks.data(), static_cast<int32_t>(tasks.size()), device_, &h) != IKGPU_OK)
+        if (ikgpu_problem_create_constrained(problem.model().handle(), tasks.data(), static_cast<int32_t>(tasks.size()), constraints.data(),
+                                             static_cast<int32_t>(constraints.size()), device_, &h) != IKGPU_OK)
             throw std::runtime_error(ikgpu_last_error());
         h_ = std::shared_ptr<ikgpu_problem>(h, ikgpu_problem_destroy);
         tasks_ = tasks;
+        constraints_ = constraints;
         q = vector_t::Zero(problem.model().nq);
         dq = vector_t::Zero(problem.model().nv);
     }
 
    private:
-    bool same(const std::vector<ikgpu_task> &t) const {
-        if (t.size() != tasks_.size()) return false;
+    static bool same(const std::vector<ikgpu_task> &t, const std::vector<ikgpu_task> &u) {
+        if (t.size() != u.size()) return false;
         for (std::size_t i = 0; i < t.size(); ++i) {
-            const ikgpu_task &a = t[i], &b = tasks_[i];
+            const ikgpu_task &a = t[i], &b = u[i];
             if (a.frame != b.frame || a.reference != b.reference || a.type != b.type || a.priority != b.priority) return false;
             for (int k = 0; k < 6; ++k)
                 if (a.weight[k] != b.weight[k]) return false;
@@ -494,7 +569,7 @@ class dls_data {
     }
     int device_;
     std::shared_ptr<ikgpu_problem> h_;
-    std::vector<ikgpu_task> tasks_;
+    std::vector<ikgpu_task> tasks_, constraints_;
 };
 
 namespace detail {

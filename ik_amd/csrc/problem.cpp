@@ -180,6 +180,17 @@ void build_generic(ProblemHost &ph, const Model &m) {
         lvl[l + 1] += lvl[l];
     }
     g.o_lvlrow0 = put_i(lvl);
+    std::vector<int32_t> ctype, cfj, crj, crow, cdim;
+    int crows = 0;
+    for (const ikgpu_task &c : ph.constraints) {
+        ctype.push_back(c.type);
+        cfj.push_back(m.frame_parent[c.frame]);
+        crj.push_back(m.frame_parent[c.reference]);
+        crow.push_back(crows);
+        cdim.push_back(task_dim(c));
+        crows += task_dim(c);
+    }
+    g.o_ctype = put_i(ctype); g.o_cfjoint = put_i(cfj); g.o_crjoint = put_i(crj); g.o_crow = put_i(crow); g.o_cdim = put_i(cdim);
     auto put_d = [&](const double *p, size_t n) { int o = static_cast<int>(g.dbls.size()); g.dbls.insert(g.dbls.end(), p, p + n); return o; };
     g.o_placement = static_cast<int>(g.dbls.size());
     for (int j = 0; j < nj; ++j) put_d(m.joint_placement[j].data(), 12);
@@ -196,6 +207,10 @@ void build_generic(ProblemHost &ph, const Model &m) {
         put_d(ph.tasks[i].type == IKGPU_POSTURE_ROW ? ident.data() : m.frame_placement[ph.tasks[i].reference].data(), 12);
     g.o_tw = static_cast<int>(g.dbls.size());
     for (int i = 0; i < nt; ++i) put_d(ph.tasks[i].weight, 6);
+    g.o_cfpl = static_cast<int>(g.dbls.size());
+    for (const ikgpu_task &c : ph.constraints) put_d(m.frame_placement[c.frame].data(), 12);
+    g.o_crpl = static_cast<int>(g.dbls.size());
+    for (const ikgpu_task &c : ph.constraints) put_d(m.frame_placement[c.reference].data(), 12);
     const int M = ph.rows, nv = m.nv;
     int o = 0;
     g.off_q = o; o += m.nq;
@@ -206,21 +221,36 @@ void build_generic(ProblemHost &ph, const Model &m) {
     g.off_G = o; o += M * (M + 1) / 2;
     g.off_y = o; o += M;
     g.off_dq = o; o += nv;
+    g.off_Jc = o; o += crows * nv;
     g.ws_words = o;
     g.off_P = o; o += nv * nv;
     g.off_Jb = o; o += mmax * nv;
     g.off_de = o; o += mmax;
     g.ws_words_pik = o;
     ph.kind = KernelKind::Generic;
-    ph.kernel_name = "dls_generic<M=" + std::to_string(M) + ",nv=" + std::to_string(nv) + ",joints=" + std::to_string(nj - 1) + ">";
+    ph.kernel_name = "dls_generic<M=" + std::to_string(M) + ",nv=" + std::to_string(nv) + ",joints=" + std::to_string(nj - 1) +
+                     (crows > 0 ? ",constraint_rows=" + std::to_string(crows) : std::string()) + ">";
     ph.q_in_chain.assign(m.nq, 1);
 }
 
 }  // namespace
 
-ProblemHost analyse_problem(const Model &m, const ikgpu_task *tasks, int ntasks, bool force_generic) {
+ProblemHost analyse_problem(const Model &m, const ikgpu_task *tasks, int ntasks, bool force_generic,
+                            const ikgpu_task *constraints, int nconstraints) {
     if (ntasks < 1) throw std::runtime_error("a problem needs at least one task");
+    if (nconstraints < 0 || (nconstraints > 0 && !constraints)) throw std::runtime_error("invalid constraint list");
     ProblemHost ph;
+    for (int i = 0; i < nconstraints; ++i) {
+        const ikgpu_task &c = constraints[i];
+        if (c.frame < 0 || c.frame >= m.nframes()) throw std::runtime_error("constraint " + std::to_string(i) + ": frame id out of range");
+        if (c.reference < 0 || c.reference >= m.nframes())
+            throw std::runtime_error("constraint " + std::to_string(i) + ": reference frame id out of range");
+        if (c.type < IKGPU_POSITION || c.type > IKGPU_FULL)
+            throw std::runtime_error("constraint " + std::to_string(i) + ": a frame constraint is of type Position, Orientation or Full");
+        ph.constraints.push_back(c);
+        ph.crows += task_dim(c);
+    }
+    if (nconstraints > 0) force_generic = true;
     ph.nq = m.nq;
     ph.nv = m.nv;
     ph.ntasks = ntasks;

@@ -30,6 +30,9 @@ struct GenericHost {
     int off_q = 0, off_oMi = 0, off_Jw = 0, off_e = 0, off_J = 0, off_G = 0, off_y = 0, off_dq = 0, ws_words = 0;
     int nlevels = 1, o_lvlrow0 = 0;                               // prioritised IK: level -> first row (into ints)
     int off_P = 0, off_Jb = 0, off_de = 0, ws_words_pik = 0;      // and its extra workspace
+    int o_ctype = 0, o_cfjoint = 0, o_crjoint = 0, o_crow = 0, o_cdim = 0;  // FrameConstraint rows (into ints)
+    int o_cfpl = 0, o_crpl = 0;                                              // (into dbls)
+    int off_Jc = 0;
 };
 
 // Host copy of one serial chain (support of one task below its base), axis-folded: every joint
@@ -56,13 +59,18 @@ struct ProblemHost {
     double base_frame_pl[12] = {};    // base joint frame -> frame of the base task
     double ref_pl[12] = {};           // Chain kind: world placement of the (fixed) reference frame
     GenericHost generic;              // Generic kind
+    std::vector<ikgpu_task> constraints;  // ik::FrameConstraint list (frame, reference, type); forces the Generic kind
+    int crows = 0;
     std::vector<uint8_t> q_in_chain;  // [nq] 1 if the entry is integrated by the kernel
     std::vector<double> lower, upper;
 };
 
 // Picks the kernel kind from the shape of the problem; force_generic skips the specialisations (used when a
 // specialised shape has no compiled instantiation).  Throws std::runtime_error on invalid input.
-ProblemHost analyse_problem(const Model &m, const ikgpu_task *tasks, int ntasks, bool force_generic = false);
+// constraints: ik::FrameConstraint entries (reference ik/ik/frame.hpp:325-449) as ikgpu_task records of which frame, reference
+// and type are read; any constraint sends the problem to the generic kernel.
+ProblemHost analyse_problem(const Model &m, const ikgpu_task *tasks, int ntasks, bool force_generic = false,
+                            const ikgpu_task *constraints = nullptr, int nconstraints = 0);
 
 // ikdev::ChainDesc<nj> / ikdev::TreeDesc<na, nb> as the flat array of doubles the kernels stage into LDS.
 std::vector<double> chain_desc_table(const ProblemHost &ph);

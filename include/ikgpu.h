@@ -135,6 +135,15 @@ void ikgpu_problem_destroy(ikgpu_problem *p);
  * specialisation that would run (NUL-terminated, truncated to cap) or fails with
  * IKGPU_ERR_UNSUPPORTED / IKGPU_ERR_INVALID and the reason in ikgpu_last_error(). Touches no device. */
 int ikgpu_problem_plan(const ikgpu_model *m, const ikgpu_task *tasks, int32_t ntasks, char *out, size_t cap);
+/* The same with ik::FrameConstraint entries (reference ik/ik/frame.hpp:325-449; problem.hpp:68-77): each is an ikgpu_task
+ * record of which frame, reference and type (Position / Orientation / Full) are read.  ik::dls keeps its step in the null
+ * space of the stacked constraint Jacobian, dq = -N J^T (JJ^T + damping^2 I)^-1 e with N = I - pinv(Jc) Jc (reference
+ * ik/ik/dls.cpp:26-34,43-53); ik::pik does not read constraints (reference ik/ik/pik.cpp).  A problem with constraints
+ * runs on the generic kernel. */
+int ikgpu_problem_create_constrained(const ikgpu_model *m, const ikgpu_task *tasks, int32_t ntasks, const ikgpu_task *constraints,
+                                     int32_t nconstraints, int32_t device, ikgpu_problem **out);
+int ikgpu_problem_plan_constrained(const ikgpu_model *m, const ikgpu_task *tasks, int32_t ntasks, const ikgpu_task *constraints,
+                                   int32_t nconstraints, char *out, size_t cap);
 int32_t ikgpu_problem_rows(const ikgpu_problem *p);        /* M = sum of task dimensions */
 const char *ikgpu_problem_kernel(const ikgpu_problem *p);  /* name of the chosen specialisation */
 

@@ -332,6 +332,8 @@ static void frame_jacobian_local(const iko_model *m, const double *Jw, const dou
     }
 }
 
+static void rowspace_projector(const double *A, int m, int n, double *Pr);
+
 static int task_dim(const iko_task *t) { return t->type == IKO_FULL ? 6 : (t->type >= IKO_ALIGN_X ? 1 : 3); } /* align / posture rows: 1 */
 
 int iko_task_rows(const iko_task *tasks, int ntasks) {
@@ -513,10 +515,71 @@ void iko_integrate(const iko_model *m, const double *q, const double *v, double 
     }
 }
 
-static int dls_ws(const iko_model *m, const iko_task *tasks, int ntasks, const double *targets,
+/* ik::FrameConstraint::compute_jacobian (frame.hpp:413-449), stacked as dls.cpp:26-34 does: the velocity of the frame
+ * relative to its reference frame, in the frame's local coordinates,
+ *   Jc = J_frame(LOCAL) - rMf.toActionMatrixInverse() J_reference(LOCAL),  top / bottom / all rows by kinematic type.
+ * Needs w->oMf and w->Jw of the current q (evaluate_ws). Jc is Mc x nv; Jf, Jr are 6 x nv scratch. */
+static int constraint_rows(const iko_task *cons, int ncons) {
+    int Mc = 0;
+    for (int i = 0; i < ncons; ++i) Mc += task_dim(&cons[i]);
+    return Mc;
+}
+
+static void constraint_jacobian_ws(const iko_model *m, const iko_task *cons, int ncons, const workspace *w, double *Jf, double *Jr,
+                                   double *Jc) {
+    const int nv = m->nv;
+    int row = 0;
+    for (int k = 0; k < ncons; ++k) {
+        const iko_task *c = &cons[k];
+        const double *oMf = w->oMf + 12 * c->frame, *oMr = w->oMf + 12 * c->reference;
+        double fMr[12];
+        memset(Jf, 0, sizeof(double) * 6 * nv);
+        memset(Jr, 0, sizeof(double) * 6 * nv);
+        frame_jacobian_local(m, w->Jw, oMf, m->frame_parent[c->frame], Jf);
+        frame_jacobian_local(m, w->Jw, oMr, m->frame_parent[c->reference], Jr);
+        se3_inv_mul(oMf, oMr, fMr); /* (rMf)^-1: its action matrix is [[R, [p]x R], [0, R]] */
+        const int d = task_dim(c), r0 = (c->type == IKO_ORIENTATION) ? 3 : 0;
+        for (int col = 0; col < nv; ++col) {
+            double v[3], wv[3], Rv[3], Rw[3], pxRw[3], out[6];
+            for (int i = 0; i < 3; ++i) { v[i] = Jr[i * nv + col]; wv[i] = Jr[(3 + i) * nv + col]; }
+            for (int i = 0; i < 3; ++i) {
+                Rv[i] = R_(fMr, i, 0) * v[0] + R_(fMr, i, 1) * v[1] + R_(fMr, i, 2) * v[2];
+                Rw[i] = R_(fMr, i, 0) * wv[0] + R_(fMr, i, 1) * wv[1] + R_(fMr, i, 2) * wv[2];
+            }
+            cross3(fMr + 9, Rw, pxRw);
+            for (int i = 0; i < 3; ++i) {
+                out[i] = Jf[i * nv + col] - (Rv[i] + pxRw[i]);
+                out[3 + i] = Jf[(3 + i) * nv + col] - Rw[i];
+            }
+            for (int r = 0; r < d; ++r) Jc[(row + r) * nv + col] = out[r0 + r];
+        }
+        row += d;
+    }
+}
+
+void iko_constraint_jacobian(const iko_model *m, const iko_task *cons, int ncons, const double *q, double *Jc) {
+    workspace *w = ws_new(m, 1);
+    double *Jf = (double *)malloc(sizeof(double) * 6 * m->nv), *Jr = (double *)malloc(sizeof(double) * 6 * m->nv);
+    iko_fk(m, q, w->oMi, w->oMf);
+    joint_jacobians_world(m, w->oMi, w->Jw);
+    constraint_jacobian_ws(m, cons, ncons, w, Jf, Jr, Jc);
+    free(Jf); free(Jr);
+    ws_free(w);
+}
+
+static int dls_ws(const iko_model *m, const iko_task *tasks, int ntasks, const iko_task *cons, int ncons, const double *targets,
                   const double *q0, const iko_params *p, double *q_out, int *success, int *iters,
                   double *trace, workspace *w) {
     const int nq = m->nq, nv = m->nv, M = w->M;
+    const int Mc = constraint_rows(cons, ncons);
+    double *Jc = NULL, *N = NULL, *Jf = NULL, *Jr = NULL;
+    if (Mc > 0) {
+        Jc = (double *)malloc(sizeof(double) * Mc * nv);
+        N = (double *)malloc(sizeof(double) * nv * nv);
+        Jf = (double *)malloc(sizeof(double) * 6 * nv);
+        Jr = (double *)malloc(sizeof(double) * 6 * nv);
+    }
+    int done = 0;
     memcpy(w->q, q0, sizeof(double) * nq);                     /* dls.cpp:8 */
     for (int it = 0; it < p->max_iterations; ++it) {           /* dls.cpp:14 */
         double e0sq;
@@ -534,6 +597,16 @@ static int dls_ws(const iko_model *m, const iko_task *tasks, int ntasks, const d
             for (int i = 0; i < M; ++i) s += w->Jt[i * nv + c] * w->y[i];
             w->dq[c] = -s;
         }
+        if (Mc > 0) {                                           /* dls.cpp:26-34, 43-49: N = I - pinv(Jc) Jc, dq = -N (...) */
+            constraint_jacobian_ws(m, cons, ncons, w, Jf, Jr, Jc);
+            rowspace_projector(Jc, Mc, nv, N);
+            for (int c = 0; c < nv; ++c) {
+                double s = w->dq[c];
+                for (int k = 0; k < nv; ++k) s -= N[c * nv + k] * w->dq[k];
+                w->tmp[c] = s;
+            }
+            memcpy(w->dq, w->tmp, sizeof(double) * nv);
+        }
         if (trace) {
             double *t = trace + (size_t)it * (nq + M + nv);
             memcpy(t, w->q, sizeof(double) * nq);
@@ -544,7 +617,8 @@ static int dls_ws(const iko_model *m, const iko_task *tasks, int ntasks, const d
             memcpy(q_out, w->q, sizeof(double) * nq);
             *success = 1;
             *iters = it;
-            return 0;
+            done = 1;
+            break;
         }
         for (int c = 0; c < nv; ++c) w->tmp[c] = p->step_length * w->dq[c];
         iko_integrate(m, w->q, w->tmp, w->qn);                  /* dls.cpp:67-68 */
@@ -553,24 +627,34 @@ static int dls_ws(const iko_model *m, const iko_task *tasks, int ntasks, const d
             w->q[i] = m->upper[i] < lo_clamped ? m->upper[i] : lo_clamped;             /* cwiseMin */
         }
     }
-    memcpy(q_out, w->q, sizeof(double) * nq);                   /* dls.cpp:76-77 */
-    *success = 0;
-    *iters = p->max_iterations;
+    if (!done) {
+        memcpy(q_out, w->q, sizeof(double) * nq);               /* dls.cpp:76-77 */
+        *success = 0;
+        *iters = p->max_iterations;
+    }
+    free(Jc); free(N); free(Jf); free(Jr);
     return 0;
+}
+
+int iko_dls_constrained(const iko_model *m, const iko_task *tasks, int ntasks, const iko_task *cons, int ncons,
+                        const double *targets, const double *q0, const iko_params *p, double *q_out, int *success, int *iters,
+                        double *trace) {
+    workspace *w = ws_new(m, iko_task_rows(tasks, ntasks));
+    int rc = dls_ws(m, tasks, ntasks, cons, ncons, targets, q0, p, q_out, success, iters, trace, w);
+    ws_free(w);
+    return rc;
 }
 
 int iko_dls(const iko_model *m, const iko_task *tasks, int ntasks, const double *targets,
             const double *q0, const iko_params *p, double *q_out, int *success, int *iters,
             double *trace) {
-    workspace *w = ws_new(m, iko_task_rows(tasks, ntasks));
-    int rc = dls_ws(m, tasks, ntasks, targets, q0, p, q_out, success, iters, trace, w);
-    ws_free(w);
-    return rc;
+    return iko_dls_constrained(m, tasks, ntasks, NULL, 0, targets, q0, p, q_out, success, iters, trace);
 }
 
 typedef struct {
     const iko_model *m; const iko_task *tasks; int ntasks; long b0, b1;
     const double *targets, *q0; const iko_params *p; double *q_out; unsigned char *success; int *iters;
+    const iko_task *cons; int ncons;
 } batch_job;
 
 static void *batch_worker(void *arg) {
@@ -579,7 +663,7 @@ static void *batch_worker(void *arg) {
     const int nq = j->m->nq;
     for (long b = j->b0; b < j->b1; ++b) {
         int ok = 0, it = 0;
-        dls_ws(j->m, j->tasks, j->ntasks, j->targets + (size_t)b * j->ntasks * 12, j->q0 + (size_t)b * nq,
+        dls_ws(j->m, j->tasks, j->ntasks, j->cons, j->ncons, j->targets + (size_t)b * j->ntasks * 12, j->q0 + (size_t)b * nq,
                j->p, j->q_out + (size_t)b * nq, &ok, &it, NULL, w);
         if (j->success) j->success[b] = (unsigned char)ok;
         if (j->iters) j->iters[b] = it;
@@ -591,12 +675,18 @@ static void *batch_worker(void *arg) {
 int iko_dls_batch(const iko_model *m, const iko_task *tasks, int ntasks, long B, const double *targets,
                   const double *q0, const iko_params *p, double *q_out, unsigned char *success,
                   int *iters, int nthreads) {
+    return iko_dls_batch_constrained(m, tasks, ntasks, NULL, 0, B, targets, q0, p, q_out, success, iters, nthreads);
+}
+
+int iko_dls_batch_constrained(const iko_model *m, const iko_task *tasks, int ntasks, const iko_task *cons, int ncons, long B,
+                              const double *targets, const double *q0, const iko_params *p, double *q_out, unsigned char *success,
+                              int *iters, int nthreads) {
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 256) nthreads = 256;
     pthread_t th[256];
     batch_job jobs[256];
     for (int t = 0; t < nthreads; ++t) {
-        batch_job j = {m, tasks, ntasks, B * t / nthreads, B * (t + 1) / nthreads, targets, q0, p, q_out, success, iters};
+        batch_job j = {m, tasks, ntasks, B * t / nthreads, B * (t + 1) / nthreads, targets, q0, p, q_out, success, iters, cons, ncons};
         jobs[t] = j;
     }
     if (nthreads == 1) { batch_worker(&jobs[0]); return 0; }

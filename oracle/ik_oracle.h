@@ -73,6 +73,17 @@ int iko_dls(const iko_model *m, const iko_task *tasks, int ntasks, const double 
             const double *q0, const iko_params *p, double *q_out, int *success, int *iters,
             double *trace);
 
+/* The same with ik::FrameConstraint entries (ik/ik/frame.hpp:325-449): iko_task records of which frame, reference and type
+ * are read.  dq = -N Jt^T (JJ)^-1 et with N = I - pinv(Jc) Jc (ik/ik/dls.cpp:26-34,43-53). */
+int iko_dls_constrained(const iko_model *m, const iko_task *tasks, int ntasks, const iko_task *cons, int ncons,
+                        const double *targets, const double *q0, const iko_params *p, double *q_out, int *success, int *iters,
+                        double *trace);
+int iko_dls_batch_constrained(const iko_model *m, const iko_task *tasks, int ntasks, const iko_task *cons, int ncons, long B,
+                              const double *targets, const double *q0, const iko_params *p, double *q_out, unsigned char *success,
+                              int *iters, int nthreads);
+/* Stacked constraint Jacobian Jc [Mc x nv] at q (ik/ik/frame.hpp:413-449). */
+void iko_constraint_jacobian(const iko_model *m, const iko_task *cons, int ncons, const double *q, double *Jc);
+
 /* Batch of independent problems, array-of-structures: q0[B][nq], targets[B][ntasks][12],
  * q_out[B][nq]; nthreads worker threads split the batch in contiguous blocks. */
 int iko_dls_batch(const iko_model *m, const iko_task *tasks, int ntasks, long B,

@@ -155,6 +155,38 @@ def dls_batch(model, tasks, targets, q0, prm, nthreads=1):
     return q, ok, it
 
 
+def dls_constrained(model, tasks, constraints, targets, q0, prm):
+    """ik::dls with ik::FrameConstraint entries (make_tasks records: frame, reference, type)."""
+    targets = np.ascontiguousarray(targets, dtype=np.float64)
+    q0 = np.ascontiguousarray(q0, dtype=np.float64)
+    q = np.empty(model.nq)
+    ok, it = C.c_int(0), C.c_int(0)
+    lib().iko_dls_constrained(C.byref(model.c), tasks, C.c_int(len(tasks)), constraints, C.c_int(len(constraints)), _p(targets), _p(q0),
+                              C.byref(prm), _p(q), C.byref(ok), C.byref(it), None)
+    return q, bool(ok.value), it.value
+
+
+def dls_batch_constrained(model, tasks, constraints, targets, q0, prm, nthreads=1):
+    targets = np.ascontiguousarray(targets, dtype=np.float64)
+    q0 = np.ascontiguousarray(q0, dtype=np.float64)
+    B = q0.shape[0]
+    assert targets.shape == (B, len(tasks), 12) and q0.shape == (B, model.nq)
+    q = np.empty_like(q0)
+    ok = np.zeros(B, dtype=np.uint8)
+    it = np.zeros(B, dtype=np.int32)
+    lib().iko_dls_batch_constrained(C.byref(model.c), tasks, C.c_int(len(tasks)), constraints, C.c_int(len(constraints)), C.c_long(B),
+                                    _p(targets), _p(q0), C.byref(prm), _p(q), _p(ok), _p(it), C.c_int(nthreads))
+    return q, ok, it
+
+
+def constraint_jacobian(model, constraints, q):
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    Mc = task_rows(constraints)
+    Jc = np.empty((Mc, model.nv))
+    lib().iko_constraint_jacobian(C.byref(model.c), constraints, C.c_int(len(constraints)), _p(q), _p(Jc))
+    return Jc
+
+
 def pik_params(max_iterations=100, step_length=1.0, stop_sq_tol=1e-4, lam=(1.0,), da=None):
     """ik::pik_parameters + pik_data::lambda / da (reference ik/ik/pik.hpp:11-16,41-44).  Keeps the arrays alive."""
     prm = _PikParams()

@@ -509,7 +509,31 @@ def clamp(m, q):
     return np.minimum(m.upper, np.maximum(q, m.lower))
 
 
-def dls(m, tasks, q0, max_iterations=100, damping=1e-2, step_length=1.0, stop_sq_tol=1e-4, trace=None):
+def action_matrix(M):
+    """pinocchio SE3::toActionMatrix: [[R, [p]x R], [0, R]] acting on [v; w]."""
+    R, p = M[:3, :3], M[:3, 3]
+    X = np.zeros((6, 6))
+    X[:3, :3] = R
+    X[:3, 3:] = skew(p) @ R
+    X[3:, 3:] = R
+    return X
+
+
+def constraint_jacobian(m, constraints, q):
+    """Stacked ik::FrameConstraint::compute_jacobian (ik/ik/frame.hpp:413-449; ik/ik/dls.cpp:26-34).  constraints are
+    FrameTask-like records (frame, reference, type)."""
+    oMi, oMf = fk(m, q)
+    Jw = joint_jacobians_world(m, oMi)
+    rows = []
+    for c in constraints:
+        rMf = se3_inv(oMf[c.reference]) @ oMf[c.frame]
+        Jf = frame_jacobian_local(m, Jw, oMf[c.frame], m.frames[c.frame]["parent"])
+        Jr = frame_jacobian_local(m, Jw, oMf[c.reference], m.frames[c.reference]["parent"])
+        rows.append((Jf - action_matrix(se3_inv(rMf)) @ Jr)[c.rows(), :])
+    return np.vstack(rows) if rows else np.zeros((0, m.nv))
+
+
+def dls(m, tasks, q0, max_iterations=100, damping=1e-2, step_length=1.0, stop_sq_tol=1e-4, trace=None, constraints=None):
     """ik::dls (ik/ik/dls.cpp:5-78).  stop_sq_tol < 0 == a visitor that never stops.
     Returns (q, success, iterations-before-exit)."""
     q = np.array(q0, dtype=float)
@@ -518,6 +542,9 @@ def dls(m, tasks, q0, max_iterations=100, damping=1e-2, step_length=1.0, stop_sq
         JJ = J @ J.T
         JJ[np.diag_indices_from(JJ)] += damping * damping
         dq = -(J.T @ np.linalg.solve(JJ, e))
+        if constraints:  # ik/ik/dls.cpp:43-53: N = I - pinv(Jc) Jc
+            Jc = constraint_jacobian(m, constraints, q)
+            dq = dq - rowspace_projector(Jc) @ dq
         if trace is not None:
             trace.append(dict(q=q.copy(), e=e.copy(), J=J.copy(), JJ=JJ.copy(), dq=dq.copy()))
         if stop_sq_tol >= 0.0 and float(np.dot(e, e)) < stop_sq_tol:

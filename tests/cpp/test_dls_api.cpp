@@ -54,6 +54,8 @@ int main(int argc, char **argv) {
         std::vector<double> posture_target;
         bool use_pik = false;
         std::vector<double> pik_lambda;
+        struct ConstraintSpec { std::string frame, reference; int type; };
+        std::vector<ConstraintSpec> constraint_specs;
         while (a < argc) {
             const std::string opt = next();
             if (opt == "posture") {
@@ -62,6 +64,12 @@ int main(int argc, char **argv) {
                 posture_weight = std::atof(next().c_str());
                 for (std::size_t i = 0; i < posture_nj; ++i) posture_target.push_back(std::atof(next().c_str()));
                 if (posture_prio > max_priority) max_priority = posture_prio;
+            } else if (opt == "constraint") {  // a FrameConstraint: <frame> <type 0|1|2> <reference frame>
+                ConstraintSpec c;
+                c.frame = next();
+                c.type = std::atoi(next().c_str());
+                c.reference = next();
+                constraint_specs.push_back(c);
             } else if (opt == "pik") {  // solve with ik::pik; the rest of the line is lambda per level
                 use_pik = true;
                 while (a < argc) pik_lambda.push_back(std::atof(next().c_str()));
@@ -91,6 +99,15 @@ int main(int argc, char **argv) {
             for (std::size_t i = 0; i < posture_nj; ++i) problem.get_posture_task("posture")->target[i] = posture_target[i];
             posture->weighting().setConstant(posture_weight);
         }
+
+        k = 0;
+        for (auto &c : constraint_specs) {  // reference ik/ik/problem.hpp:68-77
+            const ik::KinematicType type = c.type == 0 ? ik::KinematicType::Position
+                                           : c.type == 1 ? ik::KinematicType::Orientation : ik::KinematicType::Full;
+            problem.add_frame_constraint("constraint" + std::to_string(k++), ik::FrameConstraint::create(model, c.frame, type, c.reference));
+        }
+        if (problem.c_size() != problem.get_all_constraints().size() * 3 && constraint_specs.size() == 1 && constraint_specs[0].type != 2)
+            throw std::runtime_error("c_size() does not add up");
 
         struct tol_visitor : ik::inverse_kinematics_visitor {
             double t;

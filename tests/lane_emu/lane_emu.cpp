@@ -167,6 +167,22 @@ int lane_emu_run(const char *urdf, size_t len, int root_joint, const ikgpu_task 
     }
 }
 
+// ik::dls with ik::FrameConstraint entries (reference ik/ik/dls.cpp:26-34,43-53) through the generic lane program.
+int lane_emu_dls_constrained(const char *urdf, size_t len, int root_joint, const ikgpu_task *tasks, int ntasks, const ikgpu_task *cons,
+                             int ncons, int64_t B, const double *q0, const double *targets, const ikgpu_dls_params *prm, double *q_out,
+                             uint8_t *success, int32_t *iters, int layout) {
+    try {
+        ikgpu::Model m = ikgpu::Model::from_urdf(urdf, len, (root_joint & 1) != 0);
+        const ikgpu::ProblemHost ph = ikgpu::analyse_problem(m, tasks, ntasks, /*force_generic=*/true, cons, ncons);
+        const IO io{0, B, q0, targets, prm, q_out, success, iters, nullptr, nullptr, nullptr, layout};
+        run_generic(ph, io);
+        return 0;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return 1;
+    }
+}
+
 // ik::pik (reference ik/ik/pik.cpp:31-103) through the device lane program (device/pik_solver.hpp), one lane at a time.
 int lane_emu_pik(const char *urdf, size_t len, int root_joint, const ikgpu_task *tasks, int ntasks, int64_t B, const double *q0,
                  const double *targets, const ikgpu_pik_params *prm, double *q_out, uint8_t *success, int32_t *iters, int layout) {

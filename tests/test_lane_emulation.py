@@ -397,3 +397,44 @@ def test_pik_with_one_level_and_small_lambda_is_dls(emu):
     qb, okb, itb, *_ = run(emu, urdf, task, 0, q0, tg, capi.DlsParams(25, 1e-2, 1.0, 1e-10), model.nv, 6)
     assert np.array_equal(oka, okb) and np.array_equal(ita, itb)
     assert np.abs(qa - qb).max() < 1e-9
+
+
+# ---------------------------------------------------------------------------------------------------
+# ik::dls with ik::FrameConstraint rows: the step is projected into the null space of the constraint Jacobian
+# ---------------------------------------------------------------------------------------------------
+CONSTRAINT_CASES = {
+    # the demo's commented-out intent (reference ik_ros/src/cassie.cpp:49-51,74-75): keep the right foot where it is
+    "demo_right_foot_pinned": ("cassie", True, [("LeftFootFront", "pelvis", 0, 0, None), ("pelvis", "universe", 2, 0, None)],
+                               [("RightFootFront", "universe", 0)]),
+    "pelvis_with_both_feet_locked": ("cassie", True, [("pelvis", "universe", 2, 0, None)],
+                                     [("RightFootFront", "universe", 2), ("LeftFootFront", "RightFootFront", 0)]),
+    "arm_keeps_tool_orientation": ("ur5", False, [("tool0", "universe", 0, 0, None)], [("tool0", "universe", 1)]),
+    "relative_orientation_between_feet": ("cassie_fixed", False, [("LeftFootFront", "universe", 2, 0, None)],
+                                          [("RightFootFront", "LeftFootBack", 1)]),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CONSTRAINT_CASES))
+def test_constrained_dls_program_matches_oracle(emu, case):
+    from ik_amd import capi
+    name, ff, specs, cspecs = CONSTRAINT_CASES[case]
+    B = 16
+    urdf, model, om, tasks, ot, q0, tg, M = _generic_case(name, ff, specs, B, seed=9)
+    cons = (capi.Task * len(cspecs))()
+    for i, (f, r, t) in enumerate(cspecs):
+        cons[i] = capi.Task(model.getFrameId(f), model.getFrameId(r), t, 0, (C.c_double * 6)(*[1.0] * 6))
+    oc = O.make_tasks([(model.getFrameId(f), model.getFrameId(r), t, 0, None) for f, r, t in cspecs])
+    p = lambda a: C.c_void_p(a.ctypes.data)
+    for iters, damping, step, tol in ((1, 1e-2, 1.0, -1.0), (5, 1e-2, 1.0, -1.0), (40, 1e-1, 0.5, 1e-7)):
+        qo = np.empty_like(q0)
+        ok, it = np.zeros(B, np.uint8), np.zeros(B, np.int32)
+        prm = capi.DlsParams(iters, damping, step, tol)
+        rc = emu.lane_emu_dls_constrained(urdf, C.c_size_t(len(urdf)), 1 if ff else 0, tasks, len(tasks), cons, len(cons), C.c_int64(B),
+                                          p(q0), p(tg), C.byref(prm), p(qo), p(ok), p(it), 1)
+        assert rc == 0, emu.lane_emu_last_error()
+        q_ref, ok_ref, it_ref = O.dls_batch_constrained(om, ot, oc, tg, q0, O.params(iters, damping, step, tol))
+        assert np.array_equal(ok, ok_ref) and np.array_equal(it, it_ref), (case, iters)
+        assert np.abs(qo - q_ref).max() < 1e-8, (case, iters, np.abs(qo - q_ref).max())
+    # and the constraint bites: without it the same problem goes elsewhere
+    q_free, _, _ = O.dls_batch(om, ot, tg, q0, O.params(iters, damping, step, tol))
+    assert np.abs(q_free - q_ref).max() > 1e-3
