@@ -4,7 +4,8 @@
 Reads the three URDFs and the SRDF that ship with the reference (as *data*) and writes
 stripped files that keep only what the IK hot path consumes: link names, and for every
 robot-level joint its name / type / origin / axis / parent / child / position limits.
-Visual, collision, inertial, transmission and gazebo elements are dropped.  Attribute
+Of each link's <inertial> only the mass and the centre of mass (<origin>) are kept, for the centre-of-mass task;
+visual, collision, rotational inertia, transmission and gazebo elements are dropped.  Attribute
 strings are copied verbatim so that number parsing is bit-identical to parsing the
 originals.  Run in the build container only (the reference does not travel):
 
@@ -27,11 +28,23 @@ def strip(src_path, dst_path, rel):
     out = []
     out.append('<?xml version="1.0"?>')
     out.append("<!-- kinematic-only fixture derived from the reference data file %s" % rel)
-    out.append("     by fixtures/make_kinematic_urdf.py: links (names) and robot-level joints only. -->")
+    out.append("     by fixtures/make_kinematic_urdf.py: links (names, mass, centre of mass) and robot-level joints only. -->")
     out.append('<robot name="%s">' % root.get("name"))
     for el in root:
         if el.tag == "link":
-            out.append('  <link name="%s"/>' % el.get("name"))
+            inertial = el.find("inertial")
+            if inertial is None or inertial.find("mass") is None:
+                out.append('  <link name="%s"/>' % el.get("name"))
+                continue
+            # mass and centre of mass only (what pinocchio::centerOfMass reads); the rotational inertia is not on the path
+            out.append('  <link name="%s">' % el.get("name"))
+            out.append("    <inertial>")
+            org = inertial.find("origin")
+            if org is not None:
+                out.append("      <origin %s/>" % " ".join('%s="%s"' % (k, org.get(k)) for k in ("rpy", "xyz") if org.get(k) is not None))
+            out.append('      <mass value="%s"/>' % inertial.find("mass").get("value"))
+            out.append("    </inertial>")
+            out.append("  </link>")
     for el in root:
         if el.tag != "joint":
             continue

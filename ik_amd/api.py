@@ -106,6 +106,7 @@ class Model:
             idx_q=np.array(f.joint_idx_q[:nj], np.int32), idx_v=np.array(f.joint_idx_v[:nj], np.int32),
             placement=np.array(f.joint_placement[:12 * nj]).reshape(nj, 12),
             axis=np.array(f.joint_axis[:3 * nj]).reshape(nj, 3),
+            mass=np.array(f.joint_mass[:nj]), lever=np.array(f.joint_com[:3 * nj]).reshape(nj, 3),
             lower=self.lowerPositionLimit.copy(), upper=self.upperPositionLimit.copy(),
             frame_parent=np.array(f.frame_parent[:nf], np.int32),
             frame_placement=np.array(f.frame_placement[:12 * nf]).reshape(nf, 12),
@@ -227,8 +228,33 @@ def _constraint_table(problem):
     return arr, len(cons)
 
 
+class CentreOfMassTask:
+    """ik::CentreOfMassTask (reference ik/ik/centre_of_mass.hpp:14-62): e = oMr^-1 com(q) - target (three rows),
+    J = R(oMr)^T Jcom.  Needs link masses in the model (URDF <inertial>).  Runs on the generic kernel."""
+
+    def __init__(self, model, reference_frame="universe"):
+        self.reference_frame = reference_frame
+        self._ref_id = model.getFrameId(reference_frame)
+        if self._ref_id >= model.nframes:
+            raise ValueError("Reference frame not found in model: %s" % reference_frame)
+        self.target = np.zeros(3)   # the reference leaves it uninitialised; a caller sets it (cassie.cpp:101)
+        self._weighting = np.ones(3)
+
+    @staticmethod
+    def create(model, reference_frame="universe"):
+        return CentreOfMassTask(model, reference_frame)
+
+    def dimension(self):
+        return 3
+
+    def weighting(self):
+        return self._weighting
+
+
 def _abi_rows(task, prio):
     """The rows a task contributes to the ABI's task table: (frame, reference, type, priority, weight[6])."""
+    if isinstance(task, CentreOfMassTask):
+        return [(0, task._ref_id, capi.CENTRE_OF_MASS, prio, [float(x) for x in task._weighting] + [1.0] * 3)]
     if isinstance(task, PostureTask):
         return [(task._v0 + k, task._q0 + k, capi.POSTURE_ROW, prio, [float(task._weighting[k]), float(task.mask[k]), 1, 1, 1, 1])
                 for k in range(task.nj)]
@@ -243,7 +269,7 @@ def _target_slots(task):
         out = np.zeros((task.nj, 12))
         out[:, 9] = np.asarray(task.target, dtype=np.float64)
         return out
-    if isinstance(task, AlignAxisTask):
+    if isinstance(task, (AlignAxisTask, CentreOfMassTask)):
         return np.concatenate([np.eye(3).reshape(9), np.asarray(task.target, dtype=np.float64).reshape(3)])[None, :]
     return task.target.to12()[None, :]
 
@@ -274,6 +300,7 @@ class InverseKinematicsProblem:
         self._posture_tasks_map = {}
         self._frame_constraints = []
         self._frame_constraints_map = {}
+        self._com_task = None
         self._generation = 0
 
     def max_priority_level(self):
@@ -347,6 +374,19 @@ class InverseKinematicsProblem:
 
     def get_posture_task(self, name):
         return self._posture_tasks[self._posture_tasks_map[name]]
+
+    def add_centre_of_mass_task(self, task, priority=0):  # reference ik/ik/problem.hpp:121-128
+        if not 0 <= priority <= self._max_priority_level:
+            raise ValueError("Maximum priority level exceeded!")
+        if self._com_task is not None:
+            raise ValueError("a problem holds one centre-of-mass task")
+        self._com_task = task
+        self._tasks[priority].append(task)
+        self._generation += 1
+        return task
+
+    def get_centre_of_mass_task(self):  # reference ik/ik/problem.hpp:130-132
+        return self._com_task
 
 
 class dls_parameters:

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libikgpu.so")
 OK, ERR_INVALID, ERR_PARSE, ERR_UNSUPPORTED, ERR_DEVICE = 0, 1, 2, 3, 4
 JOINT_UNIVERSE, JOINT_REVOLUTE, JOINT_PRISMATIC, JOINT_FREEFLYER = 0, 1, 2, 3
 POSITION, ORIENTATION, FULL = 0, 1, 2
-ALIGN_AXIS_X, ALIGN_AXIS_Y, ALIGN_AXIS_Z, POSTURE_ROW = 3, 4, 5, 6
+ALIGN_AXIS_X, ALIGN_AXIS_Y, ALIGN_AXIS_Z, POSTURE_ROW, CENTRE_OF_MASS = 3, 4, 5, 6, 7
 SOA, AOS = 0, 1
 ROOT_FIXED, ROOT_FREEFLYER = 0, 1
 
@@ -37,7 +37,8 @@ class FlatModel(C.Structure):
                 ("joint_placement", C.POINTER(C.c_double)), ("joint_axis", C.POINTER(C.c_double)),
                 ("lower", C.POINTER(C.c_double)), ("upper", C.POINTER(C.c_double)),
                 ("frame_parent", C.POINTER(C.c_int32)), ("frame_placement", C.POINTER(C.c_double)),
-                ("joint_names", C.POINTER(C.c_char_p)), ("frame_names", C.POINTER(C.c_char_p))]
+                ("joint_names", C.POINTER(C.c_char_p)), ("frame_names", C.POINTER(C.c_char_p)),
+                ("joint_mass", C.POINTER(C.c_double)), ("joint_com", C.POINTER(C.c_double))]
 
 
 class Task(C.Structure):

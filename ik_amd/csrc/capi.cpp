@@ -196,6 +196,8 @@ int ikgpu_model_get_flat(const ikgpu_model *h, ikgpu_flat_model *out) {
     out->joint_idx_v = m.joint_idx_v.data();
     out->joint_placement = m.joint_placement.empty() ? nullptr : m.joint_placement[0].data();
     out->joint_axis = m.joint_axis.empty() ? nullptr : m.joint_axis[0].data();
+    out->joint_mass = m.joint_mass.data();
+    out->joint_com = m.joint_com.empty() ? nullptr : m.joint_com[0].data();
     out->lower = m.lower.data();
     out->upper = m.upper.data();
     out->frame_parent = m.frame_parent.data();

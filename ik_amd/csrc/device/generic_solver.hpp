@@ -19,7 +19,7 @@
 namespace ikdev {
 
 enum : int { GJ_UNIVERSE = 0, GJ_REVOLUTE = 1, GJ_PRISMATIC = 2, GJ_FREEFLYER = 3 };  // == ikgpu_joint_type
-enum : int { GT_POSITION = 0, GT_ORIENTATION = 1, GT_FULL = 2, GT_ALIGN_X = 3, GT_POSTURE_ROW = 6 };  // == ikgpu_kinematic_type
+enum : int { GT_POSITION = 0, GT_ORIENTATION = 1, GT_FULL = 2, GT_ALIGN_X = 3, GT_POSTURE_ROW = 6, GT_COM = 7 };  // == ikgpu_kinematic_type
 
 // Read-only tables shared by all lanes (device global memory; host memory in the lane emulator).
 struct GenericTables {
@@ -42,6 +42,11 @@ struct GenericTables {
     const int *c_type, *c_fjoint, *c_rjoint, *c_row, *c_dim;  // [ncons]
     const double *c_fpl, *c_rpl;                               // [ncons][12]
     int off_Jc;                                                // Mc x nv, inside the first ws_words words
+    // ik::CentreOfMassTask (ik/ik/centre_of_mass.hpp:14-62): mass and lever of the bodies on each joint, subtree masses
+    int has_com;
+    const double *j_mass, *j_lever, *j_submass;                // [njoints], [njoints][3], [njoints]
+    double inv_total_mass;
+    int off_sf;                                                // first moments of the subtrees, 3 x njoints
 };
 
 struct Ws {  // word w of this lane
@@ -128,10 +133,50 @@ IKD_FN void generic_fk(const GenericTables &T, const Ws &ws) {
 // evaluate_problem_data (ik/ik/data.cpp:25-58) into the workspace: q -> oMi, Jw, et, Jt.  Returns ||e[0]||^2.
 IKD_FN double generic_evaluate(const GenericTables &T, const Ws &ws, const double *targets_lane, int64_t tstride) {
     generic_fk(T, ws);
+    if (T.has_com) {  // pinocchio::centerOfMass, backward pass: first moment of every subtree (the subtree masses are constants)
+        for (int j = 1; j < T.njoints; ++j) {
+            const double *c = T.j_lever + 3 * j;
+            const double mj = T.j_mass[j];
+            for (int i = 0; i < 3; ++i)
+                ws[T.off_sf + 3 * j + i] = mj * dfma(ws[T.off_oMi + 12 * j + 3 * i], c[0], dfma(ws[T.off_oMi + 12 * j + 3 * i + 1], c[1],
+                                                dfma(ws[T.off_oMi + 12 * j + 3 * i + 2], c[2], ws[T.off_oMi + 12 * j + 9 + i])));
+        }
+        for (int i = 0; i < 3; ++i) ws[T.off_sf + i] = 0.0;
+        for (int j = T.njoints - 1; j > 0; --j)
+            for (int i = 0; i < 3; ++i) ws[T.off_sf + 3 * T.parent[j] + i] += ws[T.off_sf + 3 * j + i];
+    }
     double e0sq = 0.0;
     for (int t = 0; t < T.ntasks; ++t) {
         const int fj = T.t_fjoint[t], rj = T.t_rjoint[t], type = T.t_type[t], row = T.t_row[t], dim = T.t_dim[t];
         const double *w6 = T.t_w + 6 * t;
+        if (type == GT_COM) {  // ik::CentreOfMassTask, ik/ik/centre_of_mass.hpp:33-45; jacobianCenterOfMass, ik/ik/data.cpp:31-34
+            double oJ[12], oMr[12];
+            for (int k = 0; k < 12; ++k) oJ[k] = ws[T.off_oMi + 12 * rj + k];
+            g_se3_mul(oJ, T.t_rpl + 12 * t, oMr);
+            const double d[3] = {dfma(ws[T.off_sf], T.inv_total_mass, -oMr[9]), dfma(ws[T.off_sf + 1], T.inv_total_mass, -oMr[10]),
+                                 dfma(ws[T.off_sf + 2], T.inv_total_mass, -oMr[11])};
+            for (int r = 0; r < 3; ++r) {
+                const double e = (dfma(oMr[r], d[0], dfma(oMr[3 + r], d[1], oMr[6 + r] * d[2])) - targets_lane[(t * 12 + 9 + r) * tstride]) * w6[r];
+                ws[T.off_e + row + r] = e;
+                if (T.t_prio[t] == 0) e0sq = dfma(e, e, e0sq);
+            }
+            for (int j = 1; j < T.njoints; ++j) {
+                const int n = T.jtype[j] == GJ_FREEFLYER ? 6 : 1;
+                const double ms = T.j_submass[j];
+                const double f[3] = {ws[T.off_sf + 3 * j], ws[T.off_sf + 3 * j + 1], ws[T.off_sf + 3 * j + 2]};
+                for (int c = T.idx_v[j]; c < T.idx_v[j] + n; ++c) {
+                    const double v[3] = {ws[T.off_Jw + c], ws[T.off_Jw + T.nv + c], ws[T.off_Jw + 2 * T.nv + c]};
+                    const double w[3] = {ws[T.off_Jw + 3 * T.nv + c], ws[T.off_Jw + 4 * T.nv + c], ws[T.off_Jw + 5 * T.nv + c]};
+                    double fxw[3];
+                    cross(f, w, fxw);
+                    const double col[3] = {(ms * v[0] - fxw[0]) * T.inv_total_mass, (ms * v[1] - fxw[1]) * T.inv_total_mass,
+                                           (ms * v[2] - fxw[2]) * T.inv_total_mass};
+                    for (int r = 0; r < 3; ++r)
+                        ws[T.off_J + (row + r) * T.nv + c] = w6[r] * dfma(oMr[r], col[0], dfma(oMr[3 + r], col[1], oMr[6 + r] * col[2]));
+                }
+            }
+            continue;
+        }
         if (type == GT_POSTURE_ROW) {  // one row of ik::PostureTask, ik/ik/posture.hpp:51-68 (fjoint = tangent column, rjoint = q index)
             const double e = (ws[T.off_q + rj] - targets_lane[(t * 12 + 9) * tstride]) * w6[1] * w6[0];
             ws[T.off_e + row] = e;

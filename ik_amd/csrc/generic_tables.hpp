@@ -23,6 +23,8 @@ inline ikdev::GenericTables bind_generic_tables(const ProblemHost &ph, const int
     T.c_type = ibase + g.o_ctype; T.c_fjoint = ibase + g.o_cfjoint; T.c_rjoint = ibase + g.o_crjoint;
     T.c_row = ibase + g.o_crow; T.c_dim = ibase + g.o_cdim;
     T.c_fpl = dbase + g.o_cfpl; T.c_rpl = dbase + g.o_crpl; T.off_Jc = g.off_Jc;
+    T.has_com = g.has_com; T.j_mass = dbase + g.o_jmass; T.j_lever = dbase + g.o_jlever; T.j_submass = dbase + g.o_jsubmass;
+    T.inv_total_mass = g.inv_total_mass; T.off_sf = g.off_sf;
     T.off_P = g.off_P; T.off_Jb = g.off_Jb; T.off_de = g.off_de; T.ws_words_pik = g.ws_words_pik;
     return T;
 }

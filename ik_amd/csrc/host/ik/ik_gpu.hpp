@@ -312,6 +312,42 @@ class AlignAxisTask : public SingleRowTask {
     string_t frame_, reference_frame_;
 };
 
+// ---- ik::CentreOfMassTask (ik/ik/centre_of_mass.hpp:14-62) --------------------------------------------
+// e = oMr^-1 com(q) - target, J = R(oMr)^T Jcom (pinocchio::jacobianCenterOfMass, ik/ik/data.cpp:31-34).  Needs link
+// masses in the model (URDF <inertial>); runs on the generic device kernel.
+class CentreOfMassTask : public DeviceTask {
+   public:
+    CentreOfMassTask(const model_t &model, const string_t &reference_frame = "universe") : reference_frame_(reference_frame) {
+        reference_id_ = model.getFrameId(reference_frame);
+        if (reference_id_ >= static_cast<index_t>(model.nframes))
+            throw std::invalid_argument("Reference frame not found in model: " + reference_frame);
+        target << 0.0, 0.0, 0.0;  // the reference leaves it uninitialised; a caller sets it (cassie.cpp:101)
+        set_dimension(index_t(3));
+    }
+    static std::shared_ptr<CentreOfMassTask> create(const model_t &model, const string_t &reference_frame = "universe") {
+        return std::make_shared<CentreOfMassTask>(model, reference_frame);
+    }
+    vector3_t target;  // target point for the centre of mass in the task's reference frame (centre_of_mass.hpp:57)
+
+    void abi_rows(int32_t priority, std::vector<ikgpu_task> &out) const override {
+        ikgpu_task k;
+        k.frame = 0;
+        k.reference = static_cast<int32_t>(reference_id_);
+        k.type = IKGPU_CENTRE_OF_MASS;
+        k.priority = priority;
+        for (int i = 0; i < 6; ++i) k.weight[i] = i < 3 ? weighting()[i] : 1.0;
+        out.push_back(k);
+    }
+    void abi_targets(std::vector<number_t> &out) const override {
+        number_t slot[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, target[0], target[1], target[2]};
+        out.insert(out.end(), slot, slot + 12);
+    }
+
+   private:
+    string_t reference_frame_;
+    index_t reference_id_ = 0;
+};
+
 // ---- ik::Constraint / ik::FrameConstraint (ik/ik/constraint.hpp; ik/ik/frame.hpp:325-449) -------------
 // The frame may not move relative to its reference frame in the selected coordinates: ik::dls keeps its step in the
 // null space of the stacked constraint Jacobian (ik/ik/dls.cpp:26-34,43-53).  `target` is never read by the loop.
@@ -480,6 +516,16 @@ class InverseKinematicsProblem {
         if (it == posture_tasks_map_.end()) throw std::out_of_range("Posture task does not exist: " + name);
         return posture_tasks_.at(it->second);
     }
+    std::shared_ptr<CentreOfMassTask> add_centre_of_mass_task(const std::shared_ptr<CentreOfMassTask> &task,
+                                                              const std::size_t &priority = 0) {  // problem.hpp:121-128
+        if (priority > max_priority_level_) throw std::out_of_range("Maximum priority level exceeded!");
+        if (com_task_) throw std::logic_error("a problem holds one centre-of-mass task");
+        com_task_ = task;
+        tasks_[priority].push_back(task);
+        ++generation_;
+        return com_task_;
+    }
+    std::shared_ptr<CentreOfMassTask> get_centre_of_mass_task() { return com_task_; }  // problem.hpp:130-132
     const std::vector<std::shared_ptr<DeviceTask>> &get_all_tasks(const std::size_t &priority) const { return tasks_.at(priority); }
     const model_t &model() const { return model_; }
     std::size_t generation() const { return generation_; }
@@ -496,6 +542,7 @@ class InverseKinematicsProblem {
     std::unordered_map<string_t, std::size_t> posture_tasks_map_;
     std::vector<std::shared_ptr<FrameConstraint>> frame_constraints_;
     std::unordered_map<string_t, std::size_t> frame_constraints_map_;
+    std::shared_ptr<CentreOfMassTask> com_task_;
     std::size_t generation_ = 0;
 };
 

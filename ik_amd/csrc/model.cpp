@@ -12,6 +12,7 @@
 // <joint> children: reference ik/test/ur5.urdf:249-296).
 #include "model.hpp"
 
+#include <algorithm>
 #include <charconv>
 #include <cmath>
 #include <cstring>
@@ -97,7 +98,30 @@ int32_t Model::joint_id(const std::string &name) const {
     return njoints();
 }
 
+// pinocchio::InertiaTpl::operator+= restricted to mass and lever, after placing the body: inertias[joint] += placement.act(Y)
+void Model::append_body(int32_t joint, const SE3 &pl, double mass, const std::array<double, 3> &c) {
+    joint_mass.resize(joint_type.size(), 0.0);
+    joint_com.resize(joint_type.size(), {0.0, 0.0, 0.0});
+    if (!(mass > 0.0)) return;  // a massless body adds nothing (and 0 / 0 is not worth reproducing)
+    const std::array<double, 3> placed = {pl[0] * c[0] + pl[1] * c[1] + pl[2] * c[2] + pl[9], pl[3] * c[0] + pl[4] * c[1] + pl[5] * c[2] + pl[10],
+                                          pl[6] * c[0] + pl[7] * c[1] + pl[8] * c[2] + pl[11]};
+    const double mab = joint_mass[joint] + mass, mab_inv = 1.0 / mab;
+    for (int i = 0; i < 3; ++i) {
+        joint_com[joint][i] *= joint_mass[joint] * mab_inv;
+        joint_com[joint][i] += (mass * mab_inv) * placed[i];
+    }
+    joint_mass[joint] = mab;
+}
+
+double Model::total_mass() const {
+    double s = 0.0;
+    for (size_t j = 1; j < joint_mass.size(); ++j) s += joint_mass[j];
+    return s;
+}
+
 void Model::finalize() {
+    joint_mass.resize(joint_type.size(), 0.0);
+    joint_com.resize(joint_type.size(), {0.0, 0.0, 0.0});
     const size_t nj = joint_type.size(), nf = frame_parent.size();
     if (joint_parent.size() != nj || joint_idx_q.size() != nj || joint_idx_v.size() != nj ||
         joint_placement.size() != nj || joint_axis.size() != nj || joint_names.size() != nj ||
@@ -144,6 +168,9 @@ Model Model::from_flat(const ikgpu_flat_model &f) {
         m.joint_placement.push_back(p);
         m.joint_axis.push_back({f.joint_axis[3 * j], f.joint_axis[3 * j + 1], f.joint_axis[3 * j + 2]});
         m.joint_names.push_back(f.joint_names && f.joint_names[j] ? f.joint_names[j] : ("joint" + std::to_string(j)));
+        m.joint_mass.push_back(f.joint_mass ? f.joint_mass[j] : 0.0);
+        if (f.joint_mass && f.joint_com) m.joint_com.push_back({f.joint_com[3 * j], f.joint_com[3 * j + 1], f.joint_com[3 * j + 2]});
+        else m.joint_com.push_back({0.0, 0.0, 0.0});
     }
     m.lower.assign(f.lower, f.lower + f.nq);
     m.upper.assign(f.upper, f.upper + f.nq);
@@ -164,12 +191,23 @@ Model Model::from_urdf(const char *xml_text, size_t len, bool free_flyer) {
     if (root->tag != "robot") throw std::runtime_error("URDF root element must be <robot>, got <" + root->tag + ">");
 
     std::vector<std::string> links;
+    struct LinkInertial { double mass = 0.0; std::array<double, 3> com{0, 0, 0}; };
+    std::map<std::string, LinkInertial> inertials;
     std::map<std::string, UrdfJoint> joints;  // ordered by name, as urdfdom's joints_ map
     for (const auto &el : root->children) {
         if (el->tag == "link") {
             const std::string *n = el->attr("name");
             if (!n) throw std::runtime_error("<link> without a name");
             links.push_back(*n);
+            if (const xml::Element *in = el->child("inertial")) {  // mass and centre of mass; the rotational inertia is not on the path
+                const xml::Element *ms = in->child("mass"), *org = in->child("origin");
+                if (ms && ms->attr("value")) {
+                    LinkInertial li;
+                    li.mass = parse_doubles(*ms->attr("value"), "mass of " + *n).at(0);
+                    li.com = parse_vec3(org ? org->attr("xyz") : nullptr, "inertial origin of " + *n, {0, 0, 0});
+                    inertials[*n] = li;
+                }
+            }
         } else if (el->tag == "joint") {
             UrdfJoint j;
             const std::string *n = el->attr("name"), *t = el->attr("type");
@@ -296,6 +334,15 @@ Model Model::from_urdf(const char *xml_text, size_t len, bool free_flyer) {
         }
     } visitor{m, children, body_frame, add_joint, add_frame};
     visitor.visit(root_link, 0);
+
+    // appendBodyToJoint for every link that carries an <inertial>, in visiting order (= BODY frame order)
+    std::vector<std::pair<int32_t, const std::string *>> bodies;
+    for (const auto &kv : body_frame) bodies.push_back({kv.second, &kv.first});
+    std::sort(bodies.begin(), bodies.end());
+    for (const auto &b : bodies) {
+        auto it = inertials.find(*b.second);
+        if (it != inertials.end()) m.append_body(m.frame_parent[b.first], m.frame_placement[b.first], it->second.mass, it->second.com);
+    }
 
     m.finalize();
     return m;

@@ -27,6 +27,13 @@ struct Model {
     std::vector<int32_t> frame_parent;
     std::vector<SE3> frame_placement;
     std::vector<std::string> frame_names;
+    // mass and lever (centre of mass in the joint frame) of the bodies attached to each joint: what
+    // pinocchio::centerOfMass reads of model.inertias[j]
+    std::vector<double> joint_mass;
+    std::vector<std::array<double, 3>> joint_com;
+    // appendBodyToJoint restricted to (mass, lever): inertias[joint] += placement.act(Y)
+    void append_body(int32_t joint, const SE3 &placement, double mass, const std::array<double, 3> &com);
+    double total_mass() const;  // of joints 1.. (bodies welded to the universe do not count, as in Pinocchio)
     // C views handed out by ikgpu_model_get_flat
     std::vector<const char *> joint_name_ptrs, frame_name_ptrs;
 

@@ -35,7 +35,9 @@ SE3 rot_only(const double *P, bool transpose) {
     return s;
 }
 
-int task_dim(const ikgpu_task &t) { return t.type == IKGPU_FULL ? 6 : (t.type >= IKGPU_ALIGN_AXIS_X ? 1 : 3); }
+int task_dim(const ikgpu_task &t) {  // align / posture rows: 1; frame position / orientation and centre of mass: 3
+    return t.type == IKGPU_FULL ? 6 : (t.type >= IKGPU_ALIGN_AXIS_X && t.type <= IKGPU_POSTURE_ROW ? 1 : 3);
+}
 
 bool is_identity(const SE3 &s) { return s == se3_identity(); }
 
@@ -162,6 +164,15 @@ void build_generic(ProblemHost &ph, const Model &m) {
         const ikgpu_task &t = ph.tasks[i];
         ttype.push_back(t.type);
         const bool posture = t.type == IKGPU_POSTURE_ROW;  // frame / reference are then tangent / configuration indices
+        if (t.type == IKGPU_CENTRE_OF_MASS) {               // no frame of its own: the universe stands in
+            g.has_com = 1;
+            tfj.push_back(0);
+            trj.push_back(m.frame_parent[t.reference]);
+            trow.push_back(ph.task_row[i]);
+            tdim.push_back(task_dim(t));
+            tprio.push_back(t.priority);
+            continue;
+        }
         tfj.push_back(posture ? t.frame : m.frame_parent[t.frame]);
         trj.push_back(posture ? t.reference : m.frame_parent[t.reference]);
         trow.push_back(ph.task_row[i]);
@@ -201,12 +212,23 @@ void build_generic(ProblemHost &ph, const Model &m) {
     g.o_tfpl = static_cast<int>(g.dbls.size());
     const SE3 ident = se3_identity();
     for (int i = 0; i < nt; ++i)
-        put_d(ph.tasks[i].type == IKGPU_POSTURE_ROW ? ident.data() : m.frame_placement[ph.tasks[i].frame].data(), 12);
+        put_d(ph.tasks[i].type == IKGPU_POSTURE_ROW || ph.tasks[i].type == IKGPU_CENTRE_OF_MASS ? ident.data()
+                                                                                              : m.frame_placement[ph.tasks[i].frame].data(), 12);
     g.o_trpl = static_cast<int>(g.dbls.size());
     for (int i = 0; i < nt; ++i)
         put_d(ph.tasks[i].type == IKGPU_POSTURE_ROW ? ident.data() : m.frame_placement[ph.tasks[i].reference].data(), 12);
     g.o_tw = static_cast<int>(g.dbls.size());
     for (int i = 0; i < nt; ++i) put_d(ph.tasks[i].weight, 6);
+    {   // pinocchio::centerOfMass constants: mass and lever per joint, mass of every subtree, 1 / total mass
+        std::vector<double> sub(m.joint_mass);
+        if (!sub.empty()) sub[0] = 0.0;
+        for (int j = nj - 1; j > 0; --j) sub[m.joint_parent[j]] += sub[j];
+        g.o_jmass = put_d(m.joint_mass.data(), m.joint_mass.size());
+        g.o_jlever = static_cast<int>(g.dbls.size());
+        for (int j = 0; j < nj; ++j) put_d(m.joint_com[j].data(), 3);
+        g.o_jsubmass = put_d(sub.data(), sub.size());
+        g.inv_total_mass = sub.empty() || !(sub[0] > 0.0) ? 0.0 : 1.0 / sub[0];
+    }
     g.o_cfpl = static_cast<int>(g.dbls.size());
     for (const ikgpu_task &c : ph.constraints) put_d(m.frame_placement[c.frame].data(), 12);
     g.o_crpl = static_cast<int>(g.dbls.size());
@@ -222,6 +244,7 @@ void build_generic(ProblemHost &ph, const Model &m) {
     g.off_y = o; o += M;
     g.off_dq = o; o += nv;
     g.off_Jc = o; o += crows * nv;
+    g.off_sf = o; o += g.has_com ? 3 * nj : 0;
     g.ws_words = o;
     g.off_P = o; o += nv * nv;
     g.off_Jb = o; o += mmax * nv;
@@ -260,14 +283,18 @@ ProblemHost analyse_problem(const Model &m, const ikgpu_task *tasks, int ntasks,
     int last_prio = 0;
     for (int i = 0; i < ntasks; ++i) {
         const ikgpu_task &t = tasks[i];
-        if (t.type == IKGPU_POSTURE_ROW) {
+        if (t.type == IKGPU_CENTRE_OF_MASS) {
+            if (t.reference < 0 || t.reference >= m.nframes()) throw std::runtime_error("task " + std::to_string(i) + ": reference frame id out of range");
+            if (!(m.total_mass() > 0.0))
+                throw std::runtime_error("task " + std::to_string(i) + ": a centre-of-mass task needs joint masses (the model has none)");
+        } else if (t.type == IKGPU_POSTURE_ROW) {
             if (t.frame < 0 || t.frame >= m.nv) throw std::runtime_error("task " + std::to_string(i) + ": posture row tangent index out of range");
             if (t.reference < 0 || t.reference >= m.nq) throw std::runtime_error("task " + std::to_string(i) + ": posture row configuration index out of range");
         } else {
             if (t.frame < 0 || t.frame >= m.nframes()) throw std::runtime_error("task " + std::to_string(i) + ": frame id out of range");
             if (t.reference < 0 || t.reference >= m.nframes()) throw std::runtime_error("task " + std::to_string(i) + ": reference frame id out of range");
         }
-        if (t.type < IKGPU_POSITION || t.type > IKGPU_POSTURE_ROW) throw std::runtime_error("task " + std::to_string(i) + ": unknown kinematic type");
+        if (t.type < IKGPU_POSITION || t.type > IKGPU_CENTRE_OF_MASS) throw std::runtime_error("task " + std::to_string(i) + ": unknown kinematic type");
         if (t.priority < 0) throw std::runtime_error("task " + std::to_string(i) + ": negative priority");
         if (t.priority < last_prio) throw std::runtime_error("tasks must be listed in stacking order (non-decreasing priority)");
         last_prio = t.priority;

@@ -33,6 +33,8 @@ struct GenericHost {
     int o_ctype = 0, o_cfjoint = 0, o_crjoint = 0, o_crow = 0, o_cdim = 0;  // FrameConstraint rows (into ints)
     int o_cfpl = 0, o_crpl = 0;                                              // (into dbls)
     int off_Jc = 0;
+    int has_com = 0, o_jmass = 0, o_jlever = 0, o_jsubmass = 0, off_sf = 0;  // centre-of-mass task (into dbls / workspace)
+    double inv_total_mass = 0.0;
 };
 
 // Host copy of one serial chain (support of one task below its base), axis-folded: every joint

@@ -59,7 +59,11 @@ typedef enum {
      * e = (q[reference] - target) * mask, J = unit row at tangent column `frame` (the reference does not apply the mask
      * to J), both times the weight.  Here `frame` is the tangent index, `reference` the index in q, weight[0] the
      * Task::weighting() entry, weight[1] the mask entry; the target value rides in double 9 of the row's 12-double slot. */
-    IKGPU_POSTURE_ROW = 6
+    IKGPU_POSTURE_ROW = 6,
+    /* ik::CentreOfMassTask (reference ik/ik/centre_of_mass.hpp:14-62; data.cpp:31-34): three rows,
+     * e = oMr^-1 * com(q) - target, J = R(oMr)^T Jcom (pinocchio::jacobianCenterOfMass).  `frame` is not read, `reference`
+     * is the reference frame; the target point rides in doubles 9..11 of the task's 12-double slot.  Needs joint masses. */
+    IKGPU_CENTRE_OF_MASS = 7
 } ikgpu_kinematic_type;
 
 typedef enum { IKGPU_SOA = 0, IKGPU_AOS = 1 } ikgpu_layout;
@@ -82,6 +86,10 @@ typedef struct {
     const double *frame_placement;  /* [nframes][12] */
     const char *const *joint_names; /* [njoints] */
     const char *const *frame_names; /* [nframes] */
+    /* what pinocchio::centerOfMass reads of model.inertias[j]: mass and lever (centre of mass in the joint frame) of the
+     * bodies attached to each joint.  As an input both may be NULL (no masses: a centre-of-mass task is then refused). */
+    const double *joint_mass;       /* [njoints] */
+    const double *joint_com;        /* [njoints][3] */
 } ikgpu_flat_model;
 
 /* One ik::FrameTask (reference ik/ik/frame.hpp:78-200) as the device sees it: frame and

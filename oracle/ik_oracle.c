@@ -334,7 +334,42 @@ static void frame_jacobian_local(const iko_model *m, const double *Jw, const dou
 
 static void rowspace_projector(const double *A, int m, int n, double *Pr);
 
-static int task_dim(const iko_task *t) { return t->type == IKO_FULL ? 6 : (t->type >= IKO_ALIGN_X ? 1 : 3); } /* align / posture rows: 1 */
+static int task_dim(const iko_task *t) { /* align / posture rows: 1; frame position / orientation and centre of mass: 3 */
+    return t->type == IKO_FULL ? 6 : (t->type >= IKO_ALIGN_X && t->type <= IKO_POSTURE_ROW ? 1 : 3);
+}
+
+/* pinocchio::centerOfMass + jacobianCenterOfMass(model, data, q, false) (data.cpp:31-34): data.com[0] and data.Jcom (3 x nv)
+ * from the joint placements oMi and the world joint Jacobian Jw.  Backward pass over the tree: mass and first moment of
+ * every subtree; column of joint j = (m_sub v_o - (m_sub c_sub) x w) / M with [v_o; w] the joint's world-frame spatial
+ * motion.  Bodies welded to the universe (inertias[0]) do not count. */
+static void centre_of_mass(const iko_model *m, const double *oMi, const double *Jw, double *com, double *Jcom) {
+    const int nj = m->njoints, nv = m->nv;
+    double *sm = (double *)calloc((size_t)nj, sizeof(double)), *sf = (double *)calloc((size_t)nj * 3, sizeof(double));
+    for (int j = 1; j < nj; ++j) {
+        const double *M = oMi + 12 * j, *c = m->lever + 3 * j;
+        sm[j] = m->mass[j];
+        for (int i = 0; i < 3; ++i)
+            sf[3 * j + i] = m->mass[j] * (R_(M, i, 0) * c[0] + R_(M, i, 1) * c[1] + R_(M, i, 2) * c[2] + P_(M, i));
+    }
+    for (int j = nj - 1; j > 0; --j) {
+        const int p = m->parent[j];
+        sm[p] += sm[j];
+        for (int i = 0; i < 3; ++i) sf[3 * p + i] += sf[3 * j + i];
+    }
+    const double Mt = sm[0];
+    for (int i = 0; i < 3; ++i) com[i] = sf[i] / Mt;
+    for (int i = 0; i < 3 * nv; ++i) Jcom[i] = 0.0;
+    for (int j = 1; j < nj; ++j) {
+        const int n = m->jtype[j] == IKO_JOINT_FREEFLYER ? 6 : 1;
+        for (int c = m->idx_v[j]; c < m->idx_v[j] + n; ++c) {
+            const double v[3] = {Jw[c], Jw[nv + c], Jw[2 * nv + c]}, w[3] = {Jw[3 * nv + c], Jw[4 * nv + c], Jw[5 * nv + c]};
+            double fxw[3];
+            cross3(sf + 3 * j, w, fxw);
+            for (int i = 0; i < 3; ++i) Jcom[i * nv + c] = (sm[j] * v[i] - fxw[i]) / Mt;
+        }
+    }
+    free(sm); free(sf);
+}
 
 int iko_task_rows(const iko_task *tasks, int ntasks) {
     int M = 0;
@@ -388,6 +423,27 @@ static void evaluate_ws(const iko_model *m, const iko_task *tasks, int ntasks, c
         for (int ti = 0; ti < ntasks; ++ti) {
             const iko_task *t = &tasks[ti];
             if (t->priority != p) continue;
+            if (t->type == IKO_COM) {
+                /* ik::CentreOfMassTask (centre_of_mass.hpp:33-45): e = oMr.actInv(com) - target, J = R(oMr)^T Jcom; the
+                 * target point rides in doubles 9..11 of the slot; then the task weights (data.cpp:49-50). */
+                const double *oMr = w->oMf + 12 * t->reference;
+                double com[3], d[3];
+                double *Jcom = (double *)malloc(sizeof(double) * 3 * nv);
+                centre_of_mass(m, w->oMi, w->Jw, com, Jcom);
+                for (int i = 0; i < 3; ++i) d[i] = com[i] - P_(oMr, i);
+                for (int r = 0; r < 3; ++r) {
+                    const double wt = t->weight[r];
+                    const double local = R_(oMr, 0, r) * d[0] + R_(oMr, 1, r) * d[1] + R_(oMr, 2, r) * d[2];
+                    w->et[row + r] = (local - targets[12 * ti + 9 + r]) * wt;
+                    if (p == 0) acc0 += w->et[row + r] * w->et[row + r];
+                    for (int c = 0; c < nv; ++c)
+                        w->Jt[(row + r) * nv + c] =
+                            wt * (R_(oMr, 0, r) * Jcom[c] + R_(oMr, 1, r) * Jcom[nv + c] + R_(oMr, 2, r) * Jcom[2 * nv + c]);
+                }
+                free(Jcom);
+                row += 3;
+                continue;
+            }
             if (t->type == IKO_POSTURE_ROW) {
                 /* one row of ik::PostureTask (posture.hpp:51-68): e = (q_k - target_k) * mask_k, J = e_k^T (the mask is
                  * not applied to J: "todo - incorporate mask"), then the task weight on both (data.cpp:49-50).

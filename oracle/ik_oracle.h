@@ -28,7 +28,10 @@ enum { IKO_POSITION = 0, IKO_ORIENTATION = 1, IKO_FULL = 2,
        IKO_ALIGN_X = 3, IKO_ALIGN_Y = 4, IKO_ALIGN_Z = 5,
        /* one row of ik::PostureTask (ik/ik/posture.hpp:17-85): frame = tangent column, reference = index in q,
         * weight[0] = task weight, weight[1] = mask entry, target value in double 9 of the slot */
-       IKO_POSTURE_ROW = 6 };
+       IKO_POSTURE_ROW = 6,
+       /* ik::CentreOfMassTask (ik/ik/centre_of_mass.hpp:14-62): three rows; reference = reference frame, frame unused,
+        * target point in doubles 9..11 of the slot */
+       IKO_COM = 7 };
 
 /* Flat kinematic model with Pinocchio's conventions (joint 0 = universe). SE(3) values are 12
  * doubles: rotation row-major (9) then translation (3). */
@@ -40,6 +43,10 @@ typedef struct {
     const double *lower, *upper;               /* [nq] */
     const int *frame_parent;                   /* [nframes] parent joint */
     const double *frame_placement;             /* [nframes][12] */
+    /* model.inertias[j] as pinocchio::centerOfMass reads it: mass and lever (centre of mass in the joint frame) of the
+     * bodies attached to joint j; needed by IKO_COM tasks only */
+    const double *mass;                        /* [njoints] */
+    const double *lever;                       /* [njoints][3] */
 } iko_model;
 
 /* ik::FrameTask (ik/ik/frame.hpp:78-200): frame ids, kinematic type, priority level and the

@@ -34,7 +34,7 @@ class _Model(C.Structure):
     _fields_ = [("njoints", C.c_int), ("nq", C.c_int), ("nv", C.c_int), ("nframes", C.c_int),
                 ("jtype", C.c_void_p), ("parent", C.c_void_p), ("idx_q", C.c_void_p), ("idx_v", C.c_void_p),
                 ("placement", C.c_void_p), ("axis", C.c_void_p), ("lower", C.c_void_p), ("upper", C.c_void_p),
-                ("frame_parent", C.c_void_p), ("frame_placement", C.c_void_p)]
+                ("frame_parent", C.c_void_p), ("frame_placement", C.c_void_p), ("mass", C.c_void_p), ("lever", C.c_void_p)]
 
 
 class _Task(C.Structure):
@@ -72,10 +72,12 @@ class OracleModel:
             k[name] = np.ascontiguousarray(flat[name], dtype=np.int32)
         for name in ("placement", "axis", "lower", "upper", "frame_placement"):
             k[name] = np.ascontiguousarray(flat[name], dtype=np.float64)
+        k["mass"] = np.ascontiguousarray(flat.get("mass", np.zeros(self.njoints)), dtype=np.float64)
+        k["lever"] = np.ascontiguousarray(flat.get("lever", np.zeros((self.njoints, 3))), dtype=np.float64)
         self._keep = k
         self.c = _Model(self.njoints, self.nq, self.nv, self.nframes, _p(k["jtype"]), _p(k["parent"]),
                         _p(k["idx_q"]), _p(k["idx_v"]), _p(k["placement"]), _p(k["axis"]), _p(k["lower"]),
-                        _p(k["upper"]), _p(k["frame_parent"]), _p(k["frame_placement"]))
+                        _p(k["upper"]), _p(k["frame_parent"]), _p(k["frame_placement"]), _p(k["mass"]), _p(k["lever"]))
         self.lower, self.upper = k["lower"], k["upper"]
 
     def frame_id(self, name):
@@ -286,4 +288,5 @@ def flat_from_twin(m):
         lower=np.array(m.lower), upper=np.array(m.upper),
         frame_parent=np.array([f["parent"] for f in m.frames], np.int32),
         frame_placement=np.array([m12(f["placement"]) for f in m.frames]),
-        frame_names=[f["name"] for f in m.frames], joint_names=list(m.names))
+        frame_names=[f["name"] for f in m.frames], joint_names=list(m.names),
+        mass=np.array(m.mass), lever=np.array(m.lever))

@@ -354,7 +354,53 @@ def load_urdf(path_or_xml, free_flyer=False):
     m.njoints = len(m.names)
     m.lower = np.array(m.lower)
     m.upper = np.array(m.upper)
+    # what pinocchio::centerOfMass reads of model.inertias[j]: total mass of the links welded to joint j and their common
+    # centre of mass in the joint frame (appendBodyToJoint with each link's body placement)
+    inertial = {}
+    for e in root:
+        if e.tag == "link" and e.find("inertial") is not None and e.find("inertial").find("mass") is not None:
+            o = e.find("inertial").find("origin")
+            inertial[e.get("name")] = (float(e.find("inertial").find("mass").get("value")),
+                                       np.array(_floats(o.get("xyz", "0 0 0"), 3) if o is not None else [0.0, 0.0, 0.0]))
+    m.mass = np.zeros(m.njoints)
+    first_moment = np.zeros((m.njoints, 3))
+    for f in m.frames:
+        if f["type"] == "body" and f["name"] in inertial:
+            mass, c = inertial[f["name"]]
+            m.mass[f["parent"]] += mass
+            first_moment[f["parent"]] += mass * (f["placement"][:3, :3] @ c + f["placement"][:3, 3])
+    m.lever = np.where(m.mass[:, None] > 0, first_moment / np.where(m.mass > 0, m.mass, 1.0)[:, None], 0.0)
     return m
+
+
+def centre_of_mass(m, q):
+    """pinocchio::centerOfMass + jacobianCenterOfMass (ik/ik/data.cpp:31-34): data.com[0] and data.Jcom (3 x nv).
+    Bodies welded to the universe (joint 0) do not count, as in Pinocchio."""
+    oMi, _ = fk(m, q)
+    Jw = joint_jacobians_world(m, oMi)
+    sub_mass = m.mass.copy()
+    sub_mass[0] = 0.0
+    sub_first = np.array([m.mass[j] * (oMi[j][:3, :3] @ m.lever[j] + oMi[j][:3, 3]) for j in range(m.njoints)])
+    sub_first[0] = 0.0
+    for j in range(m.njoints - 1, 0, -1):
+        sub_mass[m.parent[j]] += sub_mass[j]
+        sub_first[m.parent[j]] += sub_first[j]
+    M = sub_mass[0]
+    Jcom = np.zeros((3, m.nv))
+    for j in range(1, m.njoints):
+        n = 6 if m.jtype[j] == J_FREEFLYER else 1
+        for c in range(m.idx_v[j], m.idx_v[j] + n):
+            Jcom[:, c] = (sub_mass[j] * Jw[:3, c] - np.cross(sub_first[j], Jw[3:, c])) / M
+    return sub_first[0] / M, Jcom
+
+
+class CentreOfMassTask:
+    """ik::CentreOfMassTask (ik/ik/centre_of_mass.hpp:14-62): e = oMr^-1 com - target, J = R(oMr)^T Jcom."""
+
+    def __init__(self, m, reference="universe", target=None, weights=None):
+        self.reference = frame_id(m, reference)
+        self.target = np.zeros(3) if target is None else np.array(target, float)
+        self.w = np.ones(3) if weights is None else np.array(weights, float)
 
 
 def frame_id(m, name):
@@ -480,6 +526,12 @@ def evaluate(m, tasks, q):
     Jw = joint_jacobians_world(m, oMi)
     es, Js = [], []
     for t in tasks:
+        if isinstance(t, CentreOfMassTask):
+            com, Jcom = centre_of_mass(m, q)
+            Mr = oMf[t.reference]
+            es.append((Mr[:3, :3].T @ (com - Mr[:3, 3]) - t.target) * t.w)
+            Js.append(t.w[:, None] * (Mr[:3, :3].T @ Jcom))
+            continue
         if isinstance(t, PostureTask):
             J = np.zeros((t.nj, m.nv))
             J[:, m.nv - t.nj:] = np.eye(t.nj)

@@ -54,6 +54,10 @@ int main(int argc, char **argv) {
         std::vector<double> posture_target;
         bool use_pik = false;
         std::vector<double> pik_lambda;
+        bool use_com = false;
+        std::string com_reference;
+        std::size_t com_prio = 0;
+        double com_target[3] = {0, 0, 0};
         struct ConstraintSpec { std::string frame, reference; int type; };
         std::vector<ConstraintSpec> constraint_specs;
         while (a < argc) {
@@ -64,6 +68,12 @@ int main(int argc, char **argv) {
                 posture_weight = std::atof(next().c_str());
                 for (std::size_t i = 0; i < posture_nj; ++i) posture_target.push_back(std::atof(next().c_str()));
                 if (posture_prio > max_priority) max_priority = posture_prio;
+            } else if (opt == "com") {  // a CentreOfMassTask: <reference frame> <priority> <target x y z>
+                com_reference = next();
+                com_prio = std::atoi(next().c_str());
+                for (double &x : com_target) x = std::atof(next().c_str());
+                use_com = true;
+                if (com_prio > max_priority) max_priority = com_prio;
             } else if (opt == "constraint") {  // a FrameConstraint: <frame> <type 0|1|2> <reference frame>
                 ConstraintSpec c;
                 c.frame = next();
@@ -100,6 +110,10 @@ int main(int argc, char **argv) {
             posture->weighting().setConstant(posture_weight);
         }
 
+        if (use_com) {  // reference ik/ik/centre_of_mass.hpp:28-31; problem.hpp:121-132; cassie.cpp:58,79,101
+            problem.add_centre_of_mass_task(ik::CentreOfMassTask::create(model, com_reference), com_prio);
+            problem.get_centre_of_mass_task()->target << com_target[0], com_target[1], com_target[2];
+        }
         k = 0;
         for (auto &c : constraint_specs) {  // reference ik/ik/problem.hpp:68-77
             const ik::KinematicType type = c.type == 0 ? ik::KinematicType::Position

@@ -39,6 +39,11 @@ def build(name, ff, specs, B, seed=0, xml_edit=None):
     model = ik_amd.Model.from_urdf_xml(xml, free_flyer=ff)
     problem = ik_amd.InverseKinematicsProblem(model, max(s[4] for s in specs))
     for i, (kind, f, r, t, p, w) in enumerate(specs):
+        if kind == "com":       # r = reference frame
+            task = problem.add_centre_of_mass_task(ik_amd.CentreOfMassTask.create(model, r), p)
+            if w is not None:
+                task.weighting()[:] = w
+            continue
         if kind == "posture":   # f = nj, w = (weights, mask)
             task = problem.add_posture_task("t%d" % i, ik_amd.PostureTask.create(model, f), p)
             task.weighting()[:], task.mask[:] = w
@@ -58,6 +63,9 @@ def build(name, ff, specs, B, seed=0, xml_edit=None):
             ospec += [(model.nv - t.nj + k, model.nq - t.nj + k, 6, prio, [t.weighting()[k], t.mask[k]]) for k in range(t.nj)]
             continue
         w = None if np.all(t.weighting() == 1) else list(t.weighting())
+        if isinstance(t, ik_amd.CentreOfMassTask):
+            ospec.append((0, t._ref_id, 7, prio, w))
+            continue
         ospec.append((t._frame_id, t._ref_id, 3 + int(t.axis) if isinstance(t, ik_amd.AlignAxisTask) else int(t.type), prio, w))
     rng = np.random.default_rng(seed)
     if ff:
@@ -71,7 +79,10 @@ def build(name, ff, specs, B, seed=0, xml_edit=None):
     for b in range(B):
         _, oMf = O.fk(om, qs[b])
         for i, (fid, rid, typ, _, _) in enumerate(ospec):
-            if typ == 6:
+            if typ == 7:   # centre of mass at q*, seen from the reference frame
+                tg[b, i, :9] = np.eye(3).ravel()
+                tg[b, i, 9:] = O.evaluate(om, O.make_tasks([(0, rid, 7, 0, None)]), np.zeros((1, 12)), qs[b])[0]
+            elif typ == 6:
                 tg[b, i, 9] = qs[b, rid]
             elif typ >= 3:
                 tg[b, i, :9] = np.eye(3).ravel()
@@ -100,6 +111,13 @@ CASES = {
     "posture_regulariser": ("cassie", True, [("frame", "LeftFootFront", "universe", 2, 0, None), ("frame", "pelvis", "universe", 2, 0, None),
                                              ("posture", 16, None, None, 1, ([0.1 + 0.05 * k for k in range(16)],
                                                                              [0.0 if k in (3, 9) else 1.0 for k in range(16)]))], None),
+    # ik::CentreOfMassTask (reference ik/ik/centre_of_mass.hpp:14-62): the demo's commented-out balance task under two foot
+    # poses; seen from a moving frame with weights; alone on the arm
+    "com_under_feet": ("cassie", True, [("frame", "LeftFootFront", "universe", 2, 0, None), ("frame", "RightFootFront", "universe", 2, 0, None),
+                                        ("com", None, "universe", None, 1, None)], None),
+    "com_in_foot_frame": ("cassie_fixed", False, [("frame", "LeftFootFront", "universe", 0, 0, None),
+                                                  ("com", None, "LeftFootFront", None, 0, [1.0, 2.0, 0.5])], None),
+    "com_of_the_arm": ("ur5", False, [("com", None, "universe", None, 0, None)], None),
     "posture_first_level": ("ur5", False, [("posture", 4, None, None, 0, ([1.0] * 4, [1.0] * 4)),
                                            ("frame", "tool0", "universe", 0, 0, None)], None),
 }
@@ -232,6 +250,36 @@ def test_cpp_api_program_with_posture_task(torch_cuda):
     q2, ok2, it2 = O.dls(om, ot, tg, q1, O.params(30, 0.01, 1.0, 1e-6))
     assert np.abs(np.array(out["q_first"]) - q1).max() <= TOL
     assert np.abs(np.array(out["q"]) - q2).max() <= TOL
+    assert out["success"] == int(ok2) and out["iterations"] == it2
+
+
+def test_cpp_api_program_with_centre_of_mass_task(torch_cuda):
+    """ik::CentreOfMassTask through the C++ mirror (tests/cpp/test_dls_api.cpp's `com` option): a foot pose at priority 0,
+    the centre of mass over a target point at priority 1."""
+    import json
+    import subprocess
+    import ik_amd
+    import oracle as O
+    from ik_amd import workload
+    from test_gpu_parity import _cpp_binary
+    model = ik_amd.Model.from_urdf_file(urdf_path("cassie"), free_flyer=True)
+    om = O.OracleModel(model.flat())
+    nom = workload.cassie_nominal(model.names)
+    q0, qs = workload.freeflyer_workload(model.lowerPositionLimit, model.upperPositionLimit, nom, np.arange(2), seed=11)
+    q0, qs = q0[1], qs[1]
+    fid = model.getFrameId("LeftFootFront")
+    tg = np.zeros((2, 12))
+    tg[0] = O.fk(om, qs)[1][fid]
+    tg[1, :9] = np.eye(3).ravel()
+    tg[1, 9:] = O.evaluate(om, O.make_tasks([(0, 0, 7, 0, None)]), np.zeros((1, 12)), qs)[0]
+    ot = O.make_tasks([(fid, 0, 2, 0, None), (0, 0, 7, 1, None)])
+    args = [_cpp_binary(), urdf_path("cassie"), "1", "30", "0.01", "1.0", "1e-8", "1", "LeftFootFront", "2", "0"]
+    args += ["%.17g" % x for x in tg[0]] + ["%.17g" % x for x in q0] + ["com", "universe", "1"] + ["%.17g" % x for x in tg[1, 9:]]
+    out = json.loads(subprocess.check_output(args, text=True))
+    assert out["kernel"].startswith("dls_generic<M=9")
+    q1, ok1, it1 = O.dls(om, ot, tg, q0, O.params(30, 0.01, 1.0, 1e-8))
+    q2, ok2, it2 = O.dls(om, ot, tg, q1, O.params(30, 0.01, 1.0, 1e-8))
+    assert np.abs(np.array(out["q_first"]) - q1).max() <= TOL and np.abs(np.array(out["q"]) - q2).max() <= TOL
     assert out["success"] == int(ok2) and out["iterations"] == it2
 
 

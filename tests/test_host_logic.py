@@ -61,6 +61,43 @@ def test_urdf_loader_matches_golden_model_tables(ik, case):
     assert m.getFrameId("universe") == 0 and m.getFrameId("no_such_frame") == m.nframes  # as Model::getFrameId
 
 
+@pytest.mark.parametrize("name,ff", [("cassie", True), ("cassie_fixed", False), ("ur5", False)])
+def test_loader_masses_match_the_twin(ik, name, ff):
+    """Mass and lever of the bodies on each joint (what pinocchio::centerOfMass reads of model.inertias): the product's
+    loader (appendBodyToJoint-style accumulation) against the twin's (sums of first moments)."""
+    f = ik.Model.from_urdf_file(urdf_path(name), free_flyer=ff).flat()
+    t = T.load_urdf(urdf_path(name), free_flyer=ff)
+    assert np.abs(f["mass"] - t.mass).max() < 1e-13
+    assert np.abs(f["lever"] - t.lever).max() < 1e-15
+    total = {"cassie": 34.676752, "cassie_fixed": 24.346752, "ur5": 16.9939}[name]   # links below the first moving joint
+    assert abs(f["mass"][1:].sum() - total) < 1e-9
+    if name == "cassie_fixed":
+        assert abs(f["mass"][0] - 10.33) < 1e-12   # the pelvis is welded to the universe: Pinocchio leaves it out of the CoM
+
+
+def test_centre_of_mass_task_plan_and_errors(ik):
+    from ik_amd import api, capi
+    m = ik.Model.from_urdf_file(urdf_path("cassie"), free_flyer=True)
+    p = ik.InverseKinematicsProblem(m, 1)
+    p.add_frame_task("fl", ik.FrameTask.create(m, "LeftFootFront"))
+    com = p.add_centre_of_mass_task(ik.CentreOfMassTask.create(m), 1)
+    assert p.get_centre_of_mass_task() is com and com.dimension() == 3 and p.e_size(1) == 3
+    com.target[:] = [0.0, 0.0, 1.0]                                              # reference ik_ros/src/cassie.cpp:101
+    assert api._abi_rows(com, 1) == [(0, 0, capi.CENTRE_OF_MASS, 1, [1.0] * 6)]
+    assert api._target_slots(com)[0, 9:].tolist() == [0.0, 0.0, 1.0]
+    assert ik.plan(p) == "dls_generic<M=9,nv=22,joints=17>"
+    with pytest.raises(ValueError):
+        p.add_centre_of_mass_task(ik.CentreOfMassTask.create(m), 1)
+    # a model without masses cannot carry the task
+    bare = ik.Model.from_urdf_xml(b"<robot><link name='a'/><link name='b'/><joint name='j' type='revolute'><parent link='a'/>"
+                                  b"<child link='b'/><axis xyz='0 0 1'/><limit lower='-1' upper='1'/></joint></robot>")
+    q = ik.InverseKinematicsProblem(bare)
+    q.add_centre_of_mass_task(ik.CentreOfMassTask.create(bare))
+    with pytest.raises(capi.IkgpuError) as ei:
+        ik.plan(q)
+    assert "needs joint masses" in ei.value.message
+
+
 def test_loader_on_the_reference_urdfs_when_present(ik):
     """The stripped fixtures and the reference's full URDFs (visual / inertial / transmission elements,
     comments, nested <joint> inside <transmission>) give the identical model."""

@@ -226,7 +226,7 @@ def _generic_case(name, ff, specs, B, seed=0, xml_edit=None):
     tasks = (capi.Task * len(specs))()
     ospec, fids, rids = [], [], []
     for i, (f, r, t, p, w) in enumerate(specs):
-        fid, rid = (f, r) if t == 6 else (model.getFrameId(f), model.getFrameId(r))
+        fid, rid = (f, r) if t == 6 else ((0, model.getFrameId(r)) if t == 7 else (model.getFrameId(f), model.getFrameId(r)))
         ww = list(w) + [1.0] * (6 - len(w)) if w is not None else [1.0] * 6
         tasks[i] = capi.Task(fid, rid, t, p, (C.c_double * 6)(*ww))
         ospec.append((fid, rid, t, p, w))
@@ -237,7 +237,9 @@ def _generic_case(name, ff, specs, B, seed=0, xml_edit=None):
     for b in range(B):
         _, oMf = O.fk(om, qs[b])
         for i, (f, r, t, p, w) in enumerate(specs):
-            if t == 6:
+            if t == 7:   # centre of mass at q*, seen from the reference frame: the error of the task with a zero target
+                tg[b, i, 9:] = O.evaluate(om, O.make_tasks([(0, rids[i], 7, 0, None)]), np.zeros((1, 12)), qs[b])[0]
+            elif t == 6:
                 tg[b, i, 9] = qs[b, rids[i]]
             elif t >= 3:
                 tg[b, i, 9:] = rng.normal(size=3)
@@ -246,7 +248,7 @@ def _generic_case(name, ff, specs, B, seed=0, xml_edit=None):
                 Mr, Mf = T4(oMf[rids[i]]), T4(oMf[fids[i]])
                 rel = np.linalg.inv(Mr) @ Mf
                 tg[b, i] = np.concatenate([rel[:3, :3].ravel(), rel[:3, 3]])
-    M = sum(6 if t == 2 else (1 if t >= 3 else 3) for _, _, t, _, _ in specs)
+    M = sum(6 if t == 2 else (1 if 3 <= t <= 6 else 3) for _, _, t, _, _ in specs)
     return urdf, model, om, tasks, O.make_tasks(ospec), q0, tg, M
 
 
@@ -289,6 +291,13 @@ GENERIC_CASES = {
     "posture_regulariser": ("cassie", True, [("LeftFootFront", "universe", 2, 0, None), ("pelvis", "universe", 2, 0, None),
                                              ("@posture", 16, 6, 1, ([0.1 + 0.05 * k for k in range(16)],
                                                                      [0.0 if k in (3, 9) else 1.0 for k in range(16)]))], 1, None),
+    # ik::CentreOfMassTask (reference ik/ik/centre_of_mass.hpp:14-62): the demo's commented-out balance task
+    # (ik_ros/src/cassie.cpp:58,79,101) at priority 1 under the two foot poses; and seen from a moving frame, weighted
+    "com_under_feet": ("cassie", True, [("LeftFootFront", "universe", 2, 0, None), ("RightFootFront", "universe", 2, 0, None),
+                                        ("@com", "universe", 7, 1, None)], 1, None),
+    "com_in_foot_frame": ("cassie_fixed", False, [("LeftFootFront", "universe", 0, 0, None),
+                                                  ("@com", "LeftFootFront", 7, 0, [1.0, 2.0, 0.5])], 0, None),
+    "com_of_the_arm": ("ur5", False, [("@com", "universe", 7, 0, None)], 0, None),
     "posture_only_arm": ("ur5", False, [("@posture", 4, 6, 0, ([1.0] * 4, [1.0] * 4)), ("tool0", "universe", 0, 0, None)], 0, None),
 }
 
