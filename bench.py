@@ -281,7 +281,7 @@ def main():
                                     "frac": tf / FP64_VALU_PEAK_TF, "flop_per_solve": flops,
                                     "counting": "executed FP64 VALU instructions per launch from the SQ_INSTS_VALU_{FMA,MUL,ADD,"
                                                 "TRANS}_F64 counters (x 64 lanes, FMA = 2), 50 iterations; profiles/r01_pmc"}
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:   # the CPU leg runs on rank 0 at N = 1 only
             tg_np = targets.permute(2, 0, 1).contiguous().cpu().numpy()
             cpu, q_ref, sample, conv = cpu_baseline(model, w, q0_np, tg_np, args.iters)
             res["cpu_baseline"] = cpu

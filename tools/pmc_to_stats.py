@@ -22,7 +22,7 @@ def main(src, kernel, dst, tag):
     os.makedirs(dst, exist_ok=True)
     agg = collections.defaultdict(list)
     for p in sorted(glob.glob(os.path.join(src, "*", "runc", "*counter_collection.csv"))):
-        rows = [r for r in csv.DictReader(open(p)) if "dls_" in r["Kernel_Name"]]
+        rows = [r for r in csv.DictReader(open(p)) if "dls_" in r["Kernel_Name"] or "pik_" in r["Kernel_Name"]]
         if not rows:
             continue
         keep = [k for k in ("Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size",
