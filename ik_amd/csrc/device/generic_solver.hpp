@@ -442,7 +442,7 @@ IKD_FN void generic_dls(const GenericTables &T, const LoopParams &prm, const Ws 
         }
         for (int k = M - 1; k >= 0; --k) {
             double s = ws[T.off_y + k];
-            for (int m = k + 1; m < M; ++m) s = dfma(-ws[T.off_G + tri(m, k)], ws[T.off_y + m], s);
+            for (int m = M - 1; m > k; --m) s = dfma(-ws[T.off_G + tri(m, k)], ws[T.off_y + m], s);  // (the order coop_solver.hpp takes)
             ws[T.off_y + k] = s * ws[T.off_G + tri(k, k)];
         }
         for (int c = 0; c < nv; ++c) {  // dq = -Jt^T y, ik/ik/dls.cpp:52-53 (N = I)

@@ -2,6 +2,7 @@
 // pointer struct its lane program reads (device/generic_solver.hpp: GenericTables), for base pointers that live
 // either on the device (kernels.hip) or on the host (the lane emulator under tests/).
 #pragma once
+#include "device/coop_solver.hpp"
 #include "device/generic_solver.hpp"
 #include "problem.hpp"
 
@@ -27,6 +28,17 @@ inline ikdev::GenericTables bind_generic_tables(const ProblemHost &ph, const int
     T.inv_total_mass = g.inv_total_mass; T.off_sf = g.off_sf;
     T.off_P = g.off_P; T.off_Jb = g.off_Jb; T.off_de = g.off_de; T.ws_words_pik = g.ws_words_pik;
     return T;
+}
+
+// The cooperative DLS program's layout and index tables (problem.cpp: build_coop).
+inline ikdev::CoopLayout bind_coop_layout(const ProblemHost &ph, const int32_t *ibase) {
+    const GenericHost &g = ph.generic;
+    ikdev::CoopLayout L{};
+    L.q = g.c_q; L.tg = g.c_tg; L.A0 = g.c_A0; L.A1 = g.c_A1; L.Jw = g.c_Jw; L.tb = g.c_tb; L.e = g.c_e; L.J = g.c_J; L.G = g.c_G;
+    L.dinv = g.c_dinv; L.x = g.c_x; L.dq = g.c_dq; L.words = g.coop_words;
+    L.rounds = g.coop_rounds; L.npairs = g.coop_npairs;
+    L.support = ibase + g.o_csupport; L.pair_i = ibase + g.o_cpair_i; L.pair_j = ibase + g.o_cpair_j; L.order = ibase + g.o_cup; L.lvl_start = ibase + g.o_clvl; L.tb_index = ibase + g.o_ctbindex;
+    return L;
 }
 
 }  // namespace ikgpu

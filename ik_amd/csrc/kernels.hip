@@ -6,6 +6,8 @@
 // program is device/chain_solver.hpp, the per-lane load/solve/store is device/chain_kernel_body.hpp.
 #include "kernels.hpp"
 
+#include <algorithm>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 
@@ -394,8 +396,81 @@ hipError_t launch_pik_generic(const ProblemHost &gen, const DeviceTables &dt, co
     return e != hipSuccess ? e : f;
 }
 
+namespace {
+
+// Cooperative form: 16 lanes per problem, 4 problems per 64-lane workgroup, the workspace in (dynamic) LDS.
+struct CoopStaging {  // the problem's packed tables in HBM, copied to LDS by every workgroup before the first phase
+    const int32_t *ints;
+    const double *dbls;
+    int n_ints, n_dbls;
+};
+
+template <class P>
+__device__ __forceinline__ void rebase(const P *&p, const P *from, const P *to) { p = to + (p - from); }
+
+__global__ __launch_bounds__(kBlock) void dls_coop_kernel(ikdev::CoopKernelArgs a, const CoopStaging s) {
+    extern __shared__ double coop_lds[];
+    // LDS: [double tables | int tables | four workspaces]; a table read inside the phases is then an LDS read, not an
+    // L2 round trip (73 global loads per iteration otherwise, each a dependent ~1 us stall with so few waves per CU)
+    double *ld = coop_lds;
+    int32_t *li = reinterpret_cast<int32_t *>(coop_lds + s.n_dbls);
+    double *ws0 = coop_lds + s.n_dbls + (s.n_ints + 1) / 2;
+    for (int i = threadIdx.x; i < s.n_dbls; i += blockDim.x) ld[i] = s.dbls[i];
+    for (int i = threadIdx.x; i < s.n_ints; i += blockDim.x) li[i] = s.ints[i];
+    __syncthreads();
+    ikdev::GenericTables &T = a.T;
+    rebase(T.jtype, s.ints, li); rebase(T.parent, s.ints, li); rebase(T.idx_q, s.ints, li); rebase(T.idx_v, s.ints, li);
+    rebase(T.t_type, s.ints, li); rebase(T.t_fjoint, s.ints, li); rebase(T.t_rjoint, s.ints, li); rebase(T.t_row, s.ints, li);
+    rebase(T.t_dim, s.ints, li); rebase(T.t_prio, s.ints, li); rebase(T.lvl_row0, s.ints, li);
+    rebase(T.placement, s.dbls, ld); rebase(T.axis, s.dbls, ld); rebase(T.lower, s.dbls, ld); rebase(T.upper, s.dbls, ld);
+    rebase(T.t_fpl, s.dbls, ld); rebase(T.t_rpl, s.dbls, ld); rebase(T.t_w, s.dbls, ld);
+    rebase(a.L.support, s.ints, li); rebase(a.L.pair_i, s.ints, li); rebase(a.L.pair_j, s.ints, li); rebase(a.L.order, s.ints, li); rebase(a.L.lvl_start, s.ints, li);
+    rebase(a.L.tb_index, s.ints, li);
+    const int grp = threadIdx.x / ikdev::kCoopGroup, g = threadIdx.x % ikdev::kCoopGroup;
+    const int per_block = blockDim.x / ikdev::kCoopGroup;
+    ikdev::dls_coop_body(a, static_cast<int64_t>(blockIdx.x) * per_block + grp, g, ws0 + grp * a.L.words,
+                         [](bool act) { return __any(act) != 0; });
+}
+
+}  // namespace
+
+#ifdef IKGPU_COOP_PROFILE
+// Debug builds only: per-phase cycle counters of workgroup 0 of the cooperative kernel, accumulated over its iterations.
+extern "C" int ikgpu_debug_coop_profile(long long *out16, int reset) {
+    long long zero[16] = {};
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(ikdev::g_coop_prof), sizeof(zero)) != hipSuccess) return 1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(ikdev::g_coop_prof), zero, sizeof(zero)) != hipSuccess) return 1;
+    return 0;
+}
+#endif
+
+bool generic_runs_cooperative(const ProblemHost &ph) {
+    if (!ph.generic.coop_ok) return false;
+    const char *force = std::getenv("IKGPU_GENERIC_KERNEL");  // "lane": keep the memory-resident per-lane program (tests, profiling)
+    return !(force && std::string(force) == "lane");
+}
+
 hipError_t launch_dls_generic(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const ikgpu_dls_params &prm,
                               hipStream_t stream) {
+    if (generic_runs_cooperative(ph)) {
+        ikdev::CoopKernelArgs c{};
+        c.T = bind_generic_tables(ph, dt.g_ints, dt.g_dbls);
+        c.L = bind_coop_layout(ph, dt.g_ints);
+        c.prm.max_iterations = prm.max_iterations;
+        c.prm.lam2 = prm.damping * prm.damping;
+        c.prm.step_length = prm.step_length;
+        c.prm.stop_sq_tol = prm.stop_sq_tol;
+        c.layout = io.layout; c.B = io.B; c.q0 = io.q0; c.targets = io.targets;
+        c.q_out = io.q_out; c.success = io.success; c.iters = io.iters;
+        const CoopStaging s{dt.g_ints, dt.g_dbls, static_cast<int>(ph.generic.ints.size()), static_cast<int>(ph.generic.dbls.size())};
+        int per_block = ikdev::kCoopPerBlock;
+        if (const char *pb = std::getenv("IKGPU_COOP_PER_BLOCK")) per_block = std::max(1, std::min(4, std::atoi(pb)));
+        const size_t lds = sizeof(double) * (static_cast<size_t>(per_block) * static_cast<size_t>(c.L.words) +
+                                             static_cast<size_t>(s.n_dbls) + static_cast<size_t>((s.n_ints + 1) / 2));
+        const int64_t blocks = (io.B + per_block - 1) / per_block;
+        hipLaunchKernelGGL(dls_coop_kernel, dim3(static_cast<unsigned>(blocks)), dim3(per_block * ikdev::kCoopGroup), lds, stream, c, s);
+        return hipGetLastError();
+    }
     ikdev::GenericKernelArgs a{};
     a.prm.max_iterations = prm.max_iterations;
     a.prm.lam2 = prm.damping * prm.damping;

@@ -49,6 +49,9 @@ hipError_t launch_eval_tree(const ProblemHost &ph, const DeviceTables &dt, int64
 bool tree_shape_built(int nj, int nch);
 // Generic fallback kernel.  The per-lane workspace (ws_words doubles x roundup(B, 64) lanes) is allocated and
 // freed in stream order (hipMallocAsync / hipFreeAsync), so the call stays asynchronous and re-entrant.
+// True when launch_dls_generic runs the cooperative LDS-resident program (device/coop_solver.hpp) for this problem: no
+// constraints, no centre-of-mass task, four workspaces fit 64 KB of LDS, and IKGPU_GENERIC_KERNEL is not "lane".
+bool generic_runs_cooperative(const ProblemHost &ph);
 hipError_t launch_dls_generic(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io,
                               const ikgpu_dls_params &prm, hipStream_t stream);
 // ik::pik (reference ik/ik/pik.cpp:31-103): always the generic lane program; `gen` must be a Generic-kind analysis and

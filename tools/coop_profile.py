@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Per-phase cycle counts of the cooperative generic DLS kernel (debug build: make -C ik_amd/csrc KERNEL_EXTRA=-DIKGPU_COOP_PROFILE).
+Runs the demo task set once and prints workgroup 0's cycles per phase and iteration."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import ik_amd  # noqa: E402
+from ik_amd import capi, workload  # noqa: E402
+
+model = ik_amd.Model.from_urdf_file(os.path.join(workload.MODELS_DIR, "cassie.kin.urdf"), free_flyer=True)
+problem = ik_amd.InverseKinematicsProblem(model)
+problem.add_frame_task("fl", ik_amd.FrameTask.create(model, "LeftFootFront", ik_amd.KinematicType.Position, "pelvis"))
+problem.add_frame_task("pelvis", ik_amd.FrameTask.create(model, "pelvis", ik_amd.KinematicType.Full))
+problem.add_align_axis_task("align", ik_amd.AlignAxisTask.create(model, "LeftFootFront", ik_amd.AlignAxisType.AxisY))
+data = ik_amd.dls_data(problem)
+B, iters = 65536, 50
+q0, qs = workload.freeflyer_workload(model.lowerPositionLimit, model.upperPositionLimit, workload.cassie_nominal(model.names), np.arange(B), seed=0)
+Q0 = torch.from_numpy(np.ascontiguousarray(q0.T)).cuda()
+T = torch.zeros((3, 12, B), dtype=torch.float64, device="cuda")
+T[:, [0, 4, 8]] = 1.0
+T[0, 11], T[1, 11], T[2, 9] = -0.8, 1.0, 1.0
+p = ik_amd.dls_parameters(max_iterations=iters, damping=1e-2, step_length=1.0)
+L = capi.lib()
+out = (C.c_longlong * 16)()
+ik_amd.dls_batch(problem, Q0, T, data, ik_amd.never_stop_visitor(), p)
+torch.cuda.synchronize()
+L.ikgpu_debug_coop_profile(out, 1)
+ik_amd.dls_batch(problem, Q0, T, data, ik_amd.never_stop_visitor(), p)
+torch.cuda.synchronize()
+L.ikgpu_debug_coop_profile(out, 1)
+names = ["local transforms", "tree levels + Jw", "task blocks", "task Jacobian columns", "Gram", "Cholesky", "back substitution", "dq", "integrate"]
+tot = sum(out[:9])
+for n, v in zip(names, out[:9]):
+    print("%-24s %9.0f cycles / iteration  %5.1f %%" % (n, v / iters, 100.0 * v / tot))
+print("%-24s %9.0f cycles / iteration (s_memtime, workgroup 0)" % ("total", tot / iters))
