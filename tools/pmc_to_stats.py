@@ -41,7 +41,9 @@ def main(src, kernel, dst, tag):
     stats = json.load(open(path))
     e = stats.setdefault(kernel, {})
     e["hbm_traffic_bytes_per_launch"] = traffic
-    e["pmc"] = {"batch": int(rows[0]["Grid_Size"]) if rows else None, "FETCH_SIZE_KiB": mean.get("FETCH_SIZE"),
+    # problems per launch: one per lane, except the cooperative kernel's sixteen lanes per problem
+    lanes_per_problem = 16 if rows and "coop" in rows[0]["Kernel_Name"] else 1
+    e["pmc"] = {"batch": int(rows[0]["Grid_Size"]) // lanes_per_problem if rows else None, "FETCH_SIZE_KiB": mean.get("FETCH_SIZE"),
                 "WRITE_SIZE_KiB": mean.get("WRITE_SIZE"), "SQ_LDS_BANK_CONFLICT": mean.get("SQ_LDS_BANK_CONFLICT"),
                 "SQ_LDS_IDX_ACTIVE": mean.get("SQ_LDS_IDX_ACTIVE"), "SQ_INSTS_VALU": mean.get("SQ_INSTS_VALU"),
                 "SQ_ACTIVE_INST_VALU": mean.get("SQ_ACTIVE_INST_VALU"), "SQ_WAVE_CYCLES": mean.get("SQ_WAVE_CYCLES"),
@@ -50,7 +52,11 @@ def main(src, kernel, dst, tag):
         # executed FP64 flops per launch, from the hardware instruction counters (wave instructions x 64 lanes, FMA = 2)
         fl = 64.0 * (2.0 * mean["SQ_INSTS_VALU_FMA_F64"] + mean.get("SQ_INSTS_VALU_MUL_F64", 0.0) +
                      mean.get("SQ_INSTS_VALU_ADD_F64", 0.0) + mean.get("SQ_INSTS_VALU_TRANS_F64", 0.0))
-        e["flop_per_solve_measured"] = fl / e["pmc"]["batch"]
+        if lanes_per_problem == 1:
+            e["flop_per_solve_measured"] = fl / e["pmc"]["batch"]
+        else:  # phases leave lanes idle: wave instructions x 64 is not work done, so no flop figure (and no valu_roofline)
+            e.pop("flop_per_solve_measured", None)
+            e["wave_flop_slots_per_solve"] = fl / e["pmc"]["batch"]
         e["pmc"].update({k: mean[k] for k in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64",
                                               "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_SALU", "SQ_INSTS_VMEM") if k in mean})
     json.dump(stats, open(path, "w"), indent=1)
