@@ -406,8 +406,11 @@ int ikgpu_evaluate_batch(const ikgpu_problem *p, int64_t B, const double *q, con
         if (!g.ok) return fail(IKGPU_ERR_DEVICE, "hipSetDevice failed");
         const hipStream_t st = static_cast<hipStream_t>(stream);
         hipError_t e = p->host.kind == ikgpu::KernelKind::Chain  ? ikgpu::launch_eval_chain(p->host, p->dev, B, q, targets, e_out, J_out, layout, st)
-                       : p->host.kind == ikgpu::KernelKind::Tree ? ikgpu::launch_eval_tree(p->host, p->dev, B, q, targets, e_out, J_out, nullptr, layout, st)
-                                                                 : ikgpu::launch_eval_generic(p->host, p->dev, B, q, targets, e_out, J_out, nullptr, layout, st);
+                       // (a tree problem with the demo's extras -- base-relative reference, alignment row -- has its stages evaluated
+                       // by the generic program: the tree stage kernel does not know them)
+                       : p->host.kind == ikgpu::KernelKind::Tree && !p->host.tree_extras()
+                           ? ikgpu::launch_eval_tree(p->host, p->dev, B, q, targets, e_out, J_out, nullptr, layout, st)
+                           : ikgpu::launch_eval_generic(p->gen, p->dev, B, q, targets, e_out, J_out, nullptr, layout, st);
         if (e != hipSuccess) return hip_fail(e, "launching the evaluate kernel");
         return static_cast<int>(IKGPU_OK);
     });
@@ -424,8 +427,9 @@ int ikgpu_task_frames_fk_batch(const ikgpu_problem *p, int64_t B, const double *
         if (!g.ok) return fail(IKGPU_ERR_DEVICE, "hipSetDevice failed");
         const hipStream_t st = static_cast<hipStream_t>(stream);
         hipError_t e = p->host.kind == ikgpu::KernelKind::Chain  ? ikgpu::launch_fk_chain(p->host, p->dev, B, q, oMf_out, layout, st)
-                       : p->host.kind == ikgpu::KernelKind::Tree ? ikgpu::launch_eval_tree(p->host, p->dev, B, q, q, nullptr, nullptr, oMf_out, layout, st)
-                                                                 : ikgpu::launch_eval_generic(p->host, p->dev, B, q, q, nullptr, nullptr, oMf_out, layout, st);
+                       : p->host.kind == ikgpu::KernelKind::Tree && !p->host.tree_extras()
+                           ? ikgpu::launch_eval_tree(p->host, p->dev, B, q, q, nullptr, nullptr, oMf_out, layout, st)
+                           : ikgpu::launch_eval_generic(p->gen, p->dev, B, q, q, nullptr, nullptr, oMf_out, layout, st);
         if (e != hipSuccess) return hip_fail(e, "launching the FK kernel");
         return static_cast<int>(IKGPU_OK);
     });

@@ -36,6 +36,7 @@ struct TreeDesc {
     ChainTable<NJ> chain[NCH];
     double frP[12];  // base joint frame -> frame of the base task
     double wP[6];
+    double refpl[NCH][12];  // base joint frame -> reference frame of chain c's task (used when TreeParams::ref_base[c])
 };  // all doubles: staged HBM -> LDS as a flat table
 
 struct TreeParams {
@@ -45,6 +46,23 @@ struct TreeParams {
     int hasP;            // a base task is present
     int idmask[2], idmaskP;  // identity-rotation placement masks (see chain_solver.hpp LoopParams::idmask)
     int unit[2], unitP;      // the task is Full with all-ones weights
+    // general builds only (SPEC = -1), what the reference's demo adds to two pose tasks (ik_ros/src/cassie.cpp:45-81):
+    int ref_base[2];         // chain c's target is given in a frame that rides on the floating base (TreeDesc::refpl[c]);
+                             // the task Jacobian leaves that frame's motion out, as the reference does (frame.hpp:152-182)
+    int align_chain;         // -1, or the chain whose task frame also carries an AlignAxisTask row (frame.hpp:257-301),
+    int align_axis;          //   the frame axis 0 / 1 / 2 it aligns,
+    int align_slot;          //   the target slot whose doubles 9..11 hold the direction (in the world),
+    int align_prio;          //   its priority level
+    double align_w;          //   and its weight
+};
+
+// One AlignAxisTask row on a chain's task frame, reference frame = the world: e = w (1 - r . t), r = the frame's axis in the
+// world, and (negated convention) J'(:, c) = w (r x t) . omega_c with omega_c the world angular velocity of column c.
+struct AlignRow {
+    bool on;
+    int ax;
+    double w, tn[3];
+    bool prio0;
 };
 
 // Packed lower-triangular index
@@ -184,7 +202,8 @@ struct LegFactor {
 template <int NJ>
 IKD_FN void leg_eval_factor(const double (&R1)[9], const double (&p1)[3], const double (*pl)[12], const double *frame_pl,
                             const double *w6, int idmask, bool unit, const double (&q)[NJ], const double (&oMt)[12],
-                            double lam2, bool prio0, double (&Hbb)[21], double (&gb)[6], double &e0sq, LegFactor<NJ> &F) {
+                            double lam2, bool prio0, const AlignRow &al, double (&Hbb)[21], double (&gb)[6], double &e0sq,
+                            LegFactor<NJ> &F) {
     double zax[NJ][3], org[NJ][3];
     double R[9], p[3];
 #pragma unroll
@@ -251,6 +270,35 @@ IKD_FN void leg_eval_factor(const double (&R1)[9], const double (&p1)[3], const 
 #pragma unroll
         for (int r = 0; r < 6; ++r) s = dfma(col[a][r], t.e[r], s);
         F.u[a] = s;
+    }
+    if (al.on) {  // rank-one terms of the alignment row (wave-uniform; general builds only)
+        const double r[3] = {al.ax == 0 ? R[0] : (al.ax == 1 ? R[1] : R[2]), al.ax == 0 ? R[3] : (al.ax == 1 ? R[4] : R[5]),
+                             al.ax == 0 ? R[6] : (al.ax == 1 ? R[7] : R[8])};
+        double rxt[3], aj[NJ], ab[3];
+        cross(r, al.tn, rxt);
+        const double ea = (1.0 - dot(r, al.tn)) * al.w;
+        if (al.prio0) e0sq = dfma(ea, ea, e0sq);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) aj[j] = al.w * dot(rxt, zax[j]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double rc[3] = {R1[c], R1[3 + c], R1[6 + c]};
+            ab[c] = al.w * dot(rxt, rc);
+        }
+#pragma unroll
+        for (int a = 0; a < NJ; ++a) {
+#pragma unroll
+            for (int b = 0; b <= a; ++b) F.L[tri(a, b)] = dfma(aj[a], aj[b], F.L[tri(a, b)]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) F.W[a][3 + c] = dfma(aj[a], ab[c], F.W[a][3 + c]);
+            F.u[a] = dfma(aj[a], ea, F.u[a]);
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+#pragma unroll
+            for (int b = 0; b <= a; ++b) Hbb[tri(3 + a, 3 + b)] = dfma(ab[a], ab[b], Hbb[tri(3 + a, 3 + b)]);
+            gb[3 + a] = dfma(ab[a], ea, gb[3 + a]);
+        }
     }
     IKD_SCHED_FENCE();
     // Cholesky of H_ll, right-looking, with the 6 + 1 right-hand sides (W, u) carried as extra rows: every
@@ -412,9 +460,35 @@ IKD_FN void tree_dls(const TreeDesc<NJ, NCH> &d, const TreeParams &prm, double (
             for (int j = 0; j < NJ; ++j) q[j] = (NCH > 1 && c == 1) ? qj1[j] : qj0[j];
 #pragma unroll
             for (int k = 0; k < 12; ++k) oMt[k] = targets_lane[(tslot[c] * 12 + k) * tstride];
+            AlignRow al{false, 0, 0.0, {0.0, 0.0, 0.0}, false};
+            if (SPEC < 0) {  // the demo's extras exist in the general builds only; hot builds compile none of this
+                if (prm.ref_base[c]) {  // target given in a frame on the floating base: oMt = (oM1 * refpl) * target (frame.hpp:48)
+                    double Rr[9], pr[3], tg[12];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) Rr[k] = R1[k];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) pr[k] = p1[k];
+                    se3_compose_const(Rr, pr, d.refpl[c], false);
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) tg[k] = oMt[k];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) oMt[3 * i + j] = dfma(Rr[3 * i], tg[j], dfma(Rr[3 * i + 1], tg[3 + j], Rr[3 * i + 2] * tg[6 + j]));
+                        oMt[9 + i] = dfma(Rr[3 * i], tg[9], dfma(Rr[3 * i + 1], tg[10], dfma(Rr[3 * i + 2], tg[11], pr[i])));
+                    }
+                }
+                if (prm.align_chain == c) {
+                    const double tx = targets_lane[(prm.align_slot * 12 + 9) * tstride], ty = targets_lane[(prm.align_slot * 12 + 10) * tstride],
+                                 tz = targets_lane[(prm.align_slot * 12 + 11) * tstride];
+                    const double inv = drsqrt(dfma(tx, tx, dfma(ty, ty, tz * tz)));
+                    al.on = true; al.ax = prm.align_axis; al.w = prm.align_w; al.prio0 = prm.align_prio == 0;
+                    al.tn[0] = tx * inv; al.tn[1] = ty * inv; al.tn[2] = tz * inv;
+                }
+            }
             leg_eval_factor<NJ>(R1, p1, ct.pl, ct.fr, ct.w, SPEC >= 0 ? (SPEC & ((2 << NJ) - 1)) : prm.idmask[c],
-                                SPEC >= 0 ? ((SPEC >> kSpecUnit) & 1) != 0 : prm.unit[c] != 0, q, oMt, prm.lam2, prm.prio[c] == 0, Hbb,
-                                gb, e0sq, F);
+                                SPEC >= 0 ? ((SPEC >> kSpecUnit) & 1) != 0 : prm.unit[c] != 0, q, oMt, prm.lam2, prm.prio[c] == 0, al,
+                                Hbb, gb, e0sq, F);
             if (NCH > 1 && c == 0) park.store(F);
         }
         if (prm.hasP) {

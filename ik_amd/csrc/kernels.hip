@@ -262,6 +262,9 @@ TreeKernelArgs<NJ, NCH> make_tree_args(const ProblemHost &ph, const DeviceTables
     a.prm.hasP = h.hasP;
     a.prm.idmask[0] = h.idmask[0]; a.prm.idmask[1] = h.idmask[1]; a.prm.idmaskP = h.idmaskP;
     a.prm.unit[0] = h.unit[0]; a.prm.unit[1] = h.unit[1]; a.prm.unitP = h.unit[2];
+    a.prm.ref_base[0] = h.ref_base[0]; a.prm.ref_base[1] = h.ref_base[1];
+    a.prm.align_chain = h.align_chain; a.prm.align_axis = h.align_axis; a.prm.align_slot = h.align_slot;
+    a.prm.align_prio = h.align_prio; a.prm.align_w = h.align_w;
     a.desc = reinterpret_cast<const TreeDesc<NJ, NCH> *>(dt.chain_desc);
     a.nq = ph.nq; a.nv = ph.nv; a.ntasks = ph.ntasks;
     a.lower = dt.lower; a.upper = dt.upper; a.q_in_chain = dt.q_in_chain;
@@ -282,7 +285,7 @@ hipError_t run_dls_tree(const ProblemHost &ph, const DeviceTables &dt, const Bat
     // task sits at a pure translation from the base joint -- all folded at compile time; otherwise the general build
     constexpr int kMask = HotMask<NJ>::value;
     constexpr int kHot = kMask | (1 << ikdev::kSpecUnit) | (1 << ikdev::kSpecUnitP) | (1 << ikdev::kSpecIdP);
-    const bool hot = kMask != 0 && (a.prm.idmask[0] & kMask) == kMask && (NCH == 1 || (a.prm.idmask[1] & kMask) == kMask) &&
+    const bool hot = !ph.tree_extras() && kMask != 0 && (a.prm.idmask[0] & kMask) == kMask && (NCH == 1 || (a.prm.idmask[1] & kMask) == kMask) &&
                      a.prm.unit[0] && (NCH == 1 || a.prm.unit[1]) && (!a.prm.hasP || (a.prm.unitP && (a.prm.idmaskP & 1)));
     const dim3 grid(static_cast<unsigned>((io.B + kTreeBlock - 1) / kTreeBlock));
     if (hot) hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, kHot>), grid, dim3(kTreeBlock), 0, stream, a);

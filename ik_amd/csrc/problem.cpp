@@ -93,9 +93,11 @@ struct Unsupported : std::runtime_error {
 void specialise(ProblemHost &ph, const Model &m) {
     static const char *kt[] = {"position", "orientation", "full"};
     const int ntasks = ph.ntasks;
-    for (const ikgpu_task &t : ph.tasks)
-        if (t.type > IKGPU_FULL) throw Unsupported("AlignAxisTask / PostureTask rows run on the generic kernel");
     const bool free_flyer = m.njoints() > 1 && m.joint_type[1] == IKGPU_JOINT_FREEFLYER;
+    for (const ikgpu_task &t : ph.tasks) {
+        if (t.type == IKGPU_POSTURE_ROW || t.type == IKGPU_CENTRE_OF_MASS) throw Unsupported("PostureTask / CentreOfMassTask rows run on the generic kernel");
+        if (t.type > IKGPU_FULL && !free_flyer) throw Unsupported("AlignAxisTask rows on a fixed-base model run on the generic kernel");
+    }
     std::vector<uint8_t> in_chain(m.nq, 0);
 
     auto chain_of = [&](const std::vector<int> &joints, int frame, int task_index) {
@@ -124,28 +126,49 @@ void specialise(ProblemHost &ph, const Model &m) {
     // free-flyer base: chains hang off joint 1
     for (int k = 0; k < 7; ++k) in_chain[k] = 1;
     int nchains = 0;
+    int chain_frame[2] = {-1, -1};
     for (int i = 0; i < ntasks; ++i) {
         const ikgpu_task &t = ph.tasks[i];
-        if (m.frame_parent[t.reference] != 0 || !is_identity(m.frame_placement[t.reference]))
-            throw Unsupported("reference frame other than the universe on a free-flyer model");
+        if (t.type > IKGPU_FULL) continue;  // the alignment row is matched to a chain below
+        const bool ref_world = m.frame_parent[t.reference] == 0 && is_identity(m.frame_placement[t.reference]);
+        const bool ref_on_base = m.frame_parent[t.reference] == 1;
+        if (!ref_world && !ref_on_base) throw Unsupported("reference frame neither the universe nor on the floating base");
         if (m.frame_parent[t.frame] == 0) throw Unsupported("task frame fixed in the world");
         std::vector<int> joints;
         for (int j = m.frame_parent[t.frame]; j > 1; j = m.joint_parent[j]) joints.insert(joints.begin(), j);
         if (joints.empty()) {
             if (ph.base_task >= 0) throw Unsupported("two tasks on the floating base link");
+            if (!ref_world) throw Unsupported("base-link task with a reference frame other than the universe");
             ph.base_task = i;
             std::memcpy(ph.base_frame_pl, m.frame_placement[t.frame].data(), sizeof(double) * 12);
         } else {
             if (nchains == 2) throw Unsupported("more than two chain tasks on a free-flyer model");
             (nchains == 0 ? ph.chain : ph.chainB) = chain_of(joints, t.frame, i);
+            if (ref_on_base) {
+                ph.ref_base[nchains] = 1;
+                std::memcpy(ph.chain_ref_pl[nchains], m.frame_placement[t.reference].data(), sizeof(double) * 12);
+            }
+            chain_frame[nchains] = t.frame;
             ++nchains;
         }
+    }
+    for (int i = 0; i < ntasks; ++i) {  // one AlignAxisTask row, on the frame of a chain task, direction given in the world
+        const ikgpu_task &t = ph.tasks[i];
+        if (t.type <= IKGPU_FULL) continue;
+        if (ph.align_task >= 0) throw Unsupported("more than one AlignAxisTask");
+        if (m.frame_parent[t.reference] != 0 || !is_identity(m.frame_placement[t.reference]))
+            throw Unsupported("AlignAxisTask with a reference frame other than the universe");
+        const int c = t.frame == chain_frame[0] ? 0 : (t.frame == chain_frame[1] ? 1 : -1);
+        if (c < 0) throw Unsupported("AlignAxisTask on a frame that carries no frame task");
+        ph.align_task = i;
+        ph.align_chain = c;
     }
     if (nchains == 0) throw Unsupported("free-flyer problem without a chain task");
     if (nchains == 2 && ph.chain.nj != ph.chainB.nj) throw Unsupported("the two chains differ in length");
     ph.kind = KernelKind::Tree;
     ph.kernel_name = "dls_tree<NJ=" + std::to_string(ph.chain.nj) + ",chains=" + std::to_string(nchains) +
-                     (ph.base_task >= 0 ? ",base_task>" : ">");
+                     (ph.base_task >= 0 ? ",base_task" : "") + (ph.ref_base[0] || ph.ref_base[1] ? ",base_reference" : "") +
+                     (ph.align_task >= 0 ? ",align_axis" : "") + ">";
     ph.q_in_chain = in_chain;
 }
 
@@ -408,6 +431,8 @@ std::vector<double> tree_desc_table(const ProblemHost &ph) {
     for (double &x : w6) x = 0.0;
     if (ph.base_task >= 0) weights6(ph.tasks[ph.base_task], w6);
     t.insert(t.end(), w6, w6 + 6);
+    t.insert(t.end(), ph.chain_ref_pl[0], ph.chain_ref_pl[0] + 12);
+    if (ph.chainB.nj > 0) t.insert(t.end(), ph.chain_ref_pl[1], ph.chain_ref_pl[1] + 12);
     return t;
 }
 
@@ -474,6 +499,15 @@ TreeArgsHost tree_args(const ProblemHost &ph) {
         // task with zero-weight rows in the tree kernels
         const int ti = slot_task[s];
         a.unit[s] = (ti >= 0 && ph.tasks[ti].type == IKGPU_FULL && task_has_unit_weights(ph.tasks[ti])) ? 1 : 0;
+    }
+    a.ref_base[0] = ph.ref_base[0]; a.ref_base[1] = ph.ref_base[1];
+    a.align_chain = ph.align_task >= 0 ? ph.align_chain : -1;
+    if (ph.align_task >= 0) {
+        const ikgpu_task &t = ph.tasks[ph.align_task];
+        a.align_axis = t.type - IKGPU_ALIGN_AXIS_X;
+        a.align_slot = ph.align_task;
+        a.align_prio = t.priority;
+        a.align_w = t.weight[0];
     }
     return a;
 }

@@ -64,6 +64,12 @@ struct ProblemHost {
     int base_task = -1;               // Tree kind: index of the task on the base link, or -1
     double base_frame_pl[12] = {};    // base joint frame -> frame of the base task
     double ref_pl[12] = {};           // Chain kind: world placement of the (fixed) reference frame
+    // Tree kind, what the reference's demo adds (ik_ros/src/cassie.cpp:45-81): a chain task whose reference frame rides on
+    // the floating base, and one AlignAxisTask row on a chain task's frame
+    int ref_base[2] = {0, 0};
+    double chain_ref_pl[2][12] = {{1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0}, {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0}};
+    int align_task = -1, align_chain = -1;
+    bool tree_extras() const { return ref_base[0] || ref_base[1] || align_task >= 0; }
     GenericHost generic;              // Generic kind
     std::vector<ikgpu_task> constraints;  // ik::FrameConstraint list (frame, reference, type); forces the Generic kind
     int crows = 0;
@@ -94,6 +100,9 @@ struct TreeArgsHost {
     int prio[3];
     int hasP, nch;
     int idmask[2], idmaskP, unit[3];
+    int ref_base[2];                                        // chain c's target is given in a frame on the floating base
+    int align_chain, align_axis, align_slot, align_prio;    // an AlignAxisTask row on a chain's task frame (-1: none)
+    double align_w;
 };
 TreeArgsHost tree_args(const ProblemHost &ph);
 

@@ -84,6 +84,9 @@ void run_tree(const ikgpu::ProblemHost &ph, const IO &io) {
     a.prm.prio[0] = h.prio[0]; a.prm.prio[1] = h.prio[1]; a.prm.prioP = h.prio[2]; a.prm.hasP = h.hasP;
     a.prm.idmask[0] = h.idmask[0]; a.prm.idmask[1] = h.idmask[1]; a.prm.idmaskP = h.idmaskP;
     a.prm.unit[0] = h.unit[0]; a.prm.unit[1] = h.unit[1]; a.prm.unitP = h.unit[2];
+    a.prm.ref_base[0] = h.ref_base[0]; a.prm.ref_base[1] = h.ref_base[1];
+    a.prm.align_chain = h.align_chain; a.prm.align_axis = h.align_axis; a.prm.align_slot = h.align_slot;
+    a.prm.align_prio = h.align_prio; a.prm.align_w = h.align_w;
     a.nq = ph.nq; a.nv = ph.nv; a.ntasks = ph.ntasks;
     a.lower = ph.lower.data(); a.upper = ph.upper.data(); a.q_in_chain = ph.q_in_chain.data();
     a.layout = io.layout; a.B = io.B; a.q0 = io.q0; a.targets = io.targets;
@@ -138,6 +141,8 @@ int lane_emu_run(const char *urdf, size_t len, int root_joint, const ikgpu_task 
         // root_joint bit 1 forces the generic kernel (to test it on shapes the specialisations also take)
         ikgpu::Model m = ikgpu::Model::from_urdf(urdf, len, (root_joint & 1) != 0);
         ikgpu::ProblemHost ph = ikgpu::analyse_problem(m, tasks, ntasks, (root_joint & 2) != 0);
+        // stages of a tree problem with the demo's extras are evaluated by the generic program (as capi.cpp does)
+        if (ph.kind == ikgpu::KernelKind::Tree && ph.tree_extras() && mode != 0) ph = ikgpu::analyse_problem(m, tasks, ntasks, true);
         const IO io{mode, B, q0, targets, prm, q_out, success, iters, e_out, J_out, oMf_out, layout};
         if (ph.kind == ikgpu::KernelKind::Generic) {
             run_generic(ph, io);

@@ -199,10 +199,32 @@ def test_every_other_shape_maps_to_the_generic_kernel(ik):
     assert ik.plan(p) == "dls_generic<M=6,nv=6,joints=6>"
     m, p = _problem(ik, "cassie_fixed", ["LeftFootFront", "RightFootFront"])  # fixed base, two tasks
     assert ik.plan(p) == "dls_generic<M=12,nv=16,joints=16>"
+    m, p = _problem(ik, "cassie", ["LeftFootFront", "RightFootFront", "LeftFootBack"], ff=True)   # three chain tasks
+    assert ik.plan(p) == "dls_generic<M=18,nv=22,joints=17>"
     m, p = _problem(ik, "cassie", ["LeftFootFront", "pelvis"], ff=True)
+    p.add_align_axis_task("align", ik.AlignAxisTask.create(m, "RightFootFront", ik.AlignAxisType.AxisY))   # row on a frame with no task
+    assert ik.plan(p) == "dls_generic<M=13,nv=22,joints=17>"
+
+
+def test_the_demo_task_set_has_a_register_resident_kernel(ik):
+    """The reference's demo (ik_ros/src/cassie.cpp:45-81): foot position w.r.t. the pelvis (a reference frame riding on
+    the floating base), pelvis pose in the world, foot Y axis aligned with a direction -- the tree kernel's general
+    build takes the base-relative reference and the alignment row on the chain task's own frame."""
+    m = ik.Model.from_urdf_file(urdf_path("cassie"), free_flyer=True)
+    p = ik.InverseKinematicsProblem(m, 1)
+    p.add_frame_task("fl", ik.FrameTask.create(m, "LeftFootFront", ik.KinematicType.Position, "pelvis"))
+    p.add_frame_task("pelvis", ik.FrameTask.create(m, "pelvis", ik.KinematicType.Full))
     p.add_align_axis_task("align", ik.AlignAxisTask.create(m, "LeftFootFront", ik.AlignAxisType.AxisY))
-    assert ik.plan(p) == "dls_generic<M=13,nv=22,joints=17>"                  # the demo's task kinds (cassie.cpp:45-81)
-    assert p.get_align_axis_task("align").dimension() == 1
+    assert ik.plan(p) == "dls_tree<NJ=7,chains=1,base_task,base_reference,align_axis>"
+    assert p.get_align_axis_task("align").dimension() == 1 and p.e_size(0) == 10
+    m2, p2 = _problem(ik, "cassie", ["LeftFootFront", "pelvis"], ff=True)
+    p2.add_align_axis_task("align", ik.AlignAxisTask.create(m2, "LeftFootFront", ik.AlignAxisType.AxisY), 0)
+    assert ik.plan(p2) == "dls_tree<NJ=7,chains=1,base_task,align_axis>"
+    # an alignment direction given in a moving frame stays on the generic kernel
+    p3 = ik.InverseKinematicsProblem(m)
+    p3.add_frame_task("fl", ik.FrameTask.create(m, "LeftFootFront"))
+    p3.add_align_axis_task("align", ik.AlignAxisTask.create(m, "LeftFootFront", ik.AlignAxisType.AxisX, "pelvis"))
+    assert ik.plan(p3).startswith("dls_generic<")
 
 
 def test_invalid_task_tables_are_errors(ik):

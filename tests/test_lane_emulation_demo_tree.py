@@ -1,0 +1,49 @@
+"""The tree lane program's general build with what the reference's demo adds to pose tasks (ik_ros/src/cassie.cpp:45-81): a chain
+task whose reference frame rides on the floating base, and an AlignAxisTask row on a chain task's own frame
+(device/tree_solver.hpp: TreeParams::ref_base / align_*).  Compiled for the host and run lane after lane against the C oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle as O
+from test_lane_emulation import _generic_case, emu, run  # noqa: F401  (emu is a fixture)
+
+CASES = {
+    # the demo itself: foot position w.r.t. the pelvis, pelvis pose, foot Y axis along a direction
+    "demo": [("LeftFootFront", "pelvis", 0, 0, None), ("pelvis", "universe", 2, 0, None), ("LeftFootFront", "universe", 4, 0, None)],
+    # the alignment row one priority level down (it then leaves the stop test), weighted
+    "align_at_priority_1": [("LeftFootFront", "universe", 2, 0, None), ("pelvis", "universe", 2, 0, None),
+                            ("LeftFootFront", "universe", 5, 1, [0.5])],
+    # two chains, both given in the pelvis frame, the row on the second chain, no base task
+    "two_chains_in_the_pelvis_frame": [("LeftFootFront", "pelvis", 2, 0, None), ("RightFootFront", "pelvis", 0, 0, [1.0, 2.0, 0.5]),
+                                       ("RightFootFront", "universe", 3, 0, None)],
+    # reference on the base but not the base link's own frame: a frame welded to the pelvis with an offset
+    "reference_with_an_offset": [("LeftFootFront", "vectornav", 2, 0, None), ("RightFootFront", "universe", 2, 0, None),
+                                 ("pelvis", "universe", 1, 0, None)],
+}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_tree_program_with_the_demo_extras_matches_oracle(emu, case):  # noqa: F811
+    import ik_amd
+    from ik_amd import capi
+    specs = CASES[case]
+    B = 24
+    urdf, model, om, tasks, ot, q0, tg, M = _generic_case("cassie", True, specs, B, seed=5)
+    # the host analysis picks the tree kernel for these
+    problem_tasks = (capi.Task * len(tasks))(*tasks)
+    buf = C.create_string_buffer(160)
+    capi.check(capi.lib().ikgpu_problem_plan(model._h, problem_tasks, len(tasks), buf, len(buf)))
+    assert buf.value.decode().startswith("dls_tree<NJ=7,"), buf.value
+    nt = len(tasks)
+    for iters, damping, step, tol in ((1, 1e-2, 1.0, -1.0), (3, 1e-2, 1.0, -1.0), (60, 1e-1, 0.3, 1e-6), (200, 1e-1, 1e-1, 1e-4)):
+        prm = capi.DlsParams(iters, damping, step, tol)
+        qo, ok, it, *_ = run(emu, urdf, tasks, 0, q0, tg, prm, model.nv, M, root=1, ntasks=nt)
+        q_ref, ok_ref, it_ref = O.dls_batch(om, ot, tg, q0, O.params(iters, damping, step, tol))
+        assert np.array_equal(ok, ok_ref) and np.array_equal(it, it_ref), (case, iters)
+        assert np.abs(qo - q_ref).max() < 1e-8, (case, iters, np.abs(qo - q_ref).max())
+    # the forced generic program agrees as well
+    qg, *_ = run(emu, urdf, tasks, 0, q0, tg, prm, model.nv, M, root=3, ntasks=nt)
+    assert np.abs(qg - qo).max() < 1e-8
+    assert ik_amd is not None
