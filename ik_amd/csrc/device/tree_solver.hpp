@@ -46,7 +46,7 @@ struct TreeParams {
     int hasP;            // a base task is present
     int idmask[2], idmaskP;  // identity-rotation placement masks (see chain_solver.hpp LoopParams::idmask)
     int unit[2], unitP;      // the task is Full with all-ones weights
-    // general builds only (SPEC = -1), what the reference's demo adds to two pose tasks (ik_ros/src/cassie.cpp:45-81):
+    // general builds only (SPEC <= 0), what the reference's demo adds to two pose tasks (ik_ros/src/cassie.cpp:45-81):
     int ref_base[2];         // chain c's target is given in a frame that rides on the floating base (TreeDesc::refpl[c]);
                              // the task Jacobian leaves that frame's motion out, as the reference does (frame.hpp:152-182)
     int align_chain;         // -1, or the chain whose task frame also carries an AlignAxisTask row (frame.hpp:257-301),
@@ -461,7 +461,8 @@ IKD_FN void tree_dls(const TreeDesc<NJ, NCH> &d, const TreeParams &prm, double (
 #pragma unroll
             for (int k = 0; k < 12; ++k) oMt[k] = targets_lane[(tslot[c] * 12 + k) * tstride];
             AlignRow al{false, 0, 0.0, {0.0, 0.0, 0.0}, false};
-            if (SPEC < 0) {  // the demo's extras exist in the general builds only; hot builds compile none of this
+            if (SPEC <= 0) {  // the demo's extras exist in the general builds only (SPEC = 0 on the device, -1 = all runtime
+                              // in the emulator); hot builds compile none of this
                 if (prm.ref_base[c]) {  // target given in a frame on the floating base: oMt = (oM1 * refpl) * target (frame.hpp:48)
                     double Rr[9], pr[3], tg[12];
 #pragma unroll

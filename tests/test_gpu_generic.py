@@ -346,7 +346,7 @@ def test_cpp_demo_program_matches_oracle(torch_cuda):
                                "-I" + os.path.join(ROOT, "ik_amd", "csrc", "host"), "-o", exe, src,
                                "-L" + os.path.join(ROOT, "ik_amd"), "-likgpu", "-Wl,-rpath," + os.path.join(ROOT, "ik_amd")])
     out = json.loads(subprocess.check_output([exe, urdf_path("cassie"), "4"], text=True))
-    assert out["kernel"].startswith("dls_generic<M=10,nv=22")
+    assert out["kernel"] == "dls_tree<NJ=7,chains=1,base_task,base_reference,align_axis>"   # the demo has a register-resident kernel
     model = ik_amd.Model.from_urdf_file(urdf_path("cassie"), free_flyer=True)
     om = O.OracleModel(model.flat())
     lf, pe = model.getFrameId("LeftFootFront"), model.getFrameId("pelvis")
