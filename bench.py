@@ -42,12 +42,12 @@ WORKLOADS = {
                                   "RightFootFront and pelvis (M=18)"),
     "ur5": dict(urdf="ur5", free_flyer=False, frames=["tool0"], nq=6,
                 text="UR5 arm (ur5.urdf, nq=6), one SE(3) tool0 task, targets within +-2 rad so the joint clamp is live"),
-    # the demo's own task set (reference ik_ros/src/cassie.cpp:45-81) on the generic fallback kernel
+    # the demo's own task set (reference ik_ros/src/cassie.cpp:45-81): the tree kernel's general build
     "cassie_demo": dict(urdf="cassie", free_flyer=True, frames=["LeftFootFront", "pelvis", "LeftFootFront"], nq=23,
                         tasks=[("frame", "LeftFootFront", 0, "pelvis"), ("frame", "pelvis", 2, "universe"),
                                ("align", "LeftFootFront", 1, "universe")],
                         text="Cassie demo task set (cassie.urdf + free-flyer): LeftFootFront position w.r.t. the pelvis, pelvis "
-                             "SE(3) pose, LeftFootFront Y-axis alignment (M=10), generic kernel"),
+                             "SE(3) pose, LeftFootFront Y-axis alignment (M=10)"),
     # the same tasks through the reference's other solver, ik::pik (reference ik/ik/pik.cpp:31-103): the alignment row at
     # priority 1, solved in the null space of the two pose tasks; damping factor 0.1 per level
     "cassie_demo_pik": dict(urdf="cassie", free_flyer=True, frames=["LeftFootFront", "pelvis", "LeftFootFront"], nq=23,
@@ -178,14 +178,14 @@ def main():
     QS = torch.from_numpy(np.ascontiguousarray(qs_np.T)).to(dev)
     targets = ik_amd.task_frames_fk_batch(problem, QS, data)  # FK(q*) on the device: reachable targets
     if w.get("tasks"):
-        # express each frame target in its reference frame (here: the pelvis, task 1's frame) and give the align row a
-        # direction: world x axis
+        # express each frame target in its reference frame (here: the pelvis, task 1's frame); the alignment row asks for
+        # the direction the foot's Y axis has at q* (slot 2 holds the same foot frame): reachable, like the frame targets
         Rp, pp = targets[1, :9].reshape(3, 3, B), targets[1, 9:]
-        Rf, pf = targets[0, :9].reshape(3, 3, B), targets[0, 9:]
+        Rf, pf = targets[0, :9].reshape(3, 3, B).clone(), targets[0, 9:].clone()
         targets[0, :9] = torch.einsum("kib,kjb->ijb", Rp, Rf).reshape(9, B)
         targets[0, 9:] = torch.einsum("kib,kb->ib", Rp, pf - pp)
+        targets[2, 9:] = Rf[:, 1, :]
         targets[2, :9] = torch.eye(3, dtype=torch.float64, device=dev).reshape(9, 1)
-        targets[2, 9:] = torch.tensor([1.0, 0.0, 0.0], dtype=torch.float64, device=dev).reshape(3, 1)
     # two buffer sets alternate so that the all-gather of step k overlaps the solve of step k + 1
     bufs = [ikdist.ShardBuffers(model.nq, B, world, dev) for _ in range(2)]
     out = bufs[0].out()
@@ -272,7 +272,11 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_solve": bps,
-                         "note": "fused on-chip loop: the binding roof is FP64 VALU issue, see valu_roofline"},
+                         "note": ("fused on-chip loop: the binding roof is FP64 VALU issue, see valu_roofline"
+                                  if data.kernel.startswith(("dls_chain<", "dls_tree<")) else
+                                  "generic kernel, workspace in LDS (16 lanes per problem): LDS-latency bound, DESIGN.md 3.3"
+                                  if data.kernel.startswith("dls_generic<") else
+                                  "generic per-lane kernel, workspace in HBM: bound by that traffic, DESIGN.md 3.4")},
         }
         if stats.get("flop_per_solve_measured") and args.iters == 50:
             flops = stats["flop_per_solve_measured"]
