@@ -1,6 +1,6 @@
 #!/usr/bin/env bash
 # AddressSanitizer + UBSan pass over everything that can run on the CPU: the URDF loader and problem analysis
-# (ik_amd/csrc/model.cpp, problem.cpp), the three device lane programs compiled for the host (tests/lane_emu) and
+# (ik_amd/csrc/model.cpp, problem.cpp), the device lane programs (chain, tree, generic per-lane and cooperative, PIK) compiled for the host (tests/lane_emu) and
 # the C oracle.  GPU sanitizers are not available on this pool; the device code shares these sources.
 set -euo pipefail
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"; cd "$ROOT"
@@ -12,7 +12,8 @@ import sys, ctypes as C
 sys.path[:0] = ["$ROOT/oracle", "$ROOT", "$ROOT/tests"]
 import oracle as O
 O._LIB = C.CDLL("$ROOT/oracle/libik_oracle_asan.so")
-for f in ("iko_dls", "iko_dls_batch", "iko_task_rows"): getattr(O._LIB, f).restype = C.c_int
+for f in ("iko_dls", "iko_dls_batch", "iko_task_rows", "iko_pik", "iko_pik_batch", "iko_dls_constrained", "iko_dls_batch_constrained"):
+    getattr(O._LIB, f).restype = C.c_int
 import test_lane_emulation as t
 L = C.CDLL("/tmp/liblane_emu_asan.so"); L.lane_emu_last_error.restype = C.c_char_p
 t.test_lane_program_stagewise(L, "cassie_fixed", "LeftFootFront")
@@ -22,6 +23,17 @@ t.test_tree_program_full_loop(L, 50, -1.0)
 t.test_tree_program_types_weights_priorities(L)
 t.test_tree_program_single_chain_plus_base_task(L)
 for c in sorted(t.GENERIC_CASES): t.test_generic_program_matches_oracle(L, c)
+for c in sorted(t.PIK_CASES): t.test_pik_program_matches_oracle(L, c)
+for c in sorted(t.CONSTRAINT_CASES): t.test_constrained_dls_program_matches_oracle(L, c)
+for c in t.COOP_CASES:
+    if c != "posture_regulariser": t.test_cooperative_program_matches_oracle(L, c)
+import test_lane_emulation_demo_tree as d
+for c in sorted(d.CASES): d.test_tree_program_with_the_demo_extras_matches_oracle(L, c)
+import test_oracle_pik as p, test_oracle_constraints as oc, test_oracle_com as com
+p.test_damp_pseudoinverse_known_answers(None); p.test_rowspace_projector_properties_and_rank(None)
+for k in range(len(p.LOOP_CASES)): p.test_oracle_pik_matches_the_twin(None, k)
+for k in range(len(oc.CASES)): oc.test_constrained_dls_matches_the_twin_and_stays_in_the_null_space(None, k)
+for c in com.CASES: com.test_dls_with_a_centre_of_mass_task_matches_the_twin_and_converges(None, *c)
 print("asan/ubsan: clean")
 PY
 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libstdc++.so.6)" ASAN_OPTIONS=detect_leaks=0 python /tmp/ik_asan_run.py
