@@ -18,7 +18,8 @@
 // Differences that cannot be hidden, by design of a device path:
 //   * a C++ visitor cannot run inside a kernel: inverse_kinematics_visitor carries the one-parameter
 //     family of ik/ik/visitor.hpp:19 (`||e[0]||^2 < tolerance`); override stop_tolerance(), not should_stop();
-//   * FrameTask, AlignAxisTask and PostureTask are accelerated (SURVEY.md section 8f lists the other kinds as "next");
+//   * every task kind of the reference is on the device -- FrameTask, AlignAxisTask, PostureTask, CentreOfMassTask -- and
+//     so are FrameConstraint (ik::dls) and the prioritised solver ik::pik; ik::dls_data::kernel() names the kernel chosen;
 //   * failures of the device call throw std::runtime_error (the reference has no failure channel).
 #pragma once
 
