@@ -48,9 +48,13 @@ __device__ long long g_coop_prof[16];
 #if IKD_ON_DEVICE && defined(IKGPU_COOP_PROFILE)
 #define IKC_TICK_INIT long long tick = clock64()
 #define IKC_TICK(n) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const long long now = clock64(); g_coop_prof[n] += now - tick; tick = now; } } while (0)
+#define IKC_TICK_ARG , long long &tick
+#define IKC_TICK_PASS , tick
 #else
 #define IKC_TICK_INIT ((void)0)
 #define IKC_TICK(n) ((void)0)
+#define IKC_TICK_ARG
+#define IKC_TICK_PASS
 #endif
 
 struct CoopLayout {
@@ -69,194 +73,273 @@ IKD_FN void coop_se3_mul_ws(const double *A, const double *B, double (&C)[12]) {
     g_se3_mul(a, b, C);
 }
 
+// evaluate_problem_data (ik/ik/data.cpp:25-58) on the group's workspace: q -> oMi, Jw, et, Jt.  Returns ||e[0]||^2 (the same in
+// every lane).  Ends on a barrier.
+IKD_FN double coop_evaluate(const GenericTables &T, const CoopLayout &L, const int g, double *ws IKC_TICK_ARG) {
+    (void)g;
+    const int nv = T.nv, nj = T.njoints, nt = T.ntasks;
+    // ---- forward kinematics: every joint's local transform li_j = placement_j * motion_j(q), one lane per joint, parked
+    // in the joint's own slot ...
+    const int oMi = L.A1;
+    IKC_FOR(j, nj) {
+        double Mj[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0}, li[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+        if (j > 0) {
+            const int iq = T.idx_q[j], jt = T.jtype[j];
+            const double *a = T.axis + 3 * j;
+            if (jt == GJ_REVOLUTE) {
+                double s, c;
+                dsincos(ws[L.q + iq], s, c);
+                const double k = 1.0 - c;
+                Mj[0] = c + k * a[0] * a[0];        Mj[1] = k * a[0] * a[1] - s * a[2]; Mj[2] = k * a[0] * a[2] + s * a[1];
+                Mj[3] = k * a[1] * a[0] + s * a[2]; Mj[4] = c + k * a[1] * a[1];        Mj[5] = k * a[1] * a[2] - s * a[0];
+                Mj[6] = k * a[2] * a[0] - s * a[1]; Mj[7] = k * a[2] * a[1] + s * a[0]; Mj[8] = c + k * a[2] * a[2];
+            } else if (jt == GJ_PRISMATIC) {
+                const double v = ws[L.q + iq];
+                Mj[9] = a[0] * v; Mj[10] = a[1] * v; Mj[11] = a[2] * v;
+            } else if (jt == GJ_FREEFLYER) {
+                double qb[7], R[9];
+                for (int k = 0; k < 7; ++k) qb[k] = ws[L.q + iq + k];
+                quat_to_R(qb, R);
+                for (int k = 0; k < 9; ++k) Mj[k] = R[k];
+                Mj[9] = qb[0]; Mj[10] = qb[1]; Mj[11] = qb[2];
+            }
+            g_se3_mul(T.placement + 12 * j, Mj, li);
+        }
+        for (int k = 0; k < 12; ++k) ws[(j == 0 ? oMi : L.A0 + 12 * j) + k] = li[k];
+    }
+    IKC_SYNC();
+    IKC_TICK(0);
+    // ... then, one tree level after the other, oM_j = oM_parent * li_j with one lane per ELEMENT of the product (the same
+    // expression per element as g_se3_mul, so the same bits as the sequential pass of generic_fk) ...
+    for (int lv = 0; lv < L.rounds; ++lv) {
+        const int first = L.lvl_start[lv], count = L.lvl_start[lv + 1] - first;
+        IKC_FOR(idx, 12 * count) {
+            const int j = L.order[first + idx / 12], k = idx % 12;
+            const double *A = ws + oMi + 12 * T.parent[j], *Bl = ws + L.A0 + 12 * j;
+            double val;
+            if (k < 9) {
+                const int r = k / 3, c = k % 3;
+                val = dfma(A[3 * r], Bl[c], dfma(A[3 * r + 1], Bl[3 + c], A[3 * r + 2] * Bl[6 + c]));
+            } else {
+                const int r = k - 9;
+                val = dfma(A[3 * r], Bl[9], dfma(A[3 * r + 1], Bl[10], dfma(A[3 * r + 2], Bl[11], A[9 + r])));
+            }
+            ws[oMi + 12 * j + k] = val;
+        }
+        IKC_SYNC();
+    }
+    IKC_TICK(1);
+    // ... and the world joint Jacobian columns [v; w] (computeJointJacobians), one lane per joint
+    {
+        IKC_FOR(jj, nj - 1) {
+            const int j = jj + 1;
+            double oM[12];
+            const int iv = T.idx_v[j], jt = T.jtype[j];
+            const double *a = T.axis + 3 * j;
+            for (int k = 0; k < 12; ++k) oM[k] = ws[oMi + 12 * j + k];
+            if (jt == GJ_REVOLUTE || jt == GJ_PRISMATIC) {
+                const double Ra[3] = {dfma(oM[0], a[0], dfma(oM[1], a[1], oM[2] * a[2])), dfma(oM[3], a[0], dfma(oM[4], a[1], oM[5] * a[2])),
+                                      dfma(oM[6], a[0], dfma(oM[7], a[1], oM[8] * a[2]))};
+                const double p[3] = {oM[9], oM[10], oM[11]};
+                double v[3] = {Ra[0], Ra[1], Ra[2]}, w[3] = {0, 0, 0};
+                if (jt == GJ_REVOLUTE) {
+                    cross(p, Ra, v);
+                    w[0] = Ra[0]; w[1] = Ra[1]; w[2] = Ra[2];
+                }
+                for (int r = 0; r < 3; ++r) { ws[L.Jw + r * nv + iv] = v[r]; ws[L.Jw + (3 + r) * nv + iv] = w[r]; }
+            } else if (jt == GJ_FREEFLYER) {
+                const double p[3] = {oM[9], oM[10], oM[11]};
+                for (int c = 0; c < 3; ++c) {
+                    const double Rc[3] = {oM[c], oM[3 + c], oM[6 + c]};
+                    double pxR[3];
+                    cross(p, Rc, pxR);
+                    for (int r = 0; r < 3; ++r) {
+                        ws[L.Jw + r * nv + iv + c] = Rc[r];
+                        ws[L.Jw + (3 + r) * nv + iv + c] = 0.0;
+                        ws[L.Jw + r * nv + iv + 3 + c] = pxR[r];
+                        ws[L.Jw + (3 + r) * nv + iv + 3 + c] = Rc[r];
+                    }
+                }
+            }
+        }
+        IKC_SYNC();
+    }
+    IKC_TICK(1);
+    // ---- per task: frame placement, error, the blocks its Jacobian columns need (tb: Rf 9 | pf 3 | A 9 | B 9 | spare 6)
+    IKC_FOR(t, nt) {
+        const int fj = T.t_fjoint[t], rj = T.t_rjoint[t], type = T.t_type[t], row = T.t_row[t], dim = T.t_dim[t];
+        const double *w6 = T.t_w + 6 * t;
+        double *tb = ws + L.tb + 36 * (L.tb_index[t] < 0 ? 0 : L.tb_index[t]);
+        if (type == GT_POSTURE_ROW) {  // ik/ik/posture.hpp:51-68: the whole row is written here
+            ws[L.e + row] = (ws[L.q + rj] - ws[L.tg + 12 * t + 9]) * w6[1] * w6[0];
+            for (int c = 0; c < nv; ++c) ws[L.J + row * nv + c] = (c == fj) ? w6[0] : 0.0;
+            continue;
+        }
+        double oMf[12], oMr[12], tg[12];
+        coop_se3_mul_ws(ws + oMi + 12 * fj, T.t_fpl + 12 * t, oMf);
+        coop_se3_mul_ws(ws + oMi + 12 * rj, T.t_rpl + 12 * t, oMr);
+        for (int k = 0; k < 12; ++k) { tg[k] = ws[L.tg + 12 * t + k]; tb[k] = oMf[k]; }
+        const double Rf[9] = {oMf[0], oMf[1], oMf[2], oMf[3], oMf[4], oMf[5], oMf[6], oMf[7], oMf[8]};
+        const double pf[3] = {oMf[9], oMf[10], oMf[11]};
+        if (type >= GT_ALIGN_X) {  // AlignAxisTask, ik/ik/frame.hpp:257-301: tb[12..14] = the row's direction in the frame
+            double rMf[12];
+            g_se3_inv_mul(oMr, oMf, rMf);
+            const int ax = type - GT_ALIGN_X;
+            const double r[3] = {rMf[ax], rMf[3 + ax], rMf[6 + ax]};
+            const double inv = drsqrt(dfma(tg[9], tg[9], dfma(tg[10], tg[10], tg[11] * tg[11])));
+            const double tn[3] = {tg[9] * inv, tg[10] * inv, tg[11] * inv};
+            double rxt[3];
+            cross(r, tn, rxt);
+            tb[12] = dfma(rxt[0], rMf[0], dfma(rxt[1], rMf[3], rxt[2] * rMf[6]));
+            tb[13] = dfma(rxt[0], rMf[1], dfma(rxt[1], rMf[4], rxt[2] * rMf[7]));
+            tb[14] = dfma(rxt[0], rMf[2], dfma(rxt[1], rMf[5], rxt[2] * rMf[8]));
+            ws[L.e + row] = (1.0 - dot(r, tn)) * w6[0];
+            continue;
+        }
+        double oMt[12], Re[9], pe[3];
+        g_se3_mul(oMr, tg, oMt);                        // frame.hpp:48
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) Re[3 * i + j] = dfma(Rf[i], oMt[j], dfma(Rf[3 + i], oMt[3 + j], Rf[6 + i] * oMt[6 + j]));
+        {
+            const double dp[3] = {oMt[9] - pf[0], oMt[10] - pf[1], oMt[11] - pf[2]};
+            rotT_vec(Rf, dp, pe);
+        }
+        LogAndJlog lj;
+        log6_and_jlog6_inv(Re, pe, lj);                 // frame.hpp:50-61, :162-166
+        for (int k = 0; k < 9; ++k) { tb[12 + k] = lj.A[k]; tb[21 + k] = lj.Bm[k]; }
+        const int r0 = (type == GT_ORIENTATION) ? 3 : 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+            if (r >= r0 && r < r0 + dim) ws[L.e + row + r - r0] = lj.e[r] * w6[r - r0];
+    }
+    IKC_SYNC();
+    IKC_TICK(2);
+    // ---- task Jacobian, one tangent column per lane (zero outside the support of the task's frame, frame.hpp:110)
+    IKC_FOR(c, nv) {
+        const double vw[6] = {ws[L.Jw + c], ws[L.Jw + nv + c], ws[L.Jw + 2 * nv + c],
+                              ws[L.Jw + 3 * nv + c], ws[L.Jw + 4 * nv + c], ws[L.Jw + 5 * nv + c]};
+        for (int t = 0; t < nt; ++t) {
+            const int type = T.t_type[t], row = T.t_row[t], dim = T.t_dim[t];
+            if (type == GT_POSTURE_ROW) continue;
+            if (!L.support[t * nv + c]) {
+                for (int r = 0; r < dim; ++r) ws[L.J + (row + r) * nv + c] = 0.0;
+                continue;
+            }
+            const double *w6 = T.t_w + 6 * t;
+            const double *tb = ws + L.tb + 36 * L.tb_index[t];
+            const double Rf[9] = {tb[0], tb[1], tb[2], tb[3], tb[4], tb[5], tb[6], tb[7], tb[8]};
+            const double pf[3] = {tb[9], tb[10], tb[11]};
+            double v[3] = {vw[0], vw[1], vw[2]};
+            const double w[3] = {vw[3], vw[4], vw[5]};
+            double pxw[3], vl[3], wl[3];
+            rotT_vec(Rf, w, wl);
+            if (type >= GT_ALIGN_X) {
+                const double gv[3] = {tb[12], tb[13], tb[14]};
+                ws[L.J + row * nv + c] = -w6[0] * dot(gv, wl);
+                continue;
+            }
+            cross(pf, w, pxw);
+            v[0] -= pxw[0]; v[1] -= pxw[1]; v[2] -= pxw[2];
+            rotT_vec(Rf, v, vl);
+            const int r0 = (type == GT_ORIENTATION) ? 3 : 0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double lin = -dfma(tb[12 + 3 * i], vl[0], dfma(tb[12 + 3 * i + 1], vl[1], dfma(tb[12 + 3 * i + 2], vl[2],
+                                    dfma(tb[21 + 3 * i], wl[0], dfma(tb[21 + 3 * i + 1], wl[1], tb[21 + 3 * i + 2] * wl[2])))));
+                const double ang = -dfma(tb[12 + 3 * i], wl[0], dfma(tb[12 + 3 * i + 1], wl[1], tb[12 + 3 * i + 2] * wl[2]));
+                if (i >= r0 && i < r0 + dim) ws[L.J + (row + i - r0) * nv + c] = w6[i - r0] * lin;
+                if (3 + i >= r0 && 3 + i < r0 + dim) ws[L.J + (row + 3 + i - r0) * nv + c] = w6[3 + i - r0] * ang;
+            }
+        }
+    }
+    IKC_SYNC();
+    IKC_TICK(3);
+    double e0sq = 0.0;  // ||e[0]||^2 over the rows of priority level 0, the same in every lane
+#pragma unroll 8
+    for (int r = 0; r < T.lvl_row0[1]; ++r) { const double e = ws[L.e + r]; e0sq = dfma(e, e, e0sq); }
+    return e0sq;
+}
+
+// Solve the m x m SPD system whose lower triangle sits at offG (packed by rows) with the right-hand side as row m: right-looking
+// Cholesky, ONE phase per pivot -- column k stays unscaled while the trailing triangle takes its update
+// G(i,j) -= (G(i,k) inv)(G(j,k) inv); every entry receives its updates in the order m = 0, 1, ... of the left-looking loop of
+// generic_solver.hpp, with the same roundings -- one phase that turns the strict lower triangle into L by the pivots'
+// reciprocals (row m comes out as y = L^-1 rhs), then the column-oriented back substitution.  x is left at offx.  The pair
+// tables list the lower triangle by rows; row m contributes its first m entries.
+IKD_FN void coop_chol_solve(const CoopLayout &L, const int g, double *ws, const int offG, const int offdinv, const int offx, const int M) {
+    (void)g;
+    const int npairs = tri(M, 0) + M;
+    // ---- Cholesky, right-looking, ONE phase per pivot: column k stays unscaled while the trailing triangle takes its
+    // update G(i,j) -= (G(i,k) inv)(G(j,k) inv) -- every entry receives its updates in the order m = 0, 1, ... of the
+    // left-looking loop of generic_solver.hpp, with the same roundings -- and one last phase turns the strict lower triangle
+    // into L by the pivots' reciprocals.  Row M comes out as y = L^-1 et.
+    for (int k = 0; k < M; ++k) {
+        const double inv = drsqrt(ws[offG + tri(k, k)]);
+        ws[offdinv + k] = inv;  // every lane holds the same value
+        const int p0 = tri(k + 1, 0);  // the pairs are sorted by row: rows k + 1 .. M start here
+#pragma unroll 2
+        IKC_FOR(pp, npairs - p0) {
+            const int i = L.pair_i[p0 + pp], j = L.pair_j[p0 + pp];
+            if (j > k) {
+                const double lik = ws[offG + tri(i, k)] * inv, ljk = ws[offG + tri(j, k)] * inv;
+                ws[offG + tri(i, j)] = dfma(-lik, ljk, ws[offG + tri(i, j)]);
+            }
+        }
+        IKC_SYNC();
+    }
+#pragma unroll 2
+    IKC_FOR(p, npairs) {
+        const int i = L.pair_i[p], j = L.pair_j[p];
+        if (j < i) ws[offG + tri(i, j)] *= ws[offdinv + j];
+    }
+    IKC_SYNC();
+    // ---- back substitution x = L^-T y, column oriented: x_k is final once the rows above it were eliminated
+    for (int k = M - 1; k >= 0; --k) {
+        const double xk = ws[offG + tri(M, k)] * ws[offdinv + k];
+        IKC_FOR(i, k) ws[offG + tri(M, i)] = dfma(-ws[offG + tri(k, i)], xk, ws[offG + tri(M, i)]);
+        ws[offx + k] = xk;
+        IKC_SYNC();
+    }
+}
+
+// q <- clip(integrate(q, step * dq)) (ik/ik/dls.cpp:67-71), one lane per joint; a group that is no longer active keeps its q.
+// Ends on a barrier.
+IKD_FN void coop_integrate(const GenericTables &T, const CoopLayout &L, const int g, double *ws, const double step_length, const bool active) {
+    (void)g;
+    const int nj = T.njoints;
+    // ---- integrate + clip (ik/ik/dls.cpp:67-71), one lane per joint
+    IKC_FOR(j, nj) {
+        if (j == 0) continue;
+        const int iq = T.idx_q[j], iv = T.idx_v[j];
+        if (T.jtype[j] == GJ_FREEFLYER) {
+            double qb[7], v[6], qn[7], R1[9];
+            for (int k = 0; k < 7; ++k) qb[k] = ws[L.q + iq + k];
+            for (int k = 0; k < 6; ++k) v[k] = step_length * ws[L.dq + iv + k];
+            quat_to_R(qb, R1);
+            freeflyer_integrate(qb, R1, v, qn);
+            for (int k = 0; k < 7; ++k) {
+                const double c = dmin(T.upper[iq + k], dmax(qn[k], T.lower[iq + k]));
+                ws[L.q + iq + k] = active ? c : qb[k];
+            }
+        } else {
+            const double qo = ws[L.q + iq];
+            const double c = dmin(T.upper[iq], dmax(dfma(step_length, ws[L.dq + iv], qo), T.lower[iq]));
+            ws[L.q + iq] = active ? c : qo;
+        }
+    }
+    IKC_SYNC();
+}
+
 template <class AnyFn>
 IKD_FN void coop_dls(const GenericTables &T, const CoopLayout &L, const LoopParams &prm, const int g, double *ws, int &iters_out,
                      bool &success_out, AnyFn any_active) {
     (void)g;
-    const int nv = T.nv, M = T.M, nj = T.njoints, nt = T.ntasks;
+    const int nv = T.nv, M = T.M;
     bool active = true, success = false;
     int iters = prm.max_iterations;
     IKC_TICK_INIT;
     for (int it = 0; it < prm.max_iterations; ++it) {
-        // ---- forward kinematics: every joint's local transform li_j = placement_j * motion_j(q), one lane per joint, parked
-        // in the joint's own slot ...
-        const int oMi = L.A1;
-        IKC_FOR(j, nj) {
-            double Mj[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0}, li[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
-            if (j > 0) {
-                const int iq = T.idx_q[j], jt = T.jtype[j];
-                const double *a = T.axis + 3 * j;
-                if (jt == GJ_REVOLUTE) {
-                    double s, c;
-                    dsincos(ws[L.q + iq], s, c);
-                    const double k = 1.0 - c;
-                    Mj[0] = c + k * a[0] * a[0];        Mj[1] = k * a[0] * a[1] - s * a[2]; Mj[2] = k * a[0] * a[2] + s * a[1];
-                    Mj[3] = k * a[1] * a[0] + s * a[2]; Mj[4] = c + k * a[1] * a[1];        Mj[5] = k * a[1] * a[2] - s * a[0];
-                    Mj[6] = k * a[2] * a[0] - s * a[1]; Mj[7] = k * a[2] * a[1] + s * a[0]; Mj[8] = c + k * a[2] * a[2];
-                } else if (jt == GJ_PRISMATIC) {
-                    const double v = ws[L.q + iq];
-                    Mj[9] = a[0] * v; Mj[10] = a[1] * v; Mj[11] = a[2] * v;
-                } else if (jt == GJ_FREEFLYER) {
-                    double qb[7], R[9];
-                    for (int k = 0; k < 7; ++k) qb[k] = ws[L.q + iq + k];
-                    quat_to_R(qb, R);
-                    for (int k = 0; k < 9; ++k) Mj[k] = R[k];
-                    Mj[9] = qb[0]; Mj[10] = qb[1]; Mj[11] = qb[2];
-                }
-                g_se3_mul(T.placement + 12 * j, Mj, li);
-            }
-            for (int k = 0; k < 12; ++k) ws[(j == 0 ? oMi : L.A0 + 12 * j) + k] = li[k];
-        }
-        IKC_SYNC();
-        IKC_TICK(0);
-        // ... then, one tree level after the other, oM_j = oM_parent * li_j with one lane per ELEMENT of the product (the same
-        // expression per element as g_se3_mul, so the same bits as the sequential pass of generic_fk) ...
-        for (int lv = 0; lv < L.rounds; ++lv) {
-            const int first = L.lvl_start[lv], count = L.lvl_start[lv + 1] - first;
-            IKC_FOR(idx, 12 * count) {
-                const int j = L.order[first + idx / 12], k = idx % 12;
-                const double *A = ws + oMi + 12 * T.parent[j], *Bl = ws + L.A0 + 12 * j;
-                double val;
-                if (k < 9) {
-                    const int r = k / 3, c = k % 3;
-                    val = dfma(A[3 * r], Bl[c], dfma(A[3 * r + 1], Bl[3 + c], A[3 * r + 2] * Bl[6 + c]));
-                } else {
-                    const int r = k - 9;
-                    val = dfma(A[3 * r], Bl[9], dfma(A[3 * r + 1], Bl[10], dfma(A[3 * r + 2], Bl[11], A[9 + r])));
-                }
-                ws[oMi + 12 * j + k] = val;
-            }
-            IKC_SYNC();
-        }
-        IKC_TICK(1);
-        // ... and the world joint Jacobian columns [v; w] (computeJointJacobians), one lane per joint
-        {
-            IKC_FOR(jj, nj - 1) {
-                const int j = jj + 1;
-                double oM[12];
-                const int iv = T.idx_v[j], jt = T.jtype[j];
-                const double *a = T.axis + 3 * j;
-                for (int k = 0; k < 12; ++k) oM[k] = ws[oMi + 12 * j + k];
-                if (jt == GJ_REVOLUTE || jt == GJ_PRISMATIC) {
-                    const double Ra[3] = {dfma(oM[0], a[0], dfma(oM[1], a[1], oM[2] * a[2])), dfma(oM[3], a[0], dfma(oM[4], a[1], oM[5] * a[2])),
-                                          dfma(oM[6], a[0], dfma(oM[7], a[1], oM[8] * a[2]))};
-                    const double p[3] = {oM[9], oM[10], oM[11]};
-                    double v[3] = {Ra[0], Ra[1], Ra[2]}, w[3] = {0, 0, 0};
-                    if (jt == GJ_REVOLUTE) {
-                        cross(p, Ra, v);
-                        w[0] = Ra[0]; w[1] = Ra[1]; w[2] = Ra[2];
-                    }
-                    for (int r = 0; r < 3; ++r) { ws[L.Jw + r * nv + iv] = v[r]; ws[L.Jw + (3 + r) * nv + iv] = w[r]; }
-                } else if (jt == GJ_FREEFLYER) {
-                    const double p[3] = {oM[9], oM[10], oM[11]};
-                    for (int c = 0; c < 3; ++c) {
-                        const double Rc[3] = {oM[c], oM[3 + c], oM[6 + c]};
-                        double pxR[3];
-                        cross(p, Rc, pxR);
-                        for (int r = 0; r < 3; ++r) {
-                            ws[L.Jw + r * nv + iv + c] = Rc[r];
-                            ws[L.Jw + (3 + r) * nv + iv + c] = 0.0;
-                            ws[L.Jw + r * nv + iv + 3 + c] = pxR[r];
-                            ws[L.Jw + (3 + r) * nv + iv + 3 + c] = Rc[r];
-                        }
-                    }
-                }
-            }
-            IKC_SYNC();
-        }
-        IKC_TICK(1);
-        // ---- per task: frame placement, error, the blocks its Jacobian columns need (tb: Rf 9 | pf 3 | A 9 | B 9 | spare 6)
-        IKC_FOR(t, nt) {
-            const int fj = T.t_fjoint[t], rj = T.t_rjoint[t], type = T.t_type[t], row = T.t_row[t], dim = T.t_dim[t];
-            const double *w6 = T.t_w + 6 * t;
-            double *tb = ws + L.tb + 36 * (L.tb_index[t] < 0 ? 0 : L.tb_index[t]);
-            if (type == GT_POSTURE_ROW) {  // ik/ik/posture.hpp:51-68: the whole row is written here
-                ws[L.e + row] = (ws[L.q + rj] - ws[L.tg + 12 * t + 9]) * w6[1] * w6[0];
-                for (int c = 0; c < nv; ++c) ws[L.J + row * nv + c] = (c == fj) ? w6[0] : 0.0;
-                continue;
-            }
-            double oMf[12], oMr[12], tg[12];
-            coop_se3_mul_ws(ws + oMi + 12 * fj, T.t_fpl + 12 * t, oMf);
-            coop_se3_mul_ws(ws + oMi + 12 * rj, T.t_rpl + 12 * t, oMr);
-            for (int k = 0; k < 12; ++k) { tg[k] = ws[L.tg + 12 * t + k]; tb[k] = oMf[k]; }
-            const double Rf[9] = {oMf[0], oMf[1], oMf[2], oMf[3], oMf[4], oMf[5], oMf[6], oMf[7], oMf[8]};
-            const double pf[3] = {oMf[9], oMf[10], oMf[11]};
-            if (type >= GT_ALIGN_X) {  // AlignAxisTask, ik/ik/frame.hpp:257-301: tb[12..14] = the row's direction in the frame
-                double rMf[12];
-                g_se3_inv_mul(oMr, oMf, rMf);
-                const int ax = type - GT_ALIGN_X;
-                const double r[3] = {rMf[ax], rMf[3 + ax], rMf[6 + ax]};
-                const double inv = drsqrt(dfma(tg[9], tg[9], dfma(tg[10], tg[10], tg[11] * tg[11])));
-                const double tn[3] = {tg[9] * inv, tg[10] * inv, tg[11] * inv};
-                double rxt[3];
-                cross(r, tn, rxt);
-                tb[12] = dfma(rxt[0], rMf[0], dfma(rxt[1], rMf[3], rxt[2] * rMf[6]));
-                tb[13] = dfma(rxt[0], rMf[1], dfma(rxt[1], rMf[4], rxt[2] * rMf[7]));
-                tb[14] = dfma(rxt[0], rMf[2], dfma(rxt[1], rMf[5], rxt[2] * rMf[8]));
-                ws[L.e + row] = (1.0 - dot(r, tn)) * w6[0];
-                continue;
-            }
-            double oMt[12], Re[9], pe[3];
-            g_se3_mul(oMr, tg, oMt);                        // frame.hpp:48
-            for (int i = 0; i < 3; ++i)
-                for (int j = 0; j < 3; ++j) Re[3 * i + j] = dfma(Rf[i], oMt[j], dfma(Rf[3 + i], oMt[3 + j], Rf[6 + i] * oMt[6 + j]));
-            {
-                const double dp[3] = {oMt[9] - pf[0], oMt[10] - pf[1], oMt[11] - pf[2]};
-                rotT_vec(Rf, dp, pe);
-            }
-            LogAndJlog lj;
-            log6_and_jlog6_inv(Re, pe, lj);                 // frame.hpp:50-61, :162-166
-            for (int k = 0; k < 9; ++k) { tb[12 + k] = lj.A[k]; tb[21 + k] = lj.Bm[k]; }
-            const int r0 = (type == GT_ORIENTATION) ? 3 : 0;
-#pragma unroll
-            for (int r = 0; r < 6; ++r)
-                if (r >= r0 && r < r0 + dim) ws[L.e + row + r - r0] = lj.e[r] * w6[r - r0];
-        }
-        IKC_SYNC();
-        IKC_TICK(2);
-        // ---- task Jacobian, one tangent column per lane (zero outside the support of the task's frame, frame.hpp:110)
-        IKC_FOR(c, nv) {
-            const double vw[6] = {ws[L.Jw + c], ws[L.Jw + nv + c], ws[L.Jw + 2 * nv + c],
-                                  ws[L.Jw + 3 * nv + c], ws[L.Jw + 4 * nv + c], ws[L.Jw + 5 * nv + c]};
-            for (int t = 0; t < nt; ++t) {
-                const int type = T.t_type[t], row = T.t_row[t], dim = T.t_dim[t];
-                if (type == GT_POSTURE_ROW) continue;
-                if (!L.support[t * nv + c]) {
-                    for (int r = 0; r < dim; ++r) ws[L.J + (row + r) * nv + c] = 0.0;
-                    continue;
-                }
-                const double *w6 = T.t_w + 6 * t;
-                const double *tb = ws + L.tb + 36 * L.tb_index[t];
-                const double Rf[9] = {tb[0], tb[1], tb[2], tb[3], tb[4], tb[5], tb[6], tb[7], tb[8]};
-                const double pf[3] = {tb[9], tb[10], tb[11]};
-                double v[3] = {vw[0], vw[1], vw[2]};
-                const double w[3] = {vw[3], vw[4], vw[5]};
-                double pxw[3], vl[3], wl[3];
-                rotT_vec(Rf, w, wl);
-                if (type >= GT_ALIGN_X) {
-                    const double gv[3] = {tb[12], tb[13], tb[14]};
-                    ws[L.J + row * nv + c] = -w6[0] * dot(gv, wl);
-                    continue;
-                }
-                cross(pf, w, pxw);
-                v[0] -= pxw[0]; v[1] -= pxw[1]; v[2] -= pxw[2];
-                rotT_vec(Rf, v, vl);
-                const int r0 = (type == GT_ORIENTATION) ? 3 : 0;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const double lin = -dfma(tb[12 + 3 * i], vl[0], dfma(tb[12 + 3 * i + 1], vl[1], dfma(tb[12 + 3 * i + 2], vl[2],
-                                        dfma(tb[21 + 3 * i], wl[0], dfma(tb[21 + 3 * i + 1], wl[1], tb[21 + 3 * i + 2] * wl[2])))));
-                    const double ang = -dfma(tb[12 + 3 * i], wl[0], dfma(tb[12 + 3 * i + 1], wl[1], tb[12 + 3 * i + 2] * wl[2]));
-                    if (i >= r0 && i < r0 + dim) ws[L.J + (row + i - r0) * nv + c] = w6[i - r0] * lin;
-                    if (3 + i >= r0 && 3 + i < r0 + dim) ws[L.J + (row + 3 + i - r0) * nv + c] = w6[3 + i - r0] * ang;
-                }
-            }
-        }
-        IKC_SYNC();
-        IKC_TICK(3);
-        double e0sq = 0.0;  // ||e[0]||^2 over the rows of priority level 0, the same in every lane
-#pragma unroll 8
-        for (int r = 0; r < T.lvl_row0[1]; ++r) { const double e = ws[L.e + r]; e0sq = dfma(e, e, e0sq); }
+        const double e0sq = coop_evaluate(T, L, g, ws IKC_TICK_PASS);
         // ---- JJ = Jt Jt^T + damping^2 I (ik/ik/dls.cpp:39-41), lower triangle, with the right-hand side et as row M
         IKC_FOR(p, L.npairs) {
             const int i = L.pair_i[p], j = L.pair_j[p];
@@ -272,38 +355,7 @@ IKD_FN void coop_dls(const GenericTables &T, const CoopLayout &L, const LoopPara
         }
         IKC_SYNC();
         IKC_TICK(4);
-        // ---- Cholesky, right-looking, ONE phase per pivot: column k stays unscaled while the trailing triangle takes its
-        // update G(i,j) -= (G(i,k) inv)(G(j,k) inv) -- every entry receives its updates in the order m = 0, 1, ... of the
-        // left-looking loop of generic_solver.hpp, with the same roundings -- and one last phase turns the strict lower triangle
-        // into L by the pivots' reciprocals.  Row M comes out as y = L^-1 et.
-        for (int k = 0; k < M; ++k) {
-            const double inv = drsqrt(ws[L.G + tri(k, k)]);
-            ws[L.dinv + k] = inv;  // every lane holds the same value
-            const int p0 = tri(k + 1, 0);  // the pairs are sorted by row: rows k + 1 .. M start here
-#pragma unroll 2
-            IKC_FOR(pp, L.npairs - p0) {
-                const int i = L.pair_i[p0 + pp], j = L.pair_j[p0 + pp];
-                if (j > k) {
-                    const double lik = ws[L.G + tri(i, k)] * inv, ljk = ws[L.G + tri(j, k)] * inv;
-                    ws[L.G + tri(i, j)] = dfma(-lik, ljk, ws[L.G + tri(i, j)]);
-                }
-            }
-            IKC_SYNC();
-        }
-#pragma unroll 2
-        IKC_FOR(p, L.npairs) {
-            const int i = L.pair_i[p], j = L.pair_j[p];
-            if (j < i) ws[L.G + tri(i, j)] *= ws[L.dinv + j];
-        }
-        IKC_SYNC();
-        IKC_TICK(5);
-        // ---- back substitution x = L^-T y, column oriented: x_k is final once the rows above it were eliminated
-        for (int k = M - 1; k >= 0; --k) {
-            const double xk = ws[L.G + tri(M, k)] * ws[L.dinv + k];
-            IKC_FOR(i, k) ws[L.G + tri(M, i)] = dfma(-ws[L.G + tri(k, i)], xk, ws[L.G + tri(M, i)]);
-            ws[L.x + k] = xk;
-            IKC_SYNC();
-        }
+        coop_chol_solve(L, g, ws, L.G, L.dinv, L.x, M);
         IKC_TICK(6);
         IKC_FOR(c, nv) {  // dq = -Jt^T x, ik/ik/dls.cpp:52-53 (N = I)
             double s = 0.0;
@@ -316,27 +368,7 @@ IKD_FN void coop_dls(const GenericTables &T, const CoopLayout &L, const LoopPara
         const bool stop_now = active && (prm.stop_sq_tol >= 0.0) && (e0sq < prm.stop_sq_tol);
         if (stop_now) { success = true; iters = it; }
         active = active && !stop_now;
-        // ---- integrate + clip (ik/ik/dls.cpp:67-71), one lane per joint
-        IKC_FOR(j, nj) {
-            if (j == 0) continue;
-            const int iq = T.idx_q[j], iv = T.idx_v[j];
-            if (T.jtype[j] == GJ_FREEFLYER) {
-                double qb[7], v[6], qn[7], R1[9];
-                for (int k = 0; k < 7; ++k) qb[k] = ws[L.q + iq + k];
-                for (int k = 0; k < 6; ++k) v[k] = prm.step_length * ws[L.dq + iv + k];
-                quat_to_R(qb, R1);
-                freeflyer_integrate(qb, R1, v, qn);
-                for (int k = 0; k < 7; ++k) {
-                    const double c = dmin(T.upper[iq + k], dmax(qn[k], T.lower[iq + k]));
-                    ws[L.q + iq + k] = active ? c : qb[k];
-                }
-            } else {
-                const double qo = ws[L.q + iq];
-                const double c = dmin(T.upper[iq], dmax(dfma(prm.step_length, ws[L.dq + iv], qo), T.lower[iq]));
-                ws[L.q + iq] = active ? c : qo;
-            }
-        }
-        IKC_SYNC();
+        coop_integrate(T, L, g, ws, prm.step_length, active);
         IKC_TICK(8);
         if (!any_active(active)) break;
     }

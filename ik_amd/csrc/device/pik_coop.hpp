@@ -1,0 +1,196 @@
+// pik_coop.hpp -- ik::pik(), the reference's prioritised IK (reference ik/ik/pik.cpp:31-103), in the cooperative LDS-resident form
+// of coop_solver.hpp: sixteen lanes per problem, the workspace (now with the projector P and the projected Jacobian of the
+// level) on chip.  The per-lane program (pik_solver.hpp) streams ~17 GB of workspace through HBM per iteration at B = 65536
+// (profiles/r01_pmc/pik_*.csv: 872 GB per 50-iteration launch); here HBM sees q0 and the targets on entry and q on exit.
+//
+// Per iteration: evaluate_problem_data (coop_evaluate), P = I, dq = 0, then for every priority level
+//     de   = e_l - J_l dq                                   pik.cpp:49      one lane per row
+//     Jbar = J_l P                                          pik.cpp:51      one lane per entry
+//     dq  -= damp_pseudoinverse(Jbar, lambda_l) de          pik.cpp:54-55   = Jbar^T (Jbar Jbar^T + lambda^2 I)^-1 de: the m x m
+//                                                                           SPD solve of coop_chol_solve (needs lambda > 0)
+//     P   -= pinv(Jbar) Jbar                                pik.cpp:58-61   an orthonormal basis v_1 .. v_r of the row space of Jbar
+//                                                                           by Gram-Schmidt with row pivoting on the largest
+//                                                                           remaining norm, every projection applied twice;
+//                                                                           the pivot norms are |R_kk| of Eigen's column-pivoted
+//                                                                           QR of Jbar^T (what its COD starts from) and its rank
+//                                                                           rule is applied to them: |R_kk| > eps min(m, n) max|R|
+// and dq += P da (pik.cpp:65), the stop test on e[0], integrate + clip.  The projector left by the last level is only built
+// when da != 0.  Where the rank decision is clear-cut this agrees with pik_solver.hpp (one-sided Jacobi) to rounding; where a
+// level's projected Jacobian is exactly rank deficient the decision is made on rounding noise in either form (and in the
+// reference: see pik_solver.hpp).
+#pragma once
+#include "coop_solver.hpp"
+#include "pik_solver.hpp"
+
+namespace ikdev {
+
+struct PikCoopLayout {
+    int P, Jb, de, nrm, words;  // offsets into the group's workspace beyond CoopLayout's; `words` = the whole PIK workspace
+};
+
+template <class AnyFn>
+IKD_FN void coop_pik(const GenericTables &T, const CoopLayout &L, const PikCoopLayout &K, const PikParams &prm, const int g, double *ws,
+                     int &iters_out, bool &success_out, AnyFn any_active) {
+    (void)g;
+    const int nv = T.nv;
+    const double eps = 2.220446049250313e-16;
+    bool active = true, success = false;
+    int iters = prm.max_iterations;
+    int last_level = 0;
+    for (int l = 0; l < T.nlevels; ++l)
+        if (T.lvl_row0[l + 1] > T.lvl_row0[l]) last_level = l;
+    IKC_TICK_INIT;
+    for (int it = 0; it < prm.max_iterations; ++it) {
+        const double e0sq = coop_evaluate(T, L, g, ws IKC_TICK_PASS);    // pik.cpp:41
+        IKC_FOR(i, nv * nv) ws[K.P + i] = (i / nv == i % nv) ? 1.0 : 0.0;   // pik.cpp:44-45
+        IKC_FOR(c, nv) ws[L.dq + c] = 0.0;
+        IKC_SYNC();
+        for (int l = 0; l < T.nlevels; ++l) {                              // pik.cpp:47
+            const int r0 = T.lvl_row0[l], ml = T.lvl_row0[l + 1] - r0;
+            if (ml == 0) continue;
+            const bool update_P = l != last_level || prm.has_da != 0;
+            IKC_FOR(r, ml) {
+                double s = ws[L.e + r0 + r];
+#pragma unroll 8
+                for (int c = 0; c < nv; ++c) s = dfma(-ws[L.J + (r0 + r) * nv + c], ws[L.dq + c], s);
+                ws[K.de + r] = s;
+            }
+            IKC_FOR(idx, ml * nv) {
+                const int r = idx / nv, c = idx % nv;
+                double a = 0.0;
+#pragma unroll 8
+                for (int k = 0; k < nv; ++k) a = dfma(ws[L.J + (r0 + r) * nv + k], ws[K.P + k * nv + c], a);
+                ws[K.Jb + idx] = a;
+            }
+            IKC_SYNC();
+            // damped step: (Jbar Jbar^T + lambda^2 I) x = de, dq -= Jbar^T x
+            IKC_FOR(p, tri(ml, 0) + ml) {
+                const int i = L.pair_i[p], j = L.pair_j[p];
+                double s;
+                if (i == ml) {
+                    s = ws[K.de + j];
+                } else {
+                    s = (i == j) ? prm.lam2[l] : 0.0;
+#pragma unroll 8
+                    for (int c = 0; c < nv; ++c) s = dfma(ws[K.Jb + i * nv + c], ws[K.Jb + j * nv + c], s);
+                }
+                ws[L.G + tri(i, j)] = s;
+            }
+            IKC_SYNC();
+            coop_chol_solve(L, g, ws, L.G, L.dinv, L.x, ml);
+            IKC_FOR(c, nv) {
+                double s = ws[L.dq + c];
+#pragma unroll 8
+                for (int r = 0; r < ml; ++r) s = dfma(-ws[K.Jb + r * nv + c], ws[L.x + r], s);
+                ws[L.dq + c] = s;
+            }
+            IKC_SYNC();
+            if (!update_P) continue;
+            // orthonormal basis of the row space of Jbar, in place: pivoted Gram-Schmidt, every projection applied twice.
+            // All trip counts are the same in every group of the wave (the barriers sit outside anything that depends on the
+            // data); a group whose rank is exhausted keeps walking with `live` false.
+            const double kk = eps * static_cast<double>(ml < nv ? ml : nv), thr2 = kk * kk;
+            int rank = 0;
+            bool live = true;
+            double maxpiv2 = 0.0;
+            for (int k = 0; k < ml; ++k) {
+                IKC_FOR(ii, ml - k) {
+                    const int row = k + ii;
+                    double n2 = 0.0;
+#pragma unroll 8
+                    for (int c = 0; c < nv; ++c) { const double x = ws[K.Jb + row * nv + c]; n2 = dfma(x, x, n2); }
+                    ws[K.nrm + row] = n2;
+                }
+                IKC_SYNC();
+                int piv = k;
+                double best = ws[K.nrm + k];
+                for (int i = k + 1; i < ml; ++i) {
+                    const double n2 = ws[K.nrm + i];
+                    if (n2 > best) { best = n2; piv = i; }
+                }
+                if (k == 0) maxpiv2 = best;
+                live = live && best > thr2 * maxpiv2 && best > 0.0;   // Eigen's rank rule on |R_kk| = sqrt(best)
+                const double inv = live ? 1.0 / __builtin_sqrt(best) : 0.0;
+                IKC_FOR(c, nv) {
+                    if (live) {
+                        const double a = ws[K.Jb + piv * nv + c], b = ws[K.Jb + k * nv + c];
+                        ws[K.Jb + piv * nv + c] = b;
+                        ws[K.Jb + k * nv + c] = a * inv;
+                    }
+                }
+                IKC_SYNC();
+                IKC_FOR(ii, ml - k - 1) {
+                    if (live) {
+                        const int row = k + 1 + ii;
+                        for (int pass = 0; pass < 2; ++pass) {
+                            double d = 0.0;
+#pragma unroll 8
+                            for (int c = 0; c < nv; ++c) d = dfma(ws[K.Jb + row * nv + c], ws[K.Jb + k * nv + c], d);
+#pragma unroll 8
+                            for (int c = 0; c < nv; ++c) ws[K.Jb + row * nv + c] = dfma(-d, ws[K.Jb + k * nv + c], ws[K.Jb + row * nv + c]);
+                        }
+                    }
+                }
+                IKC_SYNC();
+                if (live) ++rank;
+            }
+            IKC_FOR(idx, nv * nv) {   // P -= sum_{k < rank} v_k v_k^T
+                const int a = idx / nv, b = idx % nv;
+                double s = ws[K.P + idx];
+                for (int k = 0; k < rank; ++k) s = dfma(-ws[K.Jb + k * nv + a], ws[K.Jb + k * nv + b], s);
+                ws[K.P + idx] = s;
+            }
+            IKC_SYNC();
+        }
+        if (prm.has_da) {                                                  // pik.cpp:65 (da lives in the kernel arguments)
+            IKC_FOR(c, nv) {
+                double s = ws[L.dq + c];
+                for (int k = 0; k < nv; ++k) s = dfma(ws[K.P + c * nv + k], prm.da[k], s);
+                ws[L.dq + c] = s;
+            }
+            IKC_SYNC();
+        }
+        const bool stop_now = active && (prm.stop_sq_tol >= 0.0) && (e0sq < prm.stop_sq_tol);   // pik.cpp:67-70
+        if (stop_now) { success = true; iters = it; }
+        active = active && !stop_now;
+        coop_integrate(T, L, g, ws, prm.step_length, active);             // pik.cpp:73-77
+        if (!any_active(active)) break;
+    }
+    iters_out = iters;
+    success_out = success;
+}
+
+struct PikCoopKernelArgs {
+    GenericTables T;
+    CoopLayout L;
+    PikCoopLayout K;
+    PikParams prm;
+    int layout;
+    int64_t B;
+    const double *q0, *targets;
+    double *q_out;
+    uint8_t *success;
+    int32_t *iters;
+};
+
+template <class AnyFn>
+IKD_FN void pik_coop_body(const PikCoopKernelArgs &a, int64_t problem, const int g, double *ws, AnyFn any_active) {
+    (void)g;
+    const bool valid = problem < a.B;
+    const int64_t b = valid ? problem : a.B - 1;
+    const int nq = a.T.nq, nslots = a.T.ntasks * 12;
+    IKC_FOR(i, nq) ws[a.L.q + i] = a.q0[at(a.layout, a.B, nq, i, b)];
+    IKC_FOR(i, nslots) ws[a.L.tg + i] = a.layout == LAYOUT_SOA ? a.targets[static_cast<int64_t>(i) * a.B + b] : a.targets[b * nslots + i];
+    IKC_SYNC();
+    int iters;
+    bool success;
+    coop_pik(a.T, a.L, a.K, a.prm, g, ws, iters, success, any_active);
+    if (!valid) return;
+    IKC_FOR(i, nq) a.q_out[at(a.layout, a.B, nq, i, b)] = ws[a.L.q + i];
+    IKC_FOR(one, 1) {
+        if (a.success) a.success[b] = success ? 1 : 0;
+        if (a.iters) a.iters[b] = iters;
+    }
+}
+
+}  // namespace ikdev

@@ -3,6 +3,7 @@
 // either on the device (kernels.hip) or on the host (the lane emulator under tests/).
 #pragma once
 #include "device/coop_solver.hpp"
+#include "device/pik_coop.hpp"
 #include "device/generic_solver.hpp"
 #include "problem.hpp"
 
@@ -39,6 +40,15 @@ inline ikdev::CoopLayout bind_coop_layout(const ProblemHost &ph, const int32_t *
     L.rounds = g.coop_rounds; L.npairs = g.coop_npairs;
     L.support = ibase + g.o_csupport; L.pair_i = ibase + g.o_cpair_i; L.pair_j = ibase + g.o_cpair_j; L.order = ibase + g.o_cup; L.lvl_start = ibase + g.o_clvl; L.tb_index = ibase + g.o_ctbindex;
     return L;
+}
+
+// ik::pik in the cooperative form: the projector after the DLS workspace; the level's projected Jacobian where the joint
+// placements lived, its right-hand side and pivot norms over the joint Jacobian (all dead after coop_evaluate).
+inline ikdev::PikCoopLayout bind_pik_coop_layout(const ProblemHost &ph) {
+    const GenericHost &g = ph.generic;
+    ikdev::PikCoopLayout K{};
+    K.P = g.c_P; K.Jb = g.c_A1; K.de = g.c_Jw; K.nrm = g.c_Jw + g.coop_mmax; K.words = g.coop_words_pik;
+    return K;
 }
 
 }  // namespace ikgpu

@@ -370,35 +370,6 @@ __global__ __launch_bounds__(kBlock) void pik_generic_kernel(const ikdev::PikKer
 
 }  // namespace
 
-// ik::pik (reference ik/ik/pik.cpp:31-103) on the generic lane program; `gen` is the problem's generic analysis.
-hipError_t launch_pik_generic(const ProblemHost &gen, const DeviceTables &dt, const BatchIO &io, const ikgpu_pik_params &prm,
-                              hipStream_t stream) {
-    ikdev::PikKernelArgs a{};
-    a.T = bind_generic_tables(gen, dt.g_ints, dt.g_dbls);
-    a.prm.max_iterations = prm.max_iterations;
-    a.prm.step_length = prm.step_length;
-    a.prm.stop_sq_tol = prm.stop_sq_tol;
-    for (int l = 0; l < ikdev::kMaxPikLevels; ++l) a.prm.lam2[l] = l < prm.num_levels ? prm.lambda[l] * prm.lambda[l] : 1.0;
-    a.prm.has_da = 0;
-    if (prm.da)
-        for (int k = 0; k < gen.nv; ++k) {
-            a.prm.da[k] = prm.da[k];
-            if (prm.da[k] != 0.0) a.prm.has_da = 1;
-        }
-    a.layout = io.layout; a.B = io.B; a.q0 = io.q0; a.targets = io.targets;
-    a.q_out = io.q_out; a.success = io.success; a.iters = io.iters;
-    a.ws_stride = (io.B + kBlock - 1) / kBlock * kBlock;
-    const size_t bytes = sizeof(double) * static_cast<size_t>(gen.generic.ws_words_pik) * static_cast<size_t>(a.ws_stride);
-    void *ws = nullptr;
-    hipError_t e = hipMallocAsync(&ws, bytes, stream);
-    if (e != hipSuccess) return e;
-    a.ws = static_cast<double *>(ws);
-    hipLaunchKernelGGL(pik_generic_kernel, grid_for(io.B), dim3(kBlock), 0, stream, a);
-    e = hipGetLastError();
-    const hipError_t f = hipFreeAsync(ws, stream);
-    return e != hipSuccess ? e : f;
-}
-
 namespace {
 
 // Cooperative form: 16 lanes per problem, 4 problems per 64-lane workgroup, the workspace in (dynamic) LDS.
@@ -411,27 +382,40 @@ struct CoopStaging {  // the problem's packed tables in HBM, copied to LDS by ev
 template <class P>
 __device__ __forceinline__ void rebase(const P *&p, const P *from, const P *to) { p = to + (p - from); }
 
-__global__ __launch_bounds__(kBlock) void dls_coop_kernel(ikdev::CoopKernelArgs a, const CoopStaging s) {
-    extern __shared__ double coop_lds[];
-    // LDS: [double tables | int tables | four workspaces]; a table read inside the phases is then an LDS read, not an
-    // L2 round trip (73 global loads per iteration otherwise, each a dependent ~1 us stall with so few waves per CU)
-    double *ld = coop_lds;
-    int32_t *li = reinterpret_cast<int32_t *>(coop_lds + s.n_dbls);
-    double *ws0 = coop_lds + s.n_dbls + (s.n_ints + 1) / 2;
+// LDS of a cooperative workgroup: [double tables | int tables | one workspace per problem].  Copies the tables in, points
+// the table pointers of T and L at the copies and returns the first workspace: a table read inside the phases is then an LDS
+// read, not an L2 round trip (73 global loads per iteration otherwise, each a dependent ~1 us stall with so few waves per CU).
+__device__ __forceinline__ double *coop_stage(double *lds, ikdev::GenericTables &T, ikdev::CoopLayout &L, const CoopStaging &s) {
+    double *ld = lds;
+    int32_t *li = reinterpret_cast<int32_t *>(lds + s.n_dbls);
     for (int i = threadIdx.x; i < s.n_dbls; i += blockDim.x) ld[i] = s.dbls[i];
     for (int i = threadIdx.x; i < s.n_ints; i += blockDim.x) li[i] = s.ints[i];
     __syncthreads();
-    ikdev::GenericTables &T = a.T;
     rebase(T.jtype, s.ints, li); rebase(T.parent, s.ints, li); rebase(T.idx_q, s.ints, li); rebase(T.idx_v, s.ints, li);
     rebase(T.t_type, s.ints, li); rebase(T.t_fjoint, s.ints, li); rebase(T.t_rjoint, s.ints, li); rebase(T.t_row, s.ints, li);
     rebase(T.t_dim, s.ints, li); rebase(T.t_prio, s.ints, li); rebase(T.lvl_row0, s.ints, li);
     rebase(T.placement, s.dbls, ld); rebase(T.axis, s.dbls, ld); rebase(T.lower, s.dbls, ld); rebase(T.upper, s.dbls, ld);
     rebase(T.t_fpl, s.dbls, ld); rebase(T.t_rpl, s.dbls, ld); rebase(T.t_w, s.dbls, ld);
-    rebase(a.L.support, s.ints, li); rebase(a.L.pair_i, s.ints, li); rebase(a.L.pair_j, s.ints, li); rebase(a.L.order, s.ints, li); rebase(a.L.lvl_start, s.ints, li);
-    rebase(a.L.tb_index, s.ints, li);
+    rebase(L.support, s.ints, li); rebase(L.pair_i, s.ints, li); rebase(L.pair_j, s.ints, li); rebase(L.order, s.ints, li);
+    rebase(L.lvl_start, s.ints, li); rebase(L.tb_index, s.ints, li);
+    return lds + s.n_dbls + (s.n_ints + 1) / 2;
+}
+
+__global__ __launch_bounds__(kBlock) void dls_coop_kernel(ikdev::CoopKernelArgs a, const CoopStaging s) {
+    extern __shared__ double coop_lds[];
+    double *ws0 = coop_stage(coop_lds, a.T, a.L, s);
     const int grp = threadIdx.x / ikdev::kCoopGroup, g = threadIdx.x % ikdev::kCoopGroup;
     const int per_block = blockDim.x / ikdev::kCoopGroup;
     ikdev::dls_coop_body(a, static_cast<int64_t>(blockIdx.x) * per_block + grp, g, ws0 + grp * a.L.words,
+                         [](bool act) { return __any(act) != 0; });
+}
+
+__global__ __launch_bounds__(kBlock) void pik_coop_kernel(ikdev::PikCoopKernelArgs a, const CoopStaging s) {
+    extern __shared__ double coop_lds[];
+    double *ws0 = coop_stage(coop_lds, a.T, a.L, s);
+    const int grp = threadIdx.x / ikdev::kCoopGroup, g = threadIdx.x % ikdev::kCoopGroup;
+    const int per_block = blockDim.x / ikdev::kCoopGroup;
+    ikdev::pik_coop_body(a, static_cast<int64_t>(blockIdx.x) * per_block + grp, g, ws0 + grp * a.K.words,
                          [](bool act) { return __any(act) != 0; });
 }
 
@@ -446,6 +430,62 @@ extern "C" int ikgpu_debug_coop_profile(long long *out16, int reset) {
     return 0;
 }
 #endif
+
+// ik::pik (reference ik/ik/pik.cpp:31-103) on the generic lane program; `gen` is the problem's generic analysis.
+bool pik_runs_cooperative(const ProblemHost &gen, const ikgpu_pik_params &prm) {
+    if (!gen.generic.coop_pik_ok) return false;
+    for (int l = 0; l < prm.num_levels; ++l)
+        if (!(prm.lambda[l] > 0.0)) return false;  // the cooperative form solves (Jbar Jbar^T + lambda^2 I) by Cholesky
+    const char *force = std::getenv("IKGPU_GENERIC_KERNEL");
+    return !(force && std::string(force) == "lane");
+}
+
+hipError_t launch_pik_generic(const ProblemHost &gen, const DeviceTables &dt, const BatchIO &io, const ikgpu_pik_params &prm,
+                              hipStream_t stream) {
+    ikdev::PikParams pp{};
+    pp.max_iterations = prm.max_iterations;
+    pp.step_length = prm.step_length;
+    pp.stop_sq_tol = prm.stop_sq_tol;
+    for (int l = 0; l < ikdev::kMaxPikLevels; ++l) pp.lam2[l] = l < prm.num_levels ? prm.lambda[l] * prm.lambda[l] : 1.0;
+    pp.has_da = 0;
+    if (prm.da)
+        for (int k = 0; k < gen.nv; ++k) {
+            pp.da[k] = prm.da[k];
+            if (prm.da[k] != 0.0) pp.has_da = 1;
+        }
+    if (pik_runs_cooperative(gen, prm)) {
+        ikdev::PikCoopKernelArgs c{};
+        c.T = bind_generic_tables(gen, dt.g_ints, dt.g_dbls);
+        c.L = bind_coop_layout(gen, dt.g_ints);
+        c.K = bind_pik_coop_layout(gen);
+        c.prm = pp;
+        c.layout = io.layout; c.B = io.B; c.q0 = io.q0; c.targets = io.targets;
+        c.q_out = io.q_out; c.success = io.success; c.iters = io.iters;
+        const CoopStaging s{dt.g_ints, dt.g_dbls, static_cast<int>(gen.generic.ints.size()), static_cast<int>(gen.generic.dbls.size())};
+        const int per_block = ikdev::kCoopPerBlock;
+        const size_t lds = sizeof(double) * (static_cast<size_t>(per_block) * static_cast<size_t>(c.K.words) +
+                                             static_cast<size_t>(s.n_dbls) + static_cast<size_t>((s.n_ints + 1) / 2));
+        const int64_t blocks = (io.B + per_block - 1) / per_block;
+        hipLaunchKernelGGL(pik_coop_kernel, dim3(static_cast<unsigned>(blocks)), dim3(per_block * ikdev::kCoopGroup), lds, stream, c, s);
+        return hipGetLastError();
+    }
+    ikdev::PikKernelArgs a{};
+    a.T = bind_generic_tables(gen, dt.g_ints, dt.g_dbls);
+    a.prm = pp;
+    a.layout = io.layout; a.B = io.B; a.q0 = io.q0; a.targets = io.targets;
+    a.q_out = io.q_out; a.success = io.success; a.iters = io.iters;
+    a.ws_stride = (io.B + kBlock - 1) / kBlock * kBlock;
+    const size_t bytes = sizeof(double) * static_cast<size_t>(gen.generic.ws_words_pik) * static_cast<size_t>(a.ws_stride);
+    void *ws = nullptr;
+    hipError_t e = hipMallocAsync(&ws, bytes, stream);
+    if (e != hipSuccess) return e;
+    a.ws = static_cast<double *>(ws);
+    hipLaunchKernelGGL(pik_generic_kernel, grid_for(io.B), dim3(kBlock), 0, stream, a);
+    e = hipGetLastError();
+    const hipError_t f = hipFreeAsync(ws, stream);
+    return e != hipSuccess ? e : f;
+}
+
 
 bool generic_runs_cooperative(const ProblemHost &ph) {
     if (!ph.generic.coop_ok) return false;

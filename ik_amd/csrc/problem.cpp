@@ -221,8 +221,14 @@ void build_coop(ProblemHost &ph, const Model &m) {
     int o = 0;
     g.c_q = o; o += m.nq;
     g.c_tg = o; o += 12 * nt;
-    g.c_A1 = o; o += 12 * nj;
-    g.c_Jw = o; o += 6 * nv;
+    int mmax = 0;  // rows of the largest priority level: the prioritised solver parks that level's projected Jacobian where the
+    {              // joint placements lived (dead once the task Jacobian is built) and two short vectors over the joint Jacobian
+        std::vector<int> lvl(static_cast<size_t>(g.nlevels), 0);
+        for (int t = 0; t < nt; ++t) lvl[ph.tasks[t].priority] += task_dim(ph.tasks[t]);
+        for (int x : lvl) mmax = std::max(mmax, x);
+    }
+    g.c_A1 = o; o += std::max(12 * nj, mmax * nv);
+    g.c_Jw = o; o += std::max(6 * nv, 2 * mmax);
     g.c_e = o; o += M;
     g.c_dq = o; o += nv;
     g.c_A0 = o; g.c_J = o; o += std::max(12 * nj, M * nv);
@@ -231,7 +237,13 @@ void build_coop(ProblemHost &ph, const Model &m) {
     g.c_x = g.c_dinv + M;
     o += std::max(36 * nblocks, (M + 1) * (M + 2) / 2 + 2 * M);
     g.coop_words = o + (o % 2 == 0 ? 1 : 0);  // odd stride between the groups of a block
+    g.c_P = g.coop_words;  // ik::pik: the projector follows the DLS workspace
+    g.coop_words_pik = g.coop_words + nv * nv;
+    g.coop_words_pik += (g.coop_words_pik % 2 == 0 ? 1 : 0);
+    g.coop_mmax = mmax;
     // one 64-lane block holds the packed tables and four workspaces; 64 KB of LDS per block keeps at least two blocks on a CU
+    const size_t lds_pik = 8 * (4 * static_cast<size_t>(g.coop_words_pik) + g.dbls.size() + (g.ints.size() + 1) / 2);
+    g.coop_pik_ok = (!g.has_com && lds_pik <= 64 * 1024) ? 1 : 0;
     const size_t lds_bytes = 8 * (4 * static_cast<size_t>(g.coop_words) + g.dbls.size() + (g.ints.size() + 1) / 2);
     g.coop_ok = (ph.constraints.empty() && !g.has_com && lds_bytes <= 64 * 1024) ? 1 : 0;
 }

@@ -198,6 +198,38 @@ int lane_emu_dls_coop(const char *urdf, size_t len, int root_joint, const ikgpu_
     }
 }
 
+// ik::pik through the cooperative program (device/pik_coop.hpp).  Returns 2 when the problem has no cooperative form.
+int lane_emu_pik_coop(const char *urdf, size_t len, int root_joint, const ikgpu_task *tasks, int ntasks, int64_t B, const double *q0,
+                      const double *targets, const ikgpu_pik_params *prm, double *q_out, uint8_t *success, int32_t *iters, int layout) {
+    try {
+        ikgpu::Model m = ikgpu::Model::from_urdf(urdf, len, (root_joint & 1) != 0);
+        const ikgpu::ProblemHost ph = ikgpu::analyse_problem(m, tasks, ntasks, /*force_generic=*/true);
+        if (prm->num_levels != ph.generic.nlevels) { g_err = "num_levels does not match the task table"; return 1; }
+        if (!ph.generic.coop_pik_ok) { g_err = "no cooperative form for this problem"; return 2; }
+        ikdev::PikCoopKernelArgs a{};
+        a.T = ikgpu::bind_generic_tables(ph, ph.generic.ints.data(), ph.generic.dbls.data());
+        a.L = ikgpu::bind_coop_layout(ph, ph.generic.ints.data());
+        a.K = ikgpu::bind_pik_coop_layout(ph);
+        a.prm.max_iterations = prm->max_iterations;
+        a.prm.step_length = prm->step_length;
+        a.prm.stop_sq_tol = prm->stop_sq_tol;
+        for (int l = 0; l < ikdev::kMaxPikLevels; ++l) a.prm.lam2[l] = l < prm->num_levels ? prm->lambda[l] * prm->lambda[l] : 1.0;
+        if (prm->da)
+            for (int k = 0; k < ph.nv; ++k) {
+                a.prm.da[k] = prm->da[k];
+                if (prm->da[k] != 0.0) a.prm.has_da = 1;
+            }
+        a.layout = layout; a.B = B; a.q0 = q0; a.targets = targets;
+        a.q_out = q_out; a.success = success; a.iters = iters;
+        std::vector<double> ws(static_cast<size_t>(a.K.words), 0.0);
+        for (int64_t b = 0; b < B; ++b) ikdev::pik_coop_body(a, b, 0, ws.data(), [](bool act) { return act; });
+        return 0;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return 1;
+    }
+}
+
 // ik::dls with ik::FrameConstraint entries (reference ik/ik/dls.cpp:26-34,43-53) through the generic lane program.
 int lane_emu_dls_constrained(const char *urdf, size_t len, int root_joint, const ikgpu_task *tasks, int ntasks, const ikgpu_task *cons,
                              int ncons, int64_t B, const double *q0, const double *targets, const ikgpu_dls_params *prm, double *q_out,

@@ -74,6 +74,36 @@ def test_pik_kernel_matches_oracle(torch_cuda, case):
     assert np.array_equal(Qh, Qa.cpu().numpy()) and np.array_equal(okh, oka.cpu().numpy()) and np.array_equal(ith, ita.cpu().numpy())
 
 
+@pytest.mark.parametrize("case", ["ur5_pos_then_ori", "fixed_two_feet", "feet_then_pelvis"])
+def test_cooperative_and_per_lane_pik_kernels_agree(torch_cuda, case, monkeypatch):
+    """ik::pik has two device forms: cooperative and LDS-resident (device/pik_coop.hpp, the default when the workspace fits and
+    every lambda > 0) and per-lane with the workspace in HBM (device/pik_solver.hpp; IKGPU_GENERIC_KERNEL=lane, lambda = 0)."""
+    torch = torch_cuda
+    name, ff, specs, edit, projector_determined = PIK_CASES[case]
+    B = 1003
+    ik_amd, O, model, problem, _, om, ot, q0, tg = build(name, ff, specs, B, seed=7, xml_edit=edit)
+    levels = problem.max_priority_level() + 1
+    Q0 = torch.from_numpy(np.ascontiguousarray(q0.T)).cuda()
+    T = torch.from_numpy(np.ascontiguousarray(tg.transpose(1, 2, 0))).cuda()
+    for iters, step, tol, lam in ((1, 1.0, -1.0, [1.0] * levels), (5, 1.0, -1.0, [0.1] * levels), (40, 0.5, 1e-8, [0.05, 0.2][:levels])):
+        data = _pik_data(ik_amd, problem, lam)
+        p, v = ik_amd.pik_parameters(max_iterations=iters, step_length=step), ik_amd.inverse_kinematics_visitor(tol)
+        monkeypatch.delenv("IKGPU_GENERIC_KERNEL", raising=False)
+        Qc, okc, itc = ik_amd.pik_batch(problem, Q0, T, data, v, p)
+        Qc2, _, _ = ik_amd.pik_batch(problem, Q0, T, data, v, p)
+        assert torch.equal(Qc, Qc2)                                   # run-to-run bit-identical
+        monkeypatch.setenv("IKGPU_GENERIC_KERNEL", "lane")
+        Ql, okl, itl = ik_amd.pik_batch(problem, Q0, T, data, v, p)
+        assert torch.equal(okc, okl) and torch.equal(itc, itl), (case, iters)
+        d = (Qc - Ql).abs().amax(dim=0)
+        assert (d <= 1e-7).double().mean().item() >= 0.995, (case, iters, d.max().item())
+    # lambda = 0 is the per-lane program's (the cooperative one factors Jbar Jbar^T + lambda^2 I): same entry point, finite result
+    monkeypatch.delenv("IKGPU_GENERIC_KERNEL", raising=False)
+    data = _pik_data(ik_amd, problem, [0.0] * levels)
+    Qz, _, _ = ik_amd.pik_batch(problem, Q0, T, data, ik_amd.never_stop_visitor(), ik_amd.pik_parameters(max_iterations=2, step_length=0.5))
+    assert torch.isfinite(Qz).double().mean().item() > 0.99
+
+
 def test_pik_with_one_level_is_dls_with_damping_lambda(torch_cuda):
     """One priority level: pik's step is -J^T (J J^T + lambda^2 I)^-1 e, i.e. ik::dls with damping = lambda -- here the
     register-resident DLS kernel and the generic PIK kernel, on the same problem handle."""

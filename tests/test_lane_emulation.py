@@ -21,7 +21,7 @@ def emu(native_built):
     deps = [src] + [os.path.join(ROOT, "ik_amd", "csrc", f) for f in
                     ("model.cpp", "problem.cpp", "model.hpp", "problem.hpp", "device/lane_math.hpp",
                      "device/chain_solver.hpp", "device/chain_kernel_body.hpp", "device/tree_solver.hpp",
-                     "device/tree_kernel_body.hpp", "device/generic_solver.hpp", "device/pik_solver.hpp", "device/coop_solver.hpp", "generic_tables.hpp")]
+                     "device/tree_kernel_body.hpp", "device/generic_solver.hpp", "device/pik_solver.hpp", "device/coop_solver.hpp", "device/pik_coop.hpp", "generic_tables.hpp")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
                                "-I" + os.path.join(ROOT, "ik_amd", "csrc"), "-o", out, src,
