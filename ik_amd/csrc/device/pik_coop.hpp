@@ -104,6 +104,7 @@ IKD_FN void coop_pik(const GenericTables &T, const CoopLayout &L, const PikCoopL
                 IKC_SYNC();
                 int piv = k;
                 double best = ws[K.nrm + k];
+#pragma unroll 8
                 for (int i = k + 1; i < ml; ++i) {
                     const double n2 = ws[K.nrm + i];
                     if (n2 > best) { best = n2; piv = i; }
@@ -173,20 +174,22 @@ struct PikCoopKernelArgs {
     int32_t *iters;
 };
 
+// T, L: the tables the phases read (on the device: the copies staged in LDS, see kernels.hip; a.T / a.L otherwise).
 template <class AnyFn>
-IKD_FN void pik_coop_body(const PikCoopKernelArgs &a, int64_t problem, const int g, double *ws, AnyFn any_active) {
+IKD_FN void pik_coop_body(const PikCoopKernelArgs &a, const GenericTables &T, const CoopLayout &L, int64_t problem, const int g, double *ws,
+                          AnyFn any_active) {
     (void)g;
     const bool valid = problem < a.B;
     const int64_t b = valid ? problem : a.B - 1;
-    const int nq = a.T.nq, nslots = a.T.ntasks * 12;
-    IKC_FOR(i, nq) ws[a.L.q + i] = a.q0[at(a.layout, a.B, nq, i, b)];
-    IKC_FOR(i, nslots) ws[a.L.tg + i] = a.layout == LAYOUT_SOA ? a.targets[static_cast<int64_t>(i) * a.B + b] : a.targets[b * nslots + i];
+    const int nq = T.nq, nslots = T.ntasks * 12;
+    IKC_FOR(i, nq) ws[L.q + i] = a.q0[at(a.layout, a.B, nq, i, b)];
+    IKC_FOR(i, nslots) ws[L.tg + i] = a.layout == LAYOUT_SOA ? a.targets[static_cast<int64_t>(i) * a.B + b] : a.targets[b * nslots + i];
     IKC_SYNC();
     int iters;
     bool success;
-    coop_pik(a.T, a.L, a.K, a.prm, g, ws, iters, success, any_active);
+    coop_pik(T, L, a.K, a.prm, g, ws, iters, success, any_active);
     if (!valid) return;
-    IKC_FOR(i, nq) a.q_out[at(a.layout, a.B, nq, i, b)] = ws[a.L.q + i];
+    IKC_FOR(i, nq) a.q_out[at(a.layout, a.B, nq, i, b)] = ws[L.q + i];
     IKC_FOR(one, 1) {
         if (a.success) a.success[b] = success ? 1 : 0;
         if (a.iters) a.iters[b] = iters;

@@ -410,12 +410,16 @@ __global__ __launch_bounds__(kBlock) void dls_coop_kernel(ikdev::CoopKernelArgs 
                          [](bool act) { return __any(act) != 0; });
 }
 
-__global__ __launch_bounds__(kBlock) void pik_coop_kernel(ikdev::PikCoopKernelArgs a, const CoopStaging s) {
+__global__ __launch_bounds__(kBlock) void pik_coop_kernel(const ikdev::PikCoopKernelArgs a, const CoopStaging s) {
     extern __shared__ double coop_lds[];
-    double *ws0 = coop_stage(coop_lds, a.T, a.L, s);
+    // the arguments stay in the kernel-argument segment (they hold the 1 KB `da` array: a mutable copy would live in
+    // scratch memory, 1.3 KB per lane); only the two small table structs are copied, to be pointed at LDS
+    ikdev::GenericTables T = a.T;
+    ikdev::CoopLayout L = a.L;
+    double *ws0 = coop_stage(coop_lds, T, L, s);
     const int grp = threadIdx.x / ikdev::kCoopGroup, g = threadIdx.x % ikdev::kCoopGroup;
     const int per_block = blockDim.x / ikdev::kCoopGroup;
-    ikdev::pik_coop_body(a, static_cast<int64_t>(blockIdx.x) * per_block + grp, g, ws0 + grp * a.K.words,
+    ikdev::pik_coop_body(a, T, L, static_cast<int64_t>(blockIdx.x) * per_block + grp, g, ws0 + grp * a.K.words,
                          [](bool act) { return __any(act) != 0; });
 }
 

@@ -222,7 +222,7 @@ int lane_emu_pik_coop(const char *urdf, size_t len, int root_joint, const ikgpu_
         a.layout = layout; a.B = B; a.q0 = q0; a.targets = targets;
         a.q_out = q_out; a.success = success; a.iters = iters;
         std::vector<double> ws(static_cast<size_t>(a.K.words), 0.0);
-        for (int64_t b = 0; b < B; ++b) ikdev::pik_coop_body(a, b, 0, ws.data(), [](bool act) { return act; });
+        for (int64_t b = 0; b < B; ++b) ikdev::pik_coop_body(a, a.T, a.L, b, 0, ws.data(), [](bool act) { return act; });
         return 0;
     } catch (const std::exception &e) {
         g_err = e.what();
