@@ -58,12 +58,13 @@ __device__ long long g_coop_prof[16];
 #endif
 
 struct CoopLayout {
-    int q, tg, A0, A1, Jw, tb, e, J, G, dinv, x, dq, words;  // offsets into the group's workspace, in doubles
+    int q, tg, A0, A1, Jw, tb, e, J, G, dinv, x, dq, sf, words;  // offsets into the group's workspace, in doubles
     int rounds, npairs;
     const int *support;          // [ntasks][nv] 1 when the task's rows touch tangent column c
     const int *pair_i, *pair_j;  // [npairs]
     const int *order, *lvl_start;  // joints 1.. sorted by tree depth; first entry of each of the `rounds` levels (+ end)
     const int *tb_index;         // [ntasks] slot of the task's block in tb (-1: posture row, no block)
+    const int *col_joint;        // [nv] the joint a tangent column belongs to
 };
 
 // C = A * B on 12-double SE(3) values held in the workspace (A, B) -> registers (C)
@@ -137,6 +138,12 @@ IKD_FN double coop_evaluate(const GenericTables &T, const CoopLayout &L, const i
             const int iv = T.idx_v[j], jt = T.jtype[j];
             const double *a = T.axis + 3 * j;
             for (int k = 0; k < 12; ++k) oM[k] = ws[oMi + 12 * j + k];
+            if (T.has_com) {  // pinocchio::centerOfMass: first moment of the bodies on this joint
+                const double *cl = T.j_lever + 3 * j;
+                const double mj = T.j_mass[j];
+                for (int i = 0; i < 3; ++i)
+                    ws[L.sf + 3 * j + i] = mj * dfma(oM[3 * i], cl[0], dfma(oM[3 * i + 1], cl[1], dfma(oM[3 * i + 2], cl[2], oM[9 + i])));
+            }
             if (jt == GJ_REVOLUTE || jt == GJ_PRISMATIC) {
                 const double Ra[3] = {dfma(oM[0], a[0], dfma(oM[1], a[1], oM[2] * a[2])), dfma(oM[3], a[0], dfma(oM[4], a[1], oM[5] * a[2])),
                                       dfma(oM[6], a[0], dfma(oM[7], a[1], oM[8] * a[2]))};
@@ -164,6 +171,13 @@ IKD_FN double coop_evaluate(const GenericTables &T, const CoopLayout &L, const i
         }
         IKC_SYNC();
     }
+    if (T.has_com) {  // ... its backward pass: first moment of every subtree, one lane per component, joints in generic_evaluate's order
+        IKC_FOR(i, 3) {
+            ws[L.sf + i] = 0.0;
+            for (int j = nj - 1; j > 0; --j) ws[L.sf + 3 * T.parent[j] + i] += ws[L.sf + 3 * j + i];
+        }
+        IKC_SYNC();
+    }
     IKC_TICK(1);
     // ---- per task: frame placement, error, the blocks its Jacobian columns need (tb: Rf 9 | pf 3 | A 9 | B 9 | spare 6)
     IKC_FOR(t, nt) {
@@ -173,6 +187,16 @@ IKD_FN double coop_evaluate(const GenericTables &T, const CoopLayout &L, const i
         if (type == GT_POSTURE_ROW) {  // ik/ik/posture.hpp:51-68: the whole row is written here
             ws[L.e + row] = (ws[L.q + rj] - ws[L.tg + 12 * t + 9]) * w6[1] * w6[0];
             for (int c = 0; c < nv; ++c) ws[L.J + row * nv + c] = (c == fj) ? w6[0] : 0.0;
+            continue;
+        }
+        if (type == GT_COM) {  // ik::CentreOfMassTask, ik/ik/centre_of_mass.hpp:33-45: tb = placement of the reference frame
+            double oMr[12];
+            coop_se3_mul_ws(ws + oMi + 12 * rj, T.t_rpl + 12 * t, oMr);
+            for (int k = 0; k < 12; ++k) tb[k] = oMr[k];
+            const double d[3] = {dfma(ws[L.sf], T.inv_total_mass, -oMr[9]), dfma(ws[L.sf + 1], T.inv_total_mass, -oMr[10]),
+                                 dfma(ws[L.sf + 2], T.inv_total_mass, -oMr[11])};
+            for (int r = 0; r < 3; ++r)
+                ws[L.e + row + r] = (dfma(oMr[r], d[0], dfma(oMr[3 + r], d[1], oMr[6 + r] * d[2])) - ws[L.tg + 12 * t + 9 + r]) * w6[r];
             continue;
         }
         double oMf[12], oMr[12], tg[12];
@@ -221,6 +245,21 @@ IKD_FN double coop_evaluate(const GenericTables &T, const CoopLayout &L, const i
         for (int t = 0; t < nt; ++t) {
             const int type = T.t_type[t], row = T.t_row[t], dim = T.t_dim[t];
             if (type == GT_POSTURE_ROW) continue;
+            if (type == GT_COM) {  // jacobianCenterOfMass, ik/ik/data.cpp:31-34: every column, scaled by the mass of its joint's subtree
+                const double *w6 = T.t_w + 6 * t;
+                const double *tb = ws + L.tb + 36 * L.tb_index[t];
+                const int j = L.col_joint[c];
+                const double ms = T.j_submass[j];
+                const double f[3] = {ws[L.sf + 3 * j], ws[L.sf + 3 * j + 1], ws[L.sf + 3 * j + 2]};
+                const double w[3] = {vw[3], vw[4], vw[5]};
+                double fxw[3];
+                cross(f, w, fxw);
+                const double col[3] = {(ms * vw[0] - fxw[0]) * T.inv_total_mass, (ms * vw[1] - fxw[1]) * T.inv_total_mass,
+                                       (ms * vw[2] - fxw[2]) * T.inv_total_mass};
+                for (int r = 0; r < 3; ++r)
+                    ws[L.J + (row + r) * nv + c] = w6[r] * dfma(tb[r], col[0], dfma(tb[3 + r], col[1], tb[6 + r] * col[2]));
+                continue;
+            }
             if (!L.support[t * nv + c]) {
                 for (int r = 0; r < dim; ++r) ws[L.J + (row + r) * nv + c] = 0.0;
                 continue;

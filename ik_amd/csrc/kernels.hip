@@ -397,7 +397,8 @@ __device__ __forceinline__ double *coop_stage(double *lds, ikdev::GenericTables 
     rebase(T.placement, s.dbls, ld); rebase(T.axis, s.dbls, ld); rebase(T.lower, s.dbls, ld); rebase(T.upper, s.dbls, ld);
     rebase(T.t_fpl, s.dbls, ld); rebase(T.t_rpl, s.dbls, ld); rebase(T.t_w, s.dbls, ld);
     rebase(L.support, s.ints, li); rebase(L.pair_i, s.ints, li); rebase(L.pair_j, s.ints, li); rebase(L.order, s.ints, li);
-    rebase(L.lvl_start, s.ints, li); rebase(L.tb_index, s.ints, li);
+    rebase(L.lvl_start, s.ints, li); rebase(L.tb_index, s.ints, li); rebase(L.col_joint, s.ints, li);
+    rebase(T.j_mass, s.dbls, ld); rebase(T.j_lever, s.dbls, ld); rebase(T.j_submass, s.dbls, ld);
     return lds + s.n_dbls + (s.n_ints + 1) / 2;
 }
 

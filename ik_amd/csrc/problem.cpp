@@ -195,6 +195,10 @@ void build_coop(ProblemHost &ph, const Model &m) {
     for (int t = 0; t < nt; ++t)
         if (ph.tasks[t].type != IKGPU_POSTURE_ROW) tbi[t] = nblocks++;
     g.o_ctbindex = put_i(tbi);
+    std::vector<int32_t> colj(nv, 0);
+    for (int j = 1; j < nj; ++j)
+        for (int c = m.joint_idx_v[j]; c < m.joint_idx_v[j] + (m.joint_type[j] == IKGPU_JOINT_FREEFLYER ? 6 : 1); ++c) colj[c] = j;
+    g.o_ccoljoint = put_i(colj);
     std::vector<int32_t> pi, pj;   // lower triangle of the (M + 1) x (M + 1) augmented matrix; row M carries the right-hand side
     for (int i = 0; i <= M; ++i)
         for (int j = 0; j <= i && j < M; ++j) { pi.push_back(i); pj.push_back(j); }
@@ -231,6 +235,7 @@ void build_coop(ProblemHost &ph, const Model &m) {
     g.c_Jw = o; o += std::max(6 * nv, 2 * mmax);
     g.c_e = o; o += M;
     g.c_dq = o; o += nv;
+    g.c_sf = o; o += g.has_com ? 3 * nj : 0;
     g.c_A0 = o; g.c_J = o; o += std::max(12 * nj, M * nv);
     g.c_tb = o; g.c_G = o;
     g.c_dinv = g.c_G + (M + 1) * (M + 2) / 2;
@@ -243,9 +248,9 @@ void build_coop(ProblemHost &ph, const Model &m) {
     g.coop_mmax = mmax;
     // one 64-lane block holds the packed tables and four workspaces; 64 KB of LDS per block keeps at least two blocks on a CU
     const size_t lds_pik = 8 * (4 * static_cast<size_t>(g.coop_words_pik) + g.dbls.size() + (g.ints.size() + 1) / 2);
-    g.coop_pik_ok = (!g.has_com && lds_pik <= 64 * 1024) ? 1 : 0;
+    g.coop_pik_ok = lds_pik <= 64 * 1024 ? 1 : 0;
     const size_t lds_bytes = 8 * (4 * static_cast<size_t>(g.coop_words) + g.dbls.size() + (g.ints.size() + 1) / 2);
-    g.coop_ok = (ph.constraints.empty() && !g.has_com && lds_bytes <= 64 * 1024) ? 1 : 0;
+    g.coop_ok = (ph.constraints.empty() && lds_bytes <= 64 * 1024) ? 1 : 0;
 }
 
 void build_generic(ProblemHost &ph, const Model &m) {

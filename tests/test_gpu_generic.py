@@ -170,7 +170,7 @@ def test_generic_kernel_matches_oracle(torch_cuda, case):
 
 
 @pytest.mark.parametrize("case", ["demo_with_direction_in_pelvis_frame", "fixed_two_feet_priorities", "shared_joints", "moving_reference_prismatic",
-                                  "three_feet_frames", "posture_regulariser", "posture_first_level"])
+                                  "three_feet_frames", "posture_regulariser", "posture_first_level", "com_under_feet", "com_of_the_arm"])
 def test_cooperative_and_per_lane_generic_kernels_agree(torch_cuda, case, monkeypatch):
     """The generic DLS kernel has two forms: the cooperative LDS-resident one (device/coop_solver.hpp, the default when
     the problem fits) and the per-lane memory-resident one (device/generic_solver.hpp; IKGPU_GENERIC_KERNEL=lane)."""

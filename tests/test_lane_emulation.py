@@ -452,7 +452,7 @@ def test_constrained_dls_program_matches_oracle(emu, case):
 # ---------------------------------------------------------------------------------------------------
 # the cooperative (16 lanes per problem, LDS-resident) form of the generic DLS program, device/coop_solver.hpp
 # ---------------------------------------------------------------------------------------------------
-COOP_CASES = [c for c in sorted(GENERIC_CASES) if not c.startswith("com_")]
+COOP_CASES = sorted(GENERIC_CASES)
 
 
 @pytest.mark.parametrize("case", COOP_CASES)
@@ -482,11 +482,11 @@ def test_cooperative_program_matches_oracle(emu, case):
     assert rc == 0 and np.array_equal(qs.T, qo) and np.array_equal(oks, ok) and np.array_equal(its, it)
 
 
-def test_cooperative_program_is_refused_for_centre_of_mass_tasks(emu):
+def test_cooperative_program_is_refused_when_four_workspaces_do_not_fit_the_lds_budget(emu):
     from ik_amd import capi
-    name, ff, specs, root, edit = GENERIC_CASES["com_of_the_arm"]
+    name, ff, specs, root, edit = GENERIC_CASES["posture_regulariser"]      # M = 28, nv = 22: 2 k doubles per problem
     urdf, model, om, tasks, ot, q0, tg, M = _generic_case(name, ff, specs, 4)
     p = lambda a: C.c_void_p(a.ctypes.data)
     prm = capi.DlsParams(1, 1e-2, 1.0, -1.0)
     qo, ok, it = np.empty_like(q0), np.zeros(4, np.uint8), np.zeros(4, np.int32)
-    assert emu.lane_emu_dls_coop(urdf, C.c_size_t(len(urdf)), 0, tasks, len(tasks), C.c_int64(4), p(q0), p(tg), C.byref(prm), p(qo), p(ok), p(it), 1) == 2
+    assert emu.lane_emu_dls_coop(urdf, C.c_size_t(len(urdf)), 1, tasks, len(tasks), C.c_int64(4), p(q0), p(tg), C.byref(prm), p(qo), p(ok), p(it), 1) == 2
