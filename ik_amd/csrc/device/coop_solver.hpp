@@ -59,6 +59,8 @@ __device__ long long g_coop_prof[16];
 
 struct CoopLayout {
     int q, tg, A0, A1, Jw, tb, e, J, G, dinv, x, dq, sf, words;  // offsets into the group's workspace, in doubles
+    int cb, Jc, cnrm;            // FrameConstraint projection: per-constraint placements (36 each), Jc (Mc x nv), Mc scratch words
+    const int *csupp_f, *csupp_r;  // [ncons][nv] 1 when tangent column c moves the constrained frame / its reference frame
     int rounds, npairs;
     const int *support;          // [ntasks][nv] 1 when the task's rows touch tangent column c
     const int *pair_i, *pair_j;  // [npairs]
@@ -341,6 +343,64 @@ IKD_FN void coop_chol_solve(const CoopLayout &L, const int g, double *ws, const 
     }
 }
 
+// Orthonormal basis of the row space of the m x nv matrix at offRows, in place (v_1 .. v_rank end up in its first rows):
+// Gram-Schmidt with row pivoting on the largest remaining norm, every projection applied twice.  The pivot norms are the
+// |R_kk| of Eigen's column-pivoted QR of the transpose -- what its complete orthogonal decomposition starts from -- and its
+// rank rule is applied to them: |R_kk| > eps min(m, nv) max|R| (reference: Jbar.completeOrthogonalDecomposition().pseudoInverse()
+// * Jbar, ik/ik/pik.cpp:59-61; Jc likewise, ik/ik/dls.cpp:45-48).  offNrm: m scratch words.  All trip counts are the same in
+// every group of the wave (the barriers sit outside anything that depends on the data); a group whose rank is exhausted keeps
+// walking with `live` false.  Ends on a barrier.
+IKD_FN int coop_rowspace_basis(const int g, double *ws, const int offRows, const int offNrm, const int m, const int nv) {
+    (void)g;
+    const double kk = 2.220446049250313e-16 * static_cast<double>(m < nv ? m : nv), thr2 = kk * kk;
+    int rank = 0;
+    bool live = true;
+    double maxpiv2 = 0.0;
+    for (int k = 0; k < m; ++k) {
+        IKC_FOR(ii, m - k) {
+            const int row = k + ii;
+            double n2 = 0.0;
+#pragma unroll 8
+            for (int c = 0; c < nv; ++c) { const double x = ws[offRows + row * nv + c]; n2 = dfma(x, x, n2); }
+            ws[offNrm + row] = n2;
+        }
+        IKC_SYNC();
+        int piv = k;
+        double best = ws[offNrm + k];
+#pragma unroll 8
+        for (int i = k + 1; i < m; ++i) {
+            const double n2 = ws[offNrm + i];
+            if (n2 > best) { best = n2; piv = i; }
+        }
+        if (k == 0) maxpiv2 = best;
+        live = live && best > thr2 * maxpiv2 && best > 0.0;   // Eigen's rank rule on |R_kk| = sqrt(best)
+        const double inv = live ? 1.0 / __builtin_sqrt(best) : 0.0;
+        IKC_FOR(c, nv) {
+            if (live) {
+                const double a = ws[offRows + piv * nv + c], b = ws[offRows + k * nv + c];
+                ws[offRows + piv * nv + c] = b;
+                ws[offRows + k * nv + c] = a * inv;
+            }
+        }
+        IKC_SYNC();
+        IKC_FOR(ii, m - k - 1) {
+            if (live) {
+                const int row = k + 1 + ii;
+                for (int pass = 0; pass < 2; ++pass) {
+                    double d = 0.0;
+#pragma unroll 8
+                    for (int c = 0; c < nv; ++c) d = dfma(ws[offRows + row * nv + c], ws[offRows + k * nv + c], d);
+#pragma unroll 8
+                    for (int c = 0; c < nv; ++c) ws[offRows + row * nv + c] = dfma(-d, ws[offRows + k * nv + c], ws[offRows + row * nv + c]);
+                }
+            }
+        }
+        IKC_SYNC();
+        if (live) ++rank;
+    }
+    return rank;
+}
+
 // q <- clip(integrate(q, step * dq)) (ik/ik/dls.cpp:67-71), one lane per joint; a group that is no longer active keeps its q.
 // Ends on a barrier.
 IKD_FN void coop_integrate(const GenericTables &T, const CoopLayout &L, const int g, double *ws, const double step_length, const bool active) {
@@ -404,6 +464,71 @@ IKD_FN void coop_dls(const GenericTables &T, const CoopLayout &L, const LoopPara
         }
         IKC_SYNC();
         IKC_TICK(7);
+        if (T.Mc > 0) {  // dq <- N dq, N = I - pinv(Jc) Jc: the step stays in the null space of the constraints (dls.cpp:26-34,43-53)
+            IKC_FOR(k, T.ncons) {  // placements of the constrained frame, its reference frame, and the one in the other
+                double oMf[12], oMr[12], fMr[12];
+                coop_se3_mul_ws(ws + L.A1 + 12 * T.c_fjoint[k], T.c_fpl + 12 * k, oMf);
+                coop_se3_mul_ws(ws + L.A1 + 12 * T.c_rjoint[k], T.c_rpl + 12 * k, oMr);
+                g_se3_inv_mul(oMf, oMr, fMr);
+                for (int i = 0; i < 12; ++i) { ws[L.cb + 36 * k + i] = oMf[i]; ws[L.cb + 36 * k + 12 + i] = oMr[i]; ws[L.cb + 36 * k + 24 + i] = fMr[i]; }
+            }
+            IKC_SYNC();
+            IKC_FOR(c, nv) {  // Jc = J_frame(LOCAL) - Ad(fMr) J_reference(LOCAL) (ik/ik/frame.hpp:413-449), one tangent column per lane
+                const double vw[6] = {ws[L.Jw + c], ws[L.Jw + nv + c], ws[L.Jw + 2 * nv + c],
+                                      ws[L.Jw + 3 * nv + c], ws[L.Jw + 4 * nv + c], ws[L.Jw + 5 * nv + c]};
+                const double w[3] = {vw[3], vw[4], vw[5]};
+                for (int k = 0; k < T.ncons; ++k) {
+                    const int row = T.c_row[k], dim = T.c_dim[k], r0 = (T.c_type[k] == GT_ORIENTATION) ? 3 : 0;
+                    const double *cb = ws + L.cb + 36 * k;
+                    double out[6] = {0, 0, 0, 0, 0, 0};
+                    if (L.csupp_f[k * nv + c]) {
+                        const double Rf[9] = {cb[0], cb[1], cb[2], cb[3], cb[4], cb[5], cb[6], cb[7], cb[8]};
+                        const double pf[3] = {cb[9], cb[10], cb[11]};
+                        double v[3] = {vw[0], vw[1], vw[2]}, pxw[3], vl[3], wl[3];
+                        cross(pf, w, pxw);
+                        v[0] -= pxw[0]; v[1] -= pxw[1]; v[2] -= pxw[2];
+                        rotT_vec(Rf, v, vl);
+                        rotT_vec(Rf, w, wl);
+                        out[0] = vl[0]; out[1] = vl[1]; out[2] = vl[2]; out[3] = wl[0]; out[4] = wl[1]; out[5] = wl[2];
+                    }
+                    if (L.csupp_r[k * nv + c]) {
+                        const double Rr[9] = {cb[12], cb[13], cb[14], cb[15], cb[16], cb[17], cb[18], cb[19], cb[20]};
+                        const double pr[3] = {cb[21], cb[22], cb[23]};
+                        const double px[3] = {cb[33], cb[34], cb[35]};
+                        double v[3] = {vw[0], vw[1], vw[2]}, pxw[3], vr[3], wr[3], Rv[3], Rw[3], pxRw[3];
+                        cross(pr, w, pxw);
+                        v[0] -= pxw[0]; v[1] -= pxw[1]; v[2] -= pxw[2];
+                        rotT_vec(Rr, v, vr);
+                        rotT_vec(Rr, w, wr);
+                        for (int i = 0; i < 3; ++i) {   // Ad(fMr) [v; w] = [R v + p x (R w); R w]
+                            Rv[i] = dfma(cb[24 + 3 * i], vr[0], dfma(cb[24 + 3 * i + 1], vr[1], cb[24 + 3 * i + 2] * vr[2]));
+                            Rw[i] = dfma(cb[24 + 3 * i], wr[0], dfma(cb[24 + 3 * i + 1], wr[1], cb[24 + 3 * i + 2] * wr[2]));
+                        }
+                        cross(px, Rw, pxRw);
+                        out[0] -= Rv[0] + pxRw[0]; out[1] -= Rv[1] + pxRw[1]; out[2] -= Rv[2] + pxRw[2];
+                        out[3] -= Rw[0]; out[4] -= Rw[1]; out[5] -= Rw[2];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 6; ++r)
+                        if (r >= r0 && r < r0 + dim) ws[L.Jc + (row + r - r0) * nv + c] = out[r];
+                }
+            }
+            IKC_SYNC();
+            const int rank = coop_rowspace_basis(g, ws, L.Jc, L.cnrm, T.Mc, nv);   // v_1 .. v_rank in the first rows of Jc
+            IKC_FOR(k, T.Mc) {
+                double d = 0.0;
+                if (k < rank)
+                    for (int c = 0; c < nv; ++c) d = dfma(ws[L.Jc + k * nv + c], ws[L.dq + c], d);
+                ws[L.cnrm + k] = d;
+            }
+            IKC_SYNC();
+            IKC_FOR(c, nv) {   // the v_k are orthonormal: dq -= sum_k v_k (v_k . dq)
+                double s = ws[L.dq + c];
+                for (int k = 0; k < T.Mc; ++k) s = dfma(-ws[L.cnrm + k], ws[L.Jc + k * nv + c], s);
+                ws[L.dq + c] = s;
+            }
+            IKC_SYNC();
+        }
         const bool stop_now = active && (prm.stop_sq_tol >= 0.0) && (e0sq < prm.stop_sq_tol);
         if (stop_now) { success = true; iters = it; }
         active = active && !stop_now;

@@ -33,7 +33,6 @@ IKD_FN void coop_pik(const GenericTables &T, const CoopLayout &L, const PikCoopL
                      int &iters_out, bool &success_out, AnyFn any_active) {
     (void)g;
     const int nv = T.nv;
-    const double eps = 2.220446049250313e-16;
     bool active = true, success = false;
     int iters = prm.max_iterations;
     int last_level = 0;
@@ -86,55 +85,7 @@ IKD_FN void coop_pik(const GenericTables &T, const CoopLayout &L, const PikCoopL
             }
             IKC_SYNC();
             if (!update_P) continue;
-            // orthonormal basis of the row space of Jbar, in place: pivoted Gram-Schmidt, every projection applied twice.
-            // All trip counts are the same in every group of the wave (the barriers sit outside anything that depends on the
-            // data); a group whose rank is exhausted keeps walking with `live` false.
-            const double kk = eps * static_cast<double>(ml < nv ? ml : nv), thr2 = kk * kk;
-            int rank = 0;
-            bool live = true;
-            double maxpiv2 = 0.0;
-            for (int k = 0; k < ml; ++k) {
-                IKC_FOR(ii, ml - k) {
-                    const int row = k + ii;
-                    double n2 = 0.0;
-#pragma unroll 8
-                    for (int c = 0; c < nv; ++c) { const double x = ws[K.Jb + row * nv + c]; n2 = dfma(x, x, n2); }
-                    ws[K.nrm + row] = n2;
-                }
-                IKC_SYNC();
-                int piv = k;
-                double best = ws[K.nrm + k];
-#pragma unroll 8
-                for (int i = k + 1; i < ml; ++i) {
-                    const double n2 = ws[K.nrm + i];
-                    if (n2 > best) { best = n2; piv = i; }
-                }
-                if (k == 0) maxpiv2 = best;
-                live = live && best > thr2 * maxpiv2 && best > 0.0;   // Eigen's rank rule on |R_kk| = sqrt(best)
-                const double inv = live ? 1.0 / __builtin_sqrt(best) : 0.0;
-                IKC_FOR(c, nv) {
-                    if (live) {
-                        const double a = ws[K.Jb + piv * nv + c], b = ws[K.Jb + k * nv + c];
-                        ws[K.Jb + piv * nv + c] = b;
-                        ws[K.Jb + k * nv + c] = a * inv;
-                    }
-                }
-                IKC_SYNC();
-                IKC_FOR(ii, ml - k - 1) {
-                    if (live) {
-                        const int row = k + 1 + ii;
-                        for (int pass = 0; pass < 2; ++pass) {
-                            double d = 0.0;
-#pragma unroll 8
-                            for (int c = 0; c < nv; ++c) d = dfma(ws[K.Jb + row * nv + c], ws[K.Jb + k * nv + c], d);
-#pragma unroll 8
-                            for (int c = 0; c < nv; ++c) ws[K.Jb + row * nv + c] = dfma(-d, ws[K.Jb + k * nv + c], ws[K.Jb + row * nv + c]);
-                        }
-                    }
-                }
-                IKC_SYNC();
-                if (live) ++rank;
-            }
+            const int rank = coop_rowspace_basis(g, ws, K.Jb, K.nrm, ml, nv);   // v_1 .. v_rank in the first rows of Jb
             IKC_FOR(idx, nv * nv) {   // P -= sum_{k < rank} v_k v_k^T
                 const int a = idx / nv, b = idx % nv;
                 double s = ws[K.P + idx];

@@ -36,9 +36,9 @@ inline ikdev::CoopLayout bind_coop_layout(const ProblemHost &ph, const int32_t *
     const GenericHost &g = ph.generic;
     ikdev::CoopLayout L{};
     L.q = g.c_q; L.tg = g.c_tg; L.A0 = g.c_A0; L.A1 = g.c_A1; L.Jw = g.c_Jw; L.tb = g.c_tb; L.e = g.c_e; L.J = g.c_J; L.G = g.c_G;
-    L.dinv = g.c_dinv; L.x = g.c_x; L.dq = g.c_dq; L.sf = g.c_sf; L.words = g.coop_words;
+    L.dinv = g.c_dinv; L.x = g.c_x; L.dq = g.c_dq; L.sf = g.c_sf; L.cb = g.c_cb; L.Jc = g.c_Jc; L.cnrm = g.c_cnrm; L.words = g.coop_words;
     L.rounds = g.coop_rounds; L.npairs = g.coop_npairs;
-    L.support = ibase + g.o_csupport; L.pair_i = ibase + g.o_cpair_i; L.pair_j = ibase + g.o_cpair_j; L.order = ibase + g.o_cup; L.lvl_start = ibase + g.o_clvl; L.tb_index = ibase + g.o_ctbindex; L.col_joint = ibase + g.o_ccoljoint;
+    L.support = ibase + g.o_csupport; L.pair_i = ibase + g.o_cpair_i; L.pair_j = ibase + g.o_cpair_j; L.order = ibase + g.o_cup; L.lvl_start = ibase + g.o_clvl; L.tb_index = ibase + g.o_ctbindex; L.col_joint = ibase + g.o_ccoljoint; L.csupp_f = ibase + g.o_ccsf; L.csupp_r = ibase + g.o_ccsr;
     return L;
 }
 

@@ -399,6 +399,9 @@ __device__ __forceinline__ double *coop_stage(double *lds, ikdev::GenericTables 
     rebase(L.support, s.ints, li); rebase(L.pair_i, s.ints, li); rebase(L.pair_j, s.ints, li); rebase(L.order, s.ints, li);
     rebase(L.lvl_start, s.ints, li); rebase(L.tb_index, s.ints, li); rebase(L.col_joint, s.ints, li);
     rebase(T.j_mass, s.dbls, ld); rebase(T.j_lever, s.dbls, ld); rebase(T.j_submass, s.dbls, ld);
+    rebase(T.c_type, s.ints, li); rebase(T.c_fjoint, s.ints, li); rebase(T.c_rjoint, s.ints, li); rebase(T.c_row, s.ints, li);
+    rebase(T.c_dim, s.ints, li); rebase(T.c_fpl, s.dbls, ld); rebase(T.c_rpl, s.dbls, ld);
+    rebase(L.csupp_f, s.ints, li); rebase(L.csupp_r, s.ints, li);
     return lds + s.n_dbls + (s.n_ints + 1) / 2;
 }
 

@@ -195,6 +195,20 @@ void build_coop(ProblemHost &ph, const Model &m) {
     for (int t = 0; t < nt; ++t)
         if (ph.tasks[t].type != IKGPU_POSTURE_ROW) tbi[t] = nblocks++;
     g.o_ctbindex = put_i(tbi);
+    // FrameConstraint rows: which tangent columns move the constrained frame, which its reference frame
+    const int ncons = static_cast<int>(ph.constraints.size());
+    std::vector<int32_t> csf(static_cast<size_t>(ncons) * nv, 0), csr(static_cast<size_t>(ncons) * nv, 0);
+    for (int k = 0; k < ncons; ++k)
+        for (int side = 0; side < 2; ++side) {
+            std::vector<int32_t> &mask = side == 0 ? csf : csr;
+            const int frame = side == 0 ? ph.constraints[k].frame : ph.constraints[k].reference;
+            for (int j = m.frame_parent[frame]; j > 0; j = m.joint_parent[j]) {
+                const int n = m.joint_type[j] == IKGPU_JOINT_FREEFLYER ? 6 : 1;
+                for (int c = m.joint_idx_v[j]; c < m.joint_idx_v[j] + n; ++c) mask[static_cast<size_t>(k) * nv + c] = 1;
+            }
+        }
+    g.o_ccsf = put_i(csf);
+    g.o_ccsr = put_i(csr);
     std::vector<int32_t> colj(nv, 0);
     for (int j = 1; j < nj; ++j)
         for (int c = m.joint_idx_v[j]; c < m.joint_idx_v[j] + (m.joint_type[j] == IKGPU_JOINT_FREEFLYER ? 6 : 1); ++c) colj[c] = j;
@@ -233,14 +247,15 @@ void build_coop(ProblemHost &ph, const Model &m) {
     }
     g.c_A1 = o; o += std::max(12 * nj, mmax * nv);
     g.c_Jw = o; o += std::max(6 * nv, 2 * mmax);
-    g.c_e = o; o += M;
+    const int Mc = ph.crows;
+    g.c_e = o; g.c_cnrm = o; o += std::max(M, Mc);   // (the constraint projection runs after the error vector is dead)
     g.c_dq = o; o += nv;
     g.c_sf = o; o += g.has_com ? 3 * nj : 0;
-    g.c_A0 = o; g.c_J = o; o += std::max(12 * nj, M * nv);
-    g.c_tb = o; g.c_G = o;
+    g.c_A0 = o; g.c_J = o; g.c_Jc = o; o += std::max(std::max(12 * nj, M * nv), Mc * nv);   // (and after the task Jacobian is)
+    g.c_tb = o; g.c_G = o; g.c_cb = o;
     g.c_dinv = g.c_G + (M + 1) * (M + 2) / 2;
     g.c_x = g.c_dinv + M;
-    o += std::max(36 * nblocks, (M + 1) * (M + 2) / 2 + 2 * M);
+    o += std::max(std::max(36 * nblocks, (M + 1) * (M + 2) / 2 + 2 * M), 36 * ncons);
     g.coop_words = o + (o % 2 == 0 ? 1 : 0);  // odd stride between the groups of a block
     g.c_P = g.coop_words;  // ik::pik: the projector follows the DLS workspace
     g.coop_words_pik = g.coop_words + nv * nv;
@@ -250,7 +265,7 @@ void build_coop(ProblemHost &ph, const Model &m) {
     const size_t lds_pik = 8 * (4 * static_cast<size_t>(g.coop_words_pik) + g.dbls.size() + (g.ints.size() + 1) / 2);
     g.coop_pik_ok = lds_pik <= 64 * 1024 ? 1 : 0;
     const size_t lds_bytes = 8 * (4 * static_cast<size_t>(g.coop_words) + g.dbls.size() + (g.ints.size() + 1) / 2);
-    g.coop_ok = (ph.constraints.empty() && lds_bytes <= 64 * 1024) ? 1 : 0;
+    g.coop_ok = lds_bytes <= 64 * 1024 ? 1 : 0;
 }
 
 void build_generic(ProblemHost &ph, const Model &m) {

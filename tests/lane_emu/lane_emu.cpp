@@ -174,11 +174,22 @@ int lane_emu_run(const char *urdf, size_t len, int root_joint, const ikgpu_task 
 
 // ik::dls through the cooperative program (device/coop_solver.hpp): one host "lane" takes every item of each phase.
 // Returns 2 when the problem has no cooperative form (constraints, centre-of-mass task, workspace too large for LDS).
+int lane_emu_dls_coop_constrained(const char *urdf, size_t len, int root_joint, const ikgpu_task *tasks, int ntasks, const ikgpu_task *cons,
+                                  int ncons, int64_t B, const double *q0, const double *targets, const ikgpu_dls_params *prm, double *q_out,
+                                  uint8_t *success, int32_t *iters, int layout);
+
 int lane_emu_dls_coop(const char *urdf, size_t len, int root_joint, const ikgpu_task *tasks, int ntasks, int64_t B, const double *q0,
                       const double *targets, const ikgpu_dls_params *prm, double *q_out, uint8_t *success, int32_t *iters, int layout) {
+    return lane_emu_dls_coop_constrained(urdf, len, root_joint, tasks, ntasks, nullptr, 0, B, q0, targets, prm, q_out, success, iters, layout);
+}
+
+// ... with ik::FrameConstraint entries (the step projected into the null space of their Jacobian)
+int lane_emu_dls_coop_constrained(const char *urdf, size_t len, int root_joint, const ikgpu_task *tasks, int ntasks, const ikgpu_task *cons,
+                                  int ncons, int64_t B, const double *q0, const double *targets, const ikgpu_dls_params *prm, double *q_out,
+                                  uint8_t *success, int32_t *iters, int layout) {
     try {
         ikgpu::Model m = ikgpu::Model::from_urdf(urdf, len, (root_joint & 1) != 0);
-        const ikgpu::ProblemHost ph = ikgpu::analyse_problem(m, tasks, ntasks, /*force_generic=*/true);
+        const ikgpu::ProblemHost ph = ikgpu::analyse_problem(m, tasks, ntasks, /*force_generic=*/true, cons, ncons);
         if (!ph.generic.coop_ok) { g_err = "no cooperative form for this problem"; return 2; }
         ikdev::CoopKernelArgs a{};
         a.T = ikgpu::bind_generic_tables(ph, ph.generic.ints.data(), ph.generic.dbls.data());

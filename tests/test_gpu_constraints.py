@@ -33,8 +33,9 @@ CASES = {
 
 
 @pytest.mark.parametrize("case", sorted(CASES))
-def test_constrained_dls_matches_oracle(torch_cuda, case):
+def test_constrained_dls_matches_oracle(torch_cuda, case, monkeypatch):
     torch = torch_cuda
+    monkeypatch.delenv("IKGPU_GENERIC_KERNEL", raising=False)   # the cooperative LDS-resident form first, the per-lane form at the end
     name, ff, specs, cspecs = CASES[case]
     B = 300
     ik_amd, O, model, problem, _, om, ot, q0, tg = build(name, ff, specs, B, seed=21)
@@ -52,6 +53,11 @@ def test_constrained_dls_matches_oracle(torch_cuda, case):
         q_ref, ok_ref, it_ref = O.dls_batch_constrained(om, ot, oc, tg, q0, O.params(iters, damping, step, tol), os.cpu_count() or 1)
         assert np.array_equal(ok.cpu().numpy(), ok_ref) and np.array_equal(it.cpu().numpy(), it_ref), (case, iters)
         assert np.abs(Q.cpu().numpy().T - q_ref).max() <= TOL, (case, iters)
+    monkeypatch.setenv("IKGPU_GENERIC_KERNEL", "lane")          # same problem, same parameters, the per-lane program
+    Ql, okl, itl = ik_amd.dls_batch(problem, Q0, T, data, ik_amd.inverse_kinematics_visitor(tol), p)
+    assert torch.equal(ok, okl) and torch.equal(it, itl) and (Q - Ql).abs().max().item() < 1e-8
+    assert np.abs(Ql.cpu().numpy().T - q_ref).max() <= TOL
+    monkeypatch.delenv("IKGPU_GENERIC_KERNEL")
     # the constraint changes the answer, and holds to first order: after ONE small step the constrained coordinates of the
     # frame relative to its reference have moved by O(step^2) only
     p = ik_amd.dls_parameters(max_iterations=1, damping=1e-2, step_length=0.01)

@@ -444,6 +444,13 @@ def test_constrained_dls_program_matches_oracle(emu, case):
         q_ref, ok_ref, it_ref = O.dls_batch_constrained(om, ot, oc, tg, q0, O.params(iters, damping, step, tol))
         assert np.array_equal(ok, ok_ref) and np.array_equal(it, it_ref), (case, iters)
         assert np.abs(qo - q_ref).max() < 1e-8, (case, iters, np.abs(qo - q_ref).max())
+        # the cooperative program (device/coop_solver.hpp: pivoted Gram-Schmidt instead of Jacobi for the projector)
+        qc, okc, itc = np.empty_like(q0), np.zeros(B, np.uint8), np.zeros(B, np.int32)
+        rc = emu.lane_emu_dls_coop_constrained(urdf, C.c_size_t(len(urdf)), 1 if ff else 0, tasks, len(tasks), cons, len(cons), C.c_int64(B),
+                                               p(q0), p(tg), C.byref(prm), p(qc), p(okc), p(itc), 1)
+        assert rc == 0, emu.lane_emu_last_error()
+        assert np.array_equal(okc, ok_ref) and np.array_equal(itc, it_ref), (case, iters)
+        assert np.abs(qc - q_ref).max() < 1e-8, (case, iters, np.abs(qc - q_ref).max())
     # and the constraint bites: without it the same problem goes elsewhere
     q_free, _, _ = O.dls_batch(om, ot, tg, q0, O.params(iters, damping, step, tol))
     assert np.abs(q_free - q_ref).max() > 1e-3
