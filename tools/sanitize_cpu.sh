@@ -37,3 +37,4 @@ for c in com.CASES: com.test_dls_with_a_centre_of_mass_task_matches_the_twin_and
 print("asan/ubsan: clean")
 PY
 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libstdc++.so.6)" ASAN_OPTIONS=detect_leaks=0 python /tmp/ik_asan_run.py
+LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libstdc++.so.6)" ASAN_OPTIONS=detect_leaks=0 python tools/fuzz_urdf.py 30
