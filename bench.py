@@ -285,6 +285,36 @@ def main():
                                     "frac": tf / FP64_VALU_PEAK_TF, "flop_per_solve": flops,
                                     "counting": "executed FP64 VALU instructions per launch from the SQ_INSTS_VALU_{FMA,MUL,ADD,"
                                                 "TRANS}_F64 counters (x 64 lanes, FMA = 2), 50 iterations; profiles/r01_pmc"}
+        if world == 1 and not use_pik:
+            # secondary figures of SURVEY.md 8d, outside the timed region: the library's default stop rule
+            # (reference ik/ik/visitor.hpp:15-21, tolerance 1e-4 on the squared priority-0 error; max_iterations 100,
+            # reference ik/ik/common.hpp:59-66) and the cold path URDF text -> device handle
+            stop = ik_amd.inverse_kinematics_visitor()
+            prm_stop = ik_amd.dls_parameters(max_iterations=100, damping=1e-2, step_length=1.0)
+            solve_batch(problem, Q0, targets, data, stop, prm_stop, out=bufs[0].out())
+            ev0.record()
+            for _ in range(5):
+                Qs, oks, its = solve_batch(problem, Q0, targets, data, stop, prm_stop, out=bufs[0].out())
+            ev1.record()
+            torch.cuda.synchronize()
+            ms = float(ev0.elapsed_time(ev1)) / 5
+            res["default_stop_rule"] = {"value": B / (ms * 1e-3), "unit": "solves/s", "kernel_ms": ms,
+                                        "stop_sq_tol": stop.tolerance, "max_iterations": 100,
+                                        "mean_iterations": float(its.double().mean().item()),
+                                        "success_rate": float(oks.double().mean().item())}
+            t = time.perf_counter()
+            m2 = ik_amd.Model.from_urdf_file(os.path.join(workload.MODELS_DIR, w["urdf"] + ".kin.urdf"), free_flyer=w["free_flyer"])
+            t_parse = time.perf_counter() - t
+            p2 = ik_amd.InverseKinematicsProblem(m2)
+            for i, (kind, f, tt, r) in enumerate(task_specs(w)):
+                if kind == "align":
+                    p2.add_align_axis_task("t%d" % i, ik_amd.AlignAxisTask.create(m2, f, ik_amd.AlignAxisType(tt), r))
+                else:
+                    p2.add_frame_task("t%d" % i, ik_amd.FrameTask.create(m2, f, ik_amd.KinematicType(tt), r))
+            d2 = ik_amd.dls_data(p2, device=local_rank)
+            res["model_load"] = {"urdf_parse_ms": t_parse * 1e3, "urdf_to_device_handle_ms": (time.perf_counter() - t) * 1e3,
+                                 "kernel": d2.kernel}
+            del d2, p2, m2
         if not args.no_cpu and world == 1:   # the CPU leg runs on rank 0 at N = 1 only
             tg_np = targets.permute(2, 0, 1).contiguous().cpu().numpy()
             cpu, q_ref, sample, conv = cpu_baseline(model, w, q0_np, tg_np, args.iters)

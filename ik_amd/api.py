@@ -565,11 +565,18 @@ class pik_data(dls_data):
         self.lambda_ = [1.0] * (problem.max_priority_level() + 1)
         self.da = np.zeros(problem.model().nv)
 
-    def _bind(self, problem):
-        before = self._generation
-        super()._bind(problem)
-        if self._generation != before:
-            self.kernel = "pik_generic<" + plan_generic(problem).split("<", 1)[1]
+    @property
+    def kernel(self):
+        """Name of the kernel the next call runs with the current `lambda_` / `da`: the problem's DLS kernel when there is one
+        priority level and no secondary step (ik::pik is then the DLS iteration, include/ikgpu.h), the PIK kernel otherwise."""
+        if self._h is None or len(self.lambda_) > capi.MAX_PIK_LEVELS:
+            return ""
+        prm = self._params(inverse_kinematics_visitor(), pik_parameters())
+        return capi.lib().ikgpu_pik_kernel(self._h, C.byref(prm)).decode()
+
+    @kernel.setter
+    def kernel(self, _):
+        pass  # dls_data._bind records the DLS kernel's name; this class derives its name from the handle at every read
 
     def _params(self, visitor, p):
         prm = capi.PikParams()

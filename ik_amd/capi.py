@@ -24,7 +24,7 @@ SYMBOLS = [
     "ikgpu_problem_create", "ikgpu_problem_destroy", "ikgpu_problem_rows", "ikgpu_problem_kernel",
     "ikgpu_problem_plan",
     "ikgpu_dls_solve_batch", "ikgpu_dls_solve_batch_host", "ikgpu_evaluate_batch", "ikgpu_task_frames_fk_batch",
-    "ikgpu_pik_params_default", "ikgpu_pik_solve_batch", "ikgpu_pik_solve_batch_host",
+    "ikgpu_pik_params_default", "ikgpu_pik_solve_batch", "ikgpu_pik_solve_batch_host", "ikgpu_pik_kernel",
     "ikgpu_problem_create_constrained", "ikgpu_problem_plan_constrained",
 ]
 MAX_PIK_LEVELS, MAX_PIK_DA = 8, 128
@@ -110,6 +110,8 @@ def lib():
     L.ikgpu_pik_params_default.restype = None
     L.ikgpu_pik_solve_batch.argtypes = [vp, i64, vp, vp, C.POINTER(PikParams), vp, vp, vp, C.c_int, vp]
     L.ikgpu_pik_solve_batch_host.argtypes = [vp, i64, vp, vp, C.POINTER(PikParams), vp, vp, vp, C.c_int]
+    L.ikgpu_pik_kernel.argtypes = [vp, C.POINTER(PikParams)]
+    L.ikgpu_pik_kernel.restype = C.c_char_p
     L.ikgpu_evaluate_batch.argtypes = [vp, i64, vp, vp, vp, vp, C.c_int, vp]
     L.ikgpu_task_frames_fk_batch.argtypes = [vp, i64, vp, vp, C.c_int, vp]
     for name in ("ikgpu_model_from_urdf", "ikgpu_model_create", "ikgpu_model_get_flat", "ikgpu_problem_create",

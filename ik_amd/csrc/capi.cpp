@@ -2,6 +2,8 @@
 // solve runs the gfx950 kernels (kernels.hip) or fails with a message -- there is no CPU path.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <new>
@@ -19,6 +21,7 @@ struct ikgpu_problem {
     ikgpu::DeviceTables dev;
     int device = 0;
     int nframes = 0;
+    std::string pik_name;    // name of the generic PIK kernel instance
 };
 
 namespace {
@@ -98,6 +101,17 @@ int check_pik_params(const ikgpu_problem *p, const ikgpu_pik_params *prm) {
     if (prm->da && p->gen.nv > IKGPU_MAX_PIK_DA)
         return fail(IKGPU_ERR_UNSUPPORTED, "da is carried by value for nv <= " + std::to_string(IKGPU_MAX_PIK_DA));
     return IKGPU_OK;
+}
+
+// ik::pik with ONE priority level and no secondary velocity is the DLS iteration: P = I, so the level's step is
+// dq = -damp_pinv(J, lambda) e = -J^T (J J^T + lambda^2 I)^-1 e (reference ik/ik/pik.cpp:5-21,47-61 against ik/ik/dls.cpp:39-53),
+// and the stop test, integration and clamp are the same statements in the same order (pik.cpp:67-77, dls.cpp:61-71).
+// ik::pik does not read the problem's constraints, so a problem that has any stays on the PIK kernel.
+// IKGPU_PIK_KERNEL=generic keeps every ik::pik call on the PIK kernel (the parity tests compare the two).
+bool pik_is_one_dls_level(const ikgpu_problem *p, const ikgpu_pik_params *prm) {
+    const char *force = std::getenv("IKGPU_PIK_KERNEL");
+    if (force && std::strcmp(force, "generic") == 0) return false;
+    return prm->num_levels == 1 && !prm->da && prm->lambda[0] > 0.0 && p->host.constraints.empty();
 }
 
 // Host-pointer form of a batched solve: copy in, run `launch` on device buffers, synchronise, copy out.
@@ -252,6 +266,7 @@ int ikgpu_problem_create_constrained(const ikgpu_model *h, const ikgpu_task *tas
         auto *p = new ikgpu_problem;
         p->host = std::move(ph);
         p->gen = std::move(gen);
+        p->pik_name = "pik_generic" + p->gen.kernel_name.substr(std::min(p->gen.kernel_name.find('<'), p->gen.kernel_name.size()));
         p->device = device;
         p->nframes = h->m.nframes();
         const size_t nq = static_cast<size_t>(p->host.nq);
@@ -362,6 +377,11 @@ void ikgpu_pik_params_default(ikgpu_pik_params *p, int32_t num_levels) {
     p->da = nullptr;                      // reference ik/ik/pik.hpp:26
 }
 
+const char *ikgpu_pik_kernel(const ikgpu_problem *p, const ikgpu_pik_params *params) {
+    if (!p || !params) return "";
+    return pik_is_one_dls_level(p, params) ? p->host.kernel_name.c_str() : p->pik_name.c_str();
+}
+
 int ikgpu_pik_solve_batch(const ikgpu_problem *p, int64_t B, const double *q0, const double *targets,
                           const ikgpu_pik_params *params, double *q_out, uint8_t *success, int32_t *iters, int layout,
                           void *stream) {
@@ -372,6 +392,10 @@ int ikgpu_pik_solve_batch(const ikgpu_problem *p, int64_t B, const double *q0, c
     if (B == 0) return IKGPU_OK;
     if (!q0 || !targets || !q_out) return fail(IKGPU_ERR_INVALID, "null argument");
     if (B > (int64_t(1) << 31) * 32) return fail(IKGPU_ERR_INVALID, "batch too large for one launch");
+    if (pik_is_one_dls_level(p, params)) {
+        const ikgpu_dls_params d{params->max_iterations, params->lambda[0], params->step_length, params->stop_sq_tol};
+        return ikgpu_dls_solve_batch(p, B, q0, targets, &d, q_out, success, iters, layout, stream);
+    }
     return guarded([&] {
         DeviceGuard g(p->device);
         if (!g.ok) return fail(IKGPU_ERR_DEVICE, "hipSetDevice failed");

@@ -697,6 +697,9 @@ class pik_data : public dls_data {  // ik/ik/pik.hpp:21-50
     }
     vector_t da;                  // secondary step, projected into the null space of every level (pik.cpp:65)
     std::vector<double> lambda;   // damping factor of each priority level (pik.cpp:54-55)
+    // the kernel the next ik::pik call runs with the current lambda / da: the problem's DLS kernel for one priority level
+    // without a secondary step (ik::pik is then the DLS iteration, see ikgpu_pik_kernel), the PIK kernel otherwise
+    const char *kernel() const;
 };
 
 namespace detail {
@@ -712,6 +715,11 @@ inline ikgpu_pik_params to_abi(const inverse_kinematics_visitor &visitor, const 
     return a;
 }
 }  // namespace detail
+
+inline const char *pik_data::kernel() const {
+    const ikgpu_pik_params prm = detail::to_abi(inverse_kinematics_visitor(), pik_parameters(), *this);
+    return ikgpu_pik_kernel(handle(), &prm);
+}
 
 inline vector_t pik(InverseKinematicsProblem &problem, const vector_t &q0, pik_data &data,
                     const inverse_kinematics_visitor &visitor = inverse_kinematics_visitor(),

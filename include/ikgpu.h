@@ -198,6 +198,11 @@ int ikgpu_pik_solve_batch(const ikgpu_problem *p, int64_t B, const double *q0, c
 int ikgpu_pik_solve_batch_host(const ikgpu_problem *p, int64_t B, const double *q0, const double *targets,
                                const ikgpu_pik_params *params, double *q_out, uint8_t *success, int32_t *iters,
                                int layout);
+/* Name of the kernel ikgpu_pik_solve_batch runs with these parameters.  With ONE priority level, lambda[0] > 0, da == NULL
+ * and no constraints in the problem, ik::pik's step  -damp_pinv(J, lambda) e  (reference ik/ik/pik.cpp:5-21,47-61) IS the DLS
+ * step  -J^T (J J^T + lambda^2 I)^-1 e  (ik/ik/dls.cpp:39-53) and the loop around it is the same, so the problem's DLS
+ * kernel (ikgpu_problem_kernel) runs it; otherwise the generic PIK kernel does. */
+const char *ikgpu_pik_kernel(const ikgpu_problem *p, const ikgpu_pik_params *params);
 
 /* ---- stage kernels (device pointers), for stage-by-stage parity and for building targets:
  * evaluate_problem_data + stacking (reference ik/ik/data.cpp:25-58, ik/ik/dls.cpp:18-24):

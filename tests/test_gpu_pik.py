@@ -60,7 +60,10 @@ def test_pik_kernel_matches_oracle(torch_cuda, case):
         if da is not None and not projector_determined:
             continue
         data = _pik_data(ik_amd, problem, lam, da)
-        assert data.kernel.startswith("pik_generic<")
+        if levels == 1 and da is None:   # ik::pik with one level and no secondary step IS the DLS iteration (include/ikgpu.h)
+            assert data.kernel == ik_amd.plan(problem) and data.kernel.startswith("dls_chain<")
+        else:
+            assert data.kernel.startswith("pik_generic<")
         p = ik_amd.pik_parameters(max_iterations=iters, step_length=step)
         visitor = ik_amd.inverse_kinematics_visitor(tol)
         Q, ok, it = ik_amd.pik_batch(problem, Q0, T, data, visitor, p)
@@ -104,19 +107,49 @@ def test_cooperative_and_per_lane_pik_kernels_agree(torch_cuda, case, monkeypatc
     assert torch.isfinite(Qz).double().mean().item() > 0.99
 
 
-def test_pik_with_one_level_is_dls_with_damping_lambda(torch_cuda):
-    """One priority level: pik's step is -J^T (J J^T + lambda^2 I)^-1 e, i.e. ik::dls with damping = lambda -- here the
-    register-resident DLS kernel and the generic PIK kernel, on the same problem handle."""
+@pytest.mark.parametrize("name,ff,specs,kernel", [
+    ("cassie_fixed", False, [("frame", "LeftFootFront", "universe", 2, 0, None)], "dls_chain<"),
+    ("ur5", False, [("frame", "tool0", "universe", 2, 0, None)], "dls_chain<"),
+    ("cassie", True, [("frame", "LeftFootFront", "universe", 2, 0, None), ("frame", "RightFootFront", "universe", 2, 0, None),
+                      ("frame", "pelvis", "universe", 2, 0, None)], "dls_tree<"),
+    ("cassie", True, [("frame", "LeftFootFront", "pelvis", 0, 0, None), ("frame", "pelvis", "universe", 2, 0, None),
+                      ("align", "LeftFootFront", "universe", 1, 0, None)], "dls_tree<"),
+])
+def test_pik_with_one_level_is_dls_with_damping_lambda(torch_cuda, monkeypatch, name, ff, specs, kernel):
+    """One priority level, no secondary step: pik's step is -J^T (J J^T + lambda^2 I)^-1 e, i.e. ik::dls with damping = lambda,
+    and ikgpu_pik_solve_batch runs it on the problem's register-resident DLS kernel.  Checked against the oracle's ik::pik
+    (an SVD-based damped pseudo-inverse, oracle/ik_oracle.c) and against the generic PIK kernel on the same handle."""
     torch = torch_cuda
-    ik_amd, O, model, problem, _, om, ot, q0, tg = build("cassie_fixed", False, [("frame", "LeftFootFront", "universe", 2, 0, None)], 512, seed=6)
-    data = _pik_data(ik_amd, problem, [1e-2])
+    monkeypatch.delenv("IKGPU_PIK_KERNEL", raising=False)
+    B = 515
+    ik_amd, O, model, problem, _, om, ot, q0, tg = build(name, ff, specs, B, seed=6)
     Q0 = torch.from_numpy(np.ascontiguousarray(q0.T)).cuda()
     T = torch.from_numpy(np.ascontiguousarray(tg.transpose(1, 2, 0))).cuda()
-    v = ik_amd.inverse_kinematics_visitor(1e-10)
-    Qp, okp, itp = ik_amd.pik_batch(problem, Q0, T, data, v, ik_amd.pik_parameters(max_iterations=25))
-    Qd, okd, itd = ik_amd.dls_batch(problem, Q0, T, data, v, ik_amd.dls_parameters(max_iterations=25, damping=1e-2))
-    assert torch.equal(okp, okd) and torch.equal(itp, itd)
-    assert (Qp - Qd).abs().max().item() < 1e-8
+    for iters, step, tol, lam in ((1, 1.0, -1.0, 1.0), (25, 1.0, 1e-10, 1e-2), (50, 0.5, -1.0, 0.1)):
+        data = _pik_data(ik_amd, problem, [lam])
+        assert data.kernel == ik_amd.plan(problem) and data.kernel.startswith(kernel)
+        v, p = ik_amd.inverse_kinematics_visitor(tol), ik_amd.pik_parameters(max_iterations=iters, step_length=step)
+        Qp, okp, itp = ik_amd.pik_batch(problem, Q0, T, data, v, p)
+        q_ref, ok_ref, it_ref = O.pik_batch(om, ot, tg, q0, O.pik_params(iters, step, tol, [lam], None), os.cpu_count() or 1)
+        assert np.array_equal(okp.cpu().numpy(), ok_ref) and np.array_equal(itp.cpu().numpy(), it_ref), (name, iters)
+        assert np.abs(Qp.cpu().numpy().T - q_ref).max() <= TOL, (name, iters)
+        Qd, okd, itd = ik_amd.dls_batch(problem, Q0, T, data, v, ik_amd.dls_parameters(max_iterations=iters, damping=lam, step_length=step))
+        assert torch.equal(Qp, Qd) and torch.equal(okp, okd) and torch.equal(itp, itd)      # the very same launch
+    monkeypatch.setenv("IKGPU_PIK_KERNEL", "generic")
+    assert data.kernel.startswith("pik_generic<")
+    Qg, okg, itg = ik_amd.pik_batch(problem, Q0, T, data, v, p)
+    monkeypatch.delenv("IKGPU_PIK_KERNEL")
+    assert torch.equal(okp, okg) and torch.equal(itp, itg)
+    assert (Qp - Qg).abs().max().item() < 1e-7
+    # a secondary step, or a constraint in the problem (which ik::pik does not read), keeps the call on the PIK kernel
+    data.da = 0.01 * np.ones(model.nv)
+    assert data.kernel.startswith("pik_generic<")
+    data.da = np.zeros(model.nv)
+    problem.add_frame_constraint("hold", ik_amd.FrameConstraint.create(model, specs[0][1], ik_amd.KinematicType.Orientation))
+    data2 = _pik_data(ik_amd, problem, [lam])
+    assert data2.kernel.startswith("pik_generic<")
+    Qc, okc, itc = ik_amd.pik_batch(problem, Q0, T, data2, v, p)
+    assert torch.equal(okc, okp) and (Qc - Qp).abs().max().item() < 1e-7
 
 
 def test_single_problem_pik_with_edited_lambda_and_da(torch_cuda):
@@ -195,5 +228,16 @@ def test_cpp_api_program_with_pik(torch_cuda):
     out = json.loads(subprocess.check_output(args, text=True))
     q1, ok1, it1 = O.pik(om, ot, tg, q0, O.pik_params(30, 1.0, 1e-10, [0.05, 0.1]))
     q2, ok2, it2 = O.pik(om, ot, tg, q1, O.pik_params(30, 1.0, 1e-10, [0.05, 0.1]))
+    assert np.abs(np.array(out["q_first"]) - q1).max() <= TOL and np.abs(np.array(out["q"]) - q2).max() <= TOL
+    assert out["success"] == int(ok2) and out["iterations"] == it2
+    assert out["kernel"].startswith("pik_generic<")
+    # one level: the C++ mirror's pik_data::kernel() names the DLS kernel the call ran on
+    args = [_cpp_binary(), urdf_path("ur5"), "0", "30", "0.01", "1.0", "1e-10", "1", "tool0", "2", "0"]
+    args += ["%.17g" % x for x in tg[0]] + ["%.17g" % x for x in q0] + ["pik", "0.05"]
+    out = json.loads(subprocess.check_output(args, text=True))
+    ot1 = O.make_tasks([(fid, 0, 2, 0, None)])
+    q1, ok1, it1 = O.pik(om, ot1, tg[:1], q0, O.pik_params(30, 1.0, 1e-10, [0.05]))
+    q2, ok2, it2 = O.pik(om, ot1, tg[:1], q1, O.pik_params(30, 1.0, 1e-10, [0.05]))
+    assert out["kernel"].startswith("dls_chain<NJ=6")
     assert np.abs(np.array(out["q_first"]) - q1).max() <= TOL and np.abs(np.array(out["q"]) - q2).max() <= TOL
     assert out["success"] == int(ok2) and out["iterations"] == it2

@@ -33,15 +33,18 @@ def main():
     with tempfile.TemporaryDirectory() as td:
         asm = os.path.join(td, "kernels.s")
         cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
-               "-I" + os.path.join(ROOT, "ik_amd", "csrc"), "--offload-arch=gfx950", "-fno-fast-math", "-ffp-contract=on",
+               "-I" + os.path.join(ROOT, "ik_amd", "csrc"), "--offload-arch=gfx950", "-fno-fast-math", "-ffp-contract=" + os.environ.get("IKGPU_FP_CONTRACT", "on"),
                "-S", "--cuda-device-only", os.path.join(ROOT, "ik_amd", "csrc", "kernels.hip"), "-o", asm]
         subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
         text = open(asm).read()
     out = {}
     for disp, (frag, trips) in KERNELS.items():
-        m = re.search(r"^(_Z\w*%s\w*):" % re.escape(frag), text, re.M)
-        if not m:
+        # several instantiations share the fragment (third template argument: 0 = the general build, otherwise the mask of
+        # the hot build the launcher picks for these workloads): take the hot one
+        cands = list(re.finditer(r"^(_Z\w*%sLi(\d+)E\w*):" % re.escape(frag), text, re.M))
+        if not cands:
             continue
+        m = max(cands, key=lambda mm: int(mm.group(2)))
         name = m.group(1)
         body = text[m.end():text.index(".Lfunc_end", m.end())].split("\n")
         # Blocks carry "; =>This Inner Loop Header" / "; =>This Loop Header" / ";   in Loop: Header=BBn_m Depth=d"
