@@ -514,8 +514,7 @@ hipError_t launch_dls_generic(const ProblemHost &ph, const DeviceTables &dt, con
         c.layout = io.layout; c.B = io.B; c.q0 = io.q0; c.targets = io.targets;
         c.q_out = io.q_out; c.success = io.success; c.iters = io.iters;
         const CoopStaging s{dt.g_ints, dt.g_dbls, static_cast<int>(ph.generic.ints.size()), static_cast<int>(ph.generic.dbls.size())};
-        int per_block = ikdev::kCoopPerBlock;
-        if (const char *pb = std::getenv("IKGPU_COOP_PER_BLOCK")) per_block = std::max(1, std::min(4, std::atoi(pb)));
+        const int per_block = ikdev::kCoopPerBlock;  // 4 x 16 lanes = one wave; 2 and 1 problems per workgroup measured slower
         const size_t lds = sizeof(double) * (static_cast<size_t>(per_block) * static_cast<size_t>(c.L.words) +
                                              static_cast<size_t>(s.n_dbls) + static_cast<size_t>((s.n_ints + 1) / 2));
         const int64_t blocks = (io.B + per_block - 1) / per_block;
