@@ -8,7 +8,7 @@ B per GPU is fixed.  Default workload = the one the metric is quoted on: Cassie 
 B = 65536, 50 iterations.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--iters I]
-                    [--workload cassie_leg|cassie_full_body|ur5|cassie_demo|cassie_demo_pik] [--no-cpu]
+                    [--workload cassie_leg|cassie_full_body|ur5|ur10|cassie_demo|cassie_demo_pik] [--no-cpu]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line.
@@ -41,7 +41,12 @@ WORKLOADS = {
                              text="Cassie full body (cassie.urdf + free-flyer, nq=23 / nv=22), SE(3) tasks on LeftFootFront, "
                                   "RightFootFront and pelvis (M=18)"),
     "ur5": dict(urdf="ur5", free_flyer=False, frames=["tool0"], nq=6,
-                text="UR5 arm (ur5.urdf, nq=6), one SE(3) tool0 task, targets within +-2 rad so the joint clamp is live"),
+                text="UR5 arm (ur5.urdf, nq=6), one SE(3) tool0 task, joint-limit projection after every step"),
+    # BASELINE.json's config 5 names a UR10; the reference ships a UR5 only, this model is authored from the public
+    # ur_description constants (fixtures/make_ur10_urdf.py) and is NOT a reference file
+    "ur10": dict(urdf="ur10", free_flyer=False, frames=["tool0"], nq=6,
+                 text="UR10 arm (fixtures/models/ur10.kin.urdf, authored from public constants, not in the reference; nq=6), one SE(3) "
+                      "tool0 task, joint-limit projection after every step"),
     # the demo's own task set (reference ik_ros/src/cassie.cpp:45-81): the tree kernel's general build
     "cassie_demo": dict(urdf="cassie", free_flyer=True, frames=["LeftFootFront", "pelvis", "LeftFootFront"], nq=23,
                         tasks=[("frame", "LeftFootFront", 0, "pelvis"), ("frame", "pelvis", 2, "universe"),
@@ -76,7 +81,7 @@ def make_inputs(name, model, idx):
     lo, hi = model.lowerPositionLimit, model.upperPositionLimit
     if name in ("cassie_full_body", "cassie_demo", "cassie_demo_pik"):
         return workload.freeflyer_workload(lo, hi, workload.cassie_nominal(model.names), idx, seed=0, mode="near")
-    if name == "ur5":
+    if name in ("ur5", "ur10"):
         return workload.chain_workload(lo, hi, workload.UR5_NOMINAL, idx, seed=0, mode="near")
     return workload.chain_workload(lo, hi, workload.cassie_nominal(model.names), idx, seed=0, mode="uniform")
 
