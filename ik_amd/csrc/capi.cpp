@@ -93,9 +93,11 @@ int check_pik_params(const ikgpu_problem *p, const ikgpu_pik_params *prm) {
     if (levels > IKGPU_MAX_PIK_LEVELS)
         return fail(IKGPU_ERR_UNSUPPORTED, "the problem has " + std::to_string(levels) + " priority levels, ik::pik on the device takes at most " +
                                                std::to_string(IKGPU_MAX_PIK_LEVELS));
-    if (prm->num_levels != levels)
-        return fail(IKGPU_ERR_INVALID, "num_levels is " + std::to_string(prm->num_levels) + " but the problem has " + std::to_string(levels) +
-                                           " priority levels");
+    // a problem may declare more levels than its tasks use (the demo does, reference ik_ros/src/cassie.cpp:43): the
+    // reference's loop over 0..max_priority_level (ik/ik/pik.cpp:47) is a no-op on a level without rows
+    if (prm->num_levels < levels || prm->num_levels > IKGPU_MAX_PIK_LEVELS)
+        return fail(IKGPU_ERR_INVALID, "num_levels is " + std::to_string(prm->num_levels) + " but the problem's tasks use " +
+                                           std::to_string(levels) + " priority levels (at most " + std::to_string(IKGPU_MAX_PIK_LEVELS) + ")");
     for (int l = 0; l < levels; ++l)
         if (!(prm->lambda[l] >= 0.0)) return fail(IKGPU_ERR_INVALID, "lambda[" + std::to_string(l) + "] must be >= 0");
     if (prm->da && p->gen.nv > IKGPU_MAX_PIK_DA)
@@ -111,7 +113,7 @@ int check_pik_params(const ikgpu_problem *p, const ikgpu_pik_params *prm) {
 bool pik_is_one_dls_level(const ikgpu_problem *p, const ikgpu_pik_params *prm) {
     const char *force = std::getenv("IKGPU_PIK_KERNEL");
     if (force && std::strcmp(force, "generic") == 0) return false;
-    return prm->num_levels == 1 && !prm->da && prm->lambda[0] > 0.0 && p->host.constraints.empty();
+    return p->gen.generic.nlevels == 1 && !prm->da && prm->lambda[0] > 0.0 && p->host.constraints.empty();
 }
 
 // Host-pointer form of a batched solve: copy in, run `launch` on device buffers, synchronise, copy out.

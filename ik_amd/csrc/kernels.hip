@@ -442,7 +442,7 @@ extern "C" int ikgpu_debug_coop_profile(long long *out16, int reset) {
 // ik::pik (reference ik/ik/pik.cpp:31-103) on the generic lane program; `gen` is the problem's generic analysis.
 bool pik_runs_cooperative(const ProblemHost &gen, const ikgpu_pik_params &prm) {
     if (!gen.generic.coop_pik_ok) return false;
-    for (int l = 0; l < prm.num_levels; ++l)
+    for (int l = 0; l < gen.generic.nlevels; ++l)  // levels beyond the tasks' own are empty (capi.cpp: check_pik_params)
         if (!(prm.lambda[l] > 0.0)) return false;  // the cooperative form solves (Jbar Jbar^T + lambda^2 I) by Cholesky
     const char *force = std::getenv("IKGPU_GENERIC_KERNEL");
     return !(force && std::string(force) == "lane");

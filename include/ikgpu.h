@@ -186,7 +186,8 @@ typedef struct {
     int32_t max_iterations;               /* default 100 */
     double step_length;                   /* default 1.0 */
     double stop_sq_tol;                   /* default 1e-4; < 0 never stops */
-    int32_t num_levels;                   /* must equal the problem's max priority + 1, <= IKGPU_MAX_PIK_LEVELS */
+    int32_t num_levels;                   /* the problem's max_priority_level + 1: at least the tasks' max priority + 1 (a level
+                                           * without tasks is a no-op, as in the reference's loop pik.cpp:47), <= IKGPU_MAX_PIK_LEVELS */
     double lambda[IKGPU_MAX_PIK_LEVELS];  /* pik_data::lambda, default 1.0 each (pik.hpp:24) */
     const double *da;                     /* pik_data::da, HOST pointer to nv doubles, or NULL for zero (the default);
                                            * read during the call; nv <= IKGPU_MAX_PIK_DA when not NULL */

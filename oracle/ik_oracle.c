@@ -914,7 +914,7 @@ static int pik_ws(const iko_model *m, const iko_task *tasks, int ntasks, const d
     const int nq = m->nq, nv = m->nv, M = w->M;
     int maxp = 0;
     for (int i = 0; i < ntasks; ++i) if (tasks[i].priority > maxp) maxp = tasks[i].priority;
-    if (p->nlevels != maxp + 1) return -1;
+    if (p->nlevels < maxp + 1) return -1;                       /* trailing levels without tasks are no-ops (pik.cpp:47) */
     int *row0 = (int *)calloc((size_t)maxp + 2, sizeof(int));
     for (int i = 0; i < ntasks; ++i) row0[tasks[i].priority + 1] += task_dim(&tasks[i]);
     for (int l = 0; l <= maxp; ++l) row0[l + 1] += row0[l];

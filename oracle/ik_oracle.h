@@ -99,7 +99,8 @@ int iko_dls_batch(const iko_model *m, const iko_task *tasks, int ntasks, long B,
 
 /* ik::pik_parameters (ik/ik/pik.hpp:11-16; `damping` there is never read) + the stop rule as above + the two members
  * of ik::pik_data a caller sets (ik/ik/pik.hpp:41,44): lambda[level] (default 1.0 each, pik.hpp:24) and da (default
- * zero; NULL == zero).  nlevels must be max priority + 1. */
+ * zero; NULL == zero).  nlevels must be at least the tasks' max priority + 1
+ * (the problem's declared max_priority_level + 1; a level without tasks is a no-op, pik.cpp:47). */
 typedef struct {
     int max_iterations;
     double step_length, stop_sq_tol;
@@ -109,7 +110,7 @@ typedef struct {
 } iko_pik_params;
 
 /* ik::pik (ik/ik/pik.cpp:31-103) for one problem; same outputs and trace format as iko_dls. Returns -1 when
- * nlevels does not match the task table. */
+ * nlevels is smaller than the task table needs. */
 int iko_pik(const iko_model *m, const iko_task *tasks, int ntasks, const double *targets, const double *q0,
             const iko_pik_params *p, double *q_out, int *success, int *iters, double *trace);
 int iko_pik_batch(const iko_model *m, const iko_task *tasks, int ntasks, long B, const double *targets, const double *q0,

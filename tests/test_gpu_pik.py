@@ -152,6 +152,54 @@ def test_pik_with_one_level_is_dls_with_damping_lambda(torch_cuda, monkeypatch, 
     assert torch.equal(okc, okp) and (Qc - Qp).abs().max().item() < 1e-7
 
 
+def test_demo_problem_through_pik_as_the_demo_declares_it(torch_cuda):
+    """The demo's PIK branch (reference ik_ros/src/cassie.cpp:43,72-81,115-121): the problem is declared with max priority
+    level 1 but every task sits on level 0, so pik_data carries two lambdas and the second level has no rows -- a no-op in
+    the reference's loop (ik/ik/pik.cpp:47).  It is therefore the DLS iteration and runs on the tree kernel."""
+    torch = torch_cuda
+    import ik_amd
+    import oracle as O
+    from ik_amd import workload
+    model = ik_amd.Model.from_urdf_file(urdf_path("cassie"), free_flyer=True)
+    problem = ik_amd.InverseKinematicsProblem(model, 1)
+    fl = problem.add_frame_task("fl", ik_amd.FrameTask.create(model, "LeftFootFront", ik_amd.KinematicType.Position, "pelvis"))
+    pelvis = problem.add_frame_task("pelvis", ik_amd.FrameTask.create(model, "pelvis", ik_amd.KinematicType.Full))
+    align = problem.add_align_axis_task("align", ik_amd.AlignAxisTask.create(model, "LeftFootFront", ik_amd.AlignAxisType.AxisY))
+    data = ik_amd.pik_data(problem, device=0)
+    assert data.lambda_ == [1.0, 1.0]
+    data.lambda_ = [0.1, 1.0]
+    assert data.kernel.startswith("dls_tree<") and "align_axis" in data.kernel
+    B = 777
+    q0, qs = workload.freeflyer_workload(model.lowerPositionLimit, model.upperPositionLimit, workload.cassie_nominal(model.names),
+                                         np.arange(B), seed=3)
+    om = O.OracleModel(model.flat())
+    fids = [model.getFrameId("LeftFootFront"), model.getFrameId("pelvis")]
+    ot = O.make_tasks([(fids[0], fids[1], 0, 0, None), (fids[1], 0, 2, 0, None), (fids[0], 0, 4, 0, None)])
+    tg = np.zeros((B, 3, 12))
+    for b in range(B):
+        oMf = O.fk(om, qs[b])[1]
+        Rp, pp, Rf, pf = oMf[fids[1]][:9].reshape(3, 3), oMf[fids[1]][9:], oMf[fids[0]][:9].reshape(3, 3), oMf[fids[0]][9:]
+        tg[b, 0, :9], tg[b, 0, 9:] = (Rp.T @ Rf).ravel(), Rp.T @ (pf - pp)
+        tg[b, 1] = oMf[fids[1]]
+        tg[b, 2, :9], tg[b, 2, 9:] = np.eye(3).ravel(), Rf[:, 1]         # the direction the foot's Y axis has at q*
+    Q0 = torch.from_numpy(np.ascontiguousarray(q0.T)).cuda()
+    T = torch.from_numpy(np.ascontiguousarray(tg.transpose(1, 2, 0))).cuda()
+    # the demo's own parameters (cassie.cpp:103-106 for DLS; its PIK branch keeps the defaults): small steps, many of them
+    for iters, step, tol in ((1, 1.0, -1.0), (200, 0.1, 1e-4), (30, 0.5, -1.0)):
+        Q, ok, it = ik_amd.pik_batch(problem, Q0, T, data, ik_amd.inverse_kinematics_visitor(tol),
+                                     ik_amd.pik_parameters(max_iterations=iters, step_length=step))
+        q_ref, ok_ref, it_ref = O.pik_batch(om, ot, tg, q0, O.pik_params(iters, step, tol, [0.1, 1.0]), os.cpu_count() or 1)
+        assert np.array_equal(ok.cpu().numpy(), ok_ref) and np.array_equal(it.cpu().numpy(), it_ref), iters
+        assert np.abs(Q.cpu().numpy().T - q_ref).max() <= TOL, iters
+    # one problem through ik::pik(), targets read from the task objects
+    fl.target = ik_amd.SE3.from12(tg[5, 0])
+    pelvis.target = ik_amd.SE3.from12(tg[5, 1])
+    align.target[:] = tg[5, 2, 9:]
+    q1 = ik_amd.pik(problem, q0[5], data, ik_amd.inverse_kinematics_visitor(1e-4), ik_amd.pik_parameters(max_iterations=200, step_length=0.1))
+    q1_ref, ok1_ref, it1_ref = O.pik(om, ot, tg[5], q0[5], O.pik_params(200, 0.1, 1e-4, [0.1, 1.0]))
+    assert np.abs(q1 - q1_ref).max() <= TOL and data.success == ok1_ref and data.iterations == it1_ref
+
+
 def test_single_problem_pik_with_edited_lambda_and_da(torch_cuda):
     """ik::pik() as a caller of the reference would use it: pik_data owns lambda and da and both are read at every call."""
     import ik_amd

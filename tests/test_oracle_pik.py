@@ -132,6 +132,24 @@ def test_pik_level_count_must_match(native_built):
         O.pik(om, ot, np.zeros((2, 12)), np.zeros(m.nq), O.pik_params(1, 1.0, -1.0, [1.0]))
 
 
+def test_pik_levels_without_tasks_are_no_ops(native_built):
+    """The demo declares two priority levels and puts every task on the first (reference ik_ros/src/cassie.cpp:43,72-81): the
+    reference's loop over 0..max_priority_level (ik/ik/pik.cpp:47) then meets a level with no rows, which changes nothing."""
+    m = T.load_urdf(urdf_path("cassie"), free_flyer=True)
+    om = O.OracleModel(O.flat_from_twin(m))
+    rng = np.random.default_rng(77)
+    q0, qs = T.neutral(m), T.neutral(m)
+    q0[7:] = np.clip(rng.uniform(-0.2, 0.2, m.nq - 7), m.lower[7:], m.upper[7:])
+    qs[7:] = np.clip(q0[7:] + rng.uniform(-0.1, 0.1, m.nq - 7), m.lower[7:], m.upper[7:])
+    spec = [[("LeftFootFront", "pelvis", 0, None), ("pelvis", "universe", 2, None), ("LeftFootFront", "universe", 4, None)]]
+    levels, ot, tg = _levels(m, spec, T.fk(m, qs)[1], rng)
+    qa, oka, ita = O.pik(om, ot, tg, q0, O.pik_params(25, 0.5, 1e-9, [0.1]))
+    qb, okb, itb = O.pik(om, ot, tg, q0, O.pik_params(25, 0.5, 1e-9, [0.1, 1.0]))
+    assert np.array_equal(qa, qb) and oka == okb and ita == itb
+    qt, okt, itt = T.pik(m, levels + [[]], q0, 25, 0.5, 1e-9, [0.1, 1.0])
+    assert okt == oka and itt == ita and np.abs(qt - qa).max() < 1e-10
+
+
 def test_oracle_pik_reproduces_golden_vectors(native_built):
     with open(os.path.join(HERE, "golden", "P_pik.json")) as fh:
         cases = json.load(fh)
