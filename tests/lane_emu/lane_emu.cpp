@@ -3,6 +3,7 @@
 // programs and the host-side problem analysis can be checked against the oracle in the GPU-less
 // build container.  It is compiled by tests/ with g++ into its own shared object; libikgpu.so
 // neither contains nor calls it (the product has no CPU path).
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -50,8 +51,13 @@ void run_chain(const ikgpu::ProblemHost &ph, const IO &io) {
         a.prm.step_length = io.prm->step_length;
         a.prm.stop_sq_tol = io.prm->stop_sq_tol;
     }
+    // LANE_EMU_TRIG = 0 / 2 / 3: run the device's general build (SMASK = 0) with that LoopParams::trig, i.e. the loops that
+    // take sin / cos by dsincos_bounded<2 / 3>; unset: the runtime-parameter build (SMASK = -1), dsincos throughout
+    const char *tr = std::getenv("LANE_EMU_TRIG");
+    if (tr) a.prm.trig = std::atoi(tr);
     for (int64_t b = 0; b < io.B; ++b) {
-        if (io.mode == 0) ikdev::dls_chain_body<NJ, KT>(a, d, b, [](bool act) { return act; });
+        if (io.mode == 0 && tr) ikdev::dls_chain_body<NJ, KT, 0>(a, d, b, [](bool act) { return act; });
+        else if (io.mode == 0) ikdev::dls_chain_body<NJ, KT>(a, d, b, [](bool act) { return act; });
         else if (io.mode == 1) ikdev::eval_chain_body<NJ, KT>(a, d, b);
         else ikdev::fk_chain_body<NJ>(a, d, b);
     }
@@ -132,6 +138,15 @@ void run_generic(const ikgpu::ProblemHost &ph, const IO &io) {
 extern "C" {
 
 const char *lane_emu_last_error(void) { return g_err.c_str(); }
+
+// The device's sin / cos routines (device/lane_math.hpp): D = 0: dsincos, D = 2 / 3: dsincos_bounded<D>.
+void lane_emu_sincos(int D, int64_t n, const double *x, double *s, double *c) {
+    for (int64_t i = 0; i < n; ++i) {
+        if (D == 2) ikdev::dsincos_bounded<2>(x[i], s[i], c[i]);
+        else if (D == 3) ikdev::dsincos_bounded<3>(x[i], s[i], c[i]);
+        else ikdev::dsincos(x[i], s[i], c[i]);
+    }
+}
 
 // Host pointers, same layouts as include/ikgpu.h.  tasks must be in stacking order.
 int lane_emu_run(const char *urdf, size_t len, int root_joint, const ikgpu_task *tasks, int ntasks, int mode, int64_t B,

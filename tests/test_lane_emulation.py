@@ -89,6 +89,39 @@ def test_lane_program_full_loop(emu, name, frame, iters, tol):
     assert np.array_equal(qo2.T, qo) and np.array_equal(ok2, ok) and np.array_equal(it2, it)
 
 
+def test_bounded_sincos_accuracy(emu):
+    """dsincos_bounded<D> (device/lane_math.hpp): no range reduction, valid on |x| <= 2^D pi/4 plus the slack trig_bound() allows."""
+    p = lambda a: C.c_void_p(a.ctypes.data)
+    for D, lim in ((2, np.pi + 0.05), (3, 2 * np.pi + 0.05), (0, 50.0)):
+        x = np.concatenate([np.linspace(-lim, lim, 400001), [0.0, -0.0, 1e-300, np.pi / 4, -np.pi / 2, min(lim, np.pi)]])
+        s, c = np.empty_like(x), np.empty_like(x)
+        emu.lane_emu_sincos(D, C.c_int64(x.size), p(x), p(s), p(c))
+        assert np.abs(s - np.sin(x)).max() < 2e-15 and np.abs(c - np.cos(x)).max() < 2e-15, D
+        assert np.abs(s * s + c * c - 1.0).max() < 5e-15
+    s0, c0 = np.empty(1), np.empty(1)
+    emu.lane_emu_sincos(2, C.c_int64(1), p(np.zeros(1)), p(s0), p(c0))
+    assert s0[0] == 0.0 and c0[0] == 1.0
+
+
+@pytest.mark.parametrize("name,frame,trig", [("cassie_fixed", "LeftFootFront", 2), ("cassie_fixed", "LeftFootFront", 3),
+                                             ("ur5", "tool0", 3), ("cassie_fixed", "LeftFootFront", 0)])
+@pytest.mark.parametrize("iters,tol", [(50, -1.0), (100, 1e-4), (1, -1.0)])
+def test_lane_program_with_bounded_trig(emu, monkeypatch, name, frame, trig, iters, tol):
+    """The loops the device runs when every chain joint's limits lie within [-pi, pi] (Cassie: trig = 2) or [-2 pi, 2 pi]
+    (UR5: trig = 3): sin / cos by dsincos_bounded.  A lane whose q0 lies beyond the bound sends its wave -- here, itself --
+    to the general loop, so such a q0 is still solved correctly."""
+    from ik_amd import capi
+    urdf, model, om, task, ot, q0, qs, tg = setup(name, frame, B=192, mode="near")
+    q0[::7, 2] += 7.0          # some first evaluations far outside the bound (q0 is not clamped before the first FK)
+    prm = capi.DlsParams(iters, 1e-2, 1.0, tol)
+    monkeypatch.setenv("LANE_EMU_TRIG", str(trig))
+    qo, ok, it, *_ = run(emu, urdf, task, 0, q0, tg, prm, model.nv, 6)
+    monkeypatch.delenv("LANE_EMU_TRIG")
+    q_ref, ok_ref, it_ref = O.dls_batch(om, ot, tg, q0, O.params(iters, 1e-2, 1.0, tol))
+    assert np.array_equal(ok, ok_ref) and np.array_equal(it, it_ref)
+    assert np.abs(qo - q_ref).max() < 1e-9
+
+
 @pytest.mark.parametrize("ktype,weights", [(0, None), (1, None), (2, [1.0, 2.0, 0.5, 1.5, 1.0, 3.0]), (1, [2.0, 1.0, 0.25])])
 def test_lane_program_types_and_weights(emu, ktype, weights):
     from ik_amd import capi
