@@ -63,21 +63,7 @@ IKD_FN void dls_chain_body(const ChainKernelArgs<NJ> &a, const ChainDesc<NJ> &d,
 
     int iters;
     bool success;
-    if constexpr (SMASK >= 0) {
-        // q is clamped to the joint limits after every step, so when those lie within [-pi, pi] (or [-2 pi, 2 pi]) the
-        // iteration can take sin / cos without range reduction (dsincos_bounded).  The first evaluation is at q0 as given,
-        // which the reference does not clamp: a wave holding a q0 beyond the bound keeps the general loop.
-        const int trig = a.prm.trig;
-        bool inside = true;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) inside = inside && (__builtin_fabs(q[j]) <= trig_bound(trig));
-        const bool general = (trig == 0) || any_active(!inside);  // wave-uniform
-        if (general) chain_dls<NJ, KT, SMASK>(d, a.prm, q, oMt, iters, success, any_active);
-        else if (trig == 2) chain_dls<NJ, KT, SMASK | (2 << kSpecTrig)>(d, a.prm, q, oMt, iters, success, any_active);
-        else chain_dls<NJ, KT, SMASK | (3 << kSpecTrig)>(d, a.prm, q, oMt, iters, success, any_active);
-    } else {
-        chain_dls<NJ, KT, SMASK>(d, a.prm, q, oMt, iters, success, any_active);
-    }
+    chain_dls<NJ, KT, SMASK>(d, a.prm, q, oMt, iters, success, any_active);
 
     if (!valid) return;
 #pragma unroll

@@ -38,14 +38,9 @@ struct LoopParams {
     int priority;        // priority level of the task (the stop test reads priority-0 rows only)
     int idmask;          // bit j: placement pl[j] has an exactly-identity rotation; bit NJ: frame_pl has
     int unit_weights;    // every Task::weighting() entry is exactly 1
-    int trig;            // D = 2 / 3: the limits of every chain joint lie within [-2^D pi/4, 2^D pi/4]; 0: they do not
 };
 
 constexpr int kSpecUnit = 30;
-constexpr int kSpecTrig = 27;  // two bits: 0 = dsincos (any angle), D = 2 / 3 = dsincos_bounded<D> (lane_math.hpp)
-
-// The bound dsincos_bounded<D> is good for, with the slack its polynomials tolerate (error < 2e-15 up to here).
-IKD_FN constexpr double trig_bound(int D) { return (D == 2 ? 3.14159265358979323846 : 6.28318530717958647692) + 0.05; }
 
 template <int KT>
 struct TaskDim {
@@ -75,9 +70,8 @@ IKD_FN void chain_evaluate(const ChainDesc<NJ> &d, const double (&q)[NJ], const 
     for (int j = 0; j < NJ; ++j) {
         if (j > 0) se3_compose_const(R, p, d.pl[j], SMASK >= 0 ? ((SMASK >> j) & 1) != 0 : ((idmask >> j) & 1) != 0);
         double s, c;
-        constexpr int kTrig = SMASK >= 0 ? ((SMASK >> kSpecTrig) & 3) : 0;
-        if constexpr (kTrig == 0) dsincos(q[j], s, c);
-        else dsincos_bounded<kTrig>(q[j], s, c);
+        if constexpr (SMASK < 0) dsincos(q[j], s, c);  // stage kernels and the runtime-parameter build
+        else dsincos_fast(q[j], s, c);                 // the device's iteration loops
         rot_z_right(R, s, c);
         zax[j][0] = R[2]; zax[j][1] = R[5]; zax[j][2] = R[8];
         org[j][0] = p[0]; org[j][1] = p[1]; org[j][2] = p[2];

@@ -131,11 +131,10 @@ IKD_FN void dsincos(double x, double &s_out, double &c_out) {
     c_out = ((n + 1) & 2) ? -c0 : c0;
 }
 
-// sin and cos of an argument known to be bounded, |x| <= 2^DBL * pi/4 (DBL = 2: pi, DBL = 3: 2 pi) -- a revolute joint
-// whose limits lie inside that range, since q is clamped to its limits after every step.  No range reduction and no
-// quadrant selects: the same fdlibm kernels at x / 2^DBL, then DBL angle doublings s' = 2 s c, c' = 1 - 2 s^2.
-// 22 (DBL = 2) / 25 (DBL = 3) FP64 instructions and no integer ones, against 32 + 14 for dsincos.  Absolute error
-// < 1e-15 on the whole range (tests/test_lane_emulation.py); the caller guards the range.
+// sin and cos of a bounded argument, |x| <= 2^DBL * pi/4 (DBL = 2: pi, DBL = 3: 2 pi).  No quadrant selects: the same
+// fdlibm kernels at x / 2^DBL, then DBL angle doublings s' = 2 s c, c' = 1 - 2 s^2.  22 (DBL = 2) / 25 (DBL = 3) FP64
+// instructions and no integer ones.  Absolute error < 2e-15 on the whole range (tests/test_lane_emulation.py); the caller
+// guarantees the range (dsincos_fast reduces by 2 pi first).
 template <int DBL>
 IKD_FN void dsincos_bounded(double x, double &s_out, double &c_out) {
     const double t = x * (1.0 / static_cast<double>(1 << DBL));
@@ -161,6 +160,19 @@ IKD_FN void dsincos_bounded(double x, double &s_out, double &c_out) {
     }
     s_out = s;
     c_out = c;
+}
+
+// sin and cos of any argument for the iteration loops: Cody-Waite reduction by 2 pi into [-pi, pi] (two FMAs, exact enough
+// for |x| <~ 1e5 like dsincos), then dsincos_bounded<2>.  26 FP64 instructions, no integer ones, no selects, against
+// 32 + 14 for dsincos; absolute error < 2e-15.
+IKD_FN void dsincos_fast(double x, double &s_out, double &c_out) {
+    constexpr double kOneOverTwoPi = 0.15915494309189533577;
+    constexpr double kTwoPiHi = 6.28318530717958623200e+00;  // 2 * kPio2Hi * 2, exactly representable splits of 2 pi
+    constexpr double kTwoPiLo = 2.44929359829470641435e-16;
+    const double k = __builtin_rint(x * kOneOverTwoPi);
+    double r = dfma(-k, kTwoPiHi, x);
+    r = dfma(-k, kTwoPiLo, r);
+    dsincos_bounded<2>(r, s_out, c_out);
 }
 
 // acos on [-1, 1] (fdlibm e_acos rational approximation, divisions by drcp).

@@ -199,7 +199,8 @@ struct LegFactor {
 
 // Evaluate one chain task at the current configuration, add its base-block contributions to
 // (Hbb, gb), eliminate its NJ joint unknowns (Schur complement onto the base) and return the factor.
-template <int NJ>
+// FAST: sin / cos by dsincos_fast (the device loops) instead of dsincos (runtime-parameter build), lane_math.hpp.
+template <int NJ, bool FAST = false>
 IKD_FN void leg_eval_factor(const double (&R1)[9], const double (&p1)[3], const double (*pl)[12], const double *frame_pl,
                             const double *w6, int idmask, bool unit, const double (&q)[NJ], const double (&oMt)[12],
                             double lam2, bool prio0, const AlignRow &al, double (&Hbb)[21], double (&gb)[6], double &e0sq,
@@ -214,7 +215,8 @@ IKD_FN void leg_eval_factor(const double (&R1)[9], const double (&p1)[3], const 
     for (int j = 0; j < NJ; ++j) {
         se3_compose_const(R, p, pl[j], (idmask >> j) & 1);
         double s, c;
-        dsincos(q[j], s, c);
+        if constexpr (FAST) dsincos_fast(q[j], s, c);
+        else dsincos(q[j], s, c);
         rot_z_right(R, s, c);
         zax[j][0] = R[2]; zax[j][1] = R[5]; zax[j][2] = R[8];
         org[j][0] = p[0]; org[j][1] = p[1]; org[j][2] = p[2];
@@ -487,7 +489,7 @@ IKD_FN void tree_dls(const TreeDesc<NJ, NCH> &d, const TreeParams &prm, double (
                     al.tn[0] = tx * inv; al.tn[1] = ty * inv; al.tn[2] = tz * inv;
                 }
             }
-            leg_eval_factor<NJ>(R1, p1, ct.pl, ct.fr, ct.w, SPEC >= 0 ? (SPEC & ((2 << NJ) - 1)) : prm.idmask[c],
+            leg_eval_factor<NJ, (SPEC >= 0)>(R1, p1, ct.pl, ct.fr, ct.w, SPEC >= 0 ? (SPEC & ((2 << NJ) - 1)) : prm.idmask[c],
                                 SPEC >= 0 ? ((SPEC >> kSpecUnit) & 1) != 0 : prm.unit[c] != 0, q, oMt, prm.lam2, prm.prio[c] == 0, al,
                                 Hbb, gb, e0sq, F);
             if (NCH > 1 && c == 0) park.store(F);

@@ -63,22 +63,10 @@ __global__ __launch_bounds__(kBlock) void fk_chain_kernel(const ChainKernelArgs<
     ikdev::fk_chain_body<NJ>(a, d, static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x);
 }
 
-// Which dsincos_bounded<D> the joint limits of a chain allow (device/chain_solver.hpp: LoopParams::trig): q never leaves the
-// limits once the first step is taken.  IKGPU_TRIG=general keeps the range-reducing dsincos (tests compare the two).
-int trig_class(const ikgpu::ChainHost &c) {
-    const char *force = std::getenv("IKGPU_TRIG");
-    if (force && std::string(force) == "general") return 0;
-    double m = 0.0;
-    for (int j = 0; j < c.nj; ++j) m = std::max(m, std::max(std::fabs(c.lo[j]), std::fabs(c.hi[j])));
-    if (!(m <= ikdev::trig_bound(3))) return 0;  // also NaN / infinite limits
-    return m <= ikdev::trig_bound(2) ? 2 : 3;
-}
-
 template <int NJ>
 ChainKernelArgs<NJ> make_args(const ProblemHost &ph, const DeviceTables &dt) {
     ChainKernelArgs<NJ> a{};
     fill_chain_args(ph, a.ref_pl, a.qidx, a.vidx, &a.nq, &a.nv, &a.prm.priority, &a.prm.idmask, &a.prm.unit_weights);
-    a.prm.trig = trig_class(ph.chain);
     a.desc = reinterpret_cast<const ChainDesc<NJ> *>(dt.chain_desc);
     a.lower = dt.lower;
     a.upper = dt.upper;

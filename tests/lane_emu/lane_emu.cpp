@@ -51,10 +51,9 @@ void run_chain(const ikgpu::ProblemHost &ph, const IO &io) {
         a.prm.step_length = io.prm->step_length;
         a.prm.stop_sq_tol = io.prm->stop_sq_tol;
     }
-    // LANE_EMU_TRIG = 0 / 2 / 3: run the device's general build (SMASK = 0) with that LoopParams::trig, i.e. the loops that
-    // take sin / cos by dsincos_bounded<2 / 3>; unset: the runtime-parameter build (SMASK = -1), dsincos throughout
+    // LANE_EMU_TRIG set: run the device's general build (SMASK = 0: compile-time "skip nothing", sin / cos by dsincos_fast);
+    // unset: the runtime-parameter build (SMASK = -1), dsincos throughout
     const char *tr = std::getenv("LANE_EMU_TRIG");
-    if (tr) a.prm.trig = std::atoi(tr);
     for (int64_t b = 0; b < io.B; ++b) {
         if (io.mode == 0 && tr) ikdev::dls_chain_body<NJ, KT, 0>(a, d, b, [](bool act) { return act; });
         else if (io.mode == 0) ikdev::dls_chain_body<NJ, KT>(a, d, b, [](bool act) { return act; });
@@ -105,8 +104,10 @@ void run_tree(const ikgpu::ProblemHost &ph, const IO &io) {
         a.prm.step_length = io.prm->step_length;
         a.prm.stop_sq_tol = io.prm->stop_sq_tol;
     }
+    const char *tr = std::getenv("LANE_EMU_TRIG");  // set: the device's general build (SPEC = 0), which takes sin / cos by dsincos_fast
     for (int64_t b = 0; b < io.B; ++b) {
-        if (io.mode == 0) ikdev::dls_tree_body<NJ, NCH>(a, d, b, HostPark<NJ>{}, [](bool act) { return act; });
+        if (io.mode == 0 && tr) ikdev::dls_tree_body<NJ, NCH, 0>(a, d, b, HostPark<NJ>{}, [](bool act) { return act; });
+        else if (io.mode == 0) ikdev::dls_tree_body<NJ, NCH>(a, d, b, HostPark<NJ>{}, [](bool act) { return act; });
         else ikdev::eval_tree_body<NJ, NCH>(a, d, b);
     }
 }
@@ -139,10 +140,11 @@ extern "C" {
 
 const char *lane_emu_last_error(void) { return g_err.c_str(); }
 
-// The device's sin / cos routines (device/lane_math.hpp): D = 0: dsincos, D = 2 / 3: dsincos_bounded<D>.
+// The device's sin / cos routines (device/lane_math.hpp): D = 0: dsincos, D = 1: dsincos_fast, D = 2 / 3: dsincos_bounded<D>.
 void lane_emu_sincos(int D, int64_t n, const double *x, double *s, double *c) {
     for (int64_t i = 0; i < n; ++i) {
-        if (D == 2) ikdev::dsincos_bounded<2>(x[i], s[i], c[i]);
+        if (D == 1) ikdev::dsincos_fast(x[i], s[i], c[i]);
+        else if (D == 2) ikdev::dsincos_bounded<2>(x[i], s[i], c[i]);
         else if (D == 3) ikdev::dsincos_bounded<3>(x[i], s[i], c[i]);
         else ikdev::dsincos(x[i], s[i], c[i]);
     }

@@ -89,10 +89,11 @@ def test_lane_program_full_loop(emu, name, frame, iters, tol):
     assert np.array_equal(qo2.T, qo) and np.array_equal(ok2, ok) and np.array_equal(it2, it)
 
 
-def test_bounded_sincos_accuracy(emu):
-    """dsincos_bounded<D> (device/lane_math.hpp): no range reduction, valid on |x| <= 2^D pi/4 plus the slack trig_bound() allows."""
+def test_device_sincos_accuracy(emu):
+    """device/lane_math.hpp: dsincos (0), dsincos_fast (1: reduction by 2 pi, then) dsincos_bounded<D> (2, 3: the fdlibm kernels
+    at x / 2^D and D angle doublings, valid on |x| <= 2^D pi/4 and a little beyond)."""
     p = lambda a: C.c_void_p(a.ctypes.data)
-    for D, lim in ((2, np.pi + 0.05), (3, 2 * np.pi + 0.05), (0, 50.0)):
+    for D, lim in ((2, np.pi + 0.05), (3, 2 * np.pi + 0.05), (0, 50.0), (1, 50.0), (1, 3000.0)):   # 1: dsincos_fast, any angle
         x = np.concatenate([np.linspace(-lim, lim, 400001), [0.0, -0.0, 1e-300, np.pi / 4, -np.pi / 2, min(lim, np.pi)]])
         s, c = np.empty_like(x), np.empty_like(x)
         emu.lane_emu_sincos(D, C.c_int64(x.size), p(x), p(s), p(c))
@@ -103,18 +104,16 @@ def test_bounded_sincos_accuracy(emu):
     assert s0[0] == 0.0 and c0[0] == 1.0
 
 
-@pytest.mark.parametrize("name,frame,trig", [("cassie_fixed", "LeftFootFront", 2), ("cassie_fixed", "LeftFootFront", 3),
-                                             ("ur5", "tool0", 3), ("cassie_fixed", "LeftFootFront", 0)])
+@pytest.mark.parametrize("name,frame", [("cassie_fixed", "LeftFootFront"), ("ur5", "tool0")])
 @pytest.mark.parametrize("iters,tol", [(50, -1.0), (100, 1e-4), (1, -1.0)])
-def test_lane_program_with_bounded_trig(emu, monkeypatch, name, frame, trig, iters, tol):
-    """The loops the device runs when every chain joint's limits lie within [-pi, pi] (Cassie: trig = 2) or [-2 pi, 2 pi]
-    (UR5: trig = 3): sin / cos by dsincos_bounded.  A lane whose q0 lies beyond the bound sends its wave -- here, itself --
-    to the general loop, so such a q0 is still solved correctly."""
+def test_lane_program_device_general_build(emu, monkeypatch, name, frame, iters, tol):
+    """The device's general chain build (SMASK = 0: compile-time "skip nothing", sin / cos by dsincos_fast -- reduction by
+    2 pi and angle doubling), also from configurations more than a turn away from the joint limits."""
     from ik_amd import capi
     urdf, model, om, task, ot, q0, qs, tg = setup(name, frame, B=192, mode="near")
-    q0[::7, 2] += 7.0          # some first evaluations far outside the bound (q0 is not clamped before the first FK)
+    q0[::7, 2] += 7.0          # the first evaluation is at q0 as given (the reference does not clamp it)
     prm = capi.DlsParams(iters, 1e-2, 1.0, tol)
-    monkeypatch.setenv("LANE_EMU_TRIG", str(trig))
+    monkeypatch.setenv("LANE_EMU_TRIG", "0")
     qo, ok, it, *_ = run(emu, urdf, task, 0, q0, tg, prm, model.nv, 6)
     monkeypatch.delenv("LANE_EMU_TRIG")
     q_ref, ok_ref, it_ref = O.dls_batch(om, ot, tg, q0, O.params(iters, 1e-2, 1.0, tol))
@@ -204,6 +203,22 @@ def test_tree_program_full_loop(emu, iters, tol):
     assert np.array_equal(ok, ok_ref) and np.array_equal(it, it_ref)
     assert np.abs(qo - q_ref).max() < 1e-9
     assert np.abs(np.linalg.norm(qo[:, 3:7], axis=1) - 1).max() < 1e-12
+
+
+@pytest.mark.parametrize("iters,tol", [(1, -1.0), (50, -1.0), (100, 1e-4)])
+def test_tree_program_device_general_build(emu, monkeypatch, iters, tol):
+    """The device's general tree build (SPEC = 0: compile-time "skip nothing", sin / cos by dsincos_fast), also from
+    configurations several turns away from the joint limits."""
+    from ik_amd import capi
+    urdf, model, om, tasks, ot, q0, qs, tg, fids = setup_full_body(40)
+    q0[::5, 9] += 11.0         # LeftHipPitch far outside its limits at the first evaluation (q0 is not clamped before it)
+    prm = capi.DlsParams(iters, 1e-2, 1.0, tol)
+    monkeypatch.setenv("LANE_EMU_TRIG", "0")
+    qo, ok, it, *_ = run(emu, urdf, tasks, 0, q0, tg, prm, model.nv, 18, root=1, ntasks=3)
+    monkeypatch.delenv("LANE_EMU_TRIG")
+    q_ref, ok_ref, it_ref = O.dls_batch(om, ot, tg, q0, O.params(iters, 1e-2, 1.0, tol))
+    assert np.array_equal(ok, ok_ref) and np.array_equal(it, it_ref)
+    assert np.abs(qo - q_ref).max() < 1e-9
 
 
 def test_tree_program_types_weights_priorities(emu):

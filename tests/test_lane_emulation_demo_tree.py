@@ -47,3 +47,19 @@ def test_tree_program_with_the_demo_extras_matches_oracle(emu, case):  # noqa: F
     qg, *_ = run(emu, urdf, tasks, 0, q0, tg, prm, model.nv, M, root=3, ntasks=nt)
     assert np.abs(qg - qo).max() < 1e-8
     assert ik_amd is not None
+
+
+@pytest.mark.parametrize("case", ["demo", "two_chains_in_the_pelvis_frame"])
+def test_device_general_build_with_the_demo_extras(emu, monkeypatch, case):  # noqa: F811
+    """The same problems through the device's general build (SPEC = 0: compile-time "skip nothing", sin / cos by dsincos_fast),
+    the build the GPU runs for them; the test above runs the all-runtime build (SPEC = -1)."""
+    from ik_amd import capi
+    specs = CASES[case]
+    urdf, model, om, tasks, ot, q0, tg, M = _generic_case("cassie", True, specs, 24, seed=6)
+    monkeypatch.setenv("LANE_EMU_TRIG", "0")
+    for iters, damping, step, tol in ((1, 1e-2, 1.0, -1.0), (60, 1e-1, 0.3, 1e-6)):
+        prm = capi.DlsParams(iters, damping, step, tol)
+        qo, ok, it, *_ = run(emu, urdf, tasks, 0, q0, tg, prm, model.nv, M, root=1, ntasks=len(tasks))
+        q_ref, ok_ref, it_ref = O.dls_batch(om, ot, tg, q0, O.params(iters, damping, step, tol))
+        assert np.array_equal(ok, ok_ref) and np.array_equal(it, it_ref), (case, iters)
+        assert np.abs(qo - q_ref).max() < 1e-8, (case, iters)
