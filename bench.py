@@ -138,6 +138,8 @@ def main():
     ap.add_argument("--workload", default="cassie_leg", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--gather", action="store_true", help="run the all-gather step even at N = 1 (rehearsal)")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="launch nothing but the warm-up and timed steps (profiling passes: every dispatch is the same launch)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -290,7 +292,9 @@ def main():
                                     "frac": tf / FP64_VALU_PEAK_TF, "flop_per_solve": flops,
                                     "counting": "executed FP64 VALU instructions per launch from the SQ_INSTS_VALU_{FMA,MUL,ADD,"
                                                 "TRANS}_F64 counters (x 64 lanes, FMA = 2), 50 iterations; profiles/r01_pmc"}
-        if world == 1 and not use_pik:
+        if args.timed_only:
+            args.no_cpu = True
+        if world == 1 and not use_pik and not args.timed_only:
             # secondary figures of SURVEY.md 8d, outside the timed region: the library's default stop rule
             # (reference ik/ik/visitor.hpp:15-21, tolerance 1e-4 on the squared priority-0 error; max_iterations 100,
             # reference ik/ik/common.hpp:59-66) and the cold path URDF text -> device handle

@@ -4,7 +4,7 @@
 set -u
 W="$1"; OUT="$GRAFT_REPO_ROOT/gpurun_out/$2"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-run() { name="$1"; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 5 --warmup 2 --no-cpu --workload "$W" > "$OUT/$name.log" 2>&1 || echo "pass $name failed"; }
+run() { name="$1"; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 5 --warmup 2 --timed-only --workload "$W" > "$OUT/$name.log" 2>&1 || echo "pass $name failed"; }
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS
