@@ -112,3 +112,44 @@ def test_hip_graph_capture_and_replay(ctx):
     torch.cuda.synchronize()
     ref2, _, _ = ik.dls_batch(ctx["problem"], Q0, T, ctx["data"])
     assert torch.equal(out[0], ref2)
+
+
+def test_config4_batch_and_a_million_problems_are_batch_size_independent(ctx):
+    """BASELINE.json's largest batch (config 4: 262144 problems, there spread over eight GPUs) and four times that on one GPU:
+    a problem's result does not depend on the batch it travels in (bit-identical with the same problem in a batch of 4096), and
+    reachable targets are reached (FK(q) = target) in every lane."""
+    torch, ik = ctx["torch"], ctx["ik"]
+    from ik_amd import workload
+    model, problem, data = ctx["model"], ctx["problem"], ctx["data"]
+    p = ik.dls_parameters(max_iterations=50)
+    small = None
+    for B in (4096, 262144, 1 << 20):
+        q0, qs = workload.chain_workload(model.lowerPositionLimit, model.upperPositionLimit, workload.cassie_nominal(model.names),
+                                         np.arange(B), 0, "near")
+        Q0 = torch.from_numpy(np.ascontiguousarray(q0.T)).cuda()
+        T = ik.task_frames_fk_batch(problem, torch.from_numpy(np.ascontiguousarray(qs.T)).cuda(), data)
+        Q, ok, it = ik.dls_batch(problem, Q0, T, data, ik.never_stop_visitor(), p)
+        assert (ik.task_frames_fk_batch(problem, Q, data) - T).abs().max().item() < 1e-9
+        assert not ok.any() and bool((it == 50).all())
+        if small is None:
+            small = Q.clone()
+        else:
+            assert torch.equal(Q[:, :4096], small)
+
+
+def test_a_nan_lane_stays_alone(ctx):
+    """Lanes are independent: a problem whose q0 or target holds a NaN leaves the results of its 63 wave neighbours
+    bit-identical.  (What the NaN problem itself returns is not specified by the reference: its clamp, like the oracle's and the
+    kernel's, may turn a NaN joint value into a joint limit.)"""
+    torch, ik = ctx["torch"], ctx["ik"]
+    q0, tg = ctx["inputs"](256)
+    Q0, T = ctx["dev"](q0, tg)
+    Q, ok, it = ik.dls_batch(ctx["problem"], Q0, T, ctx["data"])
+    Q0b, Tb = Q0.clone(), T.clone()
+    Q0b[2, 70] = float("nan")        # a chain joint of problem 70
+    Tb[0, 9, 133] = float("nan")     # the target translation of problem 133
+    Qb, okb, itb = ik.dls_batch(ctx["problem"], Q0b, Tb, ctx["data"])
+    keep = torch.ones(256, dtype=torch.bool, device="cuda")
+    keep[70] = keep[133] = False
+    assert torch.equal(Qb[:, keep], Q[:, keep]) and torch.equal(okb[keep], ok[keep]) and torch.equal(itb[keep], it[keep])
+    assert okb[133].item() == 0      # a NaN target never passes the stop test
