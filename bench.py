@@ -8,7 +8,7 @@ B per GPU is fixed.  Default workload = the one the metric is quoted on: Cassie 
 B = 65536, 50 iterations.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--iters I]
-                    [--workload cassie_leg|cassie_full_body|ur5|ur10|cassie_demo|cassie_demo_pik] [--no-cpu]
+                    [--workload cassie_leg|cassie_full_body|ur5|ur10|cassie_demo|cassie_demo_posture|cassie_demo_pik] [--no-cpu]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line.
@@ -53,6 +53,14 @@ WORKLOADS = {
                                ("align", "LeftFootFront", 1, "universe")],
                         text="Cassie demo task set (cassie.urdf + free-flyer): LeftFootFront position w.r.t. the pelvis, pelvis "
                              "SE(3) pose, LeftFootFront Y-axis alignment (M=10)"),
+    # ... with the posture regulariser the demo declares and leaves commented out (cassie.cpp:63-64,76: all 16 joints, priority 1):
+    # the tree kernel's posture build
+    "cassie_demo_posture": dict(urdf="cassie", free_flyer=True, frames=["LeftFootFront", "pelvis", "LeftFootFront"], nq=23,
+                                tasks=[("frame", "LeftFootFront", 0, "pelvis"), ("frame", "pelvis", 2, "universe"),
+                                       ("align", "LeftFootFront", 1, "universe")],
+                                posture=dict(nj=16, priority=1, weight=0.05),
+                                text="Cassie demo task set (foot position w.r.t. the pelvis, pelvis SE(3) pose, foot Y-axis alignment) + a "
+                                     "PostureTask on all 16 joints at priority 1, weight 0.05 (M=26)"),
     # the same tasks through the reference's other solver, ik::pik (reference ik/ik/pik.cpp:31-103): the alignment row at
     # priority 1, solved in the null space of the two pose tasks; damping factor 0.1 per level
     "cassie_demo_pik": dict(urdf="cassie", free_flyer=True, frames=["LeftFootFront", "pelvis", "LeftFootFront"], nq=23,
@@ -65,7 +73,8 @@ WORKLOADS = {
 
 
 def bytes_per_solve(w):
-    return 8 * w["nq"] + 96 * len(w["frames"]) + 8 * w["nq"] + 1 + 4
+    posture = 8 * w["posture"]["nj"] if w.get("posture") else 0      # one target value per posture row
+    return 8 * w["nq"] + 96 * len(w["frames"]) + posture + 8 * w["nq"] + 1 + 4
 
 
 def load_kernel_stats():
@@ -79,7 +88,7 @@ def load_kernel_stats():
 def make_inputs(name, model, idx):
     w = WORKLOADS[name]
     lo, hi = model.lowerPositionLimit, model.upperPositionLimit
-    if name in ("cassie_full_body", "cassie_demo", "cassie_demo_pik"):
+    if name in ("cassie_full_body", "cassie_demo", "cassie_demo_pik", "cassie_demo_posture"):
         return workload.freeflyer_workload(lo, hi, workload.cassie_nominal(model.names), idx, seed=0, mode="near")
     if name in ("ur5", "ur10"):
         return workload.chain_workload(lo, hi, workload.UR5_NOMINAL, idx, seed=0, mode="near")
@@ -99,8 +108,11 @@ def cpu_baseline(model, w, q0_np, tg_np, iters, budget_s=12.0):
     specs = task_specs(w)
     fids = [model.getFrameId(f) for _, f, _, _ in specs]
     prios = w.get("prios") or [0] * len(specs)
-    tasks = O.make_tasks([(model.getFrameId(f), model.getFrameId(r), (3 + t) if kind == "align" else t, p, None)
-                          for (kind, f, t, r), p in zip(specs, prios)])
+    rows = [(model.getFrameId(f), model.getFrameId(r), (3 + t) if kind == "align" else t, p, None) for (kind, f, t, r), p in zip(specs, prios)]
+    if w.get("posture"):   # one row per joint: (tangent column, index in q, IKGPU_POSTURE_ROW, priority, [weight, mask])
+        po = w["posture"]
+        rows += [(model.nv - po["nj"] + k, model.nq - po["nj"] + k, 6, po["priority"], [po["weight"], 1.0]) for k in range(po["nj"])]
+    tasks = O.make_tasks(rows)
     if w.get("solver") == "pik":
         prm = O.pik_params(iters, 1.0, -1.0, w["lam"])
         solve = O.pik_batch
@@ -165,12 +177,15 @@ def main():
     w = WORKLOADS[args.workload]
     model = ik_amd.Model.from_urdf_file(os.path.join(workload.MODELS_DIR, w["urdf"] + ".kin.urdf"), free_flyer=w["free_flyer"])
     prios = w.get("prios") or [0] * len(task_specs(w))
-    problem = ik_amd.InverseKinematicsProblem(model, max(prios))
+    problem = ik_amd.InverseKinematicsProblem(model, max(prios + ([w["posture"]["priority"]] if w.get("posture") else [])))
     for i, ((kind, f, t, r), prio) in enumerate(zip(task_specs(w), prios)):
         if kind == "align":
             problem.add_align_axis_task("t%d" % i, ik_amd.AlignAxisTask.create(model, f, ik_amd.AlignAxisType(t), r), prio)
         else:
             problem.add_frame_task("t%d" % i, ik_amd.FrameTask.create(model, f, ik_amd.KinematicType(t), r), prio)
+    if w.get("posture"):
+        posture = problem.add_posture_task("posture", ik_amd.PostureTask.create(model, w["posture"]["nj"]), w["posture"]["priority"])
+        posture.weighting()[:] = w["posture"]["weight"]
     use_pik = w.get("solver") == "pik"
     if use_pik:
         data = ik_amd.pik_data(problem, device=local_rank)
@@ -193,6 +208,10 @@ def main():
         targets[0, 9:] = torch.einsum("kib,kb->ib", Rp, pf - pp)
         targets[2, 9:] = Rf[:, 1, :]
         targets[2, :9] = torch.eye(3, dtype=torch.float64, device=dev).reshape(9, 1)
+    if w.get("posture"):   # posture target = the generating configuration (double 9 of each row's slot): consistent with the poses
+        nj = w["posture"]["nj"]
+        targets[-nj:] = 0.0
+        targets[-nj:, 9, :] = QS[model.nq - nj:]
     # two buffer sets alternate so that the all-gather of step k overlaps the solve of step k + 1
     bufs = [ikdist.ShardBuffers(model.nq, B, world, dev) for _ in range(2)]
     out = bufs[0].out()
@@ -315,7 +334,9 @@ def main():
             t = time.perf_counter()
             m2 = ik_amd.Model.from_urdf_file(os.path.join(workload.MODELS_DIR, w["urdf"] + ".kin.urdf"), free_flyer=w["free_flyer"])
             t_parse = time.perf_counter() - t
-            p2 = ik_amd.InverseKinematicsProblem(m2)
+            p2 = ik_amd.InverseKinematicsProblem(m2, w["posture"]["priority"] if w.get("posture") else 0)
+            if w.get("posture"):
+                p2.add_posture_task("posture", ik_amd.PostureTask.create(m2, w["posture"]["nj"]), w["posture"]["priority"])
             for i, (kind, f, tt, r) in enumerate(task_specs(w)):
                 if kind == "align":
                     p2.add_align_axis_task("t%d" % i, ik_amd.AlignAxisTask.create(m2, f, ik_amd.AlignAxisType(tt), r))

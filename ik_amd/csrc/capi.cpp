@@ -38,7 +38,9 @@ bool shape_built(const ikgpu::ProblemHost &ph) {
 // falls back to the generic kernel.  Throws std::runtime_error on invalid input.
 ikgpu::ProblemHost analyse(const ikgpu::Model &m, const ikgpu_task *tasks, int32_t ntasks, const ikgpu_task *cons = nullptr,
                            int32_t ncons = 0) {
-    ikgpu::ProblemHost ph = ikgpu::analyse_problem(m, tasks, ntasks, false, cons, ncons);
+    // IKGPU_DLS_KERNEL=generic skips the register-resident specialisations (the parity tests compare them with the generic kernel)
+    const char *force = std::getenv("IKGPU_DLS_KERNEL");
+    ikgpu::ProblemHost ph = ikgpu::analyse_problem(m, tasks, ntasks, force && std::strcmp(force, "generic") == 0, cons, ncons);
     if (!shape_built(ph)) ph = ikgpu::analyse_problem(m, tasks, ntasks, /*force_generic=*/true, cons, ncons);
     return ph;
 }

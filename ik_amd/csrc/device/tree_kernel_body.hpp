@@ -48,7 +48,14 @@ IKD_FN void dls_tree_body(const TreeKernelArgs<NJ, NCH> &a, const TreeDesc<NJ, N
 
     int iters;
     bool success;
-    tree_dls<NJ, NCH, SPEC>(d, a.prm, qb, qj0, qj1, tl, ts, a.tslot, iters, success, park, any_active);
+    // joints outside the chains that carry a posture row live in this lane's column of q_out while the loop runs
+    const PostureState ps{a.layout == LAYOUT_SOA ? a.q_out + b : a.q_out + b * a.nq, a.layout == LAYOUT_SOA ? a.B : 1, a.lower, a.upper,
+                          valid};
+    if ((SPEC < 0 || SPEC == (1 << kSpecPost)) && a.prm.post_on && valid) {
+        for (int k = 0; k < a.prm.post_n; ++k)
+            ps.q_lane[a.prm.post_q[k] * ps.stride] = a.q0[at(a.layout, a.B, a.nq, a.prm.post_q[k], b)];
+    }
+    tree_dls<NJ, NCH, SPEC>(d, a.prm, qb, qj0, qj1, tl, ts, a.tslot, ps, iters, success, park, any_active);
 
     if (!valid) return;
 #pragma unroll

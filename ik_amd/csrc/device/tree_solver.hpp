@@ -39,6 +39,8 @@ struct TreeDesc {
     double refpl[NCH][12];  // base joint frame -> reference frame of chain c's task (used when TreeParams::ref_base[c])
 };  // all doubles: staged HBM -> LDS as a flat table
 
+constexpr int kMaxPostOut = 32;
+
 struct TreeParams {
     int max_iterations;
     double lam2, step_length, stop_sq_tol;
@@ -54,6 +56,18 @@ struct TreeParams {
     int align_slot;          //   the target slot whose doubles 9..11 hold the direction (in the world),
     int align_prio;          //   its priority level
     double align_w;          //   and its weight
+    // posture builds only (SPEC bit kSpecPost, or -1): PostureTask rows (reference ik/ik/posture.hpp:51-68), one per joint,
+    // e = (q - target) mask w, J = w in the joint's own tangent column; all on one priority level.  A row on a chain joint
+    // adds w^2 to that joint's diagonal of the normal matrix and -w e to its right-hand side; a joint outside the chains is
+    // its own 1x1 system, dq = -w e / (w^2 + lambda^2), its q kept in the caller's q_out column between iterations.
+    int post_on;                        // the problem has posture rows
+    int post_prio;                      // their priority level
+    int post_n;                         // rows on joints outside the chains
+    int post_q[kMaxPostOut];            //   index in q,
+    int post_slot[kMaxPostOut];         //   target slot (the value is double 9 of the slot),
+    double post_w[kMaxPostOut], post_m[kMaxPostOut];  // weight and mask entry
+    int postc_slot[2][8];               // rows on chain joints: target slot, -1 where the joint carries none
+    double postc_w[2][8], postc_m[2][8];
 };
 
 // One AlignAxisTask row on a chain's task frame, reference frame = the world: e = w (1 - r . t), r = the frame's axis in the
@@ -200,11 +214,20 @@ struct LegFactor {
 // Evaluate one chain task at the current configuration, add its base-block contributions to
 // (Hbb, gb), eliminate its NJ joint unknowns (Schur complement onto the base) and return the factor.
 // FAST: sin / cos by dsincos_fast (the device loops) instead of dsincos (runtime-parameter build), lane_math.hpp.
-template <int NJ, bool FAST = false>
+// Posture rows on the joints of one chain (wave-uniform description; targets per lane).
+struct ChainPosture {
+    bool on, prio0;
+    const int *slot;        // [NJ] target slot or -1
+    const double *w, *m;    // [NJ]
+    const double *targets_lane;
+    int64_t tstride;
+};
+
+template <int NJ, bool FAST = false, bool POST = false>
 IKD_FN void leg_eval_factor(const double (&R1)[9], const double (&p1)[3], const double (*pl)[12], const double *frame_pl,
                             const double *w6, int idmask, bool unit, const double (&q)[NJ], const double (&oMt)[12],
-                            double lam2, bool prio0, const AlignRow &al, double (&Hbb)[21], double (&gb)[6], double &e0sq,
-                            LegFactor<NJ> &F) {
+                            double lam2, bool prio0, const AlignRow &al, const ChainPosture &po, double (&Hbb)[21],
+                            double (&gb)[6], double &e0sq, LegFactor<NJ> &F) {
     double zax[NJ][3], org[NJ][3];
     double R[9], p[3];
 #pragma unroll
@@ -300,6 +323,19 @@ IKD_FN void leg_eval_factor(const double (&R1)[9], const double (&p1)[3], const 
 #pragma unroll
             for (int b = 0; b <= a; ++b) Hbb[tri(3 + a, 3 + b)] = dfma(ab[a], ab[b], Hbb[tri(3 + a, 3 + b)]);
             gb[3 + a] = dfma(ab[a], ea, gb[3 + a]);
+        }
+    }
+    if (POST && po.on) {  // posture rows on this chain's joints (wave-uniform; posture builds only)
+#pragma unroll
+        for (int a = 0; a < NJ; ++a) {
+            const int slot = po.slot[a];
+            if (slot >= 0) {
+                const double w = po.w[a];
+                const double ea = (q[a] - po.targets_lane[(slot * 12 + 9) * po.tstride]) * po.m[a] * w;
+                if (po.prio0) e0sq = dfma(ea, ea, e0sq);
+                F.L[tri(a, a)] = dfma(w, w, F.L[tri(a, a)]);
+                F.u[a] = dfma(-w, ea, F.u[a]);  // negated-Jacobian convention: the row's column entry is -w
+            }
         }
     }
     IKD_SCHED_FENCE();
@@ -431,13 +467,26 @@ IKD_FN void freeflyer_integrate(const double (&qb)[7], const double (&R1)[9], co
 // SPEC >= 0: compile-time specialisation (see chain_solver.hpp) -- bits 0..NJ: identity-rotation placement mask shared
 // by the chains, bit kSpecUnit: the chain tasks are Full with unit weights, bit kSpecUnitP / kSpecIdP: the base task is
 // Full with unit weights / its frame placement is a pure translation.  SPEC = -1: runtime (wave-uniform) values.
-constexpr int kSpecUnitP = 29, kSpecIdP = 28;
+// Bit kSpecPost (alone: otherwise a general build): the posture code above is compiled in.
+constexpr int kSpecUnitP = 29, kSpecIdP = 28, kSpecPost = 26;
+
+// Where the lane keeps the joints outside the chains that carry a posture row: its own column of the caller's q_out.
+struct PostureState {
+    double *q_lane;     // element i of this lane's q at q_lane[i * stride]
+    int64_t stride;
+    const double *lower, *upper;
+    bool store;         // false for the tail lanes that shadow the last problem
+};
 
 template <int NJ, int NCH, int SPEC = -1, class Park, class AnyFn>
 IKD_FN void tree_dls(const TreeDesc<NJ, NCH> &d, const TreeParams &prm, double (&qb)[7], double (&qj0)[NJ], double (&qj1)[NJ],
-                     const double *targets_lane, int64_t tstride, const int (&tslot)[3], int &iters_out,
+                     const double *targets_lane, int64_t tstride, const int (&tslot)[3], const PostureState &ps, int &iters_out,
                      bool &success_out, Park park, AnyFn any_active) {
-    bool active = true, success = false;
+    constexpr bool kGeneral = SPEC <= 0 || SPEC == (1 << kSpecPost);  // the demo's extras exist in the general builds only
+    constexpr bool kPost = SPEC < 0 || SPEC == (1 << kSpecPost);
+    // (posture builds: a tail lane shadowing the last problem would re-read that problem's outside joints while their owner
+    // updates them -- it sits the loop out instead; nothing of it is stored anyway)
+    bool active = kPost ? ps.store : true, success = false;
     int iters = prm.max_iterations;
 #pragma unroll 1
     for (int it = 0; it < prm.max_iterations; ++it) {
@@ -463,7 +512,7 @@ IKD_FN void tree_dls(const TreeDesc<NJ, NCH> &d, const TreeParams &prm, double (
 #pragma unroll
             for (int k = 0; k < 12; ++k) oMt[k] = targets_lane[(tslot[c] * 12 + k) * tstride];
             AlignRow al{false, 0, 0.0, {0.0, 0.0, 0.0}, false};
-            if (SPEC <= 0) {  // the demo's extras exist in the general builds only (SPEC = 0 on the device, -1 = all runtime
+            if (kGeneral) {  // the demo's extras exist in the general builds only (SPEC = 0 [+ posture] on the device, -1 = all runtime
                               // in the emulator); hot builds compile none of this
                 if (prm.ref_base[c]) {  // target given in a frame on the floating base: oMt = (oM1 * refpl) * target (frame.hpp:48)
                     double Rr[9], pr[3], tg[12];
@@ -489,9 +538,11 @@ IKD_FN void tree_dls(const TreeDesc<NJ, NCH> &d, const TreeParams &prm, double (
                     al.tn[0] = tx * inv; al.tn[1] = ty * inv; al.tn[2] = tz * inv;
                 }
             }
-            leg_eval_factor<NJ, (SPEC >= 0)>(R1, p1, ct.pl, ct.fr, ct.w, SPEC >= 0 ? (SPEC & ((2 << NJ) - 1)) : prm.idmask[c],
+            const ChainPosture po{kPost && prm.post_on != 0, prm.post_prio == 0, prm.postc_slot[c], prm.postc_w[c], prm.postc_m[c],
+                                  targets_lane, tstride};
+            leg_eval_factor<NJ, (SPEC >= 0), kPost>(R1, p1, ct.pl, ct.fr, ct.w, SPEC >= 0 ? (SPEC & ((2 << NJ) - 1)) : prm.idmask[c],
                                 SPEC >= 0 ? ((SPEC >> kSpecUnit) & 1) != 0 : prm.unit[c] != 0, q, oMt, prm.lam2, prm.prio[c] == 0, al,
-                                Hbb, gb, e0sq, F);
+                                po, Hbb, gb, e0sq, F);
             if (NCH > 1 && c == 0) park.store(F);
         }
         if (prm.hasP) {
@@ -523,9 +574,30 @@ IKD_FN void tree_dls(const TreeDesc<NJ, NCH> &d, const TreeParams &prm, double (
             for (int j = 0; j <= i; ++j) S[i * 6 + j] = Hbb[tri(i, j)];
         chol_solve<6>(S, gb, dqb);
 
+        if (kPost && prm.post_on && prm.post_prio == 0) {  // posture rows on joints outside the chains: their part of e[0]
+#pragma unroll 1
+            for (int k = 0; k < prm.post_n; ++k) {
+                const double ea = (ps.q_lane[prm.post_q[k] * ps.stride] - targets_lane[(prm.post_slot[k] * 12 + 9) * tstride]) *
+                                  prm.post_m[k] * prm.post_w[k];
+                e0sq = dfma(ea, ea, e0sq);
+            }
+        }
         const bool stop_now = active && (prm.stop_sq_tol >= 0.0) && (e0sq < prm.stop_sq_tol);
         if (stop_now) { success = true; iters = it; }
         active = active && !stop_now;
+
+        if (kPost && prm.post_on) {  // ... and their step: a decoupled 1x1 system each, integrated and clamped in place
+#pragma unroll 1
+            for (int k = 0; k < prm.post_n; ++k) {
+                const int qi = prm.post_q[k];
+                const double w = prm.post_w[k];
+                const double qv = ps.q_lane[qi * ps.stride];
+                const double ea = (qv - targets_lane[(prm.post_slot[k] * 12 + 9) * tstride]) * prm.post_m[k] * w;
+                const double dq = -(w * ea) * drcp(dfma(w, w, prm.lam2));
+                const double qc = dmin(ps.upper[qi], dmax(dfma(prm.step_length, dq, qv), ps.lower[qi]));
+                if (active && ps.store) ps.q_lane[qi * ps.stride] = qc;
+            }
+        }
 
 #pragma unroll 1
         for (int c = NCH - 1; c >= 0; --c) {

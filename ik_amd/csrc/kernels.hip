@@ -265,6 +265,13 @@ TreeKernelArgs<NJ, NCH> make_tree_args(const ProblemHost &ph, const DeviceTables
     a.prm.ref_base[0] = h.ref_base[0]; a.prm.ref_base[1] = h.ref_base[1];
     a.prm.align_chain = h.align_chain; a.prm.align_axis = h.align_axis; a.prm.align_slot = h.align_slot;
     a.prm.align_prio = h.align_prio; a.prm.align_w = h.align_w;
+    static_assert(ikdev::kMaxPostOut == kMaxPostureOut && kMaxChain == 8, "TreeParams posture arrays");
+    a.prm.post_on = h.post_on; a.prm.post_prio = h.post_prio; a.prm.post_n = h.post_n;
+    for (int k = 0; k < h.post_n; ++k) {
+        a.prm.post_q[k] = h.post_q[k]; a.prm.post_slot[k] = h.post_slot[k]; a.prm.post_w[k] = h.post_w[k]; a.prm.post_m[k] = h.post_m[k];
+    }
+    for (int c = 0; c < 2; ++c)
+        for (int j = 0; j < 8; ++j) { a.prm.postc_slot[c][j] = h.postc_slot[c][j]; a.prm.postc_w[c][j] = h.postc_w[c][j]; a.prm.postc_m[c][j] = h.postc_m[c][j]; }
     a.desc = reinterpret_cast<const TreeDesc<NJ, NCH> *>(dt.chain_desc);
     a.nq = ph.nq; a.nv = ph.nv; a.ntasks = ph.ntasks;
     a.lower = dt.lower; a.upper = dt.upper; a.q_in_chain = dt.q_in_chain;
@@ -289,6 +296,7 @@ hipError_t run_dls_tree(const ProblemHost &ph, const DeviceTables &dt, const Bat
                      a.prm.unit[0] && (NCH == 1 || a.prm.unit[1]) && (!a.prm.hasP || (a.prm.unitP && (a.prm.idmaskP & 1)));
     const dim3 grid(static_cast<unsigned>((io.B + kTreeBlock - 1) / kTreeBlock));
     if (hot) hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, kHot>), grid, dim3(kTreeBlock), 0, stream, a);
+    else if (ph.has_posture) hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, (1 << ikdev::kSpecPost)>), grid, dim3(kTreeBlock), 0, stream, a);
     else hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, 0>), grid, dim3(kTreeBlock), 0, stream, a);
     return hipGetLastError();
 }

@@ -95,8 +95,8 @@ void specialise(ProblemHost &ph, const Model &m) {
     const int ntasks = ph.ntasks;
     const bool free_flyer = m.njoints() > 1 && m.joint_type[1] == IKGPU_JOINT_FREEFLYER;
     for (const ikgpu_task &t : ph.tasks) {
-        if (t.type == IKGPU_POSTURE_ROW || t.type == IKGPU_CENTRE_OF_MASS) throw Unsupported("PostureTask / CentreOfMassTask rows run on the generic kernel");
-        if (t.type > IKGPU_FULL && !free_flyer) throw Unsupported("AlignAxisTask rows on a fixed-base model run on the generic kernel");
+        if (t.type == IKGPU_CENTRE_OF_MASS) throw Unsupported("CentreOfMassTask rows run on the generic kernel");
+        if (t.type > IKGPU_FULL && !free_flyer) throw Unsupported("AlignAxisTask / PostureTask rows on a fixed-base model run on the generic kernel");
     }
     std::vector<uint8_t> in_chain(m.nq, 0);
 
@@ -129,7 +129,7 @@ void specialise(ProblemHost &ph, const Model &m) {
     int chain_frame[2] = {-1, -1};
     for (int i = 0; i < ntasks; ++i) {
         const ikgpu_task &t = ph.tasks[i];
-        if (t.type > IKGPU_FULL) continue;  // the alignment row is matched to a chain below
+        if (t.type > IKGPU_FULL) continue;  // alignment and posture rows are matched to the chains below
         const bool ref_world = m.frame_parent[t.reference] == 0 && is_identity(m.frame_placement[t.reference]);
         const bool ref_on_base = m.frame_parent[t.reference] == 1;
         if (!ref_world && !ref_on_base) throw Unsupported("reference frame neither the universe nor on the floating base");
@@ -154,7 +154,7 @@ void specialise(ProblemHost &ph, const Model &m) {
     }
     for (int i = 0; i < ntasks; ++i) {  // one AlignAxisTask row, on the frame of a chain task, direction given in the world
         const ikgpu_task &t = ph.tasks[i];
-        if (t.type <= IKGPU_FULL) continue;
+        if (t.type <= IKGPU_FULL || t.type == IKGPU_POSTURE_ROW) continue;
         if (ph.align_task >= 0) throw Unsupported("more than one AlignAxisTask");
         if (m.frame_parent[t.reference] != 0 || !is_identity(m.frame_placement[t.reference]))
             throw Unsupported("AlignAxisTask with a reference frame other than the universe");
@@ -165,10 +165,40 @@ void specialise(ProblemHost &ph, const Model &m) {
     }
     if (nchains == 0) throw Unsupported("free-flyer problem without a chain task");
     if (nchains == 2 && ph.chain.nj != ph.chainB.nj) throw Unsupported("the two chains differ in length");
+    // PostureTask rows (frame = tangent column, reference = index in q, weight[0] = weight, weight[1] = mask entry)
+    for (int c = 0; c < 2; ++c)
+        for (int j = 0; j < kMaxChain; ++j) ph.posture_chain_task[c][j] = -1;
+    std::vector<uint8_t> has_row(m.nq, 0);
+    for (int i = 0; i < ntasks; ++i) {
+        const ikgpu_task &t = ph.tasks[i];
+        if (t.type != IKGPU_POSTURE_ROW) continue;
+        if (ph.has_posture && t.priority != ph.posture_prio) throw Unsupported("posture rows on different priority levels");
+        ph.has_posture = true;
+        ph.posture_prio = t.priority;
+        const int v = t.frame, qi = t.reference;
+        if (qi < 7 || qi >= m.nq || v < 6 || v >= m.nv || qi - 7 != v - 6) throw Unsupported("posture row on the floating base");
+        if (has_row[qi]) throw Unsupported("two posture rows on one joint");
+        has_row[qi] = 1;
+        int where = -1, at = -1;
+        for (int c = 0; c < nchains && where < 0; ++c) {
+            const ChainHost &ch = c == 0 ? ph.chain : ph.chainB;
+            for (int j = 0; j < ch.nj; ++j)
+                if (ch.vidx[j] == v) { where = c; at = j; break; }
+        }
+        if (where >= 0) {
+            ph.posture_chain_task[where][at] = i;
+            ph.posture_chain_w[where][at] = t.weight[0];
+            ph.posture_chain_mask[where][at] = t.weight[1];
+        } else {
+            if (static_cast<int>(ph.posture_out.size()) == kMaxPostureOut) throw Unsupported("more posture rows outside the chains than the tree kernel takes");
+            ph.posture_out.push_back({i, qi, t.weight[0], t.weight[1]});
+            in_chain[qi] = 1;  // the kernel steps and clamps this entry itself
+        }
+    }
     ph.kind = KernelKind::Tree;
     ph.kernel_name = "dls_tree<NJ=" + std::to_string(ph.chain.nj) + ",chains=" + std::to_string(nchains) +
                      (ph.base_task >= 0 ? ",base_task" : "") + (ph.ref_base[0] || ph.ref_base[1] ? ",base_reference" : "") +
-                     (ph.align_task >= 0 ? ",align_axis" : "") + ">";
+                     (ph.align_task >= 0 ? ",align_axis" : "") + (ph.has_posture ? ",posture" : "") + ">";
     ph.q_in_chain = in_chain;
 }
 
@@ -541,6 +571,21 @@ TreeArgsHost tree_args(const ProblemHost &ph) {
         a.align_prio = t.priority;
         a.align_w = t.weight[0];
     }
+    a.post_on = ph.has_posture ? 1 : 0;
+    a.post_prio = ph.posture_prio;
+    a.post_n = static_cast<int>(ph.posture_out.size());
+    for (int k = 0; k < a.post_n; ++k) {
+        a.post_q[k] = ph.posture_out[k].qi;
+        a.post_slot[k] = ph.posture_out[k].task;
+        a.post_w[k] = ph.posture_out[k].w;
+        a.post_m[k] = ph.posture_out[k].mask;
+    }
+    for (int c = 0; c < 2; ++c)
+        for (int j = 0; j < kMaxChain; ++j) {
+            a.postc_slot[c][j] = ph.has_posture ? ph.posture_chain_task[c][j] : -1;
+            a.postc_w[c][j] = ph.posture_chain_w[c][j];
+            a.postc_m[c][j] = ph.posture_chain_mask[c][j];
+        }
     return a;
 }
 

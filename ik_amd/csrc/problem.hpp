@@ -12,6 +12,7 @@
 namespace ikgpu {
 
 constexpr int kMaxChain = 8;
+constexpr int kMaxPostureOut = 32;  // == ikdev::kMaxPostOut: posture rows on joints outside the chains the tree kernel takes
 
 // Chain:   fixed base, ONE FrameTask whose support is a serial chain of revolute joints (shapes S, U).
 // Tree:    free-flyer base, up to two chain FrameTasks + at most one on the base link (shape F).
@@ -70,7 +71,15 @@ struct ProblemHost {
     int ref_base[2] = {0, 0};
     double chain_ref_pl[2][12] = {{1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0}, {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0}};
     int align_task = -1, align_chain = -1;
-    bool tree_extras() const { return ref_base[0] || ref_base[1] || align_task >= 0; }
+    // ... and PostureTask rows (one ABI record per joint, all on one priority level): on chain joints they join the chain's
+    // normal equations, on other joints they are 1x1 systems the tree kernel steps by itself (device/tree_solver.hpp)
+    struct PostureRow { int task, qi; double w, mask; };   // task index == target slot
+    bool has_posture = false;
+    int posture_prio = 0;
+    std::vector<PostureRow> posture_out;            // joints outside the chains
+    int posture_chain_task[2][kMaxChain];           // chain joints: task index, or -1 (set by specialise())
+    double posture_chain_w[2][kMaxChain] = {}, posture_chain_mask[2][kMaxChain] = {};
+    bool tree_extras() const { return ref_base[0] || ref_base[1] || align_task >= 0 || has_posture; }
     GenericHost generic;              // Generic kind
     std::vector<ikgpu_task> constraints;  // ik::FrameConstraint list (frame, reference, type); forces the Generic kind
     int crows = 0;
@@ -104,6 +113,12 @@ struct TreeArgsHost {
     int ref_base[2];                                        // chain c's target is given in a frame on the floating base
     int align_chain, align_axis, align_slot, align_prio;    // an AlignAxisTask row on a chain's task frame (-1: none)
     double align_w;
+    // PostureTask rows (device/tree_solver.hpp: TreeParams::post_*)
+    int post_on, post_prio, post_n;
+    int post_q[kMaxPostureOut], post_slot[kMaxPostureOut];
+    double post_w[kMaxPostureOut], post_m[kMaxPostureOut];
+    int postc_slot[2][kMaxChain];
+    double postc_w[2][kMaxChain], postc_m[2][kMaxChain];
 };
 TreeArgsHost tree_args(const ProblemHost &ph);
 

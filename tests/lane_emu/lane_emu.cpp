@@ -92,6 +92,12 @@ void run_tree(const ikgpu::ProblemHost &ph, const IO &io) {
     a.prm.ref_base[0] = h.ref_base[0]; a.prm.ref_base[1] = h.ref_base[1];
     a.prm.align_chain = h.align_chain; a.prm.align_axis = h.align_axis; a.prm.align_slot = h.align_slot;
     a.prm.align_prio = h.align_prio; a.prm.align_w = h.align_w;
+    a.prm.post_on = h.post_on; a.prm.post_prio = h.post_prio; a.prm.post_n = h.post_n;
+    for (int k = 0; k < h.post_n; ++k) {
+        a.prm.post_q[k] = h.post_q[k]; a.prm.post_slot[k] = h.post_slot[k]; a.prm.post_w[k] = h.post_w[k]; a.prm.post_m[k] = h.post_m[k];
+    }
+    for (int c = 0; c < 2; ++c)
+        for (int j = 0; j < 8; ++j) { a.prm.postc_slot[c][j] = h.postc_slot[c][j]; a.prm.postc_w[c][j] = h.postc_w[c][j]; a.prm.postc_m[c][j] = h.postc_m[c][j]; }
     a.nq = ph.nq; a.nv = ph.nv; a.ntasks = ph.ntasks;
     a.lower = ph.lower.data(); a.upper = ph.upper.data(); a.q_in_chain = ph.q_in_chain.data();
     a.layout = io.layout; a.B = io.B; a.q0 = io.q0; a.targets = io.targets;
@@ -106,7 +112,9 @@ void run_tree(const ikgpu::ProblemHost &ph, const IO &io) {
     }
     const char *tr = std::getenv("LANE_EMU_TRIG");  // set: the device's general build (SPEC = 0), which takes sin / cos by dsincos_fast
     for (int64_t b = 0; b < io.B; ++b) {
-        if (io.mode == 0 && tr) ikdev::dls_tree_body<NJ, NCH, 0>(a, d, b, HostPark<NJ>{}, [](bool act) { return act; });
+        if (io.mode == 0 && tr && ph.has_posture)
+            ikdev::dls_tree_body<NJ, NCH, (1 << ikdev::kSpecPost)>(a, d, b, HostPark<NJ>{}, [](bool act) { return act; });
+        else if (io.mode == 0 && tr) ikdev::dls_tree_body<NJ, NCH, 0>(a, d, b, HostPark<NJ>{}, [](bool act) { return act; });
         else if (io.mode == 0) ikdev::dls_tree_body<NJ, NCH>(a, d, b, HostPark<NJ>{}, [](bool act) { return act; });
         else ikdev::eval_tree_body<NJ, NCH>(a, d, b);
     }

@@ -261,7 +261,13 @@ def test_posture_task_expands_to_one_row_per_joint(ik):
     slots = api._target_slots(t)
     assert slots.shape == (16, 12) and np.array_equal(slots[:, 9], t.target) and np.count_nonzero(slots) == np.count_nonzero(t.target)
     assert p.e_size(0) == 6 and p.e_size(1) == 16 and p.target_slots() == 17
-    assert ik.plan(p) == "dls_generic<M=22,nv=22,joints=17>"
+    # one chain task on a free-flyer model + posture rows: the tree kernel takes the rows (7 on the chain's joints, 9 outside)
+    assert ik.plan(p) == "dls_tree<NJ=7,chains=1,posture>"
+    fixed = ik.Model.from_urdf_file(urdf_path("cassie_fixed"))
+    pf = ik.InverseKinematicsProblem(fixed)
+    pf.add_frame_task("fl", ik.FrameTask.create(fixed, "LeftFootFront"))
+    pf.add_posture_task("posture", ik.PostureTask.create(fixed, 16))
+    assert ik.plan(pf) == "dls_generic<M=22,nv=16,joints=16>"          # a fixed-base model keeps them on the generic kernel
     with pytest.raises(ValueError):
         ik.PostureTask(m, 40)
     with pytest.raises(ValueError):

@@ -63,3 +63,49 @@ def test_device_general_build_with_the_demo_extras(emu, monkeypatch, case):  # n
         q_ref, ok_ref, it_ref = O.dls_batch(om, ot, tg, q0, O.params(iters, damping, step, tol))
         assert np.array_equal(ok, ok_ref) and np.array_equal(it, it_ref), (case, iters)
         assert np.abs(qo - q_ref).max() < 1e-8, (case, iters)
+
+
+# PostureTask rows (reference ik/ik/posture.hpp:51-68) in the tree kernel's posture build: rows on chain joints join the chain's
+# normal equations, rows on joints outside the chains are 1x1 systems stepped in place (device/tree_solver.hpp)
+POSTURE_CASES = {
+    # the demo with the regulariser its source declares and leaves commented out (ik_ros/src/cassie.cpp:63-64,76): priority 1
+    "demo_with_posture": [("LeftFootFront", "pelvis", 0, 0, None), ("pelvis", "universe", 2, 0, None), ("LeftFootFront", "universe", 4, 0, None),
+                          ("@posture", 16, 6, 1, ([1.0] * 16, [1.0] * 16))],
+    # both legs as chains, the rows at priority 0 (they enter the stop test), uneven weights, a mask with holes
+    "two_chains_posture_in_the_stop_test": [("LeftFootFront", "universe", 2, 0, None), ("RightFootFront", "universe", 2, 0, None),
+                                            ("@posture", 16, 6, 0, ([0.05 + 0.02 * k for k in range(16)], [0.0 if k in (2, 7, 12) else 1.0 for k in range(16)]))],
+    # a PostureTask over the last nine joints only (the right leg and one joint of the left), one chain, no base task
+    "posture_on_a_suffix_of_the_joints": [("LeftFootFront", "universe", 2, 0, None), ("@posture", 9, 6, 0, ([0.3] * 9, [1.0] * 9))],
+}
+
+
+@pytest.mark.parametrize("case", sorted(POSTURE_CASES))
+def test_tree_program_with_posture_rows_matches_oracle(emu, monkeypatch, case):  # noqa: F811
+    from ik_amd import capi
+    specs = POSTURE_CASES[case]
+    B = 24
+    urdf, model, om, tasks, ot, q0, tg, M = _generic_case("cassie", True, specs, B, seed=8)
+    q0[::5, 15] += 3.0      # a joint outside every chain, beyond its limit: clamped by the first step that is taken
+    nt = len(tasks)
+    buf = C.create_string_buffer(160)
+    capi.check(capi.lib().ikgpu_problem_plan(model._h, (capi.Task * nt)(*tasks), nt, buf, len(buf)))
+    assert buf.value.decode().startswith("dls_tree<NJ=7,") and buf.value.decode().endswith(",posture>"), buf.value
+    for env in (None, "0"):      # the all-runtime build, then the device's posture build (SPEC = 1 << kSpecPost)
+        if env is not None:
+            monkeypatch.setenv("LANE_EMU_TRIG", env)
+        for iters, damping, step, tol in ((0, 1e-2, 1.0, 1e-4), (1, 1e-2, 1.0, -1.0), (3, 1e-2, 1.0, -1.0), (60, 1e-1, 0.3, 1e-6), (200, 1e-1, 1e-1, 1e-4)):
+            prm = capi.DlsParams(iters, damping, step, tol)
+            qo, ok, it, *_ = run(emu, urdf, tasks, 0, q0, tg, prm, model.nv, M, root=1, ntasks=nt)
+            q_ref, ok_ref, it_ref = O.dls_batch(om, ot, tg, q0, O.params(iters, damping, step, tol))
+            assert np.array_equal(ok, ok_ref) and np.array_equal(it, it_ref), (case, env, iters)
+            assert np.abs(qo - q_ref).max() < 1e-8, (case, env, iters, np.abs(qo - q_ref).max())
+    monkeypatch.delenv("LANE_EMU_TRIG")
+    # problem-major and component-major inputs give the same bits (the outside joints live in the q_out column meanwhile)
+    prm = capi.DlsParams(25, 1e-1, 0.5, 1e-6)
+    qa, oka, ita, *_ = run(emu, urdf, tasks, 0, q0, tg, prm, model.nv, M, root=1, ntasks=nt)
+    qs, oks, its, *_ = run(emu, urdf, tasks, 0, np.ascontiguousarray(q0.T), np.ascontiguousarray(tg.transpose(1, 2, 0)), prm, model.nv, M,
+                           layout=0, root=1, ntasks=nt)
+    assert np.array_equal(qs.T, qa) and np.array_equal(oks, oka) and np.array_equal(its, ita)
+    # the forced generic program agrees
+    qg, *_ = run(emu, urdf, tasks, 0, q0, tg, prm, model.nv, M, root=3, ntasks=nt)
+    assert np.abs(qg - qa).max() < 1e-8
