@@ -30,9 +30,11 @@ struct TreeKernelArgs {
 };
 
 // B independent ik::dls() calls (reference ik/ik/dls.cpp:5-78) on a free-flyer model, lane `gid`.
+// post_lane / post_stride: where a posture build keeps the joints outside the chains between iterations -- an LDS column of
+// the lane (row k at post_lane[k * post_stride]) when the kernel has LDS to spare, else (nullptr) the lane's column of q_out.
 template <int NJ, int NCH, int SPEC = -1, class Park, class AnyFn>
 IKD_FN void dls_tree_body(const TreeKernelArgs<NJ, NCH> &a, const TreeDesc<NJ, NCH> &d, int64_t gid, Park park,
-                          AnyFn any_active) {
+                          AnyFn any_active, double *post_lane = nullptr, int64_t post_stride = 0) {
     const bool valid = gid < a.B;
     const int64_t b = valid ? gid : a.B - 1;
     double qb[7], qj0[NJ], qj1[NJ];  // chain 1's angles stay unused (zero) when NCH == 1
@@ -49,13 +51,18 @@ IKD_FN void dls_tree_body(const TreeKernelArgs<NJ, NCH> &a, const TreeDesc<NJ, N
     int iters;
     bool success;
     // joints outside the chains that carry a posture row live in this lane's column of q_out while the loop runs
-    const PostureState ps{a.layout == LAYOUT_SOA ? a.q_out + b : a.q_out + b * a.nq, a.layout == LAYOUT_SOA ? a.B : 1, a.lower, a.upper,
-                          valid};
-    if ((SPEC < 0 || SPEC == (1 << kSpecPost)) && a.prm.post_on && valid) {
+    constexpr bool kPost = SPEC < 0 || SPEC == (1 << kSpecPost);
+    const PostureState ps = post_lane ? PostureState{post_lane, post_stride, true, a.lower, a.upper, valid}
+                                      : PostureState{a.layout == LAYOUT_SOA ? a.q_out + b : a.q_out + b * a.nq,
+                                                     a.layout == LAYOUT_SOA ? a.B : 1, false, a.lower, a.upper, valid};
+    if (kPost && a.prm.post_on && valid) {
         for (int k = 0; k < a.prm.post_n; ++k)
-            ps.q_lane[a.prm.post_q[k] * ps.stride] = a.q0[at(a.layout, a.B, a.nq, a.prm.post_q[k], b)];
+            ps.q_lane[(ps.by_row ? k : a.prm.post_q[k]) * ps.stride] = a.q0[at(a.layout, a.B, a.nq, a.prm.post_q[k], b)];
     }
     tree_dls<NJ, NCH, SPEC>(d, a.prm, qb, qj0, qj1, tl, ts, a.tslot, ps, iters, success, park, any_active);
+    if (kPost && a.prm.post_on && valid && ps.by_row) {
+        for (int k = 0; k < a.prm.post_n; ++k) a.q_out[at(a.layout, a.B, a.nq, a.prm.post_q[k], b)] = ps.q_lane[k * ps.stride];
+    }
 
     if (!valid) return;
 #pragma unroll

@@ -472,20 +472,21 @@ constexpr int kSpecUnitP = 29, kSpecIdP = 28, kSpecPost = 26;
 
 // Where the lane keeps the joints outside the chains that carry a posture row: its own column of the caller's q_out.
 struct PostureState {
-    double *q_lane;     // element i of this lane's q at q_lane[i * stride]
-    int64_t stride;
+    double *q_lane;     // by_row: outside row k at q_lane[k * stride] (an LDS column of the lane); else element i of this
+    int64_t stride;     // lane's q at q_lane[i * stride] (the lane's column of the caller's q_out)
+    bool by_row;
     const double *lower, *upper;
     bool store;         // false for the tail lanes that shadow the last problem
 };
 
 // Posture rows on joints outside the chains (posture builds): each is its own 1x1 system,
 //   e = (q - target) mask w,   dq = -w e / (w^2 + lambda^2),   q <- clamp(q + step dq).
-// One pass over them, four at a time with the loads issued together: `apply` takes the step of the previous iteration
+// One pass over them, three at a time with the loads issued together (4 and 8 measured slower on the demo + posture workload): `apply` takes the step of the previous iteration
 // (deferred to the top of the next one, where next to nothing is live in registers), and the error at the resulting q is
 // added to `e0sq` when the rows sit on priority level 0.
 IKD_FN void posture_outside_pass(const TreeParams &prm, const PostureState &ps, const double *targets_lane, int64_t tstride,
                                  bool apply, double &e0sq) {
-    constexpr int kChunk = 4;  // 8 measured slower (0.86 vs 0.75 ms on the demo + posture workload)
+    constexpr int kChunk = 3;
     const bool prio0 = prm.post_prio == 0;
 #pragma unroll 1
     for (int k0 = 0; k0 < prm.post_n; k0 += kChunk) {
@@ -493,7 +494,7 @@ IKD_FN void posture_outside_pass(const TreeParams &prm, const PostureState &ps, 
 #pragma unroll
         for (int u = 0; u < kChunk; ++u) {
             const int k = k0 + u < prm.post_n ? k0 + u : k0;  // a short last chunk re-reads its first row; nothing of the repeats is stored or summed
-            qv[u] = ps.q_lane[prm.post_q[k] * ps.stride];
+            qv[u] = ps.q_lane[(ps.by_row ? k : prm.post_q[k]) * ps.stride];
             tv[u] = targets_lane[(prm.post_slot[k] * 12 + 9) * tstride];
         }
 #pragma unroll
@@ -506,7 +507,7 @@ IKD_FN void posture_outside_pass(const TreeParams &prm, const PostureState &ps, 
             const double dq = -(w * ea) * drcp(dfma(w, w, prm.lam2));
             const double qc = dmin(ps.upper[qi], dmax(dfma(prm.step_length, dq, qv[u]), ps.lower[qi]));
             const double qn = apply ? qc : qv[u];
-            if (apply && ps.store && live) ps.q_lane[qi * ps.stride] = qn;
+            if (apply && ps.store && live) ps.q_lane[(ps.by_row ? k : qi) * ps.stride] = qn;
             if (prio0 && live) {
                 const double en = (qn - tv[u]) * mw;
                 e0sq = dfma(en, en, e0sq);
@@ -532,7 +533,10 @@ IKD_FN void tree_dls(const TreeDesc<NJ, NCH> &d, const TreeParams &prm, double (
         // across the chain bodies: nine doubles less at the register-pressure peak.
         const double p1[3] = {qb[0], qb[1], qb[2]};
         double Hbb[21], gb[6], e0sq = 0.0;
-        if (kPost && prm.post_on) posture_outside_pass(prm, ps, targets_lane, tstride, it > 0 && active, e0sq);
+        if (kPost && prm.post_on) {
+            posture_outside_pass(prm, ps, targets_lane, tstride, it > 0 && active, e0sq);
+            IKD_SCHED_FENCE();  // keep the chain bodies' loads out of this pass: they would only lengthen live ranges
+        }
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
 #pragma unroll

@@ -241,7 +241,11 @@ __global__ __launch_bounds__(kTreeBlock) void dls_tree_kernel(const TreeKernelAr
     const TreeDesc<NJ, NCH> &d = stage_tree_desc<NJ, NCH>(a.desc, lds_desc, kTreeBlock);
     const int64_t gid = static_cast<int64_t>(blockIdx.x) * kTreeBlock + threadIdx.x;
     LdsPark<NJ> park{lds_park[threadIdx.x / 64], static_cast<int>(threadIdx.x % 64)};
-    ikdev::dls_tree_body<NJ, NCH, SPEC>(a, d, gid, park, [](bool act) { return __any(act) != 0; });
+    // posture build with one chain (no factor to park, LDS to spare): the joints outside the chain that carry a posture row
+    // live in dynamic LDS [row][lane] between iterations; with two chains the LDS is full and they stay in the q_out column
+    extern __shared__ double lds_post[];
+    double *post_lane = (SPEC == (1 << ikdev::kSpecPost) && NCH == 1) ? lds_post + threadIdx.x : nullptr;
+    ikdev::dls_tree_body<NJ, NCH, SPEC>(a, d, gid, park, [](bool act) { return __any(act) != 0; }, post_lane, kTreeBlock);
 }
 
 template <int NJ, int NCH>
@@ -296,7 +300,9 @@ hipError_t run_dls_tree(const ProblemHost &ph, const DeviceTables &dt, const Bat
                      a.prm.unit[0] && (NCH == 1 || a.prm.unit[1]) && (!a.prm.hasP || (a.prm.unitP && (a.prm.idmaskP & 1)));
     const dim3 grid(static_cast<unsigned>((io.B + kTreeBlock - 1) / kTreeBlock));
     if (hot) hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, kHot>), grid, dim3(kTreeBlock), 0, stream, a);
-    else if (ph.has_posture) hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, (1 << ikdev::kSpecPost)>), grid, dim3(kTreeBlock), 0, stream, a);
+    else if (ph.has_posture)
+        hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, (1 << ikdev::kSpecPost)>), grid, dim3(kTreeBlock),
+                           NCH == 1 ? sizeof(double) * kTreeBlock * static_cast<size_t>(std::max(1, a.prm.post_n)) : 0, stream, a);
     else hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, 0>), grid, dim3(kTreeBlock), 0, stream, a);
     return hipGetLastError();
 }
