@@ -481,7 +481,8 @@ struct PostureState {
 
 // Posture rows on joints outside the chains (posture builds): each is its own 1x1 system,
 //   e = (q - target) mask w,   dq = -w e / (w^2 + lambda^2),   q <- clamp(q + step dq).
-// One pass over them, three at a time with the loads issued together (4 and 8 measured slower on the demo + posture workload): `apply` takes the step of the previous iteration
+// One pass over them, three at a time with the loads issued together (A/B on one box, demo + posture workload: 0.72 ms;
+// four at a time 0.76 ms; state in the q_out column instead of LDS 0.75 ms; without the fence below 0.77 ms): `apply` takes the step of the previous iteration
 // (deferred to the top of the next one, where next to nothing is live in registers), and the error at the resulting q is
 // added to `e0sq` when the rows sit on priority level 0.
 IKD_FN void posture_outside_pass(const TreeParams &prm, const PostureState &ps, const double *targets_lane, int64_t tstride,
