@@ -50,8 +50,8 @@ IKD_FN void load_target(const ChainKernelArgs<NJ> &a, int64_t b, double (&oMt)[1
 }
 
 // B independent ik::dls() calls (reference ik/ik/dls.cpp:5-78), lane `gid`.
-template <int NJ, int KT, int SMASK = -1, class AnyFn>
-IKD_FN void dls_chain_body(const ChainKernelArgs<NJ> &a, const ChainDesc<NJ> &d, int64_t gid, AnyFn any_active) {
+template <int NJ, int KT, int SMASK = -1, class Desc, class AnyFn>
+IKD_FN void dls_chain_body(const ChainKernelArgs<NJ> &a, const Desc &d, int64_t gid, AnyFn any_active) {
     const bool valid = gid < a.B;
     const int64_t b = valid ? gid : a.B - 1;  // tail lanes shadow the last problem and store nothing
 

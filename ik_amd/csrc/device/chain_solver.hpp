@@ -16,6 +16,8 @@
 // placements on the host (pl' = P_prev^T pl P, P e_z = a), which leaves oMi * a and the joint
 // origin -- all the Jacobian needs -- unchanged.
 #pragma once
+#include <type_traits>
+
 #include "lane_math.hpp"
 
 namespace ikdev {
@@ -55,8 +57,9 @@ struct TaskDim {
 // `idmask` / `unit_weights`.  A compile-time value keeps the whole iteration one basic block, so the scheduler can
 // hoist the LDS reads of the constant table far ahead of their use -- with one wave per SIMD nothing else hides that
 // latency (measured: s_waitcnt stalls were 17 % of wave cycles with runtime branches; +18 % solves/s without them).
-template <int NJ, int KT, int SMASK = -1>
-IKD_FN void chain_evaluate(const ChainDesc<NJ> &d, const double (&q)[NJ], const double (&oMt)[12], int idmask,
+// Desc: ChainDesc<NJ> (staged in LDS, or plain memory on the host) or IKD_CONST_AS ChainDesc<NJ> (HBM through scalar loads).
+template <int NJ, int KT, int SMASK = -1, class Desc = ChainDesc<NJ>>
+IKD_FN void chain_evaluate(const Desc &d, const double (&q)[NJ], const double (&oMt)[12], int idmask,
                            bool unit_weights, double (&e)[TaskDim<KT>::value], double (&col)[NJ][TaskDim<KT>::value],
                            double (&Rf)[9], double (&pf)[3]) {
     constexpr int M = TaskDim<KT>::value;
@@ -183,18 +186,21 @@ IKD_FN void chain_evaluate(const ChainDesc<NJ> &d, const double (&q)[NJ], const 
 
 // One full solve. q: in = q0 (chain joints only), out = result. Returns iterations / success.
 // any_active(bool) must return a wave-uniform "some lane still iterating" (identity on the host).
-template <int NJ, int KT, int SMASK = -1, class AnyFn>
-IKD_FN void chain_dls(const ChainDesc<NJ> &d, const LoopParams &prm, double (&q)[NJ], const double (&oMt)[12],
+template <int NJ, int KT, int SMASK = -1, class Desc, class AnyFn>
+IKD_FN void chain_dls(const Desc &d_in, const LoopParams &prm, double (&q)[NJ], const double (&oMt)[12],
                       int &iters_out, bool &success_out, AnyFn any_active) {
     constexpr int M = TaskDim<KT>::value;
     bool active = true;
     bool success = false;
     int iters = prm.max_iterations;
+    const Desc *dp = &d_in;
 #pragma unroll 1
     for (int it = 0; it < prm.max_iterations; ++it) {
-        // The constant table `d` lives in LDS on the device: re-read it every iteration (broadcast
-        // ds_read, off the VALU) instead of letting the compiler hoist ~150 doubles into registers.
+        // The constant table is re-read every iteration (scalar loads from the constant address space, or broadcast
+        // ds_read from LDS: both off the VALU) instead of letting the compiler hoist ~150 doubles into registers.
         asm volatile("" ::: "memory");
+        if constexpr (!std::is_same<Desc, ChainDesc<NJ>>::value) IKD_LAUNDER(dp);  // constant address space: see lane_math.hpp
+        const Desc &d = *dp;
         double e[M], col[NJ][M], Rf[9], pf[3];
         chain_evaluate<NJ, KT, SMASK>(d, q, oMt, prm.idmask, prm.unit_weights != 0, e, col, Rf, pf);
 

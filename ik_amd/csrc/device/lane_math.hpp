@@ -35,7 +35,14 @@
 // turning that select into a divergent branch (a branch splits the iteration's basic block and strands the LDS /
 // global loads behind it: with one wave per SIMD their latency is then fully exposed).
 #define IKD_PIN(x) asm volatile("" : "+v"(x))
+// A wave-uniform constant table read through the constant address space comes in by scalar loads (s_load_dwordx16 into
+// SGPRs, which the FP64 instructions take as operands directly): no LDS round trip, no VGPRs.  IKD_LAUNDER makes the
+// table's address opaque once per iteration, otherwise the loads are hoisted out of the loop and the ~100 doubles spill.
+#define IKD_CONST_AS __attribute__((address_space(4)))
+#define IKD_LAUNDER(ptr) asm volatile("" : "+s"(ptr))
 #else
+#define IKD_CONST_AS
+#define IKD_LAUNDER(ptr) ((void)0)
 #define IKD_PIN(x) ((void)0)
 #define IKD_SCHED_FENCE() ((void)0)
 #define IKD_ANY(pred) (pred)
@@ -232,7 +239,8 @@ IKD_FN double dacos(double x) {
 // (R, p) <- (R, p) * (Rc, pc)   with (Rc, pc) = c[0..11], uniform constants.
 // rot_identity is wave-uniform (a bit of the problem's placement mask, computed on the host): when Rc is
 // exactly the identity the 27 rotation FMAs are skipped -- multiplying by exact ones and zeros changes no bit.
-IKD_FN void se3_compose_const(double (&R)[9], double (&p)[3], const double *c, bool rot_identity = false) {
+template <class ConstPtr>  // const double *, in LDS or (constant address space) in HBM
+IKD_FN void se3_compose_const(double (&R)[9], double (&p)[3], ConstPtr c, bool rot_identity = false) {
     if (rot_identity) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) p[i] = dfma(R[3 * i], c[9], dfma(R[3 * i + 1], c[10], dfma(R[3 * i + 2], c[11], p[i])));

@@ -37,10 +37,20 @@ __device__ __forceinline__ const ChainDesc<NJ> &stage_desc(const ChainDesc<NJ> *
 // SMASK: compile-time identity-rotation placement mask (0: skip nothing), see device/chain_solver.hpp
 template <int NJ, int KT, int SMASK>
 __global__ __launch_bounds__(kBlock) void dls_chain_kernel(const ChainKernelArgs<NJ> a) {
+    const int64_t gid = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+#ifdef IKGPU_CHAIN_TABLE_SCALAR
+    // Alternative kept for tuning (-DIKGPU_CHAIN_TABLE_SCALAR): the chain table stays in HBM and is read through the constant
+    // address space -- wave-uniform scalar loads straight into SGPR operands of the FP64 instructions, no LDS round trips,
+    // 223 instead of 282 VGPRs.  Measured 0.178 ms against 0.173 ms for the LDS table on the leg workload (UR5: 0.177 vs
+    // 0.179): the table competes with the polynomial constants for the 100 SGPRs and the allocator spills them to VGPR
+    // lanes (31 v_readlane + 39 s_mov per iteration), which eats what the missing s_waitcnt stalls give.
+    typedef const IKD_CONST_AS ChainDesc<NJ> ConstDesc;
+    ikdev::dls_chain_body<NJ, KT, SMASK>(a, *(ConstDesc *)a.desc, gid, [](bool act) { return __any(act) != 0; });
+#else
     __shared__ double lds_desc[sizeof(ChainDesc<NJ>) / sizeof(double)];
     const ChainDesc<NJ> &d = stage_desc<NJ>(a.desc, lds_desc);
-    const int64_t gid = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     ikdev::dls_chain_body<NJ, KT, SMASK>(a, d, gid, [](bool act) { return __any(act) != 0; });
+#endif
 }
 
 // Placement masks with a dedicated instantiation: the Cassie leg chains (knee, shin, tarsus, foot and the foot frame
