@@ -38,12 +38,15 @@ __device__ __forceinline__ const ChainDesc<NJ> &stage_desc(const ChainDesc<NJ> *
 template <int NJ, int KT, int SMASK>
 __global__ __launch_bounds__(kBlock) void dls_chain_kernel(const ChainKernelArgs<NJ> a) {
     const int64_t gid = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-#ifdef IKGPU_CHAIN_TABLE_SCALAR
-    // Alternative kept for tuning (-DIKGPU_CHAIN_TABLE_SCALAR): the chain table stays in HBM and is read through the constant
-    // address space -- wave-uniform scalar loads straight into SGPR operands of the FP64 instructions, no LDS round trips,
-    // 223 instead of 282 VGPRs.  Measured 0.178 ms against 0.173 ms for the LDS table on the leg workload (UR5: 0.177 vs
-    // 0.179): the table competes with the polynomial constants for the 100 SGPRs and the allocator spills them to VGPR
-    // lanes (31 v_readlane + 39 s_mov per iteration), which eats what the missing s_waitcnt stalls give.
+#ifndef IKGPU_CHAIN_TABLE_IN_LDS
+    // The chain table stays in HBM and is read through the constant address space: wave-uniform scalar loads (scalar cache)
+    // straight into SGPR operands of the FP64 instructions -- no LDS, no s_waitcnt on ds_read, and 223 instead of 268 VGPRs,
+    // i.e. two waves per SIMD fit.  A/B on one box against the LDS-staged table (-DIKGPU_CHAIN_TABLE_IN_LDS), leg / UR5:
+    //   B = 65536 (one wave per SIMD either way): 0.1750 / 0.1761 ms  vs  0.1753 / 0.1750 ms   -- equal
+    //   B = 262144:                               0.615  / 0.625  ms  vs  0.674  / 0.676  ms   -- 9 % faster
+    //   B = 1048576:                              2.13   / 2.13   ms  vs  2.39   / 2.36   ms   -- 11 % faster (4.9e8 solves/s)
+    // The table competes with the polynomial constants for the 100 SGPRs (31 v_readlane + 39 s_mov per iteration of SGPR
+    // spill code), which is why the single-wave case gains nothing from the missing LDS waits.
     typedef const IKD_CONST_AS ChainDesc<NJ> ConstDesc;
     ikdev::dls_chain_body<NJ, KT, SMASK>(a, *(ConstDesc *)a.desc, gid, [](bool act) { return __any(act) != 0; });
 #else
