@@ -32,8 +32,8 @@ struct TreeKernelArgs {
 // B independent ik::dls() calls (reference ik/ik/dls.cpp:5-78) on a free-flyer model, lane `gid`.
 // post_lane / post_stride: where a posture build keeps the joints outside the chains between iterations -- an LDS column of
 // the lane (row k at post_lane[k * post_stride]) when the kernel has LDS to spare, else (nullptr) the lane's column of q_out.
-template <int NJ, int NCH, int SPEC = -1, class Park, class AnyFn>
-IKD_FN void dls_tree_body(const TreeKernelArgs<NJ, NCH> &a, const TreeDesc<NJ, NCH> &d, int64_t gid, Park park,
+template <int NJ, int NCH, int SPEC = -1, class Desc, class Park, class AnyFn>
+IKD_FN void dls_tree_body(const TreeKernelArgs<NJ, NCH> &a, const Desc &d, int64_t gid, Park park,
                           AnyFn any_active, double *post_lane = nullptr, int64_t post_stride = 0) {
     const bool valid = gid < a.B;
     const int64_t b = valid ? gid : a.B - 1;

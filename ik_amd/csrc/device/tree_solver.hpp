@@ -111,7 +111,8 @@ IKD_FN void mul_RT(const double (&X)[9], const double (&R)[9], double (&out)[9])
         for (int k = 0; k < 3; ++k) out[3 * i + k] = dfma(X[3 * i], R[3 * k], dfma(X[3 * i + 1], R[3 * k + 1], X[3 * i + 2] * R[3 * k + 2]));
 }
 
-IKD_FN void task_terms(const double (&Rf)[9], const double (&pf)[3], const double (&oMt)[12], const double *w6, bool unit,
+template <class WPtr>  // const double *, in LDS / host memory or in the constant address space
+IKD_FN void task_terms(const double (&Rf)[9], const double (&pf)[3], const double (&oMt)[12], WPtr w6, bool unit,
                        TaskTerms &t) {
     double Re[9], pe[3];
 #pragma unroll
@@ -223,9 +224,9 @@ struct ChainPosture {
     int64_t tstride;
 };
 
-template <int NJ, bool FAST = false, bool POST = false>
-IKD_FN void leg_eval_factor(const double (&R1)[9], const double (&p1)[3], const double (*pl)[12], const double *frame_pl,
-                            const double *w6, int idmask, bool unit, const double (&q)[NJ], const double (&oMt)[12],
+template <int NJ, bool FAST = false, bool POST = false, class PlPtr, class FrPtr, class WPtr>
+IKD_FN void leg_eval_factor(const double (&R1)[9], const double (&p1)[3], PlPtr pl, FrPtr frame_pl,
+                            WPtr w6, int idmask, bool unit, const double (&q)[NJ], const double (&oMt)[12],
                             double lam2, bool prio0, const AlignRow &al, const ChainPosture &po, double (&Hbb)[21],
                             double (&gb)[6], double &e0sq, LegFactor<NJ> &F) {
     double zax[NJ][3], org[NJ][3];
@@ -517,8 +518,9 @@ IKD_FN void posture_outside_pass(const TreeParams &prm, const PostureState &ps, 
     }
 }
 
-template <int NJ, int NCH, int SPEC = -1, class Park, class AnyFn>
-IKD_FN void tree_dls(const TreeDesc<NJ, NCH> &d, const TreeParams &prm, double (&qb)[7], double (&qj0)[NJ], double (&qj1)[NJ],
+// Desc: TreeDesc<NJ, NCH> (LDS / host memory) or IKD_CONST_AS TreeDesc<NJ, NCH> (HBM through scalar loads, see chain_solver.hpp).
+template <int NJ, int NCH, int SPEC = -1, class Desc, class Park, class AnyFn>
+IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], double (&qj0)[NJ], double (&qj1)[NJ],
                      const double *targets_lane, int64_t tstride, const int (&tslot)[3], const PostureState &ps, int &iters_out,
                      bool &success_out, Park park, AnyFn any_active) {
     constexpr bool kGeneral = SPEC <= 0 || SPEC == (1 << kSpecPost);  // the demo's extras exist in the general builds only
@@ -526,10 +528,13 @@ IKD_FN void tree_dls(const TreeDesc<NJ, NCH> &d, const TreeParams &prm, double (
     // (posture builds: a tail lane shadowing the last problem would re-read that problem's outside joints while their owner
     // updates them -- it sits the loop out instead; nothing of it is stored anyway)
     bool active = kPost ? ps.store : true, success = false;
+    const Desc *dp = &d_in;
     int iters = prm.max_iterations;
 #pragma unroll 1
     for (int it = 0; it < prm.max_iterations; ++it) {
-        asm volatile("" ::: "memory");  // re-read the LDS table and the targets every iteration (see chain_solver.hpp)
+        asm volatile("" ::: "memory");  // re-read the table and the targets every iteration (see chain_solver.hpp)
+        if constexpr (!std::is_same<Desc, TreeDesc<NJ, NCH>>::value) IKD_LAUNDER(dp);
+        const Desc &d = *dp;
         // R1 = R(quaternion) is recomputed where it is needed (24 instructions) instead of being kept live
         // across the chain bodies: nine doubles less at the register-pressure peak.
         const double p1[3] = {qb[0], qb[1], qb[2]};
@@ -547,7 +552,7 @@ IKD_FN void tree_dls(const TreeDesc<NJ, NCH> &d, const TreeParams &prm, double (
         LegFactor<NJ> F;
 #pragma unroll 1
         for (int c = 0; c < NCH; ++c) {
-            const ChainTable<NJ> &ct = d.chain[c];
+            const auto &ct = d.chain[c];
             double q[NJ], oMt[12], R1[9];
             quat_to_R(qb, R1);
 #pragma unroll
@@ -623,7 +628,7 @@ IKD_FN void tree_dls(const TreeDesc<NJ, NCH> &d, const TreeParams &prm, double (
 
 #pragma unroll 1
         for (int c = NCH - 1; c >= 0; --c) {
-            const ChainTable<NJ> &ct = d.chain[c];
+            const auto &ct = d.chain[c];
             if (NCH > 1 && c == 0) park.load(F);
             double dql[NJ];
             leg_back_substitute<NJ>(F, dqb, dql);

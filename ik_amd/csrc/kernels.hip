@@ -249,9 +249,14 @@ __device__ __forceinline__ const TreeDesc<NJ, NCH> &stage_tree_desc(const TreeDe
 
 template <int NJ, int NCH, int SPEC>
 __global__ __launch_bounds__(kTreeBlock) void dls_tree_kernel(const TreeKernelArgs<NJ, NCH> a) {
-    __shared__ double lds_desc[sizeof(TreeDesc<NJ, NCH>) / sizeof(double)];
     __shared__ double lds_park[kTreeWaves][NCH > 1 ? LdsPark<NJ>::kEntries : 1][64];
+#ifdef IKGPU_TREE_TABLE_SCALAR
+    typedef const IKD_CONST_AS TreeDesc<NJ, NCH> ConstDesc;   // scalar loads from HBM, as the chain kernels do
+    ConstDesc &d = *(ConstDesc *)a.desc;
+#else
+    __shared__ double lds_desc[sizeof(TreeDesc<NJ, NCH>) / sizeof(double)];
     const TreeDesc<NJ, NCH> &d = stage_tree_desc<NJ, NCH>(a.desc, lds_desc, kTreeBlock);
+#endif
     const int64_t gid = static_cast<int64_t>(blockIdx.x) * kTreeBlock + threadIdx.x;
     LdsPark<NJ> park{lds_park[threadIdx.x / 64], static_cast<int>(threadIdx.x % 64)};
     // posture build with one chain (no factor to park, LDS to spare): the joints outside the chain that carry a posture row
