@@ -56,6 +56,7 @@ struct TreeParams {
     int align_slot;          //   the target slot whose doubles 9..11 hold the direction (in the world),
     int align_prio;          //   its priority level
     double align_w;          //   and its weight
+    int fixed_base;          // general builds: the base does not move (a fixed-base model): dq_base is dropped, the base pose stays the world
     // posture builds only (SPEC bit kSpecPost, or -1): PostureTask rows (reference ik/ik/posture.hpp:51-68), one per joint,
     // e = (q - target) mask w, J = w in the joint's own tangent column; all on one priority level.  A row on a chain joint
     // adds w^2 to that joint's diagonal of the normal matrix and -w e to its right-hand side; a joint outside the chains is
@@ -621,6 +622,11 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
 #pragma unroll
             for (int j = 0; j <= i; ++j) S[i * 6 + j] = Hbb[tri(i, j)];
         chol_solve<6>(S, gb, dqb);
+        const bool fixed = kGeneral && prm.fixed_base != 0;  // wave-uniform
+        if (fixed) {  // the chains of a fixed-base model: independent systems, the base block is solved and dropped
+#pragma unroll
+            for (int i = 0; i < 6; ++i) dqb[i] = 0.0;
+        }
 
         const bool stop_now = active && (prm.stop_sq_tol >= 0.0) && (e0sq < prm.stop_sq_tol);
         if (stop_now) { success = true; iters = it; }
@@ -643,7 +649,7 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
                 qj0[j] = (NCH > 1 && c == 1) ? qj0[j] : qn;
             }
         }
-        {
+        if (!fixed) {
             double v[6], qn[7], R1[9];
             quat_to_R(qb, R1);
 #pragma unroll

@@ -288,6 +288,7 @@ TreeKernelArgs<NJ, NCH> make_tree_args(const ProblemHost &ph, const DeviceTables
     a.prm.align_chain = h.align_chain; a.prm.align_axis = h.align_axis; a.prm.align_slot = h.align_slot;
     a.prm.align_prio = h.align_prio; a.prm.align_w = h.align_w;
     static_assert(ikdev::kMaxPostOut == kMaxPostureOut && kMaxChain == 8, "TreeParams posture arrays");
+    a.prm.fixed_base = h.fixed_base;
     a.prm.post_on = h.post_on; a.prm.post_prio = h.post_prio; a.prm.post_n = h.post_n;
     for (int k = 0; k < h.post_n; ++k) {
         a.prm.post_q[k] = h.post_q[k]; a.prm.post_slot[k] = h.post_slot[k]; a.prm.post_w[k] = h.post_w[k]; a.prm.post_m[k] = h.post_m[k];

@@ -96,7 +96,6 @@ void specialise(ProblemHost &ph, const Model &m) {
     const bool free_flyer = m.njoints() > 1 && m.joint_type[1] == IKGPU_JOINT_FREEFLYER;
     for (const ikgpu_task &t : ph.tasks) {
         if (t.type == IKGPU_CENTRE_OF_MASS) throw Unsupported("CentreOfMassTask rows run on the generic kernel");
-        if (t.type > IKGPU_FULL && !free_flyer) throw Unsupported("AlignAxisTask / PostureTask rows on a fixed-base model run on the generic kernel");
     }
     std::vector<uint8_t> in_chain(m.nq, 0);
 
@@ -109,8 +108,7 @@ void specialise(ProblemHost &ph, const Model &m) {
         return build_chain(m, joints, frame, task_index, in_chain);
     };
 
-    if (!free_flyer) {
-        if (ntasks != 1) throw Unsupported("more than one task on a fixed-base model");
+    if (!free_flyer && ntasks == 1 && ph.tasks[0].type <= IKGPU_FULL) {
         const ikgpu_task &t = ph.tasks[0];
         if (m.frame_parent[t.reference] != 0) throw Unsupported("reference frame moves with the configuration");
         std::memcpy(ph.ref_pl, m.frame_placement[t.reference].data(), sizeof(double) * 12);
@@ -123,19 +121,23 @@ void specialise(ProblemHost &ph, const Model &m) {
         ph.q_in_chain = in_chain;
         return;
     }
-    // free-flyer base: chains hang off joint 1
-    for (int k = 0; k < 7; ++k) in_chain[k] = 1;
+    // Tree kind.  Free-flyer base: chains hang off joint 1.  Fixed base (several tasks, or alignment / posture rows next to one
+    // chain task): chains hang off the universe, and the kernel drops the base block it solves (TreeParams::fixed_base).
+    const int root = free_flyer ? 1 : 0;
+    ph.fixed_base = !free_flyer;
+    if (free_flyer)
+        for (int k = 0; k < 7; ++k) in_chain[k] = 1;
     int nchains = 0;
     int chain_frame[2] = {-1, -1};
     for (int i = 0; i < ntasks; ++i) {
         const ikgpu_task &t = ph.tasks[i];
         if (t.type > IKGPU_FULL) continue;  // alignment and posture rows are matched to the chains below
         const bool ref_world = m.frame_parent[t.reference] == 0 && is_identity(m.frame_placement[t.reference]);
-        const bool ref_on_base = m.frame_parent[t.reference] == 1;
+        const bool ref_on_base = free_flyer && m.frame_parent[t.reference] == 1;
         if (!ref_world && !ref_on_base) throw Unsupported("reference frame neither the universe nor on the floating base");
         if (m.frame_parent[t.frame] == 0) throw Unsupported("task frame fixed in the world");
         std::vector<int> joints;
-        for (int j = m.frame_parent[t.frame]; j > 1; j = m.joint_parent[j]) joints.insert(joints.begin(), j);
+        for (int j = m.frame_parent[t.frame]; j > root; j = m.joint_parent[j]) joints.insert(joints.begin(), j);
         if (joints.empty()) {
             if (ph.base_task >= 0) throw Unsupported("two tasks on the floating base link");
             if (!ref_world) throw Unsupported("base-link task with a reference frame other than the universe");
@@ -176,7 +178,8 @@ void specialise(ProblemHost &ph, const Model &m) {
         ph.has_posture = true;
         ph.posture_prio = t.priority;
         const int v = t.frame, qi = t.reference;
-        if (qi < 7 || qi >= m.nq || v < 6 || v >= m.nv || qi - 7 != v - 6) throw Unsupported("posture row on the floating base");
+        const int off_q = free_flyer ? 7 : 0, off_v = free_flyer ? 6 : 0;
+        if (qi < off_q || qi >= m.nq || v < off_v || v >= m.nv || qi - off_q != v - off_v) throw Unsupported("posture row on the floating base");
         if (has_row[qi]) throw Unsupported("two posture rows on one joint");
         has_row[qi] = 1;
         int where = -1, at = -1;
@@ -198,7 +201,7 @@ void specialise(ProblemHost &ph, const Model &m) {
     ph.kind = KernelKind::Tree;
     ph.kernel_name = "dls_tree<NJ=" + std::to_string(ph.chain.nj) + ",chains=" + std::to_string(nchains) +
                      (ph.base_task >= 0 ? ",base_task" : "") + (ph.ref_base[0] || ph.ref_base[1] ? ",base_reference" : "") +
-                     (ph.align_task >= 0 ? ",align_axis" : "") + (ph.has_posture ? ",posture" : "") + ">";
+                     (ph.align_task >= 0 ? ",align_axis" : "") + (ph.has_posture ? ",posture" : "") + (ph.fixed_base ? ",fixed_base" : "") + ">";
     ph.q_in_chain = in_chain;
 }
 
@@ -571,6 +574,7 @@ TreeArgsHost tree_args(const ProblemHost &ph) {
         a.align_prio = t.priority;
         a.align_w = t.weight[0];
     }
+    a.fixed_base = ph.fixed_base ? 1 : 0;
     a.post_on = ph.has_posture ? 1 : 0;
     a.post_prio = ph.posture_prio;
     a.post_n = static_cast<int>(ph.posture_out.size());

@@ -79,7 +79,10 @@ struct ProblemHost {
     std::vector<PostureRow> posture_out;            // joints outside the chains
     int posture_chain_task[2][kMaxChain];           // chain joints: task index, or -1 (set by specialise())
     double posture_chain_w[2][kMaxChain] = {}, posture_chain_mask[2][kMaxChain] = {};
-    bool tree_extras() const { return ref_base[0] || ref_base[1] || align_task >= 0 || has_posture; }
+    // ... or a FIXED base: the same kernel with the base block solved and dropped (dq_base = 0, base pose = the world), for
+    // fixed-base problems with two disjoint chain tasks or with alignment / posture rows next to one chain task
+    bool fixed_base = false;
+    bool tree_extras() const { return ref_base[0] || ref_base[1] || align_task >= 0 || has_posture || fixed_base; }
     GenericHost generic;              // Generic kind
     std::vector<ikgpu_task> constraints;  // ik::FrameConstraint list (frame, reference, type); forces the Generic kind
     int crows = 0;
@@ -114,6 +117,7 @@ struct TreeArgsHost {
     int align_chain, align_axis, align_slot, align_prio;    // an AlignAxisTask row on a chain's task frame (-1: none)
     double align_w;
     // PostureTask rows (device/tree_solver.hpp: TreeParams::post_*)
+    int fixed_base;
     int post_on, post_prio, post_n;
     int post_q[kMaxPostureOut], post_slot[kMaxPostureOut];
     double post_w[kMaxPostureOut], post_m[kMaxPostureOut];

@@ -92,6 +92,7 @@ void run_tree(const ikgpu::ProblemHost &ph, const IO &io) {
     a.prm.ref_base[0] = h.ref_base[0]; a.prm.ref_base[1] = h.ref_base[1];
     a.prm.align_chain = h.align_chain; a.prm.align_axis = h.align_axis; a.prm.align_slot = h.align_slot;
     a.prm.align_prio = h.align_prio; a.prm.align_w = h.align_w;
+    a.prm.fixed_base = h.fixed_base;
     a.prm.post_on = h.post_on; a.prm.post_prio = h.post_prio; a.prm.post_n = h.post_n;
     for (int k = 0; k < h.post_n; ++k) {
         a.prm.post_q[k] = h.post_q[k]; a.prm.post_slot[k] = h.post_slot[k]; a.prm.post_w[k] = h.post_w[k]; a.prm.post_m[k] = h.post_m[k];
@@ -188,6 +189,11 @@ int lane_emu_run(const char *urdf, size_t len, int root_joint, const ikgpu_task 
             const int nj = ph.chain.nj, nch = ph.chainB.nj > 0 ? 2 : 1;
             if (nj == 7 && nch == 2) { run_tree<7, 2>(ph, io); return 0; }
             if (nj == 7 && nch == 1) { run_tree<7, 1>(ph, io); return 0; }
+            if (nj == 6 && nch == 2) { run_tree<6, 2>(ph, io); return 0; }
+            if (nj == 6 && nch == 1) { run_tree<6, 1>(ph, io); return 0; }
+            // a tree shape without a compiled kernel runs on the generic program (as capi.cpp: shape_built())
+            run_generic(ikgpu::analyse_problem(m, tasks, ntasks, true), io);
+            return 0;
         }
         g_err = "shape not instantiated in the lane emulator: " + ph.kernel_name;
         return 1;

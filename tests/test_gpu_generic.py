@@ -134,9 +134,10 @@ CASES = {
 CHAOTIC_AT_FULL_STEP = {"com_in_foot_frame", "demo_task_set", "demo_with_direction_in_pelvis_frame"}
 
 
-# Problems that have since found a register-resident kernel (the tree kernel with the demo's extras / with posture rows,
-# tests/test_gpu_tree_posture.py): here they are kept on the generic kernel by IKGPU_DLS_KERNEL=generic
-FORCED_GENERIC = {"posture_regulariser"}
+# Problems that have since found a register-resident kernel (the tree kernel with posture rows or on a fixed base,
+# tests/test_gpu_tree_posture.py, tests/test_gpu_tree_fixed_base.py): here they are kept on the generic kernel by
+# IKGPU_DLS_KERNEL=generic
+FORCED_GENERIC = {"posture_regulariser", "fixed_two_feet_priorities", "posture_first_level"}
 
 
 @pytest.mark.parametrize("case", sorted(CASES))

@@ -197,8 +197,10 @@ def test_every_other_shape_maps_to_the_generic_kernel(ik):
     device, never on a CPU path."""
     m, p = _problem(ik, "ur5", ["tool0"], reference="wrist_1_link")          # reference frame moves with q
     assert ik.plan(p) == "dls_generic<M=6,nv=6,joints=6>"
-    m, p = _problem(ik, "cassie_fixed", ["LeftFootFront", "RightFootFront"])  # fixed base, two tasks
+    m, p = _problem(ik, "cassie_fixed", ["LeftFootFront", "LeftFootBack"])   # fixed base, two tasks sharing their joints
     assert ik.plan(p) == "dls_generic<M=12,nv=16,joints=16>"
+    m, p = _problem(ik, "cassie_fixed", ["LeftFootFront", "RightFootFront"])  # fixed base, two disjoint chains: the tree kernel
+    assert ik.plan(p) == "dls_tree<NJ=7,chains=2,fixed_base>"                 # with its base block dropped
     m, p = _problem(ik, "cassie", ["LeftFootFront", "RightFootFront", "LeftFootBack"], ff=True)   # three chain tasks
     assert ik.plan(p) == "dls_generic<M=18,nv=22,joints=17>"
     m, p = _problem(ik, "cassie", ["LeftFootFront", "pelvis"], ff=True)
@@ -267,7 +269,7 @@ def test_posture_task_expands_to_one_row_per_joint(ik):
     pf = ik.InverseKinematicsProblem(fixed)
     pf.add_frame_task("fl", ik.FrameTask.create(fixed, "LeftFootFront"))
     pf.add_posture_task("posture", ik.PostureTask.create(fixed, 16))
-    assert ik.plan(pf) == "dls_generic<M=22,nv=16,joints=16>"          # a fixed-base model keeps them on the generic kernel
+    assert ik.plan(pf) == "dls_tree<NJ=7,chains=1,posture,fixed_base>"  # a fixed-base model: same kernel, base block dropped
     with pytest.raises(ValueError):
         ik.PostureTask(m, 40)
     with pytest.raises(ValueError):

@@ -109,3 +109,39 @@ def test_tree_program_with_posture_rows_matches_oracle(emu, monkeypatch, case): 
     # the forced generic program agrees
     qg, *_ = run(emu, urdf, tasks, 0, q0, tg, prm, model.nv, M, root=3, ntasks=nt)
     assert np.abs(qg - qa).max() < 1e-8
+
+
+
+# Fixed-base models on the tree program (TreeParams::fixed_base: the base block is solved and dropped)
+FIXED_BASE_CASES = {
+    "two_feet": ("cassie_fixed", [("LeftFootFront", "universe", 2, 0, None), ("RightFootFront", "universe", 2, 0, None)], "dls_tree<NJ=7,chains=2,fixed_base>"),
+    "leg_with_alignment_and_posture": ("cassie_fixed", [("LeftFootFront", "universe", 0, 0, None), ("LeftFootFront", "universe", 5, 0, None),
+                                                        ("@posture", 16, 6, 1, ([0.1] * 16, [1.0] * 16))],
+                                       "dls_tree<NJ=7,chains=1,align_axis,posture,fixed_base>"),
+    "arm_position_with_posture": ("ur5", [("@posture", 4, 6, 0, ([1.0] * 4, [1.0] * 4)), ("tool0", "universe", 0, 0, None)],
+                                  "dls_tree<NJ=6,chains=1,posture,fixed_base>"),
+}
+
+
+@pytest.mark.parametrize("case", sorted(FIXED_BASE_CASES))
+def test_tree_program_on_a_fixed_base_matches_oracle(emu, monkeypatch, case):  # noqa: F811
+    from ik_amd import capi
+    name, specs, kernel = FIXED_BASE_CASES[case]
+    B = 24
+    urdf, model, om, tasks, ot, q0, tg, M = _generic_case(name, False, specs, B, seed=9)
+    nt = len(tasks)
+    buf = C.create_string_buffer(160)
+    capi.check(capi.lib().ikgpu_problem_plan(model._h, (capi.Task * nt)(*tasks), nt, buf, len(buf)))
+    assert buf.value.decode() == kernel
+    for env in (None, "0"):      # the all-runtime build, then the device's general / posture build
+        if env is not None:
+            monkeypatch.setenv("LANE_EMU_TRIG", env)
+        for iters, damping, step, tol in ((0, 1e-2, 1.0, 1e-4), (1, 1e-2, 1.0, -1.0), (3, 1e-2, 1.0, -1.0), (60, 1e-1, 0.3, 1e-6)):
+            prm = capi.DlsParams(iters, damping, step, tol)
+            qo, ok, it, *_ = run(emu, urdf, tasks, 0, q0, tg, prm, model.nv, M, root=0, ntasks=nt)
+            q_ref, ok_ref, it_ref = O.dls_batch(om, ot, tg, q0, O.params(iters, damping, step, tol))
+            assert np.array_equal(ok, ok_ref) and np.array_equal(it, it_ref), (case, env, iters)
+            assert np.abs(qo - q_ref).max() < 1e-8, (case, env, iters, np.abs(qo - q_ref).max())
+    monkeypatch.delenv("LANE_EMU_TRIG")
+    qg, *_ = run(emu, urdf, tasks, 0, q0, tg, prm, model.nv, M, root=2, ntasks=nt)       # the forced generic program agrees
+    assert np.abs(qg - qo).max() < 1e-8
