@@ -210,7 +210,7 @@ def test_cooperative_and_per_lane_generic_kernels_agree(torch_cuda, case, monkey
 
 
 @pytest.mark.parametrize("case,kernel", [("demo_task_set", "dls_tree<"), ("demo_with_direction_in_pelvis_frame", "dls_generic<"),
-                                         ("fixed_two_feet_priorities", "dls_generic<")])
+                                         ("fixed_two_feet_priorities", "dls_tree<NJ=7,chains=2,fixed_base>")])
 def test_full_size_properties_of_the_demo_and_generic_kernels(torch_cuda, case, kernel):
     """Full batch (65536), size-independent properties instead of an oracle run: the evaluated error of the solution
     vanishes where the solve converged, solving again from the solution moves nothing, two runs give the same bits, base
