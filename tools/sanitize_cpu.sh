@@ -8,7 +8,7 @@ g++ -O1 -g -std=c++17 -fPIC -shared -fsanitize=address,undefined -fno-sanitize-r
     -o /tmp/liblane_emu_asan.so tests/lane_emu/lane_emu.cpp ik_amd/csrc/model.cpp ik_amd/csrc/problem.cpp
 make -s -C oracle asan
 cat > /tmp/ik_asan_run.py <<PY
-import sys, ctypes as C
+import os, sys, ctypes as C
 sys.path[:0] = ["$ROOT/oracle", "$ROOT", "$ROOT/tests"]
 import oracle as O
 O._LIB = C.CDLL("$ROOT/oracle/libik_oracle_asan.so")
@@ -29,6 +29,14 @@ for c in t.COOP_CASES:
     if c != "posture_regulariser": t.test_cooperative_program_matches_oracle(L, c)
 import test_lane_emulation_demo_tree as d
 for c in sorted(d.CASES): d.test_tree_program_with_the_demo_extras_matches_oracle(L, c)
+class MP:  # the tests' monkeypatch, for the LANE_EMU_TRIG switch to the device builds
+    def setenv(self, k, v): os.environ[k] = v
+    def delenv(self, k, raising=True): os.environ.pop(k, None)
+for c in sorted(d.POSTURE_CASES): d.test_tree_program_with_posture_rows_matches_oracle(L, MP(), c)
+for c in sorted(d.FIXED_BASE_CASES): d.test_tree_program_on_a_fixed_base_matches_oracle(L, MP(), c)
+t.test_lane_program_device_general_build(L, MP(), "cassie_fixed", "LeftFootFront", 50, -1.0)
+t.test_tree_program_device_general_build(L, MP(), 50, -1.0)
+t.test_device_sincos_accuracy(L)
 import test_oracle_pik as p, test_oracle_constraints as oc, test_oracle_com as com
 p.test_damp_pseudoinverse_known_answers(None); p.test_rowspace_projector_properties_and_rank(None)
 for k in range(len(p.LOOP_CASES)): p.test_oracle_pik_matches_the_twin(None, k)
