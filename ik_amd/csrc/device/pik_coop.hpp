@@ -26,7 +26,149 @@ namespace ikdev {
 
 struct PikCoopLayout {
     int P, Jb, de, nrm, words;  // offsets into the group's workspace beyond CoopLayout's; `words` = the whole PIK workspace
+    int factored;               // 1: keep the projector as its orthonormal basis V (see coop_pik), never form the nv x nv P
 };
+
+// Orthonormal basis of the row space of a FULL-ROW-RANK, well-conditioned m x nv matrix by Cholesky QR: its Gram matrix
+// A A^T = L L^T (lower triangle packed by rows at offG0, destroyed), then V = L^-1 A in place, one lane per column with no
+// barrier inside -- m + 2 phases against the ~3 m of the pivoted Gram-Schmidt (coop_rowspace_basis), whose projections also run
+// on only m - k of the sixteen lanes.  Any orthonormal basis gives the same projector I - V^T V.  Orthogonality is lost like
+// eps cond(A)^2, and the Gram matrix cannot resolve the reference's rank rule (|R_kk| against eps max|R|), so the shortcut is
+// taken only when every pivot L_kk^2 stays above 1e-4 of the largest diagonal entry (cond^2 < ~1e5: error < 1e-10) in ALL
+// groups of the wave; otherwise it returns false with A untouched and the caller runs the rank-revealing routine.
+template <class AnyFn>
+IKD_FN bool coop_rowspace_basis_cholqr(const CoopLayout &L, const int g, double *ws, const int offRows, const int offG0, const int offdinv,
+                                       const int m, const int nv, AnyFn any_fn) {
+    (void)g;
+    const int npairs = tri(m, 0);
+    double maxdiag = 0.0;
+    for (int k = 0; k < m; ++k) maxdiag = dmax(maxdiag, ws[offG0 + tri(k, k)]);
+    bool ok = maxdiag > 0.0;
+    for (int k = 0; k < m; ++k) {
+        const double d = ws[offG0 + tri(k, k)];
+        ok = ok && d > 1e-4 * maxdiag;          // false for NaN as well
+        const double inv = drsqrt(d);
+        ws[offdinv + k] = inv;
+        const int p0 = tri(k + 1, 0);
+        IKC_FOR(pp, npairs - p0) {
+            const int i = L.pair_i[p0 + pp], j = L.pair_j[p0 + pp];
+            if (j > k) {
+                const double lik = ws[offG0 + tri(i, k)] * inv, ljk = ws[offG0 + tri(j, k)] * inv;
+                ws[offG0 + tri(i, j)] = dfma(-lik, ljk, ws[offG0 + tri(i, j)]);
+            }
+        }
+        IKC_SYNC();
+    }
+    if (any_fn(!ok)) return false;              // wave-uniform: every group of the workgroup takes the same path
+    IKC_FOR(p, npairs) {
+        const int i = L.pair_i[p], j = L.pair_j[p];
+        if (j < i) ws[offG0 + tri(i, j)] *= ws[offdinv + j];
+    }
+    IKC_SYNC();
+    IKC_FOR(c, nv) {                            // forward substitution, column c: V(k, c) = (A(k, c) - sum_{j<k} L(k, j) V(j, c)) / L(k, k)
+        for (int k = 0; k < m; ++k) {
+            double v = ws[offRows + k * nv + c];
+            for (int j = 0; j < k; ++j) v = dfma(-ws[offG0 + tri(k, j)], ws[offRows + j * nv + c], v);
+            ws[offRows + k * nv + c] = v * ws[offdinv + k];
+        }
+    }
+    IKC_SYNC();
+    return true;
+}
+
+// The level loop of ik::pik (pik.cpp:44-65) with the projector kept in factored form.  The reference updates
+// P -= pinv(Jbar) Jbar level by level; pinv(Jbar) Jbar is the orthogonal projector onto the row space of Jbar = J_l P, which
+// lies in the complement of every earlier level's row space -- so P = I - V^T V with V the orthonormal bases of all levels
+// so far stacked row-wise (R rows, kept in the nv x nv region the dense P would occupy).  Then
+//   Jbar = J_l P = J_l - (J_l V^T) V        (the first level: Jbar = J_l, nothing to project)
+//   dq += P da   = da  - V^T (V da)
+// and the nv x nv matrix is never formed: O(ml R nv) per level instead of O(ml nv^2 + rank nv^2).  The coefficients J_l V^T
+// (ml x R) sit behind V's current rows; the host checks that they fit (PikCoopLayout::factored).
+template <class AnyFn>
+IKD_FN void coop_pik_levels_factored(const GenericTables &T, const CoopLayout &L, const PikCoopLayout &K, const PikParams &prm,
+                                     const int g, double *ws, int last_level, AnyFn any_fn IKC_TICK_ARG) {
+    (void)g;
+    const int nv = T.nv;
+    int R = 0;  // rows of V so far (per problem: the four groups of a workgroup may differ; no barrier depends on it)
+    IKC_FOR(c, nv) ws[L.dq + c] = 0.0;
+    IKC_SYNC();
+    for (int l = 0; l < T.nlevels; ++l) {                              // pik.cpp:47
+        const int r0 = T.lvl_row0[l], ml = T.lvl_row0[l + 1] - r0;
+        if (ml == 0) continue;
+        const bool update_P = l != last_level || prm.has_da != 0;
+        const int cf = K.P + R * nv;                                   // ml x R coefficients, behind V
+        IKC_FOR(r, ml) {                                               // de = e_l - J_l dq
+            double s = ws[L.e + r0 + r];
+#pragma unroll 8
+            for (int c = 0; c < nv; ++c) s = dfma(-ws[L.J + (r0 + r) * nv + c], ws[L.dq + c], s);
+            ws[K.de + r] = s;
+        }
+        IKC_FOR(idx, ml * R) {                                         // J_l V^T
+            const int r = idx / R, k = idx % R;
+            double a = 0.0;
+#pragma unroll 8
+            for (int c = 0; c < nv; ++c) a = dfma(ws[L.J + (r0 + r) * nv + c], ws[K.P + k * nv + c], a);
+            ws[cf + idx] = a;
+        }
+        IKC_SYNC();
+        IKC_FOR(idx, ml * nv) {                                        // Jbar = J_l - (J_l V^T) V
+            const int r = idx / nv, c = idx % nv;
+            double a = ws[L.J + (r0 + r) * nv + c];
+            for (int k = 0; k < R; ++k) a = dfma(-ws[cf + r * R + k], ws[K.P + k * nv + c], a);
+            ws[K.Jb + idx] = a;
+        }
+        IKC_SYNC();
+        IKC_TICK(9);
+        // damped step: (Jbar Jbar^T + lambda^2 I) x = de, dq -= Jbar^T x
+        IKC_FOR(p, tri(ml, 0) + ml) {
+            const int i = L.pair_i[p], j = L.pair_j[p];
+            double s;
+            if (i == ml) {
+                s = ws[K.de + j];
+            } else {
+                s = (i == j) ? prm.lam2[l] : 0.0;
+#pragma unroll 8
+                for (int c = 0; c < nv; ++c) s = dfma(ws[K.Jb + i * nv + c], ws[K.Jb + j * nv + c], s);
+                if (update_P) ws[cf + tri(i, j)] = (i == j) ? s - prm.lam2[l] : s;   // Jbar Jbar^T, for the Cholesky-QR basis below
+            }
+            ws[L.G + tri(i, j)] = s;
+        }
+        IKC_SYNC();
+        IKC_TICK(10);
+        coop_chol_solve(L, g, ws, L.G, L.dinv, L.x, ml);
+        IKC_FOR(c, nv) {
+            double s = ws[L.dq + c];
+#pragma unroll 8
+            for (int r = 0; r < ml; ++r) s = dfma(-ws[K.Jb + r * nv + c], ws[L.x + r], s);
+            ws[L.dq + c] = s;
+        }
+        IKC_SYNC();
+        IKC_TICK(11);
+        if (!update_P) continue;
+        int rank = ml;                                                 // v_1 .. v_rank in the first rows of Jb
+        if (!coop_rowspace_basis_cholqr(L, g, ws, K.Jb, cf, cf + tri(ml, 0), ml, nv, any_fn)) rank = coop_rowspace_basis(g, ws, K.Jb, K.nrm, ml, nv);
+        if (rank > nv - R) rank = nv - R;                              // (cannot happen in exact arithmetic)
+        IKC_FOR(idx, rank * nv) ws[K.P + R * nv + idx] = ws[K.Jb + idx];   // append them to V
+        R += rank;
+        IKC_SYNC();
+        IKC_TICK(12);
+    }
+    if (prm.has_da) {                                                  // pik.cpp:65: dq += P da = da - V^T (V da)
+        const int cf = K.P + R * nv;
+        IKC_FOR(k, R) {
+            double a = 0.0;
+            for (int c = 0; c < nv; ++c) a = dfma(ws[K.P + k * nv + c], prm.da[c], a);
+            ws[cf + k] = a;
+        }
+        IKC_SYNC();
+        IKC_FOR(c, nv) {
+            double s = ws[L.dq + c] + prm.da[c];
+            for (int k = 0; k < R; ++k) s = dfma(-ws[cf + k], ws[K.P + k * nv + c], s);
+            ws[L.dq + c] = s;
+        }
+        IKC_SYNC();
+    }
+}
 
 template <class AnyFn>
 IKD_FN void coop_pik(const GenericTables &T, const CoopLayout &L, const PikCoopLayout &K, const PikParams &prm, const int g, double *ws,
@@ -41,6 +183,9 @@ IKD_FN void coop_pik(const GenericTables &T, const CoopLayout &L, const PikCoopL
     IKC_TICK_INIT;
     for (int it = 0; it < prm.max_iterations; ++it) {
         const double e0sq = coop_evaluate(T, L, g, ws IKC_TICK_PASS);    // pik.cpp:41
+        if (K.factored) {
+            coop_pik_levels_factored(T, L, K, prm, g, ws, last_level, any_active IKC_TICK_PASS);
+        } else {
         IKC_FOR(i, nv * nv) ws[K.P + i] = (i / nv == i % nv) ? 1.0 : 0.0;   // pik.cpp:44-45
         IKC_FOR(c, nv) ws[L.dq + c] = 0.0;
         IKC_SYNC();
@@ -102,10 +247,12 @@ IKD_FN void coop_pik(const GenericTables &T, const CoopLayout &L, const PikCoopL
             }
             IKC_SYNC();
         }
+        }  // !K.factored
         const bool stop_now = active && (prm.stop_sq_tol >= 0.0) && (e0sq < prm.stop_sq_tol);   // pik.cpp:67-70
         if (stop_now) { success = true; iters = it; }
         active = active && !stop_now;
         coop_integrate(T, L, g, ws, prm.step_length, active);             // pik.cpp:73-77
+        IKC_TICK(8);
         if (!any_active(active)) break;
     }
     iters_out = iters;

@@ -2,6 +2,9 @@
 // pointer struct its lane program reads (device/generic_solver.hpp: GenericTables), for base pointers that live
 // either on the device (kernels.hip) or on the host (the lane emulator under tests/).
 #pragma once
+#include <algorithm>
+#include <cstdlib>
+#include <string>
 #include "device/coop_solver.hpp"
 #include "device/pik_coop.hpp"
 #include "device/generic_solver.hpp"
@@ -48,6 +51,21 @@ inline ikdev::PikCoopLayout bind_pik_coop_layout(const ProblemHost &ph) {
     const GenericHost &g = ph.generic;
     ikdev::PikCoopLayout K{};
     K.P = g.c_P; K.Jb = g.c_A1; K.de = g.c_Jw; K.nrm = g.c_Jw + g.coop_mmax; K.words = g.coop_words_pik;
+    // factored projector (device/pik_coop.hpp): the coefficients J_l V^T (ml x R) of every level, and V da (R) when the last
+    // level's basis is kept for `da`, must fit behind V's R rows in the nv x nv region; IKGPU_PIK_PROJECTOR=dense keeps P
+    const char *force = std::getenv("IKGPU_PIK_PROJECTOR");
+    bool ok = !(force && std::string(force) == "dense");
+    const int nv = ph.nv;
+    int rows_before = 0;
+    for (int l = 0; l < g.nlevels && ok; ++l) {
+        const int ml = g.ints[g.o_lvlrow0 + l + 1] - g.ints[g.o_lvlrow0 + l];
+        const int R = std::min(rows_before, nv);
+        if (std::max(ml * R, ml * (ml + 1) / 2 + ml) > (nv - R) * nv) ok = false;   // coefficients, then the Gram copy + pivots
+        rows_before += ml;
+    }
+    const int Rend = std::min(rows_before, nv);
+    if (Rend > (nv - Rend) * nv) ok = false;   // V da
+    K.factored = ok ? 1 : 0;
     return K;
 }
 

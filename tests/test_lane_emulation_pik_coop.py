@@ -22,8 +22,12 @@ def run_pik_coop(L, urdf, tasks, q0, tg, prm, root=0):
     return qo, ok, it
 
 
+@pytest.mark.parametrize("projector", ["factored", "dense"])
 @pytest.mark.parametrize("case", sorted(PIK_CASES))
-def test_cooperative_pik_program_matches_oracle(emu, case):  # noqa: F811
+def test_cooperative_pik_program_matches_oracle(emu, monkeypatch, case, projector):  # noqa: F811
+    """projector: the default keeps P = I - V^T V as the stacked orthonormal bases V of the levels (where the coefficients fit
+    behind V, see generic_tables.hpp); IKGPU_PIK_PROJECTOR=dense forms the nv x nv matrix as the reference does."""
+    monkeypatch.setenv("IKGPU_PIK_PROJECTOR", projector)
     name, ff, specs, root, edit, projector_determined = PIK_CASES[case]
     B = 16
     urdf, model, om, tasks, ot, q0, tg, M = _generic_case(name, ff, specs, B, seed=3, xml_edit=edit)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Per-phase cycle counts of the cooperative generic DLS kernel (debug build: make -C ik_amd/csrc KERNEL_EXTRA=-DIKGPU_COOP_PROFILE).
-Runs the demo task set once and prints workgroup 0's cycles per phase and iteration."""
+"""Per-phase cycle counts of the cooperative generic kernels (debug build: make -C ik_amd/csrc KERNEL_EXTRA=-DIKGPU_COOP_PROFILE).
+Runs the demo task set once and prints workgroup 0's cycles per phase and iteration.  `python tools/coop_profile.py pik`: ik::pik with
+the alignment row on a second level (the bench's cassie_demo_pik workload) instead of ik::dls."""
 import ctypes as C
 import os
 import sys
@@ -14,28 +15,34 @@ import ik_amd  # noqa: E402
 from ik_amd import capi, workload  # noqa: E402
 
 model = ik_amd.Model.from_urdf_file(os.path.join(workload.MODELS_DIR, "cassie.kin.urdf"), free_flyer=True)
-problem = ik_amd.InverseKinematicsProblem(model)
+PIK = len(sys.argv) > 1 and sys.argv[1] == "pik"
+os.environ["IKGPU_DLS_KERNEL"] = "generic"
+problem = ik_amd.InverseKinematicsProblem(model, 1 if PIK else 0)
 problem.add_frame_task("fl", ik_amd.FrameTask.create(model, "LeftFootFront", ik_amd.KinematicType.Position, "pelvis"))
 problem.add_frame_task("pelvis", ik_amd.FrameTask.create(model, "pelvis", ik_amd.KinematicType.Full))
-problem.add_align_axis_task("align", ik_amd.AlignAxisTask.create(model, "LeftFootFront", ik_amd.AlignAxisType.AxisY))
-data = ik_amd.dls_data(problem)
+problem.add_align_axis_task("align", ik_amd.AlignAxisTask.create(model, "LeftFootFront", ik_amd.AlignAxisType.AxisY), 1 if PIK else 0)
+data = ik_amd.pik_data(problem) if PIK else ik_amd.dls_data(problem)
+if PIK:
+    data.lambda_ = [0.1, 0.1]
 B, iters = 65536, 50
 q0, qs = workload.freeflyer_workload(model.lowerPositionLimit, model.upperPositionLimit, workload.cassie_nominal(model.names), np.arange(B), seed=0)
 Q0 = torch.from_numpy(np.ascontiguousarray(q0.T)).cuda()
 T = torch.zeros((3, 12, B), dtype=torch.float64, device="cuda")
 T[:, [0, 4, 8]] = 1.0
 T[0, 11], T[1, 11], T[2, 9] = -0.8, 1.0, 1.0
-p = ik_amd.dls_parameters(max_iterations=iters, damping=1e-2, step_length=1.0)
+p = ik_amd.pik_parameters(max_iterations=iters, step_length=1.0) if PIK else ik_amd.dls_parameters(max_iterations=iters, damping=1e-2, step_length=1.0)
+solve = ik_amd.pik_batch if PIK else ik_amd.dls_batch
 L = capi.lib()
 out = (C.c_longlong * 16)()
-ik_amd.dls_batch(problem, Q0, T, data, ik_amd.never_stop_visitor(), p)
+solve(problem, Q0, T, data, ik_amd.never_stop_visitor(), p)
 torch.cuda.synchronize()
 L.ikgpu_debug_coop_profile(out, 1)
-ik_amd.dls_batch(problem, Q0, T, data, ik_amd.never_stop_visitor(), p)
+solve(problem, Q0, T, data, ik_amd.never_stop_visitor(), p)
 torch.cuda.synchronize()
 L.ikgpu_debug_coop_profile(out, 1)
-names = ["local transforms", "tree levels + Jw", "task blocks", "task Jacobian columns", "Gram", "Cholesky", "back substitution", "dq", "integrate"]
-tot = sum(out[:9])
-for n, v in zip(names, out[:9]):
+names = ["local transforms", "tree levels + Jw", "task blocks", "task Jacobian columns", "Gram", "Cholesky", "back substitution", "dq", "integrate",
+         "pik: de, Jbar", "pik: Gram", "pik: Cholesky + dq", "pik: row-space basis"]
+tot = sum(out[:13])
+for n, v in zip(names, out[:13]):
     print("%-24s %9.0f cycles / iteration  %5.1f %%" % (n, v / iters, 100.0 * v / tot))
 print("%-24s %9.0f cycles / iteration (s_memtime, workgroup 0)" % ("total", tot / iters))
