@@ -60,6 +60,8 @@ __device__ long long g_coop_prof[16];
 struct CoopLayout {
     int q, tg, A0, A1, Jw, tb, e, J, G, dinv, x, dq, sf, words;  // offsets into the group's workspace, in doubles
     int cb, Jc, cnrm;            // FrameConstraint projection: per-constraint placements (36 each), Jc (Mc x nv), Mc scratch words
+    int cholqr_c;                // 1: Jc Jc^T and its pivots fit the G region (the Cholesky-QR basis may be tried)
+    const int *cpair_i, *cpair_j;  // [tri(Mc, 0)] lower triangle of Jc Jc^T by rows
     const int *csupp_f, *csupp_r;  // [ncons][nv] 1 when tangent column c moves the constrained frame / its reference frame
     int rounds, npairs;
     const int *support;          // [ntasks][nv] 1 when the task's rows touch tangent column c
@@ -401,6 +403,54 @@ IKD_FN int coop_rowspace_basis(const int g, double *ws, const int offRows, const
     return rank;
 }
 
+// Orthonormal basis of the row space of a FULL-ROW-RANK, well-conditioned m x nv matrix by Cholesky QR: its Gram matrix
+// A A^T = L L^T (lower triangle packed by rows at offG0, destroyed), then V = L^-1 A in place, one lane per column with no
+// barrier inside -- m + 2 phases against the ~3 m of the pivoted Gram-Schmidt (coop_rowspace_basis), whose projections also run
+// on only m - k of the sixteen lanes.  Any orthonormal basis gives the same projector I - V^T V.  Orthogonality is lost like
+// eps cond(A)^2, and the Gram matrix cannot resolve the reference's rank rule (|R_kk| against eps max|R|), so the shortcut is
+// taken only when every pivot L_kk^2 stays above 1e-4 of the largest diagonal entry (cond^2 < ~1e5: error < 1e-10) in ALL
+// groups of the wave; otherwise it returns false with A untouched and the caller runs the rank-revealing routine.
+// pair_i / pair_j: the (i, j) of the lower triangle of an (at least) m-row matrix listed by rows.
+template <class AnyFn>
+IKD_FN bool coop_rowspace_basis_cholqr(const int *pair_i, const int *pair_j, const int g, double *ws, const int offRows, const int offG0,
+                                       const int offdinv, const int m, const int nv, AnyFn any_fn) {
+    (void)g;
+    const int npairs = tri(m, 0);
+    double maxdiag = 0.0;
+    for (int k = 0; k < m; ++k) maxdiag = dmax(maxdiag, ws[offG0 + tri(k, k)]);
+    bool ok = maxdiag > 0.0;
+    for (int k = 0; k < m; ++k) {
+        const double d = ws[offG0 + tri(k, k)];
+        ok = ok && d > 1e-4 * maxdiag;          // false for NaN as well
+        const double inv = drsqrt(d);
+        ws[offdinv + k] = inv;
+        const int p0 = tri(k + 1, 0);
+        IKC_FOR(pp, npairs - p0) {
+            const int i = pair_i[p0 + pp], j = pair_j[p0 + pp];
+            if (j > k) {
+                const double lik = ws[offG0 + tri(i, k)] * inv, ljk = ws[offG0 + tri(j, k)] * inv;
+                ws[offG0 + tri(i, j)] = dfma(-lik, ljk, ws[offG0 + tri(i, j)]);
+            }
+        }
+        IKC_SYNC();
+    }
+    if (any_fn(!ok)) return false;              // wave-uniform: every group of the workgroup takes the same path
+    IKC_FOR(p, npairs) {
+        const int i = pair_i[p], j = pair_j[p];
+        if (j < i) ws[offG0 + tri(i, j)] *= ws[offdinv + j];
+    }
+    IKC_SYNC();
+    IKC_FOR(c, nv) {                            // forward substitution, column c: V(k, c) = (A(k, c) - sum_{j<k} L(k, j) V(j, c)) / L(k, k)
+        for (int k = 0; k < m; ++k) {
+            double v = ws[offRows + k * nv + c];
+            for (int j = 0; j < k; ++j) v = dfma(-ws[offG0 + tri(k, j)], ws[offRows + j * nv + c], v);
+            ws[offRows + k * nv + c] = v * ws[offdinv + k];
+        }
+    }
+    IKC_SYNC();
+    return true;
+}
+
 // q <- clip(integrate(q, step * dq)) (ik/ik/dls.cpp:67-71), one lane per joint; a group that is no longer active keeps its q.
 // Ends on a barrier.
 IKD_FN void coop_integrate(const GenericTables &T, const CoopLayout &L, const int g, double *ws, const double step_length, const bool active) {
@@ -514,7 +564,19 @@ IKD_FN void coop_dls(const GenericTables &T, const CoopLayout &L, const LoopPara
                 }
             }
             IKC_SYNC();
-            const int rank = coop_rowspace_basis(g, ws, L.Jc, L.cnrm, T.Mc, nv);   // v_1 .. v_rank in the first rows of Jc
+            bool by_cholqr = false;   // full-rank, well-conditioned Jc (the usual case): Cholesky QR, see coop_rowspace_basis_cholqr
+            if (L.cholqr_c) {
+                IKC_FOR(p, tri(T.Mc, 0)) {   // Jc Jc^T where the per-constraint placements lived (dead now)
+                    const int i = L.cpair_i[p], j = L.cpair_j[p];
+                    double s = 0.0;
+#pragma unroll 8
+                    for (int c = 0; c < nv; ++c) s = dfma(ws[L.Jc + i * nv + c], ws[L.Jc + j * nv + c], s);
+                    ws[L.G + tri(i, j)] = s;
+                }
+                IKC_SYNC();
+                by_cholqr = coop_rowspace_basis_cholqr(L.cpair_i, L.cpair_j, g, ws, L.Jc, L.G, L.G + tri(T.Mc, 0), T.Mc, nv, any_active);
+            }
+            const int rank = by_cholqr ? T.Mc : coop_rowspace_basis(g, ws, L.Jc, L.cnrm, T.Mc, nv);   // v_1 .. v_rank in the first rows of Jc
             IKC_FOR(k, T.Mc) {
                 double d = 0.0;
                 if (k < rank)

@@ -29,53 +29,6 @@ struct PikCoopLayout {
     int factored;               // 1: keep the projector as its orthonormal basis V (see coop_pik), never form the nv x nv P
 };
 
-// Orthonormal basis of the row space of a FULL-ROW-RANK, well-conditioned m x nv matrix by Cholesky QR: its Gram matrix
-// A A^T = L L^T (lower triangle packed by rows at offG0, destroyed), then V = L^-1 A in place, one lane per column with no
-// barrier inside -- m + 2 phases against the ~3 m of the pivoted Gram-Schmidt (coop_rowspace_basis), whose projections also run
-// on only m - k of the sixteen lanes.  Any orthonormal basis gives the same projector I - V^T V.  Orthogonality is lost like
-// eps cond(A)^2, and the Gram matrix cannot resolve the reference's rank rule (|R_kk| against eps max|R|), so the shortcut is
-// taken only when every pivot L_kk^2 stays above 1e-4 of the largest diagonal entry (cond^2 < ~1e5: error < 1e-10) in ALL
-// groups of the wave; otherwise it returns false with A untouched and the caller runs the rank-revealing routine.
-template <class AnyFn>
-IKD_FN bool coop_rowspace_basis_cholqr(const CoopLayout &L, const int g, double *ws, const int offRows, const int offG0, const int offdinv,
-                                       const int m, const int nv, AnyFn any_fn) {
-    (void)g;
-    const int npairs = tri(m, 0);
-    double maxdiag = 0.0;
-    for (int k = 0; k < m; ++k) maxdiag = dmax(maxdiag, ws[offG0 + tri(k, k)]);
-    bool ok = maxdiag > 0.0;
-    for (int k = 0; k < m; ++k) {
-        const double d = ws[offG0 + tri(k, k)];
-        ok = ok && d > 1e-4 * maxdiag;          // false for NaN as well
-        const double inv = drsqrt(d);
-        ws[offdinv + k] = inv;
-        const int p0 = tri(k + 1, 0);
-        IKC_FOR(pp, npairs - p0) {
-            const int i = L.pair_i[p0 + pp], j = L.pair_j[p0 + pp];
-            if (j > k) {
-                const double lik = ws[offG0 + tri(i, k)] * inv, ljk = ws[offG0 + tri(j, k)] * inv;
-                ws[offG0 + tri(i, j)] = dfma(-lik, ljk, ws[offG0 + tri(i, j)]);
-            }
-        }
-        IKC_SYNC();
-    }
-    if (any_fn(!ok)) return false;              // wave-uniform: every group of the workgroup takes the same path
-    IKC_FOR(p, npairs) {
-        const int i = L.pair_i[p], j = L.pair_j[p];
-        if (j < i) ws[offG0 + tri(i, j)] *= ws[offdinv + j];
-    }
-    IKC_SYNC();
-    IKC_FOR(c, nv) {                            // forward substitution, column c: V(k, c) = (A(k, c) - sum_{j<k} L(k, j) V(j, c)) / L(k, k)
-        for (int k = 0; k < m; ++k) {
-            double v = ws[offRows + k * nv + c];
-            for (int j = 0; j < k; ++j) v = dfma(-ws[offG0 + tri(k, j)], ws[offRows + j * nv + c], v);
-            ws[offRows + k * nv + c] = v * ws[offdinv + k];
-        }
-    }
-    IKC_SYNC();
-    return true;
-}
-
 // The level loop of ik::pik (pik.cpp:44-65) with the projector kept in factored form.  The reference updates
 // P -= pinv(Jbar) Jbar level by level; pinv(Jbar) Jbar is the orthogonal projector onto the row space of Jbar = J_l P, which
 // lies in the complement of every earlier level's row space -- so P = I - V^T V with V the orthonormal bases of all levels
@@ -146,7 +99,7 @@ IKD_FN void coop_pik_levels_factored(const GenericTables &T, const CoopLayout &L
         IKC_TICK(11);
         if (!update_P) continue;
         int rank = ml;                                                 // v_1 .. v_rank in the first rows of Jb
-        if (!coop_rowspace_basis_cholqr(L, g, ws, K.Jb, cf, cf + tri(ml, 0), ml, nv, any_fn)) rank = coop_rowspace_basis(g, ws, K.Jb, K.nrm, ml, nv);
+        if (!coop_rowspace_basis_cholqr(L.pair_i, L.pair_j, g, ws, K.Jb, cf, cf + tri(ml, 0), ml, nv, any_fn)) rank = coop_rowspace_basis(g, ws, K.Jb, K.nrm, ml, nv);
         if (rank > nv - R) rank = nv - R;                              // (cannot happen in exact arithmetic)
         IKC_FOR(idx, rank * nv) ws[K.P + R * nv + idx] = ws[K.Jb + idx];   // append them to V
         R += rank;

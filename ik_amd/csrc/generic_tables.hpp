@@ -41,7 +41,15 @@ inline ikdev::CoopLayout bind_coop_layout(const ProblemHost &ph, const int32_t *
     L.q = g.c_q; L.tg = g.c_tg; L.A0 = g.c_A0; L.A1 = g.c_A1; L.Jw = g.c_Jw; L.tb = g.c_tb; L.e = g.c_e; L.J = g.c_J; L.G = g.c_G;
     L.dinv = g.c_dinv; L.x = g.c_x; L.dq = g.c_dq; L.sf = g.c_sf; L.cb = g.c_cb; L.Jc = g.c_Jc; L.cnrm = g.c_cnrm; L.words = g.coop_words;
     L.rounds = g.coop_rounds; L.npairs = g.coop_npairs;
+    {   // Cholesky-QR basis of the constraint Jacobian: Jc Jc^T (packed lower triangle) + its Mc pivots go where G / dinv / x and
+        // the per-constraint placements live (all dead by then), indexed through its own pair tables (cpair_i / cpair_j)
+        const int Mc = ph.crows, M = ph.rows, region = g.coop_words - 1 - g.c_G;
+        const char *force = std::getenv("IKGPU_PIK_PROJECTOR");   // "dense": the reference-shaped routines everywhere (tests)
+        (void)M;
+        L.cholqr_c = (Mc > 0 && Mc * (Mc + 1) / 2 + Mc <= region && !(force && std::string(force) == "dense")) ? 1 : 0;
+    }
     L.support = ibase + g.o_csupport; L.pair_i = ibase + g.o_cpair_i; L.pair_j = ibase + g.o_cpair_j; L.order = ibase + g.o_cup; L.lvl_start = ibase + g.o_clvl; L.tb_index = ibase + g.o_ctbindex; L.col_joint = ibase + g.o_ccoljoint; L.csupp_f = ibase + g.o_ccsf; L.csupp_r = ibase + g.o_ccsr;
+    L.cpair_i = ibase + g.o_ccpair_i; L.cpair_j = ibase + g.o_ccpair_j;
     return L;
 }
 

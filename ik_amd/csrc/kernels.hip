@@ -434,7 +434,7 @@ __device__ __forceinline__ double *coop_stage(double *lds, ikdev::GenericTables 
     rebase(T.j_mass, s.dbls, ld); rebase(T.j_lever, s.dbls, ld); rebase(T.j_submass, s.dbls, ld);
     rebase(T.c_type, s.ints, li); rebase(T.c_fjoint, s.ints, li); rebase(T.c_rjoint, s.ints, li); rebase(T.c_row, s.ints, li);
     rebase(T.c_dim, s.ints, li); rebase(T.c_fpl, s.dbls, ld); rebase(T.c_rpl, s.dbls, ld);
-    rebase(L.csupp_f, s.ints, li); rebase(L.csupp_r, s.ints, li);
+    rebase(L.csupp_f, s.ints, li); rebase(L.csupp_r, s.ints, li); rebase(L.cpair_i, s.ints, li); rebase(L.cpair_j, s.ints, li);
     return lds + s.n_dbls + (s.n_ints + 1) / 2;
 }
 

@@ -252,6 +252,11 @@ void build_coop(ProblemHost &ph, const Model &m) {
     g.coop_npairs = static_cast<int>(pi.size());
     g.o_cpair_i = put_i(pi);
     g.o_cpair_j = put_i(pj);
+    std::vector<int32_t> ci, cj;   // lower triangle of Jc Jc^T (Cholesky-QR basis of the constraint Jacobian)
+    for (int i = 0; i < ph.crows; ++i)
+        for (int j = 0; j <= i; ++j) { ci.push_back(i); cj.push_back(j); }
+    g.o_ccpair_i = put_i(ci);
+    g.o_ccpair_j = put_i(cj);
     // forward kinematics by tree depth: the joints of one level are independent and compose with their parent's world
     // placement from the level before (the same products, in the same order, as the sequential pass of the per-lane program)
     std::vector<int32_t> depth(nj, 0), order, lvl_start;

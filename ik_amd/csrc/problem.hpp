@@ -32,6 +32,7 @@ struct GenericHost {
     int nlevels = 1, o_lvlrow0 = 0;                               // prioritised IK: level -> first row (into ints)
     int off_P = 0, off_Jb = 0, off_de = 0, ws_words_pik = 0;      // and its extra workspace
     int o_ctype = 0, o_cfjoint = 0, o_crjoint = 0, o_crow = 0, o_cdim = 0;  // FrameConstraint rows (into ints)
+    int o_ccpair_i = 0, o_ccpair_j = 0;  // cooperative form: (i, j) of the lower triangle of the Mc x Mc matrix Jc Jc^T, by rows
     int o_cfpl = 0, o_crpl = 0;                                              // (into dbls)
     int off_Jc = 0;
     // cooperative form of the DLS program (device/coop_solver.hpp): 16 lanes per problem, workspace in LDS
