@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <mutex>
 #include <new>
 #include <stdexcept>
 #include <string>
@@ -15,7 +16,17 @@
 #include "model.hpp"
 #include "problem.hpp"
 
+// Staging area of the host-pointer entry points for small batches (host_solve below): grows on demand, guarded by a mutex a
+// caller only ever try-locks.
+struct Staging {
+    std::mutex mu;
+    void *dev = nullptr, *host = nullptr;
+    size_t cap = 0;
+};
+constexpr size_t kStageLimit = size_t(1) << 20;  // batches whose buffers total at most 1 MiB take the staged path
+
 struct ikgpu_problem {
+    mutable Staging stage;
     ikgpu::ProblemHost host;
     ikgpu::ProblemHost gen;  // the same problem analysed for the generic lane program (what ik::pik runs on)
     ikgpu::DeviceTables dev;
@@ -126,6 +137,42 @@ int host_solve(const ikgpu_problem *p, int64_t B, const double *q0, const double
         DeviceGuard g(p->device);
         if (!g.ok) return fail(IKGPU_ERR_DEVICE, "hipSetDevice failed");
         const size_t nb_q = sizeof(double) * p->host.nq * B, nb_t = sizeof(double) * 12 * p->host.ntasks * B;
+        // Small batches -- the reference's own call pattern is ONE problem per call, 50 times a second (ik_ros/src/cassie.cpp:112)
+        // -- go through a staging area the problem keeps: one pinned host buffer and one device buffer laid out
+        // [q0 | targets | q_out | iters | success], so a call is two copies and a launch instead of five allocations, five
+        // copies, a device synchronise and five frees.  A second thread calling on the same problem meanwhile takes the path below.
+        const size_t off_t = nb_q, off_q = off_t + nb_t, off_i = off_q + nb_q, off_s = off_i + sizeof(int32_t) * B;
+        const size_t total = (off_s + B + 7) / 8 * 8;
+        if (total <= kStageLimit) {
+            std::unique_lock<std::mutex> lock(p->stage.mu, std::try_to_lock);
+            if (lock.owns_lock()) {
+                Staging &st = p->stage;
+                if (st.cap < total) {
+                    if (st.dev) (void)hipFree(st.dev);
+                    if (st.host) (void)hipHostFree(st.host);
+                    st.dev = st.host = nullptr;
+                    st.cap = 0;
+                    const size_t cap = std::max<size_t>(total, 4096);
+                    if (hipMalloc(&st.dev, cap) == hipSuccess && hipHostMalloc(&st.host, cap, hipHostMallocDefault) == hipSuccess) st.cap = cap;
+                }
+                if (st.cap >= total) {
+                    char *h = static_cast<char *>(st.host), *d = static_cast<char *>(st.dev);
+                    std::memcpy(h, q0, nb_q);
+                    std::memcpy(h + off_t, targets, nb_t);
+                    hipError_t e = hipMemcpy(d, h, off_q, hipMemcpyHostToDevice);
+                    if (e != hipSuccess) return hip_fail(e, "host-pointer solve (staged copy in)");
+                    const int rc = launch(reinterpret_cast<double *>(d), reinterpret_cast<double *>(d + off_t), reinterpret_cast<double *>(d + off_q),
+                                          reinterpret_cast<uint8_t *>(d + off_s), reinterpret_cast<int32_t *>(d + off_i));
+                    if (rc != IKGPU_OK) return rc;
+                    e = hipMemcpy(h + off_q, d + off_q, total - off_q, hipMemcpyDeviceToHost);   // waits for the launch on the null stream
+                    if (e != hipSuccess) return hip_fail(e, "host-pointer solve (staged copy out)");
+                    std::memcpy(q_out, h + off_q, nb_q);
+                    if (iters) std::memcpy(iters, h + off_i, sizeof(int32_t) * B);
+                    if (success) std::memcpy(success, h + off_s, B);
+                    return static_cast<int>(IKGPU_OK);
+                }
+            }
+        }
         double *d_q0 = nullptr, *d_t = nullptr, *d_q = nullptr;
         uint8_t *d_s = nullptr;
         int32_t *d_i = nullptr;
@@ -328,6 +375,8 @@ void ikgpu_problem_destroy(ikgpu_problem *p) {
     (void)hipFree(p->dev.chain_desc);
     (void)hipFree(p->dev.g_ints);
     (void)hipFree(p->dev.g_dbls);
+    if (p->stage.dev) (void)hipFree(p->stage.dev);
+    if (p->stage.host) (void)hipHostFree(p->stage.host);
     delete p;
 }
 

@@ -153,3 +153,35 @@ def test_a_nan_lane_stays_alone(ctx):
     keep[70] = keep[133] = False
     assert torch.equal(Qb[:, keep], Q[:, keep]) and torch.equal(okb[keep], ok[keep]) and torch.equal(itb[keep], it[keep])
     assert okb[133].item() == 0      # a NaN target never passes the stop test
+
+
+def test_host_pointer_calls_from_two_threads_on_one_problem(ctx):
+    """The host-pointer entry points keep a staging area per problem for small batches (one thread at a time; a second caller
+    takes the allocate-per-call path): results are the same either way, from any number of threads, for any batch size around the
+    staging limit."""
+    import threading
+    ik = ctx["ik"]
+    problem, data = ctx["problem"], ctx["data"]
+    q0, tg = ctx["inputs"](4000)                       # 4000 problems: 4000 * (2 * 128 + 96 + 5) B > 1 MiB, beyond the staging limit
+    want, ok_w, it_w = ik.dls_batch(problem, q0, tg, data, layout="aos")
+    for B in (1, 7, 2000):                             # staged
+        Q, ok, it = ik.dls_batch(problem, q0[:B], tg[:B], data, layout="aos")
+        assert np.array_equal(Q, want[:B]) and np.array_equal(ok, ok_w[:B]) and np.array_equal(it, it_w[:B])
+    errors = []
+
+    def worker(lo):
+        try:
+            for k in range(40):
+                b = lo + k
+                Q, ok, it = ik.dls_batch(problem, q0[b:b + 1], tg[b:b + 1], data, layout="aos")
+                if not (np.array_equal(Q[0], want[b]) and ok[0] == ok_w[b] and it[0] == it_w[b]):
+                    errors.append(b)
+        except Exception as exc:  # noqa: BLE001
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=worker, args=(lo,)) for lo in (0, 100, 200)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
