@@ -106,11 +106,18 @@ hipError_t run_dls(const ProblemHost &ph, const DeviceTables &dt, const BatchIO 
     a.iters = io.iters;
     // two builds per shape: the hot one (known placement mask + unit weights, all folded at compile time) and the
     // general one (nothing skipped, weights always applied); neither has a branch inside the iteration
-    constexpr int kHot = HotMask<NJ>::value | (1 << ikdev::kSpecUnit);
-    if (HotMask<NJ>::value != 0 && (a.prm.idmask & HotMask<NJ>::value) == HotMask<NJ>::value && a.prm.unit_weights)
-        hipLaunchKernelGGL((dls_chain_kernel<NJ, KT, kHot>), grid_for(io.B), dim3(kBlock), 0, stream, a);
-    else
-        hipLaunchKernelGGL((dls_chain_kernel<NJ, KT, 0>), grid_for(io.B), dim3(kBlock), 0, stream, a);
+    // ... and, for the shapes with a known mask, one in between: the mask folded, the weights applied (a weighted task on a
+    // Cassie leg or a UR arm keeps the skipped placement products)
+    constexpr int kMask = HotMask<NJ>::value;
+    constexpr int kHot = kMask | (1 << ikdev::kSpecUnit);
+    if constexpr (kMask != 0) {
+        if ((a.prm.idmask & kMask) == kMask) {
+            if (a.prm.unit_weights) hipLaunchKernelGGL((dls_chain_kernel<NJ, KT, kHot>), grid_for(io.B), dim3(kBlock), 0, stream, a);
+            else hipLaunchKernelGGL((dls_chain_kernel<NJ, KT, kMask>), grid_for(io.B), dim3(kBlock), 0, stream, a);
+            return hipGetLastError();
+        }
+    }
+    hipLaunchKernelGGL((dls_chain_kernel<NJ, KT, 0>), grid_for(io.B), dim3(kBlock), 0, stream, a);
     return hipGetLastError();
 }
 
