@@ -185,3 +185,46 @@ def test_host_pointer_calls_from_two_threads_on_one_problem(ctx):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("case", ["full_body_tree", "demo_with_posture_tree", "generic_cooperative", "pik_cooperative"])
+def test_hip_graph_capture_of_the_other_kernels(ctx, case, monkeypatch):
+    """The tree kernels (hot build; posture build with its dynamic LDS) and the cooperative generic / PIK kernels allocate nothing
+    and never synchronise either: one capture, replays with the same bits."""
+    torch, ik = ctx["torch"], ctx["ik"]
+    from test_gpu_generic import build
+    monkeypatch.delenv("IKGPU_DLS_KERNEL", raising=False)
+    specs = {
+        "full_body_tree": [("frame", "LeftFootFront", "universe", 2, 0, None), ("frame", "RightFootFront", "universe", 2, 0, None),
+                           ("frame", "pelvis", "universe", 2, 0, None)],
+        "demo_with_posture_tree": [("frame", "LeftFootFront", "pelvis", 0, 0, None), ("frame", "pelvis", "universe", 2, 0, None),
+                                   ("posture", 16, None, None, 1, ([0.1] * 16, [1.0] * 16))],
+        "generic_cooperative": [("frame", "LeftFootFront", "universe", 2, 0, None), ("frame", "RightFootFront", "universe", 2, 0, None),
+                                ("frame", "LeftFootBack", "universe", 0, 0, None)],
+        "pik_cooperative": [("frame", "LeftFootFront", "universe", 2, 0, None), ("frame", "pelvis", "universe", 2, 1, None)],
+    }[case]
+    B = 1000
+    ik_amd, O, model, problem, data, om, ot, q0, tg = build("cassie", True, specs, B, seed=23)
+    Q0 = torch.from_numpy(np.ascontiguousarray(q0.T)).cuda()
+    T = torch.from_numpy(np.ascontiguousarray(tg.transpose(1, 2, 0))).cuda()
+    if case == "pik_cooperative":
+        data = ik.pik_data(problem, device=0)
+        data.lambda_ = [0.1, 0.1]
+        solve, p = ik.pik_batch, ik.pik_parameters(max_iterations=12, step_length=0.5)
+        assert data.kernel.startswith("pik_generic<")
+    else:
+        solve, p = ik.dls_batch, ik.dls_parameters(max_iterations=12, damping=1e-1, step_length=0.5)
+        assert data.kernel.startswith({"full_body_tree": "dls_tree<NJ=7,chains=2,base_task>", "demo_with_posture_tree": "dls_tree<NJ=7,chains=1,base_task,base_reference,posture>",
+                                       "generic_cooperative": "dls_generic<"}[case])
+    v = ik.never_stop_visitor()
+    ref, ok_ref, it_ref = solve(problem, Q0, T, data, v, p)
+    out = (torch.empty_like(Q0), torch.empty(B, dtype=torch.uint8, device="cuda"), torch.empty(B, dtype=torch.int32, device="cuda"))
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(3):
+            solve(problem, Q0, T, data, v, p, out=out)
+    out[0].zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], ref) and torch.equal(out[1], ok_ref) and torch.equal(out[2], it_ref)
