@@ -3,34 +3,32 @@
 
 A "step" is one pass of the hot path over one batch already resident in HBM: B independent
 fixed-iteration DLS solves (reference ik::dls, ik/ik/dls.cpp:5-78; lambda = 1e-2, step = 1.0,
-never-stop visitor) plus, for N > 1, the RCCL all-gather of the solved configurations.  Weak scaling:
-B per GPU is fixed.  Default workload = the one the metric is quoted on: Cassie single-leg chain,
-B = 65536, 50 iterations.
+never-stop visitor) plus, for N > 1, the RCCL all-gather of the solved configurations.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--iters I]
-                    [--workload cassie_leg|cassie_full_body|ur5|ur10|cassie_demo|cassie_demo_posture|cassie_demo_pik] [--no-cpu]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--iters I] [--workload NAME] [--no-cpu]
+                    [--scaling weak|strong] [--global-batch G] [--gather none|full|compact] [--launcher]
 
-Rank 0 prints ONE JSON line.
+N = 1 (default): the configuration the metric is quoted on -- Cassie single-leg chain, B = 65536, 50 iterations.
+N > 1 (default): BASELINE.json's config 4 -- the SAME 262144 problems split into contiguous shards (strong scaling),
+one RCCL all-gather of the results per step.  `--scaling weak` keeps B = 65536 per GPU instead.
+`python bench.py --gpus N` with N > 1 starts its own ranks (`python -m torch.distributed.run --nproc-per-node N bench.py ...` as
+a CHILD process, before this process touches the GPU) and relays rank 0's line; under an existing torch.distributed.run launch
+(RANK / WORLD_SIZE set) it is simply one rank.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
-
-import ik_amd  # noqa: E402
-from ik_amd import distributed as ikdist  # noqa: E402
-from ik_amd import workload  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 FP64_VALU_PEAK_TF = 78.6  # 256 CU x 4 SIMD x 16 FP64 FMA lanes x 2 flop x 2.4 GHz
+CONFIG4_GLOBAL_BATCH = 262144
+SIMDS = 256 * 4
 
 # Algorithmic HBM bytes per solve (SURVEY.md 8d): q0 in + targets in + q out + success + iters
 #   = 8 nq + 96 T + 8 nq + 1 + 4
@@ -41,12 +39,20 @@ WORKLOADS = {
                              text="Cassie full body (cassie.urdf + free-flyer, nq=23 / nv=22), SE(3) tasks on LeftFootFront, "
                                   "RightFootFront and pelvis (M=18)"),
     "ur5": dict(urdf="ur5", free_flyer=False, frames=["tool0"], nq=6,
-                text="UR5 arm (ur5.urdf, nq=6), one SE(3) tool0 task, joint-limit projection after every step"),
+                text="UR5 arm (ur5.urdf, nq=6), one SE(3) tool0 task, joint-limit projection after every step (stock limits, targets "
+                     "near the start: the projection rarely binds)"),
     # BASELINE.json's config 5 names a UR10; the reference ships a UR5 only, this model is authored from the public
     # ur_description constants (fixtures/make_ur10_urdf.py) and is NOT a reference file
     "ur10": dict(urdf="ur10", free_flyer=False, frames=["tool0"], nq=6,
                  text="UR10 arm (fixtures/models/ur10.kin.urdf, authored from public constants, not in the reference; nq=6), one SE(3) "
-                      "tool0 task, joint-limit projection after every step"),
+                      "tool0 task, joint-limit projection after every step (stock limits, targets near the start)"),
+    # config 5 with the projection live: limits narrowed to +-2 rad, targets FK(q*) with q* uniform in them
+    "ur5_clamp": dict(urdf="ur5", free_flyer=False, frames=["tool0"], nq=6, narrow=2.0,
+                      text="UR5 arm with every joint limit narrowed to +-2 rad, q* uniform in the limits: the joint-limit projection "
+                           "binds in the timed region"),
+    "ur10_clamp": dict(urdf="ur10", free_flyer=False, frames=["tool0"], nq=6, narrow=2.0,
+                       text="UR10 arm (authored model, not in the reference) with every joint limit narrowed to +-2 rad, q* uniform in the "
+                            "limits: the joint-limit projection binds in the timed region"),
     # the demo's own task set (reference ik_ros/src/cassie.cpp:45-81): the tree kernel's general build
     "cassie_demo": dict(urdf="cassie", free_flyer=True, frames=["LeftFootFront", "pelvis", "LeftFootFront"], nq=23,
                         tasks=[("frame", "LeftFootFront", 0, "pelvis"), ("frame", "pelvis", 2, "universe"),
@@ -72,6 +78,57 @@ WORKLOADS = {
 }
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=None, help="problems per GPU (weak scaling; default 65536)")
+    ap.add_argument("--global-batch", type=int, default=None, help="problems in the whole job (strong scaling; default 262144)")
+    ap.add_argument("--scaling", choices=("auto", "weak", "strong"), default="auto",
+                    help="auto: weak (B = 65536, the metric's batch) at N = 1, strong (config 4: 262144 problems in all) at N > 1")
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--workload", default="cassie_leg", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--gather", choices=("auto", "none", "full", "compact"), default="auto",
+                    help="the exchange step: full = every rank's whole q + flags (the default at N > 1), compact = only the rows of q a "
+                         "solve can move + flags; none = no collective (the default at N = 1)")
+    ap.add_argument("--launcher", action="store_true",
+                    help="start the ranks through torch.distributed.run even at N = 1 (rehearses the N > 1 launch and RCCL init on one GPU)")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="launch nothing but the warm-up and timed steps (profiling passes: every dispatch is the same launch)")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside a torch.distributed.run launch: start the N ranks as children of this process --
+    which has not touched the GPU (no torch import yet, no HIP call) and never will -- and relay rank 0's JSON line."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL's intra-node transport needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)]
+    cmd += [a for a in sys.argv[1:] if a != "--launcher"]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    for l in proc.stdout.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if lines:
+        print(lines[-1])
+    sys.stdout.flush()
+    if proc.returncode != 0 or not lines:
+        raise SystemExit(proc.returncode or 1)
+
+
 def bytes_per_solve(w):
     posture = 8 * w["posture"]["nj"] if w.get("posture") else 0      # one target value per posture row
     return 8 * w["nq"] + 96 * len(w["frames"]) + posture + 8 * w["nq"] + 1 + 4
@@ -85,13 +142,25 @@ def load_kernel_stats():
     return {}
 
 
+def load_model(ik_amd, workload, w):
+    xml = open(os.path.join(workload.MODELS_DIR, w["urdf"] + ".kin.urdf")).read()
+    if w.get("narrow"):
+        import re
+        xml = re.sub(r'lower="[-0-9.e]+" upper="[-0-9.e]+"', 'lower="-%.1f" upper="%.1f"' % (w["narrow"], w["narrow"]), xml)
+    return ik_amd.Model.from_urdf_xml(xml, free_flyer=w["free_flyer"]), xml
+
+
 def make_inputs(name, model, idx):
+    import numpy as np  # noqa: F401
+    from ik_amd import workload
     w = WORKLOADS[name]
     lo, hi = model.lowerPositionLimit, model.upperPositionLimit
     if name in ("cassie_full_body", "cassie_demo", "cassie_demo_pik", "cassie_demo_posture"):
         return workload.freeflyer_workload(lo, hi, workload.cassie_nominal(model.names), idx, seed=0, mode="near")
     if name in ("ur5", "ur10"):
         return workload.chain_workload(lo, hi, workload.UR5_NOMINAL, idx, seed=0, mode="near")
+    if w.get("narrow"):
+        return workload.chain_workload(lo, hi, workload.UR5_NOMINAL, idx, seed=0, mode="uniform")
     return workload.chain_workload(lo, hi, workload.cassie_nominal(model.names), idx, seed=0, mode="uniform")
 
 
@@ -99,14 +168,15 @@ def task_specs(w):
     return w.get("tasks") or [("frame", f, 2, "universe") for f in w["frames"]]
 
 
-def cpu_baseline(model, w, q0_np, tg_np, iters, budget_s=12.0):
-    """The CPU oracle (oracle/ik_oracle.c, a port -- the reference itself cannot be built here) timed on
-    this host's cores on a bounded sample of the same workload."""
+def cpu_baseline(model, xml, w, q0_np, tg_np, iters, budget_s=10.0):
+    """The CPU oracle (oracle/ik_oracle.c, a port -- the reference itself cannot be built here) timed on this host's cores
+    on a bounded sample of the same workload; beside it the optimised CPU variant (oracle/fast_cpu.cpp) where it exists
+    (chain problems), and the stability of every sampled problem (see `stable`)."""
+    import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
     om = O.OracleModel(model.flat())
     specs = task_specs(w)
-    fids = [model.getFrameId(f) for _, f, _, _ in specs]
     prios = w.get("prios") or [0] * len(specs)
     rows = [(model.getFrameId(f), model.getFrameId(r), (3 + t) if kind == "align" else t, p, None) for (kind, f, t, r), p in zip(specs, prios)]
     if w.get("posture"):   # one row per joint: (tangent column, index in q, IKGPU_POSTURE_ROW, priority, [weight, mask])
@@ -128,54 +198,73 @@ def cpu_baseline(model, w, q0_np, tg_np, iters, budget_s=12.0):
     t = time.perf_counter()
     q_ref, ok_ref, it_ref = solve(om, tasks, tg_np[:sample], q0_np[:sample], prm, cores)
     dt = time.perf_counter() - t
-    # which of the sampled problems converged on the CPU (SURVEY.md 8d parity bar): the stacked error vanishes
-    if w.get("tasks"):
-        conv = np.array([np.abs(O.evaluate(om, tasks, tg_np[b], q_ref[b])[0]).max() < 1e-8 for b in range(min(sample, 2048))])
-        conv = np.concatenate([conv, np.zeros(sample - conv.size, dtype=bool)])
-    else:
-        reached = O.fk_batch(om, q_ref, fids)
-        conv = np.abs(reached - tg_np[:sample]).reshape(sample, -1).max(axis=1) < 1e-8
-    return dict(value=sample / dt, unit="solves/s", cores=cores, kind="port",
-                sample="first %d problems of the batch, %d threads, %.2f s wall; 1-thread probe %.0f solves/s"
-                       % (sample, cores, dt, r1)), q_ref, sample, conv
+    # Stability of each sampled problem (replaces the converged / not-converged split of round 1): the same solve from
+    # q0 + 1e-13.  A problem whose own CPU answer moves by more than 1e-7 rad under that perturbation has no answer to
+    # compare to 1e-6 (a lane stalled on a joint limit or far from its target amplifies rounding differences); every other
+    # problem -- converged or not -- is held to the 1e-6 rad bar.
+    q_pert, _, _ = solve(om, tasks, tg_np[:sample], q0_np[:sample] + 1e-13, prm, cores)
+    sens = np.abs(q_pert - q_ref).max(axis=1)
+    stable = sens <= 1e-7
+    out = dict(value=sample / dt, unit="solves/s", cores=cores, kind="port",
+               sample="first %d problems of the batch, %d threads, %.2f s wall; 1-thread probe %.0f solves/s"
+                      % (sample, cores, dt, r1))
+    if not w.get("tasks") and not w.get("posture") and not model_is_free_flyer(w) and w.get("solver") != "pik":
+        fid = model.getFrameId(w["frames"][0])
+        n_fast = int(min(q0_np.shape[0], max(sample, sample * 4)))
+        t = time.perf_counter()
+        q_fast, _, _ = O.fast_dls_chain_batch(xml, fid, tg_np[:n_fast], q0_np[:n_fast], prm, cores)
+        dtf = time.perf_counter() - t
+        out["optimised"] = dict(value=n_fast / dtf, unit="solves/s", cores=cores, kind="port",
+                                what="the device lane program (support-sparse, allocation-free, unrolled) compiled g++ -O3 "
+                                     "-march=x86-64-v3 for the host, %d threads (oracle/fast_cpu.cpp)" % cores,
+                                sample="first %d problems, %.2f s wall" % (n_fast, dtf),
+                                max_abs_dq_vs_faithful_port_rad_stable=float(np.abs(q_fast[:sample] - q_ref)[stable].max()) if stable.any() else None)
+    return out, q_ref, ok_ref, it_ref, sample, stable, sens
+
+
+def model_is_free_flyer(w):
+    return bool(w["free_flyer"])
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=65536, help="problems per GPU")
-    ap.add_argument("--iters", type=int, default=50)
-    ap.add_argument("--workload", default="cassie_leg", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--gather", action="store_true", help="run the all-gather step even at N = 1 (rehearsal)")
-    ap.add_argument("--timed-only", action="store_true",
-                    help="launch nothing but the warm-up and timed steps (profiling passes: every dispatch is the same launch)")
-    args = ap.parse_args()
+    args = parse_args()
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if not launched and (args.gpus > 1 or args.launcher):
+        return self_launch(args)          # before torch / HIP are loaded in this process
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # read at HIP/HSA initialisation: set before any GPU call
+
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    import ik_amd
+    from ik_amd import distributed as ikdist
+    from ik_amd import workload
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs a torch.distributed.run launch (WORLD_SIZE=%d)" % (args.gpus, world))
-        args.gpus = world
+    args.gpus = world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # Under torch.distributed.run (RANK / WORLD_SIZE set) the process group is always created, also for N = 1,
-    # so that a one-GPU rehearsal (`python -m torch.distributed.run --nproc-per-node 1 bench.py --gather`) runs the
-    # very same RCCL code path the N > 1 launch takes.
-    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
-    distributed = world > 1 or (launched and args.gather)
+    gather = args.gather if args.gather != "auto" else ("full" if world > 1 else "none")
+    distributed = launched and gather != "none"
     if launched:
+        # under torch.distributed.run the process group is always created, also for N = 1, so that a one-GPU rehearsal
+        # (`python bench.py --launcher --gather full`) runs the very same RCCL code path the N > 1 launch takes
         import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
-    B = args.batch
+    scaling = args.scaling if args.scaling != "auto" else ("strong" if world > 1 else "weak")
+    if scaling == "strong":
+        total = args.global_batch or CONFIG4_GLOBAL_BATCH
+    else:
+        total = (args.batch or 65536) * world
+    lo, hi = ikdist.shard_range(total, rank, world)
+    B = hi - lo                                  # this rank's problems
+    b_max = ikdist.shard_size(total, 0, world)
+
     w = WORKLOADS[args.workload]
-    model = ik_amd.Model.from_urdf_file(os.path.join(workload.MODELS_DIR, w["urdf"] + ".kin.urdf"), free_flyer=w["free_flyer"])
+    model, xml = load_model(ik_amd, workload, w)
     prios = w.get("prios") or [0] * len(task_specs(w))
     problem = ik_amd.InverseKinematicsProblem(model, max(prios + ([w["posture"]["priority"]] if w.get("posture") else [])))
     for i, ((kind, f, t, r), prio) in enumerate(zip(task_specs(w), prios)):
@@ -193,28 +282,33 @@ def main():
     else:
         data = ik_amd.dls_data(problem, device=local_rank)
 
-    # this rank's shard of the global synthetic batch (weak scaling: B problems per GPU)
-    lo, hi = ikdist.shard_range(B * world, rank, world)
-    q0_np, qs_np = make_inputs(args.workload, model, np.arange(lo, hi))
-    Q0 = torch.from_numpy(np.ascontiguousarray(q0_np.T)).to(dev)
-    QS = torch.from_numpy(np.ascontiguousarray(qs_np.T)).to(dev)
-    targets = ik_amd.task_frames_fk_batch(problem, QS, data)  # FK(q*) on the device: reachable targets
-    if w.get("tasks"):
-        # express each frame target in its reference frame (here: the pelvis, task 1's frame); the alignment row asks for
-        # the direction the foot's Y axis has at q* (slot 2 holds the same foot frame): reachable, like the frame targets
-        Rp, pp = targets[1, :9].reshape(3, 3, B), targets[1, 9:]
-        Rf, pf = targets[0, :9].reshape(3, 3, B).clone(), targets[0, 9:].clone()
-        targets[0, :9] = torch.einsum("kib,kjb->ijb", Rp, Rf).reshape(9, B)
-        targets[0, 9:] = torch.einsum("kib,kb->ib", Rp, pf - pp)
-        targets[2, 9:] = Rf[:, 1, :]
-        targets[2, :9] = torch.eye(3, dtype=torch.float64, device=dev).reshape(9, 1)
-    if w.get("posture"):   # posture target = the generating configuration (double 9 of each row's slot): consistent with the poses
-        nj = w["posture"]["nj"]
-        targets[-nj:] = 0.0
-        targets[-nj:, 9, :] = QS[model.nq - nj:]
+    def device_inputs(idx):
+        """(q0 host, Q0 device [nq, b], targets device [ntasks, 12, b]) of the problems `idx` of the global synthetic batch."""
+        q0_h, qs_h = make_inputs(args.workload, model, idx)
+        b = len(idx)
+        Q0_d = torch.from_numpy(np.ascontiguousarray(q0_h.T)).to(dev)
+        QS = torch.from_numpy(np.ascontiguousarray(qs_h.T)).to(dev)
+        tg = ik_amd.task_frames_fk_batch(problem, QS, data)  # FK(q*) on the device: reachable targets
+        if w.get("tasks"):
+            # express each frame target in its reference frame (here: the pelvis, task 1's frame); the alignment row asks for
+            # the direction the foot's Y axis has at q* (slot 2 holds the same foot frame): reachable, like the frame targets
+            Rp, pp = tg[1, :9].reshape(3, 3, b), tg[1, 9:]
+            Rf, pf = tg[0, :9].reshape(3, 3, b).clone(), tg[0, 9:].clone()
+            tg[0, :9] = torch.einsum("kib,kjb->ijb", Rp, Rf).reshape(9, b)
+            tg[0, 9:] = torch.einsum("kib,kb->ib", Rp, pf - pp)
+            tg[2, 9:] = Rf[:, 1, :]
+            tg[2, :9] = torch.eye(3, dtype=torch.float64, device=dev).reshape(9, 1)
+        if w.get("posture"):   # posture target = the generating configuration (double 9 of each row's slot): consistent with the poses
+            nj = w["posture"]["nj"]
+            tg[-nj:] = 0.0
+            tg[-nj:, 9, :] = QS[model.nq - nj:]
+        return q0_h, Q0_d, tg
+
+    # this rank's shard of the global synthetic batch
+    q0_np, Q0, targets = device_inputs(np.arange(lo, hi))
     # two buffer sets alternate so that the all-gather of step k overlaps the solve of step k + 1
-    bufs = [ikdist.ShardBuffers(model.nq, B, world, dev) for _ in range(2)]
-    out = bufs[0].out()
+    rows = np.flatnonzero(data.support) if gather == "compact" else None
+    bufs = [ikdist.ShardBuffers(model.nq, total, rank, world, dev, rows=rows) for _ in range(2)]
     visitor = ik_amd.never_stop_visitor()
     if use_pik:
         prm = ik_amd.pik_parameters(max_iterations=args.iters, step_length=1.0)
@@ -242,9 +336,9 @@ def main():
         step()
     drain()
     # HIP events on the stream the kernels are launched on (torch's current stream is the one handed to the C ABI).
-    # N = 1: one pair around the K back-to-back launches -> average launch duration incl. the ~1-2 us launch boundary
-    # (agrees with rocprofv3 --kernel-trace within 1 %); N > 1: the collective shares the region, so each rank also
-    # times ONE isolated launch after the timed region.
+    # No collective: one pair around the K back-to-back launches -> average launch duration incl. the ~1-2 us launch boundary
+    # (agrees with rocprofv3 --kernel-trace within 1 %); with the collective in the region each rank also times ONE isolated
+    # launch after the timed region.
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     if launched:
         dist.barrier()
@@ -274,65 +368,113 @@ def main():
     else:
         kernel_ms = float(ev0.elapsed_time(ev1)) / args.steps
 
+    def time_solve(Q0_, tg_, reps=10, p=prm, vis=visitor, out_=None):
+        out_ = solve_batch(problem, Q0_, tg_, data, vis, p, out=out_)
+        a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            out_ = solve_batch(problem, Q0_, tg_, data, vis, p, out=out_)
+        b_.record()
+        torch.cuda.synchronize()
+        return float(a.elapsed_time(b_)) / reps, out_
+
+    # strong scaling: the whole job's batch on ONE GPU, in the same run, on the same inputs (rank 0, outside the timed region):
+    # the N = 1 point of the curve this line belongs to
+    single = None
+    if scaling == "strong" and world > 1 and not args.timed_only:
+        if rank == 0:
+            _, Q0_all, tg_all = device_inputs(np.arange(total))
+            ms_all, _ = time_solve(Q0_all, tg_all, reps=5)
+            single = {"value": total / (ms_all * 1e-3), "unit": "solves/s", "kernel_ms": ms_all, "batch": total,
+                      "what": "the same %d problems solved by rank 0 alone (no collective), in this run" % total}
+            del Q0_all, tg_all
+        dist.barrier()
+
     if rank == 0:
-        value = B * world * args.steps / elapsed
+        value = total * args.steps / elapsed
         bps = bytes_per_solve(w)
         achieved = bps * B / (kernel_ms * 1e-3) / 1e9
         stats = load_kernel_stats().get(data.kernel, {})
-        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-        # separate runs, gfx950 correction applied: tools/pmc_to_stats.py); measured at B = 65536, linear in B.
+        replay = "replayed from the committed PMC passes (profiles/, ik_amd/kernel_stats.json; rocprofv3 --pmc in separate runs, " \
+                 "gfx950 correction applied: tools/pmc_to_stats.py), measured at B = %s and scaled linearly in B -- not measured in this run" \
+                 % stats.get("pmc", {}).get("batch", "?")
+        # HBM bytes per launch from the PMC passes committed under profiles/
         traffic = None
         if stats.get("hbm_traffic_bytes_per_launch") and stats.get("pmc", {}).get("batch"):
             traffic = stats["hbm_traffic_bytes_per_launch"] * B / stats["pmc"]["batch"]
+        waves_per_simd = (B + 63) // 64 / SIMDS
+        hbm = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+               "traffic": traffic, "traffic_source": replay if traffic else None, "algorithmic_bytes_per_solve": bps}
         res = {
             "metric": "IK solves/sec (50-iter %s) at batch=65536" % ("PIK" if use_pik else "DLS"),
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("%s, %d fixed PIK iterations, step 1.0, reachable targets FK(q*)" if use_pik else
                                     "%s, %d fixed DLS iterations, damping 1e-2, step 1.0, reachable targets FK(q*)")
                                    % (w["text"], args.iters),
-                       "name": args.workload, "batch_per_gpu": B, "global_batch": B * world, "iterations": args.iters,
+                       "name": args.workload, "batch_per_gpu": b_max, "global_batch": total, "iterations": args.iters,
                        "kernel": data.kernel,
-                       "parallelism": "batch-sharded x%d + RCCL all-gather" % world if distributed else "single GPU"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_solve": bps,
-                         "note": ("fused on-chip loop: the binding roof is FP64 VALU issue, see valu_roofline"
-                                  if data.kernel.startswith(("dls_chain<", "dls_tree<")) else
-                                  "generic kernel, workspace in LDS (16 lanes per problem): LDS-latency bound, DESIGN.md 3.3"
-                                  if data.kernel.startswith("dls_generic<") else
-                                  "generic per-lane kernel, workspace in HBM: bound by that traffic, DESIGN.md 3.4")},
+                       "parallelism": ("contiguous batch shards x%d + one RCCL all-gather per step (%s payload, %d B per problem)"
+                                       % (world, gather, bufs[0].nbytes // max(1, b_max)) if distributed else "single GPU"),
+                       "waves_per_simd_per_gpu": waves_per_simd,
+                       "occupancy_note": ("one problem per lane, 64-lane workgroups: %d waves for %d SIMDs per GPU%s"
+                                          % ((B + 63) // 64, SIMDS,
+                                             " -- fewer waves than SIMDs: the launch takes as long as a full chip's (a wave's run time "
+                                             "is fixed), so throughput per GPU falls with the shard; the strong-scaling ceiling by construction"
+                                             if waves_per_simd < 1 else ""))},
         }
+        if single:
+            res["single_gpu_same_inputs"] = single
+        fused = data.kernel.startswith(("dls_chain<", "dls_tree<"))
         if stats.get("flop_per_solve_measured") and args.iters == 50:
             flops = stats["flop_per_solve_measured"]
             tf = flops * B / (kernel_ms * 1e-3) / 1e12
-            res["valu_roofline"] = {"bound": "fp64_valu", "achieved": tf, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
-                                    "frac": tf / FP64_VALU_PEAK_TF, "flop_per_solve": flops,
-                                    "counting": "executed FP64 VALU instructions per launch from the SQ_INSTS_VALU_{FMA,MUL,ADD,"
-                                                "TRANS}_F64 counters (x 64 lanes, FMA = 2), 50 iterations; profiles/r01_pmc"}
+            # the binding roof of the fused on-chip loop is FP64 vector-ALU issue, not HBM
+            res["roofline"] = {"bound": "fp64_valu", "achieved": tf, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+                               "frac": tf / FP64_VALU_PEAK_TF, "traffic": traffic, "kernel_ms": kernel_ms,
+                               "flop_per_solve": flops,
+                               "counting": "executed FP64 VALU instructions per launch from the SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 "
+                                           "counters (x 64 lanes, FMA = 2), 50 iterations; " + replay,
+                               "note": "fused on-chip loop: the binding roof is FP64 vector-ALU issue; the HBM figure the contract "
+                                       "defines is in hbm_roofline (algorithmic bytes / kernel time)"}
+            res["hbm_roofline"] = hbm
+        else:
+            hbm["kernel_ms"] = kernel_ms
+            hbm["note"] = ("fused on-chip loop without a committed flop count for this kernel: HBM figure only" if fused else
+                           "generic kernel, workspace in LDS (16 lanes per problem): LDS-latency bound, DESIGN.md 3.3"
+                           if data.kernel.startswith("dls_generic<") else
+                           "generic per-lane kernel, workspace in HBM: bound by that traffic, DESIGN.md 3.4")
+            res["roofline"] = hbm
         if args.timed_only:
             args.no_cpu = True
         if world == 1 and not use_pik and not args.timed_only:
-            # secondary figures of SURVEY.md 8d, outside the timed region: the library's default stop rule
-            # (reference ik/ik/visitor.hpp:15-21, tolerance 1e-4 on the squared priority-0 error; max_iterations 100,
-            # reference ik/ik/common.hpp:59-66) and the cold path URDF text -> device handle
+            # secondary figures of SURVEY.md 8d, outside the timed region
+            spare = bufs[state["k"] % 2].out()   # not the buffer set holding the timed region's last result
+            # (i) the library's default stop rule (reference ik/ik/visitor.hpp:15-21, tolerance 1e-4 on the squared priority-0
+            # error; max_iterations 100, reference ik/ik/common.hpp:59-66)
             stop = ik_amd.inverse_kinematics_visitor()
             prm_stop = ik_amd.dls_parameters(max_iterations=100, damping=1e-2, step_length=1.0)
-            spare = bufs[state["k"] % 2].out()   # not the buffer set holding the timed region's last result
-            solve_batch(problem, Q0, targets, data, stop, prm_stop, out=spare)
-            ev0.record()
-            for _ in range(5):
-                Qs, oks, its = solve_batch(problem, Q0, targets, data, stop, prm_stop, out=spare)
-            ev1.record()
-            torch.cuda.synchronize()
-            ms = float(ev0.elapsed_time(ev1)) / 5
+            ms, (Qs, oks, its) = time_solve(Q0, targets, reps=5, p=prm_stop, vis=stop, out_=spare)
             res["default_stop_rule"] = {"value": B / (ms * 1e-3), "unit": "solves/s", "kernel_ms": ms,
                                         "stop_sq_tol": stop.tolerance, "max_iterations": 100,
                                         "mean_iterations": float(its.double().mean().item()),
                                         "success_rate": float(oks.double().mean().item())}
+            # (ii) config 4's batch on this one GPU (4 waves per SIMD instead of 1)
+            if args.workload == "cassie_leg" and total != CONFIG4_GLOBAL_BATCH:
+                _, Q0_big, tg_big = device_inputs(np.arange(CONFIG4_GLOBAL_BATCH))
+                ms_big, _ = time_solve(Q0_big, tg_big, reps=5)
+                res["batch_262144"] = {"value": CONFIG4_GLOBAL_BATCH / (ms_big * 1e-3), "unit": "solves/s", "kernel_ms": ms_big,
+                                       "waves_per_simd": CONFIG4_GLOBAL_BATCH / 64 / SIMDS}
+                if stats.get("flop_per_solve_measured") and args.iters == 50:
+                    res["batch_262144"]["fp64_valu_frac"] = stats["flop_per_solve_measured"] * CONFIG4_GLOBAL_BATCH / (ms_big * 1e-3) / 1e12 / FP64_VALU_PEAK_TF
+                del Q0_big, tg_big
+            # (iii) end to end from host memory: pinned host buffers -> H2D -> solve -> D2H, timed with HIP events on the
+            # launch stream; and the C ABI's own host entry point (ikgpu_dls_solve_batch_host) on the same pinned buffers
+            res["end_to_end_host"] = end_to_end(torch, ik_amd, problem, data, model, Q0, targets, prm, visitor, B, args.iters)
+            # (iv) the cold path URDF text -> device handle
             t = time.perf_counter()
-            m2 = ik_amd.Model.from_urdf_file(os.path.join(workload.MODELS_DIR, w["urdf"] + ".kin.urdf"), free_flyer=w["free_flyer"])
+            m2, _ = load_model(ik_amd, workload, w)
             t_parse = time.perf_counter() - t
             p2 = ik_amd.InverseKinematicsProblem(m2, w["posture"]["priority"] if w.get("posture") else 0)
             if w.get("posture"):
@@ -348,17 +490,75 @@ def main():
             del d2, p2, m2
         if not args.no_cpu and world == 1:   # the CPU leg runs on rank 0 at N = 1 only
             tg_np = targets.permute(2, 0, 1).contiguous().cpu().numpy()
-            cpu, q_ref, sample, conv = cpu_baseline(model, w, q0_np, tg_np, args.iters)
+            cpu, q_ref, ok_ref, it_ref, sample, stable, sens = cpu_baseline(model, xml, w, q0_np, tg_np, args.iters)
             res["cpu_baseline"] = cpu
             d = np.abs(out[0].cpu().numpy().T[:sample] - q_ref).max(axis=1)
-            res["parity_vs_cpu"] = {"problems": sample, "converged_on_cpu": int(conv.sum()),
-                                    "max_abs_dq_rad_converged": float(d[conv].max()) if conv.any() else None,
-                                    "max_abs_dq_rad_not_converged": float(d[~conv].max()) if (~conv).any() else None,
-                                    "bar_rad": 1e-6}
+            flags_equal = bool(np.array_equal(out[1].cpu().numpy()[:sample], ok_ref) and np.array_equal(out[2].cpu().numpy()[:sample], it_ref))
+            worst = int(np.argmax(np.where(stable, d, -1.0)))
+            res["parity_vs_cpu"] = {"problems": sample, "bar_rad": 1e-6, "flags_equal": flags_equal,
+                                    "stable": int(stable.sum()),
+                                    "max_abs_dq_rad_stable": float(d[stable].max()) if stable.any() else None,
+                                    "worst_stable_problem": worst, "unstable": int((~stable).sum()),
+                                    "max_abs_dq_rad_unstable": float(d[~stable].max()) if (~stable).any() else None,
+                                    "stability_rule": "a problem is unstable when the CPU port's own answer moves by more than 1e-7 rad "
+                                                      "under q0 + 1e-13 (all entries); only those are excluded from the 1e-6 bar",
+                                    "max_cpu_self_sensitivity_rad": float(sens.max())}
         print(json.dumps(res))
+        sys.stdout.flush()
     if launched:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def end_to_end(torch, ik_amd, problem, data, model, Q0, targets, prm, visitor, B, iters, reps=5):
+    """Host-resident caller (the reference's call pattern keeps q_ on the host, ik_ros/src/cassie.cpp:95-112): pinned host
+    buffers -> H2D -> solve -> D2H.  Never `value` (the contract times HBM-resident inputs); reported beside it."""
+    import ctypes as C
+    from ik_amd import capi
+    dev = Q0.device
+    hq0 = Q0.cpu().pin_memory()
+    htg = targets.cpu().pin_memory()
+    hq = torch.empty_like(hq0).pin_memory()
+    hok = torch.empty(B, dtype=torch.uint8).pin_memory()
+    hit = torch.empty(B, dtype=torch.int32).pin_memory()
+    dq0, dtg = torch.empty_like(Q0), torch.empty_like(targets)
+    out = (torch.empty_like(Q0), torch.empty(B, dtype=torch.uint8, device=dev), torch.empty(B, dtype=torch.int32, device=dev))
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    h2d = krn = d2h = 0.0
+    for r in range(reps + 1):
+        ev[0].record()
+        dq0.copy_(hq0, non_blocking=True)
+        dtg.copy_(htg, non_blocking=True)
+        ev[1].record()
+        ik_amd.dls_batch(problem, dq0, dtg, data, visitor, prm, out=out)
+        ev[2].record()
+        hq.copy_(out[0], non_blocking=True)
+        hok.copy_(out[1], non_blocking=True)
+        hit.copy_(out[2], non_blocking=True)
+        ev[3].record()
+        torch.cuda.synchronize()
+        if r:   # the first round warms the pinned mappings
+            h2d += ev[0].elapsed_time(ev[1]); krn += ev[1].elapsed_time(ev[2]); d2h += ev[2].elapsed_time(ev[3])
+    h2d, krn, d2h = h2d / reps, krn / reps, d2h / reps
+    # the C ABI's host entry point on the same pinned buffers (copy in, solve, copy out, synchronise -- one call)
+    cprm = capi.DlsParams(int(prm.max_iterations), float(prm.damping), float(prm.step_length), float(visitor.tolerance))
+    L = capi.lib()
+
+    def host_call():
+        capi.check(L.ikgpu_dls_solve_batch_host(data._h, B, hq0.data_ptr(), htg.data_ptr(), C.byref(cprm), hq.data_ptr(),
+                                                hok.data_ptr(), hit.data_ptr(), capi.SOA))
+    host_call()
+    t = time.perf_counter()
+    for _ in range(reps):
+        host_call()
+    host_ms = (time.perf_counter() - t) / reps * 1e3
+    total = h2d + krn + d2h
+    return {"value": B / (total * 1e-3), "unit": "solves/s", "h2d_ms": h2d, "solve_ms": krn, "d2h_ms": d2h, "total_ms": total,
+            "bytes_in": int(hq0.numel() * 8 + htg.numel() * 8), "bytes_out": int(hq.numel() * 8 + 5 * B),
+            "h2d_GBps": (hq0.numel() + htg.numel()) * 8 / (h2d * 1e-3) / 1e9, "d2h_GBps": (hq.numel() * 8 + 5 * B) / (d2h * 1e-3) / 1e9,
+            "abi_host_entry_ms": host_ms, "abi_host_entry_value": B / (host_ms * 1e-3),
+            "what": "pinned host buffers -> H2D -> %d-iteration solve -> D2H, HIP events on the launch stream (PCIe-inclusive; never "
+                    "`value`); abi_host_entry_*: one ikgpu_dls_solve_batch_host call on the same pinned buffers, wall clock" % iters}
 
 
 if __name__ == "__main__":

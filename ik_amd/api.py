@@ -428,7 +428,11 @@ class dls_data:
         self._bind(problem)
 
     def _bind(self, problem):
-        key = (problem._generation, tuple(tuple(r[4]) for t, p in problem.ordered_tasks() for r in _abi_rows(t, p)))
+        # everything ikgpu_problem_create_constrained reads: the model, every ABI row (frame, reference, type, priority,
+        # weight[6]) and every constraint row -- the comparison the C++ mirror makes (ik_gpu.hpp dls_data::same)
+        key = (id(problem.model()), int(problem.model()._h.value or 0),
+               tuple((f, r, typ, prio, tuple(w)) for t, p in problem.ordered_tasks() for f, r, typ, prio, w in _abi_rows(t, p)),
+               tuple((c._frame_id, c._ref_id, int(c.type)) for c in problem.get_all_constraints()))
         if self._h is not None and key == self._generation:
             return
         self._release()
@@ -440,6 +444,9 @@ class dls_data:
         self._generation = key
         self.rows = int(capi.lib().ikgpu_problem_rows(h))
         self.kernel = capi.lib().ikgpu_problem_kernel(h).decode()
+        sup = (C.c_uint8 * problem.model().nq)()
+        capi.check(capi.lib().ikgpu_problem_support(h, sup))
+        self.support = np.frombuffer(sup, dtype=np.uint8).astype(bool)   # [nq]: entries of q a solve can move (the rest is only clipped)
 
     def _release(self):
         if self._h is not None:
@@ -528,10 +535,35 @@ def dls_batch(problem, Q0, targets, data, visitor=None, p=None, layout="soa", ou
         ok = torch.empty(B, dtype=torch.uint8, device=Q0.device)
         it = torch.empty(B, dtype=torch.int32, device=Q0.device)
     else:
-        Q, ok, it = out
+        Q, ok, it = _check_out(out, model.nq, B, lay, data._device)
     s = torch.cuda.current_stream(Q0.device).cuda_stream if stream is None else stream
     capi.check(L.ikgpu_dls_solve_batch(data._h, B, Q0.data_ptr(), targets.data_ptr(), C.byref(prm), Q.data_ptr(),
                                        ok.data_ptr(), it.data_ptr(), lay, C.c_void_p(s)))
+    return Q, ok, it
+
+
+def _check_tensor(name, t, shape, dtype, device):
+    """A device buffer handed to the C ABI as a raw pointer: wrong dtype / device / stride / size would make the kernel read or
+    write out of bounds, so it is refused here."""
+    import torch
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError("%s must be a CUDA tensor" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s has dtype %s, expected %s" % (name, t.dtype, dtype))
+    if t.device.index != device:
+        raise ValueError("%s lives on cuda:%s but the problem was created on device %d" % (name, t.device.index, device))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    if tuple(t.shape) != tuple(shape):
+        raise ValueError("%s has shape %s, expected %s" % (name, tuple(t.shape), tuple(shape)))
+
+
+def _check_out(out, nq, B, lay, device):
+    import torch
+    Q, ok, it = out
+    _check_tensor("out[0] (Q)", Q, (nq, B) if lay == capi.SOA else (B, nq), torch.float64, device)
+    _check_tensor("out[1] (success)", ok, (B,), torch.uint8, device)
+    _check_tensor("out[2] (iterations)", it, (B,), torch.int32, device)
     return Q, ok, it
 
 
@@ -657,7 +689,7 @@ def pik_batch(problem, Q0, targets, data, visitor=None, p=None, layout="soa", ou
         ok = torch.empty(B, dtype=torch.uint8, device=Q0.device)
         it = torch.empty(B, dtype=torch.int32, device=Q0.device)
     else:
-        Q, ok, it = out
+        Q, ok, it = _check_out(out, model.nq, B, lay, data._device)
     s = torch.cuda.current_stream(Q0.device).cuda_stream if stream is None else stream
     capi.check(L.ikgpu_pik_solve_batch(data._h, B, Q0.data_ptr(), targets.data_ptr(), C.byref(prm), Q.data_ptr(),
                                        ok.data_ptr(), it.data_ptr(), lay, C.c_void_p(s)))
@@ -673,6 +705,9 @@ def evaluate_batch(problem, Q, targets, data, layout="soa", jacobian=True):
     lay = {"soa": capi.SOA, "aos": capi.AOS}[layout]
     B = Q.shape[1] if lay == capi.SOA else Q.shape[0]
     M = data.rows
+    nt = problem.target_slots()
+    _check_tensor("Q", Q, (model.nq, B) if lay == capi.SOA else (B, model.nq), torch.float64, data._device)
+    _check_tensor("targets", targets, (nt, 12, B) if lay == capi.SOA else (B, nt, 12), torch.float64, data._device)
     e = torch.empty((M, B) if lay == capi.SOA else (B, M), dtype=torch.float64, device=Q.device)
     J = None
     if jacobian:
@@ -691,6 +726,8 @@ def task_frames_fk_batch(problem, Q, data, layout="soa"):
     lay = {"soa": capi.SOA, "aos": capi.AOS}[layout]
     B = Q.shape[1] if lay == capi.SOA else Q.shape[0]
     nt = problem.target_slots()
+    nq = problem.model().nq
+    _check_tensor("Q", Q, (nq, B) if lay == capi.SOA else (B, nq), torch.float64, data._device)
     out = torch.empty((nt, 12, B) if lay == capi.SOA else (B, nt, 12), dtype=torch.float64, device=Q.device)
     s = torch.cuda.current_stream(Q.device).cuda_stream
     capi.check(capi.lib().ikgpu_task_frames_fk_batch(data._h, B, Q.data_ptr(), out.data_ptr(), lay, C.c_void_p(s)))

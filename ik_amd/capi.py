@@ -25,7 +25,7 @@ SYMBOLS = [
     "ikgpu_problem_plan",
     "ikgpu_dls_solve_batch", "ikgpu_dls_solve_batch_host", "ikgpu_evaluate_batch", "ikgpu_task_frames_fk_batch",
     "ikgpu_pik_params_default", "ikgpu_pik_solve_batch", "ikgpu_pik_solve_batch_host", "ikgpu_pik_kernel",
-    "ikgpu_problem_create_constrained", "ikgpu_problem_plan_constrained",
+    "ikgpu_problem_create_constrained", "ikgpu_problem_plan_constrained", "ikgpu_problem_support",
 ]
 MAX_PIK_LEVELS, MAX_PIK_DA = 8, 128
 
@@ -101,6 +101,8 @@ def lib():
     L.ikgpu_problem_rows.restype = i32
     L.ikgpu_problem_kernel.argtypes = [vp]
     L.ikgpu_problem_kernel.restype = C.c_char_p
+    L.ikgpu_problem_support.argtypes = [vp, vp]
+    L.ikgpu_problem_support.restype = C.c_int
     L.ikgpu_problem_plan.argtypes = [vp, C.POINTER(Task), i32, C.c_char_p, sz]
     L.ikgpu_problem_create_constrained.argtypes = [vp, C.POINTER(Task), i32, C.POINTER(Task), i32, i32, C.POINTER(vp)]
     L.ikgpu_problem_plan_constrained.argtypes = [vp, C.POINTER(Task), i32, C.POINTER(Task), i32, C.c_char_p, sz]

@@ -384,6 +384,12 @@ int32_t ikgpu_problem_rows(const ikgpu_problem *p) { return p ? p->host.rows : -
 
 const char *ikgpu_problem_kernel(const ikgpu_problem *p) { return p ? p->host.kernel_name.c_str() : ""; }
 
+int ikgpu_problem_support(const ikgpu_problem *p, uint8_t *support) {
+    if (!p || !support) return fail(IKGPU_ERR_INVALID, "ikgpu_problem_support: null argument");
+    for (int i = 0; i < p->host.nq; ++i) support[i] = p->host.q_in_chain[static_cast<size_t>(i)] ? 1 : 0;
+    return IKGPU_OK;
+}
+
 int ikgpu_dls_solve_batch(const ikgpu_problem *p, int64_t B, const double *q0, const double *targets,
                           const ikgpu_dls_params *params, double *q_out, uint8_t *success, int32_t *iters, int layout,
                           void *stream) {

@@ -1,0 +1,238 @@
+// chain_hot.hpp -- the headline lane program: ik::dls() for ONE problem with one Full FrameTask (unit weights, reference
+// frame fixed in the world) on a serial chain of NJ <= 7 revolute joints, specialised at compile time on the STRUCTURE of the
+// chain's constant placements.
+//
+// Same algorithm and the same arithmetic as device/chain_solver.hpp (which stays the program of every other chain problem;
+// the reference path it restates is cited there: ik/ik/dls.cpp:5-78, data.cpp:25-58, frame.hpp:37-62,152-182,
+// common.hpp:53-56, visitor.hpp:15-21).  What differs is only what a lone wave pays for: measured on gfx950
+// (tools/issue_probe.hip, profiles/r02_issue_probe.csv) a wave that has its SIMD to itself -- the situation at the metric's
+// batch, 65536 problems = 1024 waves on 1024 SIMDs -- issues ONE instruction of any kind every 4 cycles (VALU, SALU, s_nop,
+// s_waitcnt alike; 16 for an FP64 transcendental, 8 for v_mov_b64) and a dependent FP64 instruction can follow its producer
+// in the next slot.  The iteration therefore costs 4 cycles x (number of instructions) + the scalar-load waits, and nothing
+// else: instruction-level parallelism buys nothing, every instruction removed buys 4 cycles.  Hence:
+//
+//  * Placement structure as a template argument.  Joint placements in URDFs are mostly axis permutations (rpy multiples of
+//    pi/2) and translations along one or two axes.  The host classifies every entry of every placement of the chain --
+//    rotation entries: exactly 0, exactly +1, exactly -1, or general; translation: which components are exactly zero --
+//    into a 21-bit code (ChainStruct).  For a structural entry the lane program uses the LITERAL 0.0 / +-1.0, and the translation
+//    unit is compiled with -fno-signed-zeros -fno-honor-nans -fno-honor-infinities (no reassociation, no reciprocal maths:
+//    results stay bit-identical on finite data) so that x * 0.0, x * 1.0, x + 0.0 fold away: a near-permutation placement costs
+//    6-15 instructions instead of 36.  No robot constant is compiled in: the non-structural values (22 doubles for a
+//    Cassie leg instead of 96) arrive in the kernel-argument segment and stay in registers for the whole loop -- no table
+//    loads, no s_waitcnt inside the iteration.  A model whose code has no instantiation runs on chain_solver.hpp.
+//  * The visitor that never stops (the metric's fixed-iteration mode) is its own instantiation: no `active` selects, no
+//    stop-test arithmetic.
+#pragma once
+#include <cstdint>
+
+#include "chain_kernel_body.hpp"
+
+namespace ikdev {
+
+// 21 bits per placement i = 0 .. NJ (i = NJ: last joint frame -> task frame), three placements per 64-bit word:
+//   bits 0-17   nine 2-bit classes of the rotation entries, row-major: 0 general (a table value), 1 exactly 0, 2 exactly +1,
+//               3 exactly -1   (URDF rpy values are decimal approximations of pi/2, so a "permutation" placement usually
+//               keeps a few entries of 1e-12 .. 1e-16: those stay general and exact -- nothing is snapped)
+//   bits 18-20  translation component k is non-zero
+constexpr int kStructBits = 21;
+constexpr int kStructPerWord = 3;
+enum : unsigned { kEntGeneral = 0, kEntZero = 1, kEntOne = 2, kEntMinusOne = 3 };
+
+template <uint64_t C0, uint64_t C1, uint64_t C2>
+struct ChainStruct {
+    static constexpr uint64_t word(int w) { return w == 0 ? C0 : (w == 1 ? C1 : C2); }
+    static constexpr unsigned code(int i) { return static_cast<unsigned>((word(i / kStructPerWord) >> (kStructBits * (i % kStructPerWord))) & 0x1fffffu); }
+    static constexpr unsigned ent(int i, int e) { return (code(i) >> (2 * e)) & 3u; }           // e = 3 m + k
+    static constexpr bool tnz(int i, int k) { return ((code(i) >> (18 + k)) & 1u) != 0; }
+    static constexpr int ngen_before(int i, int e) { return e == 0 ? 0 : ngen_before(i, e - 1) + (ent(i, e - 1) == kEntGeneral ? 1 : 0); }
+    static constexpr int count(int i) { return ngen_before(i, 9) + (tnz(i, 0) ? 1 : 0) + (tnz(i, 1) ? 1 : 0) + (tnz(i, 2) ? 1 : 0); }
+    // position of placement i's values in the compact table: [general rotation entries, row-major][non-zero translation entries]
+    static constexpr int offset(int i) { return i == 0 ? 0 : offset(i - 1) + count(i - 1); }
+    static constexpr int rot_at(int i, int e) { return offset(i) + ngen_before(i, e); }
+    static constexpr int trans_at(int i, int k) {
+        return offset(i) + ngen_before(i, 9) + (k > 0 && tnz(i, 0) ? 1 : 0) + (k > 1 && tnz(i, 1) ? 1 : 0);
+    }
+    static constexpr double literal(int i, int e) { return ent(i, e) == kEntOne ? 1.0 : (ent(i, e) == kEntMinusOne ? -1.0 : 0.0); }
+};
+
+constexpr int kHotTableMax = 64;  // doubles in the kernel-argument copy of the compact table (values, then lo[NJ], hi[NJ])
+
+struct HotTable {
+    double v[kHotTableMax];
+};
+
+// entry e = 3 m + k of placement I's rotation: the literal 0.0 / +-1.0 when structural, else its table value
+template <class S, int I, class Tab>
+IKD_FN double hot_rot(const Tab &t, int e) {
+    return S::ent(I, e) == kEntGeneral ? t.v[S::rot_at(I, e)] : S::literal(I, e);
+}
+
+// (R, p) <- (R, p) * placement I.  Written as the general product; with literal zeros and ones in it the compiler folds the
+// multiplications by 1 and (under -fno-signed-zeros -fno-honor-nans) by 0 away: same bits as the full product on finite data.
+template <class S, int I, class Tab>
+IKD_FN void hot_compose(double (&R)[9], double (&p)[3], const Tab &t) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (S::tnz(I, k)) {
+            const double tk = t.v[S::trans_at(I, k)];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) p[r] = dfma(R[3 * r + k], tk, p[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const double a = R[3 * r], b = R[3 * r + 1], d = R[3 * r + 2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            R[3 * r + k] = dfma(a, hot_rot<S, I>(t, k), dfma(b, hot_rot<S, I>(t, 3 + k), d * hot_rot<S, I>(t, 6 + k)));
+    }
+}
+
+// e (6) and the NEGATED task Jacobian columns at q (see chain_evaluate in chain_solver.hpp: same expressions, KT_FULL,
+// unit weights).  oMt: target placement in the world.
+template <int NJ, class S, class Tab>
+IKD_FN void hot_evaluate(const Tab &t, const double (&q)[NJ], const double (&oMt)[12], double (&e)[6], double (&col)[NJ][6]) {
+    double zax[NJ][3], org[NJ][3];
+    double R[9], p[3];
+    // placement 0: world -> joint-0 frame
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = hot_rot<S, 0>(t, k);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p[k] = S::tnz(0, k) ? t.v[S::trans_at(0, k)] : 0.0;
+
+    // the NJ sin / cos first: independent of the chain, the constants are live once
+    double sn[NJ], cs[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) dsincos_fast(q[j], sn[j], cs[j]);
+
+#define IKD_HOT_JOINT(J)                                                   \
+    if (J < NJ) {                                                          \
+        if (J > 0) hot_compose<S, (J < NJ ? J : 0)>(R, p, t);              \
+        rot_z_right(R, sn[J < NJ ? J : 0], cs[J < NJ ? J : 0]);            \
+        zax[J < NJ ? J : 0][0] = R[2]; zax[J < NJ ? J : 0][1] = R[5]; zax[J < NJ ? J : 0][2] = R[8]; \
+        org[J < NJ ? J : 0][0] = p[0]; org[J < NJ ? J : 0][1] = p[1]; org[J < NJ ? J : 0][2] = p[2]; \
+    }
+    IKD_HOT_JOINT(0) IKD_HOT_JOINT(1) IKD_HOT_JOINT(2) IKD_HOT_JOINT(3) IKD_HOT_JOINT(4) IKD_HOT_JOINT(5) IKD_HOT_JOINT(6)
+#undef IKD_HOT_JOINT
+    hot_compose<S, NJ>(R, p, t);
+
+    // fMt = oMf^-1 oMt
+    double Re[9], pe[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Re[3 * i + j] = dfma(R[i], oMt[j], dfma(R[3 + i], oMt[3 + j], R[6 + i] * oMt[6 + j]));
+    {
+        const double dp[3] = {oMt[9] - p[0], oMt[10] - p[1], oMt[11] - p[2]};
+        rotT_vec(R, dp, pe);
+    }
+    LogAndJlog lj;
+    log6_and_jlog6_inv(Re, pe, lj);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) e[i] = lj.e[i];
+
+    // K' = Jlog6(tMf) with the frame rotation folded in: top rows [A Rf^T | Bm Rf^T], bottom rows [0 | A Rf^T]
+    double AR[9], BR[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            AR[3 * i + k] = dfma(lj.A[3 * i], R[3 * k], dfma(lj.A[3 * i + 1], R[3 * k + 1], lj.A[3 * i + 2] * R[3 * k + 2]));
+            BR[3 * i + k] = dfma(lj.Bm[3 * i], R[3 * k], dfma(lj.Bm[3 * i + 1], R[3 * k + 1], lj.Bm[3 * i + 2] * R[3 * k + 2]));
+        }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const double dj[3] = {org[j][0] - p[0], org[j][1] - p[1], org[j][2] - p[2]};
+        double vw[3];
+        cross(dj, zax[j], vw);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            // the z-axis terms first: consecutive joints with parallel axes (identity-rotation placements) share them
+            const double bz = dfma(BR[3 * i], zax[j][0], dfma(BR[3 * i + 1], zax[j][1], BR[3 * i + 2] * zax[j][2]));
+            col[j][i] = dfma(AR[3 * i], vw[0], dfma(AR[3 * i + 1], vw[1], dfma(AR[3 * i + 2], vw[2], bz)));
+            col[j][3 + i] = dfma(AR[3 * i], zax[j][0], dfma(AR[3 * i + 1], zax[j][1], AR[3 * i + 2] * zax[j][2]));
+        }
+    }
+}
+
+// One full solve.  q: in = q0 (chain joints), out = result.  NEVERSTOP: the visitor never stops (stop_sq_tol < 0): every
+// lane takes exactly max_iterations steps.
+template <int NJ, class S, bool NEVERSTOP, class Tab, class AnyFn>
+IKD_FN void hot_dls(const Tab &t, const LoopParams &prm, double (&q)[NJ], const double (&oMt)[12], int &iters_out,
+                    bool &success_out, AnyFn any_active) {
+    constexpr int M = 6;
+    constexpr int kLim = S::offset(NJ + 1);  // lo[NJ], hi[NJ] follow the placement values
+    bool active = true;
+    bool success = false;
+    int iters = prm.max_iterations;
+#pragma unroll 1
+    for (int it = 0; it < prm.max_iterations; ++it) {
+        double e[M], col[NJ][M];
+        hot_evaluate<NJ, S>(t, q, oMt, e, col);
+
+        double G[M * M];
+#pragma unroll
+        for (int a = 0; a < M; ++a)
+#pragma unroll
+            for (int b = 0; b <= a; ++b) {
+                double s = (a == b) ? prm.lam2 : 0.0;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) s = dfma(col[j][a], col[j][b], s);
+                G[a * M + b] = s;
+            }
+        double y[M];
+        chol_solve<M>(G, e, y);
+
+        if (!NEVERSTOP) {
+            double e0sq = 0.0;
+            if (prm.priority == 0) {
+#pragma unroll
+                for (int a = 0; a < M; ++a) e0sq = dfma(e[a], e[a], e0sq);
+            }
+            const bool stop_now = active && (prm.stop_sq_tol >= 0.0) && (e0sq < prm.stop_sq_tol);
+            if (stop_now) { success = true; iters = it; }
+            active = active && !stop_now;
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int a = 0; a < M; ++a) s = dfma(col[j][a], y[a], s);
+            const double qn = dfma(prm.step_length, s, q[j]);  // dq_j = -J_task(:, j)^T y = +col_j^T y
+            const double qc = dmin(t.v[kLim + NJ + j], dmax(qn, t.v[kLim + j]));
+            q[j] = (NEVERSTOP || active) ? qc : q[j];
+        }
+        if (!NEVERSTOP && !any_active(active)) break;
+    }
+    iters_out = iters;
+    success_out = success;
+}
+
+// B independent ik::dls() calls, lane `gid`: load, solve, store -- dls_chain_body (chain_kernel_body.hpp) with the hot program.
+template <int NJ, class S, bool NEVERSTOP, class Tab, class AnyFn>
+IKD_FN void hot_chain_body(const ChainKernelArgs<NJ> &a, const Tab &t, int64_t gid, AnyFn any_active) {
+    const bool valid = gid < a.B;
+    const int64_t b = valid ? gid : a.B - 1;  // tail lanes shadow the last problem and store nothing
+    double q[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) q[j] = a.q0[at(a.layout, a.B, a.nq, a.qidx[j], b)];
+    double oMt[12];
+    load_target(a, b, oMt);
+    int iters;
+    bool success;
+    hot_dls<NJ, S, NEVERSTOP>(t, a.prm, q, oMt, iters, success, any_active);
+    if (!valid) return;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) a.q_out[at(a.layout, a.B, a.nq, a.qidx[j], b)] = q[j];
+    // entries outside the task support: only ever clamped (reference ik/ik/dls.cpp:71; no step is taken when iters == 0)
+    for (int i = 0; i < a.nq; ++i) {
+        if (a.q_in_chain[i]) continue;
+        const double v = a.q0[at(a.layout, a.B, a.nq, i, b)];
+        const double c = dmin(a.upper[i], dmax(v, a.lower[i]));
+        a.q_out[at(a.layout, a.B, a.nq, i, b)] = (iters > 0) ? c : v;
+    }
+    if (a.success) a.success[b] = success ? 1 : 0;
+    if (a.iters) a.iters[b] = iters;
+}
+
+}  // namespace ikdev

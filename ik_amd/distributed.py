@@ -4,12 +4,20 @@ One process per GPU.  Problems are independent, the model + task table are repli
 step is ONE all-gather of the solved configurations together with the success / iteration flags --
 `torch.distributed` backend "nccl" is RCCL over xGMI on MI355X; "gloo" runs the same code on CPU for tests.
 
-A rank's results live in one packed byte buffer  [ q: nq x b float64 | iterations: b int32 | success: b uint8 ]
-that the solve kernel writes through typed views, so the exchange is a single collective per step (three small
-collectives cost three launch latencies); the gathered layout is [world][nq][b]: each rank's component-major
-block stays contiguous and nothing is transposed on either side.  xGMI is a point-to-point mesh (7 links per
-GPU): the all-gather of step k is issued asynchronously and overlaps the solve of step k + 1 (two buffer
-sets alternate), so a step costs max(compute, exchange) instead of their sum.
+A rank's results travel in one packed byte buffer  [ q rows: R x b float64 | iterations: b int32 | success: b uint8 ]
+so the exchange is a single collective per step (three small collectives cost three launch latencies); the gathered
+layout is [world][slot]: each rank's component-major block stays contiguous and nothing is transposed on either side.
+
+* Shards may differ by one problem (`shard_range`, B % world != 0): every rank's slot has the size of the LARGEST
+  shard (`all_gather_into_tensor` needs equal contributions), a rank with the smaller shard leaves the tail of its
+  slot unused, and the receiver decodes slot r with rank r's own shard size.
+* Payload "full": R = nq rows, the solve kernel writes straight into the send buffer through typed views.
+  Payload "compact": only the rows of q a solve can move (`ikgpu_problem_support`: 7 of the 16 for a Cassie leg --
+  the other entries are q0 clipped to the limits, which a consumer holding q0 rebuilds with `expand_rows`) + the
+  flags: 61 instead of 133 bytes per problem on the wire.  The kernel then writes a full [nq, b] result and one
+  row-gather packs the support rows into the send buffer.
+* xGMI is a point-to-point mesh (7 links per GPU): the all-gather of step k is issued asynchronously and overlaps
+  the solve of step k + 1 (two buffer sets alternate), so a step costs max(compute, exchange) instead of their sum.
 """
 import torch
 import torch.distributed as dist
@@ -22,37 +30,61 @@ def shard_range(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-class ShardBuffers:
-    """Packed send buffer of one rank (with typed views for the kernel) and the gathered receive buffer."""
+def shard_size(total, rank, world):
+    lo, hi = shard_range(total, rank, world)
+    return hi - lo
 
-    def __init__(self, nq, b_local, world, device):
-        self.nq, self.b, self.world = int(nq), int(b_local), int(world)
-        q_bytes, it_bytes = self.nq * self.b * 8, self.b * 4
-        self.nbytes = (q_bytes + it_bytes + self.b + 15) // 16 * 16
-        self._off = (0, q_bytes, q_bytes + it_bytes)
+
+def _layout(rows, b):
+    """Byte offsets of (q rows, iterations, success) in a slot holding b problems, and the bytes used."""
+    q_bytes, it_bytes = rows * b * 8, b * 4
+    return (0, q_bytes, q_bytes + it_bytes), q_bytes + it_bytes + b
+
+
+class ShardBuffers:
+    """Packed send buffer of one rank (with typed views for the kernel) and the gathered receive buffer.
+
+    nq: rows of a configuration; total: problems in the whole job; rank / world: this process;
+    rows: None for the full payload, or the indices of the q rows to ship (compact payload)."""
+
+    def __init__(self, nq, total, rank, world, device, rows=None):
+        self.nq, self.total, self.rank, self.world = int(nq), int(total), int(rank), int(world)
+        self.b = shard_size(self.total, self.rank, self.world)
+        self.b_max = shard_size(self.total, 0, self.world)          # rank 0 always holds a largest shard
+        self.rows = None if rows is None else torch.as_tensor(rows, dtype=torch.int64, device=device)
+        self.R = self.nq if rows is None else int(self.rows.numel())
+        self.nbytes = (_layout(self.R, self.b_max)[1] + 15) // 16 * 16   # slot size: the largest shard, 16-byte aligned
         self.local = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
         self.all = torch.zeros((self.world, self.nbytes), dtype=torch.uint8, device=device)
-        self.Q, self.it, self.ok = self._views(self.local)
+        self.Qs, self.it, self.ok = self._views(self.local, self.b)
+        # compact payload: the kernel needs a full [nq, b] result to write to; the support rows are packed from it
+        self.Q = self.Qs if rows is None else torch.zeros((self.nq, self.b), dtype=torch.float64, device=device)
         self.work = None
 
-    def _views(self, flat):
-        o = self._off
-        Q = flat[o[0]:o[1]].view(torch.float64).view(self.nq, self.b)
+    def _views(self, flat, b):
+        o, _ = _layout(self.R, b)
+        Q = flat[o[0]:o[1]].view(torch.float64).view(self.R, b)
         it = flat[o[1]:o[2]].view(torch.int32)
-        ok = flat[o[2]:o[2] + self.b]
+        ok = flat[o[2]:o[2] + b]
         return Q, it, ok
 
     def out(self):
-        """(Q, success, iterations) views of the send buffer, in the order ik_amd.dls_batch(out=...) takes."""
+        """(Q, success, iterations) views the solve writes to, in the order ik_amd.dls_batch(out=...) takes."""
         return self.Q, self.ok, self.it
 
+    def pack(self):
+        """Compact payload: gather the support rows of the result into the send buffer (a no-op for the full payload)."""
+        if self.rows is not None:
+            torch.index_select(self.Q, 0, self.rows, out=self.Qs)
+
     def gathered(self):
-        """Per-rank views of the receive buffer: lists of Q [nq, b], success [b], iterations [b]."""
-        parts = [self._views(self.all[r]) for r in range(self.world)]
+        """Per-rank views of the receive buffer: lists of Q rows [R, b_r], success [b_r], iterations [b_r]."""
+        parts = [self._views(self.all[r], shard_size(self.total, r, self.world)) for r in range(self.world)]
         return [p[0] for p in parts], [p[2] for p in parts], [p[1] for p in parts]
 
     def all_gather(self, async_op=False, group=None):
         """One collective: every rank ends with every rank's packed block."""
+        self.pack()
         self.work = dist.all_gather_into_tensor(self.all.view(-1), self.local, group=group, async_op=async_op)
         return self.work
 
@@ -61,3 +93,14 @@ class ShardBuffers:
         if self.work is not None:
             self.work.wait()
             self.work = None
+
+
+def expand_rows(Q_rows, rows, q0, lower, upper, iterations):
+    """Rebuild full configurations from a compact payload: the shipped rows are the solver's result, every other entry is
+    what the loop does to it -- q0 clipped to the limits once a step was taken (reference ik/ik/dls.cpp:67-71,
+    ik/ik/common.hpp:53-56), q0 itself when the solve stopped at iteration 0 (dls.cpp:61-63 returns the unclipped q).
+    Q_rows [R, b], rows [R], q0 [nq, b], lower / upper [nq], iterations [b] -> [nq, b]."""
+    clipped = torch.minimum(torch.maximum(q0, lower[:, None]), upper[:, None])
+    Q = torch.where((iterations > 0)[None, :], clipped, q0)
+    Q[rows] = Q_rows
+    return Q

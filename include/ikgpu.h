@@ -154,6 +154,11 @@ int ikgpu_problem_plan_constrained(const ikgpu_model *m, const ikgpu_task *tasks
                                    int32_t nconstraints, char *out, size_t cap);
 int32_t ikgpu_problem_rows(const ikgpu_problem *p);        /* M = sum of task dimensions */
 const char *ikgpu_problem_kernel(const ikgpu_problem *p);  /* name of the chosen specialisation */
+/* Which entries of q a solve can move: support[i] = 1 when q[i] is integrated by the kernel (a joint in the support of some
+ * task row, or the floating base), 0 when the loop only ever clips it to its limits (reference ik/ik/dls.cpp:67-71 steps the
+ * whole q with dq = 0 there, then ik/ik/common.hpp:53-56 clips it).  A consumer that already holds q0 needs only the
+ * support entries of the result -- what the compact multi-GPU gather ships.  support: HOST pointer to nq bytes. */
+int ikgpu_problem_support(const ikgpu_problem *p, uint8_t *support);
 
 /* ---- the hot path: B independent calls of ik::dls() (reference ik/ik/dls.cpp:5-78) in lockstep.
  * All array arguments are DEVICE pointers on the problem's device:

@@ -290,3 +290,38 @@ def flat_from_twin(m):
         frame_placement=np.array([m12(f["placement"]) for f in m.frames]),
         frame_names=[f["name"] for f in m.frames], joint_names=list(m.names),
         mass=np.array(m.mass), lever=np.array(m.lever))
+
+
+# ---- the optimised CPU variant (oracle/fast_cpu.cpp): bench baseline only --------------------------------------------------
+_FAST = None
+
+
+def fast_lib():
+    global _FAST
+    if _FAST is None:
+        path = os.path.join(_HERE, "libik_fastcpu.so")
+        if not os.path.exists(path):
+            build()
+        _FAST = C.CDLL(path)
+        _FAST.fastcpu_last_error.restype = C.c_char_p
+        _FAST.fastcpu_dls_chain.restype = C.c_int
+    return _FAST
+
+
+def fast_dls_chain_batch(urdf_xml, frame_id, targets, q0, prm, nthreads=1):
+    """One Full FrameTask (w.r.t. the universe) on a fixed-base chain; targets [B, 1, 12], q0 [B, nq] (array-of-structures).
+    Returns (q, success, iterations) like dls_batch."""
+    if isinstance(urdf_xml, str):
+        urdf_xml = urdf_xml.encode("utf-8")
+    targets = np.ascontiguousarray(targets, dtype=np.float64)
+    q0 = np.ascontiguousarray(q0, dtype=np.float64)
+    B = q0.shape[0]
+    task = make_tasks([(frame_id, 0, 2, 0, None)])
+    q = np.empty_like(q0)
+    ok = np.zeros(B, dtype=np.uint8)
+    it = np.zeros(B, dtype=np.int32)
+    rc = fast_lib().fastcpu_dls_chain(urdf_xml, C.c_size_t(len(urdf_xml)), task, C.c_int64(B), _p(q0), _p(targets), C.byref(prm),
+                                      _p(q), _p(ok), _p(it), C.c_int(1), C.c_int(nthreads))
+    if rc != 0:
+        raise RuntimeError(fast_lib().fastcpu_last_error().decode())
+    return q, ok, it
