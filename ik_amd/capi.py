@@ -7,7 +7,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libikgpu.so")
+# IKGPU_LIB: another build of the same library (A/B of kernel variants: `make -C ik_amd/csrc OUT=... OBJ=... KERNEL_EXTRA=-D...`
+# writes it beside the production file instead of over it)
+LIB_PATH = os.environ.get("IKGPU_LIB") or os.path.join(_HERE, "libikgpu.so")
 
 OK, ERR_INVALID, ERR_PARSE, ERR_UNSUPPORTED, ERR_DEVICE = 0, 1, 2, 3, 4
 JOINT_UNIVERSE, JOINT_REVOLUTE, JOINT_PRISMATIC, JOINT_FREEFLYER = 0, 1, 2, 3

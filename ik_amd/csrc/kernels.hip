@@ -163,6 +163,7 @@ bool chain_shape_built(int nj, int type) {
 
 hipError_t launch_dls_chain(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io,
                             const ikgpu_dls_params &prm, hipStream_t stream) {
+    if (chain_hot_built(ph)) return launch_dls_chain_hot(ph, dt, io, prm, stream);   // structure-specialised build (kernels_hot.hip)
     const int nj = ph.chain.nj, type = ph.tasks[0].type;
 #define X(N)                                                                                              \
     if (nj == N) {                                                                                        \

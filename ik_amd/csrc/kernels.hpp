@@ -35,6 +35,11 @@ hipError_t launch_eval_chain(const ProblemHost &ph, const DeviceTables &dt, int6
 hipError_t launch_fk_chain(const ProblemHost &ph, const DeviceTables &dt, int64_t B, const double *q, double *oMf_out, int layout,
                            hipStream_t stream);
 bool chain_shape_built(int nj, int type);
+// The structure-specialised builds of the chain kernel (kernels_hot.hip, device/chain_hot.hpp): one Full task with unit
+// weights on a chain whose placement-structure code has an instantiation.  launch_dls_chain takes that route when it exists.
+bool chain_hot_built(const ProblemHost &ph);
+hipError_t launch_dls_chain_hot(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const ikgpu_dls_params &prm,
+                                hipStream_t stream);
 
 }  // namespace ikgpu
 

@@ -523,6 +523,39 @@ int chain_identity_mask(const ChainHost &c) {
     return m;
 }
 
+ChainStructure chain_structure(const ChainHost &c) {
+    ChainStructure out;
+    if (c.nj < 1 || c.nj > 7) return out;
+    out.fits = true;
+    for (int i = 0; i <= c.nj; ++i) {
+        const double *pl = i < c.nj ? c.pl[i] : c.frame_pl;
+        uint64_t code = 0;
+        for (int e = 0; e < 9; ++e) {
+            const uint64_t cls = pl[e] == 0.0 ? 1u : (pl[e] == 1.0 ? 2u : (pl[e] == -1.0 ? 3u : 0u));
+            if (cls == 0) ++out.values;
+            code |= cls << (2 * e);
+        }
+        for (int k = 0; k < 3; ++k)
+            if (pl[9 + k] != 0.0) { code |= uint64_t{1} << (18 + k); ++out.values; }
+        out.code[i / 3] |= code << (21 * (i % 3));
+    }
+    return out;
+}
+
+std::vector<double> chain_hot_table(const ChainHost &c) {
+    std::vector<double> t;
+    for (int i = 0; i <= c.nj; ++i) {
+        const double *pl = i < c.nj ? c.pl[i] : c.frame_pl;
+        for (int e = 0; e < 9; ++e)
+            if (!(pl[e] == 0.0 || pl[e] == 1.0 || pl[e] == -1.0)) t.push_back(pl[e]);
+        for (int k = 0; k < 3; ++k)
+            if (pl[9 + k] != 0.0) t.push_back(pl[9 + k]);
+    }
+    t.insert(t.end(), c.lo, c.lo + c.nj);
+    t.insert(t.end(), c.hi, c.hi + c.nj);
+    return t;
+}
+
 bool task_has_unit_weights(const ikgpu_task &t) {
     for (int i = 0; i < task_dim(t); ++i)
         if (t.weight[i] != 1.0) return false;

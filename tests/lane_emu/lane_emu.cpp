@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "device/chain_kernel_body.hpp"
+#include "device/chain_hot.hpp"
 #include "device/tree_kernel_body.hpp"
 #include "device/pik_solver.hpp"
 #include "generic_tables.hpp"
@@ -60,6 +61,45 @@ void run_chain(const ikgpu::ProblemHost &ph, const IO &io) {
         else if (io.mode == 1) ikdev::eval_chain_body<NJ, KT>(a, d, b);
         else ikdev::fk_chain_body<NJ>(a, d, b);
     }
+}
+
+// The structure-specialised chain program (device/chain_hot.hpp) with the structure codes kernels_hot.hip instantiates.
+template <int NJ, uint64_t C0, uint64_t C1, uint64_t C2>
+void run_chain_hot(const ikgpu::ProblemHost &ph, const IO &io) {
+    ikdev::ChainKernelArgs<NJ> a{};
+    ikgpu::fill_chain_args(ph, a.ref_pl, a.qidx, a.vidx, &a.nq, &a.nv, &a.prm.priority, &a.prm.idmask, &a.prm.unit_weights);
+    a.lower = ph.lower.data(); a.upper = ph.upper.data(); a.q_in_chain = ph.q_in_chain.data();
+    a.layout = io.layout; a.B = io.B; a.q0 = io.q0; a.targets = io.targets;
+    a.q_out = io.q_out; a.success = io.success; a.iters = io.iters;
+    a.prm.max_iterations = io.prm->max_iterations;
+    a.prm.lam2 = io.prm->damping * io.prm->damping;
+    a.prm.step_length = io.prm->step_length;
+    a.prm.stop_sq_tol = io.prm->stop_sq_tol;
+    ikdev::HotTable t{};
+    const std::vector<double> tab = ikgpu::chain_hot_table(ph.chain);
+    if (tab.size() > static_cast<size_t>(ikdev::kHotTableMax)) throw std::runtime_error("compact table too long");
+    std::memcpy(t.v, tab.data(), tab.size() * sizeof(double));
+    typedef ikdev::ChainStruct<C0, C1, C2> S;
+    for (int64_t b = 0; b < io.B; ++b) {
+        if (io.prm->stop_sq_tol < 0.0) ikdev::hot_chain_body<NJ, S, true>(a, t, b, [](bool act) { return act; });
+        else ikdev::hot_chain_body<NJ, S, false>(a, t, b, [](bool act) { return act; });
+    }
+}
+
+// true when the problem was run by the hot program (LANE_EMU_HOT set, a Full task with unit weights, a known structure code)
+bool try_chain_hot(const ikgpu::ProblemHost &ph, const IO &io) {
+    if (!std::getenv("LANE_EMU_HOT") || io.mode != 0 || ph.tasks[0].type != IKGPU_FULL || !ikgpu::task_has_unit_weights(ph.tasks[0])) return false;
+    const ikgpu::ChainStructure s = ikgpu::chain_structure(ph.chain);
+    if (!s.fits) return false;
+#define X(N, K0, K1, K2)                                                                      \
+    if (ph.chain.nj == N && s.code[0] == K0 && s.code[1] == K1 && s.code[2] == K2) {         \
+        run_chain_hot<N, K0, K1, K2>(ph, io);                                                 \
+        return true;                                                                          \
+    }
+    X(7, 0x04f0208cce8c7664ull, 0x395959cacad65656ull, 0x000001cacace5656ull)
+    X(6, 0x695959272b925656ull, 0x47655a33aaca549cull, 0x0000000000121256ull)
+#undef X
+    return false;
 }
 
 template <int NJ>
@@ -175,6 +215,7 @@ int lane_emu_run(const char *urdf, size_t len, int root_joint, const ikgpu_task 
             return 0;
         }
         if (ph.kind == ikgpu::KernelKind::Chain) {
+            if (try_chain_hot(ph, io)) return 0;
             const int nj = ph.chain.nj, kt = tasks[0].type;
 #define X(N)                                       \
     if (nj == N) {                                 \

@@ -20,7 +20,7 @@ def emu(native_built):
     out = os.path.join(ROOT, "tests", "lane_emu", "liblane_emu.so")
     deps = [src] + [os.path.join(ROOT, "ik_amd", "csrc", f) for f in
                     ("model.cpp", "problem.cpp", "model.hpp", "problem.hpp", "device/lane_math.hpp",
-                     "device/chain_solver.hpp", "device/chain_kernel_body.hpp", "device/tree_solver.hpp",
+                     "device/chain_solver.hpp", "device/chain_kernel_body.hpp", "device/chain_hot.hpp", "device/tree_solver.hpp",
                      "device/tree_kernel_body.hpp", "device/generic_solver.hpp", "device/pik_solver.hpp", "device/coop_solver.hpp", "device/pik_coop.hpp", "generic_tables.hpp")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
@@ -51,7 +51,7 @@ def setup(name, frame, ktype=2, weights=None, B=256, mode="near", narrow=None):
     model = ik_amd.Model.from_urdf_xml(urdf)
     om = O.OracleModel(model.flat())
     fid = model.getFrameId(frame)
-    nominal = workload.UR5_NOMINAL if name == "ur5" else workload.cassie_nominal(model.names)
+    nominal = workload.UR5_NOMINAL if name.startswith("ur") else workload.cassie_nominal(model.names)
     q0, qs = workload.chain_workload(model.lowerPositionLimit, model.upperPositionLimit, nominal, np.arange(B), 0, mode, narrow)
     tg = O.fk_batch(om, qs, [fid])
     w = list(weights) + [1.0] * (6 - len(weights)) if weights is not None else [1.0] * 6
@@ -119,6 +119,30 @@ def test_lane_program_device_general_build(emu, monkeypatch, name, frame, iters,
     q_ref, ok_ref, it_ref = O.dls_batch(om, ot, tg, q0, O.params(iters, 1e-2, 1.0, tol))
     assert np.array_equal(ok, ok_ref) and np.array_equal(it, it_ref)
     assert np.abs(qo - q_ref).max() < 1e-9
+
+
+@pytest.mark.parametrize("name,frame", [("cassie_fixed", "LeftFootFront"), ("cassie_fixed", "RightFootFront"), ("ur5", "tool0"), ("ur10", "tool0")])
+@pytest.mark.parametrize("mode,iters,tol", [("near", 50, -1.0), ("near", 100, 1e-4), ("near", 1, -1.0), ("near", 0, 1e-4),
+                                            ("uniform", 1, -1.0), ("uniform", 3, -1.0)])
+def test_lane_program_structure_specialised_build(emu, monkeypatch, name, frame, mode, iters, tol):
+    """The structure-specialised chain program (device/chain_hot.hpp; the headline kernel of kernels_hot.hip): literal zeros and
+    ones for the structural placement entries, the compact table, the one-reciprocal log6 front end with the branch-free acos.
+    "uniform" targets are far from the start: rotation errors up to pi (every acos range, the theta -> pi formula of log3)."""
+    from ik_amd import capi
+    urdf, model, om, task, ot, q0, qs, tg = setup(name, frame, B=512, mode=mode, narrow=2.0 if name.startswith("ur") and mode == "uniform" else None)
+    q0[::7, 2] += 7.0          # the first evaluation is at q0 as given (the reference does not clamp it)
+    prm = capi.DlsParams(iters, 1e-2, 1.0, tol)
+    monkeypatch.setenv("LANE_EMU_HOT", "1")
+    qo, ok, it, *_ = run(emu, urdf, task, 0, q0, tg, prm, model.nv, 6)
+    qo2, ok2, it2, *_ = run(emu, urdf, task, 0, np.ascontiguousarray(q0.T), np.ascontiguousarray(tg.transpose(1, 2, 0)), prm, model.nv, 6, layout=0)
+    monkeypatch.delenv("LANE_EMU_HOT")
+    qg, okg, itg, *_ = run(emu, urdf, task, 0, q0, tg, prm, model.nv, 6)          # the general chain program
+    q_ref, ok_ref, it_ref = O.dls_batch(om, ot, tg, q0, O.params(iters, 1e-2, 1.0, tol))
+    assert np.array_equal(ok, ok_ref) and np.array_equal(it, it_ref)
+    bar = 1e-9 if mode == "near" else (1e-9 if iters == 1 else 1e-6)
+    assert np.abs(qo - q_ref).max() < bar
+    assert np.abs(qo - qg).max() < bar
+    assert np.array_equal(qo2.T, qo) and np.array_equal(ok2, ok) and np.array_equal(it2, it)
 
 
 @pytest.mark.parametrize("ktype,weights", [(0, None), (1, None), (2, [1.0, 2.0, 0.5, 1.5, 1.0, 3.0]), (1, [2.0, 1.0, 0.25])])

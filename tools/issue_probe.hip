@@ -58,6 +58,13 @@ struct Stamp { long long cyc, real; };
 #define MULFMA(x) asm volatile("v_mul_f64 %0, %0, %1\n v_fma_f64 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b));
 #define ADDMUL(x) asm volatile("v_add_f64 %0, %0, %2\n v_mul_f64 %0, %0, %1" : "+v"(x) : "v"(a), "v"(b));
 
+// four dependent instructions in ONE asm statement: the compiler cannot put an s_nop between them
+#define FMA4DEP(x) asm volatile("v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b));
+#define MUL4DEP(x) asm volatile("v_mul_f64 %0, %0, %1\n v_mul_f64 %0, %0, %1\n v_mul_f64 %0, %0, %1\n v_mul_f64 %0, %0, %1" : "+v"(x) : "v"(a));
+#define FMA2x2(x) asm volatile("v_fma_f64 %0, %0, %2, %3\n v_fma_f64 %1, %1, %2, %3\n v_fma_f64 %0, %0, %2, %3\n v_fma_f64 %1, %1, %2, %3" : "+v"(x), "+v"(x7) : "v"(a), "v"(b));
+#define RSQFMA(x) asm volatile("v_rsq_f64 %0, %0\n v_fma_f64 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b));
+#define RSQ_3FMA(x) asm volatile("v_rsq_f64 %0, %0\n v_fma_f64 %1, %1, %2, %3\n v_fma_f64 %1, %1, %2, %3\n v_fma_f64 %1, %1, %2, %3" : "+v"(x), "+v"(x7) : "v"(a), "v"(b));
+#define C1Q(OP) REP64(OP(x0))
 #define C1(OP) REP64(OP(x0) OP(x0) OP(x0) OP(x0))
 #define C2(OP) REP64(OP(x0) OP(x1) OP(x0) OP(x1))
 #define C3(OP) REP64(OP(x0) OP(x1) OP(x2)) REP16(OP(x0) OP(x1) OP(x2)) REP4(OP(x0) OP(x1) OP(x2))   // 252
@@ -87,6 +94,7 @@ DEF(fma_readlane_c8, C8(FMA_READLANE)) DEF(fma_cmp_c8, C8(FMA_CMP)) DEF(fma_cnd_
 DEF(fma_mov32_c1, C1(FMA_MOV32)) DEF(fma_mov32_c2, C2(FMA_MOV32))
 DEF(mulfma_c1, C1(MULFMA)) DEF(mulfma_c2, C2(MULFMA)) DEF(mulfma_c4, C4(MULFMA)) DEF(mulfma_c8, C8(MULFMA))
 DEF(addmul_c1, C1(ADDMUL)) DEF(addmul_c8, C8(ADDMUL))
+DEF(fma4dep, C1Q(FMA4DEP)) DEF(mul4dep, C1Q(MUL4DEP)) DEF(fma2x2, C1Q(FMA2x2)) DEF(rsqfma, C1(RSQFMA)) DEF(rsq_3fma, C1Q(RSQ_3FMA))
 
 typedef void (*Kern)(double *, Stamp *, int, double, double);
 struct Entry { const char *name; Kern k; int chains; int inst_per_trip; };
@@ -113,6 +121,7 @@ int main(int argc, char **argv) {
         E(fma_cmp_c8, 8, 512), E(fma_cnd_c8, 8, 512), E(fma_mov32_c1, 1, 512), E(fma_mov32_c2, 2, 512),
         E(mulfma_c1, 1, 512), E(mulfma_c2, 2, 512), E(mulfma_c4, 4, 512), E(mulfma_c8, 8, 512),
         E(addmul_c1, 1, 512), E(addmul_c8, 8, 512),
+        E(fma4dep, 1, 256), E(mul4dep, 1, 256), E(fma2x2, 2, 256), E(rsqfma, 1, 512), E(rsq_3fma, 2, 256),
     };
     printf("name,chains,waves_per_simd,cycles_per_instruction,cycles_per_trip,clock_GHz,event_ms\n");
     for (int wps : {1, 2}) {

@@ -75,123 +75,137 @@ def main():
         mm = re.match(r"^\.?(L?BB\d+_\d+):", l.strip())
         if mm:
             label_at[mm.group(1).lstrip("L")] = i
-    h = find_header(body)
-    header = body[h].split(":")[0].strip().lstrip(".").lstrip("L")
-    taken = [x.lstrip(".").lstrip("L") for x in args.taken]
-    t = 0               # cycle at which the next instruction may issue
-    ready = collections.defaultdict(int)    # register -> cycle its value is available
-    pending_sload = []  # completion times of outstanding scalar loads (in order)
-    pending_sregs = []
-    pending_lds = []
-    counts = collections.Counter()
-    stall_dep = stall_wait = 0
-    sites = []
-    n = 0
-    i = h + 1
-    steps = 0
-    while i < len(lines):
-        steps += 1
-        if steps > 200000:
-            sys.exit("walk does not return to the loop header (give --taken labels)")
-        raw = lines[i]
-        if i == h:      # fell through into the header: one iteration walked
-            break
-        i += 1
-        l = raw.split(";")[0].strip()
-        if not l or l.startswith(".") or l.endswith(":"):
-            continue
-        op = l.split()[0]
-        rest = l[len(op):]
-        if op.startswith("s_cbranch") or op == "s_branch":
-            tgt = rest.strip().lstrip(".").lstrip("L")
-            counts["branch"] += 1
-            n += 1
-            t += 4
-            if tgt == header and (op == "s_branch" or tgt not in taken):
-                t += 16      # the back edge: a taken branch (instruction fetch restart; not measured precisely)
+    def walk_loop(h):
+        header = body[h].split(":")[0].strip().lstrip(".").lstrip("L")
+        taken = [x.lstrip(".").lstrip("L") for x in args.taken]
+        t = 0               # cycle at which the next instruction may issue
+        ready = collections.defaultdict(int)    # register -> cycle its value is available
+        pending_sload = []  # completion times of outstanding scalar loads (in order)
+        pending_sregs = []
+        pending_lds = []
+        counts = collections.Counter()
+        ophist = collections.Counter()
+        stall_dep = stall_wait = 0
+        sites = []
+        n = 0
+        i = h + 1
+        steps = 0
+        while i < len(lines):
+            steps += 1
+            if steps > 200000:
+                return None
+            raw = lines[i]
+            if i == h:      # fell through into the header: one iteration walked
                 break
-            if tgt in label_at and (tgt in taken or op == "s_branch"):
-                i = label_at[tgt]
-                t += 16
-            continue
-        ops = [o.strip() for o in rest.split(",")] if rest.strip() else []
-        # destination: first operand (VOPC writes vcc / an SGPR pair given first as well; stores have none)
-        is_store = op.startswith(("global_store", "ds_write", "buffer_store", "flat_store"))
-        dst = [] if is_store or op in ("s_waitcnt", "s_nop", "s_cmp_lt_i32", "s_cmp_eq_u32", "s_cmp_lg_u32") or op.startswith("s_cmp") else (regs_of(ops[0]) if ops else [])
-        srcs = []
-        for o in (ops if is_store or not dst else ops[1:]):
-            srcs += regs_of(o)
-        if op.startswith(("v_fmac", "v_mac")) or op in ("v_writelane_b32",):
-            srcs += dst          # accumulates into its destination
-        if "vcc" in l and op.startswith("v_cndmask") and not any(r[0] == "vcc" for r in srcs):
-            srcs.append(("vcc", 0))
-        if op.startswith("v_cmp") and "_e32" in op:
-            dst = [("vcc", 0)]
-            srcs = [r for o in ops for r in regs_of(o)]
-        if op.startswith("s_cmp") or op in ("s_cmp_lt_i32",):
-            dst = [("scc", 0)]
-            srcs = [r for o in ops for r in regs_of(o)]
-        cost = 4
-        lat = 4
-        f64 = "_f64" in op
-        if op.startswith(TRANS):
-            cost, lat = 16, 20
-            counts["trans_f64"] += 1
-        elif op.startswith("v_mov_b64"):
-            cost, lat = 8, 8
-            counts["v_mov_b64"] += 1
-        elif f64:
-            lat = args.f64lat
-            counts["fp64_fma" if op.startswith(("v_fma_f64", "v_fmac_f64")) else "fp64_other"] += 1
-        elif op.startswith("v_"):
-            counts["valu_other"] += 1
-        elif op.startswith("s_load"):
-            counts["s_load"] += 1
-        elif op == "s_waitcnt":
-            counts["s_waitcnt"] += 1
-        elif op.startswith("s_"):
-            counts["salu"] += 1
-        elif op.startswith("ds_"):
-            counts["lds"] += 1
-        else:
-            counts["other"] += 1
-        if op == "s_nop":
-            cost = 4 * (1 + int(ops[0], 0)) if ops else 4
-        n += 1
-        start = t
-        dep = max([ready[r] for r in srcs] + [0])
-        if dep > start:
-            stall_dep += dep - start
-            sites.append((dep - start, "dep", l))
-            start = dep
-        if op == "s_waitcnt":
-            need = 0
-            if "lgkmcnt(0)" in l or "lgkmcnt" in l:
-                need = max(pending_sload + pending_lds + [0])
-                pending_sload, pending_lds = [], []
-            if need > start:
-                stall_wait += need - start
-                sites.append((need - start, "wait", l))
-                start = need
-        if op.startswith("s_load"):
-            done = max(start + args.sload, (pending_sload[-1] if pending_sload else 0))
-            pending_sload.append(done)
-            for r in dst:
-                ready[r] = 0     # guarded by s_waitcnt, not by the scoreboard
-        elif op.startswith("ds_read"):
-            pending_lds.append(start + args.lds)
-            for r in dst:
-                ready[r] = 0
-        else:
-            for r in dst:
-                ready[r] = start + lat
-        t = start + cost
+            i += 1
+            l = raw.split(";")[0].strip()
+            if not l or l.startswith(".") or l.endswith(":"):
+                continue
+            op = l.split()[0]
+            rest = l[len(op):]
+            ophist[op] += 1
+            if op.startswith("s_cbranch") or op == "s_branch":
+                tgt = rest.strip().lstrip(".").lstrip("L")
+                counts["branch"] += 1
+                n += 1
+                t += 4
+                if tgt == header and (op == "s_branch" or tgt not in taken):
+                    t += 16      # the back edge: a taken branch (instruction fetch restart; not measured precisely)
+                    break
+                if tgt in label_at and (tgt in taken or op == "s_branch"):
+                    i = label_at[tgt]
+                    t += 16
+                continue
+            ops = [o.strip() for o in rest.split(",")] if rest.strip() else []
+            # destination: first operand (VOPC writes vcc / an SGPR pair given first as well; stores have none)
+            is_store = op.startswith(("global_store", "ds_write", "buffer_store", "flat_store"))
+            dst = [] if is_store or op in ("s_waitcnt", "s_nop", "s_cmp_lt_i32", "s_cmp_eq_u32", "s_cmp_lg_u32") or op.startswith("s_cmp") else (regs_of(ops[0]) if ops else [])
+            srcs = []
+            for o in (ops if is_store or not dst else ops[1:]):
+                srcs += regs_of(o)
+            if op.startswith(("v_fmac", "v_mac")) or op in ("v_writelane_b32",):
+                srcs += dst          # accumulates into its destination
+            if "vcc" in l and op.startswith("v_cndmask") and not any(r[0] == "vcc" for r in srcs):
+                srcs.append(("vcc", 0))
+            if op.startswith("v_cmp") and "_e32" in op:
+                dst = [("vcc", 0)]
+                srcs = [r for o in ops for r in regs_of(o)]
+            if op.startswith("s_cmp") or op in ("s_cmp_lt_i32",):
+                dst = [("scc", 0)]
+                srcs = [r for o in ops for r in regs_of(o)]
+            cost = 4
+            lat = 4
+            f64 = "_f64" in op
+            if op.startswith(TRANS):
+                cost, lat = 16, 20
+                counts["trans_f64"] += 1
+            elif op.startswith("v_mov_b64"):
+                cost, lat = 8, 8
+                counts["v_mov_b64"] += 1
+            elif f64:
+                lat = args.f64lat
+                counts["fp64_fma" if op.startswith(("v_fma_f64", "v_fmac_f64")) else "fp64_other"] += 1
+            elif op.startswith("v_"):
+                counts["valu_other"] += 1
+            elif op.startswith("s_load"):
+                counts["s_load"] += 1
+            elif op == "s_waitcnt":
+                counts["s_waitcnt"] += 1
+            elif op.startswith("s_"):
+                counts["salu"] += 1
+            elif op.startswith("ds_"):
+                counts["lds"] += 1
+            else:
+                counts["other"] += 1
+            if op == "s_nop":
+                cost = 4 * (1 + int(ops[0], 0)) if ops else 4
+            n += 1
+            start = t
+            dep = max([ready[r] for r in srcs] + [0])
+            if dep > start:
+                stall_dep += dep - start
+                sites.append((dep - start, "dep", l))
+                start = dep
+            if op == "s_waitcnt":
+                need = 0
+                if "lgkmcnt(0)" in l or "lgkmcnt" in l:
+                    need = max(pending_sload + pending_lds + [0])
+                    pending_sload, pending_lds = [], []
+                if need > start:
+                    stall_wait += need - start
+                    sites.append((need - start, "wait", l))
+                    start = need
+            if op.startswith("s_load"):
+                done = max(start + args.sload, (pending_sload[-1] if pending_sload else 0))
+                pending_sload.append(done)
+                for r in dst:
+                    ready[r] = 0     # guarded by s_waitcnt, not by the scoreboard
+            elif op.startswith("ds_read"):
+                pending_lds.append(start + args.lds)
+                for r in dst:
+                    ready[r] = 0
+            else:
+                for r in dst:
+                    ready[r] = start + lat
+            t = start + cost
+        return dict(t=t, n=n, counts=counts, ophist=ophist, stall_dep=stall_dep, stall_wait=stall_wait, sites=sites)
+
+    best = None
+    for h in [i for i, l in enumerate(body) if "Loop Header: Depth=1" in l]:
+        res = walk_loop(h)
+        if res and (best is None or res["n"] > best["n"]):
+            best = res
+    if best is None:
+        sys.exit("no loop whose walk returns to its header (give --taken labels)")
+    t, n, counts, ophist, stall_dep, stall_wait, sites = (best[k] for k in ("t", "n", "counts", "ophist", "stall_dep", "stall_wait", "sites"))
     total = t
     print("kernel %s" % name)
     print("loop: %d instructions on the walked path, %d cycles = %d quads per iteration" % (n, total, total // 4))
     print("  issue: %d cycles; dependency stalls %d; s_waitcnt stalls %d (scalar load latency %d)" %
           (total - stall_dep - stall_wait, stall_dep, stall_wait, args.sload))
     print("  " + ", ".join("%s %d" % kv for kv in sorted(counts.items(), key=lambda kv: -kv[1])))
+    if args.dump:
+        print("  opcodes: " + ", ".join("%s %d" % kv for kv in ophist.most_common(60)))
     if args.top:
         agg = collections.Counter()
         for c, kind, l in sites:

@@ -37,9 +37,13 @@ tasks = O.make_tasks([(model.getFrameId(f), 0, 2, 0, None) for f in w["frames"]]
 prm = O.params(50, 1e-2, 1.0, -1.0)
 cores = os.cpu_count() or 1
 q_ref, _, _ = O.dls_batch(om, tasks, tg, q0, prm, cores)
-q_pert, _, _ = O.dls_batch(om, tasks, tg, q0 + 1e-13, prm, cores)
+sens = np.zeros(B)
+for dq, dt in ((1e-13, 0.0), (0.0, 1e-13), (-1e-13, -1e-13)):
+    tgp = tg.copy()
+    tgp[:, :, 9:] += dt
+    q_pert, _, _ = O.dls_batch(om, tasks, tgp, q0 + dq, prm, cores)
+    sens = np.maximum(sens, np.abs(q_pert - q_ref).max(axis=1))
 d = np.abs(q_gpu - q_ref).max(axis=1)
-sens = np.abs(q_pert - q_ref).max(axis=1)
 lo, hi = model.lowerPositionLimit, model.upperPositionLimit
 on_limit = ((np.abs(q_ref - lo) < 1e-12) | (np.abs(q_ref - hi) < 1e-12)).any(axis=1)
 err = np.array([np.abs(O.evaluate(om, tasks, tg[b], q_ref[b])[0]).max() for b in range(min(B, 65536))])
