@@ -327,6 +327,32 @@ IKD_FN void hot_dls(const Tab &t, const LoopParams &prm, double (&q)[NJ], const 
     success_out = success;
 }
 
+// Entries of q outside the task support: dq = 0 there, so the loop only ever clips them to the limits (reference
+// ik/ik/dls.cpp:71 clips the whole q after each step; no step is taken when the solve stops at iteration 0).  Eight at a time,
+// every load of a group issued before its first store: one entry per pass (load, wait, store; the next load cannot move above a
+// store that might alias it) cost one HBM round trip per entry -- nine for a Cassie leg, ~10 us of a 150 us launch.
+template <int NJ>
+IKD_FN void hot_pass_through(const ChainKernelArgs<NJ> &a, int64_t b, bool stepped) {
+    constexpr int kGroup = 8;
+    for (int i0 = 0; i0 < a.nq; i0 += kGroup) {
+        double v[kGroup], lo[kGroup], hi[kGroup];
+        bool out[kGroup];
+#pragma unroll
+        for (int k = 0; k < kGroup; ++k) {
+            const int i = i0 + k < a.nq ? i0 + k : a.nq - 1;
+            out[k] = i0 + k < a.nq && !a.q_in_chain[i];
+            v[k] = a.q0[at(a.layout, a.B, a.nq, i, b)];
+            lo[k] = a.lower[i];
+            hi[k] = a.upper[i];
+        }
+#pragma unroll
+        for (int k = 0; k < kGroup; ++k) {
+            const double c = dmin(hi[k], dmax(v[k], lo[k]));
+            if (out[k]) a.q_out[at(a.layout, a.B, a.nq, i0 + k, b)] = stepped ? c : v[k];
+        }
+    }
+}
+
 // B independent ik::dls() calls, lane `gid`: load, solve, store -- dls_chain_body (chain_kernel_body.hpp) with the hot program.
 template <int NJ, class S, bool NEVERSTOP, class Tab, class AnyFn>
 IKD_FN void hot_chain_body(const ChainKernelArgs<NJ> &a, const Tab &t, int64_t gid, AnyFn any_active) {
@@ -340,6 +366,9 @@ IKD_FN void hot_chain_body(const ChainKernelArgs<NJ> &a, const Tab &t, int64_t g
     for (int j = 0; j < NJ; ++j) q[j] = a.q0[at(a.layout, a.B, a.nq, a.qidx[j], b)];
     double oMt[12];
     load_target(a, b, oMt);
+    // The visitor never stops: every lane takes max_iterations steps, so what happens to the entries outside the support is
+    // known before the loop -- copy them now (the stores drain while the loop runs) instead of after it (4 us of epilogue).
+    if (NEVERSTOP && valid) hot_pass_through(a, b, a.prm.max_iterations > 0);
     int iters;
     bool success;
 #if defined(IKGPU_HOT_STAMP) && IKD_ON_DEVICE
@@ -357,28 +386,7 @@ IKD_FN void hot_chain_body(const ChainKernelArgs<NJ> &a, const Tab &t, int64_t g
     if (!valid) return;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) a.q_out[at(a.layout, a.B, a.nq, a.qidx[j], b)] = q[j];
-    // entries outside the task support: only ever clamped (reference ik/ik/dls.cpp:71; no step is taken when iters == 0).
-    // Eight at a time, every load of a group issued before its first store: one entry per pass (load, wait, store; the next
-    // load cannot move above a store that might alias it) cost one HBM round trip per entry -- nine for a Cassie leg, ~10 us
-    // of a 150 us launch.
-    constexpr int kGroup = 8;
-    for (int i0 = 0; i0 < a.nq; i0 += kGroup) {
-        double v[kGroup], lo[kGroup], hi[kGroup];
-        bool out[kGroup];
-#pragma unroll
-        for (int k = 0; k < kGroup; ++k) {
-            const int i = i0 + k < a.nq ? i0 + k : a.nq - 1;
-            out[k] = i0 + k < a.nq && !a.q_in_chain[i];
-            v[k] = a.q0[at(a.layout, a.B, a.nq, i, b)];
-            lo[k] = a.lower[i];
-            hi[k] = a.upper[i];
-        }
-#pragma unroll
-        for (int k = 0; k < kGroup; ++k) {
-            const double c = dmin(hi[k], dmax(v[k], lo[k]));
-            if (out[k]) a.q_out[at(a.layout, a.B, a.nq, i0 + k, b)] = (iters > 0) ? c : v[k];
-        }
-    }
+    if (!NEVERSTOP) hot_pass_through(a, b, iters > 0);
     if (a.success) a.success[b] = success ? 1 : 0;
 #if defined(IKGPU_HOT_STAMP) && IKD_ON_DEVICE
     // lanes 0..5 of every wave: loop cycles, loop ticks, prologue ticks (wave start -> loop), epilogue ticks (loop end -> here,

@@ -55,12 +55,20 @@ IKD_FN void dls_tree_body(const TreeKernelArgs<NJ, NCH> &a, const Desc &d, int64
     bool success;
     // joints outside the chains that carry a posture row live in this lane's column of q_out while the loop runs
     constexpr bool kPost = SPEC < 0 || SPEC == (1 << kSpecPost);
-    const PostureState ps = post_lane ? PostureState{post_lane, post_stride, true, a.lower, a.upper, valid}
+    // (LDS layout of a posture build with room to spare: post_n rows of q, post_n rows of outside targets, NJ rows of chain targets)
+    double *t_out = post_lane ? post_lane + a.prm.post_n * post_stride : nullptr;
+    double *t_chain = post_lane ? t_out + a.prm.post_n * post_stride : nullptr;
+    const PostureState ps = post_lane ? PostureState{post_lane, post_stride, true, a.lower, a.upper, valid, t_out, t_chain}
                                       : PostureState{a.layout == LAYOUT_SOA ? a.q_out + b : a.q_out + b * a.nq,
-                                                     a.layout == LAYOUT_SOA ? a.B : 1, false, a.lower, a.upper, valid};
+                                                     a.layout == LAYOUT_SOA ? a.B : 1, false, a.lower, a.upper, valid, nullptr, nullptr};
     if (kPost && a.prm.post_on && valid) {
         for (int k = 0; k < a.prm.post_n; ++k)
             ps.q_lane[(ps.by_row ? k : a.prm.post_q[k]) * ps.stride] = a.q0[at(a.layout, a.B, a.nq, a.prm.post_q[k], b)];
+    }
+    if (kPost && a.prm.post_on && post_lane) {  // every lane (a tail lane shadows the last problem): its own LDS column
+        for (int k = 0; k < a.prm.post_n; ++k) t_out[k * post_stride] = tl[(a.prm.post_slot[k] * 12 + 9) * ts];
+        for (int j = 0; j < NJ; ++j)
+            t_chain[j * post_stride] = a.prm.postc_slot[0][j] >= 0 ? tl[(a.prm.postc_slot[0][j] * 12 + 9) * ts] : 0.0;
     }
     tree_dls<NJ, NCH, SPEC>(d, a.prm, qb, qj0, qj1, tl, ts, a.tslot, ps, iters, success, park, any_active);
     if (kPost && a.prm.post_on && valid && ps.by_row) {

@@ -223,6 +223,8 @@ struct ChainPosture {
     const double *w, *m;    // [NJ]
     const double *targets_lane;
     int64_t tstride;
+    const double *t_chain;  // when not null: the lane's LDS column of the chain rows' target values, row a at t_chain[a * t_stride]
+    int64_t t_stride;
 };
 
 template <int NJ, bool FAST = false, bool POST = false, class PlPtr, class FrPtr, class WPtr>
@@ -333,7 +335,8 @@ IKD_FN void leg_eval_factor(const double (&R1)[9], const double (&p1)[3], PlPtr 
             const int slot = po.slot[a];
             if (slot >= 0) {
                 const double w = po.w[a];
-                const double ea = (q[a] - po.targets_lane[(slot * 12 + 9) * po.tstride]) * po.m[a] * w;
+                const double tgt = po.t_chain ? po.t_chain[a * po.t_stride] : po.targets_lane[(slot * 12 + 9) * po.tstride];
+                const double ea = (q[a] - tgt) * po.m[a] * w;
                 if (po.prio0) e0sq = dfma(ea, ea, e0sq);
                 F.L[tri(a, a)] = dfma(w, w, F.L[tri(a, a)]);
                 F.u[a] = dfma(-w, ea, F.u[a]);  // negated-Jacobian convention: the row's column entry is -w
@@ -479,6 +482,9 @@ struct PostureState {
     bool by_row;
     const double *lower, *upper;
     bool store;         // false for the tail lanes that shadow the last problem
+    // by_row only: the target values of the posture rows, staged in LDS once (outside row k at t_out[k * stride], chain joint a at
+    // t_chain[a * stride]) -- read from the caller's buffer every iteration they cost 4x the launch's algorithmic HBM bytes
+    const double *t_out, *t_chain;
 };
 
 // Posture rows on joints outside the chains (posture builds): each is its own 1x1 system,
@@ -498,7 +504,7 @@ IKD_FN void posture_outside_pass(const TreeParams &prm, const PostureState &ps, 
         for (int u = 0; u < kChunk; ++u) {
             const int k = k0 + u < prm.post_n ? k0 + u : k0;  // a short last chunk re-reads its first row; nothing of the repeats is stored or summed
             qv[u] = ps.q_lane[(ps.by_row ? k : prm.post_q[k]) * ps.stride];
-            tv[u] = targets_lane[(prm.post_slot[k] * 12 + 9) * tstride];
+            tv[u] = ps.t_out ? ps.t_out[k * ps.stride] : targets_lane[(prm.post_slot[k] * 12 + 9) * tstride];
         }
 #pragma unroll
         for (int u = 0; u < kChunk; ++u) {
@@ -588,7 +594,7 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
                 }
             }
             const ChainPosture po{kPost && prm.post_on != 0, prm.post_prio == 0, prm.postc_slot[c], prm.postc_w[c], prm.postc_m[c],
-                                  targets_lane, tstride};
+                                  targets_lane, tstride, (NCH == 1 && ps.by_row) ? ps.t_chain : nullptr, ps.stride};
             leg_eval_factor<NJ, (SPEC >= 0), kPost>(R1, p1, ct.pl, ct.fr, ct.w, SPEC >= 0 ? (SPEC & ((2 << NJ) - 1)) : prm.idmask[c],
                                 SPEC >= 0 ? ((SPEC >> kSpecUnit) & 1) != 0 : prm.unit[c] != 0, q, oMt, prm.lam2, prm.prio[c] == 0, al,
                                 po, Hbb, gb, e0sq, F);

@@ -38,3 +38,10 @@ print("mode %s, %d iterations: loop cycles per wave mean %.0f (min %.0f max %.0f
       "loop time %.2f us (100 MHz ticks) -> clock %.3f GHz; %.3f us per iteration"
       % (mode, iters, cyc.mean(), cyc.min(), cyc.max(), cyc.mean() / iters, cyc.mean() / iters / 4, real.mean() / 100.0,
          cyc.mean() / (real.mean() * 10.0), real.mean() / 100.0 / iters))
+
+ticks = it[:, 1].astype(float) / 100.0
+print("loop time per wave (us): min %.2f p1 %.2f median %.2f p99 %.2f max %.2f" % (ticks.min(), np.percentile(ticks, 1), np.median(ticks), np.percentile(ticks, 99), ticks.max()))
+wg = np.arange(ticks.size)
+print("by XCD (workgroup index mod 8): loop us " + " ".join("%.2f" % ticks[wg % 8 == x].mean() for x in range(8)))
+print("by XCD: loop cycles " + " ".join("%.0f" % cyc[wg % 8 == x].mean() for x in range(8)))
+print("by XCD: end tick - first start (us) " + " ".join("%.2f" % ((t_end[wg % 8 == x].max() - t_start.min()) / 100) for x in range(8)))
