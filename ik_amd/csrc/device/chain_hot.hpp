@@ -88,125 +88,6 @@ IKD_FN void hot_compose(double (&R)[9], double (&p)[3], const Tab &t) {
     }
 }
 
-// log6(fMt) and Jlog6(tMf) sharing one log3 -- log6_and_jlog6_inv (lane_math.hpp; formulas SURVEY.md App. A.3; reference
-// ik/ik/frame.hpp:50-61,162-166) with a front end that costs fewer issue slots:
-//  * acos without a branch: one rational R(z) and ONE square root serve the three ranges of fdlibm's e_acos
-//    (|x| < 1/2: pi/2 - (x + x R(x^2));  x >= 1/2: 2 (s + s R(z));  x <= -1/2: pi - 2 (s + s R(z)),  z = (1 - |x|)/2, s = sqrt z);
-//    the compensated square root (s refined with fma(-s, s, z)) replaces e_acos's split of s into two halves and its division;
-//  * ONE reciprocal instead of three: with h = sin(theta)/2 = sqrt(z (1 - z)), z = (1 - cos theta)/2, r = 1 / (theta h) gives
-//    1/theta = r h and 1/h = r theta, and sin/(1 - cos) = cot(theta/2) = (1 - z)/h, 1/(1 - cos) = (1 - z)/(2 h^2).
-// Four FP64 transcendentals (16 cycles of issue each) instead of seven.  Results differ from the other front end by rounding only.
-IKD_FN void log6_and_jlog6_hot(const double (&Re)[9], const double (&pe)[3], LogAndJlog &o) {
-    constexpr double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17;
-    constexpr double pS0 = 1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01,
-                     pS2 = 2.01212532134862925881e-01, pS3 = -4.00555345006794114027e-02,
-                     pS4 = 7.91534994289814532176e-04, pS5 = 3.47933107596021167570e-05;
-    constexpr double qS1 = -2.40339491173441421878e+00, qS2 = 2.02094576023350569471e+00,
-                     qS3 = -6.88283971605453293030e-01, qS4 = 7.70381505559019352791e-02;
-    const double tr = Re[0] + Re[4] + Re[8];
-    double x = dfma(tr, 0.5, -0.5);
-    x = dmin(1.0, dmax(-1.0, x));  // tr >= 3 -> theta = 0 ; tr <= -1 -> theta = pi
-    // ---- theta = acos(x)
-    const double ax = __builtin_fabs(x);
-    const bool mid = ax < 0.5;
-    const double z = dfma(-0.5, x, 0.5);       // (1 - cos theta)/2 = sin^2(theta/2)
-    const double zc = dfma(0.5, x, 0.5);       // (1 + cos theta)/2 = cos^2(theta/2) = 1 - z
-    const double za = mid ? x * x : dfma(-0.5, ax, 0.5);
-    double pp_ = dfma(za, pS5, pS4);
-    pp_ = dfma(za, pp_, pS3);
-    pp_ = dfma(za, pp_, pS2);
-    pp_ = dfma(za, pp_, pS1);
-    pp_ = dfma(za, pp_, pS0);
-    pp_ = pp_ * za;
-    double qq = dfma(za, qS4, qS3);
-    qq = dfma(za, qq, qS2);
-    qq = dfma(za, qq, qS1);
-    qq = dfma(za, qq, 1.0);
-    const double rr = pp_ * drcp(qq);
-    const double sa = dsqrt(za);
-    const double tl = dfma(sa, rr, sa);        // asin(sqrt(za)) for za <= 1/4
-    const double res_mid = pio2_hi - (x - dfma(-x, rr, pio2_lo));
-    const bool pos = x > 0.0;
-    const double res_out = dfma(pos ? 2.0 : -2.0, tl, pos ? 0.0 : kPi);
-    const double theta = mid ? res_mid : res_out;
-    // ---- the scalars of log3 / log6 / Jlog6
-    const double h = dsqrt(z * zc);            // sin(theta)/2
-    const double r = drcp(dmax(theta * h, 1e-300));
-    const double inv_t = r * h, inv_h = r * theta;
-    const double cot = zc * inv_h;             // sin / (1 - cos)
-    const bool small = theta < kTaylorPrec3;
-    const double t2 = theta * theta;
-    const double inv_t2 = inv_t * inv_t;
-
-    // log3, regular branch:  w = theta / (2 sin theta) * (R - R^T)^vee
-    const double fac = dsel(theta > kTaylorPrec3, 0.25 * (theta * inv_h), 0.5);
-    double w[3] = {fac * (Re[7] - Re[5]), fac * (Re[2] - Re[6]), fac * (Re[3] - Re[1])};
-    // log3, theta >= pi - 1e-2: evaluated only when some lane of the wave is there (wave-uniform, out of line)
-    const bool near_pi = theta >= kPi - 1e-2;
-    if (__builtin_expect(IKD_ANY(near_pi), 0)) {
-        const double cphi = -x;
-        const double beta_pi = t2 * drcp(2.0 * z);
-        const double t0 = (Re[0] + cphi) * beta_pi, t1 = (Re[4] + cphi) * beta_pi, t2v = (Re[8] + cphi) * beta_pi;
-        const double a0 = dsel(Re[7] > Re[5], 1.0, -1.0) * dsel(t0 > 0.0, dsqrt(dmax(t0, 0.0)), 0.0);
-        const double a1 = dsel(Re[2] > Re[6], 1.0, -1.0) * dsel(t1 > 0.0, dsqrt(dmax(t1, 0.0)), 0.0);
-        const double a2 = dsel(Re[3] > Re[1], 1.0, -1.0) * dsel(t2v > 0.0, dsqrt(dmax(t2v, 0.0)), 0.0);
-        w[0] = dsel(near_pi, a0, w[0]);
-        w[1] = dsel(near_pi, a1, w[1]);
-        w[2] = dsel(near_pi, a2, w[2]);
-    }
-
-    // alpha = theta sin / (2 (1 - cos)); the same expression is Jlog3's diagonal term (their Taylor forms differ by t^4/720,
-    // below half an ulp of 1 for theta < 2^-13)
-    const double alpha = dsel(small, 1.0 - t2 * (1.0 / 12.0) - t2 * t2 * (1.0 / 720.0), 0.5 * (theta * cot));
-    const double beta = dsel(small, 1.0 / 12.0 + t2 * (1.0 / 720.0), dfma(-0.5 * inv_t, cot, inv_t2));
-    double wxp[3];
-    cross(w, pe, wxp);
-    const double bwp = beta * dot(w, pe);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        o.e[i] = dfma(alpha, pe[i], dfma(-0.5, wxp[i], bwp * w[i]));
-        o.e[3 + i] = w[i];
-    }
-
-    // Jlog6(tMf), tMf = (Re^T, -Re^T pe): log3 = -w, same theta.
-    const double u[3] = {-w[0], -w[1], -w[2]};
-    double pp[3];
-    rotT_vec(Re, pe, pp);
-    pp[0] = -pp[0]; pp[1] = -pp[1]; pp[2] = -pp[2];
-    const double a3 = beta;
-    const double diag = dsel(small, 0.5 * (2.0 - t2 * (1.0 / 6.0)), 0.5 * (theta * cot));
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) o.A[3 * i + j] = a3 * u[i] * u[j];
-    o.A[0] += diag; o.A[4] += diag; o.A[8] += diag;
-    o.A[1] -= 0.5 * u[2]; o.A[2] += 0.5 * u[1];
-    o.A[3] += 0.5 * u[2]; o.A[5] -= 0.5 * u[0];
-    o.A[6] -= 0.5 * u[1]; o.A[7] += 0.5 * u[0];
-
-    // beta_dot_over_theta = -2/t^4 + (1 + sin/t) / (2 t^2 (1 - cos)),   1 / (2 (1 - cos)) = cot / (4 h) = cot inv_h / 4
-    const double bdot = dsel(small, 1.0 / 360.0,
-                             dfma(-2.0 * inv_t2, inv_t2, dfma(2.0 * h, inv_t, 1.0) * inv_t2 * (0.25 * (cot * inv_h))));
-    const double up = dot(u, pp);
-    const double k1 = bdot * up, k2 = dfma(t2, bdot, 2.0 * beta);
-    const double v3[3] = {dfma(k1, u[0], -(k2 * pp[0])), dfma(k1, u[1], -(k2 * pp[1])), dfma(k1, u[2], -(k2 * pp[2]))};
-    double C[9];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) C[3 * i + j] = dfma(v3[i], u[j], beta * u[i] * pp[j]);
-    const double ub = up * beta;
-    C[0] += ub; C[4] += ub; C[8] += ub;
-    C[1] -= 0.5 * pp[2]; C[2] += 0.5 * pp[1];
-    C[3] += 0.5 * pp[2]; C[5] -= 0.5 * pp[0];
-    C[6] -= 0.5 * pp[1]; C[7] += 0.5 * pp[0];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            o.Bm[3 * i + j] = dfma(C[3 * i], o.A[j], dfma(C[3 * i + 1], o.A[3 + j], C[3 * i + 2] * o.A[6 + j]));
-}
-
 // e (6) and the NEGATED task Jacobian columns at q (see chain_evaluate in chain_solver.hpp: same expressions, KT_FULL,
 // unit weights).  oMt: target placement in the world.
 template <int NJ, class S, class Tab>

@@ -123,7 +123,7 @@ IKD_FN void task_terms(const double (&Rf)[9], const double (&pf)[3], const doubl
     const double dp[3] = {oMt[9] - pf[0], oMt[10] - pf[1], oMt[11] - pf[2]};
     rotT_vec(Rf, dp, pe);
     LogAndJlog lj;
-    log6_and_jlog6_inv(Re, pe, lj);
+    log6_and_jlog6_hot(Re, pe, lj);   // the branch-free, one-reciprocal front end (lane_math.hpp): full body 0.84 -> 0.81 ms
     // K' = +diag(w) Jlog6(tMf): the task Jacobian is carried NEGATED (J' = -J_task); H = J'^T J' is unchanged and
     // the right-hand side becomes g' = J'^T e = -J_task^T e, so the system solved is H dq = g'.
     if (unit) {  // wave-uniform: Full task, all weights exactly 1
