@@ -57,6 +57,11 @@ struct TreeParams {
     int align_prio;          //   its priority level
     double align_w;          //   and its weight
     int fixed_base;          // general builds: the base does not move (a fixed-base model): dq_base is dropped, the base pose stays the world
+    // constraint builds only (SPEC bit kSpecCons, or -1): ONE ik::FrameConstraint (reference ik/ik/frame.hpp:325-449) whose reference
+    // frame is the universe, on a frame at the end of a second chain that carries no task (the pinned stance foot): chain 1 of
+    // the table is that chain, and the step is projected onto the null space of the constraint Jacobian (dls.cpp:26-34,43-53)
+    int cons_on;
+    int cons_type;           // KT_POSITION / KT_ORIENTATION / KT_FULL: the rows of the frame's LOCAL Jacobian that are held
     // posture builds only (SPEC bit kSpecPost, or -1): PostureTask rows (reference ik/ik/posture.hpp:51-68), one per joint,
     // e = (q - target) mask w, J = w in the joint's own tangent column; all on one priority level.  A row on a chain joint
     // adds w^2 to that joint's diagonal of the normal matrix and -w e to its right-hand side; a joint outside the chains is
@@ -465,6 +470,116 @@ IKD_FN void freeflyer_integrate(const double (&qb)[7], const double (&R1)[9], co
     for (int k = 0; k < 4; ++k) out[3 + k] = rq[k] * al;
 }
 
+// The step projected onto the null space of ONE frame constraint (reference ik/ik/dls.cpp:26-34,43-53: dq <- N dq,
+// N = I - pinv(Jc) Jc; constraint Jacobian ik/ik/frame.hpp:413-449 with the universe as reference frame: the frame's LOCAL
+// Jacobian, rows by kinematic type).  The constrained frame ends a chain that carries no task, so before the projection
+// dq is zero on that chain; Jc is supported on the six base columns and the chain's NJ columns, and N is the identity on
+// every other column.  N = I - V^T V with V an orthonormal basis of the row space of Jc -- any basis of that space gives the
+// same projector, so the rows are taken in WORLD coordinates about the frame origin (the local rows are an invertible 3 x 3 /
+// block-diagonal mix of them) and orthogonalised by Gram-Schmidt with every projection applied twice.  A row whose remainder
+// falls below Eigen's rank threshold (epsilon x rows x the largest row norm, as the complete orthogonal decomposition behind
+// the reference's pseudo-inverse) is dropped, per lane, by a select.
+template <int NJ, bool FAST, class PlPtr, class FrPtr>
+IKD_FN void constraint_project(const double (&R1)[9], const double (&p1)[3], PlPtr pl, FrPtr frame_pl, int idmask,
+                               const double (&q)[NJ], int type, double (&dqb)[6], double (&dql)[NJ]) {
+    constexpr int W = 6 + NJ;
+    double zax[NJ][3], org[NJ][3];
+    double R[9], p[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = R1[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p[k] = p1[k];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        se3_compose_const(R, p, pl[j], (idmask >> j) & 1);
+        double s, c;
+        if constexpr (FAST) dsincos_fast(q[j], s, c);
+        else dsincos(q[j], s, c);
+        rot_z_right(R, s, c);
+        zax[j][0] = R[2]; zax[j][1] = R[5]; zax[j][2] = R[8];
+        org[j][0] = p[0]; org[j][1] = p[1]; org[j][2] = p[2];
+    }
+    se3_compose_const(R, p, frame_pl, (idmask >> NJ) & 1);
+    // world rows about the frame origin: rows 0..2 linear velocity, 3..5 angular velocity; columns: base linear 0..2 (body
+    // axes R1 e_c), base angular 3..5, chain joints 6..
+    double V[6][W];
+    const double dp[3] = {p1[0] - p[0], p1[1] - p[1], p1[2] - p[2]};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double rc[3] = {R1[c], R1[3 + c], R1[6 + c]};
+        double pxr[3];
+        cross(dp, rc, pxr);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            V[i][c] = rc[i];
+            V[i][3 + c] = pxr[i];
+            V[3 + i][c] = 0.0;
+            V[3 + i][3 + c] = rc[i];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const double dj[3] = {org[j][0] - p[0], org[j][1] - p[1], org[j][2] - p[2]};
+        double vw[3];
+        cross(dj, zax[j], vw);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            V[i][6 + j] = vw[i];
+            V[3 + i][6 + j] = zax[j][i];
+        }
+    }
+    const bool use_lin = type != KT_ORIENTATION, use_ang = type != KT_POSITION;  // wave-uniform
+    const int rows = (use_lin ? 3 : 0) + (use_ang ? 3 : 0);
+    double maxn2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        if (k < 3 ? use_lin : use_ang) {
+            double n2 = 0.0;
+#pragma unroll
+            for (int c = 0; c < W; ++c) n2 = dfma(V[k][c], V[k][c], n2);
+            maxn2 = dmax(maxn2, n2);
+        }
+    }
+    const double thr = 2.220446049250313e-16 * static_cast<double>(rows);
+    const double thr2 = thr * thr * maxn2;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        if (!(k < 3 ? use_lin : use_ang)) continue;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int i = 0; i < k; ++i) {
+                if (!(i < 3 ? use_lin : use_ang)) continue;
+                double d = 0.0;
+#pragma unroll
+                for (int c = 0; c < W; ++c) d = dfma(V[i][c], V[k][c], d);
+#pragma unroll
+                for (int c = 0; c < W; ++c) V[k][c] = dfma(-d, V[i][c], V[k][c]);
+            }
+        }
+        double n2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < W; ++c) n2 = dfma(V[k][c], V[k][c], n2);
+        const double inv = dsel(n2 > thr2, drsqrt(dmax(n2, 1e-300)), 0.0);
+#pragma unroll
+        for (int c = 0; c < W; ++c) V[k][c] = V[k][c] * inv;
+    }
+    // dq <- dq - V^T (V dq) on the base and chain columns
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        if (!(k < 3 ? use_lin : use_ang)) continue;
+        double d = 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) d = dfma(V[k][c], dqb[c], d);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) d = dfma(V[k][6 + j], dql[j], d);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) dqb[c] = dfma(-d, V[k][c], dqb[c]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) dql[j] = dfma(-d, V[k][6 + j], dql[j]);
+    }
+}
+
 // One full solve.  The chains share ONE copy of the evaluation / factorisation code (a rolled 2-trip
 // loop: the unrolled body of one chain is ~3000 instructions, two inlined copies overflow the
 // instruction cache).  Chain 0's factor (L, W, u) is parked while chain 1 is processed -- `park` stores /
@@ -473,7 +588,7 @@ IKD_FN void freeflyer_integrate(const double (&qb)[7], const double (&R1)[9], co
 // by the chains, bit kSpecUnit: the chain tasks are Full with unit weights, bit kSpecUnitP / kSpecIdP: the base task is
 // Full with unit weights / its frame placement is a pure translation.  SPEC = -1: runtime (wave-uniform) values.
 // Bit kSpecPost (alone: otherwise a general build): the posture code above is compiled in.
-constexpr int kSpecUnitP = 29, kSpecIdP = 28, kSpecPost = 26;
+constexpr int kSpecUnitP = 29, kSpecIdP = 28, kSpecPost = 26, kSpecCons = 25;
 
 // Where the lane keeps the joints outside the chains that carry a posture row: its own column of the caller's q_out.
 struct PostureState {
@@ -530,8 +645,9 @@ template <int NJ, int NCH, int SPEC = -1, class Desc, class Park, class AnyFn>
 IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], double (&qj0)[NJ], double (&qj1)[NJ],
                      const double *targets_lane, int64_t tstride, const int (&tslot)[3], const PostureState &ps, int &iters_out,
                      bool &success_out, Park park, AnyFn any_active) {
-    constexpr bool kGeneral = SPEC <= 0 || SPEC == (1 << kSpecPost);  // the demo's extras exist in the general builds only
+    constexpr bool kGeneral = SPEC <= 0 || SPEC == (1 << kSpecPost) || SPEC == (1 << kSpecCons);  // the demo's extras exist in the general builds only
     constexpr bool kPost = SPEC < 0 || SPEC == (1 << kSpecPost);
+    constexpr bool kCons = NCH > 1 && (SPEC < 0 || SPEC == (1 << kSpecCons));
     // (posture builds: a tail lane shadowing the last problem would re-read that problem's outside joints while their owner
     // updates them -- it sits the loop out instead; nothing of it is stored anyway)
     bool active = kPost ? ps.store : true, success = false;
@@ -557,8 +673,10 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
             gb[i] = 0.0;
         }
         LegFactor<NJ> F;
+        // (constraint builds: chain 1 carries the constrained frame and no task -- it is walked after the solve)
+        const int ntask_chains = (kCons && prm.cons_on) ? 1 : NCH;
 #pragma unroll 1
-        for (int c = 0; c < NCH; ++c) {
+        for (int c = 0; c < ntask_chains; ++c) {
             const auto &ct = d.chain[c];
             double q[NJ], oMt[12], R1[9];
             quat_to_R(qb, R1);
@@ -598,7 +716,7 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
             leg_eval_factor<NJ, (SPEC >= 0), kPost>(R1, p1, ct.pl, ct.fr, ct.w, SPEC >= 0 ? (SPEC & ((2 << NJ) - 1)) : prm.idmask[c],
                                 SPEC >= 0 ? ((SPEC >> kSpecUnit) & 1) != 0 : prm.unit[c] != 0, q, oMt, prm.lam2, prm.prio[c] == 0, al,
                                 po, Hbb, gb, e0sq, F);
-            if (NCH > 1 && c == 0) park.store(F);
+            if (NCH > 1 && c == 0 && ntask_chains > 1) park.store(F);
         }
         if (prm.hasP) {
             double oMt[12];
@@ -639,9 +757,9 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
         active = active && !stop_now;
 
 #pragma unroll 1
-        for (int c = NCH - 1; c >= 0; --c) {
+        for (int c = ntask_chains - 1; c >= 0; --c) {
             const auto &ct = d.chain[c];
-            if (NCH > 1 && c == 0) park.load(F);
+            if (NCH > 1 && c == 0 && ntask_chains > 1) park.load(F);
             double dql[NJ];
             leg_back_substitute<NJ>(F, dqb, dql);
 #pragma unroll
@@ -653,6 +771,21 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
                 // number `c` would be demoted from registers to scratch memory
                 qj1[j] = (NCH > 1 && c == 1) ? qn : qj1[j];
                 qj0[j] = (NCH > 1 && c == 1) ? qj0[j] : qn;
+            }
+        }
+        if (kCons && prm.cons_on) {
+            // the constrained chain: no task moves it, so dq is zero there before the projection N = I - pinv(Jc) Jc, which
+            // touches the base columns and this chain's only
+            double R1[9], dq1[NJ];
+            quat_to_R(qb, R1);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) dq1[j] = 0.0;
+            const auto &cc = d.chain[NCH - 1];
+            constraint_project<NJ, (SPEC >= 0)>(R1, p1, cc.pl, cc.fr, prm.idmask[NCH - 1], qj1, prm.cons_type, dqb, dq1);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const double qc = dmin(cc.hi[j], dmax(dfma(prm.step_length, dq1[j], qj1[j]), cc.lo[j]));
+                qj1[j] = active ? qc : qj1[j];
             }
         }
         if (!fixed) {

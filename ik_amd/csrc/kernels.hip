@@ -298,6 +298,7 @@ TreeKernelArgs<NJ, NCH> make_tree_args(const ProblemHost &ph, const DeviceTables
     a.prm.align_prio = h.align_prio; a.prm.align_w = h.align_w;
     static_assert(ikdev::kMaxPostOut == kMaxPostureOut && kMaxChain == 8, "TreeParams posture arrays");
     a.prm.fixed_base = h.fixed_base;
+    a.prm.cons_on = h.cons_on; a.prm.cons_type = h.cons_type;
     a.prm.post_on = h.post_on; a.prm.post_prio = h.post_prio; a.prm.post_n = h.post_n;
     for (int k = 0; k < h.post_n; ++k) {
         a.prm.post_q[k] = h.post_q[k]; a.prm.post_slot[k] = h.post_slot[k]; a.prm.post_w[k] = h.post_w[k]; a.prm.post_m[k] = h.post_m[k];
@@ -332,7 +333,10 @@ hipError_t run_dls_tree(const ProblemHost &ph, const DeviceTables &dt, const Bat
     const bool mask_only = !hot && !ph.tree_extras() && kMask != 0 && (a.prm.idmask[0] & kMask) == kMask && (NCH == 1 || (a.prm.idmask[1] & kMask) == kMask);
     if (hot) hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, kHot>), grid, dim3(kTreeBlock), 0, stream, a);
     else if (mask_only) hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, (kMask != 0 ? kMask : kHot)>), grid, dim3(kTreeBlock), 0, stream, a);
-    else if (ph.has_posture)
+    else if (ph.cons_on) {   // one FrameConstraint on the second chain: the constraint build (general + the projection)
+        if constexpr (NCH == 2) hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, (1 << ikdev::kSpecCons)>), grid, dim3(kTreeBlock), 0, stream, a);
+        else return hipErrorInvalidValue;
+    } else if (ph.has_posture)
         hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, (1 << ikdev::kSpecPost)>), grid, dim3(kTreeBlock),
                            NCH == 1 ? sizeof(double) * kTreeBlock * static_cast<size_t>(2 * std::max(1, a.prm.post_n) + NJ) : 0, stream, a);
     else hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, 0>), grid, dim3(kTreeBlock), 0, stream, a);

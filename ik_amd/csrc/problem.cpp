@@ -108,6 +108,7 @@ void specialise(ProblemHost &ph, const Model &m) {
         return build_chain(m, joints, frame, task_index, in_chain);
     };
 
+    if (!ph.constraints.empty() && !free_flyer) throw Unsupported("a constraint on a fixed-base model runs on the generic kernel");
     if (!free_flyer && ntasks == 1 && ph.tasks[0].type <= IKGPU_FULL) {
         const ikgpu_task &t = ph.tasks[0];
         if (m.frame_parent[t.reference] != 0) throw Unsupported("reference frame moves with the configuration");
@@ -166,6 +167,22 @@ void specialise(ProblemHost &ph, const Model &m) {
         ph.align_chain = c;
     }
     if (nchains == 0) throw Unsupported("free-flyer problem without a chain task");
+    if (!ph.constraints.empty()) {
+        // ONE FrameConstraint, reference frame = the universe, on a frame that ends a chain off the floating base which no task
+        // touches (the pinned stance foot of a humanoid): that chain becomes chain B with no task
+        const ikgpu_task &c = ph.constraints[0];
+        if (ph.constraints.size() != 1) throw Unsupported("more than one constraint");
+        if (nchains != 1) throw Unsupported("a constraint next to two chain tasks");
+        if (m.frame_parent[c.reference] != 0 || !is_identity(m.frame_placement[c.reference]))
+            throw Unsupported("constraint with a reference frame other than the universe");
+        std::vector<int> joints;
+        for (int j = m.frame_parent[c.frame]; j > root; j = m.joint_parent[j]) joints.insert(joints.begin(), j);
+        if (joints.empty()) throw Unsupported("constraint on the floating base link");
+        ph.chainB = chain_of(joints, c.frame, -1);   // throws when it shares a joint with the task chain
+        if (ph.chainB.nj != ph.chain.nj) throw Unsupported("the constrained chain and the task chain differ in length");
+        ph.cons_on = true;
+        ph.cons_type = c.type;
+    }
     if (nchains == 2 && ph.chain.nj != ph.chainB.nj) throw Unsupported("the two chains differ in length");
     // PostureTask rows (frame = tangent column, reference = index in q, weight[0] = weight, weight[1] = mask entry)
     for (int c = 0; c < 2; ++c)
@@ -174,6 +191,7 @@ void specialise(ProblemHost &ph, const Model &m) {
     for (int i = 0; i < ntasks; ++i) {
         const ikgpu_task &t = ph.tasks[i];
         if (t.type != IKGPU_POSTURE_ROW) continue;
+        if (ph.cons_on) throw Unsupported("posture rows next to a constraint");
         if (ph.has_posture && t.priority != ph.posture_prio) throw Unsupported("posture rows on different priority levels");
         ph.has_posture = true;
         ph.posture_prio = t.priority;
@@ -201,7 +219,8 @@ void specialise(ProblemHost &ph, const Model &m) {
     ph.kind = KernelKind::Tree;
     ph.kernel_name = "dls_tree<NJ=" + std::to_string(ph.chain.nj) + ",chains=" + std::to_string(nchains) +
                      (ph.base_task >= 0 ? ",base_task" : "") + (ph.ref_base[0] || ph.ref_base[1] ? ",base_reference" : "") +
-                     (ph.align_task >= 0 ? ",align_axis" : "") + (ph.has_posture ? ",posture" : "") + (ph.fixed_base ? ",fixed_base" : "") + ">";
+                     (ph.align_task >= 0 ? ",align_axis" : "") + (ph.has_posture ? ",posture" : "") + (ph.fixed_base ? ",fixed_base" : "") +
+                     (ph.cons_on ? ",constraint_rows=" + std::to_string(ph.crows) : std::string()) + ">";
     ph.q_in_chain = in_chain;
 }
 
@@ -431,7 +450,7 @@ ProblemHost analyse_problem(const Model &m, const ikgpu_task *tasks, int ntasks,
         ph.constraints.push_back(c);
         ph.crows += task_dim(c);
     }
-    if (nconstraints > 0) force_generic = true;
+    if (nconstraints > 1) force_generic = true;   // one constraint may fit the tree kernel (specialise() decides), more run on the generic kernel
     ph.nq = m.nq;
     ph.nv = m.nv;
     ph.ntasks = ntasks;
@@ -492,7 +511,8 @@ std::vector<double> tree_desc_table(const ProblemHost &ph) {
         t.insert(t.end(), c.frame_pl, c.frame_pl + 12);
         t.insert(t.end(), c.lo, c.lo + c.nj);
         t.insert(t.end(), c.hi, c.hi + c.nj);
-        weights6(ph.tasks[c.task], w6);
+        for (double &x : w6) x = 0.0;
+        if (c.task >= 0) weights6(ph.tasks[c.task], w6);   // (the constrained chain of a constraint build carries no task)
         t.insert(t.end(), w6, w6 + 6);
     };
     put_chain(ph.chain);
@@ -613,6 +633,8 @@ TreeArgsHost tree_args(const ProblemHost &ph) {
         a.align_w = t.weight[0];
     }
     a.fixed_base = ph.fixed_base ? 1 : 0;
+    a.cons_on = ph.cons_on ? 1 : 0;
+    a.cons_type = ph.cons_type;
     a.post_on = ph.has_posture ? 1 : 0;
     a.post_prio = ph.posture_prio;
     a.post_n = static_cast<int>(ph.posture_out.size());

@@ -83,7 +83,11 @@ struct ProblemHost {
     // ... or a FIXED base: the same kernel with the base block solved and dropped (dq_base = 0, base pose = the world), for
     // fixed-base problems with two disjoint chain tasks or with alignment / posture rows next to one chain task
     bool fixed_base = false;
-    bool tree_extras() const { return ref_base[0] || ref_base[1] || align_task >= 0 || has_posture || fixed_base; }
+    // ... or ONE FrameConstraint with the universe as reference frame on a frame that ends a second chain carrying no task (the
+    // pinned stance foot): chainB is that chain (task = -1), the tree kernel projects the step onto the constraint's null space
+    bool cons_on = false;
+    int cons_type = 0;
+    bool tree_extras() const { return ref_base[0] || ref_base[1] || align_task >= 0 || has_posture || fixed_base || cons_on; }
     GenericHost generic;              // Generic kind
     std::vector<ikgpu_task> constraints;  // ik::FrameConstraint list (frame, reference, type); forces the Generic kind
     int crows = 0;
@@ -132,6 +136,7 @@ struct TreeArgsHost {
     double align_w;
     // PostureTask rows (device/tree_solver.hpp: TreeParams::post_*)
     int fixed_base;
+    int cons_on, cons_type;
     int post_on, post_prio, post_n;
     int post_q[kMaxPostureOut], post_slot[kMaxPostureOut];
     double post_w[kMaxPostureOut], post_m[kMaxPostureOut];

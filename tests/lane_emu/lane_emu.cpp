@@ -133,6 +133,7 @@ void run_tree(const ikgpu::ProblemHost &ph, const IO &io) {
     a.prm.align_chain = h.align_chain; a.prm.align_axis = h.align_axis; a.prm.align_slot = h.align_slot;
     a.prm.align_prio = h.align_prio; a.prm.align_w = h.align_w;
     a.prm.fixed_base = h.fixed_base;
+    a.prm.cons_on = h.cons_on; a.prm.cons_type = h.cons_type;
     a.prm.post_on = h.post_on; a.prm.post_prio = h.post_prio; a.prm.post_n = h.post_n;
     for (int k = 0; k < h.post_n; ++k) {
         a.prm.post_q[k] = h.post_q[k]; a.prm.post_slot[k] = h.post_slot[k]; a.prm.post_w[k] = h.post_w[k]; a.prm.post_m[k] = h.post_m[k];
@@ -319,8 +320,17 @@ int lane_emu_dls_constrained(const char *urdf, size_t len, int root_joint, const
                              uint8_t *success, int32_t *iters, int layout) {
     try {
         ikgpu::Model m = ikgpu::Model::from_urdf(urdf, len, (root_joint & 1) != 0);
-        const ikgpu::ProblemHost ph = ikgpu::analyse_problem(m, tasks, ntasks, /*force_generic=*/true, cons, ncons);
+        // root_joint bit 2: let the analysis pick the tree kernel's constraint build when the problem has that shape
+        const ikgpu::ProblemHost ph = ikgpu::analyse_problem(m, tasks, ntasks, /*force_generic=*/(root_joint & 4) == 0, cons, ncons);
         const IO io{0, B, q0, targets, prm, q_out, success, iters, nullptr, nullptr, nullptr, layout};
+        if (ph.kind == ikgpu::KernelKind::Tree) {
+            const int nj = ph.chain.nj, nch = ph.chainB.nj > 0 ? 2 : 1;
+            if (nj == 7 && nch == 2) { run_tree<7, 2>(ph, io); return 0; }
+            if (nj == 6 && nch == 2) { run_tree<6, 2>(ph, io); return 0; }
+            g_err = "constraint tree shape not instantiated in the lane emulator: " + ph.kernel_name;
+            return 1;
+        }
+        if ((root_joint & 4) != 0) { g_err = "the problem did not map onto the tree kernel: " + ph.kernel_name; return 1; }
         run_generic(ph, io);
         return 0;
     } catch (const std::exception &e) {

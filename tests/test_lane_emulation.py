@@ -21,7 +21,7 @@ def emu(native_built):
     deps = [src] + [os.path.join(ROOT, "ik_amd", "csrc", f) for f in
                     ("model.cpp", "problem.cpp", "model.hpp", "problem.hpp", "device/lane_math.hpp",
                      "device/chain_solver.hpp", "device/chain_kernel_body.hpp", "device/chain_hot.hpp", "device/tree_solver.hpp",
-                     "device/tree_kernel_body.hpp", "device/generic_solver.hpp", "device/pik_solver.hpp", "device/coop_solver.hpp", "device/pik_coop.hpp", "generic_tables.hpp")]
+                     "device/tree_kernel_body.hpp", "device/lane_math.hpp", "device/generic_solver.hpp", "device/pik_solver.hpp", "device/coop_solver.hpp", "device/pik_coop.hpp", "generic_tables.hpp")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
                                "-I" + os.path.join(ROOT, "ik_amd", "csrc"), "-o", out, src,
@@ -493,6 +493,41 @@ CONSTRAINT_CASES = {
     "relative_orientation_between_feet": ("cassie_fixed", False, [("LeftFootFront", "universe", 2, 0, None)],
                                           [("RightFootFront", "LeftFootBack", 1)]),
 }
+
+
+@pytest.mark.parametrize("ctype", [0, 1, 2])
+@pytest.mark.parametrize("with_align", [False, True])
+def test_constraint_build_of_the_tree_program(emu, ctype, with_align):
+    """One FrameConstraint (Position / Orientation / Full, reference = the universe) on the foot of the leg that carries no task
+    -- the pinned stance foot -- next to the demo's tasks: the tree kernel's constraint build (device/tree_solver.hpp
+    constraint_project: world rows of the constraint Jacobian on base + chain columns, Gram-Schmidt applied twice, dq -= V^T V dq)
+    against the oracle's dense N = I - pinv(Jc) Jc (reference ik/ik/dls.cpp:26-34,43-53)."""
+    from ik_amd import capi
+    specs = [("LeftFootFront", "pelvis", 0, 0, None), ("pelvis", "universe", 2, 0, None)]
+    if with_align:
+        specs.append(("LeftFootFront", "universe", 4, 0, None))        # AlignAxisTask, frame Y axis
+    B = 24
+    urdf, model, om, tasks, ot, q0, tg, M = _generic_case("cassie", True, specs, B, seed=13)
+    cons = (capi.Task * 1)(capi.Task(model.getFrameId("RightFootFront"), 0, ctype, 0, (C.c_double * 6)(*[1.0] * 6)))
+    oc = O.make_tasks([(model.getFrameId("RightFootFront"), 0, ctype, 0, None)])
+    buf = C.create_string_buffer(200)
+    rc = capi.lib().ikgpu_problem_plan_constrained(ik_amd_model_handle(model), tasks, len(tasks), cons, 1, buf, len(buf))
+    assert rc == 0 and buf.value.decode().startswith("dls_tree<NJ=7,chains=1") and "constraint_rows=%d" % (6 if ctype == 2 else 3) in buf.value.decode(), buf.value
+    p = lambda a: C.c_void_p(a.ctypes.data)
+    for iters, damping, step, tol in ((1, 1e-2, 1.0, -1.0), (5, 1e-2, 1.0, -1.0), (40, 1e-1, 0.5, 1e-7), (100, 1e-1, 1e-1, 1e-4)):
+        qo = np.empty_like(q0)
+        ok, it = np.zeros(B, np.uint8), np.zeros(B, np.int32)
+        prm = capi.DlsParams(iters, damping, step, tol)
+        rc = emu.lane_emu_dls_constrained(urdf, C.c_size_t(len(urdf)), 1 | 4, tasks, len(tasks), cons, 1, C.c_int64(B),
+                                          p(q0), p(tg), C.byref(prm), p(qo), p(ok), p(it), 1)
+        assert rc == 0, emu.lane_emu_last_error()
+        q_ref, ok_ref, it_ref = O.dls_batch_constrained(om, ot, oc, tg, q0, O.params(iters, damping, step, tol))
+        assert np.array_equal(ok, ok_ref) and np.array_equal(it, it_ref), (ctype, iters)
+        assert np.abs(qo - q_ref).max() < 1e-8, (ctype, iters, np.abs(qo - q_ref).max())
+
+
+def ik_amd_model_handle(model):
+    return model._h
 
 
 @pytest.mark.parametrize("case", sorted(CONSTRAINT_CASES))
