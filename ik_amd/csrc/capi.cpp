@@ -33,6 +33,7 @@ struct ikgpu_problem {
     int device = 0;
     int nframes = 0;
     std::string pik_name;    // name of the generic PIK kernel instance
+    std::string pik_tree_name;  // ... and of the tree kernel running a two-level ik::pik (when the problem has that shape)
 };
 
 namespace {
@@ -127,6 +128,17 @@ bool pik_is_one_dls_level(const ikgpu_problem *p, const ikgpu_pik_params *prm) {
     const char *force = std::getenv("IKGPU_PIK_KERNEL");
     if (force && std::strcmp(force, "generic") == 0) return false;
     return p->gen.generic.nlevels == 1 && !prm->da && prm->lambda[0] > 0.0 && p->host.constraints.empty();
+}
+
+// ik::pik with TWO levels in the shape the tree kernel takes (kernels.hpp tree_takes_two_level_pik: level 0 = the frame tasks with a
+// Full task on the base link, level 1 = the AlignAxisTask row -- the reference demo's task set split over two levels): level 0 is
+// the tree kernel's arrow solve with damping lambda[0], level 1 a rank-one correction on the chain's joints (device/tree_solver.hpp
+// PikRow).  No secondary velocity, lambda > 0 on both levels.
+bool pik_is_two_levels_on_the_tree(const ikgpu_problem *p, const ikgpu_pik_params *prm) {
+    const char *force = std::getenv("IKGPU_PIK_KERNEL");
+    if (force && std::strcmp(force, "generic") == 0) return false;
+    return p->gen.generic.nlevels == 2 && prm->num_levels == 2 && !prm->da && prm->lambda[0] > 0.0 && prm->lambda[1] > 0.0 &&
+           p->host.constraints.empty() && ikgpu::tree_takes_two_level_pik(p->host);
 }
 
 // Host-pointer form of a batched solve: copy in, run `launch` on device buffers, synchronise, copy out.
@@ -318,6 +330,7 @@ int ikgpu_problem_create_constrained(const ikgpu_model *h, const ikgpu_task *tas
         p->host = std::move(ph);
         p->gen = std::move(gen);
         p->pik_name = "pik_generic" + p->gen.kernel_name.substr(std::min(p->gen.kernel_name.find('<'), p->gen.kernel_name.size()));
+        p->pik_tree_name = p->host.kernel_name.substr(0, p->host.kernel_name.size() - (p->host.kernel_name.empty() ? 0 : 1)) + ",pik_levels=2>";
         p->device = device;
         p->nframes = h->m.nframes();
         const size_t nq = static_cast<size_t>(p->host.nq);
@@ -438,7 +451,8 @@ void ikgpu_pik_params_default(ikgpu_pik_params *p, int32_t num_levels) {
 
 const char *ikgpu_pik_kernel(const ikgpu_problem *p, const ikgpu_pik_params *params) {
     if (!p || !params) return "";
-    return pik_is_one_dls_level(p, params) ? p->host.kernel_name.c_str() : p->pik_name.c_str();
+    if (pik_is_one_dls_level(p, params)) return p->host.kernel_name.c_str();
+    return pik_is_two_levels_on_the_tree(p, params) ? p->pik_tree_name.c_str() : p->pik_name.c_str();
 }
 
 int ikgpu_pik_solve_batch(const ikgpu_problem *p, int64_t B, const double *q0, const double *targets,
@@ -454,6 +468,17 @@ int ikgpu_pik_solve_batch(const ikgpu_problem *p, int64_t B, const double *q0, c
     if (pik_is_one_dls_level(p, params)) {
         const ikgpu_dls_params d{params->max_iterations, params->lambda[0], params->step_length, params->stop_sq_tol};
         return ikgpu_dls_solve_batch(p, B, q0, targets, &d, q_out, success, iters, layout, stream);
+    }
+    if (pik_is_two_levels_on_the_tree(p, params)) {
+        return guarded([&] {
+            DeviceGuard g(p->device);
+            if (!g.ok) return fail(IKGPU_ERR_DEVICE, "hipSetDevice failed");
+            ikgpu::BatchIO io{B, q0, targets, q_out, success, iters, layout};
+            const ikgpu_dls_params d{params->max_iterations, params->lambda[0], params->step_length, params->stop_sq_tol};
+            const hipError_t e = ikgpu::launch_dls_tree(p->host, p->dev, io, d, static_cast<hipStream_t>(stream), &params->lambda[1]);
+            if (e != hipSuccess) return hip_fail(e, "launching the tree kernel (two-level ik::pik)");
+            return static_cast<int>(IKGPU_OK);
+        });
     }
     return guarded([&] {
         DeviceGuard g(p->device);

@@ -62,6 +62,11 @@ struct TreeParams {
     // the table is that chain, and the step is projected onto the null space of the constraint Jacobian (dls.cpp:26-34,43-53)
     int cons_on;
     int cons_type;           // KT_POSITION / KT_ORIENTATION / KT_FULL: the rows of the frame's LOCAL Jacobian that are held
+    // general builds: ik::pik with TWO priority levels in the one shape the tree structure makes cheap (reference
+    // ik/ik/pik.cpp:47-61) -- level 0: the frame tasks, among them a Full task on the base link; level 1: the AlignAxisTask row.
+    // lam2 is then lambda[0]^2 and pik_lam2_1 = lambda[1]^2.  See PikRow.
+    int pik_on;
+    double pik_lam2_1;
     // posture builds only (SPEC bit kSpecPost, or -1): PostureTask rows (reference ik/ik/posture.hpp:51-68), one per joint,
     // e = (q - target) mask w, J = w in the joint's own tangent column; all on one priority level.  A row on a chain joint
     // adds w^2 to that joint's diagonal of the normal matrix and -w e to its right-hand side; a joint outside the chains is
@@ -83,6 +88,19 @@ struct AlignRow {
     int ax;
     double w, tn[3];
     bool prio0;
+    bool pik;   // the row is level 1 of ik::pik: it stays out of the level-0 system, leg_eval_factor returns a PikRow instead
+};
+
+// Level 1 of the two-level ik::pik the tree kernel takes (reference ik/ik/pik.cpp:47-61).  Level 0 holds a Full task on the
+// base link whose 6 x 6 block is invertible, so the row space of J_0 is (all six base directions) + (the row space of the
+// chain task's chain columns C): the projector after level 0 is P = diag(0_6, I - V^T V, I) with V an orthonormal basis of
+// rowspace(C).  The level-1 row is the AlignAxisTask row j = [0 | b (base angular) | a (chain)], so Jbar = j P = [0 | 0 | abar],
+// abar = a - V^T V a, its damped pseudo-inverse is Jbar^T / (|abar|^2 + lambda_1^2), and the level's step changes the chain's
+// joints only:  dq_chain -= abar (e_1 - j dq_0) / (|abar|^2 + lambda_1^2).  Negated-Jacobian convention: a, b hold -j.
+template <int NJ>
+struct PikRow {
+    bool on;
+    double a[NJ], abar[NJ], b[3], e;
 };
 
 // Packed lower-triangular index
@@ -236,7 +254,7 @@ template <int NJ, bool FAST = false, bool POST = false, class PlPtr, class FrPtr
 IKD_FN void leg_eval_factor(const double (&R1)[9], const double (&p1)[3], PlPtr pl, FrPtr frame_pl,
                             WPtr w6, int idmask, bool unit, const double (&q)[NJ], const double (&oMt)[12],
                             double lam2, bool prio0, const AlignRow &al, const ChainPosture &po, double (&Hbb)[21],
-                            double (&gb)[6], double &e0sq, LegFactor<NJ> &F) {
+                            double (&gb)[6], double &e0sq, LegFactor<NJ> &F, PikRow<NJ> &pr) {
     double zax[NJ][3], org[NJ][3];
     double R[9], p[3];
 #pragma unroll
@@ -319,6 +337,65 @@ IKD_FN void leg_eval_factor(const double (&R1)[9], const double (&p1)[3], PlPtr 
             const double rc[3] = {R1[c], R1[3 + c], R1[6 + c]};
             ab[c] = al.w * dot(rxt, rc);
         }
+        if (al.pik) {   // level 1 of ik::pik (wave-uniform): the row stays out of the level-0 system, see PikRow
+            // orthonormal basis of the row space of the chain task's chain columns (rows with weight zero -- a Position /
+            // Orientation task -- are skipped, wave-uniform), Gram-Schmidt with every projection applied twice, rank rule as in
+            // constraint_project; then abar = a - V^T V a, twice
+            double V[6][NJ];
+            double maxn2 = 0.0;
+            int rows = 0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                if (w6[r] == 0.0) continue;
+                ++rows;
+                double n2 = 0.0;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) { V[r][j] = col[j][r]; n2 = dfma(V[r][j], V[r][j], n2); }
+                maxn2 = dmax(maxn2, n2);
+            }
+            const double thr = 2.220446049250313e-16 * static_cast<double>(rows < NJ ? rows : NJ);
+            const double thr2 = thr * thr * maxn2;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                if (w6[k] == 0.0) continue;
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+                    for (int i = 0; i < k; ++i) {
+                        if (w6[i] == 0.0) continue;
+                        double d = 0.0;
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) d = dfma(V[i][j], V[k][j], d);
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) V[k][j] = dfma(-d, V[i][j], V[k][j]);
+                    }
+                }
+                double n2 = 0.0;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) n2 = dfma(V[k][j], V[k][j], n2);
+                const double inv = dsel(n2 > thr2, drsqrt(dmax(n2, 1e-300)), 0.0);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) V[k][j] = V[k][j] * inv;
+            }
+            pr.on = true;
+            pr.e = ea;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) pr.b[c] = ab[c];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) { pr.a[j] = aj[j]; pr.abar[j] = aj[j]; }
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    if (w6[k] == 0.0) continue;
+                    double d = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) d = dfma(V[k][j], pr.abar[j], d);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) pr.abar[j] = dfma(-d, V[k][j], pr.abar[j]);
+                }
+            }
+        } else {
 #pragma unroll
         for (int a = 0; a < NJ; ++a) {
 #pragma unroll
@@ -332,6 +409,7 @@ IKD_FN void leg_eval_factor(const double (&R1)[9], const double (&p1)[3], PlPtr 
 #pragma unroll
             for (int b = 0; b <= a; ++b) Hbb[tri(3 + a, 3 + b)] = dfma(ab[a], ab[b], Hbb[tri(3 + a, 3 + b)]);
             gb[3 + a] = dfma(ab[a], ea, gb[3 + a]);
+        }
         }
     }
     if (POST && po.on) {  // posture rows on this chain's joints (wave-uniform; posture builds only)
@@ -673,6 +751,8 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
             gb[i] = 0.0;
         }
         LegFactor<NJ> F;
+        PikRow<NJ> pr;
+        pr.on = false;
         // (constraint builds: chain 1 carries the constrained frame and no task -- it is walked after the solve)
         const int ntask_chains = (kCons && prm.cons_on) ? 1 : NCH;
 #pragma unroll 1
@@ -684,7 +764,7 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
             for (int j = 0; j < NJ; ++j) q[j] = (NCH > 1 && c == 1) ? qj1[j] : qj0[j];
 #pragma unroll
             for (int k = 0; k < 12; ++k) oMt[k] = targets_lane[(tslot[c] * 12 + k) * tstride];
-            AlignRow al{false, 0, 0.0, {0.0, 0.0, 0.0}, false};
+            AlignRow al{false, 0, 0.0, {0.0, 0.0, 0.0}, false, false};
             if (kGeneral) {  // the demo's extras exist in the general builds only (SPEC = 0 [+ posture] on the device, -1 = all runtime
                               // in the emulator); hot builds compile none of this
                 if (prm.ref_base[c]) {  // target given in a frame on the floating base: oMt = (oM1 * refpl) * target (frame.hpp:48)
@@ -708,6 +788,7 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
                                  tz = targets_lane[(prm.align_slot * 12 + 11) * tstride];
                     const double inv = drsqrt(dfma(tx, tx, dfma(ty, ty, tz * tz)));
                     al.on = true; al.ax = prm.align_axis; al.w = prm.align_w; al.prio0 = prm.align_prio == 0;
+                    al.pik = prm.pik_on != 0;
                     al.tn[0] = tx * inv; al.tn[1] = ty * inv; al.tn[2] = tz * inv;
                 }
             }
@@ -715,7 +796,7 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
                                   targets_lane, tstride, (NCH == 1 && ps.by_row) ? ps.t_chain : nullptr, ps.stride};
             leg_eval_factor<NJ, (SPEC >= 0), kPost>(R1, p1, ct.pl, ct.fr, ct.w, SPEC >= 0 ? (SPEC & ((2 << NJ) - 1)) : prm.idmask[c],
                                 SPEC >= 0 ? ((SPEC >> kSpecUnit) & 1) != 0 : prm.unit[c] != 0, q, oMt, prm.lam2, prm.prio[c] == 0, al,
-                                po, Hbb, gb, e0sq, F);
+                                po, Hbb, gb, e0sq, F, pr);
             if (NCH > 1 && c == 0 && ntask_chains > 1) park.store(F);
         }
         if (prm.hasP) {
@@ -762,6 +843,18 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
             if (NCH > 1 && c == 0 && ntask_chains > 1) park.load(F);
             double dql[NJ];
             leg_back_substitute<NJ>(F, dqb, dql);
+            if (kGeneral && prm.pik_on && pr.on && c == prm.align_chain) {   // level 1 of ik::pik, see PikRow (wave-uniform)
+                // negated convention: a, b, abar hold -j, so  e_1 - j dq_0 = e + a . dq_chain + b . dq_base_angular  and
+                // dq_chain -= (-abar) (...) / (|abar|^2 + lambda_1^2)
+                double de = pr.e, n2 = prm.pik_lam2_1;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) de = dfma(pr.b[k], dqb[3 + k], de);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) { de = dfma(pr.a[j], dql[j], de); n2 = dfma(pr.abar[j], pr.abar[j], n2); }
+                const double sc = de * drcp(n2);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) dql[j] = dfma(pr.abar[j], sc, dql[j]);
+            }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const double qold = (NCH > 1 && c == 1) ? qj1[j] : qj0[j];

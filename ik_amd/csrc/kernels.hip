@@ -313,12 +313,13 @@ TreeKernelArgs<NJ, NCH> make_tree_args(const ProblemHost &ph, const DeviceTables
 
 template <int NJ, int NCH>
 hipError_t run_dls_tree(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const ikgpu_dls_params &prm,
-                        hipStream_t stream) {
+                        hipStream_t stream, const double *pik_lambda1) {
     TreeKernelArgs<NJ, NCH> a = make_tree_args<NJ, NCH>(ph, dt);
     a.prm.max_iterations = prm.max_iterations;
     a.prm.lam2 = prm.damping * prm.damping;
     a.prm.step_length = prm.step_length;
     a.prm.stop_sq_tol = prm.stop_sq_tol;
+    if (pik_lambda1) { a.prm.pik_on = 1; a.prm.pik_lam2_1 = *pik_lambda1 * *pik_lambda1; }
     a.layout = io.layout; a.B = io.B; a.q0 = io.q0; a.targets = io.targets;
     a.q_out = io.q_out; a.success = io.success; a.iters = io.iters;
     // hot build: both chains carry the shape's known placement mask, every task is Full with unit weights and the base
@@ -365,10 +366,21 @@ bool tree_shape_built(int nj, int nch) {
     return false;
 }
 
+bool tree_takes_two_level_pik(const ProblemHost &ph) {
+    if (ph.kind != KernelKind::Tree || ph.align_task < 0 || ph.base_task < 0 || ph.has_posture || ph.fixed_base || ph.cons_on) return false;
+    const ikgpu_task &base = ph.tasks[ph.base_task];
+    if (base.type != IKGPU_FULL) return false;
+    for (int i = 0; i < 6; ++i)
+        if (base.weight[i] == 0.0) return false;          // the base task's 6 x 6 block must span the base directions
+    for (int i = 0; i < ph.ntasks; ++i)                    // level 0: everything but the alignment row; level 1: that row alone
+        if (ph.tasks[i].priority != (i == ph.align_task ? 1 : 0)) return false;
+    return true;
+}
+
 hipError_t launch_dls_tree(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const ikgpu_dls_params &prm,
-                           hipStream_t stream) {
+                           hipStream_t stream, const double *pik_lambda1) {
     const int nj = ph.chain.nj, nch = ph.chainB.nj > 0 ? 2 : 1;
-#define X(N, C) if (nj == N && nch == C) return run_dls_tree<N, C>(ph, dt, io, prm, stream);
+#define X(N, C) if (nj == N && nch == C) return run_dls_tree<N, C>(ph, dt, io, prm, stream, pik_lambda1);
     IKGPU_FOR_TREE(X)
 #undef X
     not_built(nj, nch);

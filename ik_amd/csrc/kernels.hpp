@@ -45,8 +45,12 @@ hipError_t launch_dls_chain_hot(const ProblemHost &ph, const DeviceTables &dt, c
 
 namespace ikgpu {
 // Free-flyer tree kernels (shape F).  dt.chain_desc holds ikdev::TreeDesc<NA, NB>.
+// pik_lambda1 != nullptr: ik::pik with two priority levels in the shape tree_takes_two_level_pik() accepts -- prm.damping is
+// lambda[0], *pik_lambda1 is lambda[1] (device/tree_solver.hpp PikRow).
 hipError_t launch_dls_tree(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io,
-                           const ikgpu_dls_params &prm, hipStream_t stream);
+                           const ikgpu_dls_params &prm, hipStream_t stream, const double *pik_lambda1 = nullptr);
+// Level 0 = every frame task, among them a Full task on the base link with six non-zero weights; level 1 = the AlignAxisTask row.
+bool tree_takes_two_level_pik(const ProblemHost &ph);
 // e_out / J_out / oMf_out: any may be null.
 hipError_t launch_eval_tree(const ProblemHost &ph, const DeviceTables &dt, int64_t B, const double *q,
                             const double *targets, double *e_out, double *J_out, double *oMf_out, int layout,

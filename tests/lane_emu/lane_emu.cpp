@@ -152,6 +152,9 @@ void run_tree(const ikgpu::ProblemHost &ph, const IO &io) {
         a.prm.step_length = io.prm->step_length;
         a.prm.stop_sq_tol = io.prm->stop_sq_tol;
     }
+    // LANE_EMU_TREE_PIK_LAMBDA1=<lambda_1>: ik::pik with two levels on the tree program (level 1 = the AlignAxisTask row, damping
+    // factor lambda_1; lambda_0 is the DLS damping), see device/tree_solver.hpp PikRow
+    if (const char *l1 = std::getenv("LANE_EMU_TREE_PIK_LAMBDA1")) { a.prm.pik_on = 1; a.prm.pik_lam2_1 = std::atof(l1) * std::atof(l1); }
     const char *tr = std::getenv("LANE_EMU_TRIG");  // set: the device's general build (SPEC = 0), which takes sin / cos by dsincos_fast
     for (int64_t b = 0; b < io.B; ++b) {
         if (io.mode == 0 && tr && ph.has_posture)

@@ -33,6 +33,11 @@ PIK_CASES = {
     "feet_then_pelvis": ("cassie", True, [("frame", "LeftFootFront", "universe", 2, 0, None), ("frame", "RightFootFront", "universe", 2, 0, None),
                                           ("frame", "pelvis", "universe", 2, 1, None)], None, False),
     "single_level_leg": ("cassie_fixed", False, [("frame", "LeftFootFront", "universe", 2, 0, None)], None, True),
+    # the bench workload cassie_demo_pik: the demo's task set over two levels -- the shape the tree kernel takes (PikRow)
+    "demo_two_levels": ("cassie", True, [("frame", "LeftFootFront", "pelvis", 0, 0, None), ("frame", "pelvis", "universe", 2, 0, None),
+                                         ("align", "LeftFootFront", "universe", 1, 1, None)], None, True),
+    "demo_two_levels_full_foot": ("cassie", True, [("frame", "LeftFootFront", "universe", 2, 0, None), ("frame", "pelvis", "universe", 2, 0, [1.0, 2.0, 0.5, 1.0, 1.5, 3.0]),
+                                                   ("align", "LeftFootFront", "universe", 2, 1, None)], None, False),   # (six foot rows + the alignment row use up the chain's seven directions: the last projector is rounding noise there)
 }
 
 
@@ -62,6 +67,8 @@ def test_pik_kernel_matches_oracle(torch_cuda, case):
         data = _pik_data(ik_amd, problem, lam, da)
         if levels == 1 and da is None:   # ik::pik with one level and no secondary step IS the DLS iteration (include/ikgpu.h)
             assert data.kernel == ik_amd.plan(problem) and data.kernel.startswith("dls_chain<")
+        elif case.startswith("demo_two_levels") and da is None:   # two levels in the tree kernel's shape (device/tree_solver.hpp PikRow)
+            assert data.kernel.startswith("dls_tree<NJ=7,chains=1") and data.kernel.endswith(",pik_levels=2>"), data.kernel
         else:
             assert data.kernel.startswith("pik_generic<")
         p = ik_amd.pik_parameters(max_iterations=iters, step_length=step)

@@ -495,6 +495,40 @@ CONSTRAINT_CASES = {
 }
 
 
+@pytest.mark.parametrize("foot_type", [0, 2])
+@pytest.mark.parametrize("lam", [(0.1, 0.1), (1e-2, 0.5), (1.0, 1.0)])
+def test_two_level_pik_on_the_tree_program(emu, monkeypatch, foot_type, lam):
+    """ik::pik with two priority levels in the shape the tree kernel takes (device/tree_solver.hpp PikRow): level 0 = the foot
+    task (Position w.r.t. the pelvis, or Full) and the pelvis pose, level 1 = the AlignAxisTask row; against the oracle's ik::pik
+    (SVD damped pseudo-inverse + COD projector, reference ik/ik/pik.cpp:31-103)."""
+    from ik_amd import capi
+    specs = [("LeftFootFront", "pelvis", foot_type, 0, None), ("pelvis", "universe", 2, 0, None), ("LeftFootFront", "universe", 4, 1, None)]
+    B = 24
+    urdf, model, om, tasks, ot, q0, tg, M = _generic_case("cassie", True, specs, B, seed=17)
+    p = lambda a: C.c_void_p(a.ctypes.data)
+    for iters, step, tol in ((1, 1.0, -1.0), (5, 1.0, -1.0), (50, 0.5, 1e-7), (100, 1.0, 1e-4)):
+        qo = np.empty_like(q0)
+        ok, it = np.zeros(B, np.uint8), np.zeros(B, np.int32)
+        prm = capi.DlsParams(iters, lam[0], step, tol)
+        e, J, oMf = np.empty((B, M)), np.empty((B, M, model.nv)), np.empty((B, len(tasks), 12))
+        monkeypatch.setenv("LANE_EMU_TREE_PIK_LAMBDA1", repr(lam[1]))
+        rc = emu.lane_emu_run(urdf, C.c_size_t(len(urdf)), 1, tasks, len(tasks), 0, C.c_int64(B), p(q0), p(tg), C.byref(prm), p(qo), p(ok), p(it),
+                              p(e), p(J), p(oMf), 1)
+        monkeypatch.delenv("LANE_EMU_TREE_PIK_LAMBDA1")
+        assert rc == 0, emu.lane_emu_last_error()
+        q_ref, ok_ref, it_ref = O.pik_batch(om, ot, tg, q0, O.pik_params(iters, step, tol, list(lam)))
+        # (full steps towards random alignment directions make a few lanes chaotic: the oracle's own answer moves by 0.7 rad
+        # under a 1e-13 perturbation of q0 there -- those lanes have no answer to compare)
+        q_pert, _, _ = O.pik_batch(om, ot, tg, q0 + 1e-13, O.pik_params(iters, step, tol, list(lam)))
+        stable = np.abs(q_pert - q_ref).max(axis=1) < 1e-9
+        assert stable.sum() >= B - 4
+        assert np.array_equal(ok[stable], ok_ref[stable]) and np.array_equal(it[stable], it_ref[stable]), (foot_type, lam, iters)
+        assert np.abs(qo - q_ref)[stable].max() < 1e-8, (foot_type, lam, iters, np.abs(qo - q_ref)[stable].max())
+    # and it is not the one-level answer (the alignment row in level 0)
+    q_dls, _, _ = O.dls_batch(om, O.make_tasks([(t.frame, t.reference, t.type, 0, None) for t in tasks]), tg, q0, O.params(100, lam[0], 1.0, 1e-4))
+    assert np.abs(q_dls - q_ref)[stable].max() > 1e-6
+
+
 @pytest.mark.parametrize("ctype", [0, 1, 2])
 @pytest.mark.parametrize("with_align", [False, True])
 def test_constraint_build_of_the_tree_program(emu, ctype, with_align):

@@ -18,10 +18,11 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = {  # display name -> (mangled-name fragment, trip count of loops nested in the iteration loop)
-    "dls_chain<NJ=7,full>": ("dls_chain_kernelILi7ELi2E", 1),
-    "dls_chain<NJ=6,full>": ("dls_chain_kernelILi6ELi2E", 1),
-    "dls_tree<NJ=7,chains=2,base_task>": ("dls_tree_kernelILi7ELi2E", 2),
+KERNELS = {  # display name -> (source file, extra flags, mangled-name fragment, trip count of loops nested in the iteration loop)
+    # the structure-specialised chain builds (kernels_hot.hip; the never-stop instantiation sorts last: "Lb1E")
+    "dls_chain<NJ=7,full>": ("kernels_hot.hip", ["-fno-signed-zeros", "-fno-honor-nans", "-fno-honor-infinities"], "dls_chain_hot_kernelILi7E", 1),
+    "dls_chain<NJ=6,full>": ("kernels_hot.hip", ["-fno-signed-zeros", "-fno-honor-nans", "-fno-honor-infinities"], "dls_chain_hot_kernelILi6E", 1),
+    "dls_tree<NJ=7,chains=2,base_task>": ("kernels.hip", [], "dls_tree_kernelILi7ELi2E", 2),
 }
 FLOPS = {"v_fma_f64": 2, "v_fmac_f64": 2, "v_mul_f64": 1, "v_add_f64": 1, "v_min_f64": 1, "v_max_f64": 1,
          "v_rcp_f64": 1, "v_rsq_f64": 1, "v_rndne_f64": 1, "v_ldexp_f64": 1, "v_cvt_i32_f64": 1, "v_cvt_f64_i32": 1,
@@ -30,21 +31,28 @@ FLOPS = {"v_fma_f64": 2, "v_fmac_f64": 2, "v_mul_f64": 1, "v_add_f64": 1, "v_min
 
 
 def main():
+    texts = {}
     with tempfile.TemporaryDirectory() as td:
-        asm = os.path.join(td, "kernels.s")
-        cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
-               "-I" + os.path.join(ROOT, "ik_amd", "csrc"), "--offload-arch=gfx950", "-fno-fast-math", "-ffp-contract=" + os.environ.get("IKGPU_FP_CONTRACT", "on"),
-               "-S", "--cuda-device-only", os.path.join(ROOT, "ik_amd", "csrc", "kernels.hip"), "-o", asm]
-        subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
-        text = open(asm).read()
+        for src, flags in {(v[0], tuple(v[1])) for v in KERNELS.values()}:
+            asm = os.path.join(td, src + ".s")
+            cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
+                   "-I" + os.path.join(ROOT, "ik_amd", "csrc"), "--offload-arch=gfx950", "-fno-fast-math", "-ffp-contract=" + os.environ.get("IKGPU_FP_CONTRACT", "on"),
+                   *flags, "-S", "--cuda-device-only", os.path.join(ROOT, "ik_amd", "csrc", src), "-o", asm]
+            subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
+            texts[src] = open(asm).read()
     out = {}
-    for disp, (frag, trips) in KERNELS.items():
+    for disp, (src, _flags, frag, trips) in KERNELS.items():
+        text = texts[src]
         # several instantiations share the fragment (third template argument: 0 = the general build, otherwise the mask of
         # the hot build the launcher picks for these workloads): take the hot one
         cands = list(re.finditer(r"^(_Z\w*%sLi(\d+)E\w*):" % re.escape(frag), text, re.M))
-        if not cands:
-            continue
-        m = max(cands, key=lambda mm: int(mm.group(2)))
+        if cands:
+            m = max(cands, key=lambda mm: int(mm.group(2)))
+        else:   # the structure-specialised kernels: (NJ, three structure words, never-stop flag) -- take the never-stop build
+            cands = [mm for mm in re.finditer(r"^(_Z\w*%s\w*):" % re.escape(frag), text, re.M) if "Lb1E" in mm.group(1)]
+            if not cands:
+                continue
+            m = cands[0]
         name = m.group(1)
         body = text[m.end():text.index(".Lfunc_end", m.end())].split("\n")
         # Blocks carry "; =>This Inner Loop Header" / "; =>This Loop Header" / ";   in Loop: Header=BBn_m Depth=d"
