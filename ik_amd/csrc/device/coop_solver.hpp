@@ -629,12 +629,14 @@ IKD_FN void dls_coop_body(const CoopKernelArgs &a, int64_t problem, const int g,
     int iters;
     bool success;
     coop_dls(a.T, a.L, a.prm, g, ws, iters, success, any_active);
-    if (!valid) return;
-    IKC_FOR(i, nq) a.q_out[at(a.layout, a.B, nq, i, b)] = ws[a.L.q + i];
-    IKC_FOR(one, 1) {
-        if (a.success) a.success[b] = success ? 1 : 0;
-        if (a.iters) a.iters[b] = iters;
+    if (valid) {   // (no early return: the workgroup goes on to its next group of problems, see dls_coop_kernel)
+        IKC_FOR(i, nq) a.q_out[at(a.layout, a.B, nq, i, b)] = ws[a.L.q + i];
+        IKC_FOR(one, 1) {
+            if (a.success) a.success[b] = success ? 1 : 0;
+            if (a.iters) a.iters[b] = iters;
+        }
     }
+    IKC_SYNC();    // the workspace is free for the next problem
 }
 
 }  // namespace ikdev

@@ -239,12 +239,14 @@ IKD_FN void pik_coop_body(const PikCoopKernelArgs &a, const GenericTables &T, co
     int iters;
     bool success;
     coop_pik(T, L, a.K, a.prm, g, ws, iters, success, any_active);
-    if (!valid) return;
-    IKC_FOR(i, nq) a.q_out[at(a.layout, a.B, nq, i, b)] = ws[L.q + i];
-    IKC_FOR(one, 1) {
-        if (a.success) a.success[b] = success ? 1 : 0;
-        if (a.iters) a.iters[b] = iters;
+    if (valid) {   // (no early return: the workgroup goes on to its next group of problems, see pik_coop_kernel)
+        IKC_FOR(i, nq) a.q_out[at(a.layout, a.B, nq, i, b)] = ws[L.q + i];
+        IKC_FOR(one, 1) {
+            if (a.success) a.success[b] = success ? 1 : 0;
+            if (a.iters) a.iters[b] = iters;
+        }
     }
+    IKC_SYNC();    // the workspace is free for the next problem
 }
 
 }  // namespace ikdev

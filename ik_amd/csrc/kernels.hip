@@ -474,8 +474,12 @@ __global__ __launch_bounds__(kBlock, 2) void dls_coop_kernel(ikdev::CoopKernelAr
     double *ws0 = coop_stage(coop_lds, a.T, a.L, s);
     const int grp = threadIdx.x / ikdev::kCoopGroup, g = threadIdx.x % ikdev::kCoopGroup;
     const int per_block = blockDim.x / ikdev::kCoopGroup;
-    ikdev::dls_coop_body(a, static_cast<int64_t>(blockIdx.x) * per_block + grp, g, ws0 + grp * a.L.words,
-                         [](bool act) { return __any(act) != 0; });
+    // persistent workgroups: the tables are staged once per workgroup (7 KB for the demo task set) and serve every group of
+    // problems the workgroup takes -- staged per four problems they were 2/3 of the launch's HBM traffic (137 MB against 43 MB of
+    // algorithmic bytes at B = 65536)
+    const int64_t nblocks = (a.B + per_block - 1) / per_block;
+    for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x)
+        ikdev::dls_coop_body(a, blk * per_block + grp, g, ws0 + grp * a.L.words, [](bool act) { return __any(act) != 0; });
 }
 
 __global__ __launch_bounds__(kBlock) void pik_coop_kernel(const ikdev::PikCoopKernelArgs a, const CoopStaging s) {
@@ -487,11 +491,30 @@ __global__ __launch_bounds__(kBlock) void pik_coop_kernel(const ikdev::PikCoopKe
     double *ws0 = coop_stage(coop_lds, T, L, s);
     const int grp = threadIdx.x / ikdev::kCoopGroup, g = threadIdx.x % ikdev::kCoopGroup;
     const int per_block = blockDim.x / ikdev::kCoopGroup;
-    ikdev::pik_coop_body(a, T, L, static_cast<int64_t>(blockIdx.x) * per_block + grp, g, ws0 + grp * a.K.words,
-                         [](bool act) { return __any(act) != 0; });
+    const int64_t nblocks = (a.B + per_block - 1) / per_block;
+    for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x)   // persistent workgroups, as dls_coop_kernel
+        ikdev::pik_coop_body(a, T, L, blk * per_block + grp, g, ws0 + grp * a.K.words, [](bool act) { return __any(act) != 0; });
 }
 
 }  // namespace
+
+// Grid of a persistent cooperative launch: as many workgroups as the device keeps resident (LDS-bound: five per CU for the demo task
+// set), never more than there are groups of problems.
+int64_t persistent_grid(const void *kernel, int block, size_t lds, int64_t nblocks) {
+    int per_cu = 0, dev = 0;
+    static int cu_count[64] = {};   // per device ordinal; hipGetDeviceProperties costs milliseconds, the launch must not
+    int cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        if (cu_count[dev] == 0) {
+            int n = 0;
+            cu_count[dev] = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0 ? n : 256;
+        }
+        cus = cu_count[dev];
+    }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    const int64_t resident = static_cast<int64_t>(per_cu) * cus;
+    return nblocks < resident ? nblocks : resident;
+}
 
 #ifdef IKGPU_COOP_PROFILE
 // Debug builds only: per-phase cycle counters of workgroup 0 of the cooperative kernel, accumulated over its iterations.
@@ -537,7 +560,7 @@ hipError_t launch_pik_generic(const ProblemHost &gen, const DeviceTables &dt, co
         const int per_block = ikdev::kCoopPerBlock;
         const size_t lds = sizeof(double) * (static_cast<size_t>(per_block) * static_cast<size_t>(c.K.words) +
                                              static_cast<size_t>(s.n_dbls) + static_cast<size_t>((s.n_ints + 1) / 2));
-        const int64_t blocks = (io.B + per_block - 1) / per_block;
+        const int64_t blocks = persistent_grid(reinterpret_cast<const void *>(pik_coop_kernel), per_block * ikdev::kCoopGroup, lds, (io.B + per_block - 1) / per_block);
         hipLaunchKernelGGL(pik_coop_kernel, dim3(static_cast<unsigned>(blocks)), dim3(per_block * ikdev::kCoopGroup), lds, stream, c, s);
         return hipGetLastError();
     }
@@ -581,7 +604,7 @@ hipError_t launch_dls_generic(const ProblemHost &ph, const DeviceTables &dt, con
         const int per_block = ikdev::kCoopPerBlock;  // 4 x 16 lanes = one wave; 2 and 1 problems per workgroup measured slower
         const size_t lds = sizeof(double) * (static_cast<size_t>(per_block) * static_cast<size_t>(c.L.words) +
                                              static_cast<size_t>(s.n_dbls) + static_cast<size_t>((s.n_ints + 1) / 2));
-        const int64_t blocks = (io.B + per_block - 1) / per_block;
+        const int64_t blocks = persistent_grid(reinterpret_cast<const void *>(dls_coop_kernel), per_block * ikdev::kCoopGroup, lds, (io.B + per_block - 1) / per_block);
         hipLaunchKernelGGL(dls_coop_kernel, dim3(static_cast<unsigned>(blocks)), dim3(per_block * ikdev::kCoopGroup), lds, stream, c, s);
         return hipGetLastError();
     }

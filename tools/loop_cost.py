@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--sload", type=int, default=200, help="scalar-load latency in cycles")
     ap.add_argument("--lds", type=int, default=64, help="ds_read latency in cycles")
     ap.add_argument("--f64lat", type=int, default=4, help="cycles from the issue of an FP64 VALU instruction to the issue of a dependent one")
+    ap.add_argument("--inner-trips", type=int, default=1, help="trip count of loops nested in the iteration loop (their back edges are taken trips - 1 times)")
+    ap.add_argument("--exit", action="append", default=[], help="LABEL:N -- the conditional branch to LABEL (the exit of a nested loop) is taken on every N-th visit")
     ap.add_argument("--top", type=int, default=0)
     ap.add_argument("--first", action="store_true", help="take the first matching instantiation instead of the one with the largest third template argument")
     ap.add_argument("--dump", action="store_true")
@@ -78,6 +80,7 @@ def main():
     def walk_loop(h):
         header = body[h].split(":")[0].strip().lstrip(".").lstrip("L")
         taken = [x.lstrip(".").lstrip("L") for x in args.taken]
+        exits = {x.split(":")[0].lstrip(".").lstrip("L"): int(x.split(":")[1]) for x in args.exit}
         t = 0               # cycle at which the next instruction may issue
         ready = collections.defaultdict(int)    # register -> cycle its value is available
         pending_sload = []  # completion times of outstanding scalar loads (in order)
@@ -90,6 +93,7 @@ def main():
         n = 0
         i = h + 1
         steps = 0
+        inner_taken = {}
         while i < len(lines):
             steps += 1
             if steps > 200000:
@@ -112,9 +116,21 @@ def main():
                 if tgt == header and (op == "s_branch" or tgt not in taken):
                     t += 16      # the back edge: a taken branch (instruction fetch restart; not measured precisely)
                     break
+                if tgt in exits and op != "s_branch":
+                    inner_taken[tgt] = inner_taken.get(tgt, 0) + 1
+                    if inner_taken[tgt] % exits[tgt] == 0:
+                        i = label_at[tgt]
+                        t += 16
+                    continue
                 if tgt in label_at and (tgt in taken or op == "s_branch"):
                     i = label_at[tgt]
                     t += 16
+                elif tgt in label_at and label_at[tgt] < i and tgt != header and args.inner_trips > 1:
+                    # back edge of a nested loop: taken trips - 1 times
+                    inner_taken[i] = inner_taken.get(i, 0) + 1
+                    if inner_taken[i] % args.inner_trips != 0:
+                        i = label_at[tgt]
+                        t += 16
                 continue
             ops = [o.strip() for o in rest.split(",")] if rest.strip() else []
             # destination: first operand (VOPC writes vcc / an SGPR pair given first as well; stores have none)

@@ -43,7 +43,9 @@ def main(src, kernel, dst, tag):
     e["hbm_traffic_bytes_per_launch"] = traffic
     # problems per launch: one per lane, except the cooperative kernel's sixteen lanes per problem
     lanes_per_problem = 16 if rows and "coop" in rows[0]["Kernel_Name"] else 1
-    e["pmc"] = {"batch": int(rows[0]["Grid_Size"]) // lanes_per_problem if rows else None, "FETCH_SIZE_KiB": mean.get("FETCH_SIZE"),
+    # (the cooperative kernels run persistent workgroups: their grid says nothing about the batch -- bench.py's default it is)
+    batch = int(os.environ.get("IKGPU_PMC_BATCH", "65536")) if lanes_per_problem == 16 else (int(rows[0]["Grid_Size"]) if rows else None)
+    e["pmc"] = {"batch": batch, "FETCH_SIZE_KiB": mean.get("FETCH_SIZE"),
                 "WRITE_SIZE_KiB": mean.get("WRITE_SIZE"), "SQ_LDS_BANK_CONFLICT": mean.get("SQ_LDS_BANK_CONFLICT"),
                 "SQ_LDS_IDX_ACTIVE": mean.get("SQ_LDS_IDX_ACTIVE"), "SQ_INSTS_VALU": mean.get("SQ_INSTS_VALU"),
                 "SQ_ACTIVE_INST_VALU": mean.get("SQ_ACTIVE_INST_VALU"), "SQ_WAVE_CYCLES": mean.get("SQ_WAVE_CYCLES"),
