@@ -209,16 +209,20 @@ def cpu_baseline(model, xml, w, q0_np, tg_np, iters, budget_s=10.0):
         tgp[:, :len(specs), 9:] += dtg
         q_pert, _, _ = solve(om, tasks, tgp, q0_np[:sample] + dq, prm, cores)
         sens = np.maximum(sens, np.abs(q_pert - q_ref).max(axis=1))
-    stable = sens <= 1e-7
     out = dict(value=sample / dt, unit="solves/s", cores=cores, kind="port",
                sample="first %d problems of the batch, %d threads, %.2f s wall; 1-thread probe %.0f solves/s"
                       % (sample, cores, dt, r1))
+    stable = sens <= 1e-7
     if not w.get("tasks") and not w.get("posture") and not model_is_free_flyer(w) and w.get("solver") != "pik":
         fid = model.getFrameId(w["frames"][0])
         n_fast = int(min(q0_np.shape[0], max(sample, sample * 4)))
         t = time.perf_counter()
         q_fast, _, _ = O.fast_dls_chain_batch(xml, fid, tg_np[:n_fast], q0_np[:n_fast], prm, cores)
         dtf = time.perf_counter() - t
+        # a fourth stability probe: two CPU restatements of the same algorithm (different order of arithmetic) that disagree
+        # with each other mark the lanes where rounding decides
+        sens = np.maximum(sens, np.abs(q_fast[:sample] - q_ref).max(axis=1))
+        stable = sens <= 1e-7
         out["optimised"] = dict(value=n_fast / dtf, unit="solves/s", cores=cores, kind="port",
                                 what="the device lane program (support-sparse, allocation-free, unrolled) compiled g++ -O3 "
                                      "-march=x86-64-v3 for the host, %d threads (oracle/fast_cpu.cpp)" % cores,
@@ -503,11 +507,15 @@ def main():
             res["parity_vs_cpu"] = {"problems": sample, "bar_rad": 1e-6, "flags_equal": flags_equal,
                                     "stable": int(stable.sum()),
                                     "max_abs_dq_rad_stable": float(d[stable].max()) if stable.any() else None,
+                                    "stable_beyond_bar": int((stable & (d > 1e-6)).sum()),
                                     "worst_stable_problem": worst, "unstable": int((~stable).sum()),
                                     "max_abs_dq_rad_unstable": float(d[~stable].max()) if (~stable).any() else None,
                                     "stability_rule": "a problem is unstable when the CPU port's own answer moves by more than 1e-7 rad "
                                                       "under a 1e-13 perturbation of q0 or of the target translations; only those are "
-                                                      "excluded from the 1e-6 bar",
+                                                      "excluded from the 1e-6 bar (chain workloads: also when the optimised CPU variant and the faithful port disagree by "
+                                                      "more than 1e-7 rad).  With the joint-limit projection live and far targets the iteration is "
+                                                      "chaotic and a few lanes in 65536 escape every probe (stable_beyond_bar); "
+                                                      "tests/test_gpu_full_size.py checks those workloads step by step along the oracle's trajectory",
                                     "max_cpu_self_sensitivity_rad": float(sens.max())}
         print(json.dumps(res))
         sys.stdout.flush()
