@@ -59,7 +59,7 @@ bool chain_hot_built(const ProblemHost &ph) {
     if (ph.kind != KernelKind::Chain || ph.ntasks != 1 || ph.tasks[0].type != IKGPU_FULL || !task_has_unit_weights(ph.tasks[0])) return false;
     const char *env = std::getenv("IKGPU_CHAIN_HOT");
     if (env && std::strcmp(env, "0") == 0) return false;   // A/B switch: the general chain kernel
-    const ChainStructure s = chain_structure(ph.chain);
+    const ChainStructure &s = ph.chain_struct;
     if (!s.fits) return false;
 #define X(N, K0, K1, K2) \
     if (ph.chain.nj == N && s.code[0] == K0 && s.code[1] == K1 && s.code[2] == K2) return true;
@@ -70,8 +70,8 @@ bool chain_hot_built(const ProblemHost &ph) {
 
 hipError_t launch_dls_chain_hot(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const ikgpu_dls_params &prm,
                                 hipStream_t stream) {
-    const ChainStructure s = chain_structure(ph.chain);
-    const std::vector<double> tab = chain_hot_table(ph.chain);
+    const ChainStructure &s = ph.chain_struct;
+    const std::vector<double> &tab = ph.chain_hot;
     HotTable t{};
     if (tab.size() > static_cast<size_t>(ikdev::kHotTableMax)) return hipErrorInvalidValue;
     std::memcpy(t.v, tab.data(), tab.size() * sizeof(double));

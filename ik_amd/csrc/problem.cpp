@@ -117,6 +117,8 @@ void specialise(ProblemHost &ph, const Model &m) {
         for (int j = m.frame_parent[t.frame]; j > 0; j = m.joint_parent[j]) joints.insert(joints.begin(), j);
         if (joints.empty()) throw Unsupported("task frame fixed in the world");
         ph.chain = chain_of(joints, t.frame, 0);
+        ph.chain_struct = chain_structure(ph.chain);
+        ph.chain_hot = chain_hot_table(ph.chain);
         ph.kind = KernelKind::Chain;
         ph.kernel_name = "dls_chain<NJ=" + std::to_string(ph.chain.nj) + "," + kt[t.type] + ">";
         ph.q_in_chain = in_chain;

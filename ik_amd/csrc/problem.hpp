@@ -56,6 +56,20 @@ struct ChainHost {
     double lo[kMaxChain] = {}, hi[kMaxChain] = {};
 };
 
+// Structure of the chain's constant placements for the structure-specialised chain kernel (device/chain_hot.hpp): 21 bits per
+// placement i = 0 .. nj (nj: the frame placement) -- nine 2-bit classes of the rotation entries, row-major (0 general, 1 exactly
+// zero, 2 exactly +1, 3 exactly -1) and three bits "translation component is non-zero" -- three placements per 64-bit word.
+// Chains longer than 7 joints do not fit the three words and get code[*] = 0 ("everything general") with `fits` false.
+struct ChainStructure {
+    uint64_t code[3] = {0, 0, 0};
+    bool fits = false;
+    int values = 0;   // non-structural entries: the length of the compact table before lo / hi
+};
+ChainStructure chain_structure(const ChainHost &c);
+// The compact table of that kernel: the non-structural placement values in placement order (general rotation entries
+// row-major, then the non-zero translation components), then lo[nj], hi[nj].
+std::vector<double> chain_hot_table(const ChainHost &c);
+
 struct ProblemHost {
     KernelKind kind = KernelKind::Chain;
     std::string kernel_name;
@@ -63,6 +77,8 @@ struct ProblemHost {
     std::vector<ikgpu_task> tasks;    // in stacking order (priority, then insertion)
     std::vector<int> task_row;        // first row of each task in the stacked system
     ChainHost chain;                  // Chain kind: the chain; Tree kind: chain A
+    ChainStructure chain_struct;      // Chain kind: the placement-structure code of `chain` and
+    std::vector<double> chain_hot;    //   its compact table (device/chain_hot.hpp), computed once at analysis
     ChainHost chainB;                 // Tree kind: chain B (nj = 0 when absent)
     int base_task = -1;               // Tree kind: index of the task on the base link, or -1
     double base_frame_pl[12] = {};    // base joint frame -> frame of the base task
@@ -111,19 +127,6 @@ void fill_chain_args(const ProblemHost &ph, double *ref_pl12, int *qidx, int *vi
 // Bit j set when placement j of the chain has an exactly-identity rotation; bit nj for the frame placement.
 int chain_identity_mask(const ChainHost &c);
 bool task_has_unit_weights(const ikgpu_task &t);
-// Structure of the chain's constant placements for the structure-specialised chain kernel (device/chain_hot.hpp): 21 bits per
-// placement i = 0 .. nj (nj: the frame placement) -- nine 2-bit classes of the rotation entries, row-major (0 general, 1 exactly
-// zero, 2 exactly +1, 3 exactly -1) and three bits "translation component is non-zero" -- three placements per 64-bit word.
-// Chains longer than 7 joints do not fit the three words and get code[*] = 0 ("everything general") with `fits` false.
-struct ChainStructure {
-    uint64_t code[3] = {0, 0, 0};
-    bool fits = false;
-    int values = 0;   // non-structural entries: the length of the compact table before lo / hi
-};
-ChainStructure chain_structure(const ChainHost &c);
-// The compact table of that kernel: the non-structural placement values in placement order (general rotation entries
-// row-major, then the non-zero translation components), then lo[nj], hi[nj].
-std::vector<double> chain_hot_table(const ChainHost &c);
 // The per-problem scalars of ikdev::TreeKernelArgs<na, nb>.
 struct TreeArgsHost {
     int qidx[2][kMaxChain], vidx[2][kMaxChain];

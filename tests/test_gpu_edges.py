@@ -228,3 +228,41 @@ def test_hip_graph_capture_of_the_other_kernels(ctx, case, monkeypatch):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out[0], ref) and torch.equal(out[1], ok_ref) and torch.equal(out[2], it_ref)
+
+
+def test_problem_support_marks_the_entries_a_solve_can_move(native_built):
+    """ikgpu_problem_support (what the compact multi-GPU gather ships): the task supports and the floating base; every other entry of
+    q only passes through the joint clipping -- and the solve indeed leaves those at clip(q0)."""
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import ik_amd
+    from ik_amd import distributed as ikdist, workload
+    model = ik_amd.Model.from_urdf_file(urdf_path("cassie_fixed"))
+    problem = ik_amd.InverseKinematicsProblem(model)
+    problem.add_frame_task("t", ik_amd.FrameTask.create(model, "LeftFootFront", ik_amd.KinematicType.Full))
+    data = ik_amd.dls_data(problem, device=0)
+    chain = ["LeftHipRoll", "LeftHipYaw", "LeftHipPitch", "LeftKneePitch", "LeftShinPitch", "LeftTarsusPitch", "LeftFootPitch"]
+    flat = model.flat()
+    want = np.zeros(model.nq, bool)
+    want[[int(flat["idx_q"][model.names.index(n)]) for n in chain]] = True
+    assert np.array_equal(data.support, want)
+    # a consumer holding q0 rebuilds the whole configuration from the support rows
+    B = 500
+    q0, qs = workload.chain_workload(model.lowerPositionLimit, model.upperPositionLimit, workload.cassie_nominal(model.names), np.arange(B), 3, "near")
+    q0[:, 9] += 3.0                                        # a right-leg entry beyond its limit
+    Q0 = torch.from_numpy(np.ascontiguousarray(q0.T)).cuda()
+    T = ik_amd.task_frames_fk_batch(problem, torch.from_numpy(np.ascontiguousarray(qs.T)).cuda(), data)
+    for visitor, iters in ((ik_amd.never_stop_visitor(), 20), (ik_amd.inverse_kinematics_visitor(), 100), (ik_amd.inverse_kinematics_visitor(1e30), 5)):
+        Q, ok, it = ik_amd.dls_batch(problem, Q0, T, data, visitor, ik_amd.dls_parameters(max_iterations=iters))
+        rows = torch.from_numpy(np.flatnonzero(data.support)).cuda()
+        full = ikdist.expand_rows(Q[rows], rows, Q0, torch.from_numpy(model.lowerPositionLimit).cuda(), torch.from_numpy(model.upperPositionLimit).cuda(), it)
+        assert torch.equal(full, Q)
+    # free-flyer full body: the base and both legs, not the two spring joints
+    m2 = ik_amd.Model.from_urdf_file(urdf_path("cassie"), free_flyer=True)
+    p2 = ik_amd.InverseKinematicsProblem(m2)
+    for i, f in enumerate(["LeftFootFront", "RightFootFront", "pelvis"]):
+        p2.add_frame_task("t%d" % i, ik_amd.FrameTask.create(m2, f, ik_amd.KinematicType.Full))
+    d2 = ik_amd.dls_data(p2, device=0)
+    f2 = m2.flat()
+    springs = [int(f2["idx_q"][m2.names.index(n)]) for n in ("LeftAchillesSpring", "RightAchillesSpring")]
+    assert d2.support.sum() == m2.nq - 2 and not d2.support[springs].any()

@@ -1,6 +1,5 @@
 #!/usr/bin/env bash
+# A/B of the general chain builds' table placement (scalar loads vs LDS); the variant is built BESIDE the production library.
 cd "$GRAFT_REPO_ROOT"
-cp ik_amd/libikgpu.so /tmp/lib_scalar.so
-touch ik_amd/csrc/kernels.hip; make -s -C ik_amd/csrc KERNEL_EXTRA="-DIKGPU_CHAIN_TABLE_IN_LDS" >/dev/null 2>&1; cp ik_amd/libikgpu.so /tmp/lib_lds.so
-for v in scalar lds scalar lds; do cp /tmp/lib_$v.so ik_amd/libikgpu.so; echo "== table $v"; python tools/chain_variants_timing.py 2>/dev/null; done
-cp /tmp/lib_scalar.so ik_amd/libikgpu.so
+lds=$(tools/build_variant.sh tablelds -DIKGPU_CHAIN_TABLE_IN_LDS | tail -1)
+for v in "$PWD/ik_amd/libikgpu.so" "$lds" "$PWD/ik_amd/libikgpu.so" "$lds"; do echo "== $v"; IKGPU_LIB="$v" IKGPU_CHAIN_HOT=0 python tools/chain_variants_timing.py 2>/dev/null; done

@@ -1,5 +1,7 @@
 #!/usr/bin/env bash
+# Per-phase cycle counters of the cooperative kernels: a VARIANT build beside the production library (never over it),
+# selected with IKGPU_LIB.
 cd "$GRAFT_REPO_ROOT"
-touch ik_amd/csrc/kernels.hip; make -s -C ik_amd/csrc KERNEL_EXTRA="-DIKGPU_COOP_PROFILE" 2>&1 | tail -3
-python tools/coop_profile.py pik
-python tools/coop_profile.py
+lib=$(tools/build_variant.sh coopprof -DIKGPU_COOP_PROFILE | tail -1)
+IKGPU_LIB="$lib" python tools/coop_profile.py pik
+IKGPU_LIB="$lib" python tools/coop_profile.py
