@@ -91,9 +91,10 @@ IKD_FN double coop_evaluate(const GenericTables &T, const CoopLayout &L, const i
         if (j > 0) {
             const int iq = T.idx_q[j], jt = T.jtype[j];
             const double *a = T.axis + 3 * j;
-            if (jt == GJ_REVOLUTE) {
+            if (jt == GJ_REVOLUTE || jt == GJ_REVOLUTE_UNBOUNDED) {
                 double s, c;
-                dsincos(ws[L.q + iq], s, c);
+                if (jt == GJ_REVOLUTE) dsincos(ws[L.q + iq], s, c);
+                else { c = ws[L.q + iq]; s = ws[L.q + iq + 1]; }   // a continuous joint's configuration IS (cos, sin)
                 const double k = 1.0 - c;
                 Mj[0] = c + k * a[0] * a[0];        Mj[1] = k * a[0] * a[1] - s * a[2]; Mj[2] = k * a[0] * a[2] + s * a[1];
                 Mj[3] = k * a[1] * a[0] + s * a[2]; Mj[4] = c + k * a[1] * a[1];        Mj[5] = k * a[1] * a[2] - s * a[0];
@@ -148,12 +149,12 @@ IKD_FN double coop_evaluate(const GenericTables &T, const CoopLayout &L, const i
                 for (int i = 0; i < 3; ++i)
                     ws[L.sf + 3 * j + i] = mj * dfma(oM[3 * i], cl[0], dfma(oM[3 * i + 1], cl[1], dfma(oM[3 * i + 2], cl[2], oM[9 + i])));
             }
-            if (jt == GJ_REVOLUTE || jt == GJ_PRISMATIC) {
+            if (jt == GJ_REVOLUTE || jt == GJ_PRISMATIC || jt == GJ_REVOLUTE_UNBOUNDED) {
                 const double Ra[3] = {dfma(oM[0], a[0], dfma(oM[1], a[1], oM[2] * a[2])), dfma(oM[3], a[0], dfma(oM[4], a[1], oM[5] * a[2])),
                                       dfma(oM[6], a[0], dfma(oM[7], a[1], oM[8] * a[2]))};
                 const double p[3] = {oM[9], oM[10], oM[11]};
                 double v[3] = {Ra[0], Ra[1], Ra[2]}, w[3] = {0, 0, 0};
-                if (jt == GJ_REVOLUTE) {
+                if (jt != GJ_PRISMATIC) {
                     cross(p, Ra, v);
                     w[0] = Ra[0]; w[1] = Ra[1]; w[2] = Ra[2];
                 }
@@ -472,6 +473,14 @@ IKD_FN void coop_integrate(const GenericTables &T, const CoopLayout &L, const in
                 const double c = dmin(T.upper[iq + k], dmax(qn[k], T.lower[iq + k]));
                 ws[L.q + iq + k] = active ? c : qb[k];
             }
+        } else if (T.jtype[j] == GJ_REVOLUTE_UNBOUNDED) {
+            const double c0 = ws[L.q + iq], s0 = ws[L.q + iq + 1];
+            double c1, s1;
+            unbounded_integrate(c0, s0, step_length * ws[L.dq + iv], c1, s1);
+            c1 = dmin(T.upper[iq], dmax(c1, T.lower[iq]));
+            s1 = dmin(T.upper[iq + 1], dmax(s1, T.lower[iq + 1]));
+            ws[L.q + iq] = active ? c1 : c0;
+            ws[L.q + iq + 1] = active ? s1 : s0;
         } else {
             const double qo = ws[L.q + iq];
             const double c = dmin(T.upper[iq], dmax(dfma(step_length, ws[L.dq + iv], qo), T.lower[iq]));

@@ -18,7 +18,18 @@
 
 namespace ikdev {
 
-enum : int { GJ_UNIVERSE = 0, GJ_REVOLUTE = 1, GJ_PRISMATIC = 2, GJ_FREEFLYER = 3 };  // == ikgpu_joint_type
+enum : int { GJ_UNIVERSE = 0, GJ_REVOLUTE = 1, GJ_PRISMATIC = 2, GJ_FREEFLYER = 3, GJ_REVOLUTE_UNBOUNDED = 4 };  // == ikgpu_joint_type
+
+// pinocchio::integrate on a "continuous" joint (SpecialOrthogonalOperation<2>): the (cos, sin) pair rotated by v, then
+// renormalised to first order -- the same (3 - |.|^2) / 2 factor as the free-flyer's quaternion.
+IKD_FN void unbounded_integrate(double c0, double s0, double v, double &c1, double &s1) {
+    double sv, cv;
+    dsincos(v, sv, cv);
+    const double c = dfma(cv, c0, -(sv * s0)), s = dfma(sv, c0, cv * s0);
+    const double k = (3.0 - dfma(c, c, s * s)) * 0.5;
+    c1 = c * k;
+    s1 = s * k;
+}
 enum : int { GT_POSITION = 0, GT_ORIENTATION = 1, GT_FULL = 2, GT_ALIGN_X = 3, GT_POSTURE_ROW = 6, GT_COM = 7 };  // == ikgpu_kinematic_type
 
 // Read-only tables shared by all lanes (device global memory; host memory in the lane emulator).
@@ -80,9 +91,10 @@ IKD_FN void generic_fk(const GenericTables &T, const Ws &ws) {
         double Mj[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0}, li[12], oP[12], oM[12];
         const int iq = T.idx_q[j], iv = T.idx_v[j], jt = T.jtype[j];
         const double *a = T.axis + 3 * j;
-        if (jt == GJ_REVOLUTE) {
+        if (jt == GJ_REVOLUTE || jt == GJ_REVOLUTE_UNBOUNDED) {
             double s, c;
-            dsincos(ws[T.off_q + iq], s, c);
+            if (jt == GJ_REVOLUTE) dsincos(ws[T.off_q + iq], s, c);
+            else { c = ws[T.off_q + iq]; s = ws[T.off_q + iq + 1]; }   // a continuous joint's configuration IS (cos, sin), used as given
             const double k = 1.0 - c;  // Rodrigues; exact entries for an aligned axis
             Mj[0] = c + k * a[0] * a[0];        Mj[1] = k * a[0] * a[1] - s * a[2]; Mj[2] = k * a[0] * a[2] + s * a[1];
             Mj[3] = k * a[1] * a[0] + s * a[2]; Mj[4] = c + k * a[1] * a[1];        Mj[5] = k * a[1] * a[2] - s * a[0];
@@ -103,12 +115,12 @@ IKD_FN void generic_fk(const GenericTables &T, const Ws &ws) {
         g_se3_mul(oP, li, oM);
         for (int k = 0; k < 12; ++k) ws[T.off_oMi + 12 * j + k] = oM[k];
         // world Jacobian columns [v; w]
-        if (jt == GJ_REVOLUTE || jt == GJ_PRISMATIC) {
+        if (jt == GJ_REVOLUTE || jt == GJ_PRISMATIC || jt == GJ_REVOLUTE_UNBOUNDED) {
             const double Ra[3] = {dfma(oM[0], a[0], dfma(oM[1], a[1], oM[2] * a[2])), dfma(oM[3], a[0], dfma(oM[4], a[1], oM[5] * a[2])),
                                   dfma(oM[6], a[0], dfma(oM[7], a[1], oM[8] * a[2]))};
             const double p[3] = {oM[9], oM[10], oM[11]};
             double v[3] = {Ra[0], Ra[1], Ra[2]}, w[3] = {0, 0, 0};
-            if (jt == GJ_REVOLUTE) {
+            if (jt != GJ_PRISMATIC) {
                 cross(p, Ra, v);
                 w[0] = Ra[0]; w[1] = Ra[1]; w[2] = Ra[2];
             }
@@ -399,6 +411,14 @@ IKD_FN void generic_integrate_clip(const GenericTables &T, const Ws &ws, double 
                 const double c = dmin(T.upper[iq + k], dmax(qn[k], T.lower[iq + k]));
                 ws[T.off_q + iq + k] = active ? c : qb[k];
             }
+        } else if (T.jtype[j] == GJ_REVOLUTE_UNBOUNDED) {
+            const double c0 = ws[T.off_q + iq], s0 = ws[T.off_q + iq + 1];
+            double c1, s1;
+            unbounded_integrate(c0, s0, step_length * ws[T.off_dq + iv], c1, s1);
+            c1 = dmin(T.upper[iq], dmax(c1, T.lower[iq]));
+            s1 = dmin(T.upper[iq + 1], dmax(s1, T.lower[iq + 1]));
+            ws[T.off_q + iq] = active ? c1 : c0;
+            ws[T.off_q + iq + 1] = active ? s1 : s0;
         } else {
             const double qo = ws[T.off_q + iq];
             const double c = dmin(T.upper[iq], dmax(dfma(step_length, ws[T.off_dq + iv], qo), T.lower[iq]));

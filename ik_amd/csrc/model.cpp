@@ -134,10 +134,10 @@ void Model::finalize() {
         if (joint_parent[j] < 0 || joint_parent[j] >= static_cast<int32_t>(j))
             throw std::runtime_error("joint parents must precede their children");
         const int t = joint_type[j];
-        if (t != IKGPU_JOINT_REVOLUTE && t != IKGPU_JOINT_PRISMATIC && t != IKGPU_JOINT_FREEFLYER)
+        if (t != IKGPU_JOINT_REVOLUTE && t != IKGPU_JOINT_PRISMATIC && t != IKGPU_JOINT_FREEFLYER && t != IKGPU_JOINT_REVOLUTE_UNBOUNDED)
             throw std::runtime_error("unknown joint type for joint " + joint_names[j]);
         if (joint_idx_q[j] != cq || joint_idx_v[j] != cv) throw std::runtime_error("idx_q / idx_v must be dense and ordered");
-        cq += (t == IKGPU_JOINT_FREEFLYER) ? 7 : 1;
+        cq += (t == IKGPU_JOINT_FREEFLYER) ? 7 : (t == IKGPU_JOINT_REVOLUTE_UNBOUNDED ? 2 : 1);
         cv += (t == IKGPU_JOINT_FREEFLYER) ? 6 : 1;
     }
     if (cq != nq || cv != nv) throw std::runtime_error("nq / nv do not match the joint list");
@@ -270,6 +270,9 @@ Model Model::from_urdf(const char *xml_text, size_t len, bool free_flyer) {
                 m.lower.push_back(-std::numeric_limits<double>::max());
                 m.upper.push_back(std::numeric_limits<double>::max());
             }
+        } else if (type == IKGPU_JOINT_REVOLUTE_UNBOUNDED) {   // (cos, sin): Pinocchio's limits for a continuous joint
+            m.nq += 2; m.nv += 1;
+            for (int i = 0; i < 2; ++i) { m.lower.push_back(-1.01); m.upper.push_back(1.01); }
         } else if (type != IKGPU_JOINT_UNIVERSE) {
             m.nq += 1; m.nv += 1;
             m.lower.push_back(lo);
@@ -312,7 +315,7 @@ Model Model::from_urdf(const char *xml_text, size_t len, bool free_flyer) {
                 if (j->type == "fixed") {
                     add_frame_(j->name, pj, pl);
                     body_frame[j->child] = add_frame_(j->child, pj, pl);
-                } else if (j->type == "revolute" || j->type == "prismatic") {
+                } else if (j->type == "revolute" || j->type == "prismatic" || j->type == "continuous") {
                     std::array<double, 3> a = j->axis;
                     const bool aligned = (a == std::array<double, 3>{1, 0, 0}) || (a == std::array<double, 3>{0, 1, 0}) ||
                                          (a == std::array<double, 3>{0, 0, 1});
@@ -321,12 +324,14 @@ Model Model::from_urdf(const char *xml_text, size_t len, bool free_flyer) {
                         if (!(n > 0.0)) throw std::runtime_error("zero axis on joint " + j->name);
                         a = {a[0] / n, a[1] / n, a[2] / n};
                     }
-                    const int32_t type = (j->type == "revolute") ? IKGPU_JOINT_REVOLUTE : IKGPU_JOINT_PRISMATIC;
+                    // "continuous": Pinocchio's JointModelRevoluteUnbounded*, configuration (cos, sin), see include/ikgpu.h
+                    const int32_t type = (j->type == "revolute") ? IKGPU_JOINT_REVOLUTE
+                                       : (j->type == "continuous") ? IKGPU_JOINT_REVOLUTE_UNBOUNDED : IKGPU_JOINT_PRISMATIC;
                     const int32_t jid = add_joint_(pj, type, pl, j->name, a, j->lower, j->upper);
                     add_frame_(j->name, jid, se3_identity());
                     body_frame[j->child] = add_frame_(j->child, jid, se3_identity());
                 } else {
-                    // "continuous" is a (cos, sin) pair in Pinocchio (nq = 2); floating/planar unused by the path
+                    // floating / planar joints are unused by the path
                     throw std::runtime_error("unsupported URDF joint type '" + j->type + "' on joint " + j->name);
                 }
                 visit(j->child, depth + 1);

@@ -97,6 +97,9 @@ void specialise(ProblemHost &ph, const Model &m) {
     for (const ikgpu_task &t : ph.tasks) {
         if (t.type == IKGPU_CENTRE_OF_MASS) throw Unsupported("CentreOfMassTask rows run on the generic kernel");
     }
+    // a "continuous" joint anywhere in the model: its (cos, sin) pair is renormalised by every integrate, also where dq = 0
+    for (int j = 1; j < m.njoints(); ++j)
+        if (m.joint_type[j] == IKGPU_JOINT_REVOLUTE_UNBOUNDED) throw Unsupported("a model with continuous joints runs on the generic kernel");
     std::vector<uint8_t> in_chain(m.nq, 0);
 
     auto chain_of = [&](const std::vector<int> &joints, int frame, int task_index) {

@@ -46,7 +46,11 @@ typedef enum {
     IKGPU_ERR_DEVICE = 4       /* HIP runtime failure, or no gfx950 device */
 } ikgpu_status;
 
-typedef enum { IKGPU_JOINT_UNIVERSE = 0, IKGPU_JOINT_REVOLUTE = 1, IKGPU_JOINT_PRISMATIC = 2, IKGPU_JOINT_FREEFLYER = 3 } ikgpu_joint_type;
+/* IKGPU_JOINT_REVOLUTE_UNBOUNDED: what Pinocchio builds for a URDF "continuous" joint (JointModelRevoluteUnbounded*): nq = 2 -- the
+ * configuration holds (cos, sin) of the angle --, nv = 1; its position limits are -1.01 / +1.01 on both entries, and integration rotates
+ * the pair by the step and renormalises it to first order (scale (3 - |.|^2) / 2).  Models with such a joint run on the generic kernel. */
+typedef enum { IKGPU_JOINT_UNIVERSE = 0, IKGPU_JOINT_REVOLUTE = 1, IKGPU_JOINT_PRISMATIC = 2, IKGPU_JOINT_FREEFLYER = 3,
+               IKGPU_JOINT_REVOLUTE_UNBOUNDED = 4 } ikgpu_joint_type;
 
 /* ik::KinematicType, reference ik/ik/frame.hpp:20 (same order). */
 typedef enum {

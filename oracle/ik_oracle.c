@@ -241,8 +241,11 @@ static void joint_transform(const iko_model *m, int j, const double *q, double *
     const double *a = m->axis + 3 * j;
     se3_identity(M);
     switch (m->jtype[j]) {
-        case IKO_JOINT_REVOLUTE: {
-            const double c = cos(q[iq]), s = sin(q[iq]), k = 1.0 - c;
+        case IKO_JOINT_REVOLUTE:
+        case IKO_JOINT_REVOLUTE_UNBOUNDED: {
+            /* a continuous joint's configuration IS (cos, sin), used as given (JointModelRevoluteUnbounded::calc) */
+            const int unb = m->jtype[j] == IKO_JOINT_REVOLUTE_UNBOUNDED;
+            const double c = unb ? q[iq] : cos(q[iq]), s = unb ? q[iq + 1] : sin(q[iq]), k = 1.0 - c;
             /* Rodrigues; for an aligned axis every entry is exact */
             R_(M, 0, 0) = c + k * a[0] * a[0];
             R_(M, 0, 1) = k * a[0] * a[1] - s * a[2];
@@ -288,10 +291,10 @@ static void joint_jacobians_world(const iko_model *m, const double *oMi, double 
         const double *M = oMi + 12 * j;
         const double *a = m->axis + 3 * j;
         const int iv = m->idx_v[j];
-        if (m->jtype[j] == IKO_JOINT_REVOLUTE || m->jtype[j] == IKO_JOINT_PRISMATIC) {
+        if (m->jtype[j] == IKO_JOINT_REVOLUTE || m->jtype[j] == IKO_JOINT_PRISMATIC || m->jtype[j] == IKO_JOINT_REVOLUTE_UNBOUNDED) {
             double Ra[3], v[3];
             for (int i = 0; i < 3; ++i) Ra[i] = R_(M, i, 0) * a[0] + R_(M, i, 1) * a[1] + R_(M, i, 2) * a[2];
-            if (m->jtype[j] == IKO_JOINT_REVOLUTE) {
+            if (m->jtype[j] != IKO_JOINT_PRISMATIC) {
                 cross3(&P_(M, 0), Ra, v);
                 for (int i = 0; i < 3; ++i) { Jw[i * nv + iv] = v[i]; Jw[(3 + i) * nv + iv] = Ra[i]; }
             } else {
@@ -565,6 +568,13 @@ void iko_integrate(const iko_model *m, const double *q, const double *v, double 
             for (int i = 0; i < 4; ++i) n2 += rq[i] * rq[i];
             const double al = (3.0 - n2) / 2.0;
             for (int i = 0; i < 4; ++i) out[iq + 3 + i] = rq[i] * al;
+        } else if (m->jtype[j] == IKO_JOINT_REVOLUTE_UNBOUNDED) {
+            /* SpecialOrthogonalOperation<2>::integrate: rotate (cos, sin) by v, first-order renormalisation */
+            const double cv = cos(v[iv]), sv = sin(v[iv]);
+            const double c = cv * q[iq] - sv * q[iq + 1], s = sv * q[iq] + cv * q[iq + 1];
+            const double k = (3.0 - (c * c + s * s)) / 2.0;
+            out[iq] = c * k;
+            out[iq + 1] = s * k;
         } else {
             out[iq] = q[iq] + v[iv];
         }

@@ -20,7 +20,8 @@
 extern "C" {
 #endif
 
-enum { IKO_JOINT_UNIVERSE = 0, IKO_JOINT_REVOLUTE = 1, IKO_JOINT_PRISMATIC = 2, IKO_JOINT_FREEFLYER = 3 };
+/* IKO_JOINT_REVOLUTE_UNBOUNDED: Pinocchio's joint for a URDF "continuous" joint: configuration (cos, sin), nq = 2, nv = 1 */
+enum { IKO_JOINT_UNIVERSE = 0, IKO_JOINT_REVOLUTE = 1, IKO_JOINT_PRISMATIC = 2, IKO_JOINT_FREEFLYER = 3, IKO_JOINT_REVOLUTE_UNBOUNDED = 4 };
 /* ik::KinematicType, ik/ik/frame.hpp:20 */
 enum { IKO_POSITION = 0, IKO_ORIENTATION = 1, IKO_FULL = 2,
        /* ik::AlignAxisTask with AlignAxisType X / Y / Z (ik/ik/frame.hpp:202-319): one row; its target direction

@@ -239,7 +239,7 @@ def exp6(nu):
 # ----------------------------------------------------------------------------------------------
 # URDF -> model with Pinocchio's conventions
 # ----------------------------------------------------------------------------------------------
-J_UNIVERSE, J_REVOLUTE, J_PRISMATIC, J_FREEFLYER = 0, 1, 2, 3
+J_UNIVERSE, J_REVOLUTE, J_PRISMATIC, J_FREEFLYER, J_REVOLUTE_UNBOUNDED = 0, 1, 2, 3, 4   # 4: a URDF "continuous" joint, q = (cos, sin)
 
 
 class Model:
@@ -311,6 +311,11 @@ def load_urdf(path_or_xml, free_flyer=False):
             m.nv += 6
             m.lower += [-DBL_MAX] * 7
             m.upper += [DBL_MAX] * 7
+        elif jtype == J_REVOLUTE_UNBOUNDED:   # Pinocchio's limits for a continuous joint
+            m.nq += 2
+            m.nv += 1
+            m.lower += [-1.01] * 2
+            m.upper += [1.01] * 2
         else:
             m.nq += 1
             m.nv += 1
@@ -339,10 +344,10 @@ def load_urdf(path_or_xml, free_flyer=False):
                 pl = pf["placement"] @ j["M"]
                 m.frames.append(dict(name=j["name"], parent=pf["parent"], placement=pl, type="fixed_joint"))
                 m.frames.append(dict(name=j["child"], parent=pf["parent"], placement=pl, type="body"))
-            elif j["type"] in ("revolute", "prismatic"):
+            elif j["type"] in ("revolute", "prismatic", "continuous"):
                 a = np.asarray(j["axis"], float)
                 a = a / np.linalg.norm(a) if not any(np.array_equal(a, e) for e in np.eye(3)) else a
-                jt = J_REVOLUTE if j["type"] == "revolute" else J_PRISMATIC
+                jt = {"revolute": J_REVOLUTE, "prismatic": J_PRISMATIC, "continuous": J_REVOLUTE_UNBOUNDED}[j["type"]]
                 jid = add_joint(pf["parent"], jt, pf["placement"] @ j["M"], j["name"], a, j["lo"], j["hi"])
                 m.frames.append(dict(name=j["name"], parent=jid, placement=np.eye(4), type="joint"))
                 m.frames.append(dict(name=j["child"], parent=jid, placement=np.eye(4), type="body"))
@@ -415,6 +420,8 @@ def neutral(m):
     for j in range(1, m.njoints):
         if m.jtype[j] == J_FREEFLYER:
             q[m.idx_q[j] + 6] = 1.0
+        if m.jtype[j] == J_REVOLUTE_UNBOUNDED:
+            q[m.idx_q[j]] = 1.0
     return q
 
 
@@ -426,6 +433,8 @@ def joint_transform(m, j, q):
     iq = m.idx_q[j]
     if t == J_REVOLUTE:
         return se3(axis_rotation(m.axis[j], math.cos(q[iq]), math.sin(q[iq])), np.zeros(3))
+    if t == J_REVOLUTE_UNBOUNDED:
+        return se3(axis_rotation(m.axis[j], q[iq], q[iq + 1]), np.zeros(3))
     if t == J_PRISMATIC:
         return se3(np.eye(3), m.axis[j] * q[iq])
     if t == J_FREEFLYER:
@@ -449,7 +458,7 @@ def joint_jacobians_world(m, oMi):
     for j in range(1, m.njoints):
         R, p = oMi[j][:3, :3], oMi[j][:3, 3]
         iv = m.idx_v[j]
-        if m.jtype[j] == J_REVOLUTE:
+        if m.jtype[j] in (J_REVOLUTE, J_REVOLUTE_UNBOUNDED):
             w = R @ m.axis[j]
             J[:3, iv] = np.cross(p, w)
             J[3:, iv] = w
@@ -497,6 +506,10 @@ def integrate(m, q, v):
                 rq = -rq
             rq = rq * ((3.0 - float(np.dot(rq, rq))) / 2.0)
             out[iq + 3:iq + 7] = rq
+        elif m.jtype[j] == J_REVOLUTE_UNBOUNDED:
+            cv, sv = math.cos(v[iv]), math.sin(v[iv])
+            pair = np.array([cv * q[iq] - sv * q[iq + 1], sv * q[iq] + cv * q[iq + 1]])
+            out[iq:iq + 2] = pair * ((3.0 - float(np.dot(pair, pair))) / 2.0)
         else:
             out[iq] = q[iq] + v[iv]
     return out

@@ -129,8 +129,8 @@ BAD = {
     "wrong root": (b"<model/>", "must be <robot>"),
     "mismatched tag": (b"<robot><link name='a'></robot>", "mismatched end tag"),
     "no links": (b"<robot name='r'/>", "no links"),
-    "continuous joint": (b"<robot><link name='a'/><link name='b'/><joint name='j' type='continuous'><parent link='a'/>"
-                         b"<child link='b'/><axis xyz='0 0 1'/></joint></robot>", "unsupported URDF joint type"),
+    "planar joint": (b"<robot><link name='a'/><link name='b'/><joint name='j' type='planar'><parent link='a'/>"
+                     b"<child link='b'/><axis xyz='0 0 1'/></joint></robot>", "unsupported URDF joint type"),
     "unknown link": (b"<robot><link name='a'/><joint name='j' type='fixed'><parent link='a'/><child link='zz'/></joint></robot>",
                      "unknown link"),
     "two roots": (b"<robot><link name='a'/><link name='b'/></robot>", "more than one root"),
