@@ -53,6 +53,28 @@ struct ChainStruct {
         return offset(i) + ngen_before(i, 9) + (k > 0 && tnz(i, 0) ? 1 : 0) + (k > 1 && tnz(i, 1) ? 1 : 0);
     }
     static constexpr double literal(int i, int e) { return ent(i, e) == kEntOne ? 1.0 : (ent(i, e) == kEntMinusOne ? -1.0 : 0.0); }
+    // Joint j (>= 1) turns about the SAME world axis as joint j - 1 when its placement has an exactly-identity rotation (R * Rz leaves
+    // the third column of R alone).  leader(j): the first joint of j's run of parallel axes; members(L): how many joints L leads.
+    static constexpr bool identity_rotation(int i) {
+        return ent(i, 0) == kEntOne && ent(i, 4) == kEntOne && ent(i, 8) == kEntOne && ent(i, 1) == kEntZero && ent(i, 2) == kEntZero &&
+               ent(i, 3) == kEntZero && ent(i, 5) == kEntZero && ent(i, 6) == kEntZero && ent(i, 7) == kEntZero;
+    }
+    static constexpr int leader(int j) { return (j > 0 && identity_rotation(j)) ? leader(j - 1) : j; }
+    static constexpr int members(int L, int nj) { return nj <= 0 ? 0 : members(L, nj - 1) + (leader(nj - 1) == L ? 1 : 0); }
+};
+
+// leader / members as compile-time tables (indexed by the unrolled joint loops: a constant index into a constant array folds;
+// the recursive constexpr functions above, called with a loop variable, would be emitted as real calls)
+template <class S, int NJ>
+struct ChainRuns {
+    struct Table { int leader[8], members[8]; };
+    static constexpr Table make() {
+        Table t{};
+        for (int j = 0; j < 8; ++j) { t.leader[j] = j < NJ ? S::leader(j) : j; t.members[j] = 0; }
+        for (int j = 0; j < NJ; ++j) ++t.members[t.leader[j]];
+        return t;
+    }
+    static constexpr Table value = make();
 };
 
 constexpr int kHotTableMax = 64;  // doubles in the kernel-argument copy of the compact table (values, then lo[NJ], hi[NJ])
@@ -103,7 +125,7 @@ IKD_FN void hot_evaluate(const Tab &t, const double (&q)[NJ], const double (&oMt
     // the NJ sin / cos first: independent of the chain, the constants are live once
     double sn[NJ], cs[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) dsincos_fast(q[j], sn[j], cs[j]);
+    for (int j = 0; j < NJ; ++j) dsincos_hot(q[j], sn[j], cs[j]);
 
 #define IKD_HOT_JOINT(J)                                                   \
     if (J < NJ) {                                                          \
@@ -162,6 +184,7 @@ IKD_FN void hot_dls(const Tab &t, const LoopParams &prm, double (&q)[NJ], const 
                     bool &success_out, AnyFn any_active) {
     constexpr int M = 6;
     constexpr int kLim = S::offset(NJ + 1);  // lo[NJ], hi[NJ] follow the placement values
+    constexpr typename ChainRuns<S, NJ>::Table kRuns = ChainRuns<S, NJ>::value;
     bool active = true;
     bool success = false;
     int iters = prm.max_iterations;
@@ -170,9 +193,26 @@ IKD_FN void hot_dls(const Tab &t, const LoopParams &prm, double (&q)[NJ], const 
         double e[M], col[NJ][M];
         hot_evaluate<NJ, S>(t, q, oMt, e, col);
 
+        // Gram matrix.  Joints of one run of parallel axes (S::leader) share their bottom (angular) rows: col[j][3..5] = A Rf^T z_j is
+        // the same vector for all of them, so  sum_j col[j][3+a] col[j][3+b] = n c_a c_b  and  sum_j col[j][3+a] col[j][b] =
+        // c_a (sum_j col[j][b])  within a run -- 102 instead of 147 multiply-adds for a Cassie leg (runs of 1, 1 and 5 joints).
         double G[M * M];
+        double top_sum[NJ][3], nbot[NJ][3];
 #pragma unroll
-        for (int a = 0; a < M; ++a)
+        for (int j = 0; j < NJ; ++j) {
+            if (kRuns.leader[j] == j) {
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    top_sum[j][b] = col[j][b];
+                    nbot[j][b] = kRuns.members[j] > 1 ? static_cast<double>(kRuns.members[j]) * col[j][3 + b] : col[j][3 + b];
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < 3; ++b) top_sum[kRuns.leader[j]][b] += col[j][b];
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
 #pragma unroll
             for (int b = 0; b <= a; ++b) {
                 double s = (a == b) ? prm.lam2 : 0.0;
@@ -180,6 +220,25 @@ IKD_FN void hot_dls(const Tab &t, const LoopParams &prm, double (&q)[NJ], const 
                 for (int j = 0; j < NJ; ++j) s = dfma(col[j][a], col[j][b], s);
                 G[a * M + b] = s;
             }
+#pragma unroll
+        for (int a = 3; a < 6; ++a) {
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                double s = 0.0;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    if (kRuns.leader[j] == j) s = dfma(col[j][a], top_sum[j][b], s);
+                G[a * M + b] = s;
+            }
+#pragma unroll
+            for (int b = 3; b <= a; ++b) {
+                double s = (a == b) ? prm.lam2 : 0.0;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    if (kRuns.leader[j] == j) s = dfma(nbot[j][a - 3], col[j][b], s);
+                G[a * M + b] = s;
+            }
+        }
         double y[M];
         chol_solve<M>(G, e, y);
 
@@ -193,11 +252,15 @@ IKD_FN void hot_dls(const Tab &t, const LoopParams &prm, double (&q)[NJ], const 
             if (stop_now) { success = true; iters = it; }
             active = active && !stop_now;
         }
+        double ang[NJ];   // the angular part of col_j^T y, shared by a run of parallel axes
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            if (kRuns.leader[j] == j) ang[j] = dfma(col[j][3], y[3], dfma(col[j][4], y[4], col[j][5] * y[5]));
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            double s = 0.0;
+            double s = ang[kRuns.leader[j]];
 #pragma unroll
-            for (int a = 0; a < M; ++a) s = dfma(col[j][a], y[a], s);
+            for (int a = 0; a < 3; ++a) s = dfma(col[j][a], y[a], s);
             const double qn = dfma(prm.step_length, s, q[j]);  // dq_j = -J_task(:, j)^T y = +col_j^T y
             const double qc = dmin(t.v[kLim + NJ + j], dmax(qn, t.v[kLim + j]));
             q[j] = (NEVERSTOP || active) ? qc : q[j];

@@ -63,6 +63,18 @@ constexpr double kTaylorPrec3 = 1.220703125e-4;  // 2^-13 exactly == (2^-52)^(1/
 constexpr double kPi = 3.141592653589793238462643383279502884;
 
 IKD_FN double dfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// a * b + c as ONE three-address v_fma_f64 whatever the register allocation: for a Horner step whose addend is a constant that
+// lives in a VGPR across the loop hipcc emits v_mov_b64 (8 cycles of issue) + v_fmac_f64 (the two-address form needs the addend in
+// its destination); the explicit form has no copy.  Only where that pattern was seen in the listing (the acos polynomials).
+IKD_FN double dfma3(double a, double b, double c) {
+#if IKD_ON_DEVICE
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+#else
+    return __builtin_fma(a, b, c);
+#endif
+}
 IKD_FN double dsel(bool c, double a, double b) { return c ? a : b; }
 IKD_FN double dmin(double a, double b) { return __builtin_fmin(a, b); }
 IKD_FN double dmax(double a, double b) { return __builtin_fmax(a, b); }
@@ -180,6 +192,43 @@ IKD_FN void dsincos_fast(double x, double &s_out, double &c_out) {
     double r = dfma(-k, kTwoPiHi, x);
     r = dfma(-k, kTwoPiLo, r);
     dsincos_bounded<2>(r, s_out, c_out);
+}
+
+// sin and cos for the headline loop (device/chain_hot.hpp): dsincos_fast with two instructions less per call.
+//  * the reduction by 2 pi drops the low word of the constant: the angle then carries an error of |x| * 3.9e-17 -- below half an
+//    ulp of x itself (a joint angle inside its limits: < 2.5e-16 rad), invisible next to the 2e-15 of the kernels;
+//  * no division of the reduced angle by 4: the fdlibm kernels are evaluated at t = r / 4 through coefficients scaled by exact
+//    powers of two -- sin t = r (1/4 + z' Q(z')), cos t = 1 + z' (-1/32 + z' C(z')), z' = r^2 -- so every Horner intermediate is
+//    2^m times the one of dsincos_bounded<2> (same mantissa bits), then the two angle doublings.
+IKD_FN void dsincos_hot(double x, double &s_out, double &c_out) {
+    constexpr double kOneOverTwoPi = 0.15915494309189533577;
+    constexpr double kTwoPiHi = 6.28318530717958623200e+00;
+    const double k = __builtin_rint(x * kOneOverTwoPi);
+    const double r = dfma(-k, kTwoPiHi, x);
+    const double z = r * r;   // = 16 t^2
+    // S_k / (64 * 16^(k-1)),  k = 1..6
+    double ps = dfma(z, 1.58969099521155010221e-10 / 67108864.0, -2.50507602534068634195e-08 / 4194304.0);
+    ps = dfma(z, ps, 2.75573137070700676789e-06 / 262144.0);
+    ps = dfma(z, ps, -1.98412698298579493134e-04 / 16384.0);
+    ps = dfma(z, ps, 8.33333333332248946124e-03 / 1024.0);
+    ps = dfma(z, ps, -1.66666666666666324348e-01 / 64.0);
+    double s = r * dfma(z, ps, 0.25);
+    // C_k / (256 * 16^(k-1)),  k = 1..6
+    double pc = dfma(z, -1.13596475577881948265e-11 / 268435456.0, 2.08757232129817482790e-09 / 16777216.0);
+    pc = dfma(z, pc, -2.75573143513906633035e-07 / 1048576.0);
+    pc = dfma(z, pc, 2.48015872894767294178e-05 / 65536.0);
+    pc = dfma(z, pc, -1.38888888888741095749e-03 / 4096.0);
+    pc = dfma(z, pc, 4.16666666666666019037e-02 / 256.0);
+    double c = dfma(z, dfma(z, pc, -0.03125), 1.0);
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const double a = s + s;
+        const double s2 = a * c;
+        c = dfma(-a, s, 1.0);
+        s = s2;
+    }
+    s_out = s;
+    c_out = c;
 }
 
 // acos on [-1, 1] (fdlibm e_acos rational approximation, divisions by drcp).
@@ -395,15 +444,15 @@ IKD_FN void log6_and_jlog6_hot(const double (&Re)[9], const double (&pe)[3], Log
     const double z = dfma(-0.5, x, 0.5);       // (1 - cos theta)/2 = sin^2(theta/2)
     const double zc = dfma(0.5, x, 0.5);       // (1 + cos theta)/2 = cos^2(theta/2) = 1 - z
     const double za = mid ? x * x : dfma(-0.5, ax, 0.5);
-    double pp_ = dfma(za, pS5, pS4);
-    pp_ = dfma(za, pp_, pS3);
-    pp_ = dfma(za, pp_, pS2);
-    pp_ = dfma(za, pp_, pS1);
-    pp_ = dfma(za, pp_, pS0);
+    double pp_ = dfma3(za, pS5, pS4);
+    pp_ = dfma3(za, pp_, pS3);
+    pp_ = dfma3(za, pp_, pS2);
+    pp_ = dfma3(za, pp_, pS1);
+    pp_ = dfma3(za, pp_, pS0);
     pp_ = pp_ * za;
-    double qq = dfma(za, qS4, qS3);
-    qq = dfma(za, qq, qS2);
-    qq = dfma(za, qq, qS1);
+    double qq = dfma3(za, qS4, qS3);
+    qq = dfma3(za, qq, qS2);
+    qq = dfma3(za, qq, qS1);
     qq = dfma(za, qq, 1.0);
     const double rr = pp_ * drcp(qq);
     const double sa = dsqrt(za);

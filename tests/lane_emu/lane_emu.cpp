@@ -193,10 +193,11 @@ extern "C" {
 
 const char *lane_emu_last_error(void) { return g_err.c_str(); }
 
-// The device's sin / cos routines (device/lane_math.hpp): D = 0: dsincos, D = 1: dsincos_fast, D = 2 / 3: dsincos_bounded<D>.
+// The device's sin / cos routines (device/lane_math.hpp): D = 0: dsincos, D = 1: dsincos_fast, D = 2 / 3: dsincos_bounded<D>, D = 4: dsincos_hot.
 void lane_emu_sincos(int D, int64_t n, const double *x, double *s, double *c) {
     for (int64_t i = 0; i < n; ++i) {
         if (D == 1) ikdev::dsincos_fast(x[i], s[i], c[i]);
+        else if (D == 4) ikdev::dsincos_hot(x[i], s[i], c[i]);
         else if (D == 2) ikdev::dsincos_bounded<2>(x[i], s[i], c[i]);
         else if (D == 3) ikdev::dsincos_bounded<3>(x[i], s[i], c[i]);
         else ikdev::dsincos(x[i], s[i], c[i]);

@@ -99,6 +99,13 @@ def test_device_sincos_accuracy(emu):
         emu.lane_emu_sincos(D, C.c_int64(x.size), p(x), p(s), p(c))
         assert np.abs(s - np.sin(x)).max() < 2e-15 and np.abs(c - np.cos(x)).max() < 2e-15, D
         assert np.abs(s * s + c * c - 1.0).max() < 5e-15
+    # dsincos_hot (the headline loop): the reduction keeps one word of 2 pi, so its error grows with the angle, 3.9e-17 |x| -- less
+    # than half an ulp of x; within +-2 pi (every joint limit of the fixture models) it meets the same 2e-15
+    for lim, bar in ((2 * np.pi + 0.05, 2e-15), (50.0, 2e-15 + 50.0 * 4e-17), (3000.0, 2e-15 + 3000.0 * 4e-17)):
+        x = np.concatenate([np.linspace(-lim, lim, 400001), [0.0, -0.0, 1e-300, np.pi / 4, -np.pi / 2, np.pi]])
+        s, c = np.empty_like(x), np.empty_like(x)
+        emu.lane_emu_sincos(4, C.c_int64(x.size), p(x), p(s), p(c))
+        assert np.abs(s - np.sin(x)).max() < bar and np.abs(c - np.cos(x)).max() < bar, lim
     s0, c0 = np.empty(1), np.empty(1)
     emu.lane_emu_sincos(2, C.c_int64(1), p(np.zeros(1)), p(s0), p(c0))
     assert s0[0] == 0.0 and c0[0] == 1.0
