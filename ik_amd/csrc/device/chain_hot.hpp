@@ -149,7 +149,8 @@ IKD_FN void hot_evaluate(const Tab &t, const double (&q)[NJ], const double (&oMt
         rotT_vec(R, dp, pe);
     }
     LogAndJlog lj;
-    log6_and_jlog6_hot(Re, pe, lj);
+    double Cm[9];
+    log6_and_jlog6_hot<false>(Re, pe, lj, &Cm);
 #pragma unroll
     for (int i = 0; i < 6; ++i) e[i] = lj.e[i];
 
@@ -160,8 +161,13 @@ IKD_FN void hot_evaluate(const Tab &t, const double (&q)[NJ], const double (&oMt
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             AR[3 * i + k] = dfma(lj.A[3 * i], R[3 * k], dfma(lj.A[3 * i + 1], R[3 * k + 1], lj.A[3 * i + 2] * R[3 * k + 2]));
-            BR[3 * i + k] = dfma(lj.Bm[3 * i], R[3 * k], dfma(lj.Bm[3 * i + 1], R[3 * k + 1], lj.Bm[3 * i + 2] * R[3 * k + 2]));
         }
+    // (C A) Rf^T = C (A Rf^T): the product C A itself is never formed
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            BR[3 * i + k] = dfma(Cm[3 * i], AR[k], dfma(Cm[3 * i + 1], AR[3 + k], Cm[3 * i + 2] * AR[6 + k]));
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const double dj[3] = {org[j][0] - p[0], org[j][1] - p[1], org[j][2] - p[2]};

@@ -428,7 +428,10 @@ IKD_FN void log6_and_jlog6_inv(const double (&Re)[9], const double (&pe)[3], Log
 //  * ONE reciprocal instead of three: with h = sin(theta)/2 = sqrt(z (1 - z)), z = (1 - cos theta)/2, r = 1 / (theta h) gives
 //    1/theta = r h and 1/h = r theta, and sin/(1 - cos) = cot(theta/2) = (1 - z)/h, 1/(1 - cos) = (1 - z)/(2 h^2).
 // Four FP64 transcendentals (16 cycles of issue each) instead of seven.  Results differ from the other front end by rounding only.
-IKD_FN void log6_and_jlog6_hot(const double (&Re)[9], const double (&pe)[3], LogAndJlog &o) {
+// WITH_BM = false: o.Bm is left unset and C is returned instead -- a caller that goes on to multiply by the frame rotation forms
+// (C A) Rf^T as C (A Rf^T) and saves the 27 multiply-adds of C A (device/chain_hot.hpp).
+template <bool WITH_BM = true>
+IKD_FN void log6_and_jlog6_hot(const double (&Re)[9], const double (&pe)[3], LogAndJlog &o, double (*Cout)[9] = nullptr) {
     constexpr double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17;
     constexpr double pS0 = 1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01,
                      pS2 = 2.01212532134862925881e-01, pS3 = -4.00555345006794114027e-02,
@@ -532,11 +535,16 @@ IKD_FN void log6_and_jlog6_hot(const double (&Re)[9], const double (&pe)[3], Log
     C[1] -= 0.5 * pp[2]; C[2] += 0.5 * pp[1];
     C[3] += 0.5 * pp[2]; C[5] -= 0.5 * pp[0];
     C[6] -= 0.5 * pp[1]; C[7] += 0.5 * pp[0];
+    if (WITH_BM) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-            o.Bm[3 * i + j] = dfma(C[3 * i], o.A[j], dfma(C[3 * i + 1], o.A[3 + j], C[3 * i + 2] * o.A[6 + j]));
+            for (int j = 0; j < 3; ++j)
+                o.Bm[3 * i + j] = dfma(C[3 * i], o.A[j], dfma(C[3 * i + 1], o.A[3 + j], C[3 * i + 2] * o.A[6 + j]));
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) (*Cout)[k] = C[k];
+    }
 }
 
 // In-place Cholesky of the SPD matrix held in the lower triangle of G (row-major M x M, only

@@ -146,19 +146,25 @@ IKD_FN void task_terms(const double (&Rf)[9], const double (&pf)[3], const doubl
     const double dp[3] = {oMt[9] - pf[0], oMt[10] - pf[1], oMt[11] - pf[2]};
     rotT_vec(Rf, dp, pe);
     LogAndJlog lj;
-    log6_and_jlog6_hot(Re, pe, lj);   // the branch-free, one-reciprocal front end (lane_math.hpp): full body 0.84 -> 0.81 ms
+    double Cm[9];
+    log6_and_jlog6_hot<false>(Re, pe, lj, &Cm);   // the branch-free, one-reciprocal front end (lane_math.hpp): full body 0.84 -> 0.81 ms
     // K' = +diag(w) Jlog6(tMf): the task Jacobian is carried NEGATED (J' = -J_task); H = J'^T J' is unchanged and
     // the right-hand side becomes g' = J'^T e = -J_task^T e, so the system solved is H dq = g'.
+    // Jlog6's top-right block is C A: (C A) Rf^T is formed as C (A Rf^T), the product C A itself never (27 multiply-adds less), and
+    // the weights scale the rows of the two products afterwards instead of the factors before.
+    double AR[9], CAR[9];
+    mul_RT(lj.A, Rf, AR);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) CAR[3 * i + k] = dfma(Cm[3 * i], AR[k], dfma(Cm[3 * i + 1], AR[3 + k], Cm[3 * i + 2] * AR[6 + k]));
     if (unit) {  // wave-uniform: Full task, all weights exactly 1
 #pragma unroll
         for (int k = 0; k < 6; ++k) t.e[k] = lj.e[k];
-        mul_RT(lj.A, Rf, t.At);
-        mul_RT(lj.Bm, Rf, t.Bt);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) t.Ab[k] = t.At[k];
+        for (int k = 0; k < 9; ++k) { t.At[k] = AR[k]; t.Bt[k] = CAR[k]; t.Ab[k] = AR[k]; }
         return;
     }
-    double A_t[9], B_t[9], A_b[9];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const double wt = w6[i], wb = w6[3 + i];
@@ -166,14 +172,11 @@ IKD_FN void task_terms(const double (&Rf)[9], const double (&pf)[3], const doubl
         t.e[3 + i] = lj.e[3 + i] * wb;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            A_t[3 * i + j] = wt * lj.A[3 * i + j];
-            B_t[3 * i + j] = wt * lj.Bm[3 * i + j];
-            A_b[3 * i + j] = wb * lj.A[3 * i + j];
+            t.At[3 * i + j] = wt * AR[3 * i + j];
+            t.Bt[3 * i + j] = wt * CAR[3 * i + j];
+            t.Ab[3 * i + j] = wb * AR[3 * i + j];
         }
     }
-    mul_RT(A_t, Rf, t.At);
-    mul_RT(B_t, Rf, t.Bt);
-    mul_RT(A_b, Rf, t.Ab);
 }
 
 // (Negated) task Jacobian columns of the six free-flyer DoFs: J_local = Ad(oMf^-1 oM1).
