@@ -67,6 +67,14 @@ WORKLOADS = {
                                 posture=dict(nj=16, priority=1, weight=0.05),
                                 text="Cassie demo task set (foot position w.r.t. the pelvis, pelvis SE(3) pose, foot Y-axis alignment) + a "
                                      "PostureTask on all 16 joints at priority 1, weight 0.05 (M=26)"),
+    # ... with the right foot pinned by a FrameConstraint (the demo's commented-out intent, cassie.cpp:49-51,74-75): the tree kernel's
+    # constraint build (reference ik/ik/dls.cpp:26-34,43-53)
+    "cassie_demo_pinned": dict(urdf="cassie", free_flyer=True, frames=["LeftFootFront", "pelvis", "LeftFootFront"], nq=23,
+                               tasks=[("frame", "LeftFootFront", 0, "pelvis"), ("frame", "pelvis", 2, "universe"),
+                                      ("align", "LeftFootFront", 1, "universe")],
+                               constraint=("RightFootFront", 0, "universe"),
+                               text="Cassie demo task set (foot position w.r.t. the pelvis, pelvis SE(3) pose, foot Y-axis alignment) with the "
+                                    "right foot's position held by a FrameConstraint (3 constraint rows)"),
     # the same tasks through the reference's other solver, ik::pik (reference ik/ik/pik.cpp:31-103): the alignment row at
     # priority 1, solved in the null space of the two pose tasks; damping factor 0.1 per level
     "cassie_demo_pik": dict(urdf="cassie", free_flyer=True, frames=["LeftFootFront", "pelvis", "LeftFootFront"], nq=23,
@@ -155,7 +163,7 @@ def make_inputs(name, model, idx):
     from ik_amd import workload
     w = WORKLOADS[name]
     lo, hi = model.lowerPositionLimit, model.upperPositionLimit
-    if name in ("cassie_full_body", "cassie_demo", "cassie_demo_pik", "cassie_demo_posture"):
+    if name in ("cassie_full_body", "cassie_demo", "cassie_demo_pik", "cassie_demo_posture", "cassie_demo_pinned"):
         return workload.freeflyer_workload(lo, hi, workload.cassie_nominal(model.names), idx, seed=0, mode="near")
     if name in ("ur5", "ur10"):
         return workload.chain_workload(lo, hi, workload.UR5_NOMINAL, idx, seed=0, mode="near")
@@ -186,6 +194,13 @@ def cpu_baseline(model, xml, w, q0_np, tg_np, iters, budget_s=10.0):
     if w.get("solver") == "pik":
         prm = O.pik_params(iters, 1.0, -1.0, w["lam"])
         solve = O.pik_batch
+    elif w.get("constraint"):
+        prm = O.params(iters, 1e-2, 1.0, -1.0)
+        cf, ct, cr = w["constraint"]
+        cons = O.make_tasks([(model.getFrameId(cf), model.getFrameId(cr), ct, 0, None)])
+
+        def solve(om_, tasks_, tg_, q0_, prm_, threads):
+            return O.dls_batch_constrained(om_, tasks_, cons, tg_, q0_, prm_, threads)
     else:
         prm = O.params(iters, 1e-2, 1.0, -1.0)
         solve = O.dls_batch
@@ -281,6 +296,9 @@ def main():
             problem.add_align_axis_task("t%d" % i, ik_amd.AlignAxisTask.create(model, f, ik_amd.AlignAxisType(t), r), prio)
         else:
             problem.add_frame_task("t%d" % i, ik_amd.FrameTask.create(model, f, ik_amd.KinematicType(t), r), prio)
+    if w.get("constraint"):
+        cf, ct, cr = w["constraint"]
+        problem.add_frame_constraint("pinned", ik_amd.FrameConstraint.create(model, cf, ik_amd.KinematicType(ct), cr))
     if w.get("posture"):
         posture = problem.add_posture_task("posture", ik_amd.PostureTask.create(model, w["posture"]["nj"]), w["posture"]["priority"])
         posture.weighting()[:] = w["posture"]["weight"]
@@ -493,6 +511,8 @@ def main():
                     p2.add_align_axis_task("t%d" % i, ik_amd.AlignAxisTask.create(m2, f, ik_amd.AlignAxisType(tt), r))
                 else:
                     p2.add_frame_task("t%d" % i, ik_amd.FrameTask.create(m2, f, ik_amd.KinematicType(tt), r))
+            if w.get("constraint"):
+                p2.add_frame_constraint("pinned", ik_amd.FrameConstraint.create(m2, w["constraint"][0], ik_amd.KinematicType(w["constraint"][1]), w["constraint"][2]))
             d2 = ik_amd.dls_data(p2, device=local_rank)
             res["model_load"] = {"urdf_parse_ms": t_parse * 1e3, "urdf_to_device_handle_ms": (time.perf_counter() - t) * 1e3,
                                  "kernel": d2.kernel}

@@ -253,7 +253,7 @@ struct ChainPosture {
     int64_t t_stride;
 };
 
-template <int NJ, bool FAST = false, bool POST = false, class PlPtr, class FrPtr, class WPtr>
+template <int NJ, bool FAST = false, bool POST = false, bool PIK = false, class PlPtr, class FrPtr, class WPtr>
 IKD_FN void leg_eval_factor(const double (&R1)[9], const double (&p1)[3], PlPtr pl, FrPtr frame_pl,
                             WPtr w6, int idmask, bool unit, const double (&q)[NJ], const double (&oMt)[12],
                             double lam2, bool prio0, const AlignRow &al, const ChainPosture &po, double (&Hbb)[21],
@@ -302,6 +302,79 @@ IKD_FN void leg_eval_factor(const double (&R1)[9], const double (&p1)[3], PlPtr 
             col[j][3 + i] = dfma(t.Ab[3 * i], zax[j][0], dfma(t.Ab[3 * i + 1], zax[j][1], t.Ab[3 * i + 2] * zax[j][2]));
         }
     }
+    if (PIK && al.on && al.pik) {   // level 1 of ik::pik (wave-uniform; PIK builds only), see PikRow.  Done here, while the chain
+                                    // columns are live and the factor is not yet: the basis V costs 42 registers
+        const double r[3] = {al.ax == 0 ? R[0] : (al.ax == 1 ? R[1] : R[2]), al.ax == 0 ? R[3] : (al.ax == 1 ? R[4] : R[5]),
+                             al.ax == 0 ? R[6] : (al.ax == 1 ? R[7] : R[8])};
+        double rxt[3], aj[NJ], ab[3];
+        cross(r, al.tn, rxt);
+        const double ea = (1.0 - dot(r, al.tn)) * al.w;
+        if (al.prio0) e0sq = dfma(ea, ea, e0sq);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) aj[j] = al.w * dot(rxt, zax[j]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double rc[3] = {R1[c], R1[3 + c], R1[6 + c]};
+            ab[c] = al.w * dot(rxt, rc);
+        }
+        // orthonormal basis of the row space of the chain task's chain columns (rows with weight zero -- a Position /
+        // Orientation task -- are skipped, wave-uniform), Gram-Schmidt with every projection applied twice, rank rule as in
+        // constraint_project; then abar = a - V^T V a, twice
+        double V[6][NJ];
+        double maxn2 = 0.0;
+        int rows = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            if (w6[r] == 0.0) continue;
+            ++rows;
+            double n2 = 0.0;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) { V[r][j] = col[j][r]; n2 = dfma(V[r][j], V[r][j], n2); }
+            maxn2 = dmax(maxn2, n2);
+        }
+        const double thr = 2.220446049250313e-16 * static_cast<double>(rows < NJ ? rows : NJ);
+        const double thr2 = thr * thr * maxn2;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            if (w6[k] == 0.0) continue;
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+                for (int i = 0; i < k; ++i) {
+                    if (w6[i] == 0.0) continue;
+                    double d = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) d = dfma(V[i][j], V[k][j], d);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) V[k][j] = dfma(-d, V[i][j], V[k][j]);
+                }
+            }
+            double n2 = 0.0;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) n2 = dfma(V[k][j], V[k][j], n2);
+            const double inv = dsel(n2 > thr2, drsqrt(dmax(n2, 1e-300)), 0.0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) V[k][j] = V[k][j] * inv;
+        }
+        pr.on = true;
+        pr.e = ea;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pr.b[c] = ab[c];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { pr.a[j] = aj[j]; pr.abar[j] = aj[j]; }
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                if (w6[k] == 0.0) continue;
+                double d = 0.0;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) d = dfma(V[k][j], pr.abar[j], d);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) pr.abar[j] = dfma(-d, V[k][j], pr.abar[j]);
+            }
+        }
+    }
     IKD_SCHED_FENCE();
     // H_ll (packed), H_lb -> W, g_l -> u
 #pragma unroll
@@ -326,7 +399,8 @@ IKD_FN void leg_eval_factor(const double (&R1)[9], const double (&p1)[3], PlPtr 
         for (int r = 0; r < 6; ++r) s = dfma(col[a][r], t.e[r], s);
         F.u[a] = s;
     }
-    if (al.on) {  // rank-one terms of the alignment row (wave-uniform; general builds only)
+    if (al.on && !(PIK && al.pik)) {  // rank-one terms of the alignment row (wave-uniform; general builds only).  A level-1 row of
+                                      // ik::pik stays out of the level-0 system: it became the PikRow above
         const double r[3] = {al.ax == 0 ? R[0] : (al.ax == 1 ? R[1] : R[2]), al.ax == 0 ? R[3] : (al.ax == 1 ? R[4] : R[5]),
                              al.ax == 0 ? R[6] : (al.ax == 1 ? R[7] : R[8])};
         double rxt[3], aj[NJ], ab[3];
@@ -340,65 +414,6 @@ IKD_FN void leg_eval_factor(const double (&R1)[9], const double (&p1)[3], PlPtr 
             const double rc[3] = {R1[c], R1[3 + c], R1[6 + c]};
             ab[c] = al.w * dot(rxt, rc);
         }
-        if (al.pik) {   // level 1 of ik::pik (wave-uniform): the row stays out of the level-0 system, see PikRow
-            // orthonormal basis of the row space of the chain task's chain columns (rows with weight zero -- a Position /
-            // Orientation task -- are skipped, wave-uniform), Gram-Schmidt with every projection applied twice, rank rule as in
-            // constraint_project; then abar = a - V^T V a, twice
-            double V[6][NJ];
-            double maxn2 = 0.0;
-            int rows = 0;
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                if (w6[r] == 0.0) continue;
-                ++rows;
-                double n2 = 0.0;
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) { V[r][j] = col[j][r]; n2 = dfma(V[r][j], V[r][j], n2); }
-                maxn2 = dmax(maxn2, n2);
-            }
-            const double thr = 2.220446049250313e-16 * static_cast<double>(rows < NJ ? rows : NJ);
-            const double thr2 = thr * thr * maxn2;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                if (w6[k] == 0.0) continue;
-#pragma unroll
-                for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-                    for (int i = 0; i < k; ++i) {
-                        if (w6[i] == 0.0) continue;
-                        double d = 0.0;
-#pragma unroll
-                        for (int j = 0; j < NJ; ++j) d = dfma(V[i][j], V[k][j], d);
-#pragma unroll
-                        for (int j = 0; j < NJ; ++j) V[k][j] = dfma(-d, V[i][j], V[k][j]);
-                    }
-                }
-                double n2 = 0.0;
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) n2 = dfma(V[k][j], V[k][j], n2);
-                const double inv = dsel(n2 > thr2, drsqrt(dmax(n2, 1e-300)), 0.0);
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) V[k][j] = V[k][j] * inv;
-            }
-            pr.on = true;
-            pr.e = ea;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) pr.b[c] = ab[c];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) { pr.a[j] = aj[j]; pr.abar[j] = aj[j]; }
-#pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    if (w6[k] == 0.0) continue;
-                    double d = 0.0;
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) d = dfma(V[k][j], pr.abar[j], d);
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) pr.abar[j] = dfma(-d, V[k][j], pr.abar[j]);
-                }
-            }
-        } else {
 #pragma unroll
         for (int a = 0; a < NJ; ++a) {
 #pragma unroll
@@ -412,7 +427,6 @@ IKD_FN void leg_eval_factor(const double (&R1)[9], const double (&p1)[3], PlPtr 
 #pragma unroll
             for (int b = 0; b <= a; ++b) Hbb[tri(3 + a, 3 + b)] = dfma(ab[a], ab[b], Hbb[tri(3 + a, 3 + b)]);
             gb[3 + a] = dfma(ab[a], ea, gb[3 + a]);
-        }
         }
     }
     if (POST && po.on) {  // posture rows on this chain's joints (wave-uniform; posture builds only)
@@ -669,7 +683,8 @@ IKD_FN void constraint_project(const double (&R1)[9], const double (&p1)[3], PlP
 // by the chains, bit kSpecUnit: the chain tasks are Full with unit weights, bit kSpecUnitP / kSpecIdP: the base task is
 // Full with unit weights / its frame placement is a pure translation.  SPEC = -1: runtime (wave-uniform) values.
 // Bit kSpecPost (alone: otherwise a general build): the posture code above is compiled in.
-constexpr int kSpecUnitP = 29, kSpecIdP = 28, kSpecPost = 26, kSpecCons = 25;
+// Bit kSpecCons / kSpecPik (alone): a general build with the FrameConstraint code / with level 1 of a two-level ik::pik.
+constexpr int kSpecUnitP = 29, kSpecIdP = 28, kSpecPost = 26, kSpecCons = 25, kSpecPik = 24;
 
 // Where the lane keeps the joints outside the chains that carry a posture row: its own column of the caller's q_out.
 struct PostureState {
@@ -726,7 +741,8 @@ template <int NJ, int NCH, int SPEC = -1, class Desc, class Park, class AnyFn>
 IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], double (&qj0)[NJ], double (&qj1)[NJ],
                      const double *targets_lane, int64_t tstride, const int (&tslot)[3], const PostureState &ps, int &iters_out,
                      bool &success_out, Park park, AnyFn any_active) {
-    constexpr bool kGeneral = SPEC <= 0 || SPEC == (1 << kSpecPost) || SPEC == (1 << kSpecCons);  // the demo's extras exist in the general builds only
+    constexpr bool kGeneral = SPEC <= 0 || SPEC == (1 << kSpecPost) || SPEC == (1 << kSpecCons) || SPEC == (1 << kSpecPik);  // the demo's extras exist in the general builds only
+    constexpr bool kPik = SPEC < 0 || SPEC == (1 << kSpecPik);  // the orthogonalisation behind PikRow costs the other builds registers
     constexpr bool kPost = SPEC < 0 || SPEC == (1 << kSpecPost);
     constexpr bool kCons = NCH > 1 && (SPEC < 0 || SPEC == (1 << kSpecCons));
     // (posture builds: a tail lane shadowing the last problem would re-read that problem's outside joints while their owner
@@ -791,13 +807,13 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
                                  tz = targets_lane[(prm.align_slot * 12 + 11) * tstride];
                     const double inv = drsqrt(dfma(tx, tx, dfma(ty, ty, tz * tz)));
                     al.on = true; al.ax = prm.align_axis; al.w = prm.align_w; al.prio0 = prm.align_prio == 0;
-                    al.pik = prm.pik_on != 0;
+                    al.pik = kPik && prm.pik_on != 0;
                     al.tn[0] = tx * inv; al.tn[1] = ty * inv; al.tn[2] = tz * inv;
                 }
             }
             const ChainPosture po{kPost && prm.post_on != 0, prm.post_prio == 0, prm.postc_slot[c], prm.postc_w[c], prm.postc_m[c],
                                   targets_lane, tstride, (NCH == 1 && ps.by_row) ? ps.t_chain : nullptr, ps.stride};
-            leg_eval_factor<NJ, (SPEC >= 0), kPost>(R1, p1, ct.pl, ct.fr, ct.w, SPEC >= 0 ? (SPEC & ((2 << NJ) - 1)) : prm.idmask[c],
+            leg_eval_factor<NJ, (SPEC >= 0), kPost, kPik>(R1, p1, ct.pl, ct.fr, ct.w, SPEC >= 0 ? (SPEC & ((2 << NJ) - 1)) : prm.idmask[c],
                                 SPEC >= 0 ? ((SPEC >> kSpecUnit) & 1) != 0 : prm.unit[c] != 0, q, oMt, prm.lam2, prm.prio[c] == 0, al,
                                 po, Hbb, gb, e0sq, F, pr);
             if (NCH > 1 && c == 0 && ntask_chains > 1) park.store(F);
@@ -846,7 +862,7 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
             if (NCH > 1 && c == 0 && ntask_chains > 1) park.load(F);
             double dql[NJ];
             leg_back_substitute<NJ>(F, dqb, dql);
-            if (kGeneral && prm.pik_on && pr.on && c == prm.align_chain) {   // level 1 of ik::pik, see PikRow (wave-uniform)
+            if (kPik && prm.pik_on && pr.on && c == prm.align_chain) {   // level 1 of ik::pik, see PikRow (wave-uniform)
                 // negated convention: a, b, abar hold -j, so  e_1 - j dq_0 = e + a . dq_chain + b . dq_base_angular  and
                 // dq_chain -= (-abar) (...) / (|abar|^2 + lambda_1^2)
                 double de = pr.e, n2 = prm.pik_lam2_1;

@@ -334,6 +334,8 @@ hipError_t run_dls_tree(const ProblemHost &ph, const DeviceTables &dt, const Bat
     const bool mask_only = !hot && !ph.tree_extras() && kMask != 0 && (a.prm.idmask[0] & kMask) == kMask && (NCH == 1 || (a.prm.idmask[1] & kMask) == kMask);
     if (hot) hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, kHot>), grid, dim3(kTreeBlock), 0, stream, a);
     else if (mask_only) hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, (kMask != 0 ? kMask : kHot)>), grid, dim3(kTreeBlock), 0, stream, a);
+    else if (pik_lambda1)   // two-level ik::pik (tree_takes_two_level_pik): the general build + the level-1 row's projection
+        hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, (1 << ikdev::kSpecPik)>), grid, dim3(kTreeBlock), 0, stream, a);
     else if (ph.cons_on) {   // one FrameConstraint on the second chain: the constraint build (general + the projection)
         if constexpr (NCH == 2) hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, (1 << ikdev::kSpecCons)>), grid, dim3(kTreeBlock), 0, stream, a);
         else return hipErrorInvalidValue;
