@@ -310,8 +310,87 @@ IKD_FN double coop_evaluate(const GenericTables &T, const CoopLayout &L, const i
 // generic_solver.hpp, with the same roundings -- one phase that turns the strict lower triangle into L by the pivots'
 // reciprocals (row m comes out as y = L^-1 rhs), then the column-oriented back substitution.  x is left at offx.  The pair
 // tables list the lower triangle by rows; row m contributes its first m entries.
+#if IKD_ON_DEVICE
+// The value x holds in lane N of this lane's group (a group is one DPP row of sixteen lanes: v_mov_b64_dpp row_newbcast)
+template <int N>
+IKD_FN double group_bcast(double x) { return __builtin_amdgcn_update_dpp(x, x, 0x150 + N, 0xf, 0xf, false); }
+
+// The same solve with the matrix in REGISTERS, one row per lane of the group (lane i: row i of the lower triangle; lane 15: the
+// right-hand side, riding along as row M), for M <= 15: the entries another lane needs come through DPP broadcasts, so the
+// factorisation has no LDS round trip and no barrier between its pivots (they were 30 % of the kernel: ~21 k cycles per
+// iteration at M = 10, bound by LDS latency; here ~400 issue slots).  Same operations in the same order on every entry as the
+// LDS form below -- L(i,k) = G(i,k) inv_k, G(i,j) -= L(i,k) L(j,k), x_k = (y_k - sum_{m > k, descending} L(m,k) x_m) inv_k -- so
+// the two agree bit for bit.  The back substitution runs redundantly in every lane (each broadcast reaches the whole group), so
+// x ends up replicated; lane 0 parks it at offx.  Ends on a barrier.
+template <int MMAX, int K, int J>
+IKD_FN void chol_regs_trail(double (&row)[16], const double lik) {   // G(i,j) -= L(i,k) L(j,k), j = K+1 .. MMAX-1 (rows past M hold zeros)
+    if constexpr (J < MMAX) {
+        row[J] = dfma(-lik, group_bcast<J>(lik), row[J]);
+        chol_regs_trail<MMAX, K, J + 1>(row, lik);
+    }
+}
+template <int MMAX, int K>
+IKD_FN void chol_regs_pivots(double (&row)[16], const int g, const int M) {
+    if constexpr (K < MMAX) {
+        if (K < M) {   // (wave-uniform)
+            const double inv = drsqrt(group_bcast<K>(row[K]));
+            const double lik = row[K] * inv;
+            row[K] = g == K ? inv : lik;       // lane K keeps 1 / L(K,K) where its diagonal entry was (nobody reads L(K,K) itself)
+            chol_regs_trail<MMAX, K, K + 1>(row, lik);
+        }
+        chol_regs_pivots<MMAX, K + 1>(row, g, M);
+    }
+}
+template <int Mm, int C>
+IKD_FN void chol_regs_sub(const double (&row)[16], double (&x)[16]) {   // x_c -= L(m,c) x_m, c = 0 .. m-1
+    if constexpr (C < Mm) {
+        x[C] = dfma(-group_bcast<Mm>(row[C]), x[Mm], x[C]);
+        chol_regs_sub<Mm, C + 1>(row, x);
+    }
+}
+template <int Mm>
+IKD_FN void chol_regs_back(const double (&row)[16], double (&x)[16], const int M) {
+    if constexpr (Mm >= 0) {
+        if (Mm < M) {
+            x[Mm] = x[Mm] * group_bcast<Mm>(row[Mm]);
+            chol_regs_sub<Mm, 0>(row, x);
+        }
+        chol_regs_back<Mm - 1>(row, x, M);
+    }
+}
+template <int MMAX, int C>
+IKD_FN void chol_regs_rhs(const double (&row)[16], double (&x)[16]) {
+    if constexpr (C < MMAX) {
+        x[C] = group_bcast<15>(row[C]);
+        chol_regs_rhs<MMAX, C + 1>(row, x);
+    }
+}
+
+template <int MMAX>
+IKD_FN void coop_chol_solve_regs(const int g, double *ws, const int offG, const int offx, const int M) {
+    const int mine = g == 15 ? M : g;             // the row of the packed triangle this lane holds (lanes M .. 14: none, zeros)
+    const bool holds = g < M || g == 15;
+    double row[16], x[16];
+#pragma unroll
+    for (int j = 0; j < MMAX; ++j) row[j] = (holds && j <= mine && j < M) ? ws[offG + tri(mine, j)] : 0.0;
+    chol_regs_pivots<MMAX, 0>(row, g, M);         // after pivot k, row[k] holds L(i,k) (lane 15: y_k; lane k: 1 / L(k,k))
+    chol_regs_rhs<MMAX, 0>(row, x);               // back substitution, in every lane: x[c] starts as y_c ...
+    chol_regs_back<MMAX - 1>(row, x, M);          // ... takes -L(m,c) x_m for m = M-1 .. c+1, then inv_c
+    if (g == 0) {
+#pragma unroll
+        for (int k = 0; k < MMAX; ++k)
+            if (k < M) ws[offx + k] = x[k];
+    }
+    IKC_SYNC();
+}
+#endif
+
 IKD_FN void coop_chol_solve(const CoopLayout &L, const int g, double *ws, const int offG, const int offdinv, const int offx, const int M) {
     (void)g;
+#if IKD_ON_DEVICE
+    if (M <= 10) { coop_chol_solve_regs<10>(g, ws, offG, offx, M); return; }   // (wave-uniform; the trailing updates run to MMAX)
+    if (M <= 15) { coop_chol_solve_regs<15>(g, ws, offG, offx, M); return; }
+#endif
     const int npairs = tri(M, 0) + M;
     // ---- Cholesky, right-looking, ONE phase per pivot: column k stays unscaled while the trailing triangle takes its
     // update G(i,j) -= (G(i,k) inv)(G(j,k) inv) -- every entry receives its updates in the order m = 0, 1, ... of the

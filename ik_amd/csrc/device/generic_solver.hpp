@@ -32,33 +32,41 @@ IKD_FN void unbounded_integrate(double c0, double s0, double v, double &c1, doub
 }
 enum : int { GT_POSITION = 0, GT_ORIENTATION = 1, GT_FULL = 2, GT_ALIGN_X = 3, GT_POSTURE_ROW = 6, GT_COM = 7 };  // == ikgpu_kinematic_type
 
-// Read-only tables shared by all lanes (device global memory; host memory in the lane emulator).
-struct GenericTables {
+// Read-only tables shared by all lanes (device global memory; host memory in the lane emulator).  DP / IP: the pointer types --
+// plain pointers (host, and the cooperative kernels, which re-point them at LDS copies), or pointers into the constant address
+// space (GenericTablesK, the per-lane kernels): every table read there has a wave-uniform index, so it becomes a scalar load
+// (s_load into SGPRs, ~100 cycles from the scalar cache) instead of 64 lanes fetching one address through the vector memory
+// path -- measured at ~1 us per dependent load with one wave per SIMD, which was 3/4 of the per-lane program's time.
+template <class DP, class IP>
+struct GenericTablesT {
     int njoints, nq, nv, ntasks, M;
-    const int *jtype, *parent, *idx_q, *idx_v;  // [njoints]
-    const double *placement;                    // [njoints][12]
-    const double *axis;                         // [njoints][3]
-    const double *lower, *upper;                // [nq]
-    const int *t_type, *t_fjoint, *t_rjoint, *t_row, *t_dim, *t_prio;  // [ntasks]
-    const double *t_fpl, *t_rpl;                // [ntasks][12] frame / reference placement on their joints
-    const double *t_w;                          // [ntasks][6]
+    IP jtype, parent, idx_q, idx_v;  // [njoints]
+    DP placement;                    // [njoints][12]
+    DP axis;                         // [njoints][3]
+    DP lower, upper;                // [nq]
+    IP t_type, t_fjoint, t_rjoint, t_row, t_dim, t_prio;  // [ntasks]
+    DP t_fpl, t_rpl;                // [ntasks][12] frame / reference placement on their joints
+    DP t_w;                          // [ntasks][6]
     // workspace layout, in doubles per lane
     int off_q, off_oMi, off_Jw, off_e, off_J, off_G, off_y, off_dq, ws_words;
     // prioritised IK (pik_solver.hpp): rows of level l are [lvl_row0[l], lvl_row0[l + 1]); its workspace extends the one above
     int nlevels;
-    const int *lvl_row0;                        // [nlevels + 1]
+    IP lvl_row0;                        // [nlevels + 1]
     int off_P, off_Jb, off_de, ws_words_pik;
     // ik::FrameConstraint rows (ik/ik/frame.hpp:325-449), projected out of the DLS step (ik/ik/dls.cpp:26-34,43-53)
     int ncons, Mc;
-    const int *c_type, *c_fjoint, *c_rjoint, *c_row, *c_dim;  // [ncons]
-    const double *c_fpl, *c_rpl;                               // [ncons][12]
+    IP c_type, c_fjoint, c_rjoint, c_row, c_dim;  // [ncons]
+    DP c_fpl, c_rpl;                               // [ncons][12]
     int off_Jc;                                                // Mc x nv, inside the first ws_words words
     // ik::CentreOfMassTask (ik/ik/centre_of_mass.hpp:14-62): mass and lever of the bodies on each joint, subtree masses
     int has_com;
-    const double *j_mass, *j_lever, *j_submass;                // [njoints], [njoints][3], [njoints]
+    DP j_mass, j_lever, j_submass;                // [njoints], [njoints][3], [njoints]
     double inv_total_mass;
     int off_sf;                                                // first moments of the subtrees, 3 x njoints
 };
+using GenericTables = GenericTablesT<const double *, const int *>;
+using GenericTablesK = GenericTablesT<const IKD_CONST_AS double *, const IKD_CONST_AS int *>;  // (the same layout)
+
 
 struct Ws {  // word w of this lane
     double *base;
@@ -66,14 +74,16 @@ struct Ws {  // word w of this lane
     IKD_FN double &operator[](int w) const { return base[static_cast<int64_t>(w) * stride]; }
 };
 
-IKD_FN void g_se3_mul(const double *A, const double *B, double *C) {  // C = A * B, C may not alias
+template <class PA, class PB>
+IKD_FN void g_se3_mul(PA A, PB B, double *C) {  // C = A * B, C may not alias
     for (int i = 0; i < 3; ++i) {
         for (int j = 0; j < 3; ++j) C[3 * i + j] = dfma(A[3 * i], B[j], dfma(A[3 * i + 1], B[3 + j], A[3 * i + 2] * B[6 + j]));
         C[9 + i] = dfma(A[3 * i], B[9], dfma(A[3 * i + 1], B[10], dfma(A[3 * i + 2], B[11], A[9 + i])));
     }
 }
 
-IKD_FN void g_se3_inv_mul(const double *A, const double *B, double *C) {  // C = A^-1 * B
+template <class PA, class PB>
+IKD_FN void g_se3_inv_mul(PA A, PB B, double *C) {  // C = A^-1 * B
     const double d[3] = {B[9] - A[9], B[10] - A[10], B[11] - A[11]};
     for (int i = 0; i < 3; ++i) {
         for (int j = 0; j < 3; ++j) C[3 * i + j] = dfma(A[i], B[j], dfma(A[3 + i], B[3 + j], A[6 + i] * B[6 + j]));
@@ -82,7 +92,8 @@ IKD_FN void g_se3_inv_mul(const double *A, const double *B, double *C) {  // C =
 }
 
 // framesForwardKinematics (joints) + computeJointJacobians (ik/ik/data.cpp:28-30) into the workspace: q -> oMi, Jw.
-IKD_FN void generic_fk(const GenericTables &T, const Ws &ws) {
+template <class TB>
+IKD_FN void generic_fk(const TB &T, const Ws &ws) {
     {
         const double I[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
         for (int k = 0; k < 12; ++k) ws[T.off_oMi + k] = I[k];
@@ -90,7 +101,7 @@ IKD_FN void generic_fk(const GenericTables &T, const Ws &ws) {
     for (int j = 1; j < T.njoints; ++j) {
         double Mj[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0}, li[12], oP[12], oM[12];
         const int iq = T.idx_q[j], iv = T.idx_v[j], jt = T.jtype[j];
-        const double *a = T.axis + 3 * j;
+        const auto a = T.axis + 3 * j;
         if (jt == GJ_REVOLUTE || jt == GJ_REVOLUTE_UNBOUNDED) {
             double s, c;
             if (jt == GJ_REVOLUTE) dsincos(ws[T.off_q + iq], s, c);
@@ -143,11 +154,12 @@ IKD_FN void generic_fk(const GenericTables &T, const Ws &ws) {
 }
 
 // evaluate_problem_data (ik/ik/data.cpp:25-58) into the workspace: q -> oMi, Jw, et, Jt.  Returns ||e[0]||^2.
-IKD_FN double generic_evaluate(const GenericTables &T, const Ws &ws, const double *targets_lane, int64_t tstride) {
+template <class TB>
+IKD_FN double generic_evaluate(const TB &T, const Ws &ws, const double *targets_lane, int64_t tstride) {
     generic_fk(T, ws);
     if (T.has_com) {  // pinocchio::centerOfMass, backward pass: first moment of every subtree (the subtree masses are constants)
         for (int j = 1; j < T.njoints; ++j) {
-            const double *c = T.j_lever + 3 * j;
+            const auto c = T.j_lever + 3 * j;
             const double mj = T.j_mass[j];
             for (int i = 0; i < 3; ++i)
                 ws[T.off_sf + 3 * j + i] = mj * dfma(ws[T.off_oMi + 12 * j + 3 * i], c[0], dfma(ws[T.off_oMi + 12 * j + 3 * i + 1], c[1],
@@ -160,7 +172,7 @@ IKD_FN double generic_evaluate(const GenericTables &T, const Ws &ws, const doubl
     double e0sq = 0.0;
     for (int t = 0; t < T.ntasks; ++t) {
         const int fj = T.t_fjoint[t], rj = T.t_rjoint[t], type = T.t_type[t], row = T.t_row[t], dim = T.t_dim[t];
-        const double *w6 = T.t_w + 6 * t;
+        const auto w6 = T.t_w + 6 * t;
         if (type == GT_COM) {  // ik::CentreOfMassTask, ik/ik/centre_of_mass.hpp:33-45; jacobianCenterOfMass, ik/ik/data.cpp:31-34
             double oJ[12], oMr[12];
             for (int k = 0; k < 12; ++k) oJ[k] = ws[T.off_oMi + 12 * rj + k];
@@ -243,9 +255,11 @@ IKD_FN double generic_evaluate(const GenericTables &T, const Ws &ws, const doubl
         LogAndJlog lj;
         log6_and_jlog6_inv(Re, pe, lj);                 // frame.hpp:50-61, :162-166
         const int r0 = (type == GT_ORIENTATION) ? 3 : 0;
-        for (int r = 0; r < dim; ++r) {
-            const double e = lj.e[r0 + r] * w6[r];
-            ws[T.off_e + row + r] = e;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {   // (static register indices: a runtime index would put lj.e into scratch memory)
+            if (k < r0 || k >= r0 + dim) continue;
+            const double e = lj.e[k] * w6[k - r0];
+            ws[T.off_e + row + k - r0] = e;
             if (T.t_prio[t] == 0) e0sq = dfma(e, e, e0sq);
         }
         for (int j = fj; j > 0; j = T.parent[j]) {      // support of the frame's joint (getFrameJacobian, LOCAL)
@@ -264,7 +278,9 @@ IKD_FN double generic_evaluate(const GenericTables &T, const Ws &ws, const doubl
                               dfma(lj.Bm[3 * i], wl[0], dfma(lj.Bm[3 * i + 1], wl[1], lj.Bm[3 * i + 2] * wl[2])))));
                     out[3 + i] = -dfma(lj.A[3 * i], wl[0], dfma(lj.A[3 * i + 1], wl[1], lj.A[3 * i + 2] * wl[2]));
                 }
-                for (int r = 0; r < dim; ++r) ws[T.off_J + (row + r) * T.nv + c] = w6[r] * out[r0 + r];
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    if (k >= r0 && k < r0 + dim) ws[T.off_J + (row + k - r0) * T.nv + c] = w6[k - r0] * out[k];
             }
         }
     }
@@ -273,7 +289,8 @@ IKD_FN double generic_evaluate(const GenericTables &T, const Ws &ws, const doubl
 
 // Column c of pinocchio::getFrameJacobian(..., LOCAL) for a frame placed at (Rf, pf) in the world, from the world joint
 // Jacobian in the workspace: linear part vl, angular part wl.
-IKD_FN void local_column(const GenericTables &T, const Ws &ws, int c, const double (&Rf)[9], const double (&pf)[3], double (&vl)[3],
+template <class TB>
+IKD_FN void local_column(const TB &T, const Ws &ws, int c, const double (&Rf)[9], const double (&pf)[3], double (&vl)[3],
                          double (&wl)[3]) {
     double v[3] = {ws[T.off_Jw + c], ws[T.off_Jw + T.nv + c], ws[T.off_Jw + 2 * T.nv + c]};
     const double w[3] = {ws[T.off_Jw + 3 * T.nv + c], ws[T.off_Jw + 4 * T.nv + c], ws[T.off_Jw + 5 * T.nv + c]};
@@ -327,7 +344,8 @@ IKD_FN void jacobi_rows(const Ws &ws, int off_rows, int off_col, int m, int nv, 
 // ik::FrameConstraint::compute_jacobian (ik/ik/frame.hpp:413-449) for every constraint, into the workspace (Jc, Mc x nv):
 // the velocity of the frame relative to its reference frame, in the frame's local coordinates:
 //   Jc = J_frame(LOCAL) - Ad(fMr) J_reference(LOCAL),  rows by kinematic type.   Needs oMi and Jw (generic_fk).
-IKD_FN void generic_constraint_jacobian(const GenericTables &T, const Ws &ws) {
+template <class TB>
+IKD_FN void generic_constraint_jacobian(const TB &T, const Ws &ws) {
     for (int k = 0; k < T.ncons; ++k) {
         const int fj = T.c_fjoint[k], rj = T.c_rjoint[k], row = T.c_row[k], dim = T.c_dim[k];
         const int r0 = (T.c_type[k] == GT_ORIENTATION) ? 3 : 0;
@@ -347,7 +365,9 @@ IKD_FN void generic_constraint_jacobian(const GenericTables &T, const Ws &ws) {
                 double vl[3], wl[3];
                 local_column(T, ws, c, Rf, pf, vl, wl);
                 const double out[6] = {vl[0], vl[1], vl[2], wl[0], wl[1], wl[2]};
-                for (int r = 0; r < dim; ++r) ws[T.off_Jc + (row + r) * T.nv + c] = out[r0 + r];
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    if (k >= r0 && k < r0 + dim) ws[T.off_Jc + (row + k - r0) * T.nv + c] = out[k];
             }
         }
         const double Rr[9] = {oMr[0], oMr[1], oMr[2], oMr[3], oMr[4], oMr[5], oMr[6], oMr[7], oMr[8]};
@@ -365,7 +385,9 @@ IKD_FN void generic_constraint_jacobian(const GenericTables &T, const Ws &ws) {
                 }
                 cross(px, Rw, pxRw);
                 const double out[6] = {Rv[0] + pxRw[0], Rv[1] + pxRw[1], Rv[2] + pxRw[2], Rw[0], Rw[1], Rw[2]};
-                for (int r = 0; r < dim; ++r) ws[T.off_Jc + (row + r) * T.nv + c] -= out[r0 + r];
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    if (k >= r0 && k < r0 + dim) ws[T.off_Jc + (row + k - r0) * T.nv + c] -= out[k];
             }
         }
     }
@@ -398,7 +420,8 @@ IKD_FN void project_out_rowspace(const Ws &ws, int off_rows, int m, int nv, int 
 
 // q <- clip(integrate(q, step * dq)) on the workspace (pinocchio::integrate + apply_joint_clipping,
 // ik/ik/common.hpp:53-56); a lane that is no longer active keeps its q.
-IKD_FN void generic_integrate_clip(const GenericTables &T, const Ws &ws, double step_length, bool active) {
+template <class TB>
+IKD_FN void generic_integrate_clip(const TB &T, const Ws &ws, double step_length, bool active) {
     for (int j = 1; j < T.njoints; ++j) {
         const int iq = T.idx_q[j], iv = T.idx_v[j];
         if (T.jtype[j] == GJ_FREEFLYER) {
@@ -428,8 +451,8 @@ IKD_FN void generic_integrate_clip(const GenericTables &T, const Ws &ws, double 
 }
 
 // One full solve on the workspace (q already stored at off_q).
-template <class AnyFn>
-IKD_FN void generic_dls(const GenericTables &T, const LoopParams &prm, const Ws &ws, const double *targets_lane,
+template <class TB, class AnyFn>
+IKD_FN void generic_dls(const TB &T, const LoopParams &prm, const Ws &ws, const double *targets_lane,
                         int64_t tstride, int &iters_out, bool &success_out, AnyFn any_active) {
     bool active = true, success = false;
     int iters = prm.max_iterations;
@@ -484,6 +507,12 @@ IKD_FN void generic_dls(const GenericTables &T, const LoopParams &prm, const Ws 
     success_out = success;
 }
 
+// The tables seen through the constant address space (device kernels: a.T holds plain pointers, as the host wrote them).
+IKD_FN GenericTablesK const_tables(const GenericTables &t) {
+    static_assert(sizeof(GenericTablesK) == sizeof(GenericTables), "same layout");
+    return __builtin_bit_cast(GenericTablesK, t);
+}
+
 // What one lane of the generic kernels does (shared by kernels.hip and the lane emulator).
 struct GenericKernelArgs {
     GenericTables T;
@@ -499,21 +528,27 @@ struct GenericKernelArgs {
     double *e_out, *J_out, *oMf_out;  // stage kernel
 };
 
-template <class AnyFn>
-IKD_FN void dls_generic_body(const GenericKernelArgs &a, int64_t gid, AnyFn any_active) {
+// ws: the lane's workspace column -- of the HBM workspace (dls_generic_body below) or of the workgroup's LDS (the on-chip form,
+// kernels.hip: word w of lane l at lds[w * 64 + l], conflict-free).
+template <class TB, class AnyFn>
+IKD_FN void dls_generic_body_ws(const GenericKernelArgs &a, const TB &T, int64_t gid, const Ws &ws, AnyFn any_active) {
     const bool valid = gid < a.B;
     const int64_t b = valid ? gid : a.B - 1;
-    const Ws ws{a.ws + gid, a.ws_stride};  // tail lanes own (padding) workspace columns too: ws_stride is a multiple of 64
-    for (int i = 0; i < a.T.nq; ++i) ws[a.T.off_q + i] = a.q0[at(a.layout, a.B, a.T.nq, i, b)];
-    const double *tl = a.layout == LAYOUT_SOA ? a.targets + b : a.targets + b * a.T.ntasks * 12;
+    for (int i = 0; i < T.nq; ++i) ws[T.off_q + i] = a.q0[at(a.layout, a.B, T.nq, i, b)];
+    const double *tl = a.layout == LAYOUT_SOA ? a.targets + b : a.targets + b * T.ntasks * 12;
     const int64_t ts = a.layout == LAYOUT_SOA ? a.B : 1;
     int iters;
     bool success;
-    generic_dls(a.T, a.prm, ws, tl, ts, iters, success, any_active);
+    generic_dls(T, a.prm, ws, tl, ts, iters, success, any_active);
     if (!valid) return;
-    for (int i = 0; i < a.T.nq; ++i) a.q_out[at(a.layout, a.B, a.T.nq, i, b)] = ws[a.T.off_q + i];
+    for (int i = 0; i < T.nq; ++i) a.q_out[at(a.layout, a.B, T.nq, i, b)] = ws[T.off_q + i];
     if (a.success) a.success[b] = success ? 1 : 0;
     if (a.iters) a.iters[b] = iters;
+}
+
+template <class AnyFn>
+IKD_FN void dls_generic_body(const GenericKernelArgs &a, int64_t gid, AnyFn any_active) {
+    dls_generic_body_ws(a, a.T, gid, Ws{a.ws + gid, a.ws_stride}, any_active);  // tail lanes own (padding) workspace columns too: ws_stride is a multiple of 64
 }
 
 // Stage kernel: e, dense J and the world placement of each task frame.

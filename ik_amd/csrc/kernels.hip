@@ -404,7 +404,15 @@ hipError_t launch_eval_tree(const ProblemHost &ph, const DeviceTables &dt, int64
 namespace {
 
 __global__ __launch_bounds__(kBlock) void dls_generic_kernel(const ikdev::GenericKernelArgs a) {
-    ikdev::dls_generic_body(a, static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x, [](bool act) { return __any(act) != 0; });
+    const int64_t gid = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    ikdev::dls_generic_body_ws(a, ikdev::const_tables(a.T), gid, ikdev::Ws{a.ws + gid, a.ws_stride}, [](bool act) { return __any(act) != 0; });
+}
+
+// The same per-lane program with its workspace in LDS, [word][lane]: one 64-lane workgroup, ws_words x 512 bytes.
+__global__ __launch_bounds__(64) void dls_generic_lds_kernel(const ikdev::GenericKernelArgs a) {
+    extern __shared__ double lane_lds[];
+    ikdev::dls_generic_body_ws(a, ikdev::const_tables(a.T), static_cast<int64_t>(blockIdx.x) * 64 + threadIdx.x, ikdev::Ws{lane_lds + threadIdx.x, 64},
+                               [](bool act) { return __any(act) != 0; });
 }
 
 __global__ __launch_bounds__(kBlock) void eval_generic_kernel(const ikdev::GenericKernelArgs a) {
@@ -584,7 +592,15 @@ hipError_t launch_pik_generic(const ProblemHost &gen, const DeviceTables &dt, co
 }
 
 
+// The per-lane program with its workspace column in LDS: when 64 columns fit the CU's 160 KB
+bool generic_runs_in_lds(const ProblemHost &ph) {
+    const char *force = std::getenv("IKGPU_GENERIC_KERNEL");
+    if (!(force && std::string(force) == "lds")) return false;
+    return static_cast<size_t>(ph.generic.ws_words) * 64 * sizeof(double) <= 160 * 1024;
+}
+
 bool generic_runs_cooperative(const ProblemHost &ph) {
+    if (generic_runs_in_lds(ph)) return false;
     if (!ph.generic.coop_ok) return false;
     const char *force = std::getenv("IKGPU_GENERIC_KERNEL");  // "lane": keep the memory-resident per-lane program (tests, profiling)
     return !(force && std::string(force) == "lane");
@@ -617,6 +633,19 @@ hipError_t launch_dls_generic(const ProblemHost &ph, const DeviceTables &dt, con
     a.prm.stop_sq_tol = prm.stop_sq_tol;
     a.layout = io.layout; a.q0 = io.q0; a.targets = io.targets;
     a.q_out = io.q_out; a.success = io.success; a.iters = io.iters;
+    if (generic_runs_in_lds(ph)) {
+        a.T = bind_generic_tables(ph, dt.g_ints, dt.g_dbls);
+        a.B = io.B;
+        const size_t lds = sizeof(double) * 64 * static_cast<size_t>(ph.generic.ws_words);
+        static bool raised = false;   // above 64 KB of dynamic LDS the kernel has to be told once
+        if (!raised) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(dls_generic_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return hipGetLastError();
+            raised = true;
+        }
+        hipLaunchKernelGGL(dls_generic_lds_kernel, dim3(static_cast<unsigned>((io.B + 63) / 64)), dim3(64), lds, stream, a);
+        return hipGetLastError();
+    }
     return with_workspace(ph, dt, a, io.B, stream, true);
 }
 
