@@ -345,6 +345,7 @@ int ikgpu_problem_create_constrained(const ikgpu_model *h, const ikgpu_task *tas
         up(&p->dev.q_in_chain, p->host.q_in_chain.data(), nq);
         up(&p->dev.g_ints, p->gen.generic.ints.data(), p->gen.generic.ints.size() * sizeof(int32_t));
         up(&p->dev.g_dbls, p->gen.generic.dbls.data(), p->gen.generic.dbls.size() * sizeof(double));
+        if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void **>(&p->dev.queue), sizeof(unsigned long long) * ikgpu::DeviceTables::kQueueSlots);
         if (p->host.kind != ikgpu::KernelKind::Generic) {
             const std::vector<double> desc = p->host.kind == ikgpu::KernelKind::Chain ? ikgpu::chain_desc_table(p->host)
                                                                                      : ikgpu::tree_desc_table(p->host);
@@ -388,6 +389,7 @@ void ikgpu_problem_destroy(ikgpu_problem *p) {
     (void)hipFree(p->dev.chain_desc);
     (void)hipFree(p->dev.g_ints);
     (void)hipFree(p->dev.g_dbls);
+    (void)hipFree(p->dev.queue);
     if (p->stage.dev) (void)hipFree(p->stage.dev);
     if (p->stage.host) (void)hipHostFree(p->stage.host);
     delete p;

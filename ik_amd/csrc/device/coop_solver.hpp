@@ -66,7 +66,8 @@ struct CoopLayout {
     int rounds, npairs;
     const int *support;          // [ntasks][nv] 1 when the task's rows touch tangent column c
     const int *pair_i, *pair_j;  // [npairs]
-    const int *order, *lvl_start;  // joints 1.. sorted by tree depth; first entry of each of the `rounds` levels (+ end)
+    const int *order, *chain_start, *lvl_start;  // joints 1.. chain by chain (problem.cpp: build_coop); first entry of each chain (+ end);
+                                                 // first chain of each of the `rounds` levels (+ end)
     const int *tb_index;         // [ntasks] slot of the task's block in tb (-1: posture row, no block)
     const int *col_joint;        // [nv] the joint a tangent column belongs to
 };
@@ -115,22 +116,25 @@ IKD_FN double coop_evaluate(const GenericTables &T, const CoopLayout &L, const i
     }
     IKC_SYNC();
     IKC_TICK(0);
-    // ... then, one tree level after the other, oM_j = oM_parent * li_j with one lane per ELEMENT of the product (the same
-    // expression per element as g_se3_mul, so the same bits as the sequential pass of generic_fk) ...
+    // ... then oM_j = oM_parent * li_j down every chain of the tree, one lane per chain with the running product in registers (the
+    // same expression per element as g_se3_mul, so the same bits as the sequential pass of generic_fk); the chains of one level
+    // hang off joints of earlier levels ...
     for (int lv = 0; lv < L.rounds; ++lv) {
         const int first = L.lvl_start[lv], count = L.lvl_start[lv + 1] - first;
-        IKC_FOR(idx, 12 * count) {
-            const int j = L.order[first + idx / 12], k = idx % 12;
-            const double *A = ws + oMi + 12 * T.parent[j], *Bl = ws + L.A0 + 12 * j;
-            double val;
-            if (k < 9) {
-                const int r = k / 3, c = k % 3;
-                val = dfma(A[3 * r], Bl[c], dfma(A[3 * r + 1], Bl[3 + c], A[3 * r + 2] * Bl[6 + c]));
-            } else {
-                const int r = k - 9;
-                val = dfma(A[3 * r], Bl[9], dfma(A[3 * r + 1], Bl[10], dfma(A[3 * r + 2], Bl[11], A[9 + r])));
+        IKC_FOR(ci, count) {
+            const int c0 = L.chain_start[first + ci], c1 = L.chain_start[first + ci + 1];
+            double oM[12];
+            {
+                const double *P = ws + oMi + 12 * T.parent[L.order[c0]];
+                for (int k = 0; k < 12; ++k) oM[k] = P[k];
             }
-            ws[oMi + 12 * j + k] = val;
+            for (int n = c0; n < c1; ++n) {
+                const int j = L.order[n];
+                double li[12], r[12];
+                for (int k = 0; k < 12; ++k) li[k] = ws[L.A0 + 12 * j + k];
+                g_se3_mul(oM, li, r);
+                for (int k = 0; k < 12; ++k) { ws[oMi + 12 * j + k] = r[k]; oM[k] = r[k]; }
+            }
         }
         IKC_SYNC();
     }
@@ -183,7 +187,7 @@ IKD_FN double coop_evaluate(const GenericTables &T, const CoopLayout &L, const i
         }
         IKC_SYNC();
     }
-    IKC_TICK(1);
+    IKC_TICK(13);
     // ---- per task: frame placement, error, the blocks its Jacobian columns need (tb: Rf 9 | pf 3 | A 9 | B 9 | spare 6)
     IKC_FOR(t, nt) {
         const int fj = T.t_fjoint[t], rj = T.t_rjoint[t], type = T.t_type[t], row = T.t_row[t], dim = T.t_dim[t];
@@ -366,13 +370,10 @@ IKD_FN void chol_regs_rhs(const double (&row)[16], double (&x)[16]) {
     }
 }
 
+// row: this lane's row of the augmented matrix (see above); leaves x at offx.  Ends on a barrier.
 template <int MMAX>
-IKD_FN void coop_chol_solve_regs(const int g, double *ws, const int offG, const int offx, const int M) {
-    const int mine = g == 15 ? M : g;             // the row of the packed triangle this lane holds (lanes M .. 14: none, zeros)
-    const bool holds = g < M || g == 15;
-    double row[16], x[16];
-#pragma unroll
-    for (int j = 0; j < MMAX; ++j) row[j] = (holds && j <= mine && j < M) ? ws[offG + tri(mine, j)] : 0.0;
+IKD_FN void chol_regs_solve(double (&row)[16], const int g, double *ws, const int offx, const int M) {
+    double x[16];
     chol_regs_pivots<MMAX, 0>(row, g, M);         // after pivot k, row[k] holds L(i,k) (lane 15: y_k; lane k: 1 / L(k,k))
     chol_regs_rhs<MMAX, 0>(row, x);               // back substitution, in every lane: x[c] starts as y_c ...
     chol_regs_back<MMAX - 1>(row, x, M);          // ... takes -L(m,c) x_m for m = M-1 .. c+1, then inv_c
@@ -382,6 +383,54 @@ IKD_FN void coop_chol_solve_regs(const int g, double *ws, const int offG, const 
             if (k < M) ws[offx + k] = x[k];
     }
     IKC_SYNC();
+}
+
+template <int MMAX>
+IKD_FN void coop_chol_solve_regs(const int g, double *ws, const int offG, const int offx, const int M) {
+    const int mine = g == 15 ? M : g;             // the row of the packed triangle this lane holds (lanes M .. 14: none, zeros)
+    const bool holds = g < M || g == 15;
+    double row[16];
+#pragma unroll
+    for (int j = 0; j < MMAX; ++j) row[j] = (holds && j <= mine && j < M) ? ws[offG + tri(mine, j)] : 0.0;
+    chol_regs_solve<MMAX>(row, g, ws, offx, M);
+}
+
+// The Gram matrix straight into that layout: lane i loads row i of the M x nv matrix at offJ into registers once, and
+// G(i,j) = [i == j] lam2 + sum_c J(i,c) J(j,c) (c ascending, as the LDS form) takes row j from lane j by DPP broadcast -- no LDS
+// traffic in the inner loop, where the pair-per-lane form reads two operands per product (the phase was bound by the CU's LDS
+// bandwidth: 18 % of the kernel).  Lane 15 holds the right-hand side (offe).  Then the solve above.
+template <int MMAX, int NVMAX, int J, int C>
+IKD_FN void gram_regs_dot(const double (&jr)[NVMAX], double &s) {
+    if constexpr (C < NVMAX) {
+        s = dfma(jr[C], group_bcast<J>(jr[C]), s);
+        gram_regs_dot<MMAX, NVMAX, J, C + 1>(jr, s);
+    }
+}
+template <int MMAX, int NVMAX, int J>
+IKD_FN void gram_regs_rows(const double (&jr)[NVMAX], double (&row)[16], const int g, const double lam2, const int M) {
+    if constexpr (J < MMAX) {
+        if (J < M) {   // (wave-uniform)
+            double s = g == J ? lam2 : 0.0;
+            gram_regs_dot<MMAX, NVMAX, J, 0>(jr, s);
+            row[J] = s;
+        } else {
+            row[J] = 0.0;
+        }
+        gram_regs_rows<MMAX, NVMAX, J + 1>(jr, row, g, lam2, M);
+    }
+}
+template <int MMAX, int NVMAX>
+IKD_FN void coop_gram_solve_regs(const int g, double *ws, const int offJ, const int offe, const int offx, const int M, const int nv,
+                                 const double lam2) {
+    double jr[NVMAX], row[16];
+#pragma unroll
+    for (int c = 0; c < NVMAX; ++c) jr[c] = (g < M && c < nv) ? ws[offJ + g * nv + c] : 0.0;
+    gram_regs_rows<MMAX, NVMAX, 0>(jr, row, g, lam2, M);
+    if (g == 15) {
+#pragma unroll
+        for (int j = 0; j < MMAX; ++j) row[j] = j < M ? ws[offe + j] : 0.0;
+    }
+    chol_regs_solve<MMAX>(row, g, ws, offx, M);
 }
 #endif
 
@@ -580,6 +629,13 @@ IKD_FN void coop_dls(const GenericTables &T, const CoopLayout &L, const LoopPara
     for (int it = 0; it < prm.max_iterations; ++it) {
         const double e0sq = coop_evaluate(T, L, g, ws IKC_TICK_PASS);
         // ---- JJ = Jt Jt^T + damping^2 I (ik/ik/dls.cpp:39-41), lower triangle, with the right-hand side et as row M
+#if IKD_ON_DEVICE
+        // (wave-uniform choices; the register form covers M <= 15, nv <= 32)
+#define IKC_GRAM_REGS(MM, NN) if (M <= MM && nv <= NN) { coop_gram_solve_regs<MM, NN>(g, ws, L.J, L.e, L.x, M, nv, prm.lam2); } else
+        IKC_GRAM_REGS(10, 8) IKC_GRAM_REGS(10, 24) IKC_GRAM_REGS(15, 24) IKC_GRAM_REGS(10, 32) IKC_GRAM_REGS(15, 32)
+#undef IKC_GRAM_REGS
+#endif
+        {
         IKC_FOR(p, L.npairs) {
             const int i = L.pair_i[p], j = L.pair_j[p];
             double s;
@@ -595,6 +651,7 @@ IKD_FN void coop_dls(const GenericTables &T, const CoopLayout &L, const LoopPara
         IKC_SYNC();
         IKC_TICK(4);
         coop_chol_solve(L, g, ws, L.G, L.dinv, L.x, M);
+        }
         IKC_TICK(6);
         IKC_FOR(c, nv) {  // dq = -Jt^T x, ik/ik/dls.cpp:52-53 (N = I)
             double s = 0.0;

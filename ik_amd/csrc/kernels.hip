@@ -469,7 +469,7 @@ __device__ __forceinline__ double *coop_stage(double *lds, ikdev::GenericTables 
     rebase(T.placement, s.dbls, ld); rebase(T.axis, s.dbls, ld); rebase(T.lower, s.dbls, ld); rebase(T.upper, s.dbls, ld);
     rebase(T.t_fpl, s.dbls, ld); rebase(T.t_rpl, s.dbls, ld); rebase(T.t_w, s.dbls, ld);
     rebase(L.support, s.ints, li); rebase(L.pair_i, s.ints, li); rebase(L.pair_j, s.ints, li); rebase(L.order, s.ints, li);
-    rebase(L.lvl_start, s.ints, li); rebase(L.tb_index, s.ints, li); rebase(L.col_joint, s.ints, li);
+    rebase(L.lvl_start, s.ints, li); rebase(L.chain_start, s.ints, li); rebase(L.tb_index, s.ints, li); rebase(L.col_joint, s.ints, li);
     rebase(T.j_mass, s.dbls, ld); rebase(T.j_lever, s.dbls, ld); rebase(T.j_submass, s.dbls, ld);
     rebase(T.c_type, s.ints, li); rebase(T.c_fjoint, s.ints, li); rebase(T.c_rjoint, s.ints, li); rebase(T.c_row, s.ints, li);
     rebase(T.c_dim, s.ints, li); rebase(T.c_fpl, s.dbls, ld); rebase(T.c_rpl, s.dbls, ld);
@@ -479,7 +479,17 @@ __device__ __forceinline__ double *coop_stage(double *lds, ikdev::GenericTables 
 
 // (two waves per SIMD asked for: the kernel sits at 261 registers otherwise -- one wave per SIMD, four workgroups per CU where
 // the LDS has room for five: 22 instead of 18.6 ms on the demo task set)
-__global__ __launch_bounds__(kBlock, 2) void dls_coop_kernel(ikdev::CoopKernelArgs a, const CoopStaging s) {
+// The next group of problems for this (one-wave) workgroup, from the launch's queue head.  Dynamic, not blockIdx + k gridDim: the
+// LDS lets five workgroups live on a CU's four SIMDs, so two of them share a SIMD and run at about half the pace of the other
+// three -- with equal shares the launch waited for those two.  Every wave leaves once the head has passed the last group.
+__device__ __forceinline__ int64_t next_block(unsigned long long *queue) {
+    unsigned long long v = 0;
+    if (threadIdx.x == 0) v = atomicAdd(queue, 1ull);
+    const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v)), hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
+    return static_cast<int64_t>((static_cast<unsigned long long>(hi) << 32) | lo);
+}
+
+__global__ __launch_bounds__(kBlock, 2) void dls_coop_kernel(ikdev::CoopKernelArgs a, const CoopStaging s, unsigned long long *queue) {
     extern __shared__ double coop_lds[];
     double *ws0 = coop_stage(coop_lds, a.T, a.L, s);
     const int grp = threadIdx.x / ikdev::kCoopGroup, g = threadIdx.x % ikdev::kCoopGroup;
@@ -488,11 +498,11 @@ __global__ __launch_bounds__(kBlock, 2) void dls_coop_kernel(ikdev::CoopKernelAr
     // problems the workgroup takes -- staged per four problems they were 2/3 of the launch's HBM traffic (137 MB against 43 MB of
     // algorithmic bytes at B = 65536)
     const int64_t nblocks = (a.B + per_block - 1) / per_block;
-    for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x)
+    for (int64_t blk = next_block(queue); blk < nblocks; blk = next_block(queue))
         ikdev::dls_coop_body(a, blk * per_block + grp, g, ws0 + grp * a.L.words, [](bool act) { return __any(act) != 0; });
 }
 
-__global__ __launch_bounds__(kBlock) void pik_coop_kernel(const ikdev::PikCoopKernelArgs a, const CoopStaging s) {
+__global__ __launch_bounds__(kBlock) void pik_coop_kernel(const ikdev::PikCoopKernelArgs a, const CoopStaging s, unsigned long long *queue) {
     extern __shared__ double coop_lds[];
     // the arguments stay in the kernel-argument segment (they hold the 1 KB `da` array: a mutable copy would live in
     // scratch memory, 1.3 KB per lane); only the two small table structs are copied, to be pointed at LDS
@@ -502,7 +512,7 @@ __global__ __launch_bounds__(kBlock) void pik_coop_kernel(const ikdev::PikCoopKe
     const int grp = threadIdx.x / ikdev::kCoopGroup, g = threadIdx.x % ikdev::kCoopGroup;
     const int per_block = blockDim.x / ikdev::kCoopGroup;
     const int64_t nblocks = (a.B + per_block - 1) / per_block;
-    for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x)   // persistent workgroups, as dls_coop_kernel
+    for (int64_t blk = next_block(queue); blk < nblocks; blk = next_block(queue))   // persistent workgroups, as dls_coop_kernel
         ikdev::pik_coop_body(a, T, L, blk * per_block + grp, g, ws0 + grp * a.K.words, [](bool act) { return __any(act) != 0; });
 }
 
@@ -571,7 +581,9 @@ hipError_t launch_pik_generic(const ProblemHost &gen, const DeviceTables &dt, co
         const size_t lds = sizeof(double) * (static_cast<size_t>(per_block) * static_cast<size_t>(c.K.words) +
                                              static_cast<size_t>(s.n_dbls) + static_cast<size_t>((s.n_ints + 1) / 2));
         const int64_t blocks = persistent_grid(reinterpret_cast<const void *>(pik_coop_kernel), per_block * ikdev::kCoopGroup, lds, (io.B + per_block - 1) / per_block);
-        hipLaunchKernelGGL(pik_coop_kernel, dim3(static_cast<unsigned>(blocks)), dim3(per_block * ikdev::kCoopGroup), lds, stream, c, s);
+        unsigned long long *queue = dt.queue + dt.queue_next.fetch_add(1) % DeviceTables::kQueueSlots;
+        if (hipMemsetAsync(queue, 0, sizeof(*queue), stream) != hipSuccess) return hipGetLastError();
+        hipLaunchKernelGGL(pik_coop_kernel, dim3(static_cast<unsigned>(blocks)), dim3(per_block * ikdev::kCoopGroup), lds, stream, c, s, queue);
         return hipGetLastError();
     }
     ikdev::PikKernelArgs a{};
@@ -623,7 +635,9 @@ hipError_t launch_dls_generic(const ProblemHost &ph, const DeviceTables &dt, con
         const size_t lds = sizeof(double) * (static_cast<size_t>(per_block) * static_cast<size_t>(c.L.words) +
                                              static_cast<size_t>(s.n_dbls) + static_cast<size_t>((s.n_ints + 1) / 2));
         const int64_t blocks = persistent_grid(reinterpret_cast<const void *>(dls_coop_kernel), per_block * ikdev::kCoopGroup, lds, (io.B + per_block - 1) / per_block);
-        hipLaunchKernelGGL(dls_coop_kernel, dim3(static_cast<unsigned>(blocks)), dim3(per_block * ikdev::kCoopGroup), lds, stream, c, s);
+        unsigned long long *queue = dt.queue + dt.queue_next.fetch_add(1) % DeviceTables::kQueueSlots;
+        if (hipMemsetAsync(queue, 0, sizeof(*queue), stream) != hipSuccess) return hipGetLastError();
+        hipLaunchKernelGGL(dls_coop_kernel, dim3(static_cast<unsigned>(blocks)), dim3(per_block * ikdev::kCoopGroup), lds, stream, c, s, queue);
         return hipGetLastError();
     }
     ikdev::GenericKernelArgs a{};

@@ -1,5 +1,6 @@
 // kernels.hpp -- host-visible launchers of the gfx950 kernels (defined in kernels.hip).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -15,6 +16,11 @@ struct DeviceTables {  // per-problem constant arrays resident in HBM
     double *chain_desc = nullptr;               // ikdev::ChainDesc<NJ> / TreeDesc as a flat array of doubles
     int32_t *g_ints = nullptr;                  // generic kernel: packed int tables
     double *g_dbls = nullptr;                   // generic kernel: packed double tables
+    // cooperative kernels: work-queue heads of the persistent workgroups, one slot per launch in flight (a ring: the launch zeroes
+    // its slot on its stream, so launches of one problem on several streams -- or replays of a captured graph -- do not share one)
+    static constexpr int kQueueSlots = 64;
+    unsigned long long *queue = nullptr;        // [kQueueSlots]
+    mutable std::atomic<unsigned> queue_next{0};
 };
 
 struct BatchIO {

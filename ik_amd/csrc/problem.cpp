@@ -281,19 +281,35 @@ void build_coop(ProblemHost &ph, const Model &m) {
         for (int j = 0; j <= i; ++j) { ci.push_back(i); cj.push_back(j); }
     g.o_ccpair_i = put_i(ci);
     g.o_ccpair_j = put_i(cj);
-    // forward kinematics by tree depth: the joints of one level are independent and compose with their parent's world
-    // placement from the level before (the same products, in the same order, as the sequential pass of the per-lane program)
-    std::vector<int32_t> depth(nj, 0), order, lvl_start;
-    int max_depth = 0;
-    for (int j = 1; j < nj; ++j) { depth[j] = depth[m.joint_parent[j]] + 1; max_depth = std::max(max_depth, depth[j]); }
-    for (int d = 1; d <= max_depth; ++d) {
-        lvl_start.push_back(static_cast<int32_t>(order.size()));
-        for (int j = 1; j < nj; ++j)
-            if (depth[j] == d) order.push_back(j);
+    // forward kinematics by CHAIN: a chain is a run of joints each the only child of the one before; one lane walks a chain with
+    // the running world placement in registers (the same products, in the same order, as the sequential pass of the per-lane
+    // program).  A joint with several children ends its chain, every child starts one; the chains of one level hang off joints of
+    // the levels before and are independent.  (By tree DEPTH -- one barrier and one LDS round trip per joint of the longest path,
+    // eight for a Cassie leg -- the phase was 23 % of the kernel.)
+    std::vector<int> nchild(nj, 0), chain_of(nj, -1);
+    for (int j = 1; j < nj; ++j) nchild[m.joint_parent[j]]++;
+    std::vector<std::vector<int32_t>> chains;
+    std::vector<int> chain_level;
+    for (int j = 1; j < nj; ++j) {   // (a joint's parent has a smaller index: model.cpp builds the tree in that order)
+        const int p = m.joint_parent[j];
+        if (p > 0 && nchild[p] == 1) { chain_of[j] = chain_of[p]; chains[chain_of[j]].push_back(j); continue; }
+        chain_of[j] = static_cast<int>(chains.size());
+        chains.push_back({j});
+        chain_level.push_back(p > 0 ? chain_level[chain_of[p]] + 1 : 0);
     }
-    lvl_start.push_back(static_cast<int32_t>(order.size()));
-    g.coop_rounds = max_depth;
+    int nlevels_fk = 0;
+    for (int l : chain_level) nlevels_fk = std::max(nlevels_fk, l + 1);
+    std::vector<int32_t> order, chain_start, lvl_start;
+    for (int l = 0; l < nlevels_fk; ++l) {
+        lvl_start.push_back(static_cast<int32_t>(chain_start.size()));
+        for (size_t c = 0; c < chains.size(); ++c)
+            if (chain_level[c] == l) { chain_start.push_back(static_cast<int32_t>(order.size())); order.insert(order.end(), chains[c].begin(), chains[c].end()); }
+    }
+    lvl_start.push_back(static_cast<int32_t>(chain_start.size()));
+    chain_start.push_back(static_cast<int32_t>(order.size()));
+    g.coop_rounds = nlevels_fk;
     g.o_cup = put_i(order);
+    g.o_cchain = put_i(chain_start);
     g.o_clvl = put_i(lvl_start);
     // LDS layout of one problem.  Two pairs of arrays never live at the same time and share their space: the local joint
     // transforms (read by the forward kinematics only) with the task Jacobian (written after it), and the per-task blocks

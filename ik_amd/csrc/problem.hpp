@@ -38,7 +38,7 @@ struct GenericHost {
     // cooperative form of the DLS program (device/coop_solver.hpp): 16 lanes per problem, workspace in LDS
     int coop_ok = 0, coop_rounds = 0, coop_words = 0, coop_npairs = 0;
     int coop_pik_ok = 0, coop_words_pik = 0, coop_mmax = 0, c_P = 0;  // ik::pik in the same form (device/pik_coop.hpp)
-    int o_csupport = 0, o_cpair_i = 0, o_cpair_j = 0, o_cup = 0, o_clvl = 0, o_ctbindex = 0, o_ccoljoint = 0, o_ccsf = 0, o_ccsr = 0;  // into ints: [ntasks][nv], [npairs] x 2, joints by depth [njoints - 1] + level starts [rounds + 1]
+    int o_csupport = 0, o_cpair_i = 0, o_cpair_j = 0, o_cup = 0, o_cchain = 0, o_clvl = 0, o_ctbindex = 0, o_ccoljoint = 0, o_ccsf = 0, o_ccsr = 0;  // into ints: [ntasks][nv], [npairs] x 2, joints by depth [njoints - 1] + level starts [rounds + 1]
     int c_q = 0, c_tg = 0, c_A0 = 0, c_A1 = 0, c_Jw = 0, c_tb = 0, c_e = 0, c_J = 0, c_G = 0, c_dinv = 0, c_x = 0, c_dq = 0, c_sf = 0, c_cb = 0, c_Jc = 0, c_cnrm = 0;
     int has_com = 0, o_jmass = 0, o_jlever = 0, o_jsubmass = 0, off_sf = 0;  // centre-of-mass task (into dbls / workspace)
     double inv_total_mass = 0.0;

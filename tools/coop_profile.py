@@ -40,9 +40,9 @@ L.ikgpu_debug_coop_profile(out, 1)
 solve(problem, Q0, T, data, ik_amd.never_stop_visitor(), p)
 torch.cuda.synchronize()
 L.ikgpu_debug_coop_profile(out, 1)
-names = ["local transforms", "tree levels + Jw", "task blocks", "task Jacobian columns", "Gram", "Cholesky", "back substitution", "dq", "integrate",
-         "pik: de, Jbar", "pik: Gram", "pik: Cholesky + dq", "pik: row-space basis"]
-tot = sum(out[:13])
-for n, v in zip(names, out[:13]):
+names = ["local transforms", "chains (oMi)", "task blocks", "task Jacobian columns", "Gram", "Cholesky", "back substitution", "dq", "integrate",
+         "pik: de, Jbar", "pik: Gram", "pik: Cholesky + dq", "pik: row-space basis", "joint Jacobian (Jw), CoM"]
+tot = sum(out[:14])
+for n, v in zip(names, out[:14]):
     print("%-24s %9.0f cycles / iteration  %5.1f %%" % (n, v / iters, 100.0 * v / tot))
 print("%-24s %9.0f cycles / iteration (s_memtime, workgroup 0)" % ("total", tot / iters))
