@@ -518,6 +518,12 @@ __global__ __launch_bounds__(kBlock) void pik_coop_kernel(const ikdev::PikCoopKe
 
 }  // namespace
 
+// A launch asking for more than the default 64 KB of dynamic LDS has to raise the kernel's limit first (once per kernel and device).
+bool raise_lds_limit(const void *kernel, size_t lds) {
+    if (lds <= 64 * 1024) return true;
+    return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+}
+
 // Grid of a persistent cooperative launch: as many workgroups as the device keeps resident (LDS-bound: five per CU for the demo task
 // set), never more than there are groups of problems.
 int64_t persistent_grid(const void *kernel, int block, size_t lds, int64_t nblocks) {
@@ -583,6 +589,7 @@ hipError_t launch_pik_generic(const ProblemHost &gen, const DeviceTables &dt, co
         const int64_t blocks = persistent_grid(reinterpret_cast<const void *>(pik_coop_kernel), per_block * ikdev::kCoopGroup, lds, (io.B + per_block - 1) / per_block);
         unsigned long long *queue = dt.queue + dt.queue_next.fetch_add(1) % DeviceTables::kQueueSlots;
         if (hipMemsetAsync(queue, 0, sizeof(*queue), stream) != hipSuccess) return hipGetLastError();
+        if (!raise_lds_limit(reinterpret_cast<const void *>(pik_coop_kernel), lds)) return hipGetLastError();
         hipLaunchKernelGGL(pik_coop_kernel, dim3(static_cast<unsigned>(blocks)), dim3(per_block * ikdev::kCoopGroup), lds, stream, c, s, queue);
         return hipGetLastError();
     }
@@ -637,6 +644,7 @@ hipError_t launch_dls_generic(const ProblemHost &ph, const DeviceTables &dt, con
         const int64_t blocks = persistent_grid(reinterpret_cast<const void *>(dls_coop_kernel), per_block * ikdev::kCoopGroup, lds, (io.B + per_block - 1) / per_block);
         unsigned long long *queue = dt.queue + dt.queue_next.fetch_add(1) % DeviceTables::kQueueSlots;
         if (hipMemsetAsync(queue, 0, sizeof(*queue), stream) != hipSuccess) return hipGetLastError();
+        if (!raise_lds_limit(reinterpret_cast<const void *>(dls_coop_kernel), lds)) return hipGetLastError();
         hipLaunchKernelGGL(dls_coop_kernel, dim3(static_cast<unsigned>(blocks)), dim3(per_block * ikdev::kCoopGroup), lds, stream, c, s, queue);
         return hipGetLastError();
     }

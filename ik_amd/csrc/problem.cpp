@@ -232,6 +232,8 @@ void specialise(ProblemHost &ph, const Model &m) {
 // Tables of the cooperative DLS program (device/coop_solver.hpp): which tangent columns each task row set touches, the
 // (i, j) pairs of the lower triangle of the augmented Gram matrix, the joints ordered by tree depth for the forward
 // kinematics, and the LDS layout.
+constexpr size_t kCoopLdsCap = 160 * 1024;
+
 void build_coop(ProblemHost &ph, const Model &m) {
     GenericHost &g = ph.generic;
     const int nj = m.njoints(), nt = ph.ntasks, nv = m.nv, M = ph.rows;
@@ -339,11 +341,13 @@ void build_coop(ProblemHost &ph, const Model &m) {
     g.coop_words_pik = g.coop_words + nv * nv;
     g.coop_words_pik += (g.coop_words_pik % 2 == 0 ? 1 : 0);
     g.coop_mmax = mmax;
-    // one 64-lane block holds the packed tables and four workspaces; 64 KB of LDS per block keeps at least two blocks on a CU
+    // one 64-lane block holds the packed tables and four workspaces, anything up to the CU's 160 KB of LDS (the launch raises the
+    // kernel's dynamic-LDS limit past the 64 KB default).  Even one block per CU beats the memory-resident per-lane program by far:
+    // M = 28 (two feet + pelvis + sixteen posture rows) 265 ms per launch there.
     const size_t lds_pik = 8 * (4 * static_cast<size_t>(g.coop_words_pik) + g.dbls.size() + (g.ints.size() + 1) / 2);
-    g.coop_pik_ok = lds_pik <= 64 * 1024 ? 1 : 0;
+    g.coop_pik_ok = lds_pik <= kCoopLdsCap ? 1 : 0;
     const size_t lds_bytes = 8 * (4 * static_cast<size_t>(g.coop_words) + g.dbls.size() + (g.ints.size() + 1) / 2);
-    g.coop_ok = lds_bytes <= 64 * 1024 ? 1 : 0;
+    g.coop_ok = lds_bytes <= kCoopLdsCap ? 1 : 0;
 }
 
 void build_generic(ProblemHost &ph, const Model &m) {
