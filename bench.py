@@ -77,6 +77,14 @@ WORKLOADS = {
                                     "right foot's position held by a FrameConstraint (3 constraint rows)"),
     # the same tasks through the reference's other solver, ik::pik (reference ik/ik/pik.cpp:31-103): the alignment row at
     # priority 1, solved in the null space of the two pose tasks; damping factor 0.1 per level
+    # ... the pinned foot AND the posture regulariser: the demo with every line but the centre of mass switched on
+    "cassie_demo_pinned_posture": dict(urdf="cassie", free_flyer=True, frames=["LeftFootFront", "pelvis", "LeftFootFront"], nq=23,
+                                       tasks=[("frame", "LeftFootFront", 0, "pelvis"), ("frame", "pelvis", 2, "universe"),
+                                              ("align", "LeftFootFront", 1, "universe")],
+                                       posture=dict(nj=16, priority=1, weight=0.05),
+                                       constraint=("RightFootFront", 0, "universe"),
+                                       text="Cassie demo task set + a PostureTask on all 16 joints (priority 1, weight 0.05) + the right foot's "
+                                            "position pinned by a FrameConstraint (M=26, 3 constraint rows)"),
     "cassie_demo_pik": dict(urdf="cassie", free_flyer=True, frames=["LeftFootFront", "pelvis", "LeftFootFront"], nq=23,
                             tasks=[("frame", "LeftFootFront", 0, "pelvis"), ("frame", "pelvis", 2, "universe"),
                                    ("align", "LeftFootFront", 1, "universe")],
@@ -163,7 +171,7 @@ def make_inputs(name, model, idx):
     from ik_amd import workload
     w = WORKLOADS[name]
     lo, hi = model.lowerPositionLimit, model.upperPositionLimit
-    if name in ("cassie_full_body", "cassie_demo", "cassie_demo_pik", "cassie_demo_posture", "cassie_demo_pinned"):
+    if name in ("cassie_full_body", "cassie_demo", "cassie_demo_pik", "cassie_demo_posture", "cassie_demo_pinned", "cassie_demo_pinned_posture"):
         return workload.freeflyer_workload(lo, hi, workload.cassie_nominal(model.names), idx, seed=0, mode="near")
     if name in ("ur5", "ur10"):
         return workload.chain_workload(lo, hi, workload.UR5_NOMINAL, idx, seed=0, mode="near")

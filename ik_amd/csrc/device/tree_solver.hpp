@@ -685,6 +685,12 @@ IKD_FN void constraint_project(const double (&R1)[9], const double (&p1)[3], PlP
 // Bit kSpecPost (alone: otherwise a general build): the posture code above is compiled in.
 // Bit kSpecCons / kSpecPik (alone): a general build with the FrameConstraint code / with level 1 of a two-level ik::pik.
 constexpr int kSpecUnitP = 29, kSpecIdP = 28, kSpecPost = 26, kSpecCons = 25, kSpecPik = 24;
+constexpr int kSpecPostCons = (1 << kSpecPost) | (1 << kSpecCons);   // posture rows next to the constraint (the demo with the stance foot pinned)
+constexpr bool spec_has_posture(int spec) { return spec < 0 || spec == (1 << kSpecPost) || spec == kSpecPostCons; }
+constexpr bool spec_has_constraint(int spec) { return spec < 0 || spec == (1 << kSpecCons) || spec == kSpecPostCons; }
+constexpr bool spec_is_general(int spec) {
+    return spec <= 0 || spec == (1 << kSpecPost) || spec == (1 << kSpecCons) || spec == (1 << kSpecPik) || spec == kSpecPostCons;
+}
 
 // Where the lane keeps the joints outside the chains that carry a posture row: its own column of the caller's q_out.
 struct PostureState {
@@ -741,10 +747,10 @@ template <int NJ, int NCH, int SPEC = -1, class Desc, class Park, class AnyFn>
 IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], double (&qj0)[NJ], double (&qj1)[NJ],
                      const double *targets_lane, int64_t tstride, const int (&tslot)[3], const PostureState &ps, int &iters_out,
                      bool &success_out, Park park, AnyFn any_active) {
-    constexpr bool kGeneral = SPEC <= 0 || SPEC == (1 << kSpecPost) || SPEC == (1 << kSpecCons) || SPEC == (1 << kSpecPik);  // the demo's extras exist in the general builds only
+    constexpr bool kGeneral = spec_is_general(SPEC);  // the demo's extras exist in the general builds only
     constexpr bool kPik = SPEC < 0 || SPEC == (1 << kSpecPik);  // the orthogonalisation behind PikRow costs the other builds registers
-    constexpr bool kPost = SPEC < 0 || SPEC == (1 << kSpecPost);
-    constexpr bool kCons = NCH > 1 && (SPEC < 0 || SPEC == (1 << kSpecCons));
+    constexpr bool kPost = spec_has_posture(SPEC);
+    constexpr bool kCons = NCH > 1 && spec_has_constraint(SPEC);
     // (posture builds: a tail lane shadowing the last problem would re-read that problem's outside joints while their owner
     // updates them -- it sits the loop out instead; nothing of it is stored anyway)
     bool active = kPost ? ps.store : true, success = false;
@@ -839,6 +845,23 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
             base_columns(t, pf, R1, p1, JL, JA);
             accumulate_base(JL, JA, t.e, Hbb, gb);
         }
+        // constraint builds with posture rows: a joint of the constrained chain carries no task, so its posture row is its own
+        // 1 x 1 system (as the joints outside the chains, posture_outside_pass); the projection below then acts on that step
+        double dq1pre[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) dq1pre[j] = 0.0;
+        if (kCons && kPost && prm.cons_on && prm.post_on) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int slot = prm.postc_slot[NCH - 1][j];
+                if (slot >= 0) {   // (wave-uniform)
+                    const double w = prm.postc_w[NCH - 1][j], mw = prm.postc_m[NCH - 1][j] * w;
+                    const double ea = (qj1[j] - targets_lane[(slot * 12 + 9) * tstride]) * mw;
+                    if (prm.post_prio == 0) e0sq = dfma(ea, ea, e0sq);
+                    dq1pre[j] = -(w * ea) * drcp(dfma(w, w, prm.lam2));
+                }
+            }
+        }
         // base: S dq_b = g'
         double S[36], dqb[6];
 #pragma unroll
@@ -886,12 +909,12 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
             }
         }
         if (kCons && prm.cons_on) {
-            // the constrained chain: no task moves it, so dq is zero there before the projection N = I - pinv(Jc) Jc, which
-            // touches the base columns and this chain's only
+            // the constrained chain: no task moves it, so dq is zero there (or its posture rows' own steps) before the projection
+            // N = I - pinv(Jc) Jc, which touches the base columns and this chain's only
             double R1[9], dq1[NJ];
             quat_to_R(qb, R1);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) dq1[j] = 0.0;
+            for (int j = 0; j < NJ; ++j) dq1[j] = dq1pre[j];
             const auto &cc = d.chain[NCH - 1];
             constraint_project<NJ, (SPEC >= 0)>(R1, p1, cc.pl, cc.fr, prm.idmask[NCH - 1], qj1, prm.cons_type, dqb, dq1);
 #pragma unroll

@@ -336,9 +336,12 @@ hipError_t run_dls_tree(const ProblemHost &ph, const DeviceTables &dt, const Bat
     else if (mask_only) hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, (kMask != 0 ? kMask : kHot)>), grid, dim3(kTreeBlock), 0, stream, a);
     else if (pik_lambda1)   // two-level ik::pik (tree_takes_two_level_pik): the general build + the level-1 row's projection
         hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, (1 << ikdev::kSpecPik)>), grid, dim3(kTreeBlock), 0, stream, a);
-    else if (ph.cons_on) {   // one FrameConstraint on the second chain: the constraint build (general + the projection)
-        if constexpr (NCH == 2) hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, (1 << ikdev::kSpecCons)>), grid, dim3(kTreeBlock), 0, stream, a);
-        else return hipErrorInvalidValue;
+    else if (ph.cons_on) {   // one FrameConstraint on the second chain: the constraint build (general + the projection), with or
+                             // without the posture code
+        if constexpr (NCH == 2) {
+            if (ph.has_posture) hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, ikdev::kSpecPostCons>), grid, dim3(kTreeBlock), 0, stream, a);
+            else hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, (1 << ikdev::kSpecCons)>), grid, dim3(kTreeBlock), 0, stream, a);
+        } else return hipErrorInvalidValue;
     } else if (ph.has_posture)
         hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, (1 << ikdev::kSpecPost)>), grid, dim3(kTreeBlock),
                            NCH == 1 ? sizeof(double) * kTreeBlock * static_cast<size_t>(2 * std::max(1, a.prm.post_n) + NJ) : 0, stream, a);

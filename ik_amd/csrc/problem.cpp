@@ -196,7 +196,6 @@ void specialise(ProblemHost &ph, const Model &m) {
     for (int i = 0; i < ntasks; ++i) {
         const ikgpu_task &t = ph.tasks[i];
         if (t.type != IKGPU_POSTURE_ROW) continue;
-        if (ph.cons_on) throw Unsupported("posture rows next to a constraint");
         if (ph.has_posture && t.priority != ph.posture_prio) throw Unsupported("posture rows on different priority levels");
         ph.has_posture = true;
         ph.posture_prio = t.priority;
@@ -206,7 +205,7 @@ void specialise(ProblemHost &ph, const Model &m) {
         if (has_row[qi]) throw Unsupported("two posture rows on one joint");
         has_row[qi] = 1;
         int where = -1, at = -1;
-        for (int c = 0; c < nchains && where < 0; ++c) {
+        for (int c = 0; c < (ph.cons_on ? 2 : nchains) && where < 0; ++c) {   // (the constrained chain is chain B)
             const ChainHost &ch = c == 0 ? ph.chain : ph.chainB;
             for (int j = 0; j < ch.nj; ++j)
                 if (ch.vidx[j] == v) { where = c; at = j; break; }

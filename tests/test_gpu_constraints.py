@@ -23,6 +23,11 @@ CASES = {
     # the demo's commented-out intent (reference ik_ros/src/cassie.cpp:49-51,74-75): keep the right foot where it is
     "demo_right_foot_pinned": ("cassie", True, [("frame", "LeftFootFront", "pelvis", 0, 0, None), ("frame", "pelvis", "universe", 2, 0, None),
                                                 ("align", "LeftFootFront", "universe", 1, 0, None)], [("RightFootFront", 0, "universe")]),
+    # ... and with the demo's posture regulariser on all sixteen joints next to it (posture + constraint build of the tree kernel)
+    "demo_right_foot_pinned_with_posture": ("cassie", True, [("frame", "LeftFootFront", "pelvis", 0, 0, None), ("frame", "pelvis", "universe", 2, 0, None),
+                                                             ("align", "LeftFootFront", "universe", 1, 0, None),
+                                                             ("posture", 16, None, None, 0, ([0.3 + 0.04 * k for k in range(16)], [1.0] * 16))],
+                                            [("RightFootFront", 0, "universe")]),
     "pelvis_with_both_feet_locked": ("cassie", True, [("frame", "pelvis", "universe", 2, 0, None)],
                                      [("RightFootFront", 2, "universe"), ("LeftFootFront", 0, "RightFootFront")]),
     "arm_keeps_tool_orientation": ("ur5", False, [("frame", "tool0", "universe", 0, 0, None)], [("tool0", 1, "universe")]),
@@ -45,7 +50,8 @@ def test_constrained_dls_matches_oracle(torch_cuda, case, monkeypatch):
     data = ik_amd.dls_data(problem, device=0)
     # one constraint with the universe as reference on the foot of the leg that carries no task (the pinned stance foot) runs on
     # the tree kernel's constraint build; every other shape on the generic kernel
-    on_tree = case == "demo_right_foot_pinned"
+    on_tree = case.startswith("demo_right_foot_pinned")
+    assert ("posture" in data.kernel) == case.endswith("with_posture")
     assert data.kernel.startswith("dls_tree<NJ=7,chains=1" if on_tree else "dls_generic<") and "constraint_rows=%d" % problem.c_size() in data.kernel
     oc = O.make_tasks([(model.getFrameId(f), model.getFrameId(r), t, 0, None) for f, t, r in cspecs])
     Q0 = torch.from_numpy(np.ascontiguousarray(q0.T)).cuda()

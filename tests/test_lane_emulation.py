@@ -537,8 +537,8 @@ def test_two_level_pik_on_the_tree_program(emu, monkeypatch, foot_type, lam):
 
 
 @pytest.mark.parametrize("ctype", [0, 1, 2])
-@pytest.mark.parametrize("with_align", [False, True])
-def test_constraint_build_of_the_tree_program(emu, ctype, with_align):
+@pytest.mark.parametrize("with_align,with_posture", [(False, False), (True, False), (True, True)])
+def test_constraint_build_of_the_tree_program(emu, ctype, with_align, with_posture):
     """One FrameConstraint (Position / Orientation / Full, reference = the universe) on the foot of the leg that carries no task
     -- the pinned stance foot -- next to the demo's tasks: the tree kernel's constraint build (device/tree_solver.hpp
     constraint_project: world rows of the constraint Jacobian on base + chain columns, Gram-Schmidt applied twice, dq -= V^T V dq)
@@ -547,6 +547,9 @@ def test_constraint_build_of_the_tree_program(emu, ctype, with_align):
     specs = [("LeftFootFront", "pelvis", 0, 0, None), ("pelvis", "universe", 2, 0, None)]
     if with_align:
         specs.append(("LeftFootFront", "universe", 4, 0, None))        # AlignAxisTask, frame Y axis
+    if with_posture:   # the demo's PostureTask on all sixteen joints: the constrained chain's joints carry no task, so their posture
+                       # rows are 1 x 1 systems whose steps the projection then acts on
+        specs.append(("@posture", 16, 6, 0, ([0.3 + 0.04 * k for k in range(16)], [1.0] * 16)))
     B = 24
     urdf, model, om, tasks, ot, q0, tg, M = _generic_case("cassie", True, specs, B, seed=13)
     cons = (capi.Task * 1)(capi.Task(model.getFrameId("RightFootFront"), 0, ctype, 0, (C.c_double * 6)(*[1.0] * 6)))
@@ -554,6 +557,7 @@ def test_constraint_build_of_the_tree_program(emu, ctype, with_align):
     buf = C.create_string_buffer(200)
     rc = capi.lib().ikgpu_problem_plan_constrained(ik_amd_model_handle(model), tasks, len(tasks), cons, 1, buf, len(buf))
     assert rc == 0 and buf.value.decode().startswith("dls_tree<NJ=7,chains=1") and "constraint_rows=%d" % (6 if ctype == 2 else 3) in buf.value.decode(), buf.value
+    assert ("posture" in buf.value.decode()) == with_posture
     p = lambda a: C.c_void_p(a.ctypes.data)
     for iters, damping, step, tol in ((1, 1e-2, 1.0, -1.0), (5, 1e-2, 1.0, -1.0), (40, 1e-1, 0.5, 1e-7), (100, 1e-1, 1e-1, 1e-4)):
         qo = np.empty_like(q0)

@@ -3,7 +3,7 @@
 # ik_amd/kernel_stats.json.
 set -e
 cd "$(dirname "$0")/.."
-for w in cassie_leg ur5 ur10 ur5_clamp ur10_clamp cassie_full_body cassie_demo cassie_demo_posture cassie_demo_pinned cassie_demo_pik; do
+for w in cassie_leg ur5 ur10 ur5_clamp ur10_clamp cassie_full_body cassie_demo cassie_demo_posture cassie_demo_pinned cassie_demo_pinned_posture cassie_demo_pik; do
   [ -f gpurun_out/bench_$w.json ] && cp gpurun_out/bench_$w.json profiles/r02_bench_$w.json
   f=$(ls -t gpurun_out/stats_$w/runc/*_kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" profiles/r02_kernel_stats_$w.csv
 done

@@ -3,7 +3,7 @@
 # register-resident kernels, the self-launcher rehearsals, the stamps of the hot chain kernel, the issue-cost probe.
 # Outputs under gpurun_out/; tools/r02_collect.sh copies what is to be judged into profiles/.
 steps=()
-for w in cassie_leg ur5 ur10 ur5_clamp ur10_clamp cassie_full_body cassie_demo cassie_demo_posture cassie_demo_pinned cassie_demo_pik; do
+for w in cassie_leg ur5 ur10 ur5_clamp ur10_clamp cassie_full_body cassie_demo cassie_demo_posture cassie_demo_pinned cassie_demo_pinned_posture cassie_demo_pik; do
   steps+=("stats_$w|300|tools/stats_session.sh $w")
 done
 for w in cassie_leg ur5 cassie_full_body cassie_demo cassie_demo_posture cassie_demo_pinned cassie_demo_pik; do
