@@ -70,6 +70,14 @@ struct CoopLayout {
                                                  // first chain of each of the `rounds` levels (+ end)
     const int *tb_index;         // [ntasks] slot of the task's block in tb (-1: posture row, no block)
     const int *col_joint;        // [nv] the joint a tangent column belongs to
+    // PostureTask rows eliminated from the linear system (coop_dls): the Mf remaining rows, the posture tasks by tangent column
+    // (CSR: pstart[nv + 1], ptask), the diagonal metric's inverse at Dd (nv words)
+    int post_elim, Mf, Dd;
+    const int *frow, *pstart, *ptask;
+    const int *jrow;             // [ntasks] first row of the task's block in J (the task's row; posture rows eliminated: its row among the rest)
+    // targets: block of task t at tg + tg_off[t] (twelve words; a posture row: one word, at + 9); LDS word i comes from slot tg_src[i]
+    int ntg;
+    const int *tg_off, *tg_src;
 };
 
 // C = A * B on 12-double SE(3) values held in the workspace (A, B) -> registers (C)
@@ -194,8 +202,9 @@ IKD_FN double coop_evaluate(const GenericTables &T, const CoopLayout &L, const i
         const double *w6 = T.t_w + 6 * t;
         double *tb = ws + L.tb + 36 * (L.tb_index[t] < 0 ? 0 : L.tb_index[t]);
         if (type == GT_POSTURE_ROW) {  // ik/ik/posture.hpp:51-68: the whole row is written here
-            ws[L.e + row] = (ws[L.q + rj] - ws[L.tg + 12 * t + 9]) * w6[1] * w6[0];
-            for (int c = 0; c < nv; ++c) ws[L.J + row * nv + c] = (c == fj) ? w6[0] : 0.0;
+            ws[L.e + row] = (ws[L.q + rj] - ws[L.tg + L.tg_off[t] + 9]) * w6[1] * w6[0];
+            if (!L.post_elim)   // (eliminated rows: coop_dls never reads their Jacobian)
+                for (int c = 0; c < nv; ++c) ws[L.J + row * nv + c] = (c == fj) ? w6[0] : 0.0;
             continue;
         }
         if (type == GT_COM) {  // ik::CentreOfMassTask, ik/ik/centre_of_mass.hpp:33-45: tb = placement of the reference frame
@@ -205,13 +214,13 @@ IKD_FN double coop_evaluate(const GenericTables &T, const CoopLayout &L, const i
             const double d[3] = {dfma(ws[L.sf], T.inv_total_mass, -oMr[9]), dfma(ws[L.sf + 1], T.inv_total_mass, -oMr[10]),
                                  dfma(ws[L.sf + 2], T.inv_total_mass, -oMr[11])};
             for (int r = 0; r < 3; ++r)
-                ws[L.e + row + r] = (dfma(oMr[r], d[0], dfma(oMr[3 + r], d[1], oMr[6 + r] * d[2])) - ws[L.tg + 12 * t + 9 + r]) * w6[r];
+                ws[L.e + row + r] = (dfma(oMr[r], d[0], dfma(oMr[3 + r], d[1], oMr[6 + r] * d[2])) - ws[L.tg + L.tg_off[t] + 9 + r]) * w6[r];
             continue;
         }
         double oMf[12], oMr[12], tg[12];
         coop_se3_mul_ws(ws + oMi + 12 * fj, T.t_fpl + 12 * t, oMf);
         coop_se3_mul_ws(ws + oMi + 12 * rj, T.t_rpl + 12 * t, oMr);
-        for (int k = 0; k < 12; ++k) { tg[k] = ws[L.tg + 12 * t + k]; tb[k] = oMf[k]; }
+        { const int to = L.tg + L.tg_off[t]; for (int k = 0; k < 12; ++k) { tg[k] = ws[to + k]; tb[k] = oMf[k]; } }
         const double Rf[9] = {oMf[0], oMf[1], oMf[2], oMf[3], oMf[4], oMf[5], oMf[6], oMf[7], oMf[8]};
         const double pf[3] = {oMf[9], oMf[10], oMf[11]};
         if (type >= GT_ALIGN_X) {  // AlignAxisTask, ik/ik/frame.hpp:257-301: tb[12..14] = the row's direction in the frame
@@ -252,7 +261,7 @@ IKD_FN double coop_evaluate(const GenericTables &T, const CoopLayout &L, const i
         const double vw[6] = {ws[L.Jw + c], ws[L.Jw + nv + c], ws[L.Jw + 2 * nv + c],
                               ws[L.Jw + 3 * nv + c], ws[L.Jw + 4 * nv + c], ws[L.Jw + 5 * nv + c]};
         for (int t = 0; t < nt; ++t) {
-            const int type = T.t_type[t], row = T.t_row[t], dim = T.t_dim[t];
+            const int type = T.t_type[t], row = L.jrow[t], dim = T.t_dim[t];   // (row: of J)
             if (type == GT_POSTURE_ROW) continue;
             if (type == GT_COM) {  // jacobianCenterOfMass, ik/ik/data.cpp:31-34: every column, scaled by the mass of its joint's subtree
                 const double *w6 = T.t_w + 6 * t;
@@ -626,8 +635,59 @@ IKD_FN void coop_dls(const GenericTables &T, const CoopLayout &L, const LoopPara
     bool active = true, success = false;
     int iters = prm.max_iterations;
     IKC_TICK_INIT;
+    // PostureTask rows (ik/ik/posture.hpp:51-68) have ONE non-zero entry each, so they are taken out of the linear system: with J_f the
+    // other Mf rows and D = lambda^2 I + sum of the posture rows' w^2 on their columns (diagonal),
+    //   dq = -J^T (J J^T + lambda^2 I)^-1 e = -(J_f^T J_f + D)^-1 J^T e = -(u - D^-1 J_f^T z),   u = D^-1 J^T e,  (I + J_f D^-1 J_f^T) z = J_f u
+    // -- an Mf x Mf system instead of M x M (the demo with its posture regulariser: 10 instead of 26; two feet + pelvis + sixteen
+    // posture rows: 12 instead of 28, which is the difference between the register Cholesky and the LDS one, 199 ms per launch).
+    const bool elim = L.post_elim != 0;
+    if (elim) {
+        IKC_FOR(c, nv) {
+            double d = prm.lam2;
+            for (int k = L.pstart[c]; k < L.pstart[c + 1]; ++k) { const double w = T.t_w[6 * L.ptask[k]]; d = dfma(w, w, d); }
+            ws[L.Dd + c] = 1.0 / d;
+        }
+        IKC_SYNC();
+    }
     for (int it = 0; it < prm.max_iterations; ++it) {
         const double e0sq = coop_evaluate(T, L, g, ws IKC_TICK_PASS);
+        if (elim) {
+            const int Mf = L.Mf;
+            IKC_FOR(c, nv) {   // u = D^-1 J^T e (parked where dq goes)
+                double s = 0.0;
+#pragma unroll 4
+                for (int k = 0; k < Mf; ++k) s = dfma(ws[L.J + k * nv + c], ws[L.e + L.frow[k]], s);
+                for (int k = L.pstart[c]; k < L.pstart[c + 1]; ++k) { const int t = L.ptask[k]; s = dfma(T.t_w[6 * t], ws[L.e + T.t_row[t]], s); }
+                ws[L.dq + c] = s * ws[L.Dd + c];
+            }
+            IKC_SYNC();
+            IKC_FOR(p, tri(Mf, 0) + Mf) {   // I + J_f D^-1 J_f^T, lower triangle, with J_f u as row Mf
+                const int i = L.pair_i[p], j = L.pair_j[p];
+                double s;
+                if (i == Mf) {
+                    s = 0.0;
+#pragma unroll 8
+                    for (int c = 0; c < nv; ++c) s = dfma(ws[L.J + j * nv + c], ws[L.dq + c], s);
+                } else {
+                    s = (i == j) ? 1.0 : 0.0;
+#pragma unroll 8
+                    for (int c = 0; c < nv; ++c) s = dfma(ws[L.J + i * nv + c] * ws[L.Dd + c], ws[L.J + j * nv + c], s);
+                }
+                ws[L.G + tri(i, j)] = s;
+            }
+            IKC_SYNC();
+            IKC_TICK(4);
+            coop_chol_solve(L, g, ws, L.G, L.dinv, L.x, Mf);
+            IKC_TICK(6);
+            IKC_FOR(c, nv) {   // dq = -(u - D^-1 J_f^T z)
+                double s = 0.0;
+#pragma unroll 4
+                for (int k = 0; k < Mf; ++k) s = dfma(ws[L.J + k * nv + c], ws[L.x + k], s);
+                ws[L.dq + c] = dfma(ws[L.Dd + c], s, -ws[L.dq + c]);
+            }
+            IKC_SYNC();
+            IKC_TICK(7);
+        } else {
         // ---- JJ = Jt Jt^T + damping^2 I (ik/ik/dls.cpp:39-41), lower triangle, with the right-hand side et as row M
 #if IKD_ON_DEVICE
         // (wave-uniform choices; the register form covers M <= 15, nv <= 32)
@@ -661,6 +721,7 @@ IKD_FN void coop_dls(const GenericTables &T, const CoopLayout &L, const LoopPara
         }
         IKC_SYNC();
         IKC_TICK(7);
+        }
         if (T.Mc > 0) {  // dq <- N dq, N = I - pinv(Jc) Jc: the step stays in the null space of the constraints (dls.cpp:26-34,43-53)
             IKC_FOR(k, T.ncons) {  // placements of the constrained frame, its reference frame, and the one in the other
                 double oMf[12], oMr[12], fMr[12];
@@ -769,7 +830,10 @@ IKD_FN void dls_coop_body(const CoopKernelArgs &a, int64_t problem, const int g,
     const int64_t b = valid ? problem : a.B - 1;
     const int nq = a.T.nq, nslots = a.T.ntasks * 12;
     IKC_FOR(i, nq) ws[a.L.q + i] = a.q0[at(a.layout, a.B, nq, i, b)];
-    IKC_FOR(i, nslots) ws[a.L.tg + i] = a.layout == LAYOUT_SOA ? a.targets[static_cast<int64_t>(i) * a.B + b] : a.targets[b * nslots + i];
+    IKC_FOR(i, a.L.ntg) {
+        const int slot = a.L.tg_src[i];
+        ws[a.L.tg + i] = a.layout == LAYOUT_SOA ? a.targets[static_cast<int64_t>(slot) * a.B + b] : a.targets[b * nslots + slot];
+    }
     IKC_SYNC();
     int iters;
     bool success;

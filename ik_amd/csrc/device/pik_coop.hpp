@@ -234,7 +234,10 @@ IKD_FN void pik_coop_body(const PikCoopKernelArgs &a, const GenericTables &T, co
     const int64_t b = valid ? problem : a.B - 1;
     const int nq = T.nq, nslots = T.ntasks * 12;
     IKC_FOR(i, nq) ws[L.q + i] = a.q0[at(a.layout, a.B, nq, i, b)];
-    IKC_FOR(i, nslots) ws[L.tg + i] = a.layout == LAYOUT_SOA ? a.targets[static_cast<int64_t>(i) * a.B + b] : a.targets[b * nslots + i];
+    IKC_FOR(i, L.ntg) {
+        const int slot = L.tg_src[i];
+        ws[L.tg + i] = a.layout == LAYOUT_SOA ? a.targets[static_cast<int64_t>(slot) * a.B + b] : a.targets[b * nslots + slot];
+    }
     IKC_SYNC();
     int iters;
     bool success;

@@ -35,7 +35,8 @@ inline ikdev::GenericTables bind_generic_tables(const ProblemHost &ph, const int
 }
 
 // The cooperative DLS program's layout and index tables (problem.cpp: build_coop).
-inline ikdev::CoopLayout bind_coop_layout(const ProblemHost &ph, const int32_t *ibase) {
+// for_pik: ik::pik keeps every row in its system, the DLS solver eliminates the posture rows and lays its workspace out for the rest
+inline ikdev::CoopLayout bind_coop_layout(const ProblemHost &ph, const int32_t *ibase, bool for_pik = false) {
     const GenericHost &g = ph.generic;
     ikdev::CoopLayout L{};
     L.q = g.c_q; L.tg = g.c_tg; L.A0 = g.c_A0; L.A1 = g.c_A1; L.Jw = g.c_Jw; L.tb = g.c_tb; L.e = g.c_e; L.J = g.c_J; L.G = g.c_G;
@@ -50,6 +51,20 @@ inline ikdev::CoopLayout bind_coop_layout(const ProblemHost &ph, const int32_t *
     }
     L.support = ibase + g.o_csupport; L.pair_i = ibase + g.o_cpair_i; L.pair_j = ibase + g.o_cpair_j; L.order = ibase + g.o_cup; L.chain_start = ibase + g.o_cchain; L.lvl_start = ibase + g.o_clvl; L.tb_index = ibase + g.o_ctbindex; L.col_joint = ibase + g.o_ccoljoint; L.csupp_f = ibase + g.o_ccsf; L.csupp_r = ibase + g.o_ccsr;
     L.cpair_i = ibase + g.o_ccpair_i; L.cpair_j = ibase + g.o_ccpair_j;
+    L.post_elim = for_pik ? 0 : g.coop_post_elim; L.Mf = g.coop_Mf; L.Dd = g.c_Dd;
+    L.frow = ibase + g.o_cfrow; L.pstart = ibase + g.o_cpstart; L.ptask = ibase + g.o_cptask;
+    L.ntg = g.coop_ntg; L.tg_off = ibase + g.o_ctgoff; L.tg_src = ibase + g.o_ctgsrc;
+    L.jrow = ibase + g.o_trow;
+    if (L.post_elim) {
+        const int Mf = g.coop_Mf;
+        L.A1 = g.d_A1; L.Jw = g.d_Jw; L.e = g.d_e; L.cnrm = g.d_e; L.dq = g.d_dq; L.Dd = g.d_Dd; L.sf = g.d_sf;
+        L.A0 = L.J = L.Jc = g.d_J; L.tb = L.G = L.cb = g.d_G;
+        L.dinv = L.G + (Mf + 1) * (Mf + 2) / 2; L.x = L.dinv + Mf; L.words = g.d_words;
+        L.jrow = ibase + g.o_cjrow;
+        const int Mc = ph.crows, region = g.d_words - 1 - g.d_G;
+        const char *force = std::getenv("IKGPU_PIK_PROJECTOR");
+        L.cholqr_c = (Mc > 0 && Mc * (Mc + 1) / 2 + Mc <= region && !(force && std::string(force) == "dense")) ? 1 : 0;
+    }
     return L;
 }
 

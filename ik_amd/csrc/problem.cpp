@@ -267,6 +267,41 @@ void build_coop(ProblemHost &ph, const Model &m) {
         }
     g.o_ccsf = put_i(csf);
     g.o_ccsr = put_i(csr);
+    // PostureTask rows are eliminated from the linear system (device/coop_solver.hpp, coop_dls): the remaining rows, and the posture
+    // rows by tangent column
+    std::vector<int32_t> frow, pstart(nv + 1, 0), ptask;
+    for (int t = 0; t < nt; ++t)
+        if (ph.tasks[t].type != IKGPU_POSTURE_ROW)
+            for (int r = 0; r < task_dim(ph.tasks[t]); ++r) frow.push_back(g.ints[g.o_trow + t] + r);
+    for (int c = 0; c < nv; ++c) {
+        pstart[c] = static_cast<int32_t>(ptask.size());
+        for (int t = 0; t < nt; ++t)
+            if (ph.tasks[t].type == IKGPU_POSTURE_ROW && ph.tasks[t].frame == c) ptask.push_back(t);
+    }
+    pstart[nv] = static_cast<int32_t>(ptask.size());
+    g.coop_post_elim = ptask.empty() ? 0 : 1;
+    g.coop_Mf = static_cast<int>(frow.size());
+    std::vector<int32_t> jrow(nt, -1), tgoff(nt, 0), tgsrc;
+    {
+        int k = 0;
+        for (int t = 0; t < nt; ++t) {
+            if (ph.tasks[t].type == IKGPU_POSTURE_ROW) {
+                tgoff[t] = static_cast<int32_t>(tgsrc.size()) - 9;
+                tgsrc.push_back(t * 12 + 9);
+            } else {
+                jrow[t] = k; k += task_dim(ph.tasks[t]);
+                tgoff[t] = static_cast<int32_t>(tgsrc.size());
+                for (int w = 0; w < 12; ++w) tgsrc.push_back(t * 12 + w);
+            }
+        }
+    }
+    g.coop_ntg = static_cast<int>(tgsrc.size());
+    g.o_cjrow = put_i(jrow);
+    g.o_ctgoff = put_i(tgoff);
+    g.o_ctgsrc = put_i(tgsrc);
+    g.o_cfrow = put_i(frow);
+    g.o_cpstart = put_i(pstart);
+    g.o_cptask = put_i(ptask);
     std::vector<int32_t> colj(nv, 0);
     for (int j = 1; j < nj; ++j)
         for (int c = m.joint_idx_v[j]; c < m.joint_idx_v[j] + (m.joint_type[j] == IKGPU_JOINT_FREEFLYER ? 6 : 1); ++c) colj[c] = j;
@@ -317,7 +352,7 @@ void build_coop(ProblemHost &ph, const Model &m) {
     // (read by the Jacobian columns only) with the Gram matrix, its pivots and the solution (written after them).
     int o = 0;
     g.c_q = o; o += m.nq;
-    g.c_tg = o; o += 12 * nt;
+    g.c_tg = o + 9; o += g.coop_ntg + 9;   // (a leading posture row's block starts nine words before its one word)
     int mmax = 0;  // rows of the largest priority level: the prioritised solver parks that level's projected Jacobian where the
     {              // joint placements lived (dead once the task Jacobian is built) and two short vectors over the joint Jacobian
         std::vector<int> lvl(static_cast<size_t>(g.nlevels), 0);
@@ -329,6 +364,7 @@ void build_coop(ProblemHost &ph, const Model &m) {
     const int Mc = ph.crows;
     g.c_e = o; g.c_cnrm = o; o += std::max(M, Mc);   // (the constraint projection runs after the error vector is dead)
     g.c_dq = o; o += nv;
+    g.c_Dd = o; o += g.coop_post_elim ? nv : 0;
     g.c_sf = o; o += g.has_com ? 3 * nj : 0;
     g.c_A0 = o; g.c_J = o; g.c_Jc = o; o += std::max(std::max(12 * nj, M * nv), Mc * nv);   // (and after the task Jacobian is)
     g.c_tb = o; g.c_G = o; g.c_cb = o;
@@ -336,6 +372,19 @@ void build_coop(ProblemHost &ph, const Model &m) {
     g.c_x = g.c_dinv + M;
     o += std::max(std::max(36 * nblocks, (M + 1) * (M + 2) / 2 + 2 * M), 36 * ncons);
     g.coop_words = o + (o % 2 == 0 ? 1 : 0);  // odd stride between the groups of a block
+    if (g.coop_post_elim) {   // the DLS solver's own layout when the posture rows are eliminated: Mf rows
+        const int Mf = g.coop_Mf;
+        int d = g.c_tg + g.coop_ntg;              // q and the targets as above
+        g.d_A1 = d; d += 12 * nj;
+        g.d_Jw = d; d += 6 * nv;
+        g.d_e = d; d += std::max(M, Mc);
+        g.d_dq = d; d += nv;
+        g.d_Dd = d; d += nv;
+        g.d_sf = d; d += g.has_com ? 3 * nj : 0;
+        g.d_J = d; d += std::max(std::max(12 * nj, Mf * nv), Mc * nv);
+        g.d_G = d; d += std::max(std::max(36 * nblocks, (Mf + 1) * (Mf + 2) / 2 + 2 * Mf), 36 * ncons);
+        g.d_words = d + (d % 2 == 0 ? 1 : 0);
+    }
     g.c_P = g.coop_words;  // ik::pik: the projector follows the DLS workspace
     g.coop_words_pik = g.coop_words + nv * nv;
     g.coop_words_pik += (g.coop_words_pik % 2 == 0 ? 1 : 0);
@@ -345,7 +394,7 @@ void build_coop(ProblemHost &ph, const Model &m) {
     // M = 28 (two feet + pelvis + sixteen posture rows) 265 ms per launch there.
     const size_t lds_pik = 8 * (4 * static_cast<size_t>(g.coop_words_pik) + g.dbls.size() + (g.ints.size() + 1) / 2);
     g.coop_pik_ok = lds_pik <= kCoopLdsCap ? 1 : 0;
-    const size_t lds_bytes = 8 * (4 * static_cast<size_t>(g.coop_words) + g.dbls.size() + (g.ints.size() + 1) / 2);
+    const size_t lds_bytes = 8 * (4 * static_cast<size_t>(g.coop_post_elim ? g.d_words : g.coop_words) + g.dbls.size() + (g.ints.size() + 1) / 2);
     g.coop_ok = lds_bytes <= kCoopLdsCap ? 1 : 0;
 }
 

@@ -37,6 +37,14 @@ struct GenericHost {
     int off_Jc = 0;
     // cooperative form of the DLS program (device/coop_solver.hpp): 16 lanes per problem, workspace in LDS
     int coop_ok = 0, coop_rounds = 0, coop_words = 0, coop_npairs = 0;
+    int coop_post_elim = 0, coop_Mf = 0, c_Dd = 0, o_cfrow = 0, o_cpstart = 0, o_cptask = 0;  // posture rows eliminated (coop_dls)
+    // ... whose DLS workspace is laid out for the Mf remaining rows (ik::pik keeps the full one above): offsets d_*, and per task the
+    // first row of its block in that compact Jacobian (o_cjrow; -1: posture row)
+    int d_words = 0, d_A1 = 0, d_Jw = 0, d_e = 0, d_dq = 0, d_Dd = 0, d_sf = 0, d_J = 0, d_G = 0, o_cjrow = 0;
+    // targets in LDS: twelve words per task with a pose / direction, ONE per posture row (its target value); o_ctgoff: [ntasks] offset
+    // of the task's block (a posture row's word sits at offset + 9, where the pose's first translation entry would), o_ctgsrc: the
+    // target slot (task * 12 + k) each LDS word is loaded from
+    int coop_ntg = 0, o_ctgoff = 0, o_ctgsrc = 0;
     int coop_pik_ok = 0, coop_words_pik = 0, coop_mmax = 0, c_P = 0;  // ik::pik in the same form (device/pik_coop.hpp)
     int o_csupport = 0, o_cpair_i = 0, o_cpair_j = 0, o_cup = 0, o_cchain = 0, o_clvl = 0, o_ctbindex = 0, o_ccoljoint = 0, o_ccsf = 0, o_ccsr = 0;  // into ints: [ntasks][nv], [npairs] x 2, joints by depth [njoints - 1] + level starts [rounds + 1]
     int c_q = 0, c_tg = 0, c_A0 = 0, c_A1 = 0, c_Jw = 0, c_tb = 0, c_e = 0, c_J = 0, c_G = 0, c_dinv = 0, c_x = 0, c_dq = 0, c_sf = 0, c_cb = 0, c_Jc = 0, c_cnrm = 0;

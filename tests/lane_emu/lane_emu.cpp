@@ -296,7 +296,7 @@ int lane_emu_pik_coop(const char *urdf, size_t len, int root_joint, const ikgpu_
         if (!ph.generic.coop_pik_ok) { g_err = "no cooperative form for this problem"; return 2; }
         ikdev::PikCoopKernelArgs a{};
         a.T = ikgpu::bind_generic_tables(ph, ph.generic.ints.data(), ph.generic.dbls.data());
-        a.L = ikgpu::bind_coop_layout(ph, ph.generic.ints.data());
+        a.L = ikgpu::bind_coop_layout(ph, ph.generic.ints.data(), /*for_pik=*/true);
         a.K = ikgpu::bind_pik_coop_layout(ph);
         a.prm.max_iterations = prm->max_iterations;
         a.prm.step_length = prm->step_length;

@@ -642,10 +642,19 @@ def test_cooperative_program_matches_oracle(emu, case):
 
 
 def test_cooperative_program_is_refused_when_four_workspaces_do_not_fit_the_lds_budget(emu):
+    """Four workspaces + the tables must fit the CU's 160 KB of LDS (round 1: 64 KB).  M = 28 (two feet, pelvis, sixteen posture rows:
+    2 k doubles per problem) fits now and matches the oracle; ten Full tasks (M = 60: 5 k doubles per problem) do not."""
     from ik_amd import capi
-    name, ff, specs, root, edit = GENERIC_CASES["posture_regulariser"]      # M = 28, nv = 22: 2 k doubles per problem
+    name, ff, specs, root, edit = GENERIC_CASES["posture_regulariser"]
     urdf, model, om, tasks, ot, q0, tg, M = _generic_case(name, ff, specs, 4)
     p = lambda a: C.c_void_p(a.ctypes.data)
-    prm = capi.DlsParams(1, 1e-2, 1.0, -1.0)
+    prm = capi.DlsParams(5, 1e-2, 1.0, -1.0)
+    qo, ok, it = np.empty_like(q0), np.zeros(4, np.uint8), np.zeros(4, np.int32)
+    assert emu.lane_emu_dls_coop(urdf, C.c_size_t(len(urdf)), 1, tasks, len(tasks), C.c_int64(4), p(q0), p(tg), C.byref(prm), p(qo), p(ok), p(it), 1) == 0
+    q_ref, _, _ = O.dls_batch(om, ot, tg, q0, O.params(5, 1e-2, 1.0, -1.0))
+    assert np.abs(qo - q_ref).max() < 1e-8
+    frames = ["LeftFootFront", "LeftFootBack", "RightFootFront", "RightFootBack", "pelvis"] * 2
+    urdf, model, om, tasks, ot, q0, tg, M = _generic_case("cassie", True, [(f, "universe", 2, 0, None) for f in frames], 4)
+    assert M == 60
     qo, ok, it = np.empty_like(q0), np.zeros(4, np.uint8), np.zeros(4, np.int32)
     assert emu.lane_emu_dls_coop(urdf, C.c_size_t(len(urdf)), 1, tasks, len(tasks), C.c_int64(4), p(q0), p(tg), C.byref(prm), p(qo), p(ok), p(it), 1) == 2
