@@ -28,6 +28,13 @@ CASES = {
                                                              ("align", "LeftFootFront", "universe", 1, 0, None),
                                                              ("posture", 16, None, None, 0, ([0.3 + 0.04 * k for k in range(16)], [1.0] * 16))],
                                             [("RightFootFront", 0, "universe")]),
+    # every line of the reference demo switched on (ik_ros/src/cassie.cpp:45-81): foot, pelvis, alignment, posture regulariser, centre of
+    # mass, and the right foot pinned -- the generic kernel (centre-of-mass rows), posture rows eliminated, 13 x 13 system
+    "demo_everything_on": ("cassie", True, [("frame", "LeftFootFront", "pelvis", 0, 0, None), ("frame", "pelvis", "universe", 2, 0, None),
+                                            ("align", "LeftFootFront", "universe", 1, 0, None),
+                                            ("posture", 16, None, None, 0, ([0.3 + 0.04 * k for k in range(16)], [1.0] * 16)),
+                                            ("com", None, "universe", None, 0, None)],
+                           [("RightFootFront", 0, "universe")]),
     "pelvis_with_both_feet_locked": ("cassie", True, [("frame", "pelvis", "universe", 2, 0, None)],
                                      [("RightFootFront", 2, "universe"), ("LeftFootFront", 0, "RightFootFront")]),
     "arm_keeps_tool_orientation": ("ur5", False, [("frame", "tool0", "universe", 0, 0, None)], [("tool0", 1, "universe")]),

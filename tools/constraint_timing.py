@@ -14,7 +14,7 @@ from test_gpu_constraints import CASES  # noqa: E402
 from test_gpu_generic import build  # noqa: E402
 
 B = 65536
-for case in ("demo_right_foot_pinned", "leg_with_relative_orientation", "pelvis_with_both_feet_locked"):
+for case in ("demo_right_foot_pinned", "demo_right_foot_pinned_with_posture", "demo_everything_on", "leg_with_relative_orientation", "pelvis_with_both_feet_locked"):
     name, ff, specs, cspecs = CASES[case]
     ik, O, model, problem, _, om, ot, q0, tg = build(name, ff, specs, 256, seed=21)
     for i, (f, t, r) in enumerate(cspecs):
