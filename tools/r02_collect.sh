@@ -18,3 +18,5 @@ python3 tools/pmc_to_stats.py gpurun_out/pmc_cassie_demo "dls_tree<NJ=7,chains=1
 python3 tools/pmc_to_stats.py gpurun_out/pmc_cassie_demo_posture "dls_tree<NJ=7,chains=1,base_task,base_reference,align_axis,posture>" profiles/r02_pmc posture | cut -c1-80
 python3 tools/pmc_to_stats.py gpurun_out/pmc_cassie_demo_pinned "dls_tree<NJ=7,chains=1,base_task,base_reference,align_axis,constraint_rows=3>" profiles/r02_pmc pinned | cut -c1-80
 python3 tools/pmc_to_stats.py gpurun_out/pmc_cassie_demo_pik "dls_tree<NJ=7,chains=1,base_task,base_reference,align_axis,pik_levels=2>" profiles/r02_pmc pik | cut -c1-80
+python3 tools/pmc_to_stats.py gpurun_out/pmc_cassie_demo_pinned_posture "dls_tree<NJ=7,chains=1,base_task,base_reference,align_axis,posture,constraint_rows=3>" profiles/r02_pmc pinned_posture | cut -c1-80
+python3 tools/pmc_to_stats.py gpurun_out/pmc_cassie_demo_generic "dls_generic<M=10,nv=22,joints=17>" profiles/r02_pmc generic_demo | cut -c1-80
