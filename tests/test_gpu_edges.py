@@ -230,6 +230,33 @@ def test_hip_graph_capture_of_the_other_kernels(ctx, case, monkeypatch):
     assert torch.equal(out[0], ref) and torch.equal(out[1], ok_ref) and torch.equal(out[2], it_ref)
 
 
+def test_concurrent_streams_on_the_cooperative_generic_kernel(ctx, monkeypatch):
+    """The persistent workgroups of the cooperative kernels take their groups of problems from a per-launch work queue (a slot of
+    a ring the launch zeroes on its stream): launches of ONE problem handle in flight on several streams must not share a head."""
+    torch, ik = ctx["torch"], ctx["ik"]
+    from test_gpu_generic import build
+    monkeypatch.delenv("IKGPU_DLS_KERNEL", raising=False)
+    specs = [("frame", "LeftFootFront", "universe", 2, 0, None), ("frame", "RightFootFront", "universe", 2, 0, None),
+             ("frame", "LeftFootBack", "universe", 0, 0, None)]
+    B = 6000
+    ik_amd, O, model, problem, data, om, ot, q0, tg = build("cassie", True, specs, B, seed=29)
+    assert data.kernel.startswith("dls_generic<")
+    Q0 = torch.from_numpy(np.ascontiguousarray(q0.T)).cuda()
+    T = torch.from_numpy(np.ascontiguousarray(tg.transpose(1, 2, 0))).cuda()
+    p = ik.dls_parameters(max_iterations=20, damping=1e-1, step_length=0.5)
+    v = ik.never_stop_visitor()
+    ref, ok_ref, it_ref = ik.dls_batch(problem, Q0, T, data, v, p)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    outs = []
+    for rep in range(3):
+        for s in streams:
+            with torch.cuda.stream(s):
+                outs.append(ik.dls_batch(problem, Q0, T, data, v, p))
+    torch.cuda.synchronize()
+    assert all(torch.equal(o[0], ref) and torch.equal(o[2], it_ref) for o in outs)
+
+
 def test_problem_support_marks_the_entries_a_solve_can_move(native_built):
     """ikgpu_problem_support (what the compact multi-GPU gather ships): the task supports and the floating base; every other entry of
     q only passes through the joint clipping -- and the solve indeed leaves those at clip(q0)."""
