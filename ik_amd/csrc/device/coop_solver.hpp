@@ -551,11 +551,72 @@ IKD_FN int coop_rowspace_basis(const int g, double *ws, const int offRows, const
 // taken only when every pivot L_kk^2 stays above 1e-4 of the largest diagonal entry (cond^2 < ~1e5: error < 1e-10) in ALL
 // groups of the wave; otherwise it returns false with A untouched and the caller runs the rank-revealing routine.
 // pair_i / pair_j: the (i, j) of the lower triangle of an (at least) m-row matrix listed by rows.
+#if IKD_ON_DEVICE
+// The factorisation of coop_rowspace_basis_cholqr in registers (one row per lane, see coop_chol_solve_regs): same pivots, same
+// test on them; L (strict lower triangle, scaled) and the pivots' reciprocals are written back for the forward substitution.
+template <int MMAX, int K>
+IKD_FN void cholqr_regs_pivots(double (&row)[16], const int g, const int m, const double thr, bool &ok) {
+    if constexpr (K < MMAX) {
+        if (K < m) {   // (wave-uniform)
+            const double d = group_bcast<K>(row[K]);
+            ok = ok && d > thr;                    // false for NaN as well
+            const double inv = drsqrt(d);
+            const double lik = row[K] * inv;
+            row[K] = g == K ? inv : lik;
+            chol_regs_trail<MMAX, K, K + 1>(row, lik);
+        }
+        cholqr_regs_pivots<MMAX, K + 1>(row, g, m, thr, ok);
+    }
+}
+template <int MMAX, int K>
+IKD_FN double cholqr_regs_maxdiag(const double (&row)[16], const int m, double acc) {
+    if constexpr (K < MMAX) {
+        if (K < m) acc = dmax(acc, group_bcast<K>(row[K]));
+        return cholqr_regs_maxdiag<MMAX, K + 1>(row, m, acc);
+    } else {
+        return acc;
+    }
+}
+template <int MMAX>
+IKD_FN bool cholqr_regs_factor(const int g, double *ws, const int offG0, const int offdinv, const int m) {
+    double row[16];
+#pragma unroll
+    for (int j = 0; j < MMAX; ++j) row[j] = (g < m && j <= g) ? ws[offG0 + tri(g, j)] : 0.0;
+    const double maxdiag = cholqr_regs_maxdiag<MMAX, 0>(row, m, 0.0);
+    bool ok = maxdiag > 0.0;
+    cholqr_regs_pivots<MMAX, 0>(row, g, m, 1e-4 * maxdiag, ok);
+    if (g < m) {
+#pragma unroll
+        for (int j = 0; j < MMAX; ++j) {
+            if (j < g) ws[offG0 + tri(g, j)] = row[j];
+            if (j == g) ws[offdinv + g] = row[j];
+        }
+    }
+    IKC_SYNC();
+    return ok;
+}
+#endif
+
 template <class AnyFn>
 IKD_FN bool coop_rowspace_basis_cholqr(const int *pair_i, const int *pair_j, const int g, double *ws, const int offRows, const int offG0,
                                        const int offdinv, const int m, const int nv, AnyFn any_fn) {
     (void)g;
     const int npairs = tri(m, 0);
+#if IKD_ON_DEVICE
+    if (m <= 16) {   // (wave-uniform)
+        const bool okr = m <= 10 ? cholqr_regs_factor<10>(g, ws, offG0, offdinv, m) : cholqr_regs_factor<16>(g, ws, offG0, offdinv, m);
+        if (any_fn(!okr)) return false;
+        IKC_FOR(c, nv) {                        // forward substitution, as below
+            for (int k = 0; k < m; ++k) {
+                double v = ws[offRows + k * nv + c];
+                for (int j = 0; j < k; ++j) v = dfma(-ws[offG0 + tri(k, j)], ws[offRows + j * nv + c], v);
+                ws[offRows + k * nv + c] = v * ws[offdinv + k];
+            }
+        }
+        IKC_SYNC();
+        return true;
+    }
+#endif
     double maxdiag = 0.0;
     for (int k = 0; k < m; ++k) maxdiag = dmax(maxdiag, ws[offG0 + tri(k, k)]);
     bool ok = maxdiag > 0.0;
