@@ -8,6 +8,9 @@
 #include "kernels.hpp"
 
 #include <algorithm>
+#include <mutex>
+#include <utility>
+#include <vector>
 #include <cstdlib>
 #include <stdexcept>
 #include <string>
@@ -524,7 +527,16 @@ __global__ __launch_bounds__(kBlock) void pik_coop_kernel(const ikdev::PikCoopKe
 // A launch asking for more than the default 64 KB of dynamic LDS has to raise the kernel's limit first (once per kernel and device).
 bool raise_lds_limit(const void *kernel, size_t lds) {
     if (lds <= 64 * 1024) return true;
-    return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    static std::mutex mu;
+    static std::vector<std::pair<const void *, int>> done;   // (kernel, device) pairs already raised
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    for (const auto &d : done)
+        if (d.first == kernel && d.second == dev) return true;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+    done.emplace_back(kernel, dev);
+    return true;
 }
 
 // Grid of a persistent cooperative launch: as many workgroups as the device keeps resident (LDS-bound: five per CU for the demo task

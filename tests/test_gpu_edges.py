@@ -187,7 +187,7 @@ def test_host_pointer_calls_from_two_threads_on_one_problem(ctx):
     assert not errors, errors
 
 
-@pytest.mark.parametrize("case", ["full_body_tree", "demo_with_posture_tree", "generic_cooperative", "pik_cooperative"])
+@pytest.mark.parametrize("case", ["full_body_tree", "demo_with_posture_tree", "generic_cooperative", "generic_cooperative_beyond_64kb", "pik_cooperative"])
 def test_hip_graph_capture_of_the_other_kernels(ctx, case, monkeypatch):
     """The tree kernels (hot build; posture build with its dynamic LDS) and the cooperative generic / PIK kernels allocate nothing
     and never synchronise either: one capture, replays with the same bits."""
@@ -201,6 +201,9 @@ def test_hip_graph_capture_of_the_other_kernels(ctx, case, monkeypatch):
                                    ("posture", 16, None, None, 1, ([0.1] * 16, [1.0] * 16))],
         "generic_cooperative": [("frame", "LeftFootFront", "universe", 2, 0, None), ("frame", "RightFootFront", "universe", 2, 0, None),
                                 ("frame", "LeftFootBack", "universe", 0, 0, None)],
+        # M = 36: four workspaces + the tables take more than the default 64 KB of dynamic LDS (the launch raises the kernel's limit once)
+        "generic_cooperative_beyond_64kb": [("frame", f, "universe", 2, 0, None) for f in
+                                            ("LeftFootFront", "LeftFootBack", "RightFootFront", "RightFootBack", "pelvis", "LeftFootFront")],
         "pik_cooperative": [("frame", "LeftFootFront", "universe", 2, 0, None), ("frame", "pelvis", "universe", 2, 1, None)],
     }[case]
     B = 1000
@@ -215,7 +218,7 @@ def test_hip_graph_capture_of_the_other_kernels(ctx, case, monkeypatch):
     else:
         solve, p = ik.dls_batch, ik.dls_parameters(max_iterations=12, damping=1e-1, step_length=0.5)
         assert data.kernel.startswith({"full_body_tree": "dls_tree<NJ=7,chains=2,base_task>", "demo_with_posture_tree": "dls_tree<NJ=7,chains=1,base_task,base_reference,posture>",
-                                       "generic_cooperative": "dls_generic<"}[case])
+                                       "generic_cooperative": "dls_generic<", "generic_cooperative_beyond_64kb": "dls_generic<M=36"}[case])
     v = ik.never_stop_visitor()
     ref, ok_ref, it_ref = solve(problem, Q0, T, data, v, p)
     out = (torch.empty_like(Q0), torch.empty(B, dtype=torch.uint8, device="cuda"), torch.empty(B, dtype=torch.int32, device="cuda"))
