@@ -40,7 +40,7 @@ IKD_FN void dls_tree_body(const TreeKernelArgs<NJ, NCH> &a, const Desc &d, int64
     double qb[7], qj0[NJ], qj1[NJ];  // chain 1's angles stay unused (zero) when NCH == 1
     // general builds: a fixed-base model has no base entries in q (do not read them: nq may be smaller than 7), its base pose is
     // the world
-    const bool fixed_base = (spec_is_general(SPEC) && SPEC != (1 << kSpecCons) && SPEC != kSpecPostCons) ? a.prm.fixed_base != 0 : false;  // (no constraints on fixed-base models)
+    const bool fixed_base = (spec_is_general(SPEC) && (SPEC < 0 || !spec_has_constraint(SPEC))) ? a.prm.fixed_base != 0 : false;  // (no constraints on fixed-base models)
 #pragma unroll
     for (int k = 0; k < 7; ++k) qb[k] = fixed_base ? (k == 6 ? 1.0 : 0.0) : a.q0[at(a.layout, a.B, a.nq, k, b)];  // free-flyer: idx_q = 0
 #pragma unroll

@@ -685,12 +685,15 @@ IKD_FN void constraint_project(const double (&R1)[9], const double (&p1)[3], PlP
 // Bit kSpecPost (alone: otherwise a general build): the posture code above is compiled in.
 // Bit kSpecCons / kSpecPik (alone): a general build with the FrameConstraint code / with level 1 of a two-level ik::pik.
 constexpr int kSpecUnitP = 29, kSpecIdP = 28, kSpecPost = 26, kSpecCons = 25, kSpecPik = 24;
+// Bit kSpecGen: the general extras next to a folded placement mask (bits 0..NJ) -- "general" builds without a mask carry none of it
+// (SPEC = 0, or the pure posture / constraint / pik flags).
+constexpr int kSpecGen = 23;
 constexpr int kSpecPostCons = (1 << kSpecPost) | (1 << kSpecCons);   // posture rows next to the constraint (the demo with the stance foot pinned)
-constexpr bool spec_has_posture(int spec) { return spec < 0 || spec == (1 << kSpecPost) || spec == kSpecPostCons; }
-constexpr bool spec_has_constraint(int spec) { return spec < 0 || spec == (1 << kSpecCons) || spec == kSpecPostCons; }
-constexpr bool spec_is_general(int spec) {
-    return spec <= 0 || spec == (1 << kSpecPost) || spec == (1 << kSpecCons) || spec == (1 << kSpecPik) || spec == kSpecPostCons;
-}
+constexpr int kSpecExtras = (1 << kSpecGen) | (1 << kSpecPost) | (1 << kSpecCons) | (1 << kSpecPik);
+constexpr bool spec_has_posture(int spec) { return spec < 0 || (spec & (1 << kSpecPost)) != 0; }
+constexpr bool spec_has_constraint(int spec) { return spec < 0 || (spec & (1 << kSpecCons)) != 0; }
+constexpr bool spec_has_pik(int spec) { return spec < 0 || (spec & (1 << kSpecPik)) != 0; }
+constexpr bool spec_is_general(int spec) { return spec <= 0 || (spec & kSpecExtras) != 0; }
 
 // Where the lane keeps the joints outside the chains that carry a posture row: its own column of the caller's q_out.
 struct PostureState {
@@ -748,7 +751,7 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
                      const double *targets_lane, int64_t tstride, const int (&tslot)[3], const PostureState &ps, int &iters_out,
                      bool &success_out, Park park, AnyFn any_active) {
     constexpr bool kGeneral = spec_is_general(SPEC);  // the demo's extras exist in the general builds only
-    constexpr bool kPik = SPEC < 0 || SPEC == (1 << kSpecPik);  // the orthogonalisation behind PikRow costs the other builds registers
+    constexpr bool kPik = spec_has_pik(SPEC);  // the orthogonalisation behind PikRow costs the other builds registers
     constexpr bool kPost = spec_has_posture(SPEC);
     constexpr bool kCons = NCH > 1 && spec_has_constraint(SPEC);
     // (posture builds: a tail lane shadowing the last problem would re-read that problem's outside joints while their owner

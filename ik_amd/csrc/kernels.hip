@@ -274,7 +274,7 @@ __global__ __launch_bounds__(kTreeBlock) void dls_tree_kernel(const TreeKernelAr
     // posture build with one chain (no factor to park, LDS to spare): the joints outside the chain that carry a posture row
     // live in dynamic LDS [row][lane] between iterations; with two chains the LDS is full and they stay in the q_out column
     extern __shared__ double lds_post[];
-    double *post_lane = (SPEC == (1 << ikdev::kSpecPost) && NCH == 1) ? lds_post + threadIdx.x : nullptr;
+    double *post_lane = (SPEC > 0 && ikdev::spec_has_posture(SPEC) && NCH == 1) ? lds_post + threadIdx.x : nullptr;
     ikdev::dls_tree_body<NJ, NCH, SPEC>(a, d, gid, park, [](bool act) { return __any(act) != 0; }, post_lane, kTreeBlock);
 }
 
@@ -335,20 +335,30 @@ hipError_t run_dls_tree(const ProblemHost &ph, const DeviceTables &dt, const Bat
     // in between (as for the chain kernels): the placement mask folded, weights / task types / base-frame placement general
     // (A/B on one box, full body: pelvis task weighted 1.07 -> 0.91 ms, feet as Position tasks 0.98 -> 0.83 ms)
     const bool mask_only = !hot && !ph.tree_extras() && kMask != 0 && (a.prm.idmask[0] & kMask) == kMask && (NCH == 1 || (a.prm.idmask[1] & kMask) == kMask);
+    // the general builds (extras: base reference, alignment row, fixed base, posture rows, the constraint, level 1 of ik::pik) exist
+    // twice where the shape's mask is known: with it folded (bit kSpecGen next to the mask) and without
+    const bool fold = kMask != 0 && (a.prm.idmask[0] & kMask) == kMask && (NCH == 1 || (a.prm.idmask[1] & kMask) == kMask);
+    const size_t post_lds = NCH == 1 ? sizeof(double) * kTreeBlock * static_cast<size_t>(2 * std::max(1, a.prm.post_n) + NJ) : 0;
+#define IKGPU_TREE_GENERAL(FLAGS, LDS)                                                                                              \
+    do {                                                                                                                            \
+        if (fold) hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, (kMask != 0 ? ((FLAGS) | kMask | (1 << ikdev::kSpecGen)) : (FLAGS))>), grid, \
+                                     dim3(kTreeBlock), LDS, stream, a);                                                             \
+        else hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, (FLAGS)>), grid, dim3(kTreeBlock), LDS, stream, a);                       \
+    } while (0)
     if (hot) hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, kHot>), grid, dim3(kTreeBlock), 0, stream, a);
     else if (mask_only) hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, (kMask != 0 ? kMask : kHot)>), grid, dim3(kTreeBlock), 0, stream, a);
     else if (pik_lambda1)   // two-level ik::pik (tree_takes_two_level_pik): the general build + the level-1 row's projection
-        hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, (1 << ikdev::kSpecPik)>), grid, dim3(kTreeBlock), 0, stream, a);
+        IKGPU_TREE_GENERAL((1 << ikdev::kSpecPik), 0);
     else if (ph.cons_on) {   // one FrameConstraint on the second chain: the constraint build (general + the projection), with or
                              // without the posture code
         if constexpr (NCH == 2) {
-            if (ph.has_posture) hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, ikdev::kSpecPostCons>), grid, dim3(kTreeBlock), 0, stream, a);
-            else hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, (1 << ikdev::kSpecCons)>), grid, dim3(kTreeBlock), 0, stream, a);
+            if (ph.has_posture) IKGPU_TREE_GENERAL(ikdev::kSpecPostCons, 0);
+            else IKGPU_TREE_GENERAL((1 << ikdev::kSpecCons), 0);
         } else return hipErrorInvalidValue;
     } else if (ph.has_posture)
-        hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, (1 << ikdev::kSpecPost)>), grid, dim3(kTreeBlock),
-                           NCH == 1 ? sizeof(double) * kTreeBlock * static_cast<size_t>(2 * std::max(1, a.prm.post_n) + NJ) : 0, stream, a);
-    else hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, 0>), grid, dim3(kTreeBlock), 0, stream, a);
+        IKGPU_TREE_GENERAL((1 << ikdev::kSpecPost), post_lds);
+    else IKGPU_TREE_GENERAL(0, 0);
+#undef IKGPU_TREE_GENERAL
     return hipGetLastError();
 }
 
