@@ -113,6 +113,9 @@ CASES = {
     "moving_reference_prismatic": ("ur5", False, [("frame", "tool0", "upper_arm_link", 2, 0, None)], _prismatic_elbow),
     "three_feet_frames": ("cassie", True, [("frame", "LeftFootFront", "universe", 0, 0, None), ("frame", "LeftFootBack", "universe", 0, 0, None),
                                            ("frame", "RightFootFront", "universe", 2, 0, None), ("frame", "pelvis", "universe", 1, 1, None)], None),
+    # M = 21 > 15: the cooperative kernel's LDS Gram matrix / Cholesky (the register forms cover M <= 15)
+    "feet_frames_beyond_the_register_solve": ("cassie", True, [("frame", "LeftFootFront", "universe", 2, 0, None), ("frame", "LeftFootBack", "universe", 0, 0, None),
+                                                               ("frame", "RightFootFront", "universe", 2, 0, None), ("frame", "pelvis", "universe", 2, 0, None)], None),
     # ik::PostureTask (reference ik/ik/posture.hpp:17-85) regularising two pose tasks, with weights and a mask with holes
     "posture_regulariser": ("cassie", True, [("frame", "LeftFootFront", "universe", 2, 0, None), ("frame", "pelvis", "universe", 2, 0, None),
                                              ("posture", 16, None, None, 1, ([0.1 + 0.05 * k for k in range(16)],
