@@ -404,6 +404,89 @@ IKD_FN void coop_chol_solve_regs(const int g, double *ws, const int offG, const 
     chol_regs_solve<MMAX>(row, g, ws, offx, M);
 }
 
+// 16 <= M <= 31: TWO rows per lane -- lane g holds row g (A: entries 0 .. g) and row g + 16 (B: entries 0 .. g + 16); lane 15's B is
+// the right-hand side (row M of the packed triangle).  Same operations, same order; an entry of row j comes from lane j mod 16.
+template <int MMAX, int K, int J>
+IKD_FN void chol_regs2_trail(double (&ra)[16], double (&rb)[32], const double lika, const double likb) {
+    if constexpr (J < MMAX) {
+        double ljk;
+        if constexpr (J < 16) ljk = group_bcast<J>(lika);
+        else ljk = group_bcast<J - 16>(likb);
+        if constexpr (J < 16) ra[J] = dfma(-lika, ljk, ra[J]);
+        rb[J] = dfma(-likb, ljk, rb[J]);
+        chol_regs2_trail<MMAX, K, J + 1>(ra, rb, lika, likb);
+    }
+}
+template <int MMAX, int K>
+IKD_FN void chol_regs2_pivots(double (&ra)[16], double (&rb)[32], const int g, const int M) {
+    if constexpr (K < MMAX) {
+        if (K < M) {   // (wave-uniform)
+            double d;
+            if constexpr (K < 16) d = group_bcast<K>(ra[K]);
+            else d = group_bcast<K - 16>(rb[K]);
+            const double inv = drsqrt(d);
+            double lika = 0.0;
+            if constexpr (K < 16) { lika = ra[K] * inv; ra[K] = g == K ? inv : lika; }
+            const double likb = rb[K] * inv;
+            if constexpr (K < 16) rb[K] = likb;
+            else rb[K] = g == K - 16 ? inv : likb;
+            chol_regs2_trail<MMAX, K, K + 1>(ra, rb, lika, likb);
+            IKD_SCHED_FENCE();   // (pivot by pivot: the scheduler otherwise pulls later pivots' broadcasts forward and the rows spill)
+        }
+        chol_regs2_pivots<MMAX, K + 1>(ra, rb, g, M);
+    }
+}
+template <int Mm, int C>
+IKD_FN void chol_regs2_sub(const double (&ra)[16], const double (&rb)[32], double (&x)[32]) {
+    if constexpr (C < Mm) {
+        double l;
+        if constexpr (Mm < 16) l = group_bcast<Mm>(ra[C]);
+        else l = group_bcast<Mm - 16>(rb[C]);
+        x[C] = dfma(-l, x[Mm], x[C]);
+        chol_regs2_sub<Mm, C + 1>(ra, rb, x);
+    }
+}
+template <int Mm>
+IKD_FN void chol_regs2_back(const double (&ra)[16], const double (&rb)[32], double (&x)[32], const int M) {
+    if constexpr (Mm >= 0) {
+        if (Mm < M) {
+            double dinv;
+            if constexpr (Mm < 16) dinv = group_bcast<Mm>(ra[Mm]);
+            else dinv = group_bcast<Mm - 16>(rb[Mm]);
+            x[Mm] = x[Mm] * dinv;
+            chol_regs2_sub<Mm, 0>(ra, rb, x);
+            IKD_SCHED_FENCE();
+        }
+        chol_regs2_back<Mm - 1>(ra, rb, x, M);
+    }
+}
+template <int MMAX, int C>
+IKD_FN void chol_regs2_rhs(const double (&rb)[32], double (&x)[32]) {
+    if constexpr (C < MMAX) {
+        x[C] = group_bcast<15>(rb[C]);
+        chol_regs2_rhs<MMAX, C + 1>(rb, x);
+    }
+}
+template <int MMAX>
+IKD_FN void coop_chol_solve_regs2(const int g, double *ws, const int offG, const int offx, const int M) {
+    const int mineb = g == 15 ? M : g + 16;
+    const bool holdsb = g == 15 || g + 16 < M;
+    double ra[16], rb[32], x[32];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) ra[j] = j <= g ? ws[offG + tri(g, j)] : 0.0;
+#pragma unroll
+    for (int j = 0; j < MMAX; ++j) rb[j] = (holdsb && j <= mineb && j < M) ? ws[offG + tri(mineb, j)] : 0.0;
+    chol_regs2_pivots<MMAX, 0>(ra, rb, g, M);
+    chol_regs2_rhs<MMAX, 0>(rb, x);
+    chol_regs2_back<MMAX - 1>(ra, rb, x, M);
+    if (g == 0) {
+#pragma unroll
+        for (int k = 0; k < MMAX; ++k)
+            if (k < M) ws[offx + k] = x[k];
+    }
+    IKC_SYNC();
+}
+
 // The Gram matrix straight into that layout: lane i loads row i of the M x nv matrix at offJ into registers once, and
 // G(i,j) = [i == j] lam2 + sum_c J(i,c) J(j,c) (c ascending, as the LDS form) takes row j from lane j by DPP broadcast -- no LDS
 // traffic in the inner loop, where the pair-per-lane form reads two operands per product (the phase was bound by the CU's LDS
@@ -443,11 +526,18 @@ IKD_FN void coop_gram_solve_regs(const int g, double *ws, const int offJ, const 
 }
 #endif
 
+// BIG: the kernel build for 16 <= M <= 31 (two rows per lane: 160 registers for the matrix alone, so it is kept out of the builds that
+// run two waves per SIMD under a 256-register cap -- problems of that size leave fewer than five workgroups per CU anyway)
+template <bool BIG = false>
 IKD_FN void coop_chol_solve(const CoopLayout &L, const int g, double *ws, const int offG, const int offdinv, const int offx, const int M) {
     (void)g;
 #if IKD_ON_DEVICE
-    if (M <= 10) { coop_chol_solve_regs<10>(g, ws, offG, offx, M); return; }   // (wave-uniform; the trailing updates run to MMAX)
-    if (M <= 15) { coop_chol_solve_regs<15>(g, ws, offG, offx, M); return; }
+    if constexpr (BIG) {   // (the launch picks this build for 16 <= M <= 31 only; ONE instantiation: see coop_dls)
+        if (M <= 31) { coop_chol_solve_regs2<31>(g, ws, offG, offx, M); return; }   // (wave-uniform; the trailing updates run to MMAX)
+    } else {
+        if (M <= 10) { coop_chol_solve_regs<10>(g, ws, offG, offx, M); return; }
+        if (M <= 15) { coop_chol_solve_regs<15>(g, ws, offG, offx, M); return; }
+    }
 #endif
     const int npairs = tri(M, 0) + M;
     // ---- Cholesky, right-looking, ONE phase per pivot: column k stays unscaled while the trailing triangle takes its
@@ -688,7 +778,7 @@ IKD_FN void coop_integrate(const GenericTables &T, const CoopLayout &L, const in
     IKC_SYNC();
 }
 
-template <class AnyFn>
+template <bool BIG = false, class AnyFn>
 IKD_FN void coop_dls(const GenericTables &T, const CoopLayout &L, const LoopParams &prm, const int g, double *ws, int &iters_out,
                      bool &success_out, AnyFn any_active) {
     (void)g;
@@ -712,6 +802,7 @@ IKD_FN void coop_dls(const GenericTables &T, const CoopLayout &L, const LoopPara
     }
     for (int it = 0; it < prm.max_iterations; ++it) {
         const double e0sq = coop_evaluate(T, L, g, ws IKC_TICK_PASS);
+        bool solved = false;   // (device, M <= 15: the register Gram form solves as well)
         if (elim) {
             const int Mf = L.Mf;
             IKC_FOR(c, nv) {   // u = D^-1 J^T e (parked where dq goes)
@@ -737,22 +828,11 @@ IKD_FN void coop_dls(const GenericTables &T, const CoopLayout &L, const LoopPara
                 ws[L.G + tri(i, j)] = s;
             }
             IKC_SYNC();
-            IKC_TICK(4);
-            coop_chol_solve(L, g, ws, L.G, L.dinv, L.x, Mf);
-            IKC_TICK(6);
-            IKC_FOR(c, nv) {   // dq = -(u - D^-1 J_f^T z)
-                double s = 0.0;
-#pragma unroll 4
-                for (int k = 0; k < Mf; ++k) s = dfma(ws[L.J + k * nv + c], ws[L.x + k], s);
-                ws[L.dq + c] = dfma(ws[L.Dd + c], s, -ws[L.dq + c]);
-            }
-            IKC_SYNC();
-            IKC_TICK(7);
         } else {
         // ---- JJ = Jt Jt^T + damping^2 I (ik/ik/dls.cpp:39-41), lower triangle, with the right-hand side et as row M
 #if IKD_ON_DEVICE
         // (wave-uniform choices; the register form covers M <= 15, nv <= 32)
-#define IKC_GRAM_REGS(MM, NN) if (M <= MM && nv <= NN) { coop_gram_solve_regs<MM, NN>(g, ws, L.J, L.e, L.x, M, nv, prm.lam2); } else
+#define IKC_GRAM_REGS(MM, NN) if (!BIG && M <= MM && nv <= NN) { coop_gram_solve_regs<MM, NN>(g, ws, L.J, L.e, L.x, M, nv, prm.lam2); solved = true; } else
         IKC_GRAM_REGS(10, 8) IKC_GRAM_REGS(10, 24) IKC_GRAM_REGS(15, 24) IKC_GRAM_REGS(10, 32) IKC_GRAM_REGS(15, 32)
 #undef IKC_GRAM_REGS
 #endif
@@ -770,19 +850,31 @@ IKD_FN void coop_dls(const GenericTables &T, const CoopLayout &L, const LoopPara
             ws[L.G + tri(i, j)] = s;
         }
         IKC_SYNC();
-        IKC_TICK(4);
-        coop_chol_solve(L, g, ws, L.G, L.dinv, L.x, M);
         }
+        }
+        IKC_TICK(4);
+        // (ONE call site for the solve: two inlined copies of the two-row register form in sibling branches send hipcc's register
+        // allocation past 512 registers)
+        if (!solved) coop_chol_solve<BIG>(L, g, ws, L.G, L.dinv, L.x, elim ? L.Mf : M);
         IKC_TICK(6);
-        IKC_FOR(c, nv) {  // dq = -Jt^T x, ik/ik/dls.cpp:52-53 (N = I)
-            double s = 0.0;
+        if (elim) {
+            const int Mf = L.Mf;
+            IKC_FOR(c, nv) {   // dq = -(u - D^-1 J_f^T z)
+                double s = 0.0;
+#pragma unroll 4
+                for (int k = 0; k < Mf; ++k) s = dfma(ws[L.J + k * nv + c], ws[L.x + k], s);
+                ws[L.dq + c] = dfma(ws[L.Dd + c], s, -ws[L.dq + c]);
+            }
+        } else {
+            IKC_FOR(c, nv) {  // dq = -Jt^T x, ik/ik/dls.cpp:52-53 (N = I)
+                double s = 0.0;
 #pragma unroll 8
-            for (int r = 0; r < M; ++r) s = dfma(ws[L.J + r * nv + c], ws[L.x + r], s);
-            ws[L.dq + c] = -s;
+                for (int r = 0; r < M; ++r) s = dfma(ws[L.J + r * nv + c], ws[L.x + r], s);
+                ws[L.dq + c] = -s;
+            }
         }
         IKC_SYNC();
         IKC_TICK(7);
-        }
         if (T.Mc > 0) {  // dq <- N dq, N = I - pinv(Jc) Jc: the step stays in the null space of the constraints (dls.cpp:26-34,43-53)
             IKC_FOR(k, T.ncons) {  // placements of the constrained frame, its reference frame, and the one in the other
                 double oMf[12], oMr[12], fMr[12];
@@ -884,7 +976,7 @@ struct CoopKernelArgs {
 };
 
 // One problem (index `problem`) on the group's workspace `ws`; g = lane within the group.
-template <class AnyFn>
+template <bool BIG = false, class AnyFn>
 IKD_FN void dls_coop_body(const CoopKernelArgs &a, int64_t problem, const int g, double *ws, AnyFn any_active) {
     (void)g;
     const bool valid = problem < a.B;
@@ -898,7 +990,7 @@ IKD_FN void dls_coop_body(const CoopKernelArgs &a, int64_t problem, const int g,
     IKC_SYNC();
     int iters;
     bool success;
-    coop_dls(a.T, a.L, a.prm, g, ws, iters, success, any_active);
+    coop_dls<BIG>(a.T, a.L, a.prm, g, ws, iters, success, any_active);
     if (valid) {   // (no early return: the workgroup goes on to its next group of problems, see dls_coop_kernel)
         IKC_FOR(i, nq) a.q_out[at(a.layout, a.B, nq, i, b)] = ws[a.L.q + i];
         IKC_FOR(one, 1) {

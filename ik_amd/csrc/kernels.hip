@@ -515,7 +515,19 @@ __global__ __launch_bounds__(kBlock, 2) void dls_coop_kernel(ikdev::CoopKernelAr
     // algorithmic bytes at B = 65536)
     const int64_t nblocks = (a.B + per_block - 1) / per_block;
     for (int64_t blk = next_block(queue); blk < nblocks; blk = next_block(queue))
-        ikdev::dls_coop_body(a, blk * per_block + grp, g, ws0 + grp * a.L.words, [](bool act) { return __any(act) != 0; });
+        ikdev::dls_coop_body<false>(a, blk * per_block + grp, g, ws0 + grp * a.L.words, [](bool act) { return __any(act) != 0; });
+}
+
+// The same for 16 <= M <= 31 (rows left after the posture elimination): two matrix rows per lane in the register Cholesky, no
+// register cap -- workspaces of that size leave at most four workgroups on a CU, one per SIMD.
+__global__ __launch_bounds__(kBlock) void dls_coop_big_kernel(ikdev::CoopKernelArgs a, const CoopStaging s, unsigned long long *queue) {
+    extern __shared__ double coop_lds[];
+    double *ws0 = coop_stage(coop_lds, a.T, a.L, s);
+    const int grp = threadIdx.x / ikdev::kCoopGroup, g = threadIdx.x % ikdev::kCoopGroup;
+    const int per_block = blockDim.x / ikdev::kCoopGroup;
+    const int64_t nblocks = (a.B + per_block - 1) / per_block;
+    for (int64_t blk = next_block(queue); blk < nblocks; blk = next_block(queue))
+        ikdev::dls_coop_body<true>(a, blk * per_block + grp, g, ws0 + grp * a.L.words, [](bool act) { return __any(act) != 0; });
 }
 
 __global__ __launch_bounds__(kBlock) void pik_coop_kernel(const ikdev::PikCoopKernelArgs a, const CoopStaging s, unsigned long long *queue) {
@@ -669,6 +681,13 @@ hipError_t launch_dls_generic(const ProblemHost &ph, const DeviceTables &dt, con
         const int64_t blocks = persistent_grid(reinterpret_cast<const void *>(dls_coop_kernel), per_block * ikdev::kCoopGroup, lds, (io.B + per_block - 1) / per_block);
         unsigned long long *queue = dt.queue + dt.queue_next.fetch_add(1) % DeviceTables::kQueueSlots;
         if (hipMemsetAsync(queue, 0, sizeof(*queue), stream) != hipSuccess) return hipGetLastError();
+        const int rows = c.L.post_elim ? c.L.Mf : c.T.M;   // the size of the system the solver factorises
+        if (rows >= 16 && rows <= 31) {
+            const int64_t blocks_big = persistent_grid(reinterpret_cast<const void *>(dls_coop_big_kernel), per_block * ikdev::kCoopGroup, lds, (io.B + per_block - 1) / per_block);
+            if (!raise_lds_limit(reinterpret_cast<const void *>(dls_coop_big_kernel), lds)) return hipGetLastError();
+            hipLaunchKernelGGL(dls_coop_big_kernel, dim3(static_cast<unsigned>(blocks_big)), dim3(per_block * ikdev::kCoopGroup), lds, stream, c, s, queue);
+            return hipGetLastError();
+        }
         if (!raise_lds_limit(reinterpret_cast<const void *>(dls_coop_kernel), lds)) return hipGetLastError();
         hipLaunchKernelGGL(dls_coop_kernel, dim3(static_cast<unsigned>(blocks)), dim3(per_block * ikdev::kCoopGroup), lds, stream, c, s, queue);
         return hipGetLastError();
