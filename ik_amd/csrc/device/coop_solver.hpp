@@ -69,6 +69,8 @@ struct CoopLayout {
     const int *order, *chain_start, *lvl_start;  // joints 1.. chain by chain (problem.cpp: build_coop); first entry of each chain (+ end);
                                                  // first chain of each of the `rounds` levels (+ end)
     const int *tb_index;         // [ntasks] slot of the task's block in tb (-1: posture row, no block)
+    const int *btask;            // [nblocks] the task of each block
+    int nblocks;
     const int *col_joint;        // [nv] the joint a tangent column belongs to
     // PostureTask rows eliminated from the linear system (coop_dls): the Mf remaining rows, the posture tasks by tangent column
     // (CSR: pstart[nv + 1], ptask), the diagonal metric's inverse at Dd (nv words)
@@ -260,9 +262,9 @@ IKD_FN double coop_evaluate(const GenericTables &T, const CoopLayout &L, const i
     IKC_FOR(c, nv) {
         const double vw[6] = {ws[L.Jw + c], ws[L.Jw + nv + c], ws[L.Jw + 2 * nv + c],
                               ws[L.Jw + 3 * nv + c], ws[L.Jw + 4 * nv + c], ws[L.Jw + 5 * nv + c]};
-        for (int t = 0; t < nt; ++t) {
+        for (int kb = 0; kb < L.nblocks; ++kb) {   // (the tasks with a block: posture rows have no column work)
+            const int t = L.btask[kb];
             const int type = T.t_type[t], row = L.jrow[t], dim = T.t_dim[t];   // (row: of J)
-            if (type == GT_POSTURE_ROW) continue;
             if (type == GT_COM) {  // jacobianCenterOfMass, ik/ik/data.cpp:31-34: every column, scaled by the mass of its joint's subtree
                 const double *w6 = T.t_w + 6 * t;
                 const double *tb = ws + L.tb + 36 * L.tb_index[t];
@@ -407,14 +409,15 @@ IKD_FN void coop_chol_solve_regs(const int g, double *ws, const int offG, const 
 // 16 <= M <= 31: TWO rows per lane -- lane g holds row g (A: entries 0 .. g) and row g + 16 (B: entries 0 .. g + 16); lane 15's B is
 // the right-hand side (row M of the packed triangle).  Same operations, same order; an entry of row j comes from lane j mod 16.
 template <int MMAX, int K, int J>
-IKD_FN void chol_regs2_trail(double (&ra)[16], double (&rb)[32], const double lika, const double likb) {
+IKD_FN void chol_regs2_trail(double (&ra)[16], double (&rb)[32], const double lika, const double likb, const int M) {
     if constexpr (J < MMAX) {
+        if (J >= M) return;   // (wave-uniform: one taken branch per pivot instead of 4 (MMAX - M) wasted slots)
         double ljk;
         if constexpr (J < 16) ljk = group_bcast<J>(lika);
         else ljk = group_bcast<J - 16>(likb);
         if constexpr (J < 16) ra[J] = dfma(-lika, ljk, ra[J]);
         rb[J] = dfma(-likb, ljk, rb[J]);
-        chol_regs2_trail<MMAX, K, J + 1>(ra, rb, lika, likb);
+        chol_regs2_trail<MMAX, K, J + 1>(ra, rb, lika, likb, M);
     }
 }
 template <int MMAX, int K>
@@ -430,7 +433,7 @@ IKD_FN void chol_regs2_pivots(double (&ra)[16], double (&rb)[32], const int g, c
             const double likb = rb[K] * inv;
             if constexpr (K < 16) rb[K] = likb;
             else rb[K] = g == K - 16 ? inv : likb;
-            chol_regs2_trail<MMAX, K, K + 1>(ra, rb, lika, likb);
+            chol_regs2_trail<MMAX, K, K + 1>(ra, rb, lika, likb, M);
             IKD_SCHED_FENCE();   // (pivot by pivot: the scheduler otherwise pulls later pivots' broadcasts forward and the rows spill)
         }
         chol_regs2_pivots<MMAX, K + 1>(ra, rb, g, M);

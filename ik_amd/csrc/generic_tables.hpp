@@ -49,7 +49,7 @@ inline ikdev::CoopLayout bind_coop_layout(const ProblemHost &ph, const int32_t *
         (void)M;
         L.cholqr_c = (Mc > 0 && Mc * (Mc + 1) / 2 + Mc <= region && !(force && std::string(force) == "dense")) ? 1 : 0;
     }
-    L.support = ibase + g.o_csupport; L.pair_i = ibase + g.o_cpair_i; L.pair_j = ibase + g.o_cpair_j; L.order = ibase + g.o_cup; L.chain_start = ibase + g.o_cchain; L.lvl_start = ibase + g.o_clvl; L.tb_index = ibase + g.o_ctbindex; L.col_joint = ibase + g.o_ccoljoint; L.csupp_f = ibase + g.o_ccsf; L.csupp_r = ibase + g.o_ccsr;
+    L.support = ibase + g.o_csupport; L.pair_i = ibase + g.o_cpair_i; L.pair_j = ibase + g.o_cpair_j; L.order = ibase + g.o_cup; L.chain_start = ibase + g.o_cchain; L.lvl_start = ibase + g.o_clvl; L.tb_index = ibase + g.o_ctbindex; L.btask = ibase + g.o_cbtask; L.nblocks = g.coop_nblocks; L.col_joint = ibase + g.o_ccoljoint; L.csupp_f = ibase + g.o_ccsf; L.csupp_r = ibase + g.o_ccsr;
     L.cpair_i = ibase + g.o_ccpair_i; L.cpair_j = ibase + g.o_ccpair_j;
     L.post_elim = for_pik ? 0 : g.coop_post_elim; L.Mf = g.coop_Mf; L.Dd = g.c_Dd;
     L.frow = ibase + g.o_cfrow; L.pstart = ibase + g.o_cpstart; L.ptask = ibase + g.o_cptask;

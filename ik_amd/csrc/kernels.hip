@@ -485,7 +485,7 @@ __device__ __forceinline__ double *coop_stage(double *lds, ikdev::GenericTables 
     rebase(T.placement, s.dbls, ld); rebase(T.axis, s.dbls, ld); rebase(T.lower, s.dbls, ld); rebase(T.upper, s.dbls, ld);
     rebase(T.t_fpl, s.dbls, ld); rebase(T.t_rpl, s.dbls, ld); rebase(T.t_w, s.dbls, ld);
     rebase(L.support, s.ints, li); rebase(L.pair_i, s.ints, li); rebase(L.pair_j, s.ints, li); rebase(L.order, s.ints, li);
-    rebase(L.lvl_start, s.ints, li); rebase(L.chain_start, s.ints, li); rebase(L.tb_index, s.ints, li); rebase(L.frow, s.ints, li); rebase(L.pstart, s.ints, li); rebase(L.ptask, s.ints, li); rebase(L.tg_off, s.ints, li); rebase(L.tg_src, s.ints, li); rebase(L.jrow, s.ints, li); rebase(L.col_joint, s.ints, li);
+    rebase(L.lvl_start, s.ints, li); rebase(L.chain_start, s.ints, li); rebase(L.tb_index, s.ints, li); rebase(L.btask, s.ints, li); rebase(L.frow, s.ints, li); rebase(L.pstart, s.ints, li); rebase(L.ptask, s.ints, li); rebase(L.tg_off, s.ints, li); rebase(L.tg_src, s.ints, li); rebase(L.jrow, s.ints, li); rebase(L.col_joint, s.ints, li);
     rebase(T.j_mass, s.dbls, ld); rebase(T.j_lever, s.dbls, ld); rebase(T.j_submass, s.dbls, ld);
     rebase(T.c_type, s.ints, li); rebase(T.c_fjoint, s.ints, li); rebase(T.c_rjoint, s.ints, li); rebase(T.c_row, s.ints, li);
     rebase(T.c_dim, s.ints, li); rebase(T.c_fpl, s.dbls, ld); rebase(T.c_rpl, s.dbls, ld);

@@ -253,6 +253,11 @@ void build_coop(ProblemHost &ph, const Model &m) {
     for (int t = 0; t < nt; ++t)
         if (ph.tasks[t].type != IKGPU_POSTURE_ROW) tbi[t] = nblocks++;
     g.o_ctbindex = put_i(tbi);
+    std::vector<int32_t> btask;
+    for (int t = 0; t < nt; ++t)
+        if (tbi[t] >= 0) btask.push_back(t);
+    g.o_cbtask = put_i(btask);
+    g.coop_nblocks = nblocks;
     // FrameConstraint rows: which tangent columns move the constrained frame, which its reference frame
     const int ncons = static_cast<int>(ph.constraints.size());
     std::vector<int32_t> csf(static_cast<size_t>(ncons) * nv, 0), csr(static_cast<size_t>(ncons) * nv, 0);

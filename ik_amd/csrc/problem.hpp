@@ -36,7 +36,7 @@ struct GenericHost {
     int o_cfpl = 0, o_crpl = 0;                                              // (into dbls)
     int off_Jc = 0;
     // cooperative form of the DLS program (device/coop_solver.hpp): 16 lanes per problem, workspace in LDS
-    int coop_ok = 0, coop_rounds = 0, coop_words = 0, coop_npairs = 0;
+    int coop_ok = 0, coop_rounds = 0, coop_words = 0, coop_npairs = 0, coop_nblocks = 0, o_cbtask = 0;
     int coop_post_elim = 0, coop_Mf = 0, c_Dd = 0, o_cfrow = 0, o_cpstart = 0, o_cptask = 0;  // posture rows eliminated (coop_dls)
     // ... whose DLS workspace is laid out for the Mf remaining rows (ik::pik keeps the full one above): offsets d_*, and per task the
     // first row of its block in that compact Jacobian (o_cjrow; -1: posture row)
