@@ -116,6 +116,16 @@ CASES = {
     # M = 21 > 15: the cooperative kernel's LDS Gram matrix / Cholesky (the register forms cover M <= 15)
     "feet_frames_beyond_the_register_solve": ("cassie", True, [("frame", "LeftFootFront", "universe", 2, 0, None), ("frame", "LeftFootBack", "universe", 0, 0, None),
                                                                ("frame", "RightFootFront", "universe", 2, 0, None), ("frame", "pelvis", "universe", 2, 0, None)], None),
+    # the boundaries of the register solves: M = 16 (first size with two rows per lane), M = 31 (last), M = 32 (the LDS form)
+    "rows_16": ("cassie", True, [("frame", "LeftFootFront", "universe", 2, 0, None), ("frame", "LeftFootBack", "universe", 0, 0, None),
+                                 ("frame", "RightFootFront", "universe", 2, 0, None), ("align", "RightFootFront", "universe", 1, 0, None)], None),
+    "rows_31": ("cassie", True, [("frame", "LeftFootFront", "universe", 2, 0, None), ("frame", "LeftFootBack", "universe", 2, 0, None),
+                                 ("frame", "RightFootFront", "universe", 2, 0, None), ("frame", "RightFootBack", "universe", 2, 0, None),
+                                 ("frame", "pelvis", "universe", 2, 0, None), ("align", "RightFootFront", "universe", 1, 0, None)], None),
+    "rows_32": ("cassie", True, [("frame", "LeftFootFront", "universe", 2, 0, None), ("frame", "LeftFootBack", "universe", 2, 0, None),
+                                 ("frame", "RightFootFront", "universe", 2, 0, None), ("frame", "RightFootBack", "universe", 2, 0, None),
+                                 ("frame", "pelvis", "universe", 2, 0, None), ("align", "RightFootFront", "universe", 1, 0, None),
+                                 ("align", "LeftFootFront", "universe", 0, 0, None)], None),
     # ik::PostureTask (reference ik/ik/posture.hpp:17-85) regularising two pose tasks, with weights and a mask with holes
     "posture_regulariser": ("cassie", True, [("frame", "LeftFootFront", "universe", 2, 0, None), ("frame", "pelvis", "universe", 2, 0, None),
                                              ("posture", 16, None, None, 1, ([0.1 + 0.05 * k for k in range(16)],
@@ -134,7 +144,9 @@ CASES = {
 
 # (the demo task set with a random, in general unreachable, direction for its alignment row never settles at full step
 # either: at 40 full steps one problem in 500 sits a hair above the bar, 1.09e-6)
-CHAOTIC_AT_FULL_STEP = {"com_in_foot_frame", "demo_task_set", "demo_with_direction_in_pelvis_frame"}
+# (rows_16: a pose and a position task on one foot plus an alignment row with a random direction -- at 40 full steps 77 % of the
+# problems agree to the bar, both forms of the kernel part from the oracle alike: tools/forms_vs_oracle.py)
+CHAOTIC_AT_FULL_STEP = {"com_in_foot_frame", "demo_task_set", "demo_with_direction_in_pelvis_frame", "rows_16"}
 
 
 # Problems that have since found a register-resident kernel (the tree kernel with posture rows or on a fixed base,
