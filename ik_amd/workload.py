@@ -38,7 +38,8 @@ def cassie_nominal(joint_names):
     """SRDF default pose of the 16 Cassie leg joints (fixtures/models/cassie.nominal.json)."""
     with open(os.path.join(MODELS_DIR, "cassie.nominal.json")) as fh:
         vals = json.load(fh)["joints"]
-    return np.array([vals[n] for n in joint_names if n in vals])
+    # (joints a test added to the model -- "tail-joint*", tests/test_gpu_generic.py -- rest at zero)
+    return np.array([vals.get(n, 0.0) for n in joint_names if n in vals or n.startswith("tail-joint")])
 
 
 UR5_NOMINAL = np.array([0.0, -np.pi / 2, np.pi / 2, 0.0, np.pi / 2, 0.0])

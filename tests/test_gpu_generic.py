@@ -98,6 +98,20 @@ def _prismatic_elbow(xml):
               .replace(b'lower="-3.14159265359" upper="3.14159265359"', b'lower="-0.2" upper="0.2"', 1)
 
 
+def _tail(n):
+    """A chain of n extra revolute joints off the pelvis (nv = 22 + n): the tangent-space sizes the Cassie / UR5 fixtures do not reach."""
+    def edit(xml):
+        extra, parent = [], "pelvis"
+        for k in range(n):
+            link = "tail%d" % k
+            extra.append('<link name="%s"><inertial><mass value="0.%d"/><origin rpy="0 0 0" xyz="0.01 0 0.02"/></inertial></link>' % (link, k % 9 + 1))
+            extra.append('<joint name="tail-joint%d" type="revolute"><parent link="%s"/><child link="%s"/><origin rpy="0 0 0" xyz="0.05 0 %s"/>'
+                         '<axis xyz="%s"/><limit lower="-1.5" upper="1.5"/></joint>' % (k, parent, link, "0.03" if k % 2 else "-0.02", ("0 0 1", "0 1 0", "1 0 0")[k % 3]))
+            parent = link
+        return xml.replace(b"</robot>", ("\n".join(extra) + "\n</robot>").encode())
+    return edit
+
+
 CASES = {
     # the demo's own task set (reference ik_ros/src/cassie.cpp:45-81) -- since the tree kernel learnt base-relative references
     # and an alignment row it runs there (dls_tree<7,1,base_task,base_reference,align_axis>); kept here for its stage kernels ...
@@ -126,6 +140,11 @@ CASES = {
                                  ("frame", "RightFootFront", "universe", 2, 0, None), ("frame", "RightFootBack", "universe", 2, 0, None),
                                  ("frame", "pelvis", "universe", 2, 0, None), ("align", "RightFootFront", "universe", 1, 0, None),
                                  ("align", "LeftFootFront", "universe", 0, 0, None)], None),
+    # tangent-space sizes beyond the fixtures': nv = 30 (the register Gram matrix's widest build), nv = 36 (its LDS form)
+    "nv_30": ("cassie", True, [("frame", "LeftFootFront", "universe", 2, 0, None), ("frame", "tail7", "universe", 0, 0, None),
+                               ("frame", "pelvis", "universe", 2, 0, None)], _tail(8)),
+    "nv_36": ("cassie", True, [("frame", "LeftFootFront", "universe", 2, 0, None), ("frame", "tail13", "universe", 0, 0, None),
+                               ("frame", "pelvis", "universe", 2, 0, None)], _tail(14)),
     # ik::PostureTask (reference ik/ik/posture.hpp:17-85) regularising two pose tasks, with weights and a mask with holes
     "posture_regulariser": ("cassie", True, [("frame", "LeftFootFront", "universe", 2, 0, None), ("frame", "pelvis", "universe", 2, 0, None),
                                              ("posture", 16, None, None, 1, ([0.1 + 0.05 * k for k in range(16)],
