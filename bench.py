@@ -400,8 +400,22 @@ def main():
         ev1.record()
         torch.cuda.synchronize()
         kernel_ms = float(ev0.elapsed_time(ev1))
+        # ... and ONE isolated all-gather (wall clock over issue + completion, every rank inside; max over ranks): what a step has to
+        # hide behind the next solve
+        reps_g = 5
+        dist.barrier()
+        torch.cuda.synchronize()
+        tg0 = time.perf_counter()
+        for _ in range(reps_g):
+            bufs[0].all_gather(async_op=True)
+            bufs[0].wait()
+        torch.cuda.synchronize()
+        tgm = torch.tensor([(time.perf_counter() - tg0) / reps_g * 1e3], dtype=torch.float64, device=dev)
+        dist.all_reduce(tgm, op=dist.ReduceOp.MAX)
+        all_gather_ms = float(tgm.item())
     else:
         kernel_ms = float(ev0.elapsed_time(ev1)) / args.steps
+        all_gather_ms = None
 
     def time_solve(Q0_, tg_, reps=10, p=prm, vis=visitor, out_=None):
         out_ = solve_batch(problem, Q0_, tg_, data, vis, p, out=out_)
@@ -461,6 +475,10 @@ def main():
         }
         if single:
             res["single_gpu_same_inputs"] = single
+        if all_gather_ms is not None:
+            res["all_gather"] = {"ms": all_gather_ms, "bytes_per_rank_out": int(bufs[0].nbytes * world), "payload": gather,
+                                 "what": "one isolated all-gather of the step's payload after the timed region (issue to completion, max "
+                                         "over ranks); in the timed region it overlaps the next step's solve"}
         fused = data.kernel.startswith(("dls_chain<", "dls_tree<"))
         if stats.get("flop_per_solve_measured") and args.iters == 50:
             flops = stats["flop_per_solve_measured"]
