@@ -283,7 +283,8 @@ IKD_FN void hot_dls(const Tab &t, const LoopParams &prm, double (&q)[NJ], const 
 // store that might alias it) cost one HBM round trip per entry -- nine for a Cassie leg, ~10 us of a 150 us launch.
 template <int NJ>
 IKD_FN void hot_pass_through(const ChainKernelArgs<NJ> &a, int64_t b, bool stepped) {
-    constexpr int kGroup = 8;
+    constexpr int kGroup = 16;   // (a Cassie model's sixteen entries in ONE pass: with groups of eight the second group's loads waited
+                                 // for the first group's stores -- a second HBM round trip in the prologue)
     for (int i0 = 0; i0 < a.nq; i0 += kGroup) {
         double v[kGroup], lo[kGroup], hi[kGroup];
         bool out[kGroup];
