@@ -329,6 +329,14 @@ IKD_FN double coop_evaluate(const GenericTables &T, const CoopLayout &L, const i
 // The value x holds in lane N of this lane's group (a group is one DPP row of sixteen lanes: v_mov_b64_dpp row_newbcast)
 template <int N>
 IKD_FN double group_bcast(double x) { return __builtin_amdgcn_update_dpp(x, x, 0x150 + N, 0xf, 0xf, false); }
+// acc += (x in lane N of the group) * y, ONE instruction (v_fmac_f64 with a DPP row broadcast on its first source; the broadcast as a
+// separate v_mov_b64_dpp costs two more issue slots, profiles/r02_issue_probe_dpp.csv).  The source register must not have been
+// written by the instruction just before (a VALU write needs two wait states before a DPP read: callers fence with dpp_settle()).
+template <int N>
+IKD_FN void fmac_bcast(double &acc, const double x_lane_n, const double y) {
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x_lane_n), "v"(y), "n"(N));
+}
+IKD_FN void dpp_settle() { asm volatile("s_nop 1"); }
 
 // The same solve with the matrix in REGISTERS, one row per lane of the group (lane i: row i of the lower triangle; lane 15: the
 // right-hand side, riding along as row M), for M <= 15: the entries another lane needs come through DPP broadcasts, so the
@@ -338,10 +346,10 @@ IKD_FN double group_bcast(double x) { return __builtin_amdgcn_update_dpp(x, x, 0
 // the two agree bit for bit.  The back substitution runs redundantly in every lane (each broadcast reaches the whole group), so
 // x ends up replicated; lane 0 parks it at offx.  Ends on a barrier.
 template <int MMAX, int K, int J>
-IKD_FN void chol_regs_trail(double (&row)[16], const double lik) {   // G(i,j) -= L(i,k) L(j,k), j = K+1 .. MMAX-1 (rows past M hold zeros)
+IKD_FN void chol_regs_trail(double (&row)[16], const double lik, const double nlik) {   // G(i,j) -= L(i,k) L(j,k), j = K+1 .. MMAX-1 (rows past M hold zeros)
     if constexpr (J < MMAX) {
-        row[J] = dfma(-lik, group_bcast<J>(lik), row[J]);
-        chol_regs_trail<MMAX, K, J + 1>(row, lik);
+        fmac_bcast<J>(row[J], lik, nlik);
+        chol_regs_trail<MMAX, K, J + 1>(row, lik, nlik);
     }
 }
 template <int MMAX, int K>
@@ -349,18 +357,19 @@ IKD_FN void chol_regs_pivots(double (&row)[16], const int g, const int M) {
     if constexpr (K < MMAX) {
         if (K < M) {   // (wave-uniform)
             const double inv = drsqrt(group_bcast<K>(row[K]));
-            const double lik = row[K] * inv;
+            const double lik = row[K] * inv, nlik = -lik;
             row[K] = g == K ? inv : lik;       // lane K keeps 1 / L(K,K) where its diagonal entry was (nobody reads L(K,K) itself)
-            chol_regs_trail<MMAX, K, K + 1>(row, lik);
+            dpp_settle();
+            chol_regs_trail<MMAX, K, K + 1>(row, lik, nlik);
         }
         chol_regs_pivots<MMAX, K + 1>(row, g, M);
     }
 }
 template <int Mm, int C>
-IKD_FN void chol_regs_sub(const double (&row)[16], double (&x)[16]) {   // x_c -= L(m,c) x_m, c = 0 .. m-1
+IKD_FN void chol_regs_sub(const double (&row)[16], double (&x)[16], const double nxm) {   // x_c -= L(m,c) x_m, c = 0 .. m-1
     if constexpr (C < Mm) {
-        x[C] = dfma(-group_bcast<Mm>(row[C]), x[Mm], x[C]);
-        chol_regs_sub<Mm, C + 1>(row, x);
+        fmac_bcast<Mm>(x[C], row[C], nxm);
+        chol_regs_sub<Mm, C + 1>(row, x, nxm);
     }
 }
 template <int Mm>
@@ -368,7 +377,7 @@ IKD_FN void chol_regs_back(const double (&row)[16], double (&x)[16], const int M
     if constexpr (Mm >= 0) {
         if (Mm < M) {
             x[Mm] = x[Mm] * group_bcast<Mm>(row[Mm]);
-            chol_regs_sub<Mm, 0>(row, x);
+            chol_regs_sub<Mm, 0>(row, x, -x[Mm]);
         }
         chol_regs_back<Mm - 1>(row, x, M);
     }
@@ -409,15 +418,16 @@ IKD_FN void coop_chol_solve_regs(const int g, double *ws, const int offG, const 
 // 16 <= M <= 31: TWO rows per lane -- lane g holds row g (A: entries 0 .. g) and row g + 16 (B: entries 0 .. g + 16); lane 15's B is
 // the right-hand side (row M of the packed triangle).  Same operations, same order; an entry of row j comes from lane j mod 16.
 template <int MMAX, int K, int J>
-IKD_FN void chol_regs2_trail(double (&ra)[16], double (&rb)[32], const double lika, const double likb, const int M) {
+IKD_FN void chol_regs2_trail(double (&ra)[16], double (&rb)[32], const double lika, const double likb, const double nlika, const double nlikb, const int M) {
     if constexpr (J < MMAX) {
         if (J >= M) return;   // (wave-uniform: one taken branch per pivot instead of 4 (MMAX - M) wasted slots)
-        double ljk;
-        if constexpr (J < 16) ljk = group_bcast<J>(lika);
-        else ljk = group_bcast<J - 16>(likb);
-        if constexpr (J < 16) ra[J] = dfma(-lika, ljk, ra[J]);
-        rb[J] = dfma(-likb, ljk, rb[J]);
-        chol_regs2_trail<MMAX, K, J + 1>(ra, rb, lika, likb, M);
+        if constexpr (J < 16) {
+            fmac_bcast<J>(ra[J], lika, nlika);
+            fmac_bcast<J>(rb[J], lika, nlikb);
+        } else {
+            fmac_bcast<J - 16>(rb[J], likb, nlikb);
+        }
+        chol_regs2_trail<MMAX, K, J + 1>(ra, rb, lika, likb, nlika, nlikb, M);
     }
 }
 template <int MMAX, int K>
@@ -433,20 +443,19 @@ IKD_FN void chol_regs2_pivots(double (&ra)[16], double (&rb)[32], const int g, c
             const double likb = rb[K] * inv;
             if constexpr (K < 16) rb[K] = likb;
             else rb[K] = g == K - 16 ? inv : likb;
-            chol_regs2_trail<MMAX, K, K + 1>(ra, rb, lika, likb, M);
+            dpp_settle();
+            chol_regs2_trail<MMAX, K, K + 1>(ra, rb, lika, likb, -lika, -likb, M);
             IKD_SCHED_FENCE();   // (pivot by pivot: the scheduler otherwise pulls later pivots' broadcasts forward and the rows spill)
         }
         chol_regs2_pivots<MMAX, K + 1>(ra, rb, g, M);
     }
 }
 template <int Mm, int C>
-IKD_FN void chol_regs2_sub(const double (&ra)[16], const double (&rb)[32], double (&x)[32]) {
+IKD_FN void chol_regs2_sub(const double (&ra)[16], const double (&rb)[32], double (&x)[32], const double nxm) {
     if constexpr (C < Mm) {
-        double l;
-        if constexpr (Mm < 16) l = group_bcast<Mm>(ra[C]);
-        else l = group_bcast<Mm - 16>(rb[C]);
-        x[C] = dfma(-l, x[Mm], x[C]);
-        chol_regs2_sub<Mm, C + 1>(ra, rb, x);
+        if constexpr (Mm < 16) fmac_bcast<Mm>(x[C], ra[C], nxm);
+        else fmac_bcast<Mm - 16>(x[C], rb[C], nxm);
+        chol_regs2_sub<Mm, C + 1>(ra, rb, x, nxm);
     }
 }
 template <int Mm>
@@ -457,7 +466,7 @@ IKD_FN void chol_regs2_back(const double (&ra)[16], const double (&rb)[32], doub
             if constexpr (Mm < 16) dinv = group_bcast<Mm>(ra[Mm]);
             else dinv = group_bcast<Mm - 16>(rb[Mm]);
             x[Mm] = x[Mm] * dinv;
-            chol_regs2_sub<Mm, 0>(ra, rb, x);
+            chol_regs2_sub<Mm, 0>(ra, rb, x, -x[Mm]);
             IKD_SCHED_FENCE();
         }
         chol_regs2_back<Mm - 1>(ra, rb, x, M);
@@ -497,7 +506,7 @@ IKD_FN void coop_chol_solve_regs2(const int g, double *ws, const int offG, const
 template <int MMAX, int NVMAX, int J, int C>
 IKD_FN void gram_regs_dot(const double (&jr)[NVMAX], double &s) {
     if constexpr (C < NVMAX) {
-        s = dfma(jr[C], group_bcast<J>(jr[C]), s);
+        fmac_bcast<J>(s, jr[C], jr[C]);
         gram_regs_dot<MMAX, NVMAX, J, C + 1>(jr, s);
     }
 }
@@ -654,9 +663,10 @@ IKD_FN void cholqr_regs_pivots(double (&row)[16], const int g, const int m, cons
             const double d = group_bcast<K>(row[K]);
             ok = ok && d > thr;                    // false for NaN as well
             const double inv = drsqrt(d);
-            const double lik = row[K] * inv;
+            const double lik = row[K] * inv, nlik = -lik;
             row[K] = g == K ? inv : lik;
-            chol_regs_trail<MMAX, K, K + 1>(row, lik);
+            dpp_settle();
+            chol_regs_trail<MMAX, K, K + 1>(row, lik, nlik);
         }
         cholqr_regs_pivots<MMAX, K + 1>(row, g, m, thr, ok);
     }
