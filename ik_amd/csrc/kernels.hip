@@ -658,6 +658,9 @@ bool generic_runs_in_lds(const ProblemHost &ph) {
 bool generic_runs_cooperative(const ProblemHost &ph) {
     if (generic_runs_in_lds(ph)) return false;
     if (!ph.generic.coop_ok) return false;
+    // beyond 31 rows the solve falls back to the LDS Cholesky, one barrier per pivot: measured SLOWER than the per-lane program there
+    // (M = 32: 490 against 367 ms per launch; M = 31 with the two-row register form: 151 against 341)
+    if ((ph.generic.coop_post_elim ? ph.generic.coop_Mf : ph.rows) > 31 && !std::getenv("IKGPU_GENERIC_COOP_ANY_SIZE")) return false;
     const char *force = std::getenv("IKGPU_GENERIC_KERNEL");  // "lane": keep the memory-resident per-lane program (tests, profiling)
     return !(force && std::string(force) == "lane");
 }

@@ -194,6 +194,8 @@ def test_hip_graph_capture_of_the_other_kernels(ctx, case, monkeypatch):
     torch, ik = ctx["torch"], ctx["ik"]
     from test_gpu_generic import build
     monkeypatch.delenv("IKGPU_DLS_KERNEL", raising=False)
+    if case == "generic_cooperative_beyond_64kb":   # (beyond 31 rows the dispatch prefers the per-lane form: keep the cooperative one here)
+        monkeypatch.setenv("IKGPU_GENERIC_COOP_ANY_SIZE", "1")
     specs = {
         "full_body_tree": [("frame", "LeftFootFront", "universe", 2, 0, None), ("frame", "RightFootFront", "universe", 2, 0, None),
                            ("frame", "pelvis", "universe", 2, 0, None)],
