@@ -844,9 +844,9 @@ IKD_FN void coop_dls(const GenericTables &T, const CoopLayout &L, const LoopPara
         } else {
         // ---- JJ = Jt Jt^T + damping^2 I (ik/ik/dls.cpp:39-41), lower triangle, with the right-hand side et as row M
 #if IKD_ON_DEVICE
-        // (wave-uniform choices; the register form covers M <= 15, nv <= 32)
+        // (wave-uniform choices; the register form covers M <= 15, nv <= 40)
 #define IKC_GRAM_REGS(MM, NN) if (!BIG && M <= MM && nv <= NN) { coop_gram_solve_regs<MM, NN>(g, ws, L.J, L.e, L.x, M, nv, prm.lam2); solved = true; } else
-        IKC_GRAM_REGS(10, 8) IKC_GRAM_REGS(10, 24) IKC_GRAM_REGS(15, 24) IKC_GRAM_REGS(10, 32) IKC_GRAM_REGS(15, 32)
+        IKC_GRAM_REGS(10, 8) IKC_GRAM_REGS(10, 24) IKC_GRAM_REGS(15, 24) IKC_GRAM_REGS(10, 32) IKC_GRAM_REGS(15, 32) IKC_GRAM_REGS(15, 40)
 #undef IKC_GRAM_REGS
 #endif
         {
