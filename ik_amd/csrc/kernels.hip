@@ -505,7 +505,10 @@ __device__ __forceinline__ int64_t next_block(unsigned long long *queue) {
     return static_cast<int64_t>((static_cast<unsigned long long>(hi) << 32) | lo);
 }
 
-__global__ __launch_bounds__(kBlock, 2) void dls_coop_kernel(ikdev::CoopKernelArgs a, const CoopStaging s, unsigned long long *queue) {
+#ifndef IKGPU_COOP_WAVES
+#define IKGPU_COOP_WAVES 2   // (A/B knob: 1 = no register cap, four workgroups per CU)
+#endif
+__global__ __launch_bounds__(kBlock, IKGPU_COOP_WAVES) void dls_coop_kernel(ikdev::CoopKernelArgs a, const CoopStaging s, unsigned long long *queue) {
     extern __shared__ double coop_lds[];
     double *ws0 = coop_stage(coop_lds, a.T, a.L, s);
     const int grp = threadIdx.x / ikdev::kCoopGroup, g = threadIdx.x % ikdev::kCoopGroup;
