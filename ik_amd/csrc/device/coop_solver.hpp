@@ -479,15 +479,62 @@ IKD_FN void chol_regs2_rhs(const double (&rb)[32], double (&x)[32]) {
         chol_regs2_rhs<MMAX, C + 1>(rb, x);
     }
 }
-template <int MMAX>
-IKD_FN void coop_chol_solve_regs2(const int g, double *ws, const int offG, const int offx, const int M) {
+// ... and its Gram matrix in registers: lane g holds rows g and g + 16 of J; row j comes from lane j mod 16 (A or B half)
+template <int MMAX, int NVMAX, int J, int C>
+IKD_FN void gram_regs2_dot(const double (&ja)[NVMAX], const double (&jb)[NVMAX], double &sa, double &sb) {
+    if constexpr (C < NVMAX) {
+        if constexpr (J < 16) {
+            fmac_bcast<J>(sa, ja[C], ja[C]);
+            fmac_bcast<J>(sb, ja[C], jb[C]);
+        } else {
+            fmac_bcast<J - 16>(sb, jb[C], jb[C]);   // (row A of a lane is above row j >= 16: not in the lower triangle)
+        }
+        gram_regs2_dot<MMAX, NVMAX, J, C + 1>(ja, jb, sa, sb);
+    }
+}
+template <int MMAX, int NVMAX, int J>
+IKD_FN void gram_regs2_rows(const double (&ja)[NVMAX], const double (&jb)[NVMAX], double (&ra)[16], double (&rb)[32], const int g,
+                            const double lam2, const int M) {
+    if constexpr (J < MMAX) {
+        if (J >= M) return;   // (wave-uniform)
+        double sa = g == J ? lam2 : 0.0, sb = g + 16 == J ? lam2 : 0.0;
+        gram_regs2_dot<MMAX, NVMAX, J, 0>(ja, jb, sa, sb);
+        if constexpr (J < 16) ra[J] = sa;
+        rb[J] = sb;
+        gram_regs2_rows<MMAX, NVMAX, J + 1>(ja, jb, ra, rb, g, lam2, M);
+    }
+}
+
+// offJ >= 0: the matrix is J J^T + lam2 I of the M x nv rows at offJ (nv <= NVMAX), formed in registers, right-hand side at offe;
+// offJ < 0: the packed lower triangle (right-hand side as row M) is read from offG.
+template <int MMAX, int NVMAX>
+IKD_FN void coop_chol_solve_regs2(const int g, double *ws, const int offG, const int offx, const int M, const int offJ, const int offe,
+                                  const int nv, const double lam2) {
     const int mineb = g == 15 ? M : g + 16;
     const bool holdsb = g == 15 || g + 16 < M;
     double ra[16], rb[32], x[32];
+    if (offJ >= 0) {   // (wave-uniform)
+        double ja[NVMAX], jb[NVMAX];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) ra[j] = j <= g ? ws[offG + tri(g, j)] : 0.0;
+        for (int c = 0; c < NVMAX; ++c) {
+            ja[c] = c < nv ? ws[offJ + g * nv + c] : 0.0;
+            jb[c] = (g + 16 < M && c < nv) ? ws[offJ + (g + 16) * nv + c] : 0.0;
+        }
 #pragma unroll
-    for (int j = 0; j < MMAX; ++j) rb[j] = (holdsb && j <= mineb && j < M) ? ws[offG + tri(mineb, j)] : 0.0;
+        for (int j = 0; j < 16; ++j) ra[j] = 0.0;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) rb[j] = 0.0;
+        gram_regs2_rows<MMAX, NVMAX, 0>(ja, jb, ra, rb, g, lam2, M);
+        if (g == 15) {
+#pragma unroll
+            for (int j = 0; j < MMAX; ++j) rb[j] = j < M ? ws[offe + j] : 0.0;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) ra[j] = j <= g ? ws[offG + tri(g, j)] : 0.0;
+#pragma unroll
+        for (int j = 0; j < MMAX; ++j) rb[j] = (holdsb && j <= mineb && j < M) ? ws[offG + tri(mineb, j)] : 0.0;
+    }
     chol_regs2_pivots<MMAX, 0>(ra, rb, g, M);
     chol_regs2_rhs<MMAX, 0>(rb, x);
     chol_regs2_back<MMAX - 1>(ra, rb, x, M);
@@ -541,11 +588,12 @@ IKD_FN void coop_gram_solve_regs(const int g, double *ws, const int offJ, const 
 // BIG: the kernel build for 16 <= M <= 31 (two rows per lane: 160 registers for the matrix alone, so it is kept out of the builds that
 // run two waves per SIMD under a 256-register cap -- problems of that size leave fewer than five workgroups per CU anyway)
 template <bool BIG = false>
-IKD_FN void coop_chol_solve(const CoopLayout &L, const int g, double *ws, const int offG, const int offdinv, const int offx, const int M) {
-    (void)g;
+IKD_FN void coop_chol_solve(const CoopLayout &L, const int g, double *ws, const int offG, const int offdinv, const int offx, const int M,
+                            const int offJ = -1, const int offe = 0, const int nv = 0, const double lam2 = 0.0) {
+    (void)g; (void)offJ; (void)offe; (void)nv; (void)lam2;
 #if IKD_ON_DEVICE
     if constexpr (BIG) {   // (the launch picks this build for 16 <= M <= 31 only; ONE instantiation: see coop_dls)
-        if (M <= 31) { coop_chol_solve_regs2<31>(g, ws, offG, offx, M); return; }   // (wave-uniform; the trailing updates run to MMAX)
+        if (M <= 31) { coop_chol_solve_regs2<31, 24>(g, ws, offG, offx, M, offJ, offe, nv, lam2); return; }   // (wave-uniform)
     } else {
         if (M <= 10) { coop_chol_solve_regs<10>(g, ws, offG, offx, M); return; }
         if (M <= 15) { coop_chol_solve_regs<15>(g, ws, offG, offx, M); return; }
@@ -816,6 +864,7 @@ IKD_FN void coop_dls(const GenericTables &T, const CoopLayout &L, const LoopPara
     for (int it = 0; it < prm.max_iterations; ++it) {
         const double e0sq = coop_evaluate(T, L, g, ws IKC_TICK_PASS);
         bool solved = false;   // (device, M <= 15: the register Gram form solves as well)
+        bool gram_in_regs = false;
         if (elim) {
             const int Mf = L.Mf;
             IKC_FOR(c, nv) {   // u = D^-1 J^T e (parked where dq goes)
@@ -849,7 +898,9 @@ IKD_FN void coop_dls(const GenericTables &T, const CoopLayout &L, const LoopPara
         IKC_GRAM_REGS(10, 8) IKC_GRAM_REGS(10, 24) IKC_GRAM_REGS(15, 24) IKC_GRAM_REGS(10, 32) IKC_GRAM_REGS(15, 32) IKC_GRAM_REGS(15, 40)
 #undef IKC_GRAM_REGS
 #endif
-        {
+        if (BIG && nv <= 24) {
+            gram_in_regs = true;   // (the two-row register form builds J J^T itself)
+        } else {
         IKC_FOR(p, L.npairs) {
             const int i = L.pair_i[p], j = L.pair_j[p];
             double s;
@@ -868,7 +919,7 @@ IKD_FN void coop_dls(const GenericTables &T, const CoopLayout &L, const LoopPara
         IKC_TICK(4);
         // (ONE call site for the solve: two inlined copies of the two-row register form in sibling branches send hipcc's register
         // allocation past 512 registers)
-        if (!solved) coop_chol_solve<BIG>(L, g, ws, L.G, L.dinv, L.x, elim ? L.Mf : M);
+        if (!solved) coop_chol_solve<BIG>(L, g, ws, L.G, L.dinv, L.x, elim ? L.Mf : M, gram_in_regs ? L.J : -1, L.e, nv, prm.lam2);
         IKC_TICK(6);
         if (elim) {
             const int Mf = L.Mf;
