@@ -67,6 +67,7 @@ struct Stamp { long long cyc, real; };
 // DPP row broadcast (the cooperative kernels' register Cholesky / Gram): v_mov_b64_dpp alone, and feeding an FMA on another chain
 #define DPPB(x) asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "=v"(x) : "v"(a));
 #define DPPB_FMA(x) asm volatile("v_mov_b64_dpp %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf\n v_fma_f64 %0, %1, %2, %0" : "+v"(x), "+v"(x7) : "v"(a));
+#define FMAC_DPP(x) asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(a), "v"(b));
 #define C1Q(OP) REP64(OP(x0))
 #define C1(OP) REP64(OP(x0) OP(x0) OP(x0) OP(x0))
 #define C2(OP) REP64(OP(x0) OP(x1) OP(x0) OP(x1))
@@ -97,7 +98,7 @@ DEF(fma_readlane_c8, C8(FMA_READLANE)) DEF(fma_cmp_c8, C8(FMA_CMP)) DEF(fma_cnd_
 DEF(fma_mov32_c1, C1(FMA_MOV32)) DEF(fma_mov32_c2, C2(FMA_MOV32))
 DEF(mulfma_c1, C1(MULFMA)) DEF(mulfma_c2, C2(MULFMA)) DEF(mulfma_c4, C4(MULFMA)) DEF(mulfma_c8, C8(MULFMA))
 DEF(addmul_c1, C1(ADDMUL)) DEF(addmul_c8, C8(ADDMUL))
-DEF(dppb_c8, C8(DPPB)) DEF(dppb_fma, C1Q(DPPB_FMA))
+DEF(dppb_c8, C8(DPPB)) DEF(dppb_fma, C1Q(DPPB_FMA)) DEF(dppb_fmac_c8, C8(FMAC_DPP)) DEF(dppb_fmac_c1, C1(FMAC_DPP))
 DEF(fma4dep, C1Q(FMA4DEP)) DEF(mul4dep, C1Q(MUL4DEP)) DEF(fma2x2, C1Q(FMA2x2)) DEF(rsqfma, C1(RSQFMA)) DEF(rsq_3fma, C1Q(RSQ_3FMA))
 
 typedef void (*Kern)(double *, Stamp *, int, double, double);
@@ -125,7 +126,7 @@ int main(int argc, char **argv) {
         E(fma_cmp_c8, 8, 512), E(fma_cnd_c8, 8, 512), E(fma_mov32_c1, 1, 512), E(fma_mov32_c2, 2, 512),
         E(mulfma_c1, 1, 512), E(mulfma_c2, 2, 512), E(mulfma_c4, 4, 512), E(mulfma_c8, 8, 512),
         E(addmul_c1, 1, 512), E(addmul_c8, 8, 512),
-        E(dppb_c8, 8, 256), E(dppb_fma, 1, 128),
+        E(dppb_c8, 8, 256), E(dppb_fma, 1, 128), E(dppb_fmac_c8, 8, 256), E(dppb_fmac_c1, 1, 256),
         E(fma4dep, 1, 256), E(mul4dep, 1, 256), E(fma2x2, 2, 256), E(rsqfma, 1, 512), E(rsq_3fma, 2, 256),
     };
     printf("name,chains,waves_per_simd,cycles_per_instruction,cycles_per_trip,clock_GHz,event_ms\n");
