@@ -337,6 +337,29 @@ IKD_FN void fmac_bcast(double &acc, const double x_lane_n, const double y) {
     asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x_lane_n), "v"(y), "n"(N));
 }
 IKD_FN void dpp_settle() { asm volatile("s_nop 1"); }
+// Eight columns of two dot products in ONE asm statement: s0 += x_c(lane J0) x_c, s1 += x_c(lane J1) x_c, c = 0 .. 7, the two
+// accumulators alternating (a v_fmac_f64_dpp that depends on the one before takes 8 cycles, independent ones 4.8), and nothing of the
+// compiler's between them (it puts an s_nop after every single-instruction asm statement whose result the next one reads).
+#define IKC_F2(A, B, X, Y, L) "v_fmac_f64_dpp %" #A ", %" #X ", %" #Y " row_newbcast:%" #L " row_mask:0xf bank_mask:0xf\n"
+template <int J0, int J1>
+IKD_FN void fmac2_bcast8(double &s0, double &s1, const double c0, const double c1, const double c2, const double c3, const double c4,
+                         const double c5, const double c6, const double c7) {
+    asm volatile(IKC_F2(0, 0, 2, 2, 10) IKC_F2(1, 1, 2, 2, 11) IKC_F2(0, 0, 3, 3, 10) IKC_F2(1, 1, 3, 3, 11) IKC_F2(0, 0, 4, 4, 10)
+                 IKC_F2(1, 1, 4, 4, 11) IKC_F2(0, 0, 5, 5, 10) IKC_F2(1, 1, 5, 5, 11) IKC_F2(0, 0, 6, 6, 10) IKC_F2(1, 1, 6, 6, 11)
+                 IKC_F2(0, 0, 7, 7, 10) IKC_F2(1, 1, 7, 7, 11) IKC_F2(0, 0, 8, 8, 10) IKC_F2(1, 1, 8, 8, 11) IKC_F2(0, 0, 9, 9, 10)
+                 IKC_F2(1, 1, 9, 9, 11)
+                 : "+v"(s0), "+v"(s1)
+                 : "v"(c0), "v"(c1), "v"(c2), "v"(c3), "v"(c4), "v"(c5), "v"(c6), "v"(c7), "n"(J0), "n"(J1));
+}
+template <int J0>
+IKD_FN void fmac1_bcast8(double &s0, const double c0, const double c1, const double c2, const double c3, const double c4, const double c5,
+                         const double c6, const double c7) {
+    asm volatile(IKC_F2(0, 0, 1, 1, 9) IKC_F2(0, 0, 2, 2, 9) IKC_F2(0, 0, 3, 3, 9) IKC_F2(0, 0, 4, 4, 9) IKC_F2(0, 0, 5, 5, 9) IKC_F2(0, 0, 6, 6, 9)
+                 IKC_F2(0, 0, 7, 7, 9) IKC_F2(0, 0, 8, 8, 9)
+                 : "+v"(s0)
+                 : "v"(c0), "v"(c1), "v"(c2), "v"(c3), "v"(c4), "v"(c5), "v"(c6), "v"(c7), "n"(J0));
+}
+#undef IKC_F2
 
 // The same solve with the matrix in REGISTERS, one row per lane of the group (lane i: row i of the lower triangle; lane 15: the
 // right-hand side, riding along as row M), for M <= 15: the entries another lane needs come through DPP broadcasts, so the
@@ -420,7 +443,8 @@ IKD_FN void coop_chol_solve_regs(const int g, double *ws, const int offG, const 
 template <int MMAX, int K, int J>
 IKD_FN void chol_regs2_trail(double (&ra)[16], double (&rb)[32], const double lika, const double likb, const double nlika, const double nlikb, const int M) {
     if constexpr (J < MMAX) {
-        if (J >= M) return;   // (wave-uniform: one taken branch per pivot instead of 4 (MMAX - M) wasted slots)
+        // (no guard on J: rows past M hold zeros, and a wave-uniform test per update costs more than the update -- M sits in a
+        // spilled SGPR here: v_readlane + s_and + s_cbranch against one v_fmac)
         if constexpr (J < 16) {
             fmac_bcast<J>(ra[J], lika, nlika);
             fmac_bcast<J>(rb[J], lika, nlikb);
@@ -550,24 +574,30 @@ IKD_FN void coop_chol_solve_regs2(const int g, double *ws, const int offG, const
 // G(i,j) = [i == j] lam2 + sum_c J(i,c) J(j,c) (c ascending, as the LDS form) takes row j from lane j by DPP broadcast -- no LDS
 // traffic in the inner loop, where the pair-per-lane form reads two operands per product (the phase was bound by the CU's LDS
 // bandwidth: 18 % of the kernel).  Lane 15 holds the right-hand side (offe).  Then the solve above.
-template <int MMAX, int NVMAX, int J, int C>
-IKD_FN void gram_regs_dot(const double (&jr)[NVMAX], double &s) {
+template <int NVMAX, int J0, int J1, int C>
+IKD_FN void gram_regs_dot2(const double (&jr)[NVMAX], double &s0, double &s1) {   // rows J0 and J1 (J1 < 0: row J0 alone), eight columns at a time
     if constexpr (C < NVMAX) {
-        fmac_bcast<J>(s, jr[C], jr[C]);
-        gram_regs_dot<MMAX, NVMAX, J, C + 1>(jr, s);
+        if constexpr (J1 >= 0) fmac2_bcast8<J0, J1>(s0, s1, jr[C], jr[C + 1], jr[C + 2], jr[C + 3], jr[C + 4], jr[C + 5], jr[C + 6], jr[C + 7]);
+        else fmac1_bcast8<J0>(s0, jr[C], jr[C + 1], jr[C + 2], jr[C + 3], jr[C + 4], jr[C + 5], jr[C + 6], jr[C + 7]);
+        gram_regs_dot2<NVMAX, J0, J1, C + 8>(jr, s0, s1);
     }
 }
 template <int MMAX, int NVMAX, int J>
 IKD_FN void gram_regs_rows(const double (&jr)[NVMAX], double (&row)[16], const int g, const double lam2, const int M) {
+    static_assert(NVMAX % 8 == 0, "eight columns per asm block");
     if constexpr (J < MMAX) {
-        if (J < M) {   // (wave-uniform)
-            double s = g == J ? lam2 : 0.0;
-            gram_regs_dot<MMAX, NVMAX, J, 0>(jr, s);
-            row[J] = s;
+        double s0 = g == J ? lam2 : 0.0, s1 = g == J + 1 ? lam2 : 0.0;
+        if (J + 1 < M) {          // (wave-uniform) two rows at a time: their accumulators alternate
+            gram_regs_dot2<NVMAX, J, J + 1, 0>(jr, s0, s1);
+        } else if (J < M) {
+            gram_regs_dot2<NVMAX, J, -1, 0>(jr, s0, s1);
+            s1 = 0.0;
         } else {
-            row[J] = 0.0;
+            s0 = 0.0; s1 = 0.0;
         }
-        gram_regs_rows<MMAX, NVMAX, J + 1>(jr, row, g, lam2, M);
+        row[J] = s0;
+        if constexpr (J + 1 < 16) row[J + 1] = s1;
+        gram_regs_rows<MMAX, NVMAX, J + 2>(jr, row, g, lam2, M);
     }
 }
 template <int MMAX, int NVMAX>
