@@ -207,8 +207,8 @@ def cpu_baseline(model, xml, w, q0_np, tg_np, iters, budget_s=10.0):
         cf, ct, cr = w["constraint"]
         cons = O.make_tasks([(model.getFrameId(cf), model.getFrameId(cr), ct, 0, None)])
 
-        def solve(om_, tasks_, tg_, q0_, prm_, threads):
-            return O.dls_batch_constrained(om_, tasks_, cons, tg_, q0_, prm_, threads)
+        def solve(om_, tasks_, tg_, q0_, prm_, threads, ext=None):
+            return O.dls_batch_constrained(om_, tasks_, cons, tg_, q0_, prm_, threads, ext=ext)
     else:
         prm = O.params(iters, 1e-2, 1.0, -1.0)
         solve = O.dls_batch
@@ -237,21 +237,24 @@ def cpu_baseline(model, xml, w, q0_np, tg_np, iters, budget_s=10.0):
                       % (sample, cores, dt, r1))
     stable = sens <= 1e-7
     if not w.get("tasks") and not w.get("posture") and not model_is_free_flyer(w) and w.get("solver") != "pik":
+        # the optimised CPU variant (the device's lane program compiled for the host): a second BASELINE figure, nothing else --
+        # it takes no part in deciding which problems are held to the parity bar
         fid = model.getFrameId(w["frames"][0])
         n_fast = int(min(q0_np.shape[0], max(sample, sample * 4)))
         t = time.perf_counter()
         q_fast, _, _ = O.fast_dls_chain_batch(xml, fid, tg_np[:n_fast], q0_np[:n_fast], prm, cores)
         dtf = time.perf_counter() - t
-        # a fourth stability probe: two CPU restatements of the same algorithm (different order of arithmetic) that disagree
-        # with each other mark the lanes where rounding decides
-        sens = np.maximum(sens, np.abs(q_fast[:sample] - q_ref).max(axis=1))
-        stable = sens <= 1e-7
         out["optimised"] = dict(value=n_fast / dtf, unit="solves/s", cores=cores, kind="port",
                                 what="the device lane program (support-sparse, allocation-free, unrolled) compiled g++ -O3 "
                                      "-march=x86-64-v3 for the host, %d threads (oracle/fast_cpu.cpp)" % cores,
-                                sample="first %d problems, %.2f s wall" % (n_fast, dtf),
-                                max_abs_dq_vs_faithful_port_rad_stable=float(np.abs(q_fast[:sample] - q_ref)[stable].max()) if stable.any() else None)
-    return out, q_ref, ok_ref, it_ref, sample, stable, sens
+                                sample="first %d problems, %.2f s wall" % (n_fast, dtf))
+
+    def solve_ext(idx):
+        """the same oracle in _Float128 arithmetic (oracle/ik_oracle_ext.c) on the problems `idx` of the sample"""
+        return solve(om, tasks, tg_np[idx], q0_np[idx], prm, cores, ext="q")[0] if w.get("solver") == "pik" or not w.get("constraint") \
+            else O.dls_batch_constrained(om, tasks, cons, tg_np[idx], q0_np[idx], prm, cores, ext="q")[0]
+    out_ext = solve_ext
+    return out, q_ref, ok_ref, it_ref, sample, stable, sens, out_ext
 
 
 def model_is_free_flyer(w):
@@ -444,16 +447,28 @@ def main():
         bps = bytes_per_solve(w)
         achieved = bps * B / (kernel_ms * 1e-3) / 1e9
         stats = load_kernel_stats().get(data.kernel, {})
-        replay = "replayed from the committed PMC passes (profiles/, ik_amd/kernel_stats.json; rocprofv3 --pmc in separate runs, " \
+        # One build, one counter set: an entry of ik_amd/kernel_stats.json is replayed only when it was measured on THIS tree's device
+        # sources (tools/pmc_session.sh records tools/source_stamp.py's hash; tools/pmc_to_stats.py stamps it next to the kernel's symbol)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import source_stamp
+        tree_sha = source_stamp.device_source_sha16()
+        stamp = stats.get("stamp")
+        if not stamp or stamp.get("device_source_sha16") != tree_sha:
+            stale = "no counters replayed: ik_amd/kernel_stats.json holds %s for this kernel, the tree's device sources are %s" % (
+                ("a session of device sources " + stamp["device_source_sha16"]) if stamp else "no stamped session", tree_sha)
+            stats, stamp = {}, None
+        else:
+            stale = None
+        replay = "replayed from the committed PMC session %s (profiles/, ik_amd/kernel_stats.json; rocprofv3 --pmc in separate runs, " \
                  "gfx950 correction applied: tools/pmc_to_stats.py), measured at B = %s and scaled linearly in B -- not measured in this run" \
-                 % stats.get("pmc", {}).get("batch", "?")
+                 % ((stamp or {}).get("session", "?"), stats.get("pmc", {}).get("batch", "?"))
         # HBM bytes per launch from the PMC passes committed under profiles/
         traffic = None
         if stats.get("hbm_traffic_bytes_per_launch") and stats.get("pmc", {}).get("batch"):
             traffic = stats["hbm_traffic_bytes_per_launch"] * B / stats["pmc"]["batch"]
         waves_per_simd = (B + 63) // 64 / SIMDS
         hbm = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-               "traffic": traffic, "traffic_source": replay if traffic else None, "algorithmic_bytes_per_solve": bps}
+               "traffic": traffic, "traffic_source": replay if traffic else stale, "counter_stamp": stamp, "algorithmic_bytes_per_solve": bps}
         res = {
             "metric": "IK solves/sec (50-iter %s) at batch=65536" % ("PIK" if use_pik else "DLS"),
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -486,7 +501,7 @@ def main():
             # the binding roof of the fused on-chip loop is FP64 vector-ALU issue, not HBM
             res["roofline"] = {"bound": "fp64_valu", "achieved": tf, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
                                "frac": tf / FP64_VALU_PEAK_TF, "traffic": traffic, "kernel_ms": kernel_ms,
-                               "flop_per_solve": flops,
+                               "flop_per_solve": flops, "counter_stamp": stamp,
                                "counting": "executed FP64 VALU instructions per launch from the SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 "
                                            "counters (x 64 lanes, FMA = 2), 50 iterations; " + replay,
                                "note": "fused on-chip loop: the binding roof is FP64 vector-ALU issue; the HBM figure the contract "
@@ -513,6 +528,47 @@ def main():
                                         "stop_sq_tol": stop.tolerance, "max_iterations": 100,
                                         "mean_iterations": float(its.double().mean().item()),
                                         "success_rate": float(oks.double().mean().item())}
+            # (i-b) the stop rule on batches larger than the machine: lock-step waves (a wave runs until its last lane stops) against lane
+            # refill (a finished lane takes the next problem: device/chain_kernel_body.hpp); same results bit for bit
+            if data.kernel.startswith("dls_chain<"):
+                big = []
+                for bb in (CONFIG4_GLOBAL_BATCH, 4 * CONFIG4_GLOBAL_BATCH):
+                    _, Q0_b, tg_b = device_inputs(np.arange(bb))
+                    row = {"batch": bb}
+                    for label, val in (("lock_step", "0"), ("lane_refill", "1")):
+                        os.environ["IKGPU_REFILL"] = val
+                        ms_b, (Qb, okb, itb) = time_solve(Q0_b, tg_b, reps=3, p=prm_stop, vis=stop)
+                        row[label] = {"kernel_ms": ms_b, "value": bb / (ms_b * 1e-3), "unit": "solves/s"}
+                        if label == "lock_step":
+                            keep = (Qb.clone(), okb.clone(), itb.clone())
+                            row["mean_iterations"] = float(itb.double().mean().item())
+                            row["success_rate"] = float(okb.double().mean().item())
+                        else:
+                            row["bit_identical"] = bool(torch.equal(keep[0], Qb) and torch.equal(keep[1], okb) and torch.equal(keep[2], itb))
+                        row[label]["useful_iterations_per_s"] = row["mean_iterations"] * bb / (ms_b * 1e-3)
+                    os.environ.pop("IKGPU_REFILL", None)
+                    big.append(row)
+                    del Q0_b, tg_b
+                res["stop_rule_large_batches"] = big
+            # (i-c) the general chain build on the headline inputs: what a chain without a structure-specialised kernel runs on
+            if data.kernel.startswith("dls_chain<") and not data.kernel.endswith(",general>"):
+                os.environ["IKGPU_CHAIN_HOT"] = "0"
+                try:
+                    data_gen = ik_amd.dls_data(problem, device=local_rank)
+                finally:
+                    os.environ.pop("IKGPU_CHAIN_HOT", None)
+                out_gen = solve_batch(problem, Q0, targets, data_gen, visitor, prm)
+                a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a_.record()
+                for _ in range(10):
+                    out_gen = solve_batch(problem, Q0, targets, data_gen, visitor, prm, out=out_gen)
+                b_.record()
+                torch.cuda.synchronize()
+                ms_gen = float(a_.elapsed_time(b_)) / 10
+                res["general_build"] = {"kernel": data_gen.kernel, "kernel_ms": ms_gen, "value": B / (ms_gen * 1e-3), "unit": "solves/s",
+                                        "max_abs_dq_vs_headline_build_rad": float((out_gen[0] - out[0]).abs().max().item()),
+                                        "what": "the same inputs on the general chain build (IKGPU_CHAIN_HOT=0 at problem creation)"}
+                del data_gen
             # (ii) config 4's batch on this one GPU (4 waves per SIMD instead of 1)
             if args.workload == "cassie_leg" and total != CONFIG4_GLOBAL_BATCH:
                 _, Q0_big, tg_big = device_inputs(np.arange(CONFIG4_GLOBAL_BATCH))
@@ -545,23 +601,36 @@ def main():
             del d2, p2, m2
         if not args.no_cpu and world == 1:   # the CPU leg runs on rank 0 at N = 1 only
             tg_np = targets.permute(2, 0, 1).contiguous().cpu().numpy()
-            cpu, q_ref, ok_ref, it_ref, sample, stable, sens = cpu_baseline(model, xml, w, q0_np, tg_np, args.iters)
+            cpu, q_ref, ok_ref, it_ref, sample, stable, sens, solve_ext = cpu_baseline(model, xml, w, q0_np, tg_np, args.iters)
             res["cpu_baseline"] = cpu
-            d = np.abs(out[0].cpu().numpy().T[:sample] - q_ref).max(axis=1)
+            q_gpu = out[0].cpu().numpy().T[:sample]
+            d = np.abs(q_gpu - q_ref).max(axis=1)
             flags_equal = bool(np.array_equal(out[1].cpu().numpy()[:sample], ok_ref) and np.array_equal(out[2].cpu().numpy()[:sample], it_ref))
-            worst = int(np.argmax(np.where(stable, d, -1.0)))
+            beyond = stable & (d > 1e-6)
+            # every problem the probes exclude (and any that passes them and still misses the bar) is arbitrated by the same oracle in
+            # _Float128: r = |q_gpu - q_ext| / max(|q_cpu - q_ext|, 1e-9); "failing": r > 10, "mirror": the CPU port 10x farther than the GPU
+            arb = np.flatnonzero(~stable | beyond)[:4096]
+            arbitration = {"arbitrated": int(arb.size), "failing": 0, "mirror": 0, "median_ratio": None}
+            if arb.size:
+                q_ext = solve_ext(arb)
+                eg, eo = np.abs(q_gpu[arb] - q_ext).max(axis=1), np.abs(q_ref[arb] - q_ext).max(axis=1)
+                ratio = eg / np.maximum(eo, 1e-9)
+                arbitration.update(failing=int((ratio > 10).sum()), mirror=int((eo / np.maximum(eg, 1e-9) > 10).sum()),
+                                   median_ratio=float(np.median(ratio)), max_ratio=float(ratio.max()))
             res["parity_vs_cpu"] = {"problems": sample, "bar_rad": 1e-6, "flags_equal": flags_equal,
                                     "stable": int(stable.sum()),
                                     "max_abs_dq_rad_stable": float(d[stable].max()) if stable.any() else None,
-                                    "stable_beyond_bar": int((stable & (d > 1e-6)).sum()),
-                                    "worst_stable_problem": worst, "unstable": int((~stable).sum()),
-                                    "max_abs_dq_rad_unstable": float(d[~stable].max()) if (~stable).any() else None,
-                                    "stability_rule": "a problem is unstable when the CPU port's own answer moves by more than 1e-7 rad "
-                                                      "under a 1e-13 perturbation of q0 or of the target translations; only those are "
-                                                      "excluded from the 1e-6 bar (chain workloads: also when the optimised CPU variant and the faithful port disagree by "
-                                                      "more than 1e-7 rad).  With the joint-limit projection live and far targets the iteration is "
-                                                      "chaotic and a few lanes in 65536 escape every probe (stable_beyond_bar); "
-                                                      "tests/test_gpu_full_size.py checks those workloads step by step along the oracle's trajectory",
+                                    "stable_beyond_bar": int(beyond.sum()),
+                                    "excluded_by_perturbation": int((~stable).sum()),
+                                    "max_abs_dq_rad_excluded": float(d[~stable].max()) if (~stable).any() else None,
+                                    "extended_precision_arbitration": arbitration,
+                                    "rule": "a problem is excluded from the 1e-6 bar only when the CPU port's OWN answer moves by more than 1e-7 rad "
+                                            "under a 1e-13 perturbation of q0 or of the target translations (probes of the oracle alone); every "
+                                            "excluded problem is arbitrated by the same oracle in _Float128 arithmetic (oracle/ik_oracle_ext.c): "
+                                            "r = |q_gpu - q_ext| / max(|q_cpu - q_ext|, 1e-9), failing = r > 10, mirror = the CPU port 10x farther from "
+                                            "q_ext than the GPU.  In the chaotic clamp workloads r is the ratio of two draws from one heavy-tailed "
+                                            "distribution (median 1, failing ~ mirror); tests/test_gpu_full_size.py asserts exactly that and checks "
+                                            "those workloads step by step along the oracle's trajectory",
                                     "max_cpu_self_sensitivity_rad": float(sens.max())}
         print(json.dumps(res))
         sys.stdout.flush()

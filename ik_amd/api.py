@@ -470,6 +470,17 @@ def plan(problem):
     return buf.value.decode()
 
 
+def precompile(problem):
+    """Compile ahead of time (host-only, no device) what dls_data(problem) would compile at run time -- the structure-specialised
+    chain kernel of a chain without a pre-built instantiation -- into the on-disk cache; returns the kernel name.  Raises
+    IkgpuError (UNSUPPORTED) with the compiler's log when the compilation fails (the problem then runs on the general build)."""
+    arr = _task_table(problem)
+    cons, ncons = _constraint_table(problem)
+    buf = C.create_string_buffer(160)
+    capi.check(capi.lib().ikgpu_problem_precompile(problem.model()._h, arr, len(arr), cons, ncons, buf, len(buf)))
+    return buf.value.decode()
+
+
 def _params(visitor, p):
     return capi.DlsParams(int(p.max_iterations), float(p.damping), float(p.step_length), float(visitor.tolerance))
 

@@ -28,6 +28,7 @@ SYMBOLS = [
     "ikgpu_dls_solve_batch", "ikgpu_dls_solve_batch_host", "ikgpu_evaluate_batch", "ikgpu_task_frames_fk_batch",
     "ikgpu_pik_params_default", "ikgpu_pik_solve_batch", "ikgpu_pik_solve_batch_host", "ikgpu_pik_kernel",
     "ikgpu_problem_create_constrained", "ikgpu_problem_plan_constrained", "ikgpu_problem_support",
+    "ikgpu_problem_precompile",
 ]
 MAX_PIK_LEVELS, MAX_PIK_DA = 8, 128
 
@@ -108,6 +109,7 @@ def lib():
     L.ikgpu_problem_plan.argtypes = [vp, C.POINTER(Task), i32, C.c_char_p, sz]
     L.ikgpu_problem_create_constrained.argtypes = [vp, C.POINTER(Task), i32, C.POINTER(Task), i32, i32, C.POINTER(vp)]
     L.ikgpu_problem_plan_constrained.argtypes = [vp, C.POINTER(Task), i32, C.POINTER(Task), i32, C.c_char_p, sz]
+    L.ikgpu_problem_precompile.argtypes = [vp, C.POINTER(Task), i32, C.POINTER(Task), i32, C.c_char_p, sz]
     L.ikgpu_dls_solve_batch.argtypes = [vp, i64, vp, vp, C.POINTER(DlsParams), vp, vp, vp, C.c_int, vp]
     L.ikgpu_dls_solve_batch_host.argtypes = [vp, i64, vp, vp, C.POINTER(DlsParams), vp, vp, vp, C.c_int]
     L.ikgpu_pik_params_default.argtypes = [C.POINTER(PikParams), i32]

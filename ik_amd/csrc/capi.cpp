@@ -49,11 +49,15 @@ bool shape_built(const ikgpu::ProblemHost &ph) {
 // Analysis + the "is this specialisation compiled" check; a specialised shape without an instantiation
 // falls back to the generic kernel.  Throws std::runtime_error on invalid input.
 ikgpu::ProblemHost analyse(const ikgpu::Model &m, const ikgpu_task *tasks, int32_t ntasks, const ikgpu_task *cons = nullptr,
-                           int32_t ncons = 0) {
+                           int32_t ncons = 0, bool compile_rtc = false) {
     // IKGPU_DLS_KERNEL=generic skips the register-resident specialisations (the parity tests compare them with the generic kernel)
     const char *force = std::getenv("IKGPU_DLS_KERNEL");
     ikgpu::ProblemHost ph = ikgpu::analyse_problem(m, tasks, ntasks, force && std::strcmp(force, "generic") == 0, cons, ncons);
     if (!shape_built(ph)) ph = ikgpu::analyse_problem(m, tasks, ntasks, /*force_generic=*/true, cons, ncons);
+    if (ph.kind == ikgpu::KernelKind::Chain) {   // which build of the chain kernel: decided here, once, and part of the name
+        ph.chain_build = ikgpu::select_chain_build(ph, compile_rtc);
+        ph.kernel_name = ikgpu::chain_kernel_name(ph);
+    }
     return ph;
 }
 
@@ -306,7 +310,7 @@ int ikgpu_problem_create_constrained(const ikgpu_model *h, const ikgpu_task *tas
     *out = nullptr;
     ikgpu::ProblemHost ph, gen;
     try {
-        ph = analyse(h->m, tasks, ntasks, constraints, nconstraints);
+        ph = analyse(h->m, tasks, ntasks, constraints, nconstraints, /*compile_rtc=*/true);
         gen = ph.kind == ikgpu::KernelKind::Generic
                   ? ph
                   : ikgpu::analyse_problem(h->m, tasks, ntasks, /*force_generic=*/true, constraints, nconstraints);
@@ -345,7 +349,7 @@ int ikgpu_problem_create_constrained(const ikgpu_model *h, const ikgpu_task *tas
         up(&p->dev.q_in_chain, p->host.q_in_chain.data(), nq);
         up(&p->dev.g_ints, p->gen.generic.ints.data(), p->gen.generic.ints.size() * sizeof(int32_t));
         up(&p->dev.g_dbls, p->gen.generic.dbls.data(), p->gen.generic.dbls.size() * sizeof(double));
-        if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void **>(&p->dev.queue), sizeof(unsigned long long) * ikgpu::DeviceTables::kQueueSlots);
+        if (err == hipSuccess) err = p->dev.queues.grow();
         if (p->host.kind != ikgpu::KernelKind::Generic) {
             const std::vector<double> desc = p->host.kind == ikgpu::KernelKind::Chain ? ikgpu::chain_desc_table(p->host)
                                                                                      : ikgpu::tree_desc_table(p->host);
@@ -380,6 +384,25 @@ int ikgpu_problem_plan_constrained(const ikgpu_model *h, const ikgpu_task *tasks
     }
 }
 
+int ikgpu_problem_precompile(const ikgpu_model *h, const ikgpu_task *tasks, int32_t ntasks, const ikgpu_task *constraints,
+                             int32_t nconstraints, char *out, size_t cap) {
+    if (!h || !tasks || (nconstraints > 0 && !constraints)) return fail(IKGPU_ERR_INVALID, "null argument");
+    if (nconstraints < 0) return fail(IKGPU_ERR_INVALID, "negative constraint count");
+    try {
+        const ikgpu::ProblemHost planned = analyse(h->m, tasks, ntasks, constraints, nconstraints, /*compile_rtc=*/false);
+        const ikgpu::ProblemHost ph = analyse(h->m, tasks, ntasks, constraints, nconstraints, /*compile_rtc=*/true);
+        if (out && cap) {
+            std::strncpy(out, ph.kernel_name.c_str(), cap - 1);
+            out[cap - 1] = '\0';
+        }
+        if (planned.kernel_name != ph.kernel_name)   // planned a run-time compiled build, got the general one
+            return fail(IKGPU_ERR_UNSUPPORTED, "run-time compilation failed, the problem runs on " + ph.kernel_name + ": " + ikgpu::rtc_last_log());
+        return IKGPU_OK;
+    } catch (const std::exception &e) {
+        return fail(IKGPU_ERR_INVALID, e.what());
+    }
+}
+
 void ikgpu_problem_destroy(ikgpu_problem *p) {
     if (!p) return;
     DeviceGuard g(p->device);
@@ -389,7 +412,7 @@ void ikgpu_problem_destroy(ikgpu_problem *p) {
     (void)hipFree(p->dev.chain_desc);
     (void)hipFree(p->dev.g_ints);
     (void)hipFree(p->dev.g_dbls);
-    (void)hipFree(p->dev.queue);
+    p->dev.queues.release();
     if (p->stage.dev) (void)hipFree(p->stage.dev);
     if (p->stage.host) (void)hipHostFree(p->stage.host);
     delete p;

@@ -23,7 +23,9 @@
 //  * The visitor that never stops (the metric's fixed-iteration mode) is its own instantiation: no `active` selects, no
 //    stop-test arithmetic.
 #pragma once
+#if !defined(__HIPCC_RTC__)
 #include <cstdint>
+#endif
 
 #include "chain_kernel_body.hpp"
 
@@ -77,7 +79,7 @@ struct ChainRuns {
     static constexpr Table value = make();
 };
 
-constexpr int kHotTableMax = 64;  // doubles in the kernel-argument copy of the compact table (values, then lo[NJ], hi[NJ])
+constexpr int kHotTableMax = 112;  // doubles in the kernel-argument copy of the compact table (values, then lo[NJ], hi[NJ]): 8 x 12 + 2 x 7 when nothing is structural
 
 struct HotTable {
     double v[kHotTableMax];
@@ -183,14 +185,84 @@ IKD_FN void hot_evaluate(const Tab &t, const double (&q)[NJ], const double (&oMt
     }
 }
 
+// Gram matrix G = J J^T + lam2 I (lower triangle) from the negated task Jacobian columns.
+template <int NJ, class S>
+IKD_FN void hot_gram(const double (&col)[NJ][6], double lam2, double (&G)[36]) {
+    constexpr int M = 6;
+    constexpr typename ChainRuns<S, NJ>::Table kRuns = ChainRuns<S, NJ>::value;
+            // Gram matrix.  Joints of one run of parallel axes (S::leader) share their bottom (angular) rows: col[j][3..5] = A Rf^T z_j is
+            // the same vector for all of them, so  sum_j col[j][3+a] col[j][3+b] = n c_a c_b  and  sum_j col[j][3+a] col[j][b] =
+            // c_a (sum_j col[j][b])  within a run -- 102 instead of 147 multiply-adds for a Cassie leg (runs of 1, 1 and 5 joints).
+                    double top_sum[NJ][3], nbot[NJ][3];
+    #pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if (kRuns.leader[j] == j) {
+    #pragma unroll
+                    for (int b = 0; b < 3; ++b) {
+                        top_sum[j][b] = col[j][b];
+                        nbot[j][b] = kRuns.members[j] > 1 ? static_cast<double>(kRuns.members[j]) * col[j][3 + b] : col[j][3 + b];
+                    }
+                } else {
+    #pragma unroll
+                    for (int b = 0; b < 3; ++b) top_sum[kRuns.leader[j]][b] += col[j][b];
+                }
+            }
+    #pragma unroll
+            for (int a = 0; a < 3; ++a)
+    #pragma unroll
+                for (int b = 0; b <= a; ++b) {
+                    double s = (a == b) ? lam2 : 0.0;
+    #pragma unroll
+                    for (int j = 0; j < NJ; ++j) s = dfma(col[j][a], col[j][b], s);
+                    G[a * M + b] = s;
+                }
+    #pragma unroll
+            for (int a = 3; a < 6; ++a) {
+    #pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    double s = 0.0;
+    #pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        if (kRuns.leader[j] == j) s = dfma(col[j][a], top_sum[j][b], s);
+                    G[a * M + b] = s;
+                }
+    #pragma unroll
+                for (int b = 3; b <= a; ++b) {
+                    double s = (a == b) ? lam2 : 0.0;
+    #pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        if (kRuns.leader[j] == j) s = dfma(nbot[j][a - 3], col[j][b], s);
+                    G[a * M + b] = s;
+                }
+            }
+}
+
+// q <- clip(q + step_length dq), dq = -J^T y = +col^T y (reference ik/ik/dls.cpp:52-53,67-71) where `take`; q stays elsewhere.
+template <int NJ, class S, class Tab>
+IKD_FN void hot_step(const Tab &t, const LoopParams &prm, const double (&col)[NJ][6], const double (&y)[6], double (&q)[NJ], bool take) {
+    constexpr int kLim = S::offset(NJ + 1);  // lo[NJ], hi[NJ] follow the placement values
+    constexpr typename ChainRuns<S, NJ>::Table kRuns = ChainRuns<S, NJ>::value;
+    double ang[NJ];   // the angular part of col_j^T y, shared by a run of parallel axes
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+        if (kRuns.leader[j] == j) ang[j] = dfma(col[j][3], y[3], dfma(col[j][4], y[4], col[j][5] * y[5]));
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        double s = ang[kRuns.leader[j]];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) s = dfma(col[j][a], y[a], s);
+        const double qn = dfma(prm.step_length, s, q[j]);  // dq_j = -J_task(:, j)^T y = +col_j^T y
+        const double qc = dmin(t.v[kLim + NJ + j], dmax(qn, t.v[kLim + j]));
+        q[j] = take ? qc : q[j];
+    }
+}
+
 // One full solve.  q: in = q0 (chain joints), out = result.  NEVERSTOP: the visitor never stops (stop_sq_tol < 0): every
 // lane takes exactly max_iterations steps.
 template <int NJ, class S, bool NEVERSTOP, class Tab, class AnyFn>
 IKD_FN void hot_dls(const Tab &t, const LoopParams &prm, double (&q)[NJ], const double (&oMt)[12], int &iters_out,
                     bool &success_out, AnyFn any_active) {
     constexpr int M = 6;
-    constexpr int kLim = S::offset(NJ + 1);  // lo[NJ], hi[NJ] follow the placement values
-    constexpr typename ChainRuns<S, NJ>::Table kRuns = ChainRuns<S, NJ>::value;
     bool active = true;
     bool success = false;
     int iters = prm.max_iterations;
@@ -199,52 +271,8 @@ IKD_FN void hot_dls(const Tab &t, const LoopParams &prm, double (&q)[NJ], const 
         double e[M], col[NJ][M];
         hot_evaluate<NJ, S>(t, q, oMt, e, col);
 
-        // Gram matrix.  Joints of one run of parallel axes (S::leader) share their bottom (angular) rows: col[j][3..5] = A Rf^T z_j is
-        // the same vector for all of them, so  sum_j col[j][3+a] col[j][3+b] = n c_a c_b  and  sum_j col[j][3+a] col[j][b] =
-        // c_a (sum_j col[j][b])  within a run -- 102 instead of 147 multiply-adds for a Cassie leg (runs of 1, 1 and 5 joints).
         double G[M * M];
-        double top_sum[NJ][3], nbot[NJ][3];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            if (kRuns.leader[j] == j) {
-#pragma unroll
-                for (int b = 0; b < 3; ++b) {
-                    top_sum[j][b] = col[j][b];
-                    nbot[j][b] = kRuns.members[j] > 1 ? static_cast<double>(kRuns.members[j]) * col[j][3 + b] : col[j][3 + b];
-                }
-            } else {
-#pragma unroll
-                for (int b = 0; b < 3; ++b) top_sum[kRuns.leader[j]][b] += col[j][b];
-            }
-        }
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b <= a; ++b) {
-                double s = (a == b) ? prm.lam2 : 0.0;
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) s = dfma(col[j][a], col[j][b], s);
-                G[a * M + b] = s;
-            }
-#pragma unroll
-        for (int a = 3; a < 6; ++a) {
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                double s = 0.0;
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    if (kRuns.leader[j] == j) s = dfma(col[j][a], top_sum[j][b], s);
-                G[a * M + b] = s;
-            }
-#pragma unroll
-            for (int b = 3; b <= a; ++b) {
-                double s = (a == b) ? prm.lam2 : 0.0;
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    if (kRuns.leader[j] == j) s = dfma(nbot[j][a - 3], col[j][b], s);
-                G[a * M + b] = s;
-            }
-        }
+        hot_gram<NJ, S>(col, prm.lam2, G);
         double y[M];
         chol_solve<M>(G, e, y);
 
@@ -258,19 +286,7 @@ IKD_FN void hot_dls(const Tab &t, const LoopParams &prm, double (&q)[NJ], const 
             if (stop_now) { success = true; iters = it; }
             active = active && !stop_now;
         }
-        double ang[NJ];   // the angular part of col_j^T y, shared by a run of parallel axes
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-            if (kRuns.leader[j] == j) ang[j] = dfma(col[j][3], y[3], dfma(col[j][4], y[4], col[j][5] * y[5]));
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            double s = ang[kRuns.leader[j]];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) s = dfma(col[j][a], y[a], s);
-            const double qn = dfma(prm.step_length, s, q[j]);  // dq_j = -J_task(:, j)^T y = +col_j^T y
-            const double qc = dmin(t.v[kLim + NJ + j], dmax(qn, t.v[kLim + j]));
-            q[j] = (NEVERSTOP || active) ? qc : q[j];
-        }
+        hot_step<NJ, S>(t, prm, col, y, q, NEVERSTOP || active);
         if (!NEVERSTOP && !any_active(active)) break;
     }
     iters_out = iters;
@@ -303,6 +319,30 @@ IKD_FN void hot_pass_through(const ChainKernelArgs<NJ> &a, int64_t b, bool stepp
         }
     }
 }
+
+#if IKD_HIP_LANG
+// The hot program under lane refill (chain_kernel_body.hpp chain_refill_loop): the stop-rule mode for batches larger than the machine.
+template <int NJ, class S, class Tab>
+__device__ __forceinline__ void hot_refill_body(const ChainKernelArgs<NJ> &a, const Tab &t, unsigned long long *queue) {
+    chain_refill_loop<NJ>(a, queue, [&](double (&q)[NJ], const double (&oMt)[12], bool have) {
+        constexpr int M = 6;
+        double e[M], col[NJ][M];
+        hot_evaluate<NJ, S>(t, q, oMt, e, col);
+        double G[M * M];
+        hot_gram<NJ, S>(col, a.prm.lam2, G);
+        double y[M];
+        chol_solve<M>(G, e, y);
+        double e0sq = 0.0;
+        if (a.prm.priority == 0) {
+#pragma unroll
+            for (int k = 0; k < M; ++k) e0sq = dfma(e[k], e[k], e0sq);
+        }
+        const bool stop_now = have && (a.prm.stop_sq_tol >= 0.0) && (e0sq < a.prm.stop_sq_tol);
+        hot_step<NJ, S>(t, a.prm, col, y, q, !stop_now);
+        return stop_now;
+    });
+}
+#endif
 
 // B independent ik::dls() calls, lane `gid`: load, solve, store -- dls_chain_body (chain_kernel_body.hpp) with the hot program.
 template <int NJ, class S, bool NEVERSTOP, class Tab, class AnyFn>
@@ -353,5 +393,45 @@ IKD_FN void hot_chain_body(const ChainKernelArgs<NJ> &a, const Tab &t, int64_t g
 #endif
     if (a.iters) a.iters[b] = iters;
 }
+
+#if IKD_HIP_LANG
+// ---- kernel entries, shared by the instantiations compiled into the library (kernels_hot.hip) and the ones compiled at run time for
+// a chain's own structure code (rtc.cpp) -----------------------------------------------------------------------------------------
+#ifndef IKGPU_HOT_PIN_LO
+// the placement values are parked in vector registers, the joint limits stay in scalar registers (A/B on one box, B = 65536:
+// everything in VGPRs 0.1440 ms -- 22 v_accvgpr_read per iteration --, limits in SGPRs 0.1417 ms)
+#define IKGPU_HOT_PIN_LO 0
+#define IKGPU_HOT_PIN_HI (S::offset(NJ + 1))
+#endif
+
+// The compact table (<= 36 doubles for the fixture shapes) arrives in the kernel-argument segment and is parked in vector
+// registers for the whole loop: in scalar registers it competes with the ~40 polynomial constants for the 100 SGPRs (31 v_readlane
+// + 39 s_mov of spill code per iteration in the round-1 kernel); a lone wave has 512 VGPRs to itself.
+template <int NJ, class S>
+__device__ __forceinline__ void hot_park_table(const HotTable &t, HotTable &tv) {
+    constexpr int kUsed = S::offset(NJ + 1) + 2 * NJ;
+    static_assert(kUsed <= kHotTableMax, "compact table too long");
+#pragma unroll
+    for (int k = 0; k < kHotTableMax; ++k) {
+        tv.v[k] = k < kUsed ? t.v[k] : 0.0;
+        if (k >= IKGPU_HOT_PIN_LO && k < kUsed && k < IKGPU_HOT_PIN_HI) IKD_PIN(tv.v[k]);
+    }
+}
+
+template <int NJ, class S, bool NEVERSTOP>
+__device__ __forceinline__ void hot_kernel_entry(const ChainKernelArgs<NJ> &a, const HotTable &t) {
+    const int64_t gid = static_cast<int64_t>(blockIdx.x) * 64 + threadIdx.x;   // one wave64 per workgroup
+    HotTable tv;
+    hot_park_table<NJ, S>(t, tv);
+    hot_chain_body<NJ, S, NEVERSTOP>(a, tv, gid, [](bool act) { return __any(act) != 0; });
+}
+
+template <int NJ, class S>
+__device__ __forceinline__ void hot_refill_entry(const ChainKernelArgs<NJ> &a, const HotTable &t, unsigned long long *queue) {
+    HotTable tv;
+    hot_park_table<NJ, S>(t, tv);
+    hot_refill_body<NJ, S>(a, tv, queue);
+}
+#endif
 
 }  // namespace ikdev

@@ -2,7 +2,9 @@
 // load its problem from HBM, solve, store.  Shared by the __global__ wrappers (kernels.hip) and
 // by the CPU lane emulator under tests/ (which runs it in a plain loop over b).
 #pragma once
+#if !defined(__HIPCC_RTC__)
 #include <cstdint>
+#endif
 
 #include "chain_solver.hpp"
 
@@ -79,6 +81,85 @@ IKD_FN void dls_chain_body(const ChainKernelArgs<NJ> &a, const Desc &d, int64_t 
     if (a.success) a.success[b] = success ? 1 : 0;
     if (a.iters) a.iters[b] = iters;
 }
+
+#if IKD_HIP_LANG
+// ---- lane refill: the stop-rule mode without lock-step divergence ----------------------------------------------------------------
+// With the reference's default visitor (ik/ik/visitor.hpp:15-21) a problem stops after a handful of iterations or never
+// (max_iterations, ik/ik/dls.cpp:76-77); in the lock-step kernels a wave runs until its LAST lane stops, so one lane that never
+// converges keeps 63 finished ones idle.  Here a wave is persistent: a lane whose visitor fired (or whose iteration count reached
+// max_iterations) stores its result and takes the next unsolved problem from the launch's queue head; the wave leaves when the
+// queue is exhausted and every lane is idle.  A lane's state is (q, target, it): the iteration is the same code as the lock-step
+// loop's, so results are bit-identical whatever the batch composition.  Worth it when the batch is larger than the machine
+// (B > resident lanes); at B = resident lanes every problem has its own lane anyway and the launch lasts as long as its slowest problem.
+//
+// queue[0]: head -- problems handed out beyond the first (static) round, queue[1]: waves that have left; the last wave out
+// zeroes both, so the next launch on the same stream finds the slot clean (host: QueuePool in kernels.hpp).
+// iterate(q, oMt, have) runs ONE iteration of this lane's problem in place and returns "the visitor stopped it before the step".
+template <int NJ, class IterFn>
+__device__ __forceinline__ void chain_refill_loop(const ChainKernelArgs<NJ> &a, unsigned long long *queue, IterFn iterate) {
+    const int lane = static_cast<int>(threadIdx.x) & 63;                 // one wave per workgroup
+    const int64_t first_round = static_cast<int64_t>(gridDim.x) * 64;
+    int64_t b = static_cast<int64_t>(blockIdx.x) * 64 + lane;
+    bool have = b < a.B;
+    int64_t bs = have ? b : a.B - 1;                                     // idle lanes shadow a valid problem
+    double q[NJ], oMt[12];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) q[j] = a.q0[at(a.layout, a.B, a.nq, a.qidx[j], bs)];
+    load_target(a, bs, oMt);
+    int it = 0;
+    const int max_it = a.prm.max_iterations;                             // >= 1: the host sends max_iterations == 0 to the lock-step kernel
+    while (__any(have)) {
+        const bool stop_now = iterate(q, oMt, have) && have;
+        ++it;
+        const bool done = have && (stop_now || it >= max_it);
+        if (__any(done)) {
+            if (done) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) a.q_out[at(a.layout, a.B, a.nq, a.qidx[j], b)] = q[j];
+                if (a.success) a.success[b] = stop_now ? 1 : 0;
+                a.iters[b] = stop_now ? it - 1 : max_it;                 // never null here: the pass-through kernel reads it
+            }
+            const unsigned long long mask = __ballot(done);
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(queue, static_cast<unsigned long long>(__popcll(mask)));
+            const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(base)), hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(base >> 32));
+            base = (static_cast<unsigned long long>(hi) << 32) | lo;
+            const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+            if (done) {
+                b = first_round + static_cast<int64_t>(base) + rank;
+                have = b < a.B;
+                if (have) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) q[j] = a.q0[at(a.layout, a.B, a.nq, a.qidx[j], b)];
+                    load_target(a, b, oMt);
+                    it = 0;
+                }
+            }
+        }
+    }
+    // the last wave out resets the slot (every wave's atomics on queue[0] are ordered before its own arrival on queue[1])
+    if (lane == 0) {
+        __threadfence();
+        if (atomicAdd(queue + 1, 1ull) == static_cast<unsigned long long>(gridDim.x) - 1ull) {
+            queue[0] = 0ull;
+            queue[1] = 0ull;
+            __threadfence();
+        }
+    }
+}
+
+// The general chain program under lane refill (device/chain_solver.hpp chain_dls, one iteration at a time).
+template <int NJ, int KT, int SMASK, class Desc>
+__device__ __forceinline__ void dls_chain_refill_body(const ChainKernelArgs<NJ> &a, const Desc &d_in, unsigned long long *queue) {
+    const Desc *dp = &d_in;
+    chain_refill_loop<NJ>(a, queue, [&](double (&q)[NJ], const double (&oMt)[12], bool) {
+        asm volatile("" ::: "memory");
+        if constexpr (!std::is_same<Desc, ChainDesc<NJ>>::value) IKD_LAUNDER(dp);   // see chain_dls
+        return chain_iteration<NJ, KT, SMASK>(*dp, a.prm, q, oMt, true);
+    });
+}
+
+#endif  // IKD_HIP_LANG
 
 // evaluate_problem_data + stacking (reference ik/ik/data.cpp:25-58, ik/ik/dls.cpp:18-24):
 // e [M x B], dense J [M x nv x B] (zero outside the support, as the reference's zero-initialised

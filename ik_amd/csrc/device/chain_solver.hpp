@@ -16,7 +16,9 @@
 // placements on the host (pl' = P_prev^T pl P, P e_z = a), which leaves oMi * a and the joint
 // origin -- all the Jacobian needs -- unchanged.
 #pragma once
+#if !defined(__HIPCC_RTC__)
 #include <type_traits>
+#endif
 
 #include "lane_math.hpp"
 
@@ -184,12 +186,53 @@ IKD_FN void chain_evaluate(const Desc &d, const double (&q)[NJ], const double (&
     (void)M;
 }
 
+// ONE iteration at q (reference ik/ik/dls.cpp:14-71): evaluate, Gram, solve, the visitor's test BEFORE the step (dls.cpp:61-64;
+// ik/ik/visitor.hpp:19: ||e[0]||^2 < stop_sq_tol on the priority-0 rows), then q <- clip(q + step_length dq) where the lane is
+// `active` and the visitor did not fire.  Returns "the visitor fired" (false for an inactive lane).  Shared by the lock-step loop
+// (chain_dls) and the lane-refill loop (chain_kernel_body.hpp): one source of the arithmetic, bit-identical results.
+template <int NJ, int KT, int SMASK = -1, class Desc>
+IKD_FN bool chain_iteration(const Desc &d, const LoopParams &prm, double (&q)[NJ], const double (&oMt)[12], bool active) {
+    constexpr int M = TaskDim<KT>::value;
+    double e[M], col[NJ][M], Rf[9], pf[3];
+    chain_evaluate<NJ, KT, SMASK>(d, q, oMt, prm.idmask, prm.unit_weights != 0, e, col, Rf, pf);
+
+    double G[M * M];
+#pragma unroll
+    for (int a = 0; a < M; ++a)
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+            double s = (a == b) ? prm.lam2 : 0.0;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) s = dfma(col[j][a], col[j][b], s);
+            G[a * M + b] = s;
+        }
+    double y[M];
+    chol_solve<M>(G, e, y);
+
+    double e0sq = 0.0;
+    if (prm.priority == 0) {
+#pragma unroll
+        for (int a = 0; a < M; ++a) e0sq = dfma(e[a], e[a], e0sq);
+    }
+    const bool stop_now = active && (prm.stop_sq_tol >= 0.0) && (e0sq < prm.stop_sq_tol);
+    const bool step = active && !stop_now;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        double s = 0.0;
+#pragma unroll
+        for (int a = 0; a < M; ++a) s = dfma(col[j][a], y[a], s);
+        const double qn = dfma(prm.step_length, s, q[j]);  // dq_j = -J_task(:, j)^T y = +col_j^T y
+        const double qc = dmin(d.hi[j], dmax(qn, d.lo[j]));
+        q[j] = step ? qc : q[j];
+    }
+    return stop_now;
+}
+
 // One full solve. q: in = q0 (chain joints only), out = result. Returns iterations / success.
 // any_active(bool) must return a wave-uniform "some lane still iterating" (identity on the host).
 template <int NJ, int KT, int SMASK = -1, class Desc, class AnyFn>
 IKD_FN void chain_dls(const Desc &d_in, const LoopParams &prm, double (&q)[NJ], const double (&oMt)[12],
                       int &iters_out, bool &success_out, AnyFn any_active) {
-    constexpr int M = TaskDim<KT>::value;
     bool active = true;
     bool success = false;
     int iters = prm.max_iterations;
@@ -200,41 +243,9 @@ IKD_FN void chain_dls(const Desc &d_in, const LoopParams &prm, double (&q)[NJ], 
         // ds_read from LDS: both off the VALU) instead of letting the compiler hoist ~150 doubles into registers.
         asm volatile("" ::: "memory");
         if constexpr (!std::is_same<Desc, ChainDesc<NJ>>::value) IKD_LAUNDER(dp);  // constant address space: see lane_math.hpp
-        const Desc &d = *dp;
-        double e[M], col[NJ][M], Rf[9], pf[3];
-        chain_evaluate<NJ, KT, SMASK>(d, q, oMt, prm.idmask, prm.unit_weights != 0, e, col, Rf, pf);
-
-        double G[M * M];
-#pragma unroll
-        for (int a = 0; a < M; ++a)
-#pragma unroll
-            for (int b = 0; b <= a; ++b) {
-                double s = (a == b) ? prm.lam2 : 0.0;
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) s = dfma(col[j][a], col[j][b], s);
-                G[a * M + b] = s;
-            }
-        double y[M];
-        chol_solve<M>(G, e, y);
-
-        double e0sq = 0.0;
-        if (prm.priority == 0) {
-#pragma unroll
-            for (int a = 0; a < M; ++a) e0sq = dfma(e[a], e[a], e0sq);
-        }
-        const bool stop_now = active && (prm.stop_sq_tol >= 0.0) && (e0sq < prm.stop_sq_tol);
+        const bool stop_now = chain_iteration<NJ, KT, SMASK>(*dp, prm, q, oMt, active);
         if (stop_now) { success = true; iters = it; }
         active = active && !stop_now;
-
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            double s = 0.0;
-#pragma unroll
-            for (int a = 0; a < M; ++a) s = dfma(col[j][a], y[a], s);
-            const double qn = dfma(prm.step_length, s, q[j]);  // dq_j = -J_task(:, j)^T y = +col_j^T y
-            const double qc = dmin(d.hi[j], dmax(qn, d.lo[j]));
-            q[j] = active ? qc : q[j];
-        }
         if (!any_active(active)) break;
     }
     iters_out = iters;

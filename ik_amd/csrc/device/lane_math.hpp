@@ -9,14 +9,37 @@
 // is involved.  libikgpu.so never contains or calls a host build of this code.
 #pragma once
 
+#if defined(__HIPCC_RTC__)
+// Compiled at run time through hipRTC (rtc.cpp): no standard headers there -- hipRTC pre-includes the HIP built-ins; the few
+// standard names the lane programs use are declared here.
+typedef signed long long int64_t;
+typedef unsigned long long uint64_t;
+typedef signed int int32_t;
+typedef unsigned int uint32_t;
+typedef unsigned char uint8_t;
+namespace std {
+template <class A, class B> struct is_same { static constexpr bool value = false; };
+template <class A> struct is_same<A, A> { static constexpr bool value = true; };
+}  // namespace std
+#else
 #include <cmath>
 #include <cstdint>
+#endif
 
-#if defined(__HIPCC__)
+#if defined(__HIPCC_RTC__)
+#define IKD_FN __host__ __device__ inline __attribute__((always_inline))
+#elif defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define IKD_FN __host__ __device__ inline __attribute__((always_inline))
 #else
 #define IKD_FN inline __attribute__((always_inline))
+#endif
+
+// HIP language mode (both passes of hipcc, and hipRTC): __device__-only code (wave intrinsics, atomics) may be declared
+#if defined(__HIPCC__) || defined(__HIPCC_RTC__)
+#define IKD_HIP_LANG 1
+#else
+#define IKD_HIP_LANG 0
 #endif
 
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -60,6 +60,33 @@ __global__ __launch_bounds__(kBlock) void dls_chain_kernel(const ChainKernelArgs
 #endif
 }
 
+// The same lane program with lane refill (device/chain_kernel_body.hpp): persistent one-wave workgroups, stop-rule mode only.
+template <int NJ, int KT, int SMASK>
+__global__ __launch_bounds__(kBlock) void dls_chain_refill_kernel(const ChainKernelArgs<NJ> a, unsigned long long *queue) {
+    typedef const IKD_CONST_AS ChainDesc<NJ> ConstDesc;
+    ikdev::dls_chain_refill_body<NJ, KT, SMASK>(a, *(ConstDesc *)a.desc, queue);
+}
+
+struct PassThroughArgs {
+    const double *q0, *lower, *upper;
+    const uint8_t *q_in_chain;
+    const int32_t *iters;
+    double *q_out;
+    int64_t B;
+    int nq, layout;
+};
+__global__ __launch_bounds__(256) void chain_pass_through_kernel(const PassThroughArgs a) {
+    const int64_t b = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (b >= a.B) return;
+    const bool stepped = a.iters[b] > 0;
+    for (int i = 0; i < a.nq; ++i) {
+        if (a.q_in_chain[i]) continue;
+        const double v = a.q0[ikdev::at(a.layout, a.B, a.nq, i, b)];
+        const double c = ikdev::dmin(a.upper[i], ikdev::dmax(v, a.lower[i]));
+        a.q_out[ikdev::at(a.layout, a.B, a.nq, i, b)] = stepped ? c : v;
+    }
+}
+
 // Placement masks with a dedicated instantiation: the Cassie leg chains (knee, shin, tarsus, foot and the foot frame
 // are pure translations: 0xf8) and the UR5 arm (0x05).  Any other model runs the SMASK = 0 build.
 template <int NJ> struct HotMask { static constexpr int value = 0; };
@@ -93,6 +120,29 @@ ChainKernelArgs<NJ> make_args(const ProblemHost &ph, const DeviceTables &dt) {
 
 inline dim3 grid_for(int64_t B) { return dim3(static_cast<unsigned>((B + kBlock - 1) / kBlock)); }
 
+// A lane-refill launch: the launch's queue slot, an iteration-count array when the caller passed none (the pass-through kernel
+// reads it), the refill kernel, then the entries of q outside the chain.
+template <int NJ, class LaunchFn>
+hipError_t run_refill(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, ChainKernelArgs<NJ> &a, hipStream_t stream, LaunchFn launch) {
+    hipError_t e = hipSuccess;
+    unsigned long long *queue = dt.queues.slot_for(stream, &e);
+    if (!queue) return e;
+    int32_t *iters = io.iters;
+    void *tmp = nullptr;
+    if (!iters) {
+        if ((e = hipMallocAsync(&tmp, sizeof(int32_t) * static_cast<size_t>(io.B), stream)) != hipSuccess) return e;
+        iters = static_cast<int32_t *>(tmp);
+    }
+    launch(queue, iters);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = launch_chain_pass_through(ph, dt, io, iters, stream);
+    if (tmp) {
+        const hipError_t f = hipFreeAsync(tmp, stream);
+        if (e == hipSuccess) e = f;
+    }
+    return e;
+}
+
 template <int NJ, int KT>
 hipError_t run_dls(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const ikgpu_dls_params &prm,
                    hipStream_t stream) {
@@ -114,15 +164,26 @@ hipError_t run_dls(const ProblemHost &ph, const DeviceTables &dt, const BatchIO 
     // Cassie leg or a UR arm keeps the skipped placement products)
     constexpr int kMask = HotMask<NJ>::value;
     constexpr int kHot = kMask | (1 << ikdev::kSpecUnit);
+    // stop-rule mode on a batch larger than the machine: lane refill (same lane program, persistent waves), then the entries outside the chain
+#define IKGPU_CHAIN_LAUNCH(SM)                                                                                                  \
+    do {                                                                                                                        \
+        const void *rk = reinterpret_cast<const void *>(dls_chain_refill_kernel<NJ, KT, SM>);                                    \
+        const int64_t rgrid = refill_grid(rk, io.B);                                                                            \
+        if (refill_wanted(prm, io.B, rgrid)) return run_refill<NJ>(ph, dt, io, a, stream, [&](unsigned long long *queue, int32_t *it) { \
+            a.iters = it;                                                                                                       \
+            hipLaunchKernelGGL((dls_chain_refill_kernel<NJ, KT, SM>), dim3(static_cast<unsigned>(rgrid)), dim3(kBlock), 0, stream, a, queue); \
+        });                                                                                                                     \
+        hipLaunchKernelGGL((dls_chain_kernel<NJ, KT, SM>), grid_for(io.B), dim3(kBlock), 0, stream, a);                          \
+        return hipGetLastError();                                                                                               \
+    } while (0)
     if constexpr (kMask != 0) {
         if ((a.prm.idmask & kMask) == kMask) {
-            if (a.prm.unit_weights) hipLaunchKernelGGL((dls_chain_kernel<NJ, KT, kHot>), grid_for(io.B), dim3(kBlock), 0, stream, a);
-            else hipLaunchKernelGGL((dls_chain_kernel<NJ, KT, kMask>), grid_for(io.B), dim3(kBlock), 0, stream, a);
-            return hipGetLastError();
+            if (a.prm.unit_weights) IKGPU_CHAIN_LAUNCH(kHot);
+            else IKGPU_CHAIN_LAUNCH(kMask);
         }
     }
-    hipLaunchKernelGGL((dls_chain_kernel<NJ, KT, 0>), grid_for(io.B), dim3(kBlock), 0, stream, a);
-    return hipGetLastError();
+    IKGPU_CHAIN_LAUNCH(0);
+#undef IKGPU_CHAIN_LAUNCH
 }
 
 template <int NJ, int KT>
@@ -160,13 +221,40 @@ hipError_t run_fk(const ProblemHost &ph, const DeviceTables &dt, int64_t B, cons
 
 #define IKGPU_FOR_NJ(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
 
+bool refill_wanted(const ikgpu_dls_params &prm, int64_t B, int64_t resident_waves) {
+    if (!(prm.stop_sq_tol >= 0.0) || prm.max_iterations < 1) return false;   // the never-stop visitor: every lane takes the same number of steps
+    const char *env = std::getenv("IKGPU_REFILL");
+    if (env && env[0] == '0') return false;
+    if (env && env[0] == '1') return true;
+    return B > resident_waves * kBlock;   // otherwise every problem has its own lane from the start: nothing to refill
+}
+
+int64_t refill_grid(const void *kernel, int64_t B) {
+    int64_t waves = (B + kBlock - 1) / kBlock;
+    int64_t resident = persistent_grid(kernel, kBlock, 0, waves);
+    if (const char *env = std::getenv("IKGPU_REFILL_WAVES_PER_CU")) {
+        const long w = std::strtol(env, nullptr, 10);
+        if (w > 0) resident = std::min<int64_t>(waves, w * 256);
+    }
+    return resident;
+}
+
+hipError_t launch_chain_pass_through(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const int32_t *iters, hipStream_t stream) {
+    bool any_outside = false;
+    for (uint8_t in : ph.q_in_chain) any_outside = any_outside || !in;
+    if (!any_outside) return hipSuccess;
+    const PassThroughArgs p{io.q0, dt.lower, dt.upper, dt.q_in_chain, iters, io.q_out, io.B, ph.nq, io.layout};
+    hipLaunchKernelGGL(chain_pass_through_kernel, dim3(static_cast<unsigned>((io.B + 255) / 256)), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
 bool chain_shape_built(int nj, int type) {
     return nj >= 1 && nj <= kMaxChain && (type == IKGPU_FULL || type == IKGPU_POSITION || type == IKGPU_ORIENTATION);
 }
 
 hipError_t launch_dls_chain(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io,
                             const ikgpu_dls_params &prm, hipStream_t stream) {
-    if (chain_hot_built(ph)) return launch_dls_chain_hot(ph, dt, io, prm, stream);   // structure-specialised build (kernels_hot.hip)
+    if (ph.chain_build != 0) return launch_dls_chain_hot(ph, dt, io, prm, stream);   // structure-specialised build (kernels_hot.hip / rtc.cpp)
     const int nj = ph.chain.nj, type = ph.tasks[0].type;
 #define X(N)                                                                                              \
     if (nj == N) {                                                                                        \
@@ -505,6 +593,19 @@ __device__ __forceinline__ int64_t next_block(unsigned long long *queue) {
     return static_cast<int64_t>((static_cast<unsigned long long>(hi) << 32) | lo);
 }
 
+// A workgroup that has taken its last (failed) pull from the head signs out on queue[1]; the last one out zeroes the slot, so the
+// next launch on this stream finds it clean (QueuePool, kernels.hpp) -- no host-side reset, no other launch can hold this slot.
+__device__ __forceinline__ void leave_queue(unsigned long long *queue) {
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(queue + 1, 1ull) == static_cast<unsigned long long>(gridDim.x) - 1ull) {
+            queue[0] = 0ull;
+            queue[1] = 0ull;
+            __threadfence();
+        }
+    }
+}
+
 #ifndef IKGPU_COOP_WAVES
 #define IKGPU_COOP_WAVES 2   // (A/B knob: 1 = no register cap, four workgroups per CU)
 #endif
@@ -519,6 +620,7 @@ __global__ __launch_bounds__(kBlock, IKGPU_COOP_WAVES) void dls_coop_kernel(ikde
     const int64_t nblocks = (a.B + per_block - 1) / per_block;
     for (int64_t blk = next_block(queue); blk < nblocks; blk = next_block(queue))
         ikdev::dls_coop_body<false>(a, blk * per_block + grp, g, ws0 + grp * a.L.words, [](bool act) { return __any(act) != 0; });
+    leave_queue(queue);
 }
 
 // The same for 16 <= M <= 31 (rows left after the posture elimination): two matrix rows per lane in the register Cholesky, no
@@ -531,6 +633,7 @@ __global__ __launch_bounds__(kBlock) void dls_coop_big_kernel(ikdev::CoopKernelA
     const int64_t nblocks = (a.B + per_block - 1) / per_block;
     for (int64_t blk = next_block(queue); blk < nblocks; blk = next_block(queue))
         ikdev::dls_coop_body<true>(a, blk * per_block + grp, g, ws0 + grp * a.L.words, [](bool act) { return __any(act) != 0; });
+    leave_queue(queue);
 }
 
 __global__ __launch_bounds__(kBlock) void pik_coop_kernel(const ikdev::PikCoopKernelArgs a, const CoopStaging s, unsigned long long *queue) {
@@ -545,6 +648,7 @@ __global__ __launch_bounds__(kBlock) void pik_coop_kernel(const ikdev::PikCoopKe
     const int64_t nblocks = (a.B + per_block - 1) / per_block;
     for (int64_t blk = next_block(queue); blk < nblocks; blk = next_block(queue))   // persistent workgroups, as dls_coop_kernel
         ikdev::pik_coop_body(a, T, L, blk * per_block + grp, g, ws0 + grp * a.K.words, [](bool act) { return __any(act) != 0; });
+    leave_queue(queue);
 }
 
 }  // namespace
@@ -564,21 +668,73 @@ bool raise_lds_limit(const void *kernel, size_t lds) {
     return true;
 }
 
-// Grid of a persistent cooperative launch: as many workgroups as the device keeps resident (LDS-bound: five per CU for the demo task
-// set), never more than there are groups of problems.
-int64_t persistent_grid(const void *kernel, int block, size_t lds, int64_t nblocks) {
-    int per_cu = 0, dev = 0;
-    static int cu_count[64] = {};   // per device ordinal; hipGetDeviceProperties costs milliseconds, the launch must not
-    int cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
-        if (cu_count[dev] == 0) {
-            int n = 0;
-            cu_count[dev] = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0 ? n : 256;
+hipError_t QueuePool::grow() {
+    std::lock_guard<std::mutex> lock(mu);
+    void *p = nullptr;
+    const size_t bytes = sizeof(unsigned long long) * 2 * kChunkSlots;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return e;
+    if ((e = hipMemset(p, 0, bytes)) != hipSuccess) { (void)hipFree(p); return e; }
+    chunks.push_back(static_cast<unsigned long long *>(p));
+    used_in_last = 0;
+    return hipSuccess;
+}
+
+unsigned long long *QueuePool::slot_for(hipStream_t stream, hipError_t *err) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing(stream, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
+    const bool capturing = cap == hipStreamCaptureStatusActive;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!capturing) {
+            auto it = by_stream.find(stream);
+            if (it != by_stream.end()) return it->second;
         }
-        cus = cu_count[dev];
+        if (used_in_last < kChunkSlots && !chunks.empty()) {
+            unsigned long long *slot = chunks.back() + 2 * used_in_last++;
+            if (!capturing) by_stream.emplace(stream, slot);
+            return slot;
+        }
     }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-    const int64_t resident = static_cast<int64_t>(per_cu) * cus;
+    if (capturing) {   // allocation and memset are not capturable: a problem takes kChunkSlots captured launches (+ one chunk per grow() outside a capture)
+        *err = hipErrorStreamCaptureUnsupported;
+        return nullptr;
+    }
+    if ((*err = grow()) != hipSuccess) return nullptr;
+    return slot_for(stream, err);
+}
+
+void QueuePool::release() {
+    std::lock_guard<std::mutex> lock(mu);
+    for (unsigned long long *c : chunks) (void)hipFree(c);
+    chunks.clear();
+    by_stream.clear();
+    used_in_last = kChunkSlots;
+}
+
+// Grid of a persistent launch: as many workgroups as the device keeps resident (LDS-bound: five per CU for the demo task set),
+// never more than there are groups of problems.  The occupancy query costs ~10 us: cached per (kernel, block, lds, device).  Call
+// raise_lds_limit first: the query fails above the default 64 KB of dynamic LDS otherwise.
+int64_t persistent_grid(const void *kernel, int block, size_t lds, int64_t nblocks) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    struct Key { const void *k; int block; size_t lds; int dev; int64_t resident; };
+    static std::mutex mu;
+    static std::vector<Key> cache;
+    int64_t resident = 0;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        for (const Key &c : cache)
+            if (c.k == kernel && c.block == block && c.lds == lds && c.dev == dev) { resident = c.resident; break; }
+    }
+    if (resident == 0) {
+        int per_cu = 0, cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        resident = static_cast<int64_t>(per_cu) * cus;
+        std::lock_guard<std::mutex> lock(mu);
+        cache.push_back(Key{kernel, block, lds, dev, resident});
+    }
     return nblocks < resident ? nblocks : resident;
 }
 
@@ -626,10 +782,11 @@ hipError_t launch_pik_generic(const ProblemHost &gen, const DeviceTables &dt, co
         const int per_block = ikdev::kCoopPerBlock;
         const size_t lds = sizeof(double) * (static_cast<size_t>(per_block) * static_cast<size_t>(c.K.words) +
                                              static_cast<size_t>(s.n_dbls) + static_cast<size_t>((s.n_ints + 1) / 2));
-        const int64_t blocks = persistent_grid(reinterpret_cast<const void *>(pik_coop_kernel), per_block * ikdev::kCoopGroup, lds, (io.B + per_block - 1) / per_block);
-        unsigned long long *queue = dt.queue + dt.queue_next.fetch_add(1) % DeviceTables::kQueueSlots;
-        if (hipMemsetAsync(queue, 0, sizeof(*queue), stream) != hipSuccess) return hipGetLastError();
         if (!raise_lds_limit(reinterpret_cast<const void *>(pik_coop_kernel), lds)) return hipGetLastError();
+        const int64_t blocks = persistent_grid(reinterpret_cast<const void *>(pik_coop_kernel), per_block * ikdev::kCoopGroup, lds, (io.B + per_block - 1) / per_block);
+        hipError_t qe = hipSuccess;
+        unsigned long long *queue = dt.queues.slot_for(stream, &qe);
+        if (!queue) return qe;
         hipLaunchKernelGGL(pik_coop_kernel, dim3(static_cast<unsigned>(blocks)), dim3(per_block * ikdev::kCoopGroup), lds, stream, c, s, queue);
         return hipGetLastError();
     }
@@ -684,17 +841,18 @@ hipError_t launch_dls_generic(const ProblemHost &ph, const DeviceTables &dt, con
         const int per_block = ikdev::kCoopPerBlock;  // 4 x 16 lanes = one wave; 2 and 1 problems per workgroup measured slower
         const size_t lds = sizeof(double) * (static_cast<size_t>(per_block) * static_cast<size_t>(c.L.words) +
                                              static_cast<size_t>(s.n_dbls) + static_cast<size_t>((s.n_ints + 1) / 2));
-        const int64_t blocks = persistent_grid(reinterpret_cast<const void *>(dls_coop_kernel), per_block * ikdev::kCoopGroup, lds, (io.B + per_block - 1) / per_block);
-        unsigned long long *queue = dt.queue + dt.queue_next.fetch_add(1) % DeviceTables::kQueueSlots;
-        if (hipMemsetAsync(queue, 0, sizeof(*queue), stream) != hipSuccess) return hipGetLastError();
+        hipError_t qe = hipSuccess;
+        unsigned long long *queue = dt.queues.slot_for(stream, &qe);
+        if (!queue) return qe;
         const int rows = c.L.post_elim ? c.L.Mf : c.T.M;   // the size of the system the solver factorises
         if (rows >= 16 && rows <= 31) {
-            const int64_t blocks_big = persistent_grid(reinterpret_cast<const void *>(dls_coop_big_kernel), per_block * ikdev::kCoopGroup, lds, (io.B + per_block - 1) / per_block);
             if (!raise_lds_limit(reinterpret_cast<const void *>(dls_coop_big_kernel), lds)) return hipGetLastError();
+            const int64_t blocks_big = persistent_grid(reinterpret_cast<const void *>(dls_coop_big_kernel), per_block * ikdev::kCoopGroup, lds, (io.B + per_block - 1) / per_block);
             hipLaunchKernelGGL(dls_coop_big_kernel, dim3(static_cast<unsigned>(blocks_big)), dim3(per_block * ikdev::kCoopGroup), lds, stream, c, s, queue);
             return hipGetLastError();
         }
         if (!raise_lds_limit(reinterpret_cast<const void *>(dls_coop_kernel), lds)) return hipGetLastError();
+        const int64_t blocks = persistent_grid(reinterpret_cast<const void *>(dls_coop_kernel), per_block * ikdev::kCoopGroup, lds, (io.B + per_block - 1) / per_block);
         hipLaunchKernelGGL(dls_coop_kernel, dim3(static_cast<unsigned>(blocks)), dim3(per_block * ikdev::kCoopGroup), lds, stream, c, s, queue);
         return hipGetLastError();
     }
@@ -709,12 +867,7 @@ hipError_t launch_dls_generic(const ProblemHost &ph, const DeviceTables &dt, con
         a.T = bind_generic_tables(ph, dt.g_ints, dt.g_dbls);
         a.B = io.B;
         const size_t lds = sizeof(double) * 64 * static_cast<size_t>(ph.generic.ws_words);
-        static bool raised = false;   // above 64 KB of dynamic LDS the kernel has to be told once
-        if (!raised) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(dls_generic_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                return hipGetLastError();
-            raised = true;
-        }
+        if (!raise_lds_limit(reinterpret_cast<const void *>(dls_generic_lds_kernel), lds)) return hipGetLastError();
         hipLaunchKernelGGL(dls_generic_lds_kernel, dim3(static_cast<unsigned>((io.B + 63) / 64)), dim3(64), lds, stream, a);
         return hipGetLastError();
     }

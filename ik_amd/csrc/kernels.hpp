@@ -1,14 +1,34 @@
 // kernels.hpp -- host-visible launchers of the gfx950 kernels (defined in kernels.hip).
 #pragma once
-#include <atomic>
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <mutex>
+#include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "problem.hpp"
 
 namespace ikgpu {
+
+// Work-queue heads of the persistent kernels (the cooperative generic kernels' groups of problems, the chain kernels' lane refill).
+// A slot is two 64-bit words {head, workgroups that have left}: the LAST workgroup out of a launch zeroes both, so launches that
+// follow each other on ONE stream share one slot with no host-side reset between them.  Launches on different streams may overlap,
+// so every stream owns a slot; a launch recorded during stream capture gets a slot no live launch ever uses (the graph bakes the
+// pointer in and may be replayed next to anything on any stream; a graph never overlaps itself).  Nobody else can hold a launch's
+// slot: there is no ring to wrap around.
+struct QueuePool {
+    static constexpr int kChunkSlots = 256;     // the first chunk is allocated (and zeroed) when the problem is created
+    std::mutex mu;
+    std::vector<unsigned long long *> chunks;   // device allocations of kChunkSlots slots each
+    int used_in_last = kChunkSlots;
+    std::unordered_map<hipStream_t, unsigned long long *> by_stream;
+    hipError_t grow();                           // one more zeroed chunk (not during stream capture: hipMalloc / hipMemset are not capturable)
+    // the slot of a launch on `stream`, or nullptr with *err set
+    unsigned long long *slot_for(hipStream_t stream, hipError_t *err);
+    void release();
+};
 
 struct DeviceTables {  // per-problem constant arrays resident in HBM
     double *lower = nullptr, *upper = nullptr;  // [nq]
@@ -16,11 +36,7 @@ struct DeviceTables {  // per-problem constant arrays resident in HBM
     double *chain_desc = nullptr;               // ikdev::ChainDesc<NJ> / TreeDesc as a flat array of doubles
     int32_t *g_ints = nullptr;                  // generic kernel: packed int tables
     double *g_dbls = nullptr;                   // generic kernel: packed double tables
-    // cooperative kernels: work-queue heads of the persistent workgroups, one slot per launch in flight (a ring: the launch zeroes
-    // its slot on its stream, so launches of one problem on several streams -- or replays of a captured graph -- do not share one)
-    static constexpr int kQueueSlots = 64;
-    unsigned long long *queue = nullptr;        // [kQueueSlots]
-    mutable std::atomic<unsigned> queue_next{0};
+    mutable struct QueuePool queues;            // work-queue heads of the persistent kernels (below)
 };
 
 struct BatchIO {
@@ -44,6 +60,29 @@ bool chain_shape_built(int nj, int type);
 // The structure-specialised builds of the chain kernel (kernels_hot.hip, device/chain_hot.hpp): one Full task with unit
 // weights on a chain whose placement-structure code has an instantiation.  launch_dls_chain takes that route when it exists.
 bool chain_hot_built(const ProblemHost &ph);
+// Which build a Chain problem launches (ProblemHost::chain_build), decided once at problem creation: 1 when chain_hot_built, else 2
+// when the structure-specialised kernel could be compiled for this chain's structure code at run time (rtc.cpp; needs libhiprtc
+// and, the first time, a few seconds), else 0 = the general build.  IKGPU_CHAIN_HOT=0 forces the general build, IKGPU_RTC=0 keeps
+// run-time compilation off.  compile: false = plan only (ikgpu_problem_plan: names what WOULD run without compiling anything).
+int select_chain_build(const ProblemHost &ph, bool compile);
+// ",hot>" / ",hot-rtc>" / ",general>" appended to "dls_chain<NJ=..,type"
+std::string chain_kernel_name(const ProblemHost &ph);
+// Lane refill (device/chain_kernel_body.hpp chain_refill_loop): persistent one-wave workgroups whose lanes take the next unsolved
+// problem as soon as their visitor stops them.  Taken for the stop-rule mode (stop_sq_tol >= 0, max_iterations >= 1) when the batch
+// is larger than the lanes the device keeps resident; IKGPU_REFILL=0 never, =1 whenever the mode allows.  `resident_waves`: what
+// hipOccupancyMaxActiveBlocksPerMultiprocessor reports for the refill kernel x the device's CUs (IKGPU_REFILL_WAVES_PER_CU overrides).
+bool refill_wanted(const ikgpu_dls_params &prm, int64_t B, int64_t resident_waves);
+int64_t refill_grid(const void *kernel, int64_t B);
+// After a refill launch: the entries of q outside the chain (q0 clipped when iters > 0, else q0 -- reference ik/ik/dls.cpp:61-71),
+// one thread per problem; `iters` is the launch's own iteration-count array (never null).
+hipError_t launch_chain_pass_through(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const int32_t *iters, hipStream_t stream);
+// Run-time compiled hot build (rtc.cpp): dls_chain_hot_kernel<NJ, code...> for THIS chain's structure code through hipRTC.
+// available(compile = false): would it be attempted (libhiprtc loads, not disabled); (compile = true): compiled and loaded, or cached.
+bool rtc_chain_hot_available(const ProblemHost &ph, bool compile);
+std::string rtc_last_log();   // compiler log (or cache note) of the calling process's last run-time compilation attempt
+hipError_t rtc_launch_chain_hot(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const ikgpu_dls_params &prm, hipStream_t stream);
+int64_t persistent_grid(const void *kernel, int block, size_t lds, int64_t nblocks);
+bool raise_lds_limit(const void *kernel, size_t lds);
 hipError_t launch_dls_chain_hot(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const ikgpu_dls_params &prm,
                                 hipStream_t stream);
 

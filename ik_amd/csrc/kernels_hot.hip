@@ -18,12 +18,6 @@
 namespace ikgpu {
 namespace {
 
-#ifndef IKGPU_HOT_PIN_LO
-// the placement values are parked in vector registers, the joint limits stay in scalar registers (A/B on one box, B = 65536:
-// everything in VGPRs 0.1440 ms -- 22 v_accvgpr_read per iteration --, limits in SGPRs 0.1417 ms)
-#define IKGPU_HOT_PIN_LO 0
-#define IKGPU_HOT_PIN_HI (S::offset(NJ + 1))
-#endif
 constexpr int kBlock = 64;  // one wave64 per workgroup: 1024 workgroups at B = 65536 cover 256 CUs x 4 SIMDs
 
 using ikdev::ChainKernelArgs;
@@ -32,20 +26,15 @@ using ikdev::HotTable;
 
 template <int NJ, uint64_t C0, uint64_t C1, uint64_t C2, bool NEVERSTOP>
 __global__ __launch_bounds__(kBlock) void dls_chain_hot_kernel(const ChainKernelArgs<NJ> a, const HotTable t) {
-    typedef ChainStruct<C0, C1, C2> S;
-    const int64_t gid = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-    // The compact table (<= 36 doubles for the shapes built here) arrives in the kernel-argument segment and is parked in
-    // vector registers for the whole loop: in scalar registers it competes with the ~40 polynomial constants for the 100
-    // SGPRs (31 v_readlane + 39 s_mov of spill code per iteration in the round-1 kernel); a lone wave has 512 VGPRs to itself.
-    HotTable tv;
-    constexpr int kUsed = S::offset(NJ + 1) + 2 * NJ;
-    static_assert(kUsed <= ikdev::kHotTableMax, "compact table too long");
-#pragma unroll
-    for (int k = 0; k < ikdev::kHotTableMax; ++k) {
-        tv.v[k] = k < kUsed ? t.v[k] : 0.0;
-        if (k >= IKGPU_HOT_PIN_LO && k < kUsed && k < IKGPU_HOT_PIN_HI) IKD_PIN(tv.v[k]);
-    }
-    ikdev::hot_chain_body<NJ, S, NEVERSTOP>(a, tv, gid, [](bool act) { return __any(act) != 0; });
+    ikdev::hot_kernel_entry<NJ, ChainStruct<C0, C1, C2>, NEVERSTOP>(a, t);
+}
+
+// The same program with lane refill (device/chain_kernel_body.hpp chain_refill_loop): the stop-rule mode on batches larger than the machine.
+// Two waves per SIMD asked for (<= 256 registers): a wave that refills waits for its gathered loads (~2 us, most iterations have a
+// lane that finishes) and the other wave of the SIMD computes meanwhile.
+template <int NJ, uint64_t C0, uint64_t C1, uint64_t C2>
+__global__ __launch_bounds__(kBlock, 2) void dls_chain_hot_refill_kernel(const ChainKernelArgs<NJ> a, const HotTable t, unsigned long long *queue) {
+    ikdev::hot_refill_entry<NJ, ChainStruct<C0, C1, C2>>(a, t, queue);
 }
 
 // X(NJ, code0, code1, code2)
@@ -55,10 +44,38 @@ __global__ __launch_bounds__(kBlock) void dls_chain_hot_kernel(const ChainKernel
 
 }  // namespace
 
-bool chain_hot_built(const ProblemHost &ph) {
+// The hot program's preconditions: one Full FrameTask with unit weights on a chain whose structure code fits three words.
+static bool chain_hot_eligible(const ProblemHost &ph) {
     if (ph.kind != KernelKind::Chain || ph.ntasks != 1 || ph.tasks[0].type != IKGPU_FULL || !task_has_unit_weights(ph.tasks[0])) return false;
     const char *env = std::getenv("IKGPU_CHAIN_HOT");
     if (env && std::strcmp(env, "0") == 0) return false;   // A/B switch: the general chain kernel
+    return ph.chain_struct.fits;
+}
+
+// A lane-refill launch of a hot build: queue slot, an iteration-count array when the caller passed none, the kernel, then the
+// entries of q outside the chain (kernels.hip launch_chain_pass_through).
+template <int NJ, class LaunchFn>
+static hipError_t hot_refill_launch(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, ChainKernelArgs<NJ> &a, hipStream_t stream, LaunchFn launch) {
+    hipError_t e = hipSuccess;
+    unsigned long long *queue = dt.queues.slot_for(stream, &e);
+    if (!queue) return e;
+    void *tmp = nullptr;
+    if (!a.iters) {
+        if ((e = hipMallocAsync(&tmp, sizeof(int32_t) * static_cast<size_t>(io.B), stream)) != hipSuccess) return e;
+        a.iters = static_cast<int32_t *>(tmp);
+    }
+    launch(queue);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = launch_chain_pass_through(ph, dt, io, a.iters, stream);
+    if (tmp) {
+        const hipError_t f = hipFreeAsync(tmp, stream);
+        if (e == hipSuccess) e = f;
+    }
+    return e;
+}
+
+bool chain_hot_built(const ProblemHost &ph) {
+    if (!chain_hot_eligible(ph)) return false;
     const ChainStructure &s = ph.chain_struct;
     if (!s.fits) return false;
 #define X(N, K0, K1, K2) \
@@ -68,8 +85,22 @@ bool chain_hot_built(const ProblemHost &ph) {
     return false;
 }
 
+int select_chain_build(const ProblemHost &ph, bool compile) {
+    if (chain_hot_built(ph)) return 1;
+    if (chain_hot_eligible(ph) && rtc_chain_hot_available(ph, compile)) return 2;
+    return 0;
+}
+
+std::string chain_kernel_name(const ProblemHost &ph) {
+    std::string n = ph.kernel_name;
+    const size_t cut = n.rfind(',');
+    if (cut == std::string::npos) return n;
+    return n.substr(0, cut) + (ph.chain_build == 1 ? ",hot>" : ph.chain_build == 2 ? ",hot-rtc>" : ",general>");
+}
+
 hipError_t launch_dls_chain_hot(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const ikgpu_dls_params &prm,
                                 hipStream_t stream) {
+    if (ph.chain_build == 2) return rtc_launch_chain_hot(ph, dt, io, prm, stream);
     const ChainStructure &s = ph.chain_struct;
     const std::vector<double> &tab = ph.chain_hot;
     HotTable t{};
@@ -88,7 +119,14 @@ hipError_t launch_dls_chain_hot(const ProblemHost &ph, const DeviceTables &dt, c
         a.layout = io.layout; a.B = io.B; a.q0 = io.q0; a.targets = io.targets;                                          \
         a.q_out = io.q_out; a.success = io.success; a.iters = io.iters;                                                  \
         if (prm.stop_sq_tol < 0.0) hipLaunchKernelGGL((dls_chain_hot_kernel<N, K0, K1, K2, true>), grid, dim3(kBlock), 0, stream, a, t); \
-        else hipLaunchKernelGGL((dls_chain_hot_kernel<N, K0, K1, K2, false>), grid, dim3(kBlock), 0, stream, a, t);          \
+        else {                                                                                                           \
+            const void *rk = reinterpret_cast<const void *>(dls_chain_hot_refill_kernel<N, K0, K1, K2>);                   \
+            const int64_t rgrid = refill_grid(rk, io.B);                                                                 \
+            if (refill_wanted(prm, io.B, rgrid)) return hot_refill_launch<N>(ph, dt, io, a, stream, [&](unsigned long long *queue) { \
+                hipLaunchKernelGGL((dls_chain_hot_refill_kernel<N, K0, K1, K2>), dim3(static_cast<unsigned>(rgrid)), dim3(kBlock), 0, stream, a, t, queue); \
+            });                                                                                                          \
+            hipLaunchKernelGGL((dls_chain_hot_kernel<N, K0, K1, K2, false>), grid, dim3(kBlock), 0, stream, a, t);          \
+        }                                                                                                                \
         return hipGetLastError();                                                                                        \
     }
     IKGPU_HOT_SHAPES(X)

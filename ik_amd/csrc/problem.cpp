@@ -123,7 +123,7 @@ void specialise(ProblemHost &ph, const Model &m) {
         ph.chain_struct = chain_structure(ph.chain);
         ph.chain_hot = chain_hot_table(ph.chain);
         ph.kind = KernelKind::Chain;
-        ph.kernel_name = "dls_chain<NJ=" + std::to_string(ph.chain.nj) + "," + kt[t.type] + ">";
+        ph.kernel_name = "dls_chain<NJ=" + std::to_string(ph.chain.nj) + "," + kt[t.type] + ",general>";   // capi.cpp renames it when a hot build is taken
         ph.q_in_chain = in_chain;
         return;
     }

@@ -87,6 +87,10 @@ struct ProblemHost {
     ChainHost chain;                  // Chain kind: the chain; Tree kind: chain A
     ChainStructure chain_struct;      // Chain kind: the placement-structure code of `chain` and
     std::vector<double> chain_hot;    //   its compact table (device/chain_hot.hpp), computed once at analysis
+    // Chain kind: which build of the chain kernel this problem launches, decided ONCE when the problem is created (capi.cpp) and
+    // part of kernel_name: 0 "general" (device/chain_solver.hpp), 1 "hot" (structure-specialised, compiled into the library:
+    // kernels_hot.hip), 2 "hot-rtc" (the same kernel template instantiated for this chain's structure code at run time: rtc.cpp)
+    int chain_build = 0;
     ChainHost chainB;                 // Tree kind: chain B (nj = 0 when absent)
     int base_task = -1;               // Tree kind: index of the task on the base link, or -1
     double base_frame_pl[12] = {};    // base joint frame -> frame of the base task

@@ -1,0 +1,326 @@
+// rtc.cpp -- the structure-specialised chain kernel (device/chain_hot.hpp) for ANY chain: `dls_chain_hot_kernel<NJ, code...>` is
+// compiled for the problem's own placement-structure code at problem-creation time through hipRTC, so a robot that is not one of
+// the fixture models (kernels_hot.hip pre-builds Cassie's legs and the UR arms) gets the same lane program instead of the general
+// build.  The reference's loader takes any URDF (pinocchio::urdf::buildModelFromXML, ik_ros/src/cassie.cpp:34-35); this is what
+// keeps the headline kernel from being a property of two URDFs.
+//
+//  * The four device headers the kernel needs are embedded in the library verbatim (.incbin below) and handed to hipRTC as named
+//    headers: what is compiled at run time is exactly the source the pre-built instantiations were compiled from, with the flags of
+//    kernels_hot.hip (-fno-signed-zeros -fno-honor-nans -fno-honor-infinities -ffp-contract=on; no fast-math).
+//  * libhiprtc is opened with dlopen: when it is absent, or IKGPU_RTC=0, or the compilation fails, the problem runs on the general
+//    chain build -- never on a CPU path.
+//  * Code objects are cached in memory (per structure code) and on disk ($IKGPU_CACHE_DIR, else $XDG_CACHE_HOME/ikgpu, else
+//    ~/.cache/ikgpu; keyed by a hash of headers + source + flags + the hipRTC version), modules are loaded per device on first launch.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstddef>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "device/chain_hot.hpp"
+#include "kernels.hpp"
+
+// The device headers, verbatim.  (Paths are relative to ik_amd/csrc, where the Makefile runs the compiler.)
+#define IKGPU_EMBED(sym, path)                                                                                   \
+    __asm__(".section .rodata\n.global " #sym "\n.type " #sym ", @object\n" #sym ":\n.incbin \"" path "\"\n.byte 0\n" \
+            ".global " #sym "_end\n" #sym "_end:\n.previous\n");                                                    \
+    extern "C" const char sym[];                                                                                 \
+    extern "C" const char sym##_end[];
+IKGPU_EMBED(ikgpu_src_lane_math, "device/lane_math.hpp")
+IKGPU_EMBED(ikgpu_src_chain_solver, "device/chain_solver.hpp")
+IKGPU_EMBED(ikgpu_src_chain_kernel_body, "device/chain_kernel_body.hpp")
+IKGPU_EMBED(ikgpu_src_chain_hot, "device/chain_hot.hpp")
+
+namespace ikgpu {
+namespace {
+
+struct RtcApi {
+    void *lib = nullptr;
+    decltype(&hiprtcCreateProgram) create = nullptr;
+    decltype(&hiprtcCompileProgram) compile = nullptr;
+    decltype(&hiprtcGetCodeSize) code_size = nullptr;
+    decltype(&hiprtcGetCode) code = nullptr;
+    decltype(&hiprtcGetProgramLogSize) log_size = nullptr;
+    decltype(&hiprtcGetProgramLog) log = nullptr;
+    decltype(&hiprtcDestroyProgram) destroy = nullptr;
+    decltype(&hiprtcVersion) version = nullptr;
+    bool ok = false;
+};
+
+const RtcApi &rtc_api() {
+    static const RtcApi api = [] {
+        RtcApi a;
+        for (const char *name : {"libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"}) {
+            a.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (a.lib) break;
+        }
+        if (!a.lib) return a;
+        auto sym = [&](const char *n) { return dlsym(a.lib, n); };
+        a.create = reinterpret_cast<decltype(a.create)>(sym("hiprtcCreateProgram"));
+        a.compile = reinterpret_cast<decltype(a.compile)>(sym("hiprtcCompileProgram"));
+        a.code_size = reinterpret_cast<decltype(a.code_size)>(sym("hiprtcGetCodeSize"));
+        a.code = reinterpret_cast<decltype(a.code)>(sym("hiprtcGetCode"));
+        a.log_size = reinterpret_cast<decltype(a.log_size)>(sym("hiprtcGetProgramLogSize"));
+        a.log = reinterpret_cast<decltype(a.log)>(sym("hiprtcGetProgramLog"));
+        a.destroy = reinterpret_cast<decltype(a.destroy)>(sym("hiprtcDestroyProgram"));
+        a.version = reinterpret_cast<decltype(a.version)>(sym("hiprtcVersion"));
+        a.ok = a.create && a.compile && a.code_size && a.code && a.log_size && a.log && a.destroy;
+        return a;
+    }();
+    return api;
+}
+
+bool rtc_enabled() {
+    const char *env = std::getenv("IKGPU_RTC");
+    return !(env && env[0] == '0');
+}
+
+uint64_t fnv1a(uint64_t h, const void *data, size_t n) {
+    const unsigned char *p = static_cast<const unsigned char *>(data);
+    for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+const char *const kFlags[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-fast-math", "-ffp-contract=on",
+                              "-fno-signed-zeros", "-fno-honor-nans", "-fno-honor-infinities"};
+
+// values: non-structural placement entries of the chain.  The refill kernel asks for two waves per SIMD (256 registers) unless the
+// parked table alone would take most of them.
+std::string hot_source(int nj, const uint64_t code[3], int values) {
+    char buf[2048];
+    const char *refill_bounds = values <= 40 ? "__launch_bounds__(64, 2)" : "__launch_bounds__(64)";
+    std::snprintf(buf, sizeof buf,
+                  "#include \"chain_hot.hpp\"\n"
+                  "typedef ikdev::ChainStruct<0x%llxull, 0x%llxull, 0x%llxull> S;\n"
+                  "extern \"C\" __global__ __launch_bounds__(64) void ikgpu_hot_never(const ikdev::ChainKernelArgs<%d> a, const ikdev::HotTable t) {\n"
+                  "    ikdev::hot_kernel_entry<%d, S, true>(a, t);\n}\n"
+                  "extern \"C\" __global__ __launch_bounds__(64) void ikgpu_hot_stop(const ikdev::ChainKernelArgs<%d> a, const ikdev::HotTable t) {\n"
+                  "    ikdev::hot_kernel_entry<%d, S, false>(a, t);\n}\n"
+                  "extern \"C\" __global__ %s void ikgpu_hot_refill(const ikdev::ChainKernelArgs<%d> a, const ikdev::HotTable t, unsigned long long *queue) {\n"
+                  "    ikdev::hot_refill_entry<%d, S>(a, t, queue);\n}\n",
+                  static_cast<unsigned long long>(code[0]), static_cast<unsigned long long>(code[1]), static_cast<unsigned long long>(code[2]),
+                  nj, nj, nj, nj, refill_bounds, nj, nj);
+    return buf;
+}
+
+std::string cache_dir() {
+    std::string d;
+    if (const char *e = std::getenv("IKGPU_CACHE_DIR")) d = e;
+    else if (const char *x = std::getenv("XDG_CACHE_HOME")) d = std::string(x) + "/ikgpu";
+    else if (const char *h = std::getenv("HOME")) d = std::string(h) + "/.cache/ikgpu";
+    else d = "/tmp/ikgpu-cache-" + std::to_string(static_cast<long>(getuid()));
+    // mkdir -p (two levels are enough for the defaults)
+    const size_t slash = d.rfind('/');
+    if (slash != std::string::npos && slash > 0) (void)mkdir(d.substr(0, slash).c_str(), 0755);
+    (void)mkdir(d.c_str(), 0755);
+    return d;
+}
+
+bool read_file(const std::string &path, std::vector<char> &out) {
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    std::fseek(f, 0, SEEK_END);
+    const long n = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    out.resize(n > 0 ? static_cast<size_t>(n) : 0);
+    const bool ok = n > 0 && std::fread(out.data(), 1, out.size(), f) == out.size();
+    std::fclose(f);
+    return ok;
+}
+
+void write_file_atomically(const std::string &path, const std::vector<char> &data) {
+    const std::string tmp = path + ".tmp." + std::to_string(static_cast<long>(getpid()));
+    FILE *f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return;
+    const bool ok = std::fwrite(data.data(), 1, data.size(), f) == data.size();
+    std::fclose(f);
+    if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) (void)std::remove(tmp.c_str());
+}
+
+typedef std::tuple<int, uint64_t, uint64_t, uint64_t> ShapeKey;
+
+struct HotCode {
+    bool tried = false, ok = false;
+    std::vector<char> code;
+    std::string log;
+};
+struct HotModule {
+    hipModule_t mod = nullptr;
+    hipFunction_t never = nullptr, stop = nullptr, refill = nullptr;
+    int refill_waves_per_cu = 0;
+};
+
+std::mutex g_mu;
+std::map<ShapeKey, HotCode> g_codes;
+std::map<std::pair<ShapeKey, int>, HotModule> g_modules;
+std::string g_last_log;
+
+ShapeKey key_of(const ProblemHost &ph) {
+    return ShapeKey(ph.chain.nj, ph.chain_struct.code[0], ph.chain_struct.code[1], ph.chain_struct.code[2]);
+}
+
+// Compiles (or fetches) the code object of this shape.  Called with g_mu held.
+HotCode &code_for(const ProblemHost &ph) {
+    HotCode &hc = g_codes[key_of(ph)];
+    if (hc.tried) return hc;
+    hc.tried = true;
+    const RtcApi &api = rtc_api();
+    if (!api.ok) { hc.log = "libhiprtc could not be loaded"; return hc; }
+    const std::string src = hot_source(ph.chain.nj, ph.chain_struct.code, ph.chain_struct.values);
+    struct Hdr { const char *name, *begin, *end; };
+    const Hdr hdrs[] = {{"lane_math.hpp", ikgpu_src_lane_math, ikgpu_src_lane_math_end},
+                        {"chain_solver.hpp", ikgpu_src_chain_solver, ikgpu_src_chain_solver_end},
+                        {"chain_kernel_body.hpp", ikgpu_src_chain_kernel_body, ikgpu_src_chain_kernel_body_end},
+                        {"chain_hot.hpp", ikgpu_src_chain_hot, ikgpu_src_chain_hot_end}};
+    uint64_t h = 14695981039346656037ull;
+    for (const Hdr &x : hdrs) h = fnv1a(h, x.begin, static_cast<size_t>(x.end - x.begin));
+    h = fnv1a(h, src.data(), src.size());
+    for (const char *f : kFlags) h = fnv1a(h, f, std::strlen(f));
+    int vmaj = 0, vmin = 0;
+    if (api.version) (void)api.version(&vmaj, &vmin);
+    h = fnv1a(h, &vmaj, sizeof vmaj);
+    h = fnv1a(h, &vmin, sizeof vmin);
+    char name[64];
+    std::snprintf(name, sizeof name, "/chain_hot_%016llx.hsaco", static_cast<unsigned long long>(h));
+    const std::string path = cache_dir() + name;
+    if (read_file(path, hc.code)) { hc.ok = true; hc.log = "cached: " + path; return hc; }
+
+    hiprtcProgram prog = nullptr;
+    const char *hsrc[4], *hname[4];
+    for (int i = 0; i < 4; ++i) { hsrc[i] = hdrs[i].begin; hname[i] = hdrs[i].name; }
+    if (api.create(&prog, src.c_str(), "ikgpu_chain_hot.hip", 4, hsrc, hname) != HIPRTC_SUCCESS) { hc.log = "hiprtcCreateProgram failed"; return hc; }
+    const hiprtcResult rc = api.compile(prog, static_cast<int>(sizeof kFlags / sizeof kFlags[0]), const_cast<const char **>(kFlags));
+    size_t ls = 0;
+    if (api.log_size(prog, &ls) == HIPRTC_SUCCESS && ls > 1) {
+        hc.log.resize(ls);
+        (void)api.log(prog, &hc.log[0]);
+    }
+    size_t cs = 0;
+    if (rc == HIPRTC_SUCCESS && api.code_size(prog, &cs) == HIPRTC_SUCCESS && cs > 0) {
+        hc.code.resize(cs);
+        hc.ok = api.code(prog, hc.code.data()) == HIPRTC_SUCCESS;
+    }
+    (void)api.destroy(&prog);
+    if (hc.ok) write_file_atomically(path, hc.code);
+    else if (std::getenv("IKGPU_RTC_VERBOSE")) std::fprintf(stderr, "ikgpu: run-time compilation of the chain kernel failed:\n%s\n", hc.log.c_str());
+    return hc;
+}
+
+// The loaded module of this shape on the current device.  Called with g_mu held.
+HotModule *module_for(const ProblemHost &ph, hipError_t *err) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    HotModule &m = g_modules[std::make_pair(key_of(ph), dev)];
+    if (m.mod) return &m;
+    HotCode &hc = code_for(ph);
+    if (!hc.ok) { *err = hipErrorInvalidImage; return nullptr; }
+    hipError_t e = hipModuleLoadData(&m.mod, hc.code.data());
+    if (e == hipSuccess) e = hipModuleGetFunction(&m.never, m.mod, "ikgpu_hot_never");
+    if (e == hipSuccess) e = hipModuleGetFunction(&m.stop, m.mod, "ikgpu_hot_stop");
+    if (e == hipSuccess) e = hipModuleGetFunction(&m.refill, m.mod, "ikgpu_hot_refill");
+    if (e == hipSuccess) {
+        int per_cu = 0;
+        if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, m.refill, 64, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+        m.refill_waves_per_cu = per_cu;
+    }
+    if (e != hipSuccess) { *err = e; m = HotModule{}; return nullptr; }
+    return &m;
+}
+
+template <int NJ>
+hipError_t launch_shape(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const ikgpu_dls_params &prm, hipStream_t stream,
+                        const HotModule &m) {
+    struct Args {   // the kernel-argument segment: (ChainKernelArgs<NJ> a, HotTable t, unsigned long long *queue), natural alignment
+        ikdev::ChainKernelArgs<NJ> a;
+        ikdev::HotTable t;
+        unsigned long long *queue;
+    } args{};
+    static_assert(sizeof(ikdev::ChainKernelArgs<NJ>) % 8 == 0 && sizeof(ikdev::HotTable) % 8 == 0, "argument layout");
+    ikdev::ChainKernelArgs<NJ> &a = args.a;
+    fill_chain_args(ph, a.ref_pl, a.qidx, a.vidx, &a.nq, &a.nv, &a.prm.priority, &a.prm.idmask, &a.prm.unit_weights);
+    a.lower = dt.lower; a.upper = dt.upper; a.q_in_chain = dt.q_in_chain;
+    a.prm.max_iterations = prm.max_iterations;
+    a.prm.lam2 = prm.damping * prm.damping;
+    a.prm.step_length = prm.step_length;
+    a.prm.stop_sq_tol = prm.stop_sq_tol;
+    a.layout = io.layout; a.B = io.B; a.q0 = io.q0; a.targets = io.targets;
+    a.q_out = io.q_out; a.success = io.success; a.iters = io.iters;
+    if (ph.chain_hot.size() > static_cast<size_t>(ikdev::kHotTableMax)) return hipErrorInvalidValue;
+    std::memcpy(args.t.v, ph.chain_hot.data(), ph.chain_hot.size() * sizeof(double));
+
+    const int64_t waves = (io.B + 63) / 64;
+    auto launch = [&](hipFunction_t fn, int64_t grid, size_t nbytes) {
+        void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &nbytes, HIP_LAUNCH_PARAM_END};
+        return hipModuleLaunchKernel(fn, static_cast<unsigned>(grid), 1, 1, 64, 1, 1, 0, stream, nullptr, config);
+    };
+    const size_t two = offsetof(Args, queue), three = sizeof(Args);
+    if (prm.stop_sq_tol < 0.0) return launch(m.never, waves, two);
+    int64_t resident = std::min<int64_t>(waves, static_cast<int64_t>(m.refill_waves_per_cu) * 256);
+    if (const char *env = std::getenv("IKGPU_REFILL_WAVES_PER_CU")) {
+        const long w = std::strtol(env, nullptr, 10);
+        if (w > 0) resident = std::min<int64_t>(waves, w * 256);
+    }
+    if (!refill_wanted(prm, io.B, resident)) return launch(m.stop, waves, two);
+    hipError_t e = hipSuccess;
+    args.queue = dt.queues.slot_for(stream, &e);
+    if (!args.queue) return e;
+    void *tmp = nullptr;
+    if (!a.iters) {
+        if ((e = hipMallocAsync(&tmp, sizeof(int32_t) * static_cast<size_t>(io.B), stream)) != hipSuccess) return e;
+        a.iters = static_cast<int32_t *>(tmp);
+    }
+    e = launch(m.refill, resident, three);
+    if (e == hipSuccess) e = launch_chain_pass_through(ph, dt, io, a.iters, stream);
+    if (tmp) {
+        const hipError_t f = hipFreeAsync(tmp, stream);
+        if (e == hipSuccess) e = f;
+    }
+    return e;
+}
+
+}  // namespace
+
+bool rtc_chain_hot_available(const ProblemHost &ph, bool compile) {
+    if (!rtc_enabled() || ph.kind != KernelKind::Chain || !ph.chain_struct.fits || ph.chain.nj < 1 || ph.chain.nj > 7) return false;
+    if (!rtc_api().ok) return false;
+    if (!compile) return true;
+    std::lock_guard<std::mutex> lock(g_mu);
+    const HotCode &hc = code_for(ph);
+    g_last_log = hc.log;
+    return hc.ok;
+}
+
+std::string rtc_last_log() {
+    std::lock_guard<std::mutex> lock(g_mu);
+    return g_last_log;
+}
+
+hipError_t rtc_launch_chain_hot(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const ikgpu_dls_params &prm, hipStream_t stream) {
+    HotModule m;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        hipError_t e = hipSuccess;
+        HotModule *pm = module_for(ph, &e);
+        if (!pm) return e;
+        m = *pm;
+    }
+    switch (ph.chain.nj) {
+#define X(N) case N: return launch_shape<N>(ph, dt, io, prm, stream, m);
+        X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#undef X
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace ikgpu

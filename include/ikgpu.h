@@ -156,6 +156,17 @@ int ikgpu_problem_create_constrained(const ikgpu_model *m, const ikgpu_task *tas
                                      int32_t nconstraints, int32_t device, ikgpu_problem **out);
 int ikgpu_problem_plan_constrained(const ikgpu_model *m, const ikgpu_task *tasks, int32_t ntasks, const ikgpu_task *constraints,
                                    int32_t nconstraints, char *out, size_t cap);
+/* Host-only, touches no device: compiles ahead of time whatever ikgpu_problem_create would compile at run time for this problem
+ * -- today the structure-specialised chain kernel (`dls_chain<..,hot-rtc>`) of a fixed-base chain whose placement structure has no
+ * pre-built instantiation, through hipRTC -- and leaves the code object in the on-disk cache ($IKGPU_CACHE_DIR, else
+ * $XDG_CACHE_HOME/ikgpu, else ~/.cache/ikgpu), so that the first ikgpu_problem_create on the robot does not pay the few seconds
+ * of compilation.  There is no counterpart in the reference (its kernels are the CPU's); it belongs to the cold path that stands
+ * in for InverseKinematicsProblem + dls_data construction (reference ik/ik/problem.hpp:17-22, ik/ik/dls.hpp:36-52).
+ * Returns IKGPU_OK when there was nothing to compile or the compilation succeeded (the name of the kernel that will run is written
+ * to `out` as by ikgpu_problem_plan), IKGPU_ERR_UNSUPPORTED when hipRTC is unavailable or the compilation failed (the problem then
+ * runs on the general build; the compiler's log is in ikgpu_last_error()). */
+int ikgpu_problem_precompile(const ikgpu_model *m, const ikgpu_task *tasks, int32_t ntasks, const ikgpu_task *constraints,
+                             int32_t nconstraints, char *out, size_t cap);
 int32_t ikgpu_problem_rows(const ikgpu_problem *p);        /* M = sum of task dimensions */
 const char *ikgpu_problem_kernel(const ikgpu_problem *p);  /* name of the chosen specialisation */
 /* Which entries of q a solve can move: support[i] = 1 when q[i] is integrated by the kernel (a joint in the support of some

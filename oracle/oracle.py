@@ -56,6 +56,23 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+# ---- the same restatement in extended precision (oracle/ik_oracle_ext.c): "q" = _Float128 (113-bit significand), "ld" = x87 long
+# double (64-bit).  Same ABI, same names; used by the parity tests to arbitrate lanes the perturbation probes exclude.
+_EXT = {}
+
+
+def ext_lib(kind="q"):
+    if kind not in _EXT:
+        path = os.path.join(_HERE, "libik_oracle_%s.so" % kind)
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        for f in (L.iko_dls_batch, L.iko_dls_batch_constrained, L.iko_pik_batch, L.iko_task_rows, L.iko_ext_bits):
+            f.restype = C.c_int
+        _EXT[kind] = L
+    return _EXT[kind]
+
+
 class OracleModel:
     """Wraps a flat model dict: jtype, parent, idx_q, idx_v (int32 [nj]); placement [nj,12];
     axis [nj,3]; lower, upper [nq]; frame_parent int32 [nf]; frame_placement [nf,12];
@@ -143,8 +160,9 @@ def dls(model, tasks, targets, q0, prm, trace=False):
     return q, bool(ok.value), it.value
 
 
-def dls_batch(model, tasks, targets, q0, prm, nthreads=1):
-    """targets [B, ntasks, 12], q0 [B, nq] (array-of-structures)."""
+def dls_batch(model, tasks, targets, q0, prm, nthreads=1, ext=None):
+    """targets [B, ntasks, 12], q0 [B, nq] (array-of-structures).  ext: None (the double oracle), "q" or "ld" (the same
+    statements in _Float128 / long double arithmetic, results rounded to double once at the end)."""
     targets = np.ascontiguousarray(targets, dtype=np.float64)
     q0 = np.ascontiguousarray(q0, dtype=np.float64)
     B = q0.shape[0]
@@ -152,7 +170,7 @@ def dls_batch(model, tasks, targets, q0, prm, nthreads=1):
     q = np.empty_like(q0)
     ok = np.zeros(B, dtype=np.uint8)
     it = np.zeros(B, dtype=np.int32)
-    lib().iko_dls_batch(C.byref(model.c), tasks, C.c_int(len(tasks)), C.c_long(B), _p(targets), _p(q0),
+    (ext_lib(ext) if ext else lib()).iko_dls_batch(C.byref(model.c), tasks, C.c_int(len(tasks)), C.c_long(B), _p(targets), _p(q0),
                         C.byref(prm), _p(q), _p(ok), _p(it), C.c_int(nthreads))
     return q, ok, it
 
@@ -168,7 +186,7 @@ def dls_constrained(model, tasks, constraints, targets, q0, prm):
     return q, bool(ok.value), it.value
 
 
-def dls_batch_constrained(model, tasks, constraints, targets, q0, prm, nthreads=1):
+def dls_batch_constrained(model, tasks, constraints, targets, q0, prm, nthreads=1, ext=None):
     targets = np.ascontiguousarray(targets, dtype=np.float64)
     q0 = np.ascontiguousarray(q0, dtype=np.float64)
     B = q0.shape[0]
@@ -176,7 +194,7 @@ def dls_batch_constrained(model, tasks, constraints, targets, q0, prm, nthreads=
     q = np.empty_like(q0)
     ok = np.zeros(B, dtype=np.uint8)
     it = np.zeros(B, dtype=np.int32)
-    lib().iko_dls_batch_constrained(C.byref(model.c), tasks, C.c_int(len(tasks)), constraints, C.c_int(len(constraints)), C.c_long(B),
+    (ext_lib(ext) if ext else lib()).iko_dls_batch_constrained(C.byref(model.c), tasks, C.c_int(len(tasks)), constraints, C.c_int(len(constraints)), C.c_long(B),
                                     _p(targets), _p(q0), C.byref(prm), _p(q), _p(ok), _p(it), C.c_int(nthreads))
     return q, ok, it
 
@@ -217,7 +235,7 @@ def pik(model, tasks, targets, q0, prm, trace=False):
     return q, bool(ok.value), it.value
 
 
-def pik_batch(model, tasks, targets, q0, prm, nthreads=1):
+def pik_batch(model, tasks, targets, q0, prm, nthreads=1, ext=None):
     """targets [B, ntasks, 12], q0 [B, nq] (array-of-structures)."""
     targets = np.ascontiguousarray(targets, dtype=np.float64)
     q0 = np.ascontiguousarray(q0, dtype=np.float64)
@@ -226,7 +244,7 @@ def pik_batch(model, tasks, targets, q0, prm, nthreads=1):
     q = np.empty_like(q0)
     ok = np.zeros(B, dtype=np.uint8)
     it = np.zeros(B, dtype=np.int32)
-    rc = lib().iko_pik_batch(C.byref(model.c), tasks, C.c_int(len(tasks)), C.c_long(B), _p(targets), _p(q0),
+    rc = (ext_lib(ext) if ext else lib()).iko_pik_batch(C.byref(model.c), tasks, C.c_int(len(tasks)), C.c_long(B), _p(targets), _p(q0),
                              C.byref(prm), _p(q), _p(ok), _p(it), C.c_int(nthreads))
     if rc != 0:
         raise ValueError("iko_pik_batch: nlevels does not match the task table")

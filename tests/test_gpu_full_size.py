@@ -1,30 +1,37 @@
 """Full-size (B = 65536) lane-by-lane parity of BASELINE.json's configs 2/4 (Cassie leg), 3 (Cassie full body) and 5 (UR5 and UR10,
-stock limits and limits narrowed to +-2 rad so the joint-limit projection binds) against the CPU oracle, through the C ABI, at the
-metric's 50 fixed iterations.  Flags and iteration counts must be equal on every problem; |q_gpu - q_oracle| <= 1e-6 rad
-(BASELINE.json north_star) on every STABLE problem.
+stock limits and limits narrowed to +-2 rad so the joint-limit projection binds) and of a NON-fixture arm (arm7: general joint-origin
+rotations, oblique axes) against the CPU oracle, through the C ABI, at the metric's 50 fixed iterations -- for EVERY build of the chain
+kernel a problem can get: "hot" (structure-specialised, compiled into the library), "hot-rtc" (the same kernel compiled for the
+chain's structure code at run time) and "general" (IKGPU_CHAIN_HOT=0: what any chain ran on before round 3 and what runs when
+hipRTC is absent).  Flags and iteration counts must be equal on every problem.
 
-Stability rule (it replaces round 1's "converged on the CPU" split): a problem is unstable when the oracle's OWN answer moves by
-more than 1e-7 rad under a 1e-13 perturbation of its inputs -- q0 + 1e-13, target translations + 1e-13, and both with the
-opposite sign (the target perturbation matters: a first step that lands every joint on a limit erases a perturbation of q0,
-while the target enters every iteration).  A lane stalled on a joint limit or far from a reachable pose amplifies rounding
-differences, so neither side has an answer good to 1e-6 there; such lanes are counted and bounded separately.  Every other
-problem, converged or not, is held to the bar.  On chain problems a fourth probe joins the three: the optimised CPU variant
-(oracle/fast_cpu.cpp -- the same algorithm with a different order of arithmetic) against the faithful port; two CPU
-restatements that disagree with each other mark exactly the lanes where rounding decides.
+Parity rule (round 3; nothing of the system under test decides which lanes count):
+  1. sensitivity probes of the ORACLE ALONE: a problem is *excluded from the 1e-6 rad bar* when the oracle's own answer moves by more
+     than 1e-7 rad under a 1e-13 perturbation of its inputs (q0 +, target translations +, both -).  A lane stalled on a joint limit
+     or far from a reachable pose amplifies rounding differences, so neither side has an answer good to 1e-6 there.
+  2. every other problem, converged or not: |q_gpu - q_oracle| <= 1e-6 rad.
+  3. every excluded problem (and any problem that passes the probes and still misses the bar) is ARBITRATED by the same oracle in
+     _Float128 arithmetic (oracle/ik_oracle_ext.c, 113-bit significand): r = |q_gpu - q_ext| / max(|q_oracle - q_ext|, 1e-9).
+     r <= 10 -- the device is no farther from the (near-)exact trajectory than ten times the double oracle -- is required of every
+     such lane where the excluded set is a handful (Cassie leg: 5 lanes).  In the chaotic clamp workloads (thousands of excluded
+     lanes whose 50-step map amplifies one rounding error by > 1e9) r is the ratio of two independent draws from the same heavy-tailed
+     distribution, so the assertion is statistical: median r in [0.5, 2], at most 10 % of the arbitrated lanes with r > 10, and about
+     as many with r < 0.1 (the double oracle ten times farther than the device) -- neither side is systematically nearer.
+  The per-case counts (excluded by perturbation / arbitrated / failing the r <= 10 rule / mirror) are written to
+  gpurun_out/parity_counts.json (committed as profiles/r03_parity_counts.json).
 
-A perturbation test cannot prove stability (with the joint-limit projection live and targets far away the iteration is chaotic: a
-few lanes in 65536 pass every probe and still differ), so the END-TO-END assertion on the clamp workloads tolerates a 1e-4
-fraction of escapes and prints their number -- and the proof that those are chaos, not error, is the second test:
-`test_step_synchronised_along_the_oracle_trajectory` feeds the device the ORACLE's iterate at each of the 50 steps and
-demands the next iterate to 1e-9 rad on ALL 65536 lanes, no exclusions: every step of every problem agrees, only the
-composition of 50 steps amplifies.  The oracle runs on all host cores (a few seconds per case)."""
+The proof that the chaotic lanes are chaos and not error is `test_step_synchronised_along_the_oracle_trajectory`: the device is fed
+the ORACLE's iterate at each of the 50 steps and must return the next iterate to 1e-9 rad on ALL 65536 lanes, no exclusions; at
+every tenth step the one-step errors of device and double oracle against the _Float128 oracle are compared as distributions (the
+device's median / 99th percentile / maximum within 2x of the double oracle's + 1e-15).  The oracle runs on all host cores."""
+import json
 import os
 import re
 
 import numpy as np
 import pytest
 
-from conftest import urdf_path
+from conftest import ROOT, urdf_path
 
 pytestmark = pytest.mark.gpu
 
@@ -40,18 +47,63 @@ def torch_cuda(native_built):
     return torch
 
 
-def oracle_sensitivity(O, om, tasks, tg, q0, prm, cores, q_ref):
+COUNTS = {}
+
+
+def _record(label, counts):
+    COUNTS[label] = counts
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_counts.json"), "w") as fh:
+        json.dump(COUNTS, fh, indent=1, sort_keys=True)
+
+
+def oracle_sensitivity(O, solve, tg, q0, q_ref):
     """max |q - q_ref| of the oracle's own answers under three 1e-13 perturbations of the inputs."""
     sens = np.zeros(q0.shape[0])
     for dq, dt in ((1e-13, 0.0), (0.0, 1e-13), (-1e-13, -1e-13)):
         tgp = tg.copy()
         tgp[:, :, 9:] += dt
-        qp, _, _ = O.dls_batch(om, tasks, tgp, q0 + dq, prm, cores)
+        qp, _, _ = solve(tgp, q0 + dq, None)
         sens = np.maximum(sens, np.abs(qp - q_ref).max(axis=1))
     return sens
 
 
-def _compare(torch, model, problem, data, tasks, q0, targets_dev, max_unstable_frac, label, fast=None, escapes=0.0):
+def parity_counts(q_gpu, q_ref, sens, solve_ext, tg, q0):
+    """The round-3 parity rule on one batch: returns the counts dict (see the module docstring)."""
+    stable = sens <= 1e-7
+    d = np.abs(q_gpu - q_ref).max(axis=1)
+    beyond = stable & (d > TOL)
+    arb = np.flatnonzero(~stable | beyond)
+    c = {"problems": int(d.size), "stable": int(stable.sum()), "max_abs_dq_rad_stable_within_bar": float(d[stable & ~beyond].max()) if (stable & ~beyond).any() else 0.0,
+         "excluded_by_perturbation": int((~stable).sum()), "stable_beyond_bar": int(beyond.sum()), "arbitrated": int(arb.size),
+         "failing": 0, "mirror": 0, "median_ratio": None, "max_oracle_self_sensitivity_rad": float(sens.max())}
+    if arb.size:
+        q_ext, _, _ = solve_ext(tg[arb], q0[arb])
+        eg, eo = np.abs(q_gpu[arb] - q_ext).max(axis=1), np.abs(q_ref[arb] - q_ext).max(axis=1)
+        ratio, mirror = eg / np.maximum(eo, 1e-9), eo / np.maximum(eg, 1e-9)
+        c.update(failing=int((ratio > 10).sum()), mirror=int((mirror > 10).sum()), median_ratio=float(np.median(ratio)),
+                 max_ratio=float(ratio.max()), failing_lanes=[int(x) for x in arb[ratio > 10][:16]])
+    return c
+
+
+def assert_parity(c, label, max_excluded, statistical):
+    """max_excluded: lanes (>= 1) or fraction (< 1) the perturbation probes may exclude; statistical: the chaotic-regime form of rule 3."""
+    allowed = max_excluded if max_excluded >= 1 else max_excluded * c["problems"]
+    assert c["excluded_by_perturbation"] <= allowed, (label, c)
+    if not statistical:
+        assert c["stable_beyond_bar"] == 0 and c["failing"] == 0, (label, c)
+        return
+    assert c["stable_beyond_bar"] <= max(1, 1e-4 * c["problems"]), (label, c)   # (they are arbitrated with the excluded lanes)
+    if c["arbitrated"] >= 100:
+        assert 0.5 <= c["median_ratio"] <= 2.0, (label, c)
+        assert c["failing"] <= 0.10 * c["arbitrated"], (label, c)
+        assert c["failing"] <= 1.5 * c["mirror"] + 20, (label, c)
+    else:
+        assert c["failing"] == 0, (label, c)
+
+
+def _compare(torch, model, problem, data, tasks, q0, targets_dev, max_excluded, label, statistical=False):
     import ik_amd
     import oracle as O
     om = O.OracleModel(model.flat())
@@ -61,35 +113,35 @@ def _compare(torch, model, problem, data, tasks, q0, targets_dev, max_unstable_f
     tg = targets_dev.permute(2, 0, 1).contiguous().cpu().numpy()
     prm = O.params(ITERS, 1e-2, 1.0, -1.0)
     cores = os.cpu_count() or 1
-    q_ref, ok_ref, it_ref = O.dls_batch(om, tasks, tg, q0, prm, cores)
-    sens = oracle_sensitivity(O, om, tasks, tg, q0, prm, cores, q_ref)
-    if fast is not None:    # (urdf xml, frame id): the optimised CPU variant as a fourth probe
-        q_fast, _, _ = O.fast_dls_chain_batch(fast[0], fast[1], tg, q0, prm, cores)
-        sens = np.maximum(sens, np.abs(q_fast - q_ref).max(axis=1))
+
+    def solve(tg_, q0_, ext):
+        return O.dls_batch(om, tasks, tg_, q0_, prm, cores, ext=ext)
+    q_ref, ok_ref, it_ref = solve(tg, q0, None)
     assert np.array_equal(ok.cpu().numpy(), ok_ref) and np.array_equal(it.cpu().numpy(), it_ref), label
-    stable = sens <= 1e-7
-    d = np.abs(q_gpu - q_ref).max(axis=1)
-    print("%s: kernel %s, %d problems, %d stable (max |dq| %.3e), %d unstable (max |dq| %.3e, max self-sensitivity %.3e)"
-          % (label, data.kernel, d.size, stable.sum(), d[stable].max(), (~stable).sum(), d[~stable].max() if (~stable).any() else 0.0, sens.max()))
-    assert (~stable).mean() <= max_unstable_frac, (label, (~stable).mean())
-    bad = stable & (d > TOL)
-    print("%s: %d stable lanes beyond the bar (allowed: %d)" % (label, bad.sum(), int(escapes * d.size)))
-    assert bad.sum() <= int(escapes * d.size), (label, np.flatnonzero(bad)[:8], d[bad][:8])
+    sens = oracle_sensitivity(O, solve, tg, q0, q_ref)
+    c = parity_counts(q_gpu, q_ref, sens, lambda t_, q_: solve(t_, q_, "q"), tg, q0)
+    c["kernel"] = data.kernel
+    print("%s: %s" % (label, json.dumps(c)))
+    _record(label, c)
+    assert_parity(c, label, max_excluded, statistical)
     return q_gpu
 
 
 CHAIN_CASES = [
-    # name, frame, narrowed limits, target distribution, allowed unstable fraction, allowed escapes among the stable lanes
-    ("cassie_fixed", "LeftFootFront", None, "uniform", 0.01, 0.0),   # the bench workload of configs 2 / 4 (~6 % stall on a limit)
-    ("cassie_fixed", "LeftFootFront", None, "near", 0.0, 0.0),
-    ("ur5", "tool0", None, "near", 0.0, 0.0),                         # config 5, stock limits
-    ("ur10", "tool0", None, "near", 0.0, 0.0),
-    ("ur5", "tool0", 2.0, "uniform", 0.6, 1e-4),                      # config 5 with the projection live: far targets are chaotic
-    ("ur10", "tool0", 2.0, "uniform", 0.6, 1e-4),
+    # name, frame, narrowed limits, target distribution, lanes / fraction the probes may exclude, statistical form of rule 3
+    ("cassie_fixed", "LeftFootFront", None, "uniform", 32, False),    # the bench workload of configs 2 / 4 (~6 % stall on a limit)
+    ("cassie_fixed", "LeftFootFront", None, "near", 0, False),
+    ("ur5", "tool0", None, "near", 0, False),                          # config 5, stock limits
+    ("ur10", "tool0", None, "near", 0, False),
+    ("ur5", "tool0", 2.0, "uniform", 0.12, True),                      # config 5 with the projection live: far targets are chaotic
+    ("ur10", "tool0", 2.0, "uniform", 0.12, True),
+    ("arm7", "tool", None, "near", 0, False),                          # a non-fixture chain: no pre-built structure-specialised kernel
+    ("arm7", "tool", None, "uniform", 0.30, True),
 ]
+BUILDS = ["default", "general"]   # default: hot for the fixture robots, hot-rtc for arm7 (general when hipRTC is absent)
 
 
-def _chain_case(torch, name, frame, narrow, mode):
+def _chain_case(torch, name, frame, narrow, mode, build="default"):
     import ik_amd
     import oracle as O
     from ik_amd import workload
@@ -99,22 +151,37 @@ def _chain_case(torch, name, frame, narrow, mode):
     model = ik_amd.Model.from_urdf_xml(xml)
     problem = ik_amd.InverseKinematicsProblem(model)
     problem.add_frame_task("t", ik_amd.FrameTask.create(model, frame, ik_amd.KinematicType.Full))
-    data = ik_amd.dls_data(problem, device=0)
-    nominal = workload.UR5_NOMINAL if name.startswith("ur") else workload.cassie_nominal(model.names)
+    # the build is decided when the problem is created (ikgpu_problem_create) and is part of the kernel's name
+    prev = os.environ.get("IKGPU_CHAIN_HOT")
+    if build == "general":
+        os.environ["IKGPU_CHAIN_HOT"] = "0"
+    try:
+        data = ik_amd.dls_data(problem, device=0)
+    finally:
+        if build == "general":
+            if prev is None:
+                del os.environ["IKGPU_CHAIN_HOT"]
+            else:
+                os.environ["IKGPU_CHAIN_HOT"] = prev
+    want = ",general>" if build == "general" else (",hot-rtc>", ",general>") if name == "arm7" else ",hot>"
+    assert data.kernel.endswith(want), (data.kernel, build)
+    nominal = workload.UR5_NOMINAL if name.startswith("ur") else np.zeros(model.nq) if name == "arm7" else workload.cassie_nominal(model.names)
     q0, qs = workload.chain_workload(model.lowerPositionLimit, model.upperPositionLimit, nominal, np.arange(B), 0, mode)
     T = ik_amd.task_frames_fk_batch(problem, torch.from_numpy(np.ascontiguousarray(qs.T)).cuda(), data)
     tasks = O.make_tasks([(model.getFrameId(frame), 0, 2, 0, None)])
     return xml, model, problem, data, q0, T, tasks
 
 
+@pytest.mark.parametrize("build", BUILDS)
 @pytest.mark.parametrize("name,frame,narrow,mode", [c[:4] for c in CHAIN_CASES])
-def test_step_synchronised_along_the_oracle_trajectory(torch_cuda, name, frame, narrow, mode):
+def test_step_synchronised_along_the_oracle_trajectory(torch_cuda, name, frame, narrow, mode, build):
     """All 65536 lanes, all 50 steps, no exclusions: from the oracle's k-th iterate the device's next iterate equals the
-    oracle's to 1e-9 rad (one DLS step: evaluate, solve, integrate, project onto the limits -- reference ik/ik/dls.cpp:14-71)."""
+    oracle's to 1e-9 rad (one DLS step: evaluate, solve, integrate, project onto the limits -- reference ik/ik/dls.cpp:14-71).
+    Every tenth step, on the first 8192 lanes: the device's and the double oracle's one-step errors against the _Float128 oracle."""
     torch = torch_cuda
     import ik_amd
     import oracle as O
-    xml, model, problem, data, q0, T, tasks = _chain_case(torch, name, frame, narrow, mode)
+    xml, model, problem, data, q0, T, tasks = _chain_case(torch, name, frame, narrow, mode, build)
     om = O.OracleModel(model.flat())
     tg = T.permute(2, 0, 1).contiguous().cpu().numpy()
     one = O.params(1, 1e-2, 1.0, -1.0)
@@ -122,22 +189,33 @@ def test_step_synchronised_along_the_oracle_trajectory(torch_cuda, name, frame, 
     cores = os.cpu_count() or 1
     q, worst = q0, 0.0
     out = None
+    NX = 8192
+    worst_ratio = 0.0
     for k in range(ITERS):
         q_next, _, _ = O.dls_batch(om, tasks, tg, q, one, cores)
         out = ik_amd.dls_batch(problem, torch.from_numpy(np.ascontiguousarray(q.T)).cuda(), T, data, ik_amd.never_stop_visitor(), p1, out=out)
-        d = np.abs(out[0].cpu().numpy().T - q_next).max()
+        q_dev = out[0].cpu().numpy().T
+        d = np.abs(q_dev - q_next).max()
         worst = max(worst, d)
-        assert d <= 1e-9, (name, mode, narrow, k, d)
+        assert d <= 1e-9, (name, mode, narrow, build, k, d)
+        if k % 10 == 0:
+            q_x, _, _ = O.dls_batch(om, tasks, tg[:NX], q[:NX], one, cores, ext="q")
+            e_dev, e_orc = np.abs(q_dev[:NX] - q_x).max(axis=1), np.abs(q_next[:NX] - q_x).max(axis=1)
+            for pct in (50, 99, 100):
+                a, b = np.percentile(e_dev, pct), np.percentile(e_orc, pct)
+                worst_ratio = max(worst_ratio, a / (b + 1e-15))
+                assert a <= 2.0 * b + 1e-15, (name, mode, narrow, build, k, pct, a, b)
         q = q_next
-    print("%s %s narrow=%s: worst one-step |dq| over %d steps x %d lanes: %.3e rad" % (name, mode, narrow, ITERS, B, worst))
+    print("%s %s narrow=%s [%s]: worst one-step |dq| over %d steps x %d lanes: %.3e rad; one-step error vs _Float128, device / oracle, worst "
+          "percentile ratio %.2f" % (name, mode, narrow, data.kernel, ITERS, B, worst, worst_ratio))
 
 
-@pytest.mark.parametrize("name,frame,narrow,mode,max_unstable,escapes", CHAIN_CASES)
-def test_chain_configs_lane_by_lane(torch_cuda, name, frame, narrow, mode, max_unstable, escapes):
+@pytest.mark.parametrize("build", BUILDS)
+@pytest.mark.parametrize("name,frame,narrow,mode,max_excluded,statistical", CHAIN_CASES)
+def test_chain_configs_lane_by_lane(torch_cuda, name, frame, narrow, mode, max_excluded, statistical, build):
     torch = torch_cuda
-    xml, model, problem, data, q0, T, tasks = _chain_case(torch, name, frame, narrow, mode)
-    q = _compare(torch, model, problem, data, tasks, q0, T, max_unstable, "%s %s narrow=%s %s" % (name, frame, narrow, mode),
-                 fast=(xml, model.getFrameId(frame)), escapes=escapes)
+    xml, model, problem, data, q0, T, tasks = _chain_case(torch, name, frame, narrow, mode, build)
+    q = _compare(torch, model, problem, data, tasks, q0, T, max_excluded, "%s %s narrow=%s %s [%s]" % (name, frame, narrow, mode, build), statistical)
     lo, hi = model.lowerPositionLimit, model.upperPositionLimit
     assert (q >= lo - 1e-15).all() and (q <= hi + 1e-15).all()
     if narrow:
@@ -160,5 +238,5 @@ def test_full_body_lane_by_lane(torch_cuda):
                                          np.arange(B), seed=0, mode="near")
     T = ik_amd.task_frames_fk_batch(problem, torch.from_numpy(np.ascontiguousarray(qs.T)).cuda(), data)
     tasks = O.make_tasks([(model.getFrameId(f), 0, 2, 0, None) for f in frames])
-    q = _compare(torch, model, problem, data, tasks, q0, T, 0.0, "cassie full body near")
+    q = _compare(torch, model, problem, data, tasks, q0, T, 0, "cassie full body near")
     assert np.abs(np.linalg.norm(q[:, 3:7], axis=1) - 1.0).max() < 1e-9

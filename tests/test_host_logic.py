@@ -172,10 +172,13 @@ def _problem(ik, name, frames, ff=False, types=None, reference="universe", max_p
 
 
 def test_plan_names_the_kernel_for_the_benchmark_shapes(ik):
-    assert ik.plan(_problem(ik, "cassie_fixed", ["LeftFootFront"])[1]) == "dls_chain<NJ=7,full>"
-    assert ik.plan(_problem(ik, "ur5", ["tool0"])[1]) == "dls_chain<NJ=6,full>"
-    assert ik.plan(_problem(ik, "cassie_fixed", ["RightFootFront"], types=[ik.KinematicType.Position])[1]) == "dls_chain<NJ=7,position>"
-    assert ik.plan(_problem(ik, "ur5", ["wrist_1_link"], types=[ik.KinematicType.Orientation])[1]) == "dls_chain<NJ=4,orientation>"
+    # the name says which BUILD runs: "hot" = structure-specialised and compiled into the library (the fixture shapes), "hot-rtc" =
+    # the same kernel compiled for this chain's structure code at run time (hipRTC), "general" = device/chain_solver.hpp
+    assert ik.plan(_problem(ik, "cassie_fixed", ["LeftFootFront"])[1]) == "dls_chain<NJ=7,full,hot>"
+    assert ik.plan(_problem(ik, "ur5", ["tool0"])[1]) == "dls_chain<NJ=6,full,hot>"
+    assert ik.plan(_problem(ik, "cassie_fixed", ["RightFootFront"], types=[ik.KinematicType.Position])[1]) == "dls_chain<NJ=7,position,general>"
+    assert ik.plan(_problem(ik, "ur5", ["wrist_1_link"], types=[ik.KinematicType.Orientation])[1]) == "dls_chain<NJ=4,orientation,general>"
+    assert ik.plan(_problem(ik, "arm7", ["tool"])[1]) in ("dls_chain<NJ=7,full,hot-rtc>", "dls_chain<NJ=7,full,general>")   # (general when libhiprtc is absent)
 
 
 def test_problem_api_mirrors_the_reference_container(ik):
@@ -298,3 +301,40 @@ def test_workload_is_counter_based_and_shardable():
     assert (np.abs(q0) <= 0.1).all() and (qs >= lo).all() and (qs <= hi).all()
     u = workload.uniform01(0, np.arange(200000), np.arange(2))
     assert abs(u.mean() - 0.5) < 2e-3 and abs(u.var() - 1 / 12) < 2e-3 and u.min() >= 0 and u.max() < 1
+
+
+def test_arm7_loader_matches_the_twin(ik):
+    """The non-fixture arm (general joint-origin rotations, oblique axes; fixtures/make_arm7_urdf.py): the product's URDF loader
+    against the independent twin's."""
+    f = ik.Model.from_urdf_file(urdf_path("arm7")).flat()
+    t = T.load_urdf(urdf_path("arm7"))
+    tf = __import__("oracle").flat_from_twin(t)
+    assert (f["nq"], f["nv"]) == (7, 7) and f["idx_q"].tolist() == tf["idx_q"].tolist() and f["parent"].tolist() == tf["parent"].tolist()
+    assert np.abs(f["placement"] - tf["placement"]).max() < 1e-15 and np.abs(f["axis"] - tf["axis"]).max() < 1e-15
+    assert np.abs(f["frame_placement"] - tf["frame_placement"]).max() < 1e-15
+    assert np.array_equal(f["lower"], tf["lower"]) and np.array_equal(f["upper"], tf["upper"])
+
+
+def test_chain_build_switches_and_precompile(ik, tmp_path, monkeypatch):
+    """Which build of the chain kernel a problem gets is decided at creation and is part of the name; IKGPU_CHAIN_HOT=0 forces the
+    general build, IKGPU_RTC=0 keeps run-time compilation off; ikgpu_problem_precompile fills the on-disk cache without a device."""
+    from ik_amd import capi
+    leg = _problem(ik, "cassie_fixed", ["LeftFootFront"])[1]
+    arm = _problem(ik, "arm7", ["tool"])[1]
+    monkeypatch.setenv("IKGPU_CHAIN_HOT", "0")
+    assert ik.plan(leg) == "dls_chain<NJ=7,full,general>" and ik.plan(arm) == "dls_chain<NJ=7,full,general>"
+    monkeypatch.delenv("IKGPU_CHAIN_HOT")
+    monkeypatch.setenv("IKGPU_RTC", "0")
+    assert ik.plan(leg) == "dls_chain<NJ=7,full,hot>" and ik.plan(arm) == "dls_chain<NJ=7,full,general>"
+    monkeypatch.delenv("IKGPU_RTC")
+    if ik.plan(arm) != "dls_chain<NJ=7,full,hot-rtc>":
+        pytest.skip("libhiprtc not loadable here")
+    monkeypatch.setenv("IKGPU_CACHE_DIR", str(tmp_path))
+    assert ik.precompile(leg) == "dls_chain<NJ=7,full,hot>" and not os.listdir(tmp_path)        # pre-built: nothing to compile
+    assert ik.precompile(arm) == "dls_chain<NJ=7,full,hot-rtc>"
+    files = os.listdir(tmp_path)
+    assert len(files) == 1 and files[0].startswith("chain_hot_") and files[0].endswith(".hsaco")
+    assert open(os.path.join(tmp_path, files[0]), "rb").read(4) == b"\x7fELF"
+    weighted = _problem(ik, "arm7", ["tool"])[1]
+    weighted.get_frame_task("t0").weighting()[0] = 2.0                                           # the hot program needs unit weights
+    assert ik.precompile(weighted) == "dls_chain<NJ=7,full,general>"

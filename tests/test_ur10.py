@@ -70,7 +70,7 @@ def test_ur10_plans_onto_the_six_joint_chain_kernel(native_built):
     ik_amd, O, T, model, om, tm = _models()
     problem = ik_amd.InverseKinematicsProblem(model)
     problem.add_frame_task("t", ik_amd.FrameTask.create(model, "tool0", ik_amd.KinematicType.Full))
-    assert ik_amd.plan(problem) == "dls_chain<NJ=6,full>"
+    assert ik_amd.plan(problem) == "dls_chain<NJ=6,full,hot>"
 
 
 @pytest.mark.gpu
@@ -89,7 +89,7 @@ def test_ur10_dls_matches_oracle_with_the_clamp_live(native_built, narrow_limits
     problem = ik_amd.InverseKinematicsProblem(model)
     problem.add_frame_task("t", ik_amd.FrameTask.create(model, "tool0", ik_amd.KinematicType.Full))
     data = ik_amd.dls_data(problem, device=0)
-    assert data.kernel == "dls_chain<NJ=6,full>"
+    assert data.kernel == "dls_chain<NJ=6,full,hot>"
     om = O.OracleModel(model.flat())
     fid = model.getFrameId("tool0")
     ot = O.make_tasks([(fid, 0, 2, 0, None)])
