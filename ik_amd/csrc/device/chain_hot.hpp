@@ -323,8 +323,8 @@ IKD_FN void hot_pass_through(const ChainKernelArgs<NJ> &a, int64_t b, bool stepp
 #if IKD_HIP_LANG
 // The hot program under lane refill (chain_kernel_body.hpp chain_refill_loop): the stop-rule mode for batches larger than the machine.
 template <int NJ, class S, class Tab>
-__device__ __forceinline__ void hot_refill_body(const ChainKernelArgs<NJ> &a, const Tab &t, unsigned long long *queue) {
-    chain_refill_loop<NJ>(a, queue, [&](double (&q)[NJ], const double (&oMt)[12], bool have) {
+__device__ __forceinline__ void hot_refill_body(const ChainKernelArgs<NJ> &a, const Tab &t, unsigned long long *queue, int chunk) {
+    chain_refill_loop<NJ>(a, queue, chunk, [&](double (&q)[NJ], const double (&oMt)[12], bool have) {
         constexpr int M = 6;
         double e[M], col[NJ][M];
         hot_evaluate<NJ, S>(t, q, oMt, e, col);
@@ -427,10 +427,10 @@ __device__ __forceinline__ void hot_kernel_entry(const ChainKernelArgs<NJ> &a, c
 }
 
 template <int NJ, class S>
-__device__ __forceinline__ void hot_refill_entry(const ChainKernelArgs<NJ> &a, const HotTable &t, unsigned long long *queue) {
+__device__ __forceinline__ void hot_refill_entry(const ChainKernelArgs<NJ> &a, const HotTable &t, unsigned long long *queue, int chunk) {
     HotTable tv;
     hot_park_table<NJ, S>(t, tv);
-    hot_refill_body<NJ, S>(a, tv, queue);
+    hot_refill_body<NJ, S>(a, tv, queue, chunk);
 }
 #endif
 

@@ -92,11 +92,11 @@ IKD_FN void dls_chain_body(const ChainKernelArgs<NJ> &a, const Desc &d, int64_t 
 // loop's, so results are bit-identical whatever the batch composition.  Worth it when the batch is larger than the machine
 // (B > resident lanes); at B = resident lanes every problem has its own lane anyway and the launch lasts as long as its slowest problem.
 //
-// queue[0]: head -- problems handed out beyond the first (static) round, queue[1]: waves that have left; the last wave out
+// queue[0]: head -- problems handed out (in chunks) beyond the first (static) round, queue[1]: waves that have left; the last wave out
 // zeroes both, so the next launch on the same stream finds the slot clean (host: QueuePool in kernels.hpp).
 // iterate(q, oMt, have) runs ONE iteration of this lane's problem in place and returns "the visitor stopped it before the step".
 template <int NJ, class IterFn>
-__device__ __forceinline__ void chain_refill_loop(const ChainKernelArgs<NJ> &a, unsigned long long *queue, IterFn iterate) {
+__device__ __forceinline__ void chain_refill_loop(const ChainKernelArgs<NJ> &a, unsigned long long *queue, int chunk, IterFn iterate) {
     const int lane = static_cast<int>(threadIdx.x) & 63;                 // one wave per workgroup
     const int64_t first_round = static_cast<int64_t>(gridDim.x) * 64;
     int64_t b = static_cast<int64_t>(blockIdx.x) * 64 + lane;
@@ -108,6 +108,11 @@ __device__ __forceinline__ void chain_refill_loop(const ChainKernelArgs<NJ> &a, 
     load_target(a, bs, oMt);
     int it = 0;
     const int max_it = a.prm.max_iterations;                             // >= 1: the host sends max_iterations == 0 to the lock-step kernel
+    // The wave's own reserve [pool_lo, pool_hi) of unsolved problems (wave-uniform): finished lanes are served from it, and only when
+    // it runs dry does the wave pull `chunk` (>= 64) more from the launch's head.  One atomic per finished LANE-GROUP on one address
+    // saturated the memory-side atomic unit (measured: ~30-70 M same-address atomics/s device-wide, every refill waiting ~30 us).
+    int64_t pool_lo = 0, pool_hi = 0;
+    bool exhausted = first_round >= a.B;                                 // the head has passed the end of the batch
     while (__any(have)) {
         const bool stop_now = iterate(q, oMt, have) && have;
         ++it;
@@ -120,15 +125,28 @@ __device__ __forceinline__ void chain_refill_loop(const ChainKernelArgs<NJ> &a, 
                 a.iters[b] = stop_now ? it - 1 : max_it;                 // never null here: the pass-through kernel reads it
             }
             const unsigned long long mask = __ballot(done);
-            unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(queue, static_cast<unsigned long long>(__popcll(mask)));
-            const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(base)), hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(base >> 32));
-            base = (static_cast<unsigned long long>(hi) << 32) | lo;
+            const int need = __popcll(mask);
             const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+            const int64_t avail = pool_hi - pool_lo;
+            int64_t nb = pool_lo + rank;                                 // ranks below `avail` are served from the reserve
+            bool got = rank < avail;
+            if (avail < need && !exhausted) {                            // wave-uniform: pull the next chunk, serve the other ranks from it
+                unsigned long long v = 0;
+                if (lane == 0) v = atomicAdd(queue, static_cast<unsigned long long>(chunk));
+                const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v)), hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
+                const int64_t nlo = first_round + static_cast<int64_t>((static_cast<unsigned long long>(hi) << 32) | lo);
+                const int64_t nhi = nlo + chunk < a.B ? nlo + chunk : a.B;
+                exhausted = nlo + chunk >= a.B;
+                if (rank >= avail) { nb = nlo + (rank - avail); got = nb < nhi; }
+                pool_lo = nlo + (need - avail);
+                pool_hi = nhi > pool_lo ? nhi : pool_lo;
+            } else {
+                pool_lo += need < avail ? need : avail;
+            }
             if (done) {
-                b = first_round + static_cast<int64_t>(base) + rank;
-                have = b < a.B;
-                if (have) {
+                have = got;
+                if (got) {
+                    b = nb;
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) q[j] = a.q0[at(a.layout, a.B, a.nq, a.qidx[j], b)];
                     load_target(a, b, oMt);
@@ -150,9 +168,9 @@ __device__ __forceinline__ void chain_refill_loop(const ChainKernelArgs<NJ> &a, 
 
 // The general chain program under lane refill (device/chain_solver.hpp chain_dls, one iteration at a time).
 template <int NJ, int KT, int SMASK, class Desc>
-__device__ __forceinline__ void dls_chain_refill_body(const ChainKernelArgs<NJ> &a, const Desc &d_in, unsigned long long *queue) {
+__device__ __forceinline__ void dls_chain_refill_body(const ChainKernelArgs<NJ> &a, const Desc &d_in, unsigned long long *queue, int chunk) {
     const Desc *dp = &d_in;
-    chain_refill_loop<NJ>(a, queue, [&](double (&q)[NJ], const double (&oMt)[12], bool) {
+    chain_refill_loop<NJ>(a, queue, chunk, [&](double (&q)[NJ], const double (&oMt)[12], bool) {
         asm volatile("" ::: "memory");
         if constexpr (!std::is_same<Desc, ChainDesc<NJ>>::value) IKD_LAUNDER(dp);   // see chain_dls
         return chain_iteration<NJ, KT, SMASK>(*dp, a.prm, q, oMt, true);

@@ -62,9 +62,9 @@ __global__ __launch_bounds__(kBlock) void dls_chain_kernel(const ChainKernelArgs
 
 // The same lane program with lane refill (device/chain_kernel_body.hpp): persistent one-wave workgroups, stop-rule mode only.
 template <int NJ, int KT, int SMASK>
-__global__ __launch_bounds__(kBlock) void dls_chain_refill_kernel(const ChainKernelArgs<NJ> a, unsigned long long *queue) {
+__global__ __launch_bounds__(kBlock) void dls_chain_refill_kernel(const ChainKernelArgs<NJ> a, unsigned long long *queue, int chunk) {
     typedef const IKD_CONST_AS ChainDesc<NJ> ConstDesc;
-    ikdev::dls_chain_refill_body<NJ, KT, SMASK>(a, *(ConstDesc *)a.desc, queue);
+    ikdev::dls_chain_refill_body<NJ, KT, SMASK>(a, *(ConstDesc *)a.desc, queue, chunk);
 }
 
 struct PassThroughArgs {
@@ -171,7 +171,7 @@ hipError_t run_dls(const ProblemHost &ph, const DeviceTables &dt, const BatchIO 
         const int64_t rgrid = refill_grid(rk, io.B);                                                                            \
         if (refill_wanted(prm, io.B, rgrid)) return run_refill<NJ>(ph, dt, io, a, stream, [&](unsigned long long *queue, int32_t *it) { \
             a.iters = it;                                                                                                       \
-            hipLaunchKernelGGL((dls_chain_refill_kernel<NJ, KT, SM>), dim3(static_cast<unsigned>(rgrid)), dim3(kBlock), 0, stream, a, queue); \
+            hipLaunchKernelGGL((dls_chain_refill_kernel<NJ, KT, SM>), dim3(static_cast<unsigned>(rgrid)), dim3(kBlock), 0, stream, a, queue, refill_chunk(io.B, rgrid)); \
         });                                                                                                                     \
         hipLaunchKernelGGL((dls_chain_kernel<NJ, KT, SM>), grid_for(io.B), dim3(kBlock), 0, stream, a);                          \
         return hipGetLastError();                                                                                               \
@@ -229,14 +229,35 @@ bool refill_wanted(const ikgpu_dls_params &prm, int64_t B, int64_t resident_wave
     return B > resident_waves * kBlock;   // otherwise every problem has its own lane from the start: nothing to refill
 }
 
-int64_t refill_grid(const void *kernel, int64_t B) {
-    int64_t waves = (B + kBlock - 1) / kBlock;
-    int64_t resident = persistent_grid(kernel, kBlock, 0, waves);
+int64_t refill_resident(int64_t occupancy_waves, int64_t B) {
+    const int64_t waves = (B + kBlock - 1) / kBlock;
     if (const char *env = std::getenv("IKGPU_REFILL_WAVES_PER_CU")) {
         const long w = std::strtol(env, nullptr, 10);
-        if (w > 0) resident = std::min<int64_t>(waves, w * 256);
+        if (w > 0) return std::min<int64_t>(waves, w * 256);
     }
-    return resident;
+    // One wave per SIMD until every lane has >= 8 problems to go through: the launch ends with problems that run to max_iterations,
+    // and a wave that shares its SIMD takes twice as long over them (measured, B = 262144: 0.45 ms with 4 waves per CU, 0.58 with 8;
+    // B = 1048576: 0.99 against 0.84).
+    const int64_t want = std::max<int64_t>(1024, waves / 8);
+    return std::min<int64_t>(waves, std::min<int64_t>(want, occupancy_waves));
+}
+
+int64_t refill_grid(const void *kernel, int64_t B) {
+    const int64_t waves = (B + kBlock - 1) / kBlock;
+    return refill_resident(persistent_grid(kernel, kBlock, 0, INT64_MAX), B);
+}
+
+// Problems a wave pulls from the head at a time (a multiple of 64, >= 64): about a quarter of an even share of what is left after the
+// static first round, so that the head sees ~4 atomics per wave and the last chunks are small against a wave's whole share.
+int refill_chunk(int64_t B, int64_t grid) {
+    if (const char *env = std::getenv("IKGPU_REFILL_CHUNK")) {
+        const long c = std::strtol(env, nullptr, 10);
+        if (c >= 64) return static_cast<int>(c / 64 * 64);
+    }
+    const int64_t left = B - grid * kBlock;
+    int64_t c = left > 0 ? left / (grid * 4) : 0;
+    c = (c + 63) / 64 * 64;
+    return static_cast<int>(std::min<int64_t>(std::max<int64_t>(c, 64), 4096));
 }
 
 hipError_t launch_chain_pass_through(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const int32_t *iters, hipStream_t stream) {

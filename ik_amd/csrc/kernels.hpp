@@ -73,6 +73,8 @@ std::string chain_kernel_name(const ProblemHost &ph);
 // hipOccupancyMaxActiveBlocksPerMultiprocessor reports for the refill kernel x the device's CUs (IKGPU_REFILL_WAVES_PER_CU overrides).
 bool refill_wanted(const ikgpu_dls_params &prm, int64_t B, int64_t resident_waves);
 int64_t refill_grid(const void *kernel, int64_t B);
+int64_t refill_resident(int64_t occupancy_waves, int64_t B);   // persistent waves of a refill launch given what the device can hold
+int refill_chunk(int64_t B, int64_t grid);   // problems a wave reserves per pull from the head (IKGPU_REFILL_CHUNK overrides)
 // After a refill launch: the entries of q outside the chain (q0 clipped when iters > 0, else q0 -- reference ik/ik/dls.cpp:61-71),
 // one thread per problem; `iters` is the launch's own iteration-count array (never null).
 hipError_t launch_chain_pass_through(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const int32_t *iters, hipStream_t stream);

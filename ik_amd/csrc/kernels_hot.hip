@@ -33,8 +33,8 @@ __global__ __launch_bounds__(kBlock) void dls_chain_hot_kernel(const ChainKernel
 // Two waves per SIMD asked for (<= 256 registers): a wave that refills waits for its gathered loads (~2 us, most iterations have a
 // lane that finishes) and the other wave of the SIMD computes meanwhile.
 template <int NJ, uint64_t C0, uint64_t C1, uint64_t C2>
-__global__ __launch_bounds__(kBlock, 2) void dls_chain_hot_refill_kernel(const ChainKernelArgs<NJ> a, const HotTable t, unsigned long long *queue) {
-    ikdev::hot_refill_entry<NJ, ChainStruct<C0, C1, C2>>(a, t, queue);
+__global__ __launch_bounds__(kBlock, 2) void dls_chain_hot_refill_kernel(const ChainKernelArgs<NJ> a, const HotTable t, unsigned long long *queue, int chunk) {
+    ikdev::hot_refill_entry<NJ, ChainStruct<C0, C1, C2>>(a, t, queue, chunk);
 }
 
 // X(NJ, code0, code1, code2)
@@ -123,7 +123,7 @@ hipError_t launch_dls_chain_hot(const ProblemHost &ph, const DeviceTables &dt, c
             const void *rk = reinterpret_cast<const void *>(dls_chain_hot_refill_kernel<N, K0, K1, K2>);                   \
             const int64_t rgrid = refill_grid(rk, io.B);                                                                 \
             if (refill_wanted(prm, io.B, rgrid)) return hot_refill_launch<N>(ph, dt, io, a, stream, [&](unsigned long long *queue) { \
-                hipLaunchKernelGGL((dls_chain_hot_refill_kernel<N, K0, K1, K2>), dim3(static_cast<unsigned>(rgrid)), dim3(kBlock), 0, stream, a, t, queue); \
+                hipLaunchKernelGGL((dls_chain_hot_refill_kernel<N, K0, K1, K2>), dim3(static_cast<unsigned>(rgrid)), dim3(kBlock), 0, stream, a, t, queue, refill_chunk(io.B, rgrid)); \
             });                                                                                                          \
             hipLaunchKernelGGL((dls_chain_hot_kernel<N, K0, K1, K2, false>), grid, dim3(kBlock), 0, stream, a, t);          \
         }                                                                                                                \

@@ -107,8 +107,8 @@ std::string hot_source(int nj, const uint64_t code[3], int values) {
                   "    ikdev::hot_kernel_entry<%d, S, true>(a, t);\n}\n"
                   "extern \"C\" __global__ __launch_bounds__(64) void ikgpu_hot_stop(const ikdev::ChainKernelArgs<%d> a, const ikdev::HotTable t) {\n"
                   "    ikdev::hot_kernel_entry<%d, S, false>(a, t);\n}\n"
-                  "extern \"C\" __global__ %s void ikgpu_hot_refill(const ikdev::ChainKernelArgs<%d> a, const ikdev::HotTable t, unsigned long long *queue) {\n"
-                  "    ikdev::hot_refill_entry<%d, S>(a, t, queue);\n}\n",
+                  "extern \"C\" __global__ %s void ikgpu_hot_refill(const ikdev::ChainKernelArgs<%d> a, const ikdev::HotTable t, unsigned long long *queue, int chunk) {\n"
+                  "    ikdev::hot_refill_entry<%d, S>(a, t, queue, chunk);\n}\n",
                   static_cast<unsigned long long>(code[0]), static_cast<unsigned long long>(code[1]), static_cast<unsigned long long>(code[2]),
                   nj, nj, nj, nj, refill_bounds, nj, nj);
     return buf;
@@ -245,6 +245,7 @@ hipError_t launch_shape(const ProblemHost &ph, const DeviceTables &dt, const Bat
         ikdev::ChainKernelArgs<NJ> a;
         ikdev::HotTable t;
         unsigned long long *queue;
+        int chunk;
     } args{};
     static_assert(sizeof(ikdev::ChainKernelArgs<NJ>) % 8 == 0 && sizeof(ikdev::HotTable) % 8 == 0, "argument layout");
     ikdev::ChainKernelArgs<NJ> &a = args.a;
@@ -264,13 +265,14 @@ hipError_t launch_shape(const ProblemHost &ph, const DeviceTables &dt, const Bat
         void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &nbytes, HIP_LAUNCH_PARAM_END};
         return hipModuleLaunchKernel(fn, static_cast<unsigned>(grid), 1, 1, 64, 1, 1, 0, stream, nullptr, config);
     };
-    const size_t two = offsetof(Args, queue), three = sizeof(Args);
+    const size_t two = offsetof(Args, queue), three = offsetof(Args, chunk) + sizeof(int);
     if (prm.stop_sq_tol < 0.0) return launch(m.never, waves, two);
-    int64_t resident = std::min<int64_t>(waves, static_cast<int64_t>(m.refill_waves_per_cu) * 256);
-    if (const char *env = std::getenv("IKGPU_REFILL_WAVES_PER_CU")) {
-        const long w = std::strtol(env, nullptr, 10);
-        if (w > 0) resident = std::min<int64_t>(waves, w * 256);
+    int cus = 256;
+    {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
     }
+    const int64_t resident = refill_resident(static_cast<int64_t>(m.refill_waves_per_cu) * cus, io.B);
     if (!refill_wanted(prm, io.B, resident)) return launch(m.stop, waves, two);
     hipError_t e = hipSuccess;
     args.queue = dt.queues.slot_for(stream, &e);
@@ -280,6 +282,7 @@ hipError_t launch_shape(const ProblemHost &ph, const DeviceTables &dt, const Bat
         if ((e = hipMallocAsync(&tmp, sizeof(int32_t) * static_cast<size_t>(io.B), stream)) != hipSuccess) return e;
         a.iters = static_cast<int32_t *>(tmp);
     }
+    args.chunk = refill_chunk(io.B, resident);
     e = launch(m.refill, resident, three);
     if (e == hipSuccess) e = launch_chain_pass_through(ph, dt, io, a.iters, stream);
     if (tmp) {

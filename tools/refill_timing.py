@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Stop-rule mode of the chain kernels on batches larger than the machine: lock-step against lane refill, by batch size, resident
+waves per CU, target distribution (uniform: ~3 % of the problems never converge; near: all converge) and max_iterations.
+    python tools/refill_timing.py [model frame]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import ik_amd  # noqa: E402
+from ik_amd import workload  # noqa: E402
+
+name, frame = (sys.argv[1], sys.argv[2]) if len(sys.argv) > 2 else ("cassie_fixed", "LeftFootFront")
+model = ik_amd.Model.from_urdf_file(os.path.join(workload.MODELS_DIR, name + ".kin.urdf"))
+problem = ik_amd.InverseKinematicsProblem(model)
+problem.add_frame_task("t", ik_amd.FrameTask.create(model, frame, ik_amd.KinematicType.Full))
+nominal = workload.UR5_NOMINAL if name.startswith("ur") else np.zeros(model.nq) if name == "arm7" else workload.cassie_nominal(model.names)
+
+
+def timed(data, Q0, T, vis, prm, reps=3):
+    out = ik_amd.dls_batch(problem, Q0, T, data, vis, prm)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        out = ik_amd.dls_batch(problem, Q0, T, data, vis, prm, out=out)
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps, out
+
+
+for build in ("default", "general"):
+    if build == "general":
+        os.environ["IKGPU_CHAIN_HOT"] = "0"
+    data = ik_amd.dls_data(problem, device=0)
+    os.environ.pop("IKGPU_CHAIN_HOT", None)
+    print("==", data.kernel)
+    for mode in ("uniform", "near"):
+        for B in (65536, 262144, 1048576):
+            q0, qs = workload.chain_workload(model.lowerPositionLimit, model.upperPositionLimit, nominal, np.arange(B), 0, mode)
+            Q0 = torch.from_numpy(np.ascontiguousarray(q0.T)).cuda()
+            T = ik_amd.task_frames_fk_batch(problem, torch.from_numpy(np.ascontiguousarray(qs.T)).cuda(), data)
+            ms50, _ = timed(data, Q0, T, ik_amd.never_stop_visitor(), ik_amd.dls_parameters(max_iterations=50))
+            for max_it in (100, 20):
+                prm = ik_amd.dls_parameters(max_iterations=max_it)
+                vis = ik_amd.inverse_kinematics_visitor()
+                os.environ["IKGPU_REFILL"] = "0"
+                ms0, out0 = timed(data, Q0, T, vis, prm)
+                mean_it = float(out0[2].double().mean())
+                row = "%s B=%7d max_it=%3d mean_it %.2f | 50 fixed %.3f ms | lock-step %.3f ms" % (mode, B, max_it, mean_it, ms50, ms0)
+                os.environ["IKGPU_REFILL"] = "1"
+                for wpc in ("4", "8"):
+                    os.environ["IKGPU_REFILL_WAVES_PER_CU"] = wpc
+                    ms1, out1 = timed(data, Q0, T, vis, prm)
+                    same = all(torch.equal(x, y) for x, y in zip(out0, out1))
+                    row += " | refill %s w/CU %.3f ms%s" % (wpc, ms1, "" if same else " DIFFERENT")
+                os.environ.pop("IKGPU_REFILL_WAVES_PER_CU")
+                os.environ.pop("IKGPU_REFILL")
+                ideal = mean_it * B / 65536 * ms50 / 50
+                print(row + " | ideal (mean_it x B / lanes) %.3f ms" % ideal)
