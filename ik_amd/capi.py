@@ -29,6 +29,9 @@ SYMBOLS = [
     "ikgpu_pik_params_default", "ikgpu_pik_solve_batch", "ikgpu_pik_solve_batch_host", "ikgpu_pik_kernel",
     "ikgpu_problem_create_constrained", "ikgpu_problem_plan_constrained", "ikgpu_problem_support",
     "ikgpu_problem_precompile",
+    "ikgpu_shard_range", "ikgpu_shard_slot_layout", "ikgpu_shard_slot_bytes", "ikgpu_shard_group_create", "ikgpu_shard_group_destroy",
+    "ikgpu_shard_group_size", "ikgpu_shard_group_problem", "ikgpu_shard_group_uses_rccl", "ikgpu_shard_group_stream",
+    "ikgpu_dls_solve_batch_sharded", "ikgpu_shard_group_synchronize",
 ]
 MAX_PIK_LEVELS, MAX_PIK_DA = 8, 128
 
@@ -110,6 +113,25 @@ def lib():
     L.ikgpu_problem_create_constrained.argtypes = [vp, C.POINTER(Task), i32, C.POINTER(Task), i32, i32, C.POINTER(vp)]
     L.ikgpu_problem_plan_constrained.argtypes = [vp, C.POINTER(Task), i32, C.POINTER(Task), i32, C.c_char_p, sz]
     L.ikgpu_problem_precompile.argtypes = [vp, C.POINTER(Task), i32, C.POINTER(Task), i32, C.c_char_p, sz]
+    L.ikgpu_shard_range.argtypes = [i64, i32, i32, C.POINTER(i64), C.POINTER(i64)]
+    L.ikgpu_shard_range.restype = None
+    L.ikgpu_shard_slot_layout.argtypes = [i32, i64, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
+    L.ikgpu_shard_slot_layout.restype = sz
+    L.ikgpu_shard_slot_bytes.argtypes = [i32, i64, i32]
+    L.ikgpu_shard_slot_bytes.restype = sz
+    L.ikgpu_shard_group_create.argtypes = [vp, C.POINTER(Task), i32, C.POINTER(Task), i32, C.POINTER(i32), i32, C.POINTER(vp)]
+    L.ikgpu_shard_group_destroy.argtypes = [vp]
+    L.ikgpu_shard_group_destroy.restype = None
+    L.ikgpu_shard_group_size.argtypes = [vp]
+    L.ikgpu_shard_group_size.restype = i32
+    L.ikgpu_shard_group_problem.argtypes = [vp, i32]
+    L.ikgpu_shard_group_problem.restype = vp
+    L.ikgpu_shard_group_uses_rccl.argtypes = [vp]
+    L.ikgpu_shard_group_uses_rccl.restype = i32
+    L.ikgpu_shard_group_stream.argtypes = [vp, i32]
+    L.ikgpu_shard_group_stream.restype = vp
+    L.ikgpu_dls_solve_batch_sharded.argtypes = [vp, i64, C.POINTER(vp), C.POINTER(vp), C.POINTER(DlsParams), C.POINTER(vp)]
+    L.ikgpu_shard_group_synchronize.argtypes = [vp]
     L.ikgpu_dls_solve_batch.argtypes = [vp, i64, vp, vp, C.POINTER(DlsParams), vp, vp, vp, C.c_int, vp]
     L.ikgpu_dls_solve_batch_host.argtypes = [vp, i64, vp, vp, C.POINTER(DlsParams), vp, vp, vp, C.c_int]
     L.ikgpu_pik_params_default.argtypes = [C.POINTER(PikParams), i32]

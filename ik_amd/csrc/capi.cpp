@@ -10,6 +10,7 @@
 #include <new>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "ikgpu.h"
 #include "kernels.hpp"
@@ -25,8 +26,22 @@ struct Staging {
 };
 constexpr size_t kStageLimit = size_t(1) << 20;  // batches whose buffers total at most 1 MiB take the staged path
 
+// Larger batches through the host-pointer entry points: a pipeline the problem keeps -- one device arena (grow-only), three
+// streams, events -- so that a call allocates nothing and never synchronises the device: chunks of problems flow
+// H2D (chunk k + 1)  ||  solve (chunk k)  ||  D2H (chunk k - 1).
+struct HostPipe {
+    std::mutex mu;
+    void *dev = nullptr;
+    size_t cap = 0;
+    static constexpr int kRunStreams = 8;
+    hipStream_t in = nullptr, out = nullptr;
+    hipStream_t run[kRunStreams] = {};   // chunk k solves on run[k % 8]
+    std::vector<hipEvent_t> ev_in, ev_run;
+};
+
 struct ikgpu_problem {
     mutable Staging stage;
+    mutable HostPipe pipe;
     ikgpu::ProblemHost host;
     ikgpu::ProblemHost gen;  // the same problem analysed for the generic lane program (what ik::pik runs on)
     ikgpu::DeviceTables dev;
@@ -65,6 +80,13 @@ int fail(int code, const std::string &msg) {
     g_last_error = msg;
     return code;
 }
+
+}  // namespace
+
+// (shard.cpp reports through the same thread-local message)
+int ikgpu_set_last_error(int code, const std::string &msg) { return fail(code, msg); }
+
+namespace {
 
 int hip_fail(hipError_t e, const char *what) {
     return fail(IKGPU_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
@@ -148,7 +170,7 @@ bool pik_is_two_levels_on_the_tree(const ikgpu_problem *p, const ikgpu_pik_param
 // Host-pointer form of a batched solve: copy in, run `launch` on device buffers, synchronise, copy out.
 template <class Launch>
 int host_solve(const ikgpu_problem *p, int64_t B, const double *q0, const double *targets, double *q_out, uint8_t *success,
-               int32_t *iters, Launch &&launch) {
+               int32_t *iters, int layout, Launch &&launch) {
     return guarded([&] {
         DeviceGuard g(p->device);
         if (!g.ok) return fail(IKGPU_ERR_DEVICE, "hipSetDevice failed");
@@ -177,8 +199,8 @@ int host_solve(const ikgpu_problem *p, int64_t B, const double *q0, const double
                     std::memcpy(h + off_t, targets, nb_t);
                     hipError_t e = hipMemcpy(d, h, off_q, hipMemcpyHostToDevice);
                     if (e != hipSuccess) return hip_fail(e, "host-pointer solve (staged copy in)");
-                    const int rc = launch(reinterpret_cast<double *>(d), reinterpret_cast<double *>(d + off_t), reinterpret_cast<double *>(d + off_q),
-                                          reinterpret_cast<uint8_t *>(d + off_s), reinterpret_cast<int32_t *>(d + off_i));
+                    const int rc = launch(B, reinterpret_cast<double *>(d), reinterpret_cast<double *>(d + off_t), reinterpret_cast<double *>(d + off_q),
+                                          reinterpret_cast<uint8_t *>(d + off_s), reinterpret_cast<int32_t *>(d + off_i), nullptr);
                     if (rc != IKGPU_OK) return rc;
                     e = hipMemcpy(h + off_q, d + off_q, total - off_q, hipMemcpyDeviceToHost);   // waits for the launch on the null stream
                     if (e != hipSuccess) return hip_fail(e, "host-pointer solve (staged copy out)");
@@ -189,31 +211,82 @@ int host_solve(const ikgpu_problem *p, int64_t B, const double *q0, const double
                 }
             }
         }
-        double *d_q0 = nullptr, *d_t = nullptr, *d_q = nullptr;
-        uint8_t *d_s = nullptr;
-        int32_t *d_i = nullptr;
+        // The pipelined path.  Chunk k lives compactly on the device ([rows][b_k], component-major, or [b_k][rows]); for the
+        // component-major layout one 2-D copy per array gathers / scatters the chunk's columns of the caller's [rows][B] arrays.
+        // Pinned caller buffers make every copy asynchronous; pageable ones still work (the runtime stages them).
+        std::lock_guard<std::mutex> plock(p->pipe.mu);
+        HostPipe &pp = p->pipe;
+        // Chunks that fill the device: one problem per lane means a launch lasts as long as ONE wave whatever its size, and kernels of
+        // different streams were measured NOT to overlap here (B = 65536 in 8 chunks on 8 streams: 0.93 ms; 2 chunks: 0.55 ms; 1 chunk,
+        // i.e. no overlap at all: 0.61 ms; tools/host_entry_timing.py) -- so two halves up to 131072 problems, 65536 per chunk above
+        // (B = 262144: 1.49 ms against 2.21 unpipelined).
+        int64_t chunk = B <= 131072 ? ((B + 1) / 2 + 63) / 64 * 64 : 65536;
+        if (const char *env = std::getenv("IKGPU_HOST_CHUNK")) { const long c = std::strtol(env, nullptr, 10); if (c >= 64) chunk = c; }
+        const int64_t nchunks = (B + chunk - 1) / chunk;
+        const size_t nq = static_cast<size_t>(p->host.nq), nt = static_cast<size_t>(12 * p->host.ntasks);
+        const size_t per_problem = 8 * nq + 8 * nt + 8 * nq + 4 + 1;
+        const size_t need = per_problem * static_cast<size_t>(B) + 64 * static_cast<size_t>(nchunks) * 5;   // (every array 64-byte aligned)
         hipError_t e = hipSuccess;
         auto step = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-        step(hipMalloc(reinterpret_cast<void **>(&d_q0), nb_q));
-        step(hipMalloc(reinterpret_cast<void **>(&d_t), nb_t));
-        step(hipMalloc(reinterpret_cast<void **>(&d_q), nb_q));
-        step(hipMalloc(reinterpret_cast<void **>(&d_s), B));
-        step(hipMalloc(reinterpret_cast<void **>(&d_i), sizeof(int32_t) * B));
-        if (e == hipSuccess) step(hipMemcpy(d_q0, q0, nb_q, hipMemcpyHostToDevice));
-        if (e == hipSuccess) step(hipMemcpy(d_t, targets, nb_t, hipMemcpyHostToDevice));
-        int rc = IKGPU_OK;
-        if (e == hipSuccess) {
-            rc = launch(d_q0, d_t, d_q, d_s, d_i);
-            if (rc == IKGPU_OK) {
-                step(hipDeviceSynchronize());
-                step(hipMemcpy(q_out, d_q, nb_q, hipMemcpyDeviceToHost));
-                if (success) step(hipMemcpy(success, d_s, B, hipMemcpyDeviceToHost));
-                if (iters) step(hipMemcpy(iters, d_i, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
-            }
+        if (!pp.in) {
+            step(hipStreamCreateWithFlags(&pp.in, hipStreamNonBlocking));
+            step(hipStreamCreateWithFlags(&pp.out, hipStreamNonBlocking));
+            for (hipStream_t &r : pp.run) step(hipStreamCreateWithFlags(&r, hipStreamNonBlocking));
         }
-        (void)hipFree(d_q0); (void)hipFree(d_t); (void)hipFree(d_q); (void)hipFree(d_s); (void)hipFree(d_i);
+        if (e == hipSuccess && pp.cap < need) {
+            if (pp.dev) { (void)hipFree(pp.dev); pp.dev = nullptr; pp.cap = 0; }   // (every call leaves its streams idle)
+            step(hipMalloc(&pp.dev, need));
+            if (e == hipSuccess) pp.cap = need;
+        }
+        while (e == hipSuccess && static_cast<int64_t>(pp.ev_in.size()) < nchunks) {
+            hipEvent_t a = nullptr, b = nullptr;
+            step(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+            step(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+            if (e == hipSuccess) { pp.ev_in.push_back(a); pp.ev_run.push_back(b); }
+        }
+        if (e != hipSuccess) return hip_fail(e, "host-pointer solve (pipeline set-up)");
+        char *cur = static_cast<char *>(pp.dev);
+        auto take = [&](size_t bytes) { char *r = cur; cur += (bytes + 63) / 64 * 64; return r; };
+        const bool soa = layout == IKGPU_SOA;
+        // rows x [b0, b0 + bk) of a host array with B columns  <->  a compact rows x bk device array (SoA), or bk x rows contiguous (AoS)
+        auto copy = [&](void *dev, const void *host_c, void *host, size_t rows, size_t elem, int64_t b0, int64_t bk, bool to_device, hipStream_t st) {
+            if (soa && rows > 1) {
+                const size_t w = static_cast<size_t>(bk) * elem, hp = static_cast<size_t>(B) * elem;
+                return to_device ? hipMemcpy2DAsync(dev, w, static_cast<const char *>(host_c) + static_cast<size_t>(b0) * elem, hp, w, rows, hipMemcpyHostToDevice, st)
+                                 : hipMemcpy2DAsync(static_cast<char *>(host) + static_cast<size_t>(b0) * elem, hp, dev, w, w, rows, hipMemcpyDeviceToHost, st);
+            }
+            const size_t off = static_cast<size_t>(b0) * rows * elem, bytes = static_cast<size_t>(bk) * rows * elem;
+            return to_device ? hipMemcpyAsync(dev, static_cast<const char *>(host_c) + off, bytes, hipMemcpyHostToDevice, st)
+                             : hipMemcpyAsync(static_cast<char *>(host) + off, dev, bytes, hipMemcpyDeviceToHost, st);
+        };
+        int rc = IKGPU_OK;
+        for (int64_t k = 0; k < nchunks && rc == IKGPU_OK && e == hipSuccess; ++k) {
+            const int64_t b0 = k * chunk, bk = std::min<int64_t>(chunk, B - b0);
+            double *d_q0 = reinterpret_cast<double *>(take(8 * nq * bk)), *d_t = reinterpret_cast<double *>(take(8 * nt * bk));
+            double *d_q = reinterpret_cast<double *>(take(8 * nq * bk));
+            int32_t *d_i = reinterpret_cast<int32_t *>(take(4 * bk));
+            uint8_t *d_s = reinterpret_cast<uint8_t *>(take(bk));
+            step(copy(d_q0, q0, nullptr, nq, 8, b0, bk, true, pp.in));
+            step(copy(d_t, targets, nullptr, nt, 8, b0, bk, true, pp.in));
+            step(hipEventRecord(pp.ev_in[k], pp.in));
+            const hipStream_t run = pp.run[k % HostPipe::kRunStreams];
+            step(hipStreamWaitEvent(run, pp.ev_in[k], 0));
+            if (e != hipSuccess) break;
+            rc = launch(bk, d_q0, d_t, d_q, d_s, d_i, run);
+            if (rc != IKGPU_OK) break;
+            step(hipEventRecord(pp.ev_run[k], run));
+            step(hipStreamWaitEvent(pp.out, pp.ev_run[k], 0));
+            step(copy(d_q, nullptr, q_out, nq, 8, b0, bk, false, pp.out));
+            if (iters) step(copy(d_i, nullptr, iters, 1, 4, b0, bk, false, pp.out));
+            if (success) step(copy(d_s, nullptr, success, 1, 1, b0, bk, false, pp.out));
+        }
+        // the arena is reused by the next call: everything in flight has to land first (also on a failure half way through)
+        hipError_t w = hipStreamSynchronize(pp.in);
+        for (hipStream_t r : pp.run) { const hipError_t x = hipStreamSynchronize(r); if (w == hipSuccess) w = x; }
+        { const hipError_t x = hipStreamSynchronize(pp.out); if (w == hipSuccess) w = x; }
         if (rc != IKGPU_OK) return rc;
-        if (e != hipSuccess) return hip_fail(e, "host-pointer solve");
+        step(w);
+        if (e != hipSuccess) return hip_fail(e, "host-pointer solve (pipeline)");
         return static_cast<int>(IKGPU_OK);
     });
 }
@@ -413,6 +486,11 @@ void ikgpu_problem_destroy(ikgpu_problem *p) {
     (void)hipFree(p->dev.g_ints);
     (void)hipFree(p->dev.g_dbls);
     p->dev.queues.release();
+    if (p->pipe.dev) (void)hipFree(p->pipe.dev);
+    for (hipEvent_t ev : p->pipe.ev_in) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : p->pipe.ev_run) (void)hipEventDestroy(ev);
+    if (p->pipe.in) { (void)hipStreamDestroy(p->pipe.in); (void)hipStreamDestroy(p->pipe.out); }
+    for (hipStream_t r : p->pipe.run) if (r) (void)hipStreamDestroy(r);
     if (p->stage.dev) (void)hipFree(p->stage.dev);
     if (p->stage.host) (void)hipHostFree(p->stage.host);
     delete p;
@@ -459,8 +537,9 @@ int ikgpu_dls_solve_batch_host(const ikgpu_problem *p, int64_t B, const double *
     if (int rc = check_params(params)) return rc;
     if (B == 0) return IKGPU_OK;  // an empty batch is a no-op (its pointers may be null)
     if (!q0 || !targets || !q_out) return fail(IKGPU_ERR_INVALID, "null argument");
-    return host_solve(p, B, q0, targets, q_out, success, iters, [&](const double *d_q0, const double *d_t, double *d_q, uint8_t *d_s, int32_t *d_i) {
-        return ikgpu_dls_solve_batch(p, B, d_q0, d_t, params, d_q, d_s, d_i, layout, nullptr);
+    if (layout != IKGPU_SOA && layout != IKGPU_AOS) return fail(IKGPU_ERR_INVALID, "unknown layout");
+    return host_solve(p, B, q0, targets, q_out, success, iters, layout, [&](int64_t Bk, const double *d_q0, const double *d_t, double *d_q, uint8_t *d_s, int32_t *d_i, hipStream_t st) {
+        return ikgpu_dls_solve_batch(p, Bk, d_q0, d_t, params, d_q, d_s, d_i, layout, st);
     });
 }
 
@@ -523,8 +602,9 @@ int ikgpu_pik_solve_batch_host(const ikgpu_problem *p, int64_t B, const double *
     if (int rc = check_pik_params(p, params)) return rc;
     if (B == 0) return IKGPU_OK;
     if (!q0 || !targets || !q_out) return fail(IKGPU_ERR_INVALID, "null argument");
-    return host_solve(p, B, q0, targets, q_out, success, iters, [&](const double *d_q0, const double *d_t, double *d_q, uint8_t *d_s, int32_t *d_i) {
-        return ikgpu_pik_solve_batch(p, B, d_q0, d_t, params, d_q, d_s, d_i, layout, nullptr);
+    if (layout != IKGPU_SOA && layout != IKGPU_AOS) return fail(IKGPU_ERR_INVALID, "unknown layout");
+    return host_solve(p, B, q0, targets, q_out, success, iters, layout, [&](int64_t Bk, const double *d_q0, const double *d_t, double *d_q, uint8_t *d_s, int32_t *d_i, hipStream_t st) {
+        return ikgpu_pik_solve_batch(p, Bk, d_q0, d_t, params, d_q, d_s, d_i, layout, st);
     });
 }
 

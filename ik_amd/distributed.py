@@ -19,15 +19,20 @@ layout is [world][slot]: each rank's component-major block stays contiguous and 
 * xGMI is a point-to-point mesh (7 links per GPU): the all-gather of step k is issued asynchronously and overlaps
   the solve of step k + 1 (two buffer sets alternate), so a step costs max(compute, exchange) instead of their sum.
 """
+import ctypes as C
+
 import torch
 import torch.distributed as dist
 
+from . import capi
+
 
 def shard_range(total, rank, world):
-    """Contiguous block [lo, hi) of problem indices owned by `rank` (sizes differ by at most one)."""
-    base, rem = divmod(int(total), int(world))
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
+    """Contiguous block [lo, hi) of problem indices owned by `rank` (sizes differ by at most one): ikgpu_shard_range, the rule the
+    C ABI's one-process form (ikgpu_dls_solve_batch_sharded) splits by."""
+    lo, hi = C.c_int64(), C.c_int64()
+    capi.lib().ikgpu_shard_range(int(total), int(rank), int(world), C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
 
 
 def shard_size(total, rank, world):
@@ -36,9 +41,10 @@ def shard_size(total, rank, world):
 
 
 def _layout(rows, b):
-    """Byte offsets of (q rows, iterations, success) in a slot holding b problems, and the bytes used."""
-    q_bytes, it_bytes = rows * b * 8, b * 4
-    return (0, q_bytes, q_bytes + it_bytes), q_bytes + it_bytes + b
+    """Byte offsets of (q rows, iterations, success) in a slot holding b problems, and the bytes used (ikgpu_shard_slot_layout)."""
+    oq, oi, os_ = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    used = capi.lib().ikgpu_shard_slot_layout(int(rows), int(b), C.byref(oq), C.byref(oi), C.byref(os_))
+    return (oq.value, oi.value, os_.value), used
 
 
 class ShardBuffers:
@@ -53,7 +59,7 @@ class ShardBuffers:
         self.b_max = shard_size(self.total, 0, self.world)          # rank 0 always holds a largest shard
         self.rows = None if rows is None else torch.as_tensor(rows, dtype=torch.int64, device=device)
         self.R = self.nq if rows is None else int(self.rows.numel())
-        self.nbytes = (_layout(self.R, self.b_max)[1] + 15) // 16 * 16   # slot size: the largest shard, 16-byte aligned
+        self.nbytes = capi.lib().ikgpu_shard_slot_bytes(self.R, self.total, self.world)   # slot size: the largest shard, 16-byte aligned
         self.local = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
         self.all = torch.zeros((self.world, self.nbytes), dtype=torch.uint8, device=device)
         self.Qs, self.it, self.ok = self._views(self.local, self.b)
@@ -104,3 +110,59 @@ def expand_rows(Q_rows, rows, q0, lower, upper, iterations):
     Q = torch.where((iterations > 0)[None, :], clipped, q0)
     Q[rows] = Q_rows
     return Q
+
+
+class ShardGroup:
+    """ikgpu_shard_group: ONE process driving several GPUs through the C ABI (ikgpu_dls_solve_batch_sharded) -- per-device problem
+    handles and streams, one RCCL communicator per device, one ncclAllGather of the packed slots per step.  The C++ caller's form
+    of what ShardBuffers + torch.distributed do with one process per GPU; same shard rule, same slot layout."""
+
+    def __init__(self, problem, devices):
+        from . import api
+        arr = api._task_table(problem)
+        cons, ncons = api._constraint_table(problem)
+        self.devices = [int(d) for d in devices]
+        dev = (C.c_int32 * len(self.devices))(*self.devices)
+        self._h = C.c_void_p()
+        capi.check(capi.lib().ikgpu_shard_group_create(problem.model()._h, arr, len(arr), cons, ncons, dev, len(self.devices), C.byref(self._h)))
+        self.nq = problem.model().nq
+        self.uses_rccl = bool(capi.lib().ikgpu_shard_group_uses_rccl(self._h))
+
+    def close(self):
+        if self._h:
+            capi.lib().ikgpu_shard_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def slot_bytes(self, total):
+        return capi.lib().ikgpu_shard_slot_bytes(self.nq, int(total), len(self.devices))
+
+    def solve(self, total, Q0, targets, visitor, p):
+        """Q0[r] [nq, b_r], targets[r] [ntasks, 12, b_r]: float64 CUDA tensors on device r (complete: synchronise their producers
+        first).  Returns per-device uint8 tensors [ndev, slot_bytes] holding every rank's slot; synchronises the group."""
+        from . import api
+        n = len(self.devices)
+        prm = api._params(visitor, p)
+        out = [torch.zeros((n, self.slot_bytes(total)), dtype=torch.uint8, device="cuda:%d" % d) for d in self.devices]
+        q = (C.c_void_p * n)(*[t.data_ptr() for t in Q0])
+        tg = (C.c_void_p * n)(*[t.data_ptr() for t in targets])
+        g = (C.c_void_p * n)(*[t.data_ptr() for t in out])
+        capi.check(capi.lib().ikgpu_dls_solve_batch_sharded(self._h, int(total), q, tg, C.byref(prm), g))
+        capi.check(capi.lib().ikgpu_shard_group_synchronize(self._h))
+        return out
+
+    def decode(self, gathered, total):
+        """gathered [ndev, slot_bytes] (one device's copy) -> lists of (Q [nq, b_r], success [b_r], iterations [b_r]) per rank."""
+        n = len(self.devices)
+        res = []
+        for r in range(n):
+            b = shard_size(total, r, n)
+            (oq, oi, os_), _ = _layout(self.nq, b)
+            flat = gathered[r]
+            res.append((flat[oq:oi].view(torch.float64).view(self.nq, b), flat[os_:os_ + b], flat[oi:os_].view(torch.int32)))
+        return res

@@ -193,6 +193,35 @@ int ikgpu_dls_solve_batch_host(const ikgpu_problem *p, int64_t B, const double *
                                const ikgpu_dls_params *params, double *q_out, uint8_t *success, int32_t *iters,
                                int layout);
 
+/* ---- the hot path on several GPUs of one node, from ONE process (the reference's caller is a single C++ process,
+ * ik_ros/src/cassie.cpp:95-112; it has no multi-device code of its own).  Problems are independent and the model + task table are
+ * replicated, so a batch of `total` problems is split into contiguous shards -- rank r of n owns [lo, hi) as ikgpu_shard_range
+ * gives it (sizes differ by at most one) -- each device solves its shard with ikgpu_dls_solve_batch into a packed slot
+ *     [ q rows: nq x b float64 | iterations: b int32 | success: b uint8 ]        (ikgpu_shard_slot_layout, b = the shard's size)
+ * and ONE RCCL all-gather over xGMI leaves every device with every rank's slot: [n][slot_bytes], slot_bytes = the largest
+ * shard's layout rounded up to 16 (ikgpu_shard_slot_bytes); slot r is decoded with rank r's own shard size.  The Python
+ * one-process-per-GPU path (ik_amd/distributed.py, torch.distributed) uses the same two layout functions. */
+void ikgpu_shard_range(int64_t total, int32_t rank, int32_t nranks, int64_t *lo, int64_t *hi);
+size_t ikgpu_shard_slot_layout(int32_t rows, int64_t b, size_t *off_q, size_t *off_iters, size_t *off_success); /* returns bytes used */
+size_t ikgpu_shard_slot_bytes(int32_t rows, int64_t total, int32_t nranks);
+typedef struct ikgpu_shard_group ikgpu_shard_group; /* one problem handle, one stream and one RCCL communicator per device */
+/* devices: ndev distinct HIP device ordinals.  Creates the per-device problem handles (as ikgpu_problem_create_constrained) and
+ * the communicators (ncclCommInitAll; librccl is opened at run time -- a group of one device works without it). */
+int ikgpu_shard_group_create(const ikgpu_model *m, const ikgpu_task *tasks, int32_t ntasks, const ikgpu_task *constraints,
+                             int32_t nconstraints, const int32_t *devices, int32_t ndev, ikgpu_shard_group **out);
+void ikgpu_shard_group_destroy(ikgpu_shard_group *g);
+int32_t ikgpu_shard_group_size(const ikgpu_shard_group *g);
+const ikgpu_problem *ikgpu_shard_group_problem(const ikgpu_shard_group *g, int32_t rank);
+int32_t ikgpu_shard_group_uses_rccl(const ikgpu_shard_group *g);
+void *ikgpu_shard_group_stream(const ikgpu_shard_group *g, int32_t rank); /* the hipStream_t rank's work is enqueued on */
+/* One step.  q0[r], targets[r]: DEVICE pointers on device r to rank r's shard, component-major ([nq x b_r], [ntasks x 12 x b_r]);
+ * gathered[r]: DEVICE pointer on device r to ndev * ikgpu_shard_slot_bytes(nq, total, ndev) bytes.  Asynchronous: the solve and
+ * the collective are enqueued on each rank's own stream (inputs must be complete before the call);
+ * ikgpu_shard_group_synchronize waits for all of them. */
+int ikgpu_dls_solve_batch_sharded(ikgpu_shard_group *g, int64_t total, const double *const *q0, const double *const *targets,
+                                  const ikgpu_dls_params *params, void *const *gathered);
+int ikgpu_shard_group_synchronize(ikgpu_shard_group *g);
+
 /* ---- the other solver of the reference: B independent calls of ik::pik(), prioritised IK (reference
  * ik/ik/pik.cpp:31-103, declared ik/ik/pik.hpp:56-59), in lockstep.  Arguments as ikgpu_dls_solve_batch.  Every priority
  * level l of the task table is solved in the null space of the levels before it, with the damped pseudo-inverse of

@@ -1,0 +1,76 @@
+"""The C ABI's one-process multi-GPU entry (ikgpu_dls_solve_batch_sharded: per-device handles and streams, one RCCL communicator per
+device, one ncclAllGather of the packed slots) on the devices this box has (the driver's GPU box has one: the whole path runs,
+the collective is RCCL's all-gather over a communicator of one), and the pipelined host-pointer entry (chunks: H2D || solve || D2H)."""
+import numpy as np
+import pytest
+
+from conftest import urdf_path
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup(native_built):
+    import torch
+    import ik_amd
+    from ik_amd import workload
+    assert torch.cuda.is_available()
+    model = ik_amd.Model.from_urdf_file(urdf_path("cassie_fixed"))
+    problem = ik_amd.InverseKinematicsProblem(model)
+    problem.add_frame_task("t", ik_amd.FrameTask.create(model, "LeftFootFront", ik_amd.KinematicType.Full))
+    data = ik_amd.dls_data(problem, device=0)
+
+    def inputs(B):
+        q0, qs = workload.chain_workload(model.lowerPositionLimit, model.upperPositionLimit, workload.cassie_nominal(model.names), np.arange(B), 0, "uniform")
+        Q0 = torch.from_numpy(np.ascontiguousarray(q0.T)).cuda()
+        T = ik_amd.task_frames_fk_batch(problem, torch.from_numpy(np.ascontiguousarray(qs.T)).cuda(), data)
+        return Q0, T
+    return torch, ik_amd, model, problem, data, inputs
+
+
+@pytest.mark.parametrize("stop", [False, True])
+def test_sharded_solve_matches_the_single_device_solve(setup, stop):
+    torch, ik_amd, model, problem, data, inputs = setup
+    from ik_amd import distributed as D
+    ndev = min(torch.cuda.device_count(), 2)
+    total = 20001
+    Q0, T = inputs(total)
+    vis = ik_amd.inverse_kinematics_visitor() if stop else ik_amd.never_stop_visitor()
+    prm = ik_amd.dls_parameters(max_iterations=30)
+    ref = ik_amd.dls_batch(problem, Q0, T, data, vis, prm)
+    torch.cuda.synchronize()
+    group = D.ShardGroup(problem, list(range(ndev)))
+    assert group.uses_rccl, "librccl should be loadable on the GPU box"
+    q_parts, t_parts = [], []
+    for r in range(ndev):
+        lo, hi = D.shard_range(total, r, ndev)
+        q_parts.append(Q0[:, lo:hi].contiguous().to("cuda:%d" % r))
+        t_parts.append(T[:, :, lo:hi].contiguous().to("cuda:%d" % r))
+    torch.cuda.synchronize()
+    out = group.solve(total, q_parts, t_parts, vis, prm)
+    for d in range(ndev):                                   # every device holds every rank's slot
+        parts = group.decode(out[d], total)
+        Q = torch.cat([p[0].to("cuda:0") for p in parts], dim=1)
+        ok = torch.cat([p[1].to("cuda:0") for p in parts])
+        it = torch.cat([p[2].to("cuda:0") for p in parts])
+        assert torch.equal(Q, ref[0]) and torch.equal(ok, ref[1]) and torch.equal(it, ref[2])
+    group.close()
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("B", [8192, 20000, 65536 + 77])
+def test_pipelined_host_entry_matches_the_device_entry(setup, layout, B):
+    """numpy arrays take ikgpu_dls_solve_batch_host: above 1 MiB the chunked pipeline (pageable memory here; pinned in bench.py)."""
+    torch, ik_amd, model, problem, data, inputs = setup
+    Q0, T = inputs(B)
+    vis, prm = ik_amd.inverse_kinematics_visitor(), ik_amd.dls_parameters(max_iterations=25)
+    ref = ik_amd.dls_batch(problem, Q0, T, data, vis, prm)
+    q_h, t_h = Q0.cpu().numpy(), T.cpu().numpy()
+    if layout == "aos":
+        q_h, t_h = np.ascontiguousarray(q_h.T), np.ascontiguousarray(t_h.transpose(2, 0, 1))
+    Q, ok, it = ik_amd.dls_batch(problem, q_h, t_h, data, vis, prm, layout=layout)
+    if layout == "aos":
+        Q = Q.T
+    assert np.array_equal(Q, ref[0].cpu().numpy()) and np.array_equal(ok, ref[1].cpu().numpy()) and np.array_equal(it, ref[2].cpu().numpy())
+    Q2, _, _ = ik_amd.dls_batch(problem, q_h, t_h, data, vis, prm, layout=layout)      # the arena is reused
+    assert np.array_equal(Q2.T if layout == "aos" else Q2, ref[0].cpu().numpy())

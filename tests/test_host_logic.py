@@ -338,3 +338,26 @@ def test_chain_build_switches_and_precompile(ik, tmp_path, monkeypatch):
     weighted = _problem(ik, "arm7", ["tool"])[1]
     weighted.get_frame_task("t0").weighting()[0] = 2.0                                           # the hot program needs unit weights
     assert ik.precompile(weighted) == "dls_chain<NJ=7,full,general>"
+
+
+def test_shard_rule_and_slot_layout_of_the_c_abi(ik):
+    """ikgpu_shard_range / ikgpu_shard_slot_layout / ikgpu_shard_slot_bytes (what ikgpu_dls_solve_batch_sharded splits and packs by)
+    against their definitions; ik_amd.distributed uses the same functions for the one-process-per-GPU path."""
+    from ik_amd import capi, distributed as D
+    L = capi.lib()
+    for total in (1, 7, 10, 64, 65536, 262144, 262145, 1000003):
+        for world in (1, 2, 3, 4, 8):
+            if total < world:
+                continue
+            base, rem = divmod(total, world)
+            prev_hi = 0
+            for r in range(world):
+                lo, hi = D.shard_range(total, r, world)
+                assert lo == prev_hi == r * base + min(r, rem) and hi - lo == base + (1 if r < rem else 0)
+                prev_hi = hi
+            assert prev_hi == total
+            for rows in (6, 7, 16, 23):
+                b_max = base + (1 if rem else 0)
+                (oq, oi, os_), used = D._layout(rows, b_max)
+                assert (oq, oi, os_, used) == (0, rows * b_max * 8, rows * b_max * 8 + 4 * b_max, rows * b_max * 8 + 5 * b_max)
+                assert L.ikgpu_shard_slot_bytes(rows, total, world) == (used + 15) // 16 * 16

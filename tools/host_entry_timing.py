@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""ikgpu_dls_solve_batch_host on pinned host buffers, wall clock per call, by batch size and chunk size (IKGPU_HOST_CHUNK)."""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import ik_amd  # noqa: E402
+from ik_amd import capi, workload  # noqa: E402
+
+model = ik_amd.Model.from_urdf_file(os.path.join(workload.MODELS_DIR, "cassie_fixed.kin.urdf"))
+problem = ik_amd.InverseKinematicsProblem(model)
+problem.add_frame_task("t", ik_amd.FrameTask.create(model, "LeftFootFront", ik_amd.KinematicType.Full))
+data = ik_amd.dls_data(problem, device=0)
+L = capi.lib()
+for B in (65536, 262144):
+    q0, qs = workload.chain_workload(model.lowerPositionLimit, model.upperPositionLimit, workload.cassie_nominal(model.names), np.arange(B), 0, "uniform")
+    Q0 = torch.from_numpy(np.ascontiguousarray(q0.T)).cuda()
+    T = ik_amd.task_frames_fk_batch(problem, torch.from_numpy(np.ascontiguousarray(qs.T)).cuda(), data)
+    ref = ik_amd.dls_batch(problem, Q0, T, data, ik_amd.never_stop_visitor(), ik_amd.dls_parameters(max_iterations=50))
+    for layout in ("soa", "aos"):
+        hq0 = (Q0 if layout == "soa" else Q0.t().contiguous()).cpu().pin_memory()
+        htg = (T if layout == "soa" else T.permute(2, 0, 1).contiguous()).cpu().pin_memory()
+        hq = torch.empty_like(hq0).pin_memory()
+        hok, hit = torch.empty(B, dtype=torch.uint8).pin_memory(), torch.empty(B, dtype=torch.int32).pin_memory()
+        prm = capi.DlsParams(50, 1e-2, 1.0, -1.0)
+        for chunk in ("", "8192", "16384", "32768", "65536", str(B)):
+            if chunk:
+                os.environ["IKGPU_HOST_CHUNK"] = chunk
+            else:
+                os.environ.pop("IKGPU_HOST_CHUNK", None)
+
+            def call():
+                capi.check(L.ikgpu_dls_solve_batch_host(data._h, B, hq0.data_ptr(), htg.data_ptr(), C.byref(prm), hq.data_ptr(), hok.data_ptr(), hit.data_ptr(),
+                                                        capi.SOA if layout == "soa" else capi.AOS))
+            call(); call()
+            ts = []
+            for _ in range(30):
+                t = time.perf_counter()
+                call()
+                ts.append((time.perf_counter() - t) * 1e3)
+            ts.sort()
+            ms = ts[len(ts) // 2]
+            same = torch.equal(hq if layout == "soa" else hq.t(), ref[0].cpu())
+            print("B %d %s chunk %-7s: median %.3f ms (min %.3f, max %.3f) = %.3e solves/s%s" % (B, layout, chunk or "default", ms, ts[0], ts[-1], B / ms * 1e3, "" if same else "  DIFFERENT"))
