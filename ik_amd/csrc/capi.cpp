@@ -47,6 +47,11 @@ struct ikgpu_problem {
     ikgpu::DeviceTables dev;
     int device = 0;
     int nframes = 0;
+    // A Tree-kind problem with few rows runs ik::dls on the lane program specialised for it at run time instead (gen.generic_build == 2):
+    // the dense M x M system of a small task set is cheaper than the tree kernel's arrow elimination (the reference demo's own task
+    // set, M = 10: 0.39 against 0.51 ms per 65536 problems); `host` stays the tree analysis (stage kernels, two-level ik::pik)
+    bool dls_on_static_gen = false;
+    std::string dls_name;    // what ikgpu_problem_kernel reports
     std::string pik_name;    // name of the generic PIK kernel instance
     std::string pik_tree_name;  // ... and of the tree kernel running a two-level ik::pik (when the problem has that shape)
 };
@@ -73,12 +78,29 @@ ikgpu::ProblemHost analyse(const ikgpu::Model &m, const ikgpu_task *tasks, int32
         ph.chain_build = ikgpu::select_chain_build(ph, compile_rtc);
         ph.kernel_name = ikgpu::chain_kernel_name(ph);
     }
+    if (ph.kind == ikgpu::KernelKind::Generic && ikgpu::rtc_generic_static_available(ph, compile_rtc, &ph.generic_key)) {
+        ph.generic_build = 2;   // the lane program specialised for this problem (the name says so: "...,static>")
+        ph.kernel_name = ph.kernel_name.substr(0, ph.kernel_name.size() - 1) + ",static>";
+    }
     return ph;
 }
 
 int fail(int code, const std::string &msg) {
     g_last_error = msg;
     return code;
+}
+
+// Tree-kind problems the static generic program is tried for first: few rows (IKGPU_TREE_STATIC_ROWS, default 12; 0 = never).
+bool tree_prefers_static(const ikgpu::ProblemHost &ph) {
+    if (ph.kind != ikgpu::KernelKind::Tree) return false;
+    long rows = 12;
+    if (const char *env = std::getenv("IKGPU_TREE_STATIC_ROWS")) rows = std::strtol(env, nullptr, 10);
+    return ph.rows <= rows;
+}
+
+std::string static_name(const ikgpu::ProblemHost &gen) {
+    const std::string &n = gen.kernel_name;
+    return n.size() > 8 && n.compare(n.size() - 8, 8, ",static>") == 0 ? n : n.substr(0, n.size() - 1) + ",static>";
 }
 
 }  // namespace
@@ -406,7 +428,18 @@ int ikgpu_problem_create_constrained(const ikgpu_model *h, const ikgpu_task *tas
         auto *p = new ikgpu_problem;
         p->host = std::move(ph);
         p->gen = std::move(gen);
-        p->pik_name = "pik_generic" + p->gen.kernel_name.substr(std::min(p->gen.kernel_name.find('<'), p->gen.kernel_name.size()));
+        p->dls_name = p->host.kernel_name;
+        if (tree_prefers_static(p->host) && ikgpu::rtc_generic_static_available(p->gen, /*compile=*/true, &p->gen.generic_key)) {
+            p->gen.generic_build = 2;
+            p->dls_on_static_gen = true;
+            p->dls_name = static_name(p->gen);
+        }
+        {
+            std::string gname = p->gen.kernel_name;   // ("...,static>": the DLS program's build, not ik::pik's)
+            const size_t st = gname.find(",static>");
+            if (st != std::string::npos) gname = gname.substr(0, st) + ">";
+            p->pik_name = "pik_generic" + gname.substr(std::min(gname.find('<'), gname.size()));
+        }
         p->pik_tree_name = p->host.kernel_name.substr(0, p->host.kernel_name.size() - (p->host.kernel_name.empty() ? 0 : 1)) + ",pik_levels=2>";
         p->device = device;
         p->nframes = h->m.nframes();
@@ -447,8 +480,13 @@ int ikgpu_problem_plan_constrained(const ikgpu_model *h, const ikgpu_task *tasks
     if (nconstraints < 0) return fail(IKGPU_ERR_INVALID, "negative constraint count");
     try {
         const ikgpu::ProblemHost ph = analyse(h->m, tasks, ntasks, constraints, nconstraints);
+        std::string name = ph.kernel_name;
+        if (tree_prefers_static(ph)) {
+            const ikgpu::ProblemHost gen = ikgpu::analyse_problem(h->m, tasks, ntasks, /*force_generic=*/true, constraints, nconstraints);
+            if (ikgpu::rtc_generic_static_available(gen, /*compile=*/false, nullptr)) name = static_name(gen);
+        }
         if (out && cap) {
-            std::strncpy(out, ph.kernel_name.c_str(), cap - 1);
+            std::strncpy(out, name.c_str(), cap - 1);
             out[cap - 1] = '\0';
         }
         return IKGPU_OK;
@@ -464,12 +502,20 @@ int ikgpu_problem_precompile(const ikgpu_model *h, const ikgpu_task *tasks, int3
     try {
         const ikgpu::ProblemHost planned = analyse(h->m, tasks, ntasks, constraints, nconstraints, /*compile_rtc=*/false);
         const ikgpu::ProblemHost ph = analyse(h->m, tasks, ntasks, constraints, nconstraints, /*compile_rtc=*/true);
+        std::string want = planned.kernel_name, got = ph.kernel_name;
+        if (tree_prefers_static(ph)) {
+            ikgpu::ProblemHost gen = ikgpu::analyse_problem(h->m, tasks, ntasks, /*force_generic=*/true, constraints, nconstraints);
+            if (ikgpu::rtc_generic_static_available(gen, /*compile=*/false, nullptr)) {
+                want = static_name(gen);
+                if (ikgpu::rtc_generic_static_available(gen, /*compile=*/true, &gen.generic_key)) got = want;
+            }
+        }
         if (out && cap) {
-            std::strncpy(out, ph.kernel_name.c_str(), cap - 1);
+            std::strncpy(out, got.c_str(), cap - 1);
             out[cap - 1] = '\0';
         }
-        if (planned.kernel_name != ph.kernel_name)   // planned a run-time compiled build, got the general one
-            return fail(IKGPU_ERR_UNSUPPORTED, "run-time compilation failed, the problem runs on " + ph.kernel_name + ": " + ikgpu::rtc_last_log());
+        if (want != got)   // planned a run-time compiled build, got the pre-built one
+            return fail(IKGPU_ERR_UNSUPPORTED, "run-time compilation failed, the problem runs on " + got + ": " + ikgpu::rtc_last_log());
         return IKGPU_OK;
     } catch (const std::exception &e) {
         return fail(IKGPU_ERR_INVALID, e.what());
@@ -498,7 +544,7 @@ void ikgpu_problem_destroy(ikgpu_problem *p) {
 
 int32_t ikgpu_problem_rows(const ikgpu_problem *p) { return p ? p->host.rows : -1; }
 
-const char *ikgpu_problem_kernel(const ikgpu_problem *p) { return p ? p->host.kernel_name.c_str() : ""; }
+const char *ikgpu_problem_kernel(const ikgpu_problem *p) { return p ? p->dls_name.c_str() : ""; }
 
 int ikgpu_problem_support(const ikgpu_problem *p, uint8_t *support) {
     if (!p || !support) return fail(IKGPU_ERR_INVALID, "ikgpu_problem_support: null argument");
@@ -521,8 +567,10 @@ int ikgpu_dls_solve_batch(const ikgpu_problem *p, int64_t B, const double *q0, c
         if (!g.ok) return fail(IKGPU_ERR_DEVICE, "hipSetDevice failed");
         ikgpu::BatchIO io{B, q0, targets, q_out, success, iters, layout};
         const hipStream_t st = static_cast<hipStream_t>(stream);
-        hipError_t e = p->host.kind == ikgpu::KernelKind::Chain  ? ikgpu::launch_dls_chain(p->host, p->dev, io, *params, st)
+        hipError_t e = p->dls_on_static_gen                      ? ikgpu::rtc_launch_generic_static(p->gen, p->gen.generic_key, io, *params, st)
+                       : p->host.kind == ikgpu::KernelKind::Chain  ? ikgpu::launch_dls_chain(p->host, p->dev, io, *params, st)
                        : p->host.kind == ikgpu::KernelKind::Tree ? ikgpu::launch_dls_tree(p->host, p->dev, io, *params, st)
+                       : p->host.generic_build == 2              ? ikgpu::rtc_launch_generic_static(p->host, p->host.generic_key, io, *params, st)
                                                                  : ikgpu::launch_dls_generic(p->host, p->dev, io, *params, st);
         if (e != hipSuccess) return hip_fail(e, "launching the DLS kernel");
         return static_cast<int>(IKGPU_OK);
@@ -555,7 +603,7 @@ void ikgpu_pik_params_default(ikgpu_pik_params *p, int32_t num_levels) {
 
 const char *ikgpu_pik_kernel(const ikgpu_problem *p, const ikgpu_pik_params *params) {
     if (!p || !params) return "";
-    if (pik_is_one_dls_level(p, params)) return p->host.kernel_name.c_str();
+    if (pik_is_one_dls_level(p, params)) return p->dls_name.c_str();
     return pik_is_two_levels_on_the_tree(p, params) ? p->pik_tree_name.c_str() : p->pik_name.c_str();
 }
 

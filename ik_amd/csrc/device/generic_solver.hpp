@@ -11,7 +11,9 @@
 // per-lane workspace lives in HBM as [word][lane], which makes every access of a wave a coalesced 512-byte
 // transaction.  Sizes are runtime values; nothing here is unrolled.
 #pragma once
+#if !defined(__HIPCC_RTC__)
 #include <cstdint>
+#endif
 
 #include "chain_solver.hpp"
 #include "tree_solver.hpp"
@@ -74,9 +76,26 @@ struct Ws {  // word w of this lane
     IKD_FN double &operator[](int w) const { return base[static_cast<int64_t>(w) * stride]; }
 };
 
+// The same lane program specialised at run time (rtc_generic.cpp): the tables are `static constexpr` members of a generated type, the
+// workspace is a LOCAL array -- with every loop fully unrolled all its indices are constants, so it is promoted to registers, the
+// structural zeros of the dense M x nv Jacobian fold away (the translation unit is compiled with -fno-signed-zeros -fno-honor-nans
+// -fno-honor-infinities, as kernels_hot.hip) and everything the task list never reads (joints outside every support, unused
+// Jacobian columns) is dead code.  IKD_UNROLL marks the loops that must unroll for that; it expands to nothing in the ordinary builds.
+struct WsReg {
+    double *w;
+    IKD_FN double &operator[](int i) const { return w[i]; }
+};
+#ifdef IKD_STATIC_TABLES
+#define IKD_UNROLL _Pragma("unroll")
+#else
+#define IKD_UNROLL
+#endif
+
 template <class PA, class PB>
 IKD_FN void g_se3_mul(PA A, PB B, double *C) {  // C = A * B, C may not alias
+    IKD_UNROLL
     for (int i = 0; i < 3; ++i) {
+        IKD_UNROLL
         for (int j = 0; j < 3; ++j) C[3 * i + j] = dfma(A[3 * i], B[j], dfma(A[3 * i + 1], B[3 + j], A[3 * i + 2] * B[6 + j]));
         C[9 + i] = dfma(A[3 * i], B[9], dfma(A[3 * i + 1], B[10], dfma(A[3 * i + 2], B[11], A[9 + i])));
     }
@@ -85,19 +104,23 @@ IKD_FN void g_se3_mul(PA A, PB B, double *C) {  // C = A * B, C may not alias
 template <class PA, class PB>
 IKD_FN void g_se3_inv_mul(PA A, PB B, double *C) {  // C = A^-1 * B
     const double d[3] = {B[9] - A[9], B[10] - A[10], B[11] - A[11]};
+    IKD_UNROLL
     for (int i = 0; i < 3; ++i) {
+        IKD_UNROLL
         for (int j = 0; j < 3; ++j) C[3 * i + j] = dfma(A[i], B[j], dfma(A[3 + i], B[3 + j], A[6 + i] * B[6 + j]));
         C[9 + i] = dfma(A[i], d[0], dfma(A[3 + i], d[1], A[6 + i] * d[2]));
     }
 }
 
 // framesForwardKinematics (joints) + computeJointJacobians (ik/ik/data.cpp:28-30) into the workspace: q -> oMi, Jw.
-template <class TB>
-IKD_FN void generic_fk(const TB &T, const Ws &ws) {
+template <class TB, class WS>
+IKD_FN void generic_fk(const TB &T, const WS &ws) {
     {
         const double I[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+        IKD_UNROLL
         for (int k = 0; k < 12; ++k) ws[T.off_oMi + k] = I[k];
     }
+    IKD_UNROLL
     for (int j = 1; j < T.njoints; ++j) {
         double Mj[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0}, li[12], oP[12], oM[12];
         const int iq = T.idx_q[j], iv = T.idx_v[j], jt = T.jtype[j];
@@ -115,15 +138,19 @@ IKD_FN void generic_fk(const TB &T, const Ws &ws) {
             Mj[9] = a[0] * v; Mj[10] = a[1] * v; Mj[11] = a[2] * v;
         } else if (jt == GJ_FREEFLYER) {
             double qb[7];
+            IKD_UNROLL
             for (int k = 0; k < 7; ++k) qb[k] = ws[T.off_q + iq + k];
             double R[9];
             quat_to_R(qb, R);
+            IKD_UNROLL
             for (int k = 0; k < 9; ++k) Mj[k] = R[k];
             Mj[9] = qb[0]; Mj[10] = qb[1]; Mj[11] = qb[2];
         }
         g_se3_mul(T.placement + 12 * j, Mj, li);
+        IKD_UNROLL
         for (int k = 0; k < 12; ++k) oP[k] = ws[T.off_oMi + 12 * T.parent[j] + k];
         g_se3_mul(oP, li, oM);
+        IKD_UNROLL
         for (int k = 0; k < 12; ++k) ws[T.off_oMi + 12 * j + k] = oM[k];
         // world Jacobian columns [v; w]
         if (jt == GJ_REVOLUTE || jt == GJ_PRISMATIC || jt == GJ_REVOLUTE_UNBOUNDED) {
@@ -135,13 +162,16 @@ IKD_FN void generic_fk(const TB &T, const Ws &ws) {
                 cross(p, Ra, v);
                 w[0] = Ra[0]; w[1] = Ra[1]; w[2] = Ra[2];
             }
+            IKD_UNROLL
             for (int r = 0; r < 3; ++r) { ws[T.off_Jw + r * T.nv + iv] = v[r]; ws[T.off_Jw + (3 + r) * T.nv + iv] = w[r]; }
         } else if (jt == GJ_FREEFLYER) {  // Ad(oM1) = [[R, [p]x R], [0, R]]
             const double p[3] = {oM[9], oM[10], oM[11]};
+            IKD_UNROLL
             for (int c = 0; c < 3; ++c) {
                 const double Rc[3] = {oM[c], oM[3 + c], oM[6 + c]};
                 double pxR[3];
                 cross(p, Rc, pxR);
+                IKD_UNROLL
                 for (int r = 0; r < 3; ++r) {
                     ws[T.off_Jw + r * T.nv + iv + c] = Rc[r];
                     ws[T.off_Jw + (3 + r) * T.nv + iv + c] = 0.0;
@@ -154,40 +184,50 @@ IKD_FN void generic_fk(const TB &T, const Ws &ws) {
 }
 
 // evaluate_problem_data (ik/ik/data.cpp:25-58) into the workspace: q -> oMi, Jw, et, Jt.  Returns ||e[0]||^2.
-template <class TB>
-IKD_FN double generic_evaluate(const TB &T, const Ws &ws, const double *targets_lane, int64_t tstride) {
+template <class TB, class WS>
+IKD_FN double generic_evaluate(const TB &T, const WS &ws, const double *targets_lane, int64_t tstride) {
     generic_fk(T, ws);
     if (T.has_com) {  // pinocchio::centerOfMass, backward pass: first moment of every subtree (the subtree masses are constants)
+        IKD_UNROLL
         for (int j = 1; j < T.njoints; ++j) {
             const auto c = T.j_lever + 3 * j;
             const double mj = T.j_mass[j];
+            IKD_UNROLL
             for (int i = 0; i < 3; ++i)
                 ws[T.off_sf + 3 * j + i] = mj * dfma(ws[T.off_oMi + 12 * j + 3 * i], c[0], dfma(ws[T.off_oMi + 12 * j + 3 * i + 1], c[1],
                                                 dfma(ws[T.off_oMi + 12 * j + 3 * i + 2], c[2], ws[T.off_oMi + 12 * j + 9 + i])));
         }
+        IKD_UNROLL
         for (int i = 0; i < 3; ++i) ws[T.off_sf + i] = 0.0;
+        IKD_UNROLL
         for (int j = T.njoints - 1; j > 0; --j)
+            IKD_UNROLL
             for (int i = 0; i < 3; ++i) ws[T.off_sf + 3 * T.parent[j] + i] += ws[T.off_sf + 3 * j + i];
     }
     double e0sq = 0.0;
+    IKD_UNROLL
     for (int t = 0; t < T.ntasks; ++t) {
         const int fj = T.t_fjoint[t], rj = T.t_rjoint[t], type = T.t_type[t], row = T.t_row[t], dim = T.t_dim[t];
         const auto w6 = T.t_w + 6 * t;
         if (type == GT_COM) {  // ik::CentreOfMassTask, ik/ik/centre_of_mass.hpp:33-45; jacobianCenterOfMass, ik/ik/data.cpp:31-34
             double oJ[12], oMr[12];
+            IKD_UNROLL
             for (int k = 0; k < 12; ++k) oJ[k] = ws[T.off_oMi + 12 * rj + k];
             g_se3_mul(oJ, T.t_rpl + 12 * t, oMr);
             const double d[3] = {dfma(ws[T.off_sf], T.inv_total_mass, -oMr[9]), dfma(ws[T.off_sf + 1], T.inv_total_mass, -oMr[10]),
                                  dfma(ws[T.off_sf + 2], T.inv_total_mass, -oMr[11])};
+            IKD_UNROLL
             for (int r = 0; r < 3; ++r) {
                 const double e = (dfma(oMr[r], d[0], dfma(oMr[3 + r], d[1], oMr[6 + r] * d[2])) - targets_lane[(t * 12 + 9 + r) * tstride]) * w6[r];
                 ws[T.off_e + row + r] = e;
                 if (T.t_prio[t] == 0) e0sq = dfma(e, e, e0sq);
             }
+            IKD_UNROLL
             for (int j = 1; j < T.njoints; ++j) {
                 const int n = T.jtype[j] == GJ_FREEFLYER ? 6 : 1;
                 const double ms = T.j_submass[j];
                 const double f[3] = {ws[T.off_sf + 3 * j], ws[T.off_sf + 3 * j + 1], ws[T.off_sf + 3 * j + 2]};
+                IKD_UNROLL
                 for (int c = T.idx_v[j]; c < T.idx_v[j] + n; ++c) {
                     const double v[3] = {ws[T.off_Jw + c], ws[T.off_Jw + T.nv + c], ws[T.off_Jw + 2 * T.nv + c]};
                     const double w[3] = {ws[T.off_Jw + 3 * T.nv + c], ws[T.off_Jw + 4 * T.nv + c], ws[T.off_Jw + 5 * T.nv + c]};
@@ -195,6 +235,7 @@ IKD_FN double generic_evaluate(const TB &T, const Ws &ws, const double *targets_
                     cross(f, w, fxw);
                     const double col[3] = {(ms * v[0] - fxw[0]) * T.inv_total_mass, (ms * v[1] - fxw[1]) * T.inv_total_mass,
                                            (ms * v[2] - fxw[2]) * T.inv_total_mass};
+                    IKD_UNROLL
                     for (int r = 0; r < 3; ++r)
                         ws[T.off_J + (row + r) * T.nv + c] = w6[r] * dfma(oMr[r], col[0], dfma(oMr[3 + r], col[1], oMr[6 + r] * col[2]));
                 }
@@ -205,16 +246,22 @@ IKD_FN double generic_evaluate(const TB &T, const Ws &ws, const double *targets_
             const double e = (ws[T.off_q + rj] - targets_lane[(t * 12 + 9) * tstride]) * w6[1] * w6[0];
             ws[T.off_e + row] = e;
             if (T.t_prio[t] == 0) e0sq = dfma(e, e, e0sq);
+            IKD_UNROLL
             for (int c = 0; c < T.nv; ++c) ws[T.off_J + row * T.nv + c] = (c == fj) ? w6[0] : 0.0;
             continue;
         }
         double oJ[12], oMf[12], oMr[12], tg[12];
+        IKD_UNROLL
         for (int k = 0; k < 12; ++k) oJ[k] = ws[T.off_oMi + 12 * fj + k];
         g_se3_mul(oJ, T.t_fpl + 12 * t, oMf);
+        IKD_UNROLL
         for (int k = 0; k < 12; ++k) oJ[k] = ws[T.off_oMi + 12 * rj + k];
         g_se3_mul(oJ, T.t_rpl + 12 * t, oMr);
+        IKD_UNROLL
         for (int k = 0; k < 12; ++k) tg[k] = targets_lane[(t * 12 + k) * tstride];
+        IKD_UNROLL
         for (int r = 0; r < dim; ++r)
+            IKD_UNROLL
             for (int c = 0; c < T.nv; ++c) ws[T.off_J + (row + r) * T.nv + c] = 0.0;  // frame.hpp:110: zero outside the support
         const double Rf[9] = {oMf[0], oMf[1], oMf[2], oMf[3], oMf[4], oMf[5], oMf[6], oMf[7], oMf[8]};
         const double pf[3] = {oMf[9], oMf[10], oMf[11]};
@@ -233,8 +280,10 @@ IKD_FN double generic_evaluate(const TB &T, const Ws &ws, const double *targets_
             const double e = (1.0 - dot(r, tn)) * w6[0];
             ws[T.off_e + row] = e;
             if (T.t_prio[t] == 0) e0sq = dfma(e, e, e0sq);
+            IKD_UNROLL
             for (int j = fj; j > 0; j = T.parent[j]) {
                 const int n = T.jtype[j] == GJ_FREEFLYER ? 6 : 1;
+                IKD_UNROLL
                 for (int c = T.idx_v[j]; c < T.idx_v[j] + n; ++c) {
                     const double w[3] = {ws[T.off_Jw + 3 * T.nv + c], ws[T.off_Jw + 4 * T.nv + c], ws[T.off_Jw + 5 * T.nv + c]};
                     double wl[3];
@@ -246,7 +295,9 @@ IKD_FN double generic_evaluate(const TB &T, const Ws &ws, const double *targets_
         }
         double oMt[12], Re[9], pe[3];
         g_se3_mul(oMr, tg, oMt);                        // frame.hpp:48
+        IKD_UNROLL
         for (int i = 0; i < 3; ++i)
+            IKD_UNROLL
             for (int j = 0; j < 3; ++j) Re[3 * i + j] = dfma(Rf[i], oMt[j], dfma(Rf[3 + i], oMt[3 + j], Rf[6 + i] * oMt[6 + j]));
         {
             const double dp[3] = {oMt[9] - pf[0], oMt[10] - pf[1], oMt[11] - pf[2]};
@@ -262,8 +313,10 @@ IKD_FN double generic_evaluate(const TB &T, const Ws &ws, const double *targets_
             ws[T.off_e + row + k - r0] = e;
             if (T.t_prio[t] == 0) e0sq = dfma(e, e, e0sq);
         }
+        IKD_UNROLL
         for (int j = fj; j > 0; j = T.parent[j]) {      // support of the frame's joint (getFrameJacobian, LOCAL)
             const int n = T.jtype[j] == GJ_FREEFLYER ? 6 : 1;
+            IKD_UNROLL
             for (int c = T.idx_v[j]; c < T.idx_v[j] + n; ++c) {
                 double v[3] = {ws[T.off_Jw + c], ws[T.off_Jw + T.nv + c], ws[T.off_Jw + 2 * T.nv + c]};
                 const double w[3] = {ws[T.off_Jw + 3 * T.nv + c], ws[T.off_Jw + 4 * T.nv + c], ws[T.off_Jw + 5 * T.nv + c]};
@@ -273,6 +326,7 @@ IKD_FN double generic_evaluate(const TB &T, const Ws &ws, const double *targets_
                 rotT_vec(Rf, v, vl);
                 rotT_vec(Rf, w, wl);
                 double out[6];
+                IKD_UNROLL
                 for (int i = 0; i < 3; ++i) {
                     out[i] = -dfma(lj.A[3 * i], vl[0], dfma(lj.A[3 * i + 1], vl[1], dfma(lj.A[3 * i + 2], vl[2],
                               dfma(lj.Bm[3 * i], wl[0], dfma(lj.Bm[3 * i + 1], wl[1], lj.Bm[3 * i + 2] * wl[2])))));
@@ -289,8 +343,8 @@ IKD_FN double generic_evaluate(const TB &T, const Ws &ws, const double *targets_
 
 // Column c of pinocchio::getFrameJacobian(..., LOCAL) for a frame placed at (Rf, pf) in the world, from the world joint
 // Jacobian in the workspace: linear part vl, angular part wl.
-template <class TB>
-IKD_FN void local_column(const TB &T, const Ws &ws, int c, const double (&Rf)[9], const double (&pf)[3], double (&vl)[3],
+template <class TB, class WS>
+IKD_FN void local_column(const TB &T, const WS &ws, int c, const double (&Rf)[9], const double (&pf)[3], double (&vl)[3],
                          double (&wl)[3]) {
     double v[3] = {ws[T.off_Jw + c], ws[T.off_Jw + T.nv + c], ws[T.off_Jw + 2 * T.nv + c]};
     const double w[3] = {ws[T.off_Jw + 3 * T.nv + c], ws[T.off_Jw + 4 * T.nv + c], ws[T.off_Jw + 5 * T.nv + c]};
@@ -305,8 +359,8 @@ IKD_FN void local_column(const TB &T, const Ws &ws, int c, const double (&Rf)[9]
 // mutually orthogonal, U^T A = diag(sigma) V^T, so that row i ends as sigma_i v_i^T.  A companion column at off_col
 // (length m; pass a negative offset for none) is rotated along and ends as U^T col.  Every lane of a wave runs the same
 // sweeps: a lane whose pair is already orthogonal applies the identity rotation, and the wave leaves on a uniform vote.
-template <class AnyFn>
-IKD_FN void jacobi_rows(const Ws &ws, int off_rows, int off_col, int m, int nv, AnyFn any_lane) {
+template <class WS, class AnyFn>
+IKD_FN void jacobi_rows(const WS &ws, int off_rows, int off_col, int m, int nv, AnyFn any_lane) {
     const double eps = 2.220446049250313e-16;
     for (int sweep = 0; sweep < 40; ++sweep) {
         bool rotated = false;
@@ -344,23 +398,30 @@ IKD_FN void jacobi_rows(const Ws &ws, int off_rows, int off_col, int m, int nv, 
 // ik::FrameConstraint::compute_jacobian (ik/ik/frame.hpp:413-449) for every constraint, into the workspace (Jc, Mc x nv):
 // the velocity of the frame relative to its reference frame, in the frame's local coordinates:
 //   Jc = J_frame(LOCAL) - Ad(fMr) J_reference(LOCAL),  rows by kinematic type.   Needs oMi and Jw (generic_fk).
-template <class TB>
-IKD_FN void generic_constraint_jacobian(const TB &T, const Ws &ws) {
+template <class TB, class WS>
+IKD_FN void generic_constraint_jacobian(const TB &T, const WS &ws) {
+    IKD_UNROLL
     for (int k = 0; k < T.ncons; ++k) {
         const int fj = T.c_fjoint[k], rj = T.c_rjoint[k], row = T.c_row[k], dim = T.c_dim[k];
         const int r0 = (T.c_type[k] == GT_ORIENTATION) ? 3 : 0;
         double oJ[12], oMf[12], oMr[12], fMr[12];
+        IKD_UNROLL
         for (int i = 0; i < 12; ++i) oJ[i] = ws[T.off_oMi + 12 * fj + i];
         g_se3_mul(oJ, T.c_fpl + 12 * k, oMf);
+        IKD_UNROLL
         for (int i = 0; i < 12; ++i) oJ[i] = ws[T.off_oMi + 12 * rj + i];
         g_se3_mul(oJ, T.c_rpl + 12 * k, oMr);
         g_se3_inv_mul(oMf, oMr, fMr);
+        IKD_UNROLL
         for (int r = 0; r < dim; ++r)
+            IKD_UNROLL
             for (int c = 0; c < T.nv; ++c) ws[T.off_Jc + (row + r) * T.nv + c] = 0.0;
         const double Rf[9] = {oMf[0], oMf[1], oMf[2], oMf[3], oMf[4], oMf[5], oMf[6], oMf[7], oMf[8]};
         const double pf[3] = {oMf[9], oMf[10], oMf[11]};
+        IKD_UNROLL
         for (int j = fj; j > 0; j = T.parent[j]) {
             const int n = T.jtype[j] == GJ_FREEFLYER ? 6 : 1;
+            IKD_UNROLL
             for (int c = T.idx_v[j]; c < T.idx_v[j] + n; ++c) {
                 double vl[3], wl[3];
                 local_column(T, ws, c, Rf, pf, vl, wl);
@@ -374,11 +435,14 @@ IKD_FN void generic_constraint_jacobian(const TB &T, const Ws &ws) {
         const double pr[3] = {oMr[9], oMr[10], oMr[11]};
         const double Rx[9] = {fMr[0], fMr[1], fMr[2], fMr[3], fMr[4], fMr[5], fMr[6], fMr[7], fMr[8]};
         const double px[3] = {fMr[9], fMr[10], fMr[11]};
+        IKD_UNROLL
         for (int j = rj; j > 0; j = T.parent[j]) {
             const int n = T.jtype[j] == GJ_FREEFLYER ? 6 : 1;
+            IKD_UNROLL
             for (int c = T.idx_v[j]; c < T.idx_v[j] + n; ++c) {
                 double vr[3], wr[3], Rv[3], Rw[3], pxRw[3];
                 local_column(T, ws, c, Rr, pr, vr, wr);
+                IKD_UNROLL
                 for (int i = 0; i < 3; ++i) {   // Ad(fMr) [v; w] = [R v + p x (R w); R w]
                     Rv[i] = dfma(Rx[3 * i], vr[0], dfma(Rx[3 * i + 1], vr[1], Rx[3 * i + 2] * vr[2]));
                     Rw[i] = dfma(Rx[3 * i], wr[0], dfma(Rx[3 * i + 1], wr[1], Rx[3 * i + 2] * wr[2]));
@@ -395,8 +459,8 @@ IKD_FN void generic_constraint_jacobian(const TB &T, const Ws &ws) {
 
 // v <- (I - pinv(A) A) v for the m x nv matrix stored at off_rows (destroyed): ik/ik/dls.cpp:43-53's N applied to a vector.
 // Rank as Eigen's COD counts it, relative to the largest value: sigma_i > eps * min(m, nv) * sigma_max (see pik_solver.hpp).
-template <class AnyFn>
-IKD_FN void project_out_rowspace(const Ws &ws, int off_rows, int m, int nv, int off_vec, AnyFn any_lane) {
+template <class WS, class AnyFn>
+IKD_FN void project_out_rowspace(const WS &ws, int off_rows, int m, int nv, int off_vec, AnyFn any_lane) {
     jacobi_rows(ws, off_rows, -1, m, nv, any_lane);
     double smax2 = 0.0;
     for (int i = 0; i < m; ++i) {
@@ -418,18 +482,67 @@ IKD_FN void project_out_rowspace(const Ws &ws, int off_rows, int m, int nv, int 
     }
 }
 
+// The same projection, v <- (I - pinv(A) A) v, for the run-time specialised program (every loop unrolls: no data-dependent sweep
+// count): N = I - V^T V with V an orthonormal basis of the row space of A from Gram-Schmidt with every projection applied twice; a
+// row whose remainder falls below the rank threshold of the complete orthogonal decomposition behind the reference's pseudo-inverse
+// (epsilon x rows x the largest row norm) is dropped by a select -- what the tree kernel's constraint_project does (tree_solver.hpp).
+template <class WS>
+IKD_FN void project_out_rowspace_gs(const WS &ws, int off_rows, int m, int nv, int off_vec) {
+    double maxn2 = 0.0;
+    IKD_UNROLL
+    for (int i = 0; i < m; ++i) {
+        double n2 = 0.0;
+        IKD_UNROLL
+        for (int c = 0; c < nv; ++c) { const double x = ws[off_rows + i * nv + c]; n2 = dfma(x, x, n2); }
+        maxn2 = dmax(maxn2, n2);
+    }
+    const double thr = 2.220446049250313e-16 * static_cast<double>(m);
+    const double thr2 = thr * thr * maxn2;
+    IKD_UNROLL
+    for (int k = 0; k < m; ++k) {
+        IKD_UNROLL
+        for (int pass = 0; pass < 2; ++pass) {
+            IKD_UNROLL
+            for (int i = 0; i < k; ++i) {
+                double d = 0.0;
+                IKD_UNROLL
+                for (int c = 0; c < nv; ++c) d = dfma(ws[off_rows + i * nv + c], ws[off_rows + k * nv + c], d);
+                IKD_UNROLL
+                for (int c = 0; c < nv; ++c) ws[off_rows + k * nv + c] = dfma(-d, ws[off_rows + i * nv + c], ws[off_rows + k * nv + c]);
+            }
+        }
+        double n2 = 0.0;
+        IKD_UNROLL
+        for (int c = 0; c < nv; ++c) { const double x = ws[off_rows + k * nv + c]; n2 = dfma(x, x, n2); }
+        const double inv = dsel(n2 > thr2, drsqrt(dmax(n2, 1e-300)), 0.0);
+        double d = 0.0;
+        IKD_UNROLL
+        for (int c = 0; c < nv; ++c) {
+            const double x = ws[off_rows + k * nv + c] * inv;
+            ws[off_rows + k * nv + c] = x;
+            d = dfma(x, ws[off_vec + c], d);
+        }
+        IKD_UNROLL
+        for (int c = 0; c < nv; ++c) ws[off_vec + c] = dfma(-d, ws[off_rows + k * nv + c], ws[off_vec + c]);
+    }
+}
+
 // q <- clip(integrate(q, step * dq)) on the workspace (pinocchio::integrate + apply_joint_clipping,
 // ik/ik/common.hpp:53-56); a lane that is no longer active keeps its q.
-template <class TB>
-IKD_FN void generic_integrate_clip(const TB &T, const Ws &ws, double step_length, bool active) {
+template <class TB, class WS>
+IKD_FN void generic_integrate_clip(const TB &T, const WS &ws, double step_length, bool active) {
+    IKD_UNROLL
     for (int j = 1; j < T.njoints; ++j) {
         const int iq = T.idx_q[j], iv = T.idx_v[j];
         if (T.jtype[j] == GJ_FREEFLYER) {
             double qb[7], v[6], qn[7], R1[9];
+            IKD_UNROLL
             for (int k = 0; k < 7; ++k) qb[k] = ws[T.off_q + iq + k];
+            IKD_UNROLL
             for (int k = 0; k < 6; ++k) v[k] = step_length * ws[T.off_dq + iv + k];
             quat_to_R(qb, R1);
             freeflyer_integrate(qb, R1, v, qn);
+            IKD_UNROLL
             for (int k = 0; k < 7; ++k) {
                 const double c = dmin(T.upper[iq + k], dmax(qn[k], T.lower[iq + k]));
                 ws[T.off_q + iq + k] = active ? c : qb[k];
@@ -451,8 +564,8 @@ IKD_FN void generic_integrate_clip(const TB &T, const Ws &ws, double step_length
 }
 
 // One full solve on the workspace (q already stored at off_q).
-template <class TB, class AnyFn>
-IKD_FN void generic_dls(const TB &T, const LoopParams &prm, const Ws &ws, const double *targets_lane,
+template <class TB, class WS, class AnyFn>
+IKD_FN void generic_dls(const TB &T, const LoopParams &prm, const WS &ws, const double *targets_lane,
                         int64_t tstride, int &iters_out, bool &success_out, AnyFn any_active) {
     bool active = true, success = false;
     int iters = prm.max_iterations;
@@ -460,42 +573,59 @@ IKD_FN void generic_dls(const TB &T, const LoopParams &prm, const Ws &ws, const 
     for (int it = 0; it < prm.max_iterations; ++it) {
         const double e0sq = generic_evaluate(T, ws, targets_lane, tstride);
         // JJ = Jt Jt^T + damping^2 I (lower triangle, packed), ik/ik/dls.cpp:39-41
+        IKD_UNROLL
         for (int i = 0; i < M; ++i)
+            IKD_UNROLL
             for (int j = 0; j <= i; ++j) {
                 double s = (i == j) ? prm.lam2 : 0.0;
+                IKD_UNROLL
                 for (int c = 0; c < nv; ++c) s = dfma(ws[T.off_J + i * nv + c], ws[T.off_J + j * nv + c], s);
                 ws[T.off_G + tri(i, j)] = s;
             }
         // Cholesky in place (diagonal holds 1/L_ii), forward and backward substitution: y = JJ^-1 et
+        IKD_UNROLL
         for (int k = 0; k < M; ++k) {
             double d = ws[T.off_G + tri(k, k)];
+            IKD_UNROLL
             for (int m = 0; m < k; ++m) { const double l = ws[T.off_G + tri(k, m)]; d = dfma(-l, l, d); }
             const double inv = drsqrt(d);
             ws[T.off_G + tri(k, k)] = inv;
+            IKD_UNROLL
             for (int i = k + 1; i < M; ++i) {
                 double s = ws[T.off_G + tri(i, k)];
+                IKD_UNROLL
                 for (int m = 0; m < k; ++m) s = dfma(-ws[T.off_G + tri(i, m)], ws[T.off_G + tri(k, m)], s);
                 ws[T.off_G + tri(i, k)] = s * inv;
             }
         }
+        IKD_UNROLL
         for (int k = 0; k < M; ++k) {
             double s = ws[T.off_e + k];
+            IKD_UNROLL
             for (int m = 0; m < k; ++m) s = dfma(-ws[T.off_G + tri(k, m)], ws[T.off_y + m], s);
             ws[T.off_y + k] = s * ws[T.off_G + tri(k, k)];
         }
+        IKD_UNROLL
         for (int k = M - 1; k >= 0; --k) {
             double s = ws[T.off_y + k];
+            IKD_UNROLL
             for (int m = M - 1; m > k; --m) s = dfma(-ws[T.off_G + tri(m, k)], ws[T.off_y + m], s);  // (the order coop_solver.hpp takes)
             ws[T.off_y + k] = s * ws[T.off_G + tri(k, k)];
         }
+        IKD_UNROLL
         for (int c = 0; c < nv; ++c) {  // dq = -Jt^T y, ik/ik/dls.cpp:52-53 (N = I)
             double s = 0.0;
+            IKD_UNROLL
             for (int r = 0; r < M; ++r) s = dfma(ws[T.off_J + r * nv + c], ws[T.off_y + r], s);
             ws[T.off_dq + c] = -s;
         }
         if (T.Mc > 0) {  // dq <- N dq, N = I - pinv(Jc) Jc: the step stays in the null space of the constraints (dls.cpp:26-34,43-53)
             generic_constraint_jacobian(T, ws);
+#ifdef IKD_STATIC_TABLES
+            project_out_rowspace_gs(ws, T.off_Jc, T.Mc, nv, T.off_dq);
+#else
             project_out_rowspace(ws, T.off_Jc, T.Mc, nv, T.off_dq, any_active);
+#endif
         }
         const bool stop_now = active && (prm.stop_sq_tol >= 0.0) && (e0sq < prm.stop_sq_tol);
         if (stop_now) { success = true; iters = it; }
@@ -530,10 +660,11 @@ struct GenericKernelArgs {
 
 // ws: the lane's workspace column -- of the HBM workspace (dls_generic_body below) or of the workgroup's LDS (the on-chip form,
 // kernels.hip: word w of lane l at lds[w * 64 + l], conflict-free).
-template <class TB, class AnyFn>
-IKD_FN void dls_generic_body_ws(const GenericKernelArgs &a, const TB &T, int64_t gid, const Ws &ws, AnyFn any_active) {
+template <class TB, class WS, class AnyFn>
+IKD_FN void dls_generic_body_ws(const GenericKernelArgs &a, const TB &T, int64_t gid, const WS &ws, AnyFn any_active) {
     const bool valid = gid < a.B;
     const int64_t b = valid ? gid : a.B - 1;
+    IKD_UNROLL
     for (int i = 0; i < T.nq; ++i) ws[T.off_q + i] = a.q0[at(a.layout, a.B, T.nq, i, b)];
     const double *tl = a.layout == LAYOUT_SOA ? a.targets + b : a.targets + b * T.ntasks * 12;
     const int64_t ts = a.layout == LAYOUT_SOA ? a.B : 1;
@@ -541,6 +672,7 @@ IKD_FN void dls_generic_body_ws(const GenericKernelArgs &a, const TB &T, int64_t
     bool success;
     generic_dls(T, a.prm, ws, tl, ts, iters, success, any_active);
     if (!valid) return;
+    IKD_UNROLL
     for (int i = 0; i < T.nq; ++i) a.q_out[at(a.layout, a.B, T.nq, i, b)] = ws[T.off_q + i];
     if (a.success) a.success[b] = success ? 1 : 0;
     if (a.iters) a.iters[b] = iters;

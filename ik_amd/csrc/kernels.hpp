@@ -81,6 +81,10 @@ hipError_t launch_chain_pass_through(const ProblemHost &ph, const DeviceTables &
 // Run-time compiled hot build (rtc.cpp): dls_chain_hot_kernel<NJ, code...> for THIS chain's structure code through hipRTC.
 // available(compile = false): would it be attempted (libhiprtc loads, not disabled); (compile = true): compiled and loaded, or cached.
 bool rtc_chain_hot_available(const ProblemHost &ph, bool compile);
+// The generic lane program specialised for one problem at run time (rtc.cpp: tables as compile-time constants, workspace in
+// registers).  available(compile = true) compiles / fetches it and returns the key rtc_launch_generic_static takes.
+bool rtc_generic_static_available(const ProblemHost &gen, bool compile, uint64_t *key_out);
+hipError_t rtc_launch_generic_static(const ProblemHost &gen, uint64_t key, const BatchIO &io, const ikgpu_dls_params &prm, hipStream_t stream);
 std::string rtc_last_log();   // compiler log (or cache note) of the calling process's last run-time compilation attempt
 hipError_t rtc_launch_chain_hot(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const ikgpu_dls_params &prm, hipStream_t stream);
 int64_t persistent_grid(const void *kernel, int block, size_t lds, int64_t nblocks);

@@ -91,6 +91,10 @@ struct ProblemHost {
     // part of kernel_name: 0 "general" (device/chain_solver.hpp), 1 "hot" (structure-specialised, compiled into the library:
     // kernels_hot.hip), 2 "hot-rtc" (the same kernel template instantiated for this chain's structure code at run time: rtc.cpp)
     int chain_build = 0;
+    // Generic kind: 0 = the cooperative / per-lane memory-resident forms (kernels.hip), 2 = "static": the per-lane program compiled
+    // for this problem at run time with its tables as constants (rtc.cpp); generic_key names the code object
+    int generic_build = 0;
+    uint64_t generic_key = 0;
     ChainHost chainB;                 // Tree kind: chain B (nj = 0 when absent)
     int base_task = -1;               // Tree kind: index of the task on the base link, or -1
     double base_frame_pl[12] = {};    // base joint frame -> frame of the base task

@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "device/chain_hot.hpp"
+#include "device/generic_solver.hpp"
 #include "kernels.hpp"
 
 // The device headers, verbatim.  (Paths are relative to ik_amd/csrc, where the Makefile runs the compiler.)
@@ -41,6 +42,8 @@ IKGPU_EMBED(ikgpu_src_lane_math, "device/lane_math.hpp")
 IKGPU_EMBED(ikgpu_src_chain_solver, "device/chain_solver.hpp")
 IKGPU_EMBED(ikgpu_src_chain_kernel_body, "device/chain_kernel_body.hpp")
 IKGPU_EMBED(ikgpu_src_chain_hot, "device/chain_hot.hpp")
+IKGPU_EMBED(ikgpu_src_tree_solver, "device/tree_solver.hpp")
+IKGPU_EMBED(ikgpu_src_generic_solver, "device/generic_solver.hpp")
 
 namespace ikgpu {
 namespace {
@@ -170,36 +173,46 @@ ShapeKey key_of(const ProblemHost &ph) {
     return ShapeKey(ph.chain.nj, ph.chain_struct.code[0], ph.chain_struct.code[1], ph.chain_struct.code[2]);
 }
 
-// Compiles (or fetches) the code object of this shape.  Called with g_mu held.
-HotCode &code_for(const ProblemHost &ph) {
-    HotCode &hc = g_codes[key_of(ph)];
-    if (hc.tried) return hc;
-    hc.tried = true;
-    const RtcApi &api = rtc_api();
-    if (!api.ok) { hc.log = "libhiprtc could not be loaded"; return hc; }
-    const std::string src = hot_source(ph.chain.nj, ph.chain_struct.code, ph.chain_struct.values);
-    struct Hdr { const char *name, *begin, *end; };
-    const Hdr hdrs[] = {{"lane_math.hpp", ikgpu_src_lane_math, ikgpu_src_lane_math_end},
+struct Hdr { const char *name, *begin, *end; };
+const Hdr kHeaders[] = {{"lane_math.hpp", ikgpu_src_lane_math, ikgpu_src_lane_math_end},
                         {"chain_solver.hpp", ikgpu_src_chain_solver, ikgpu_src_chain_solver_end},
                         {"chain_kernel_body.hpp", ikgpu_src_chain_kernel_body, ikgpu_src_chain_kernel_body_end},
-                        {"chain_hot.hpp", ikgpu_src_chain_hot, ikgpu_src_chain_hot_end}};
+                        {"chain_hot.hpp", ikgpu_src_chain_hot, ikgpu_src_chain_hot_end},
+                        {"tree_solver.hpp", ikgpu_src_tree_solver, ikgpu_src_tree_solver_end},
+                        {"generic_solver.hpp", ikgpu_src_generic_solver, ikgpu_src_generic_solver_end}};
+constexpr int kNumHeaders = static_cast<int>(sizeof kHeaders / sizeof kHeaders[0]);
+
+uint64_t source_hash(const std::string &src) {
+    const RtcApi &api = rtc_api();
     uint64_t h = 14695981039346656037ull;
-    for (const Hdr &x : hdrs) h = fnv1a(h, x.begin, static_cast<size_t>(x.end - x.begin));
+    for (const Hdr &x : kHeaders) h = fnv1a(h, x.begin, static_cast<size_t>(x.end - x.begin));
     h = fnv1a(h, src.data(), src.size());
     for (const char *f : kFlags) h = fnv1a(h, f, std::strlen(f));
     int vmaj = 0, vmin = 0;
     if (api.version) (void)api.version(&vmaj, &vmin);
     h = fnv1a(h, &vmaj, sizeof vmaj);
-    h = fnv1a(h, &vmin, sizeof vmin);
-    char name[64];
-    std::snprintf(name, sizeof name, "/chain_hot_%016llx.hsaco", static_cast<unsigned long long>(h));
-    const std::string path = cache_dir() + name;
-    if (read_file(path, hc.code)) { hc.ok = true; hc.log = "cached: " + path; return hc; }
+    return fnv1a(h, &vmin, sizeof vmin);
+}
 
+// Compiles `src` against the embedded device headers, or fetches the code object from the on-disk cache (file name: prefix + the
+// hash of headers, source, flags and hipRTC version).  IKGPU_RTC_DUMP=<dir>: also writes the generated source there.
+void compile_cached(const char *prefix, const std::string &src, HotCode &hc) {
+    hc.tried = true;
+    const RtcApi &api = rtc_api();
+    if (!api.ok) { hc.log = "libhiprtc could not be loaded"; return; }
+    const uint64_t h = source_hash(src);
+    char name[96];
+    std::snprintf(name, sizeof name, "/%s_%016llx", prefix, static_cast<unsigned long long>(h));
+    if (const char *dump = std::getenv("IKGPU_RTC_DUMP")) {
+        std::vector<char> text(src.begin(), src.end());
+        write_file_atomically(std::string(dump) + name + ".hip", text);
+    }
+    const std::string path = cache_dir() + name + ".hsaco";
+    if (read_file(path, hc.code)) { hc.ok = true; hc.log = "cached: " + path; return; }
     hiprtcProgram prog = nullptr;
-    const char *hsrc[4], *hname[4];
-    for (int i = 0; i < 4; ++i) { hsrc[i] = hdrs[i].begin; hname[i] = hdrs[i].name; }
-    if (api.create(&prog, src.c_str(), "ikgpu_chain_hot.hip", 4, hsrc, hname) != HIPRTC_SUCCESS) { hc.log = "hiprtcCreateProgram failed"; return hc; }
+    const char *hsrc[kNumHeaders], *hname[kNumHeaders];
+    for (int i = 0; i < kNumHeaders; ++i) { hsrc[i] = kHeaders[i].begin; hname[i] = kHeaders[i].name; }
+    if (api.create(&prog, src.c_str(), "ikgpu_rtc.hip", kNumHeaders, hsrc, hname) != HIPRTC_SUCCESS) { hc.log = "hiprtcCreateProgram failed"; return; }
     const hiprtcResult rc = api.compile(prog, static_cast<int>(sizeof kFlags / sizeof kFlags[0]), const_cast<const char **>(kFlags));
     size_t ls = 0;
     if (api.log_size(prog, &ls) == HIPRTC_SUCCESS && ls > 1) {
@@ -213,7 +226,13 @@ HotCode &code_for(const ProblemHost &ph) {
     }
     (void)api.destroy(&prog);
     if (hc.ok) write_file_atomically(path, hc.code);
-    else if (std::getenv("IKGPU_RTC_VERBOSE")) std::fprintf(stderr, "ikgpu: run-time compilation of the chain kernel failed:\n%s\n", hc.log.c_str());
+    else if (std::getenv("IKGPU_RTC_VERBOSE")) std::fprintf(stderr, "ikgpu: run-time compilation failed:\n%s\n", hc.log.c_str());
+}
+
+// Compiles (or fetches) the code object of this shape.  Called with g_mu held.
+HotCode &code_for(const ProblemHost &ph) {
+    HotCode &hc = g_codes[key_of(ph)];
+    if (!hc.tried) compile_cached("chain_hot", hot_source(ph.chain.nj, ph.chain_struct.code, ph.chain_struct.values), hc);
     return hc;
 }
 
@@ -292,6 +311,78 @@ hipError_t launch_shape(const ProblemHost &ph, const DeviceTables &dt, const Bat
     return e;
 }
 
+// ---- the generic lane program specialised for ONE problem (device/generic_solver.hpp with IKD_STATIC_TABLES) -----------------------
+// The model tree and the task table become `static constexpr` members of a generated type; the workspace is a local array.  With
+// every loop unrolled the compiler sees the whole iteration as straight-line code over constants: FK of joints no task reads is
+// dead, the dense M x nv Jacobian keeps only its structurally non-zero entries, the workspace lives in registers.
+
+std::string hexd(double v) {
+    char b[64];
+    if (v != v) return "__builtin_nan(\"\")";
+    if (v > 1.7976931348623157e308) return "__builtin_inf()";
+    if (v < -1.7976931348623157e308) return "(-__builtin_inf())";
+    std::snprintf(b, sizeof b, "%a", v);
+    return b;
+}
+
+template <class It>
+std::string int_array(const char *name, It begin, int n) {
+    std::string o = std::string("    static constexpr int ") + name + "[] = {";
+    for (int i = 0; i < n; ++i) o += std::to_string(static_cast<long long>(begin[i])) + (i + 1 < n ? ", " : "");
+    if (n == 0) o += "0";
+    return o + "};\n";
+}
+
+template <class It>
+std::string dbl_array(const char *name, It begin, int n) {
+    std::string o = std::string("    static constexpr double ") + name + "[] = {";
+    for (int i = 0; i < n; ++i) o += hexd(begin[i]) + (i + 1 < n ? ", " : "");
+    if (n == 0) o += "0.0";
+    return o + "};\n";
+}
+
+std::string generic_static_source(const ProblemHost &ph) {
+    const GenericHost &g = ph.generic;
+    const int nj = g.njoints, nt = ph.ntasks;
+    const int32_t *I = g.ints.data();
+    const double *D = g.dbls.data();
+    std::string o = "#define IKD_STATIC_TABLES 1\n#include \"chain_kernel_body.hpp\"\n#include \"generic_solver.hpp\"\nnamespace {\nstruct T {\n";
+    auto scalar = [&](const char *n, long long v) { o += std::string("    static constexpr int ") + n + " = " + std::to_string(v) + ";\n"; };
+    scalar("njoints", nj); scalar("nq", ph.nq); scalar("nv", ph.nv); scalar("ntasks", nt); scalar("M", ph.rows);
+    o += int_array("jtype", I + g.o_jtype, nj) + int_array("parent", I + g.o_parent, nj) + int_array("idx_q", I + g.o_idx_q, nj) + int_array("idx_v", I + g.o_idx_v, nj);
+    o += dbl_array("placement", D + g.o_placement, 12 * nj) + dbl_array("axis", D + g.o_axis, 3 * nj);
+    o += dbl_array("lower", D + g.o_lower, ph.nq) + dbl_array("upper", D + g.o_upper, ph.nq);
+    o += int_array("t_type", I + g.o_ttype, nt) + int_array("t_fjoint", I + g.o_tfjoint, nt) + int_array("t_rjoint", I + g.o_trjoint, nt);
+    o += int_array("t_row", I + g.o_trow, nt) + int_array("t_dim", I + g.o_tdim, nt) + int_array("t_prio", I + g.o_tprio, nt);
+    o += dbl_array("t_fpl", D + g.o_tfpl, 12 * nt) + dbl_array("t_rpl", D + g.o_trpl, 12 * nt) + dbl_array("t_w", D + g.o_tw, 6 * nt);
+    scalar("off_q", g.off_q); scalar("off_oMi", g.off_oMi); scalar("off_Jw", g.off_Jw); scalar("off_e", g.off_e); scalar("off_J", g.off_J);
+    scalar("off_G", g.off_G); scalar("off_y", g.off_y); scalar("off_dq", g.off_dq); scalar("ws_words", g.ws_words);
+    scalar("nlevels", g.nlevels);
+    o += int_array("lvl_row0", I + g.o_lvlrow0, g.nlevels + 1);
+    const int nc = static_cast<int>(ph.constraints.size());
+    scalar("ncons", nc); scalar("Mc", ph.crows); scalar("off_Jc", g.off_Jc);
+    o += int_array("c_type", I + g.o_ctype, nc) + int_array("c_fjoint", I + g.o_cfjoint, nc) + int_array("c_rjoint", I + g.o_crjoint, nc);
+    o += int_array("c_row", I + g.o_crow, nc) + int_array("c_dim", I + g.o_cdim, nc);
+    o += dbl_array("c_fpl", D + g.o_cfpl, 12 * nc) + dbl_array("c_rpl", D + g.o_crpl, 12 * nc);
+    scalar("has_com", g.has_com); scalar("off_sf", g.off_sf);
+    if (g.has_com) o += dbl_array("j_mass", D + g.o_jmass, nj) + dbl_array("j_lever", D + g.o_jlever, 3 * nj) + dbl_array("j_submass", D + g.o_jsubmass, nj);
+    else o += "    static constexpr double j_mass[] = {0.0}, j_lever[] = {0.0}, j_submass[] = {0.0};\n";
+    o += "    static constexpr double inv_total_mass = " + hexd(g.inv_total_mass) + ";\n";
+    o += "};\n}  // namespace\n"
+         "extern \"C\" __global__ __launch_bounds__(64) void ikgpu_lane_dls(const ikdev::GenericKernelArgs a) {\n"
+         "    double w[T::ws_words];\n"
+         "    ikdev::dls_generic_body_ws(a, T{}, static_cast<int64_t>(blockIdx.x) * 64 + threadIdx.x, ikdev::WsReg{w}, [](bool act) { return __any(act) != 0; });\n"
+         "}\n";
+    return o;
+}
+
+struct GenModule {
+    hipModule_t mod = nullptr;
+    hipFunction_t dls = nullptr;
+};
+std::map<uint64_t, HotCode> g_gen_codes;                      // by hash of the generated source
+std::map<std::pair<uint64_t, int>, GenModule> g_gen_modules;   // (hash, device)
+
 }  // namespace
 
 bool rtc_chain_hot_available(const ProblemHost &ph, bool compile) {
@@ -324,6 +415,56 @@ hipError_t rtc_launch_chain_hot(const ProblemHost &ph, const DeviceTables &dt, c
 #undef X
         default: return hipErrorInvalidValue;
     }
+}
+
+}  // namespace ikgpu
+
+namespace ikgpu {
+
+// What the static program takes: sizes the unrolled program stays compilable at (constraints project by Gram-Schmidt there).  IKGPU_GENERIC_KERNEL (lane / lds / coop: tests, A/B) keeps the other forms.
+bool rtc_generic_static_available(const ProblemHost &gen, bool compile, uint64_t *key_out) {
+    if (!rtc_enabled() || gen.kind != KernelKind::Generic || gen.crows > 12) return false;
+    if (std::getenv("IKGPU_GENERIC_KERNEL")) return false;
+    if (const char *env = std::getenv("IKGPU_GENERIC_STATIC")) { if (env[0] == '0') return false; }
+    if (gen.rows < 1 || gen.rows > 24 || gen.nv > 32 || gen.generic.ws_words > 1400) return false;
+    if (!rtc_api().ok) return false;
+    if (!compile) return true;
+    const std::string src = generic_static_source(gen);
+    const uint64_t key = source_hash(src);
+    if (key_out) *key_out = key;
+    std::lock_guard<std::mutex> lock(g_mu);
+    HotCode &hc = g_gen_codes[key];
+    if (!hc.tried) compile_cached("generic_static", src, hc);
+    g_last_log = hc.log;
+    return hc.ok;
+}
+
+hipError_t rtc_launch_generic_static(const ProblemHost &gen, uint64_t key, const BatchIO &io, const ikgpu_dls_params &prm, hipStream_t stream) {
+    GenModule m;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        GenModule &gm = g_gen_modules[std::make_pair(key, dev)];
+        if (!gm.mod) {
+            const HotCode &hc = g_gen_codes[key];
+            if (!hc.ok) return hipErrorInvalidImage;
+            hipError_t e = hipModuleLoadData(&gm.mod, hc.code.data());
+            if (e == hipSuccess) e = hipModuleGetFunction(&gm.dls, gm.mod, "ikgpu_lane_dls");
+            if (e != hipSuccess) { gm = GenModule{}; return e; }
+        }
+        m = gm;
+    }
+    ikdev::GenericKernelArgs a{};
+    a.prm.max_iterations = prm.max_iterations;
+    a.prm.lam2 = prm.damping * prm.damping;
+    a.prm.step_length = prm.step_length;
+    a.prm.stop_sq_tol = prm.stop_sq_tol;
+    a.layout = io.layout; a.B = io.B; a.q0 = io.q0; a.targets = io.targets;
+    a.q_out = io.q_out; a.success = io.success; a.iters = io.iters;
+    size_t nbytes = sizeof a;
+    void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &nbytes, HIP_LAUNCH_PARAM_END};
+    return hipModuleLaunchKernel(m.dls, static_cast<unsigned>((io.B + 63) / 64), 1, 1, 64, 1, 1, 0, stream, nullptr, config);
 }
 
 }  // namespace ikgpu

@@ -11,6 +11,11 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 MODELS = os.path.join(ROOT, "fixtures", "models")
 
+# The product routes a Tree-kind problem with few rows to the lane program specialised for it at run time (capi.cpp
+# tree_prefers_static: rows <= 12).  The tests written for the tree kernel keep it under test by switching that routing off for the
+# session; tests/test_gpu_static.py switches it back on and checks the routed problems against the oracle AND the tree kernel.
+os.environ.setdefault("IKGPU_TREE_STATIC_ROWS", "0")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

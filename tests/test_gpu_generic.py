@@ -28,8 +28,10 @@ def T4(m12):
     return M
 
 
-def build(name, ff, specs, B, seed=0, xml_edit=None):
-    """specs: (kind 'frame'|'align', frame, reference, type-or-axis, priority, weights)."""
+def build(name, ff, specs, B, seed=0, xml_edit=None, static=True):
+    """specs: (kind 'frame'|'align', frame, reference, type-or-axis, priority, weights).
+    static: False keeps a generic problem off the run-time specialised lane program (IKGPU_GENERIC_STATIC=0 when the handle is
+    created): the cooperative / per-lane memory-resident forms then run."""
     import ik_amd
     import oracle as O
     from ik_amd import workload
@@ -54,7 +56,19 @@ def build(name, ff, specs, B, seed=0, xml_edit=None):
             task = problem.add_frame_task("t%d" % i, ik_amd.FrameTask.create(model, f, ik_amd.KinematicType(t), r), p)
         if w is not None:
             task.weighting()[:] = w
-    data = ik_amd.dls_data(problem, device=0)
+    prev = os.environ.get("IKGPU_GENERIC_STATIC")
+    if not static:
+        os.environ["IKGPU_GENERIC_STATIC"] = "0"
+    try:
+        data = ik_amd.dls_data(problem, device=0)
+    finally:
+        if not static:
+            if prev is None:
+                del os.environ["IKGPU_GENERIC_STATIC"]
+            else:
+                os.environ["IKGPU_GENERIC_STATIC"] = prev
+    if not static:
+        assert not data.kernel.endswith(",static>"), data.kernel
     om = O.OracleModel(model.flat())
     ordered = problem.ordered_tasks()
     ospec = []
@@ -174,14 +188,19 @@ CHAOTIC_AT_FULL_STEP = {"com_in_foot_frame", "demo_task_set", "demo_with_directi
 FORCED_GENERIC = {"posture_regulariser", "fixed_two_feet_priorities", "posture_first_level"}
 
 
+@pytest.mark.parametrize("static", [True, False], ids=["static", "coop"])
 @pytest.mark.parametrize("case", sorted(CASES))
-def test_generic_kernel_matches_oracle(torch_cuda, case, monkeypatch):
+def test_generic_kernel_matches_oracle(torch_cuda, case, static, monkeypatch):
+    """Every generic problem on BOTH forms a handle can get: the lane program specialised for the problem at run time ("...,static>",
+    rtc.cpp) and the cooperative LDS-resident kernel (IKGPU_GENERIC_STATIC=0)."""
     torch = torch_cuda
     name, ff, specs, edit = CASES[case]
     B = 500  # not a multiple of 64
     if case in FORCED_GENERIC:
         monkeypatch.setenv("IKGPU_DLS_KERNEL", "generic")
-    ik_amd, O, model, problem, data, om, ot, q0, tg = build(name, ff, specs, B, xml_edit=edit)
+    ik_amd, O, model, problem, data, om, ot, q0, tg = build(name, ff, specs, B, xml_edit=edit, static=static)
+    if case == "demo_task_set" and not static:
+        pytest.skip("the demo task set runs on the tree kernel either way")
     assert data.kernel.startswith("dls_tree<NJ=7,chains=1,base_task,base_reference,align_axis>" if case == "demo_task_set" else "dls_generic<")
     Q0 = torch.from_numpy(np.ascontiguousarray(q0.T)).cuda()
     T = torch.from_numpy(np.ascontiguousarray(tg.transpose(1, 2, 0))).cuda()
@@ -221,8 +240,9 @@ def test_cooperative_and_per_lane_generic_kernels_agree(torch_cuda, case, monkey
     B = 1003   # not a multiple of 4 (problems per workgroup) nor of 64
     if case in FORCED_GENERIC:
         monkeypatch.setenv("IKGPU_DLS_KERNEL", "generic")
-    ik_amd, O, model, problem, data, om, ot, q0, tg = build(name, ff, specs, B, seed=3, xml_edit=edit)
-    assert data.kernel.startswith("dls_generic<")
+    ik_amd, O, model, problem, data, om, ot, q0, tg = build(name, ff, specs, B, seed=3, xml_edit=edit, static=False)
+    assert data.kernel.startswith("dls_generic<") and not data.kernel.endswith(",static>")
+    data_static = build(name, ff, specs, B, seed=3, xml_edit=edit, static=True)[4]
     Q0 = torch.from_numpy(np.ascontiguousarray(q0.T)).cuda()
     T = torch.from_numpy(np.ascontiguousarray(tg.transpose(1, 2, 0))).cuda()
     for iters, damping, step, tol in ((1, 1e-2, 1.0, -1.0), (3, 1e-2, 1.0, -1.0), (200, 1e-1, 1e-1, 1e-4)):
@@ -230,6 +250,10 @@ def test_cooperative_and_per_lane_generic_kernels_agree(torch_cuda, case, monkey
         v = ik_amd.inverse_kinematics_visitor(tol)
         monkeypatch.delenv("IKGPU_GENERIC_KERNEL", raising=False)
         Qc, okc, itc = ik_amd.dls_batch(problem, Q0, T, data, v, p)
+        if data_static.kernel.endswith(",static>"):     # the run-time specialised lane program: same flags, same q to 1e-9
+            Qs, oks, its = ik_amd.dls_batch(problem, Q0, T, data_static, v, p)
+            assert torch.equal(okc, oks) and torch.equal(itc, its), (case, iters, "static")
+            assert (Qc - Qs).abs().max().item() < 1e-9, (case, iters, "static")
         Qc2, _, _ = ik_amd.dls_batch(problem, Q0, T, data, v, p)
         assert torch.equal(Qc, Qc2)                                  # run-to-run bit-identical (no lane races)
         monkeypatch.setenv("IKGPU_GENERIC_KERNEL", "lane")

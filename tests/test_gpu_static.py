@@ -1,0 +1,106 @@
+"""The generic lane program specialised for ONE problem at run time (rtc.cpp, device/generic_solver.hpp with IKD_STATIC_TABLES): the
+model tree and the task table are compile-time constants, the workspace is a register array, every loop is unrolled.  It is what a
+generic problem runs on by default ("dls_generic<...,static>") and what a Tree-kind problem with few rows is routed to
+(capi.cpp tree_prefers_static).  Here: the routing, parity with the oracle, and agreement with the kernels it replaces."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import urdf_path
+from test_gpu_generic import CASES, build
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def torch_cuda(native_built):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+DEMO = [("frame", "LeftFootFront", "pelvis", 0, 0, None), ("frame", "pelvis", "universe", 2, 0, None), ("align", "LeftFootFront", "universe", 1, 0, None)]
+ROUTED = {
+    # name: (model, free-flyer, task specs, constraint (frame, type) or None)
+    "demo_task_set": ("cassie", True, DEMO, None),
+    "demo_right_foot_pinned": ("cassie", True, DEMO, ("RightFootFront", 0)),
+    "fixed_two_feet_positions": ("cassie_fixed", False, [("frame", "LeftFootFront", "universe", 0, 0, None), ("frame", "RightFootFront", "universe", 0, 0, None)], None),
+    "pelvis_and_foot": ("cassie", True, [("frame", "pelvis", "universe", 2, 0, None), ("frame", "RightFootFront", "universe", 2, 0, [1.0, 2.0, 0.5, 1.0, 1.0, 3.0])], None),
+}
+
+
+def _build(name, B, rows, seed=0):
+    """(data routed by the product's default, data on the tree kernel, ...): the same problem twice."""
+    import ik_amd
+    model_name, ff, specs, cons = ROUTED[name]
+    out = {}
+    for label, val in (("static", str(rows)), ("tree", "0")):
+        os.environ["IKGPU_TREE_STATIC_ROWS"] = val
+        try:
+            ik, O, model, problem, data, om, ot, q0, tg = build(model_name, ff, specs, B, seed=seed)
+            if cons:
+                problem.add_frame_constraint("c", ik_amd.FrameConstraint.create(model, cons[0], ik_amd.KinematicType(cons[1])))
+                data = ik_amd.dls_data(problem, device=0)
+        finally:
+            os.environ["IKGPU_TREE_STATIC_ROWS"] = "0"
+        out[label] = (ik, O, model, problem, data, om, ot, q0, tg)
+    return out
+
+
+@pytest.mark.parametrize("name", sorted(ROUTED))
+def test_small_tree_problems_run_on_the_static_program_and_agree_with_the_tree_kernel_and_the_oracle(torch_cuda, name):
+    torch = torch_cuda
+    B = 4096 + 13
+    both = _build(name, B, 12)
+    ik, O, model, problem, data_s, om, ot, q0, tg = both["static"]
+    data_t = both["tree"][4]
+    if not data_s.kernel.endswith(",static>"):
+        pytest.skip("hipRTC unavailable: %s" % data_s.kernel)
+    assert data_s.kernel.startswith("dls_generic<") and data_t.kernel.startswith("dls_tree<"), (data_s.kernel, data_t.kernel)
+    cons = ROUTED[name][3]
+    Q0 = torch.from_numpy(np.ascontiguousarray(q0.T)).cuda()
+    T = torch.from_numpy(np.ascontiguousarray(tg.transpose(1, 2, 0))).cuda()
+    for iters, damping, step, tol in ((1, 1e-2, 1.0, -1.0), (50, 1e-2, 1.0, -1.0), (100, 1e-1, 0.5, 1e-4)):
+        p = ik.dls_parameters(max_iterations=iters, damping=damping, step_length=step)
+        v = ik.inverse_kinematics_visitor(tol)
+        Qs, oks, its = ik.dls_batch(problem, Q0, T, data_s, v, p)
+        Qt, okt, itt = ik.dls_batch(both["tree"][3], Q0, T, data_t, v, p)
+        prm = O.params(iters, damping, step, tol)
+        if cons:
+            oc = O.make_tasks([(model.getFrameId(cons[0]), 0, cons[1], 0, None)])
+            q_ref, ok_ref, it_ref = O.dls_batch_constrained(om, ot, oc, tg, q0, prm, os.cpu_count() or 1)
+        else:
+            q_ref, ok_ref, it_ref = O.dls_batch(om, ot, tg, q0, prm, os.cpu_count() or 1)
+        same = its.cpu().numpy() == it_ref                     # (a stop decision within rounding of the tolerance may flip: rare)
+        assert same.mean() > 0.999 and np.array_equal(oks.cpu().numpy()[same], ok_ref[same]), (name, iters)
+        d = np.abs(Qs.cpu().numpy().T - q_ref).max(axis=1)
+        assert d[same].max() <= TOL, (name, iters, d[same].max())
+        agree = (its == itt)
+        assert agree.double().mean().item() > 0.999
+        assert (Qs - Qt).abs().max(dim=0).values[agree].max().item() <= 1e-8, (name, iters)
+    print("%s: %s replaces %s" % (name, data_s.kernel, data_t.kernel))
+
+
+@pytest.mark.parametrize("case", ["shared_joints", "moving_reference_prismatic", "com_of_the_arm", "demo_with_direction_in_pelvis_frame"])
+def test_static_generic_program_full_size_properties(torch_cuda, case):
+    """B = 65536 on the static program: results independent of the batch composition (a problem solved alone or in the batch gives
+    the same bits), run-to-run identical, within the joint limits."""
+    torch = torch_cuda
+    name, ff, specs, edit = CASES[case]
+    ik, O, model, problem, data, om, ot, q0, tg = build(name, ff, specs, 512, seed=5, xml_edit=edit)
+    if not data.kernel.endswith(",static>"):
+        pytest.skip("hipRTC unavailable: %s" % data.kernel)
+    rep = 65536 // 512
+    Q0 = torch.from_numpy(np.ascontiguousarray(np.tile(q0, (rep, 1)).T)).cuda()
+    T = torch.from_numpy(np.ascontiguousarray(np.tile(tg, (rep, 1, 1)).transpose(1, 2, 0))).cuda()
+    p = ik.dls_parameters(max_iterations=50, damping=1e-1, step_length=0.5)
+    Q, ok, it = ik.dls_batch(problem, Q0, T, data, ik.never_stop_visitor(), p)
+    Q2, _, _ = ik.dls_batch(problem, Q0, T, data, ik.never_stop_visitor(), p)
+    assert torch.equal(Q, Q2)
+    assert torch.equal(Q[:, :512], Q[:, 512 * 77:512 * 78])           # every copy of a problem gives the same bits
+    Qs, _, _ = ik.dls_batch(problem, Q0[:, :512].contiguous(), T[:, :, :512].contiguous(), data, ik.never_stop_visitor(), p)
+    assert torch.equal(Q[:, :512], Qs)
+    lo, hi = torch.from_numpy(model.lowerPositionLimit).cuda(), torch.from_numpy(model.upperPositionLimit).cuda()
+    assert (Q >= lo[:, None] - 1e-15).all() and (Q <= hi[:, None] + 1e-15).all()

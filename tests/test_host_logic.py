@@ -15,6 +15,11 @@ from conftest import MODELS, ROOT, urdf_path
 import twin as T
 
 
+def _g(name):
+    """A generic problem's kernel name without the build suffix (",static>": the lane program specialised at run time, when hipRTC is there)."""
+    return name.replace(",static>", ">")
+
+
 @pytest.fixture(scope="module")
 def ik(native_built):
     import ik_amd
@@ -85,7 +90,7 @@ def test_centre_of_mass_task_plan_and_errors(ik):
     com.target[:] = [0.0, 0.0, 1.0]                                              # reference ik_ros/src/cassie.cpp:101
     assert api._abi_rows(com, 1) == [(0, 0, capi.CENTRE_OF_MASS, 1, [1.0] * 6)]
     assert api._target_slots(com)[0, 9:].tolist() == [0.0, 0.0, 1.0]
-    assert ik.plan(p) == "dls_generic<M=9,nv=22,joints=17>"
+    assert _g(ik.plan(p)) == "dls_generic<M=9,nv=22,joints=17>"
     with pytest.raises(ValueError):
         p.add_centre_of_mass_task(ik.CentreOfMassTask.create(m), 1)
     # a model without masses cannot carry the task
@@ -199,16 +204,16 @@ def test_every_other_shape_maps_to_the_generic_kernel(ik):
     """Shapes without a register-resident specialisation run on the memory-resident generic kernel -- on the
     device, never on a CPU path."""
     m, p = _problem(ik, "ur5", ["tool0"], reference="wrist_1_link")          # reference frame moves with q
-    assert ik.plan(p) == "dls_generic<M=6,nv=6,joints=6>"
+    assert _g(ik.plan(p)) == "dls_generic<M=6,nv=6,joints=6>"
     m, p = _problem(ik, "cassie_fixed", ["LeftFootFront", "LeftFootBack"])   # fixed base, two tasks sharing their joints
-    assert ik.plan(p) == "dls_generic<M=12,nv=16,joints=16>"
+    assert _g(ik.plan(p)) == "dls_generic<M=12,nv=16,joints=16>"
     m, p = _problem(ik, "cassie_fixed", ["LeftFootFront", "RightFootFront"])  # fixed base, two disjoint chains: the tree kernel
     assert ik.plan(p) == "dls_tree<NJ=7,chains=2,fixed_base>"                 # with its base block dropped
     m, p = _problem(ik, "cassie", ["LeftFootFront", "RightFootFront", "LeftFootBack"], ff=True)   # three chain tasks
-    assert ik.plan(p) == "dls_generic<M=18,nv=22,joints=17>"
+    assert _g(ik.plan(p)) == "dls_generic<M=18,nv=22,joints=17>"
     m, p = _problem(ik, "cassie", ["LeftFootFront", "pelvis"], ff=True)
     p.add_align_axis_task("align", ik.AlignAxisTask.create(m, "RightFootFront", ik.AlignAxisType.AxisY))   # row on a frame with no task
-    assert ik.plan(p) == "dls_generic<M=13,nv=22,joints=17>"
+    assert _g(ik.plan(p)) == "dls_generic<M=13,nv=22,joints=17>"
 
 
 def test_the_demo_task_set_has_a_register_resident_kernel(ik):

@@ -1,4 +1,4 @@
-"""Kernel time of the three forms of the generic DLS kernel (cooperative LDS / per-lane HBM / per-lane LDS) on problems that
+"""Kernel time of the forms of the generic DLS kernel (cooperative LDS / per-lane HBM / per-lane LDS / the lane program specialised at run time) on problems that
 plan onto it, B = 65536, 50 iterations.
     python tools/generic_forms.py [case ...]"""
 import os
@@ -23,8 +23,13 @@ for case in cases:
     T = torch.from_numpy(np.ascontiguousarray(np.tile(tg, (rep, 1, 1)).transpose(1, 2, 0))).cuda()
     p = ik.dls_parameters(max_iterations=50, damping=1e-1, step_length=0.5)
     res = {}
-    for form in ("coop", "lane", "lds"):
-        os.environ["IKGPU_GENERIC_KERNEL"] = "" if form == "coop" else form
+    for form in ("coop", "lane", "lds", "static"):
+        os.environ.pop("IKGPU_GENERIC_KERNEL", None)
+        os.environ.pop("IKGPU_GENERIC_STATIC", None)
+        if form in ("lane", "lds"):
+            os.environ["IKGPU_GENERIC_KERNEL"] = form
+        elif form == "coop":
+            os.environ["IKGPU_GENERIC_STATIC"] = "0"
         data = ik.dls_data(problem, device=0)
         Q = None
         for _ in range(2):
