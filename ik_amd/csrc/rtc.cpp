@@ -196,8 +196,23 @@ uint64_t source_hash(const std::string &src) {
 
 // Compiles `src` against the embedded device headers, or fetches the code object from the on-disk cache (file name: prefix + the
 // hash of headers, source, flags and hipRTC version).  IKGPU_RTC_DUMP=<dir>: also writes the generated source there.
-void compile_cached(const char *prefix, const std::string &src, HotCode &hc) {
+void compile_cached(const char *prefix, const std::string &src_in, HotCode &hc) {
     hc.tried = true;
+    std::string src = src_in;
+    // (debugging aid: IKGPU_RTC_DEFINES="-DX -DY" is prepended to the source as #define lines and so takes part in the cache key)
+    if (const char *defs = std::getenv("IKGPU_RTC_DEFINES")) {
+        std::string d(defs), pre;
+        size_t pos = 0;
+        while ((pos = d.find("-D", pos)) != std::string::npos) {
+            size_t end = d.find(' ', pos);
+            if (end == std::string::npos) end = d.size();
+            std::string item = d.substr(pos + 2, end - pos - 2);
+            const size_t eq = item.find('=');
+            pre += "#define " + (eq == std::string::npos ? item + " 1" : item.substr(0, eq) + " " + item.substr(eq + 1)) + "\n";
+            pos = end;
+        }
+        src = pre + src;
+    }
     const RtcApi &api = rtc_api();
     if (!api.ok) { hc.log = "libhiprtc could not be loaded"; return; }
     const uint64_t h = source_hash(src);
@@ -213,7 +228,17 @@ void compile_cached(const char *prefix, const std::string &src, HotCode &hc) {
     const char *hsrc[kNumHeaders], *hname[kNumHeaders];
     for (int i = 0; i < kNumHeaders; ++i) { hsrc[i] = kHeaders[i].begin; hname[i] = kHeaders[i].name; }
     if (api.create(&prog, src.c_str(), "ikgpu_rtc.hip", kNumHeaders, hsrc, hname) != HIPRTC_SUCCESS) { hc.log = "hiprtcCreateProgram failed"; return; }
-    const hiprtcResult rc = api.compile(prog, static_cast<int>(sizeof kFlags / sizeof kFlags[0]), const_cast<const char **>(kFlags));
+    // (debugging aid: IKGPU_RTC_PLAIN_FLAGS drops the three no-signed-zeros / no-NaN / no-infinity flags; set it together with a
+    // fresh IKGPU_CACHE_DIR -- the flags are part of the cache key only in their default form)
+    std::vector<const char *> flags(kFlags, kFlags + sizeof kFlags / sizeof kFlags[0]);
+    if (const char *m = std::getenv("IKGPU_RTC_PLAIN_FLAGS")) {   // bit k set: drop the k-th of the three flags
+        const long mask = std::strtol(m, nullptr, 10);
+        std::vector<const char *> keep(kFlags, kFlags + 5);
+        for (int k = 0; k < 3; ++k)
+            if (!((mask >> k) & 1)) keep.push_back(kFlags[5 + k]);
+        flags = keep;
+    }
+    const hiprtcResult rc = api.compile(prog, static_cast<int>(flags.size()), flags.data());
     size_t ls = 0;
     if (api.log_size(prog, &ls) == HIPRTC_SUCCESS && ls > 1) {
         hc.log.resize(ls);
