@@ -330,13 +330,28 @@ IKD_FN double coop_evaluate(const GenericTables &T, const CoopLayout &L, const i
 template <int N>
 IKD_FN double group_bcast(double x) { return __builtin_amdgcn_update_dpp(x, x, 0x150 + N, 0xf, 0xf, false); }
 // acc += (x in lane N of the group) * y, ONE instruction (v_fmac_f64 with a DPP row broadcast on its first source; the broadcast as a
-// separate v_mov_b64_dpp costs two more issue slots, profiles/r02_issue_probe_dpp.csv).  The source register must not have been
-// written by the instruction just before (a VALU write needs two wait states before a DPP read: callers fence with dpp_settle()).
+// separate v_mov_b64_dpp costs two more issue slots, profiles/r02_issue_probe_dpp.csv).
+// HAZARD (a VALU write needs two wait states before a DPP read of the same VGPR): LLVM's hazard recogniser sees neither the writes
+// nor the DPP reads of inline asm, so every such pair that involves an asm statement is fenced IN THE CODE by an s_nop that is
+// data-tied to the register in question -- the producer is ordered before the nop, every later reader after it:
+//   * a compiler-generated VALU write read by an asm DPP (the pivot column `lik`):  dpp_settle(lik) before the asm block;
+//   * an asm fmac's write read by a compiler-generated DPP (group_bcast of row[K] at the next pivot; the right-hand-side broadcasts):
+//     dpp_settle(row[K]) / dpp_settle_all(row) before the group_bcast.
 template <int N>
 IKD_FN void fmac_bcast(double &acc, const double x_lane_n, const double y) {
     asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x_lane_n), "v"(y), "n"(N));
 }
-IKD_FN void dpp_settle() { asm volatile("s_nop 1"); }
+IKD_FN void dpp_settle(double &x) { asm volatile("s_nop 1" : "+v"(x)); }
+IKD_FN void dpp_settle(double &x, double &y) { asm volatile("s_nop 1" : "+v"(x), "+v"(y)); }
+template <int N>
+IKD_FN void dpp_settle_all(double (&r)[N]) {   // one s_nop ordered after the last write of every element
+    static_assert(N == 16 || N == 32, "register rows of the cooperative solver");
+    asm volatile("s_nop 1" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]),
+                 "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]));
+    if constexpr (N == 32)
+        asm volatile("s_nop 1" : "+v"(r[16]), "+v"(r[17]), "+v"(r[18]), "+v"(r[19]), "+v"(r[20]), "+v"(r[21]), "+v"(r[22]), "+v"(r[23]), "+v"(r[24]),
+                     "+v"(r[25]), "+v"(r[26]), "+v"(r[27]), "+v"(r[28]), "+v"(r[29]), "+v"(r[30]), "+v"(r[31]));
+}
 // Eight columns of two dot products in ONE asm statement: s0 += x_c(lane J0) x_c, s1 += x_c(lane J1) x_c, c = 0 .. 7, the two
 // accumulators alternating (a v_fmac_f64_dpp that depends on the one before takes 8 cycles, independent ones 4.8), and nothing of the
 // compiler's between them (it puts an s_nop after every single-instruction asm statement whose result the next one reads).
@@ -348,7 +363,7 @@ IKD_FN void fmac2_bcast8(double &s0, double &s1, const double c0, const double c
                  IKC_F2(1, 1, 4, 4, 11) IKC_F2(0, 0, 5, 5, 10) IKC_F2(1, 1, 5, 5, 11) IKC_F2(0, 0, 6, 6, 10) IKC_F2(1, 1, 6, 6, 11)
                  IKC_F2(0, 0, 7, 7, 10) IKC_F2(1, 1, 7, 7, 11) IKC_F2(0, 0, 8, 8, 10) IKC_F2(1, 1, 8, 8, 11) IKC_F2(0, 0, 9, 9, 10)
                  IKC_F2(1, 1, 9, 9, 11)
-                 : "+v"(s0), "+v"(s1)
+                 : "+&v"(s0), "+&v"(s1)   // (written before the last inputs are read: never in a register an input lives in)
                  : "v"(c0), "v"(c1), "v"(c2), "v"(c3), "v"(c4), "v"(c5), "v"(c6), "v"(c7), "n"(J0), "n"(J1));
 }
 template <int J0>
@@ -356,7 +371,7 @@ IKD_FN void fmac1_bcast8(double &s0, const double c0, const double c1, const dou
                          const double c6, const double c7) {
     asm volatile(IKC_F2(0, 0, 1, 1, 9) IKC_F2(0, 0, 2, 2, 9) IKC_F2(0, 0, 3, 3, 9) IKC_F2(0, 0, 4, 4, 9) IKC_F2(0, 0, 5, 5, 9) IKC_F2(0, 0, 6, 6, 9)
                  IKC_F2(0, 0, 7, 7, 9) IKC_F2(0, 0, 8, 8, 9)
-                 : "+v"(s0)
+                 : "+&v"(s0)
                  : "v"(c0), "v"(c1), "v"(c2), "v"(c3), "v"(c4), "v"(c5), "v"(c6), "v"(c7), "n"(J0));
 }
 #undef IKC_F2
@@ -379,10 +394,12 @@ template <int MMAX, int K>
 IKD_FN void chol_regs_pivots(double (&row)[16], const int g, const int M) {
     if constexpr (K < MMAX) {
         if (K < M) {   // (wave-uniform)
+            if constexpr (K > 0) dpp_settle(row[K]);   // row[K]'s last writer is the asm fmac of pivot K - 1
             const double inv = drsqrt(group_bcast<K>(row[K]));
-            const double lik = row[K] * inv, nlik = -lik;
+            double lik = row[K] * inv;
+            const double nlik = -lik;
             row[K] = g == K ? inv : lik;       // lane K keeps 1 / L(K,K) where its diagonal entry was (nobody reads L(K,K) itself)
-            dpp_settle();
+            dpp_settle(lik);
             chol_regs_trail<MMAX, K, K + 1>(row, lik, nlik);
         }
         chol_regs_pivots<MMAX, K + 1>(row, g, M);
@@ -418,6 +435,7 @@ template <int MMAX>
 IKD_FN void chol_regs_solve(double (&row)[16], const int g, double *ws, const int offx, const int M) {
     double x[16];
     chol_regs_pivots<MMAX, 0>(row, g, M);         // after pivot k, row[k] holds L(i,k) (lane 15: y_k; lane k: 1 / L(k,k))
+    dpp_settle_all(row);                          // the broadcasts below read entries the asm fmacs wrote
     chol_regs_rhs<MMAX, 0>(row, x);               // back substitution, in every lane: x[c] starts as y_c ...
     chol_regs_back<MMAX - 1>(row, x, M);          // ... takes -L(m,c) x_m for m = M-1 .. c+1, then inv_c
     if (g == 0) {
@@ -459,15 +477,19 @@ IKD_FN void chol_regs2_pivots(double (&ra)[16], double (&rb)[32], const int g, c
     if constexpr (K < MMAX) {
         if (K < M) {   // (wave-uniform)
             double d;
+            if constexpr (K > 0) {   // the pivot entry's last writer is the asm fmac of pivot K - 1
+                if constexpr (K < 16) dpp_settle(ra[K]);
+                else dpp_settle(rb[K]);
+            }
             if constexpr (K < 16) d = group_bcast<K>(ra[K]);
             else d = group_bcast<K - 16>(rb[K]);
             const double inv = drsqrt(d);
             double lika = 0.0;
             if constexpr (K < 16) { lika = ra[K] * inv; ra[K] = g == K ? inv : lika; }
-            const double likb = rb[K] * inv;
+            double likb = rb[K] * inv;
             if constexpr (K < 16) rb[K] = likb;
             else rb[K] = g == K - 16 ? inv : likb;
-            dpp_settle();
+            dpp_settle(lika, likb);
             chol_regs2_trail<MMAX, K, K + 1>(ra, rb, lika, likb, -lika, -likb, M);
             IKD_SCHED_FENCE();   // (pivot by pivot: the scheduler otherwise pulls later pivots' broadcasts forward and the rows spill)
         }
@@ -560,6 +582,8 @@ IKD_FN void coop_chol_solve_regs2(const int g, double *ws, const int offG, const
         for (int j = 0; j < MMAX; ++j) rb[j] = (holdsb && j <= mineb && j < M) ? ws[offG + tri(mineb, j)] : 0.0;
     }
     chol_regs2_pivots<MMAX, 0>(ra, rb, g, M);
+    dpp_settle_all(ra);                           // the broadcasts below read entries the asm fmacs wrote
+    dpp_settle_all(rb);
     chol_regs2_rhs<MMAX, 0>(rb, x);
     chol_regs2_back<MMAX - 1>(ra, rb, x, M);
     if (g == 0) {
@@ -738,12 +762,14 @@ template <int MMAX, int K>
 IKD_FN void cholqr_regs_pivots(double (&row)[16], const int g, const int m, const double thr, bool &ok) {
     if constexpr (K < MMAX) {
         if (K < m) {   // (wave-uniform)
+            if constexpr (K > 0) dpp_settle(row[K]);
             const double d = group_bcast<K>(row[K]);
             ok = ok && d > thr;                    // false for NaN as well
             const double inv = drsqrt(d);
-            const double lik = row[K] * inv, nlik = -lik;
+            double lik = row[K] * inv;
+            const double nlik = -lik;
             row[K] = g == K ? inv : lik;
-            dpp_settle();
+            dpp_settle(lik);
             chol_regs_trail<MMAX, K, K + 1>(row, lik, nlik);
         }
         cholqr_regs_pivots<MMAX, K + 1>(row, g, m, thr, ok);

@@ -447,11 +447,19 @@ hipError_t rtc_launch_chain_hot(const ProblemHost &ph, const DeviceTables &dt, c
 namespace ikgpu {
 
 // What the static program takes: sizes the unrolled program stays compilable at (constraints project by Gram-Schmidt there).  IKGPU_GENERIC_KERNEL (lane / lds / coop: tests, A/B) keeps the other forms.
+#ifndef IKGPU_STATIC_MAX_ROWS
+#define IKGPU_STATIC_MAX_ROWS 24
+#endif
 bool rtc_generic_static_available(const ProblemHost &gen, bool compile, uint64_t *key_out) {
     if (!rtc_enabled() || gen.kind != KernelKind::Generic || gen.crows > 12) return false;
     if (std::getenv("IKGPU_GENERIC_KERNEL")) return false;
     if (const char *env = std::getenv("IKGPU_GENERIC_STATIC")) { if (env[0] == '0') return false; }
-    if (gen.rows < 1 || gen.rows > 24 || gen.nv > 32 || gen.generic.ws_words > 1400) return false;
+    // (measured compile times of the unrolled program: M = 10: 2 s, 15: 9 s, 21: ~20 s, 31: 48 s with 19 KB of scratch per lane;
+    // 28 rows of which 16 are posture rows: 440 s -- such problems keep the cooperative kernel)
+    if (gen.rows < 1 || gen.rows > IKGPU_STATIC_MAX_ROWS || gen.nv > 36 || gen.generic.ws_words > 2400) return false;
+    int posture_rows = 0;
+    for (const ikgpu_task &t : gen.tasks) posture_rows += t.type == IKGPU_POSTURE_ROW ? 1 : 0;
+    if (posture_rows > 8) return false;
     if (!rtc_api().ok) return false;
     if (!compile) return true;
     const std::string src = generic_static_source(gen);
