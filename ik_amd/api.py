@@ -389,6 +389,9 @@ class InverseKinematicsProblem:
         return self._com_task
 
 
+Problem = InverseKinematicsProblem   # the name BASELINE.json's north_star uses for reference ik/ik/problem.hpp:9's class
+
+
 class dls_parameters:
     """ik::dls_parameters (reference ik/ik/dls.hpp:24-28, ik/ik/common.hpp:59-66)."""
 
@@ -405,8 +408,12 @@ class inverse_kinematics_visitor:
     inside the kernel; the one-parameter family `||e[0]||^2 < tolerance` is what crosses the ABI.
     tolerance < 0 is a visitor whose should_stop() always returns false."""
 
-    def __init__(self, tolerance=1e-4):
+    def __init__(self, tolerance=1e-4, step_tolerance=0.0, level_tolerances=()):
         self.tolerance = tolerance
+        # the rest of what should_stop(ik, e, dq) is handed (reference ik/ik/visitor.hpp:15-21): also stop when ||dq||^2 <
+        # step_tolerance (<= 0: off); test ||e[l]||^2 < level_tolerances[l] on every level instead of level 0 alone (empty: off)
+        self.step_tolerance = step_tolerance
+        self.level_tolerances = tuple(level_tolerances)
 
 
 class never_stop_visitor(inverse_kinematics_visitor):
@@ -482,7 +489,12 @@ def precompile(problem):
 
 
 def _params(visitor, p):
-    return capi.DlsParams(int(p.max_iterations), float(p.damping), float(p.step_length), float(visitor.tolerance))
+    lt = tuple(getattr(visitor, "level_tolerances", ()))
+    if len(lt) > capi.MAX_VISITOR_LEVELS:
+        raise ValueError("at most %d level tolerances" % capi.MAX_VISITOR_LEVELS)
+    return capi.DlsParams(int(p.max_iterations), float(p.damping), float(p.step_length), float(visitor.tolerance),
+                          float(getattr(visitor, "step_tolerance", 0.0)), len(lt),
+                          (C.c_double * capi.MAX_VISITOR_LEVELS)(*(list(lt) + [0.0] * (capi.MAX_VISITOR_LEVELS - len(lt)))))
 
 
 def dls(problem, q0, data, visitor=None, p=None):

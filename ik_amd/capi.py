@@ -52,9 +52,13 @@ class Task(C.Structure):
                 ("weight", C.c_double * 6)]
 
 
+MAX_VISITOR_LEVELS = 8
+
+
 class DlsParams(C.Structure):
     _fields_ = [("max_iterations", C.c_int32), ("damping", C.c_double), ("step_length", C.c_double),
-                ("stop_sq_tol", C.c_double)]
+                ("stop_sq_tol", C.c_double), ("dq_sq_tol", C.c_double), ("num_level_tols", C.c_int32),
+                ("level_sq_tol", C.c_double * MAX_VISITOR_LEVELS)]
 
 
 class PikParams(C.Structure):
@@ -147,7 +151,7 @@ def lib():
                  "ikgpu_task_frames_fk_batch", "ikgpu_pik_solve_batch", "ikgpu_pik_solve_batch_host",
                  "ikgpu_problem_create_constrained", "ikgpu_problem_plan_constrained"):
         getattr(L, name).restype = C.c_int
-    if L.ikgpu_abi_version() != 1:
+    if L.ikgpu_abi_version() != 2:
         raise ImportError("libikgpu.so ABI version mismatch")
     _lib = L
     return L

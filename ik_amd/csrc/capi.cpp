@@ -144,6 +144,8 @@ int check_params(const ikgpu_dls_params *p) {
     if (p->max_iterations < 0) return fail(IKGPU_ERR_INVALID, "max_iterations must be >= 0");
     if (!(p->damping > 0.0))
         return fail(IKGPU_ERR_INVALID, "damping must be > 0: the device solves JJ^T + damping^2 I by Cholesky (SPD)");
+    if (p->num_level_tols < 0 || p->num_level_tols > IKGPU_MAX_VISITOR_LEVELS)
+        return fail(IKGPU_ERR_INVALID, "num_level_tols must be in 0.." + std::to_string(IKGPU_MAX_VISITOR_LEVELS));
     return IKGPU_OK;
 }
 
@@ -327,6 +329,9 @@ void ikgpu_dls_params_default(ikgpu_dls_params *p) {
     p->damping = 1e-2;        // reference ik/ik/dls.hpp:25
     p->step_length = 1.0;     // reference ik/ik/common.hpp:65
     p->stop_sq_tol = 1e-4;    // reference ik/ik/visitor.hpp:19
+    p->dq_sq_tol = 0.0;       // the derived-visitor family: off (the reference's own visitor)
+    p->num_level_tols = 0;
+    for (double &t : p->level_sq_tol) t = 0.0;
 }
 
 int ikgpu_model_from_urdf(const char *xml, size_t len, int root_joint, ikgpu_model **out) {
@@ -433,6 +438,10 @@ int ikgpu_problem_create_constrained(const ikgpu_model *h, const ikgpu_task *tas
             p->gen.generic_build = 2;
             p->dls_on_static_gen = true;
             p->dls_name = static_name(p->gen);
+        }
+        if (p->host.kind == ikgpu::KernelKind::Generic) {   // (analyse() compiled it: gen is a copy of host)
+            p->gen.generic_build = p->host.generic_build;
+            p->gen.generic_key = p->host.generic_key;
         }
         {
             std::string gname = p->gen.kernel_name;   // ("...,static>": the DLS program's build, not ik::pik's)
@@ -567,6 +576,14 @@ int ikgpu_dls_solve_batch(const ikgpu_problem *p, int64_t B, const double *q0, c
         if (!g.ok) return fail(IKGPU_ERR_DEVICE, "hipSetDevice failed");
         ikgpu::BatchIO io{B, q0, targets, q_out, success, iters, layout};
         const hipStream_t st = static_cast<hipStream_t>(stream);
+        if (ikgpu::visitor_extended(*params)) {
+            // a derived visitor (step tolerance / per-level tolerances): the generic lane program implements the family -- the one
+            // specialised for this problem when there is one, else its memory-resident per-lane form
+            const hipError_t ev = p->gen.generic_build == 2 ? ikgpu::rtc_launch_generic_static(p->gen, p->gen.generic_key, io, *params, st)
+                                                            : ikgpu::launch_dls_generic(p->gen, p->dev, io, *params, st, /*force_lane=*/true);
+            if (ev != hipSuccess) return hip_fail(ev, "launching the generic DLS kernel (derived visitor)");
+            return static_cast<int>(IKGPU_OK);
+        }
         hipError_t e = p->dls_on_static_gen                      ? ikgpu::rtc_launch_generic_static(p->gen, p->gen.generic_key, io, *params, st)
                        : p->host.kind == ikgpu::KernelKind::Chain  ? ikgpu::launch_dls_chain(p->host, p->dev, io, *params, st)
                        : p->host.kind == ikgpu::KernelKind::Tree ? ikgpu::launch_dls_tree(p->host, p->dev, io, *params, st)

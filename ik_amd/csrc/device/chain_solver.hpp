@@ -42,6 +42,11 @@ struct LoopParams {
     int priority;        // priority level of the task (the stop test reads priority-0 rows only)
     int idmask;          // bit j: placement pl[j] has an exactly-identity rotation; bit NJ: frame_pl has
     int unit_weights;    // every Task::weighting() entry is exactly 1
+    // derived-visitor family (include/ikgpu.h ikgpu_dls_params; read by the generic lane program only -- a solve that uses them is
+    // routed there): dq_sq_tol > 0: also stop when ||dq||^2 < dq_sq_tol; nlt > 0: the error test is ||e[l]||^2 < lvl_tol[l], all l < nlt
+    double dq_sq_tol;
+    int nlt;
+    double lvl_tol[8];
 };
 
 constexpr int kSpecUnit = 30;

@@ -645,7 +645,26 @@ IKD_FN void generic_dls(const TB &T, const LoopParams &prm, const WS &ws, const 
             project_out_rowspace(ws, T.off_Jc, T.Mc, nv, T.off_dq, any_active);
 #endif
         }
-        const bool stop_now = active && (prm.stop_sq_tol >= 0.0) && (e0sq < prm.stop_sq_tol);
+        // inverse_kinematics_visitor::should_stop(ik, e, dq) (ik/ik/visitor.hpp:15-21; dls.cpp:61-64) and its derived family
+        bool err_ok = (prm.stop_sq_tol >= 0.0) && (e0sq < prm.stop_sq_tol);
+        if (prm.nlt > 0) {   // (wave-uniform) every listed level under its own tolerance
+            err_ok = true;
+            IKD_UNROLL
+            for (int l = 0; l < T.nlevels; ++l) {
+                double s = 0.0;
+                IKD_UNROLL
+                for (int r = T.lvl_row0[l]; r < T.lvl_row0[l + 1]; ++r) s = dfma(ws[T.off_e + r], ws[T.off_e + r], s);
+                if (l < prm.nlt) err_ok = err_ok && (s < prm.lvl_tol[l < 8 ? l : 7]);
+            }
+        }
+        bool step_small = false;
+        if (prm.dq_sq_tol > 0.0) {   // (wave-uniform)
+            double s = 0.0;
+            IKD_UNROLL
+            for (int c = 0; c < nv; ++c) s = dfma(ws[T.off_dq + c], ws[T.off_dq + c], s);
+            step_small = s < prm.dq_sq_tol;
+        }
+        const bool stop_now = active && (err_ok || step_small);
         if (stop_now) { success = true; iters = it; }
         active = active && !stop_now;
         generic_integrate_clip(T, ws, prm.step_length, active);  // ik/ik/dls.cpp:67-71

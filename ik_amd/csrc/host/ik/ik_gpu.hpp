@@ -564,6 +564,12 @@ class inverse_kinematics_visitor {  // ik/ik/visitor.hpp:7-22
     virtual ~inverse_kinematics_visitor() = default;
     // should_stop(ik, e, dq) := e[0].squaredNorm() < stop_tolerance(); negative: never stop
     virtual number_t stop_tolerance() const { return 1e-4; }
+    // The rest of what should_stop(ik, e, dq) is handed (ik/ik/visitor.hpp:15-21): a derived visitor may ALSO stop on a negligible
+    // step, dq.squaredNorm() < step_tolerance() (<= 0: off), and may test every priority level instead of level 0 alone:
+    // e[l].squaredNorm() < level_tolerances()[l] for every l (empty: the test above).  A C++ body cannot run inside the kernel;
+    // these three numbers are what crosses the ABI (ikgpu_dls_params).
+    virtual number_t step_tolerance() const { return 0.0; }
+    virtual std::vector<number_t> level_tolerances() const { return {}; }
 };
 class default_inverse_kinematics_visitor : public inverse_kinematics_visitor {};
 class never_stop_visitor : public inverse_kinematics_visitor {
@@ -620,6 +626,8 @@ class dls_data {
     std::vector<ikgpu_task> tasks_, constraints_;
 };
 
+using Problem = InverseKinematicsProblem;   // the name BASELINE.json's north_star uses for ik/ik/problem.hpp:9's class
+
 namespace detail {
 inline ikgpu_dls_params to_abi(const inverse_kinematics_visitor &visitor, const dls_parameters &p) {
     ikgpu_dls_params a;
@@ -627,6 +635,11 @@ inline ikgpu_dls_params to_abi(const inverse_kinematics_visitor &visitor, const 
     a.damping = p.damping;
     a.step_length = p.step_length;
     a.stop_sq_tol = visitor.stop_tolerance();
+    a.dq_sq_tol = visitor.step_tolerance();
+    const std::vector<number_t> lt = visitor.level_tolerances();
+    if (lt.size() > IKGPU_MAX_VISITOR_LEVELS) throw std::invalid_argument("more level tolerances than the device visitor takes");
+    a.num_level_tols = static_cast<int32_t>(lt.size());
+    for (int l = 0; l < IKGPU_MAX_VISITOR_LEVELS; ++l) a.level_sq_tol[l] = l < a.num_level_tols ? lt[static_cast<std::size_t>(l)] : 0.0;
     return a;
 }
 inline std::vector<number_t> gather_targets(const InverseKinematicsProblem &problem) {

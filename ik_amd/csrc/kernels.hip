@@ -847,8 +847,8 @@ bool generic_runs_cooperative(const ProblemHost &ph) {
 }
 
 hipError_t launch_dls_generic(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const ikgpu_dls_params &prm,
-                              hipStream_t stream) {
-    if (generic_runs_cooperative(ph)) {
+                              hipStream_t stream, bool force_lane) {
+    if (!force_lane && generic_runs_cooperative(ph)) {
         ikdev::CoopKernelArgs c{};
         c.T = bind_generic_tables(ph, dt.g_ints, dt.g_dbls);
         c.L = bind_coop_layout(ph, dt.g_ints);
@@ -882,9 +882,10 @@ hipError_t launch_dls_generic(const ProblemHost &ph, const DeviceTables &dt, con
     a.prm.lam2 = prm.damping * prm.damping;
     a.prm.step_length = prm.step_length;
     a.prm.stop_sq_tol = prm.stop_sq_tol;
+    fill_visitor(a.prm, prm);
     a.layout = io.layout; a.q0 = io.q0; a.targets = io.targets;
     a.q_out = io.q_out; a.success = io.success; a.iters = io.iters;
-    if (generic_runs_in_lds(ph)) {
+    if (!force_lane && generic_runs_in_lds(ph)) {
         a.T = bind_generic_tables(ph, dt.g_ints, dt.g_dbls);
         a.B = io.B;
         const size_t lds = sizeof(double) * 64 * static_cast<size_t>(ph.generic.ws_words);

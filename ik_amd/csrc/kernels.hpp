@@ -39,6 +39,15 @@ struct DeviceTables {  // per-problem constant arrays resident in HBM
     mutable struct QueuePool queues;            // work-queue heads of the persistent kernels (below)
 };
 
+// The derived-visitor members of ikgpu_dls_params (include/ikgpu.h) into the loop parameters the generic lane program reads.
+template <class LP>
+inline void fill_visitor(LP &lp, const ikgpu_dls_params &prm) {
+    lp.dq_sq_tol = prm.dq_sq_tol;
+    lp.nlt = prm.num_level_tols;
+    for (int l = 0; l < 8; ++l) lp.lvl_tol[l] = l < prm.num_level_tols ? prm.level_sq_tol[l] : 0.0;
+}
+inline bool visitor_extended(const ikgpu_dls_params &prm) { return prm.dq_sq_tol > 0.0 || prm.num_level_tols > 0; }
+
 struct BatchIO {
     int64_t B;
     const double *q0;       // [nq x B]
@@ -112,8 +121,10 @@ bool tree_shape_built(int nj, int nch);
 // True when launch_dls_generic runs the cooperative LDS-resident program (device/coop_solver.hpp) for this problem: no
 // constraints, no centre-of-mass task, four workspaces fit 64 KB of LDS, and IKGPU_GENERIC_KERNEL is not "lane".
 bool generic_runs_cooperative(const ProblemHost &ph);
+// force_lane: the per-lane memory-resident form whatever the problem's size (the derived-visitor family is implemented there and in
+// the run-time specialised program, not in the cooperative kernel)
 hipError_t launch_dls_generic(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io,
-                              const ikgpu_dls_params &prm, hipStream_t stream);
+                              const ikgpu_dls_params &prm, hipStream_t stream, bool force_lane = false);
 // ik::pik (reference ik/ik/pik.cpp:31-103): always the generic lane program; `gen` must be a Generic-kind analysis and
 // dt.g_ints / dt.g_dbls its uploaded tables.
 hipError_t launch_pik_generic(const ProblemHost &gen, const DeviceTables &dt, const BatchIO &io, const ikgpu_pik_params &prm,

@@ -493,6 +493,7 @@ hipError_t rtc_launch_generic_static(const ProblemHost &gen, uint64_t key, const
     a.prm.lam2 = prm.damping * prm.damping;
     a.prm.step_length = prm.step_length;
     a.prm.stop_sq_tol = prm.stop_sq_tol;
+    fill_visitor(a.prm, prm);
     a.layout = io.layout; a.B = io.B; a.q0 = io.q0; a.targets = io.targets;
     a.q_out = io.q_out; a.success = io.success; a.iters = io.iters;
     size_t nbytes = sizeof a;

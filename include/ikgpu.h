@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define IKGPU_ABI_VERSION 1
+#define IKGPU_ABI_VERSION 2   /* 2: ikgpu_dls_params grew the derived-visitor fields */
 
 typedef enum {
     IKGPU_OK = 0,
@@ -111,11 +111,20 @@ typedef struct {
  * stops, *before* stepping, when ||e[0]||^2 < stop_sq_tol (1e-4 in the reference).  A negative
  * value means "a visitor that never stops": exactly max_iterations steps are taken.
  * max_time and random_restart are unused by the reference loop and have no counterpart. */
+#define IKGPU_MAX_VISITOR_LEVELS 8
 typedef struct {
     int32_t max_iterations; /* default 100 */
     double damping;         /* default 1e-2; damping^2 is added to the Gram diagonal (dls.cpp:41) */
     double step_length;     /* default 1.0 */
     double stop_sq_tol;     /* default 1e-4; < 0 never stops */
+    /* The rest of what a class derived from inverse_kinematics_visitor can decide on: should_stop(ik, e, dq) is virtual and is
+     * handed EVERY level's error and the step (ik/ik/visitor.hpp:15-21, called at ik/ik/dls.cpp:61).  A C++ visitor cannot run
+     * inside a kernel; this closed family covers what such a visitor realistically tests.  Set by ikgpu_dls_params_default to the
+     * reference's own visitor (both switched off; so does zero-initialising the three members).  A solve with either switched on runs on the problem's generic lane program. */
+    double dq_sq_tol;       /* > 0: ALSO stop when ||dq||^2 < dq_sq_tol (the step about to be taken is negligible); <= 0 (default 0): off */
+    int32_t num_level_tols; /* 0 (default): the error test is ||e[0]||^2 < stop_sq_tol.  n > 0: it is ||e[l]||^2 < level_sq_tol[l] for
+                             * every priority level l < n (stop_sq_tol is then not read) */
+    double level_sq_tol[IKGPU_MAX_VISITOR_LEVELS];
 } ikgpu_dls_params;
 
 typedef struct ikgpu_model ikgpu_model;     /* immutable host-side kinematic model */

@@ -633,6 +633,40 @@ void iko_constraint_jacobian(const iko_model *m, const iko_task *cons, int ncons
     ws_free(w);
 }
 
+static iko_visitor g_visitor = {-1.0, 0, {0, 0, 0, 0, 0, 0, 0, 0}};
+void iko_set_visitor(const iko_visitor *v) {
+    if (v) g_visitor = *v;
+    else { g_visitor.dq_sq_tol = -1.0; g_visitor.nlevels = 0; }
+}
+
+/* should_stop(ik, e, dq) of the visitor family above (visitor.hpp:15-21 is the member with nlevels == 0 and dq_sq_tol < 0) */
+static int visitor_should_stop(const iko_task *tasks, int ntasks, const double *et, const double *dq, int nv, const iko_params *p, double e0sq) {
+    int stop;
+    if (g_visitor.nlevels > 0) {
+        stop = 1;
+        int row = 0, maxp = 0;
+        for (int i = 0; i < ntasks; ++i) if (tasks[i].priority > maxp) maxp = tasks[i].priority;
+        for (int l = 0; l <= maxp; ++l) {                      /* rows are stacked by priority, then insertion (dls.cpp:20-24) */
+            double s = 0.0;
+            for (int ti = 0; ti < ntasks; ++ti) {
+                if (tasks[ti].priority != l) continue;
+                const int d = task_dim(&tasks[ti]);
+                for (int r = 0; r < d; ++r) s += et[row + r] * et[row + r];
+                row += d;
+            }
+            if (l < g_visitor.nlevels && !(s < g_visitor.level_sq_tol[l])) stop = 0;
+        }
+    } else {
+        stop = p->stop_sq_tol >= 0.0 && e0sq < p->stop_sq_tol;
+    }
+    if (!stop && g_visitor.dq_sq_tol >= 0.0) {
+        double s = 0.0;
+        for (int c = 0; c < nv; ++c) s += dq[c] * dq[c];
+        stop = s < g_visitor.dq_sq_tol;
+    }
+    return stop;
+}
+
 static int dls_ws(const iko_model *m, const iko_task *tasks, int ntasks, const iko_task *cons, int ncons, const double *targets,
                   const double *q0, const iko_params *p, double *q_out, int *success, int *iters,
                   double *trace, workspace *w) {
@@ -679,7 +713,7 @@ static int dls_ws(const iko_model *m, const iko_task *tasks, int ntasks, const i
             memcpy(t + nq, w->et, sizeof(double) * M);
             memcpy(t + nq + M, w->dq, sizeof(double) * nv);
         }
-        if (p->stop_sq_tol >= 0.0 && e0sq < p->stop_sq_tol) {  /* visitor.hpp:19; dls.cpp:61-64 */
+        if (visitor_should_stop(tasks, ntasks, w->et, w->dq, nv, p, e0sq)) {  /* visitor.hpp:19; dls.cpp:61-64 */
             memcpy(q_out, w->q, sizeof(double) * nq);
             *success = 1;
             *iters = it;

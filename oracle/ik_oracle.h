@@ -64,6 +64,17 @@ typedef struct {
     double damping, step_length, stop_sq_tol;
 } iko_params;
 
+/* The rest of what inverse_kinematics_visitor::should_stop(ik, e, dq) is handed (ik/ik/visitor.hpp:15-21: every level's error and
+ * the step): a closed family of derived visitors.  nlevels == 0: the error test is the reference's own (||e[0]||^2 < stop_sq_tol of
+ * iko_params); nlevels > 0: it is ||e[l]||^2 < level_sq_tol[l] for EVERY l < nlevels.  dq_sq_tol >= 0: the solve ALSO stops when
+ * ||dq||^2 < dq_sq_tol.  Process-wide setting read by the dls entry points (test infrastructure); NULL restores the reference's visitor. */
+typedef struct {
+    double dq_sq_tol;
+    int nlevels;
+    double level_sq_tol[8];
+} iko_visitor;
+void iko_set_visitor(const iko_visitor *v);
+
 int iko_task_rows(const iko_task *tasks, int ntasks);
 
 /* framesForwardKinematics: oMi[njoints][12], oMf[nframes][12] (either may be NULL). */

@@ -116,6 +116,16 @@ def params(max_iterations=100, damping=1e-2, step_length=1.0, stop_sq_tol=1e-4):
     return _Params(max_iterations, damping, step_length, stop_sq_tol)
 
 
+class _Visitor(C.Structure):
+    _fields_ = [("dq_sq_tol", C.c_double), ("nlevels", C.c_int), ("level_sq_tol", C.c_double * 8)]
+
+
+def set_visitor(dq_sq_tol=-1.0, level_sq_tol=()):
+    """The derived-visitor family of ik_oracle.h (process-wide; call set_visitor() with no arguments to restore the reference's)."""
+    v = _Visitor(float(dq_sq_tol), len(level_sq_tol), (C.c_double * 8)(*list(level_sq_tol)))
+    lib().iko_set_visitor(C.byref(v))
+
+
 def task_rows(tasks):
     return lib().iko_task_rows(tasks, len(tasks))
 

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(native_built):
     assert not missing, missing
     assert sorted(capi.SYMBOLS) == declared
     lib.ikgpu_abi_version.restype = C.c_int
-    assert lib.ikgpu_abi_version() == 1
+    assert lib.ikgpu_abi_version() == 2   # 2: ikgpu_dls_params carries the derived-visitor members
 
 
 def test_default_parameters_are_the_reference_defaults(ik):
@@ -366,3 +366,37 @@ def test_shard_rule_and_slot_layout_of_the_c_abi(ik):
                 (oq, oi, os_), used = D._layout(rows, b_max)
                 assert (oq, oi, os_, used) == (0, rows * b_max * 8, rows * b_max * 8 + 4 * b_max, rows * b_max * 8 + 5 * b_max)
                 assert L.ikgpu_shard_slot_bytes(rows, total, world) == (used + 15) // 16 * 16
+
+
+def test_derived_visitor_defaults_and_oracle_family(ik):
+    """ikgpu_dls_params_default switches the derived-visitor members off (= the reference's visitor, ik/ik/visitor.hpp:15-21); the
+    oracle's restatement of the family stops earlier on a step tolerance and later on a stricter second-level tolerance."""
+    from ik_amd import capi
+    import oracle as O
+    p = capi.DlsParams(7, 0.5, 0.25, 3.0, 9.0, 5)
+    capi.lib().ikgpu_dls_params_default(C.byref(p))
+    assert (p.dq_sq_tol, p.num_level_tols, list(p.level_sq_tol)) == (0.0, 0, [0.0] * 8)
+    assert capi.lib().ikgpu_abi_version() == 2
+    v = ik.inverse_kinematics_visitor()
+    assert (v.tolerance, v.step_tolerance, v.level_tolerances) == (1e-4, 0.0, ())
+    assert ik.Problem is ik.InverseKinematicsProblem
+    model = ik.Model.from_urdf_file(urdf_path("ur5"))
+    om = O.OracleModel(model.flat())
+    fid = model.getFrameId("tool0")
+    tasks = O.make_tasks([(fid, 0, 0, 0, None), (fid, 0, 1, 1, None)])       # position at level 0, orientation at level 1
+    rng = np.random.default_rng(1)
+    q0 = rng.uniform(-1, 1, (64, 6))
+    tg = np.repeat(O.fk_batch(om, q0 + rng.uniform(-0.2, 0.2, (64, 6)), [fid]), 2, axis=1)
+    prm = O.params(200, 1e-1, 0.5, 1e-4)
+    _, ok0, it0 = O.dls_batch(om, tasks, tg, q0, prm)
+    try:
+        O.set_visitor(level_sq_tol=(1e-4, 1e-6))
+        _, ok1, it1 = O.dls_batch(om, tasks, tg, q0, prm)
+        O.set_visitor(dq_sq_tol=1e-2)
+        _, ok2, it2 = O.dls_batch(om, tasks, tg, q0, prm)
+    finally:
+        O.set_visitor()
+    assert (it1 >= it0).all() and (it1 > it0).any()          # the second level has to converge too
+    assert (it2 <= it0).all() and (it2 < it0).any()          # a coarse step tolerance fires first
+    _, ok3, it3 = O.dls_batch(om, tasks, tg, q0, prm)
+    assert np.array_equal(it3, it0)                          # restored
