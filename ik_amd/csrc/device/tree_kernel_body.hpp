@@ -94,6 +94,114 @@ IKD_FN void dls_tree_body(const TreeKernelArgs<NJ, NCH> &a, const Desc &d, int64
     if (a.iters) a.iters[b] = iters;
 }
 
+#if IKD_HIP_LANG
+// ---- lane refill for the tree kernels: chain_kernel_body.hpp's chain_refill_loop with the tree kernel's lane state ------------------
+// (the floating base's 7 numbers + the chains' joint angles + the lane's target pointer).  tree_dls calls step() at the end of every
+// iteration; builds without per-lane state outside q only (no posture rows, no ik::pik level).  queue / chunk: as the chain kernels'.
+template <int NJ, int NCH>
+struct TreeRefill {
+    static constexpr bool on = true;
+    const TreeKernelArgs<NJ, NCH> *a;
+    unsigned long long *queue;
+    int chunk;
+    bool fixed_base;
+    int64_t b, first_round, pool_lo, pool_hi;
+    bool exhausted;
+    bool start;   // this lane holds a problem of the first (static) round
+
+    __device__ __forceinline__ void load(int64_t bb, double (&qb)[7], double (&qj0)[NJ], double (&qj1)[NJ]) const {
+        const TreeKernelArgs<NJ, NCH> &A = *a;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) qb[k] = fixed_base ? (k == 6 ? 1.0 : 0.0) : A.q0[at(A.layout, A.B, A.nq, k, bb)];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            qj0[j] = A.q0[at(A.layout, A.B, A.nq, A.qidx[0][j], bb)];
+            qj1[j] = NCH > 1 ? A.q0[at(A.layout, A.B, A.nq, A.qidx[NCH - 1][j], bb)] : 0.0;
+        }
+    }
+    __device__ __forceinline__ const double *target_pointer(int64_t bb) const {
+        return a->layout == LAYOUT_SOA ? a->targets + bb : a->targets + bb * a->ntasks * 12;
+    }
+
+    // done lanes store (q, success, iters) and take the next problem; returns the wave-uniform "some lane still holds a problem"
+    template <class ReloadFn>
+    __device__ __forceinline__ bool step(bool done, bool stopped, int iters, double (&qb)[7], double (&qj0)[NJ], double (&qj1)[NJ], const double *&tl,
+                                         bool &active, ReloadFn reload_targets) {
+        const TreeKernelArgs<NJ, NCH> &A = *a;
+        const int lane = static_cast<int>(threadIdx.x) & 63;
+        if (__any(done)) {
+            if (done) {
+#pragma unroll
+                for (int k = 0; k < 7; ++k)
+                    if (!fixed_base) A.q_out[at(A.layout, A.B, A.nq, k, b)] = qb[k];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    A.q_out[at(A.layout, A.B, A.nq, A.qidx[0][j], b)] = qj0[j];
+                    if (NCH > 1) A.q_out[at(A.layout, A.B, A.nq, A.qidx[NCH - 1][j], b)] = qj1[j];
+                }
+                if (A.success) A.success[b] = stopped ? 1 : 0;
+                A.iters[b] = iters;                                       // never null here: the pass-through kernel reads it
+            }
+            const unsigned long long mask = __ballot(done);
+            const int need = __popcll(mask);
+            const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+            const int64_t avail = pool_hi - pool_lo;
+            int64_t nb = pool_lo + rank;
+            bool got = rank < avail;
+            if (avail < need && !exhausted) {                             // wave-uniform: pull the next chunk
+                unsigned long long v = 0;
+                if (lane == 0) v = atomicAdd(queue, static_cast<unsigned long long>(chunk));
+                const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v)), hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
+                const int64_t nlo = first_round + static_cast<int64_t>((static_cast<unsigned long long>(hi) << 32) | lo);
+                const int64_t nhi = nlo + chunk < A.B ? nlo + chunk : A.B;
+                exhausted = nlo + chunk >= A.B;
+                if (rank >= avail) { nb = nlo + (rank - avail); got = nb < nhi; }
+                pool_lo = nlo + (need - avail);
+                pool_hi = nhi > pool_lo ? nhi : pool_lo;
+            } else {
+                pool_lo += need < avail ? need : avail;
+            }
+            if (done) {
+                active = got;
+                if (got) {
+                    b = nb;
+                    load(b, qb, qj0, qj1);
+                    tl = target_pointer(b);
+                    reload_targets(tl);
+                }
+            }
+        }
+        return __any(active) != 0;
+    }
+};
+
+// B independent ik::dls() calls under lane refill (persistent waves; `wave` counts 64-lane waves across the grid).
+template <int NJ, int NCH, int SPEC, class Desc, class Park>
+__device__ __forceinline__ void dls_tree_refill_body(const TreeKernelArgs<NJ, NCH> &a, const Desc &d, int64_t wave, int64_t nwaves, Park park,
+                                                     unsigned long long *queue, int chunk) {
+    const int lane = static_cast<int>(threadIdx.x) & 63;
+    const bool fixed_base = spec_is_general(SPEC) ? a.prm.fixed_base != 0 : false;
+    TreeRefill<NJ, NCH> rf{&a, queue, chunk, fixed_base, wave * 64 + lane, nwaves * 64, 0, 0, nwaves * 64 >= a.B, wave * 64 + lane < a.B};
+    const int64_t bs = rf.start ? rf.b : a.B - 1;
+    double qb[7], qj0[NJ], qj1[NJ];
+    rf.load(bs, qb, qj0, qj1);
+    const double *tl = rf.target_pointer(bs);
+    const int64_t ts = a.layout == LAYOUT_SOA ? a.B : 1;
+    const PostureState ps{nullptr, 0, false, a.lower, a.upper, false, nullptr, nullptr};
+    int iters;
+    bool success;
+    tree_dls<NJ, NCH, SPEC>(d, a.prm, qb, qj0, qj1, tl, ts, a.tslot, ps, iters, success, park, [](bool act) { return __any(act) != 0; }, rf);
+    if (lane == 0) {   // the last wave out resets the slot
+        __threadfence();
+        if (atomicAdd(queue + 1, 1ull) == static_cast<unsigned long long>(nwaves) - 1ull) {
+            queue[0] = 0ull;
+            queue[1] = 0ull;
+            __threadfence();
+        }
+    }
+}
+#endif  // IKD_HIP_LANG
+
 // Stage kernel: world placement of every task frame and the stacked weighted error / dense Jacobian
 // (reference ik/ik/data.cpp:25-58).  Rows are emitted in task order with each task's kinematic type
 // selecting its rows, exactly as the reference stacks them.  slot 0 / 1: chains, slot 2: base task.

@@ -746,17 +746,25 @@ IKD_FN void posture_outside_pass(const TreeParams &prm, const PostureState &ps, 
 }
 
 // Desc: TreeDesc<NJ, NCH> (LDS / host memory) or IKD_CONST_AS TreeDesc<NJ, NCH> (HBM through scalar loads, see chain_solver.hpp).
-template <int NJ, int NCH, int SPEC = -1, class Desc, class Park, class AnyFn>
+// Lane refill hook of tree_dls (the stop-rule mode on batches larger than the machine: tree_kernel_body.hpp TreeRefill): NoRefill is
+// the lock-step loop -- every `if constexpr (R::on)` below compiles to nothing there.
+struct NoRefill {
+    static constexpr bool on = false;
+};
+
+template <int NJ, int NCH, int SPEC = -1, class Desc, class Park, class AnyFn, class R = NoRefill>
 IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], double (&qj0)[NJ], double (&qj1)[NJ],
                      const double *targets_lane, int64_t tstride, const int (&tslot)[3], const PostureState &ps, int &iters_out,
-                     bool &success_out, Park park, AnyFn any_active) {
+                     bool &success_out, Park park, AnyFn any_active, R refill = R{}) {
     constexpr bool kGeneral = spec_is_general(SPEC);  // the demo's extras exist in the general builds only
+    static_assert(!R::on || !(spec_has_posture(SPEC) || spec_has_pik(SPEC)), "lane refill: builds without per-lane state outside q");
     constexpr bool kPik = spec_has_pik(SPEC);  // the orthogonalisation behind PikRow costs the other builds registers
     constexpr bool kPost = spec_has_posture(SPEC);
     constexpr bool kCons = NCH > 1 && spec_has_constraint(SPEC);
     // (posture builds: a tail lane shadowing the last problem would re-read that problem's outside joints while their owner
     // updates them -- it sits the loop out instead; nothing of it is stored anyway)
     bool active = kPost ? ps.store : true, success = false;
+    if constexpr (R::on) active = refill.start;   // (a tail lane of the first round holds no problem)
     const Desc *dp = &d_in;
     int iters = prm.max_iterations;
     // hot builds: the three pose targets stay in registers (the general builds re-read them every iteration -- their register budget
@@ -769,8 +777,9 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
         tg1[k] = (kTgRegs && NCH > 1) ? targets_lane[(tslot[1] * 12 + k) * tstride] : 0.0;
         tgP[k] = (kTgRegs && prm.hasP) ? targets_lane[(tslot[2] * 12 + k) * tstride] : 0.0;
     }
+    int lit = 0;   // (refill) this lane's own iteration count
 #pragma unroll 1
-    for (int it = 0; it < prm.max_iterations; ++it) {
+    for (int it = 0; R::on || it < prm.max_iterations; ++it) {
         asm volatile("" ::: "memory");  // re-read the table and the targets every iteration (see chain_solver.hpp)
         if constexpr (!std::is_same<Desc, TreeDesc<NJ, NCH>>::value) IKD_LAUNDER(dp);
         const Desc &d = *dp;
@@ -889,7 +898,8 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
         }
 
         const bool stop_now = active && (prm.stop_sq_tol >= 0.0) && (e0sq < prm.stop_sq_tol);
-        if (stop_now) { success = true; iters = it; }
+        if (stop_now) { success = true; iters = R::on ? lit : it; }
+        const bool had = active;   // (refill) the lane held a problem during this iteration
         active = active && !stop_now;
 
 #pragma unroll 1
@@ -945,7 +955,24 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
 #pragma unroll
             for (int i = 0; i < 7; ++i) qb[i] = active ? qn[i] : qb[i];
         }
-        if (!any_active(active)) break;
+        if constexpr (R::on) {
+            // a lane whose visitor fired (q is the configuration the error was evaluated at, dls.cpp:61-63) or whose count reached
+            // max_iterations (the stepped q, dls.cpp:76-77) stores its result and takes the next unsolved problem
+            ++lit;
+            const bool done = had && (stop_now || lit >= prm.max_iterations);
+            const bool any_left = refill.step(done, stop_now, stop_now ? lit - 1 : prm.max_iterations, qb, qj0, qj1, targets_lane, active, [&](const double *tl) {
+#pragma unroll
+                for (int k = 0; k < 12; ++k) {
+                    tg0[k] = kTgRegs ? tl[(tslot[0] * 12 + k) * tstride] : 0.0;
+                    tg1[k] = (kTgRegs && NCH > 1) ? tl[(tslot[1] * 12 + k) * tstride] : 0.0;
+                    tgP[k] = (kTgRegs && prm.hasP) ? tl[(tslot[2] * 12 + k) * tstride] : 0.0;
+                }
+            });
+            if (done) { lit = 0; success = false; }
+            if (!any_left) break;
+        } else {
+            if (!any_active(active)) break;
+        }
     }
     if (kPost && prm.post_on && prm.max_iterations > 0) {  // the step of the last iteration, for the lanes that never stopped
         double unused = 0.0;

@@ -423,6 +423,13 @@ TreeKernelArgs<NJ, NCH> make_tree_args(const ProblemHost &ph, const DeviceTables
     return a;
 }
 
+}  // namespace
+// kernels_tree_refill.hip
+template <int NJ, int NCH>
+bool launch_tree_refill(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const ikgpu_dls_params &prm, hipStream_t stream,
+                        ikdev::TreeKernelArgs<NJ, NCH> a, bool hot, hipError_t *err);
+namespace {
+
 template <int NJ, int NCH>
 hipError_t run_dls_tree(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const ikgpu_dls_params &prm,
                         hipStream_t stream, const double *pik_lambda1) {
@@ -454,6 +461,11 @@ hipError_t run_dls_tree(const ProblemHost &ph, const DeviceTables &dt, const Bat
                                      dim3(kTreeBlock), LDS, stream, a);                                                             \
         else hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, (FLAGS)>), grid, dim3(kTreeBlock), LDS, stream, a);                       \
     } while (0)
+    // stop-rule mode on a batch larger than the machine: lane refill (kernels_tree_refill.hip) for the builds that have it
+    if ((hot || (!mask_only && !pik_lambda1 && !ph.cons_on && !ph.has_posture && !fold)) && prm.stop_sq_tol >= 0.0 && prm.max_iterations >= 1) {
+        hipError_t re = hipSuccess;
+        if (launch_tree_refill<NJ, NCH>(ph, dt, io, prm, stream, a, hot, &re)) return re;
+    }
     if (hot) hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, kHot>), grid, dim3(kTreeBlock), 0, stream, a);
     else if (mask_only) hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, (kMask != 0 ? kMask : kHot)>), grid, dim3(kTreeBlock), 0, stream, a);
     else if (pik_lambda1)   // two-level ik::pik (tree_takes_two_level_pik): the general build + the level-1 row's projection

@@ -15,10 +15,18 @@ import ik_amd  # noqa: E402
 from ik_amd import workload  # noqa: E402
 
 name, frame = (sys.argv[1], sys.argv[2]) if len(sys.argv) > 2 else ("cassie_fixed", "LeftFootFront")
-model = ik_amd.Model.from_urdf_file(os.path.join(workload.MODELS_DIR, name + ".kin.urdf"))
-problem = ik_amd.InverseKinematicsProblem(model)
-problem.add_frame_task("t", ik_amd.FrameTask.create(model, frame, ik_amd.KinematicType.Full))
-nominal = workload.UR5_NOMINAL if name.startswith("ur") else np.zeros(model.nq) if name == "arm7" else workload.cassie_nominal(model.names)
+FULL_BODY = name == "full_body"
+if FULL_BODY:
+    model = ik_amd.Model.from_urdf_file(os.path.join(workload.MODELS_DIR, "cassie.kin.urdf"), free_flyer=True)
+    problem = ik_amd.InverseKinematicsProblem(model)
+    for i, f in enumerate(["LeftFootFront", "RightFootFront", "pelvis"]):
+        problem.add_frame_task("t%d" % i, ik_amd.FrameTask.create(model, f, ik_amd.KinematicType.Full))
+    nominal = workload.cassie_nominal(model.names)
+else:
+    model = ik_amd.Model.from_urdf_file(os.path.join(workload.MODELS_DIR, name + ".kin.urdf"))
+    problem = ik_amd.InverseKinematicsProblem(model)
+    problem.add_frame_task("t", ik_amd.FrameTask.create(model, frame, ik_amd.KinematicType.Full))
+    nominal = workload.UR5_NOMINAL if name.startswith("ur") else np.zeros(model.nq) if name == "arm7" else workload.cassie_nominal(model.names)
 
 
 def timed(data, Q0, T, vis, prm, reps=3):
@@ -32,7 +40,7 @@ def timed(data, Q0, T, vis, prm, reps=3):
     return a.elapsed_time(b) / reps, out
 
 
-for build in ("default", "general"):
+for build in (("default",) if FULL_BODY else ("default", "general")):
     if build == "general":
         os.environ["IKGPU_CHAIN_HOT"] = "0"
     data = ik_amd.dls_data(problem, device=0)
@@ -40,7 +48,10 @@ for build in ("default", "general"):
     print("==", data.kernel)
     for mode in ("uniform", "near"):
         for B in (65536, 262144, 1048576):
-            q0, qs = workload.chain_workload(model.lowerPositionLimit, model.upperPositionLimit, nominal, np.arange(B), 0, mode)
+            if FULL_BODY:
+                q0, qs = workload.freeflyer_workload(model.lowerPositionLimit, model.upperPositionLimit, nominal, np.arange(B), seed=0, mode=mode)
+            else:
+                q0, qs = workload.chain_workload(model.lowerPositionLimit, model.upperPositionLimit, nominal, np.arange(B), 0, mode)
             Q0 = torch.from_numpy(np.ascontiguousarray(q0.T)).cuda()
             T = ik_amd.task_frames_fk_batch(problem, torch.from_numpy(np.ascontiguousarray(qs.T)).cuda(), data)
             ms50, _ = timed(data, Q0, T, ik_amd.never_stop_visitor(), ik_amd.dls_parameters(max_iterations=50))
