@@ -53,7 +53,18 @@ WORKLOADS = {
     "ur10_clamp": dict(urdf="ur10", free_flyer=False, frames=["tool0"], nq=6, narrow=2.0,
                        text="UR10 arm (authored model, not in the reference) with every joint limit narrowed to +-2 rad, q* uniform in the "
                             "limits: the joint-limit projection binds in the timed region"),
-    # the demo's own task set (reference ik_ros/src/cassie.cpp:45-81): the tree kernel's general build
+    # a chain that is NOT one of the fixture robots (fixtures/make_arm7_urdf.py: general joint-origin rotations, oblique axes): the
+    # structure-specialised kernel compiled for its structure code at run time ("hot-rtc"), or the general build without hipRTC
+    "arm7": dict(urdf="arm7", free_flyer=False, frames=["tool"], nq=7,
+                 text="made-up 7-joint arm with general joint-origin rotations and oblique axes (fixtures/models/arm7.kin.urdf, not in the "
+                      "reference), one SE(3) tool task, targets near the start"),
+    # two tasks that share joints on a fixed-base arm: no chain / tree kernel takes it -- the generic lane program, specialised for the
+    # problem at run time ("...,static>") or, without hipRTC, the cooperative kernel
+    "ur5_two_tasks": dict(urdf="ur5", free_flyer=False, frames=["tool0", "wrist_1_link"], nq=6,
+                          tasks=[("frame", "tool0", 0, "universe"), ("frame", "wrist_1_link", 0, "universe")],
+                          text="UR5 arm, two Position tasks that share joints (tool0 and wrist_1_link; M=6): the generic lane program"),
+    # the demo's own task set (reference ik_ros/src/cassie.cpp:45-81): the tree kernel's general build, or (few rows) the generic lane
+    # program specialised for it at run time
     "cassie_demo": dict(urdf="cassie", free_flyer=True, frames=["LeftFootFront", "pelvis", "LeftFootFront"], nq=23,
                         tasks=[("frame", "LeftFootFront", 0, "pelvis"), ("frame", "pelvis", 2, "universe"),
                                ("align", "LeftFootFront", 1, "universe")],
@@ -167,14 +178,16 @@ def load_model(ik_amd, workload, w):
 
 
 def make_inputs(name, model, idx):
-    import numpy as np  # noqa: F401
+    import numpy as np
     from ik_amd import workload
     w = WORKLOADS[name]
     lo, hi = model.lowerPositionLimit, model.upperPositionLimit
     if name in ("cassie_full_body", "cassie_demo", "cassie_demo_pik", "cassie_demo_posture", "cassie_demo_pinned", "cassie_demo_pinned_posture"):
         return workload.freeflyer_workload(lo, hi, workload.cassie_nominal(model.names), idx, seed=0, mode="near")
-    if name in ("ur5", "ur10"):
+    if name in ("ur5", "ur10", "ur5_two_tasks"):
         return workload.chain_workload(lo, hi, workload.UR5_NOMINAL, idx, seed=0, mode="near")
+    if name == "arm7":
+        return workload.chain_workload(lo, hi, np.zeros(model.nq), idx, seed=0, mode="near")
     if w.get("narrow"):
         return workload.chain_workload(lo, hi, workload.UR5_NOMINAL, idx, seed=0, mode="uniform")
     return workload.chain_workload(lo, hi, workload.cassie_nominal(model.names), idx, seed=0, mode="uniform")
@@ -327,7 +340,7 @@ def main():
         Q0_d = torch.from_numpy(np.ascontiguousarray(q0_h.T)).to(dev)
         QS = torch.from_numpy(np.ascontiguousarray(qs_h.T)).to(dev)
         tg = ik_amd.task_frames_fk_batch(problem, QS, data)  # FK(q*) on the device: reachable targets
-        if w.get("tasks"):
+        if w.get("tasks") and w["urdf"] == "cassie":
             # express each frame target in its reference frame (here: the pelvis, task 1's frame); the alignment row asks for
             # the direction the foot's Y axis has at q* (slot 2 holds the same foot frame): reachable, like the frame targets
             Rp, pp = tg[1, :9].reshape(3, 3, b), tg[1, 9:]
@@ -497,7 +510,7 @@ def main():
             res["all_gather"] = {"ms": all_gather_ms, "bytes_per_rank_out": int(bufs[0].nbytes * world), "payload": gather,
                                  "what": "one isolated all-gather of the step's payload after the timed region (issue to completion, max "
                                          "over ranks); in the timed region it overlaps the next step's solve"}
-        fused = data.kernel.startswith(("dls_chain<", "dls_tree<"))
+        fused = data.kernel.startswith(("dls_chain<", "dls_tree<")) or data.kernel.endswith(",static>")
         if stats.get("flop_per_solve_measured") and args.iters == 50:
             flops = stats["flop_per_solve_measured"]
             tf = flops * B / (kernel_ms * 1e-3) / 1e12
@@ -514,7 +527,7 @@ def main():
             hbm["kernel_ms"] = kernel_ms
             hbm["note"] = ("fused on-chip loop without a committed flop count for this kernel: HBM figure only" if fused else
                            "generic kernel, workspace in LDS (16 lanes per problem): LDS-latency bound, DESIGN.md 3.3"
-                           if data.kernel.startswith("dls_generic<") else
+                           if data.kernel.startswith("dls_generic<") and not data.kernel.endswith(",static>") else
                            "generic per-lane kernel, workspace in HBM: bound by that traffic, DESIGN.md 3.4")
             res["roofline"] = hbm
         if args.timed_only:
@@ -533,7 +546,7 @@ def main():
                                         "success_rate": float(oks.double().mean().item())}
             # (i-b) the stop rule on batches larger than the machine: lock-step waves (a wave runs until its last lane stops) against lane
             # refill (a finished lane takes the next problem: device/chain_kernel_body.hpp); same results bit for bit
-            if data.kernel.startswith("dls_chain<"):
+            if data.kernel.startswith("dls_chain<") or data.kernel == "dls_tree<NJ=7,chains=2,base_task>":
                 big = []
                 for bb in (CONFIG4_GLOBAL_BATCH, 4 * CONFIG4_GLOBAL_BATCH):
                     _, Q0_b, tg_b = device_inputs(np.arange(bb))

@@ -16,6 +16,7 @@ JOINT_UNIVERSE, JOINT_REVOLUTE, JOINT_PRISMATIC, JOINT_FREEFLYER = 0, 1, 2, 3
 POSITION, ORIENTATION, FULL = 0, 1, 2
 ALIGN_AXIS_X, ALIGN_AXIS_Y, ALIGN_AXIS_Z, POSTURE_ROW, CENTRE_OF_MASS = 3, 4, 5, 6, 7
 SOA, AOS = 0, 1
+TARGETS_POSE7 = 0x100
 ROOT_FIXED, ROOT_FREEFLYER = 0, 1
 
 # Every symbol include/ikgpu.h declares (tests check the library exports all of them).
@@ -31,7 +32,7 @@ SYMBOLS = [
     "ikgpu_problem_precompile",
     "ikgpu_shard_range", "ikgpu_shard_slot_layout", "ikgpu_shard_slot_bytes", "ikgpu_shard_group_create", "ikgpu_shard_group_destroy",
     "ikgpu_shard_group_size", "ikgpu_shard_group_problem", "ikgpu_shard_group_uses_rccl", "ikgpu_shard_group_stream",
-    "ikgpu_dls_solve_batch_sharded", "ikgpu_shard_group_synchronize",
+    "ikgpu_dls_solve_batch_sharded", "ikgpu_shard_group_synchronize", "ikgpu_targets_from_pose7",
 ]
 MAX_PIK_LEVELS, MAX_PIK_DA = 8, 128
 
@@ -136,6 +137,7 @@ def lib():
     L.ikgpu_shard_group_stream.restype = vp
     L.ikgpu_dls_solve_batch_sharded.argtypes = [vp, i64, C.POINTER(vp), C.POINTER(vp), C.POINTER(DlsParams), C.POINTER(vp)]
     L.ikgpu_shard_group_synchronize.argtypes = [vp]
+    L.ikgpu_targets_from_pose7.argtypes = [i64, i32, vp, vp, C.c_int, vp]
     L.ikgpu_dls_solve_batch.argtypes = [vp, i64, vp, vp, C.POINTER(DlsParams), vp, vp, vp, C.c_int, vp]
     L.ikgpu_dls_solve_batch_host.argtypes = [vp, i64, vp, vp, C.POINTER(DlsParams), vp, vp, vp, C.c_int]
     L.ikgpu_pik_params_default.argtypes = [C.POINTER(PikParams), i32]

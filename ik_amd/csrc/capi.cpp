@@ -194,17 +194,21 @@ bool pik_is_two_levels_on_the_tree(const ikgpu_problem *p, const ikgpu_pik_param
 // Host-pointer form of a batched solve: copy in, run `launch` on device buffers, synchronise, copy out.
 template <class Launch>
 int host_solve(const ikgpu_problem *p, int64_t B, const double *q0, const double *targets, double *q_out, uint8_t *success,
-               int32_t *iters, int layout, Launch &&launch) {
+               int32_t *iters, int layout_in, Launch &&launch) {
+    const bool pose7 = (layout_in & IKGPU_TARGETS_POSE7) != 0;   // targets arrive as 7 doubles per task and are expanded on the device
+    const int layout = layout_in & ~IKGPU_TARGETS_POSE7;
     return guarded([&] {
         DeviceGuard g(p->device);
         if (!g.ok) return fail(IKGPU_ERR_DEVICE, "hipSetDevice failed");
         const size_t nb_q = sizeof(double) * p->host.nq * B, nb_t = sizeof(double) * 12 * p->host.ntasks * B;
+        const size_t nb_t7 = pose7 ? sizeof(double) * 7 * p->host.ntasks * B : 0;
         // Small batches -- the reference's own call pattern is ONE problem per call, 50 times a second (ik_ros/src/cassie.cpp:112)
         // -- go through a staging area the problem keeps: one pinned host buffer and one device buffer laid out
         // [q0 | targets | q_out | iters | success], so a call is two copies and a launch instead of five allocations, five
         // copies, a device synchronise and five frees.  A second thread calling on the same problem meanwhile takes the path below.
         const size_t off_t = nb_q, off_q = off_t + nb_t, off_i = off_q + nb_q, off_s = off_i + sizeof(int32_t) * B;
-        const size_t total = (off_s + B + 7) / 8 * 8;
+        const size_t off_7 = (off_s + B + 7) / 8 * 8;                  // (pose7 targets land behind everything else)
+        const size_t total = off_7 + nb_t7;
         if (total <= kStageLimit) {
             std::unique_lock<std::mutex> lock(p->stage.mu, std::try_to_lock);
             if (lock.owns_lock()) {
@@ -220,8 +224,17 @@ int host_solve(const ikgpu_problem *p, int64_t B, const double *q0, const double
                 if (st.cap >= total) {
                     char *h = static_cast<char *>(st.host), *d = static_cast<char *>(st.dev);
                     std::memcpy(h, q0, nb_q);
-                    std::memcpy(h + off_t, targets, nb_t);
-                    hipError_t e = hipMemcpy(d, h, off_q, hipMemcpyHostToDevice);
+                    hipError_t e = hipSuccess;
+                    if (pose7) {
+                        std::memcpy(h + off_7, targets, nb_t7);
+                        e = hipMemcpy(d, h, nb_q, hipMemcpyHostToDevice);
+                        if (e == hipSuccess) e = hipMemcpy(d + off_7, h + off_7, nb_t7, hipMemcpyHostToDevice);
+                        if (e == hipSuccess) e = ikgpu::launch_targets_from_pose7(B, p->host.ntasks, reinterpret_cast<const double *>(d + off_7),
+                                                                                  reinterpret_cast<double *>(d + off_t), layout, nullptr);
+                    } else {
+                        std::memcpy(h + off_t, targets, nb_t);
+                        e = hipMemcpy(d, h, off_q, hipMemcpyHostToDevice);
+                    }
                     if (e != hipSuccess) return hip_fail(e, "host-pointer solve (staged copy in)");
                     const int rc = launch(B, reinterpret_cast<double *>(d), reinterpret_cast<double *>(d + off_t), reinterpret_cast<double *>(d + off_q),
                                           reinterpret_cast<uint8_t *>(d + off_s), reinterpret_cast<int32_t *>(d + off_i), nullptr);
@@ -248,8 +261,9 @@ int host_solve(const ikgpu_problem *p, int64_t B, const double *q0, const double
         if (const char *env = std::getenv("IKGPU_HOST_CHUNK")) { const long c = std::strtol(env, nullptr, 10); if (c >= 64) chunk = c; }
         const int64_t nchunks = (B + chunk - 1) / chunk;
         const size_t nq = static_cast<size_t>(p->host.nq), nt = static_cast<size_t>(12 * p->host.ntasks);
-        const size_t per_problem = 8 * nq + 8 * nt + 8 * nq + 4 + 1;
-        const size_t need = per_problem * static_cast<size_t>(B) + 64 * static_cast<size_t>(nchunks) * 5;   // (every array 64-byte aligned)
+        const size_t nt7 = pose7 ? static_cast<size_t>(7 * p->host.ntasks) : 0;
+        const size_t per_problem = 8 * nq + 8 * nt + 8 * nq + 4 + 1 + 8 * nt7;
+        const size_t need = per_problem * static_cast<size_t>(B) + 64 * static_cast<size_t>(nchunks) * 6;   // (every array 64-byte aligned)
         hipError_t e = hipSuccess;
         auto step = [&](hipError_t r) { if (e == hipSuccess) e = r; };
         if (!pp.in) {
@@ -290,11 +304,14 @@ int host_solve(const ikgpu_problem *p, int64_t B, const double *q0, const double
             double *d_q = reinterpret_cast<double *>(take(8 * nq * bk));
             int32_t *d_i = reinterpret_cast<int32_t *>(take(4 * bk));
             uint8_t *d_s = reinterpret_cast<uint8_t *>(take(bk));
+            double *d_t7 = pose7 ? reinterpret_cast<double *>(take(8 * nt7 * bk)) : nullptr;
             step(copy(d_q0, q0, nullptr, nq, 8, b0, bk, true, pp.in));
-            step(copy(d_t, targets, nullptr, nt, 8, b0, bk, true, pp.in));
+            if (pose7) step(copy(d_t7, targets, nullptr, nt7, 8, b0, bk, true, pp.in));
+            else step(copy(d_t, targets, nullptr, nt, 8, b0, bk, true, pp.in));
             step(hipEventRecord(pp.ev_in[k], pp.in));
             const hipStream_t run = pp.run[k % HostPipe::kRunStreams];
             step(hipStreamWaitEvent(run, pp.ev_in[k], 0));
+            if (pose7) step(ikgpu::launch_targets_from_pose7(bk, p->host.ntasks, d_t7, d_t, layout, run));
             if (e != hipSuccess) break;
             rc = launch(bk, d_q0, d_t, d_q, d_s, d_i, run);
             if (rc != IKGPU_OK) break;
@@ -602,9 +619,10 @@ int ikgpu_dls_solve_batch_host(const ikgpu_problem *p, int64_t B, const double *
     if (int rc = check_params(params)) return rc;
     if (B == 0) return IKGPU_OK;  // an empty batch is a no-op (its pointers may be null)
     if (!q0 || !targets || !q_out) return fail(IKGPU_ERR_INVALID, "null argument");
-    if (layout != IKGPU_SOA && layout != IKGPU_AOS) return fail(IKGPU_ERR_INVALID, "unknown layout");
+    const int lay = layout & ~IKGPU_TARGETS_POSE7;
+    if (lay != IKGPU_SOA && lay != IKGPU_AOS) return fail(IKGPU_ERR_INVALID, "unknown layout");
     return host_solve(p, B, q0, targets, q_out, success, iters, layout, [&](int64_t Bk, const double *d_q0, const double *d_t, double *d_q, uint8_t *d_s, int32_t *d_i, hipStream_t st) {
-        return ikgpu_dls_solve_batch(p, Bk, d_q0, d_t, params, d_q, d_s, d_i, layout, st);
+        return ikgpu_dls_solve_batch(p, Bk, d_q0, d_t, params, d_q, d_s, d_i, lay, st);
     });
 }
 
@@ -635,7 +653,8 @@ int ikgpu_pik_solve_batch(const ikgpu_problem *p, int64_t B, const double *q0, c
     if (!q0 || !targets || !q_out) return fail(IKGPU_ERR_INVALID, "null argument");
     if (B > (int64_t(1) << 31) * 32) return fail(IKGPU_ERR_INVALID, "batch too large for one launch");
     if (pik_is_one_dls_level(p, params)) {
-        const ikgpu_dls_params d{params->max_iterations, params->lambda[0], params->step_length, params->stop_sq_tol};
+        ikgpu_dls_params d{};   // (the derived-visitor members stay off)
+        d.max_iterations = params->max_iterations; d.damping = params->lambda[0]; d.step_length = params->step_length; d.stop_sq_tol = params->stop_sq_tol;
         return ikgpu_dls_solve_batch(p, B, q0, targets, &d, q_out, success, iters, layout, stream);
     }
     if (pik_is_two_levels_on_the_tree(p, params)) {
@@ -643,7 +662,8 @@ int ikgpu_pik_solve_batch(const ikgpu_problem *p, int64_t B, const double *q0, c
             DeviceGuard g(p->device);
             if (!g.ok) return fail(IKGPU_ERR_DEVICE, "hipSetDevice failed");
             ikgpu::BatchIO io{B, q0, targets, q_out, success, iters, layout};
-            const ikgpu_dls_params d{params->max_iterations, params->lambda[0], params->step_length, params->stop_sq_tol};
+            ikgpu_dls_params d{};
+            d.max_iterations = params->max_iterations; d.damping = params->lambda[0]; d.step_length = params->step_length; d.stop_sq_tol = params->stop_sq_tol;
             const hipError_t e = ikgpu::launch_dls_tree(p->host, p->dev, io, d, static_cast<hipStream_t>(stream), &params->lambda[1]);
             if (e != hipSuccess) return hip_fail(e, "launching the tree kernel (two-level ik::pik)");
             return static_cast<int>(IKGPU_OK);
@@ -667,10 +687,21 @@ int ikgpu_pik_solve_batch_host(const ikgpu_problem *p, int64_t B, const double *
     if (int rc = check_pik_params(p, params)) return rc;
     if (B == 0) return IKGPU_OK;
     if (!q0 || !targets || !q_out) return fail(IKGPU_ERR_INVALID, "null argument");
-    if (layout != IKGPU_SOA && layout != IKGPU_AOS) return fail(IKGPU_ERR_INVALID, "unknown layout");
+    const int lay = layout & ~IKGPU_TARGETS_POSE7;
+    if (lay != IKGPU_SOA && lay != IKGPU_AOS) return fail(IKGPU_ERR_INVALID, "unknown layout");
     return host_solve(p, B, q0, targets, q_out, success, iters, layout, [&](int64_t Bk, const double *d_q0, const double *d_t, double *d_q, uint8_t *d_s, int32_t *d_i, hipStream_t st) {
-        return ikgpu_pik_solve_batch(p, Bk, d_q0, d_t, params, d_q, d_s, d_i, layout, st);
+        return ikgpu_pik_solve_batch(p, Bk, d_q0, d_t, params, d_q, d_s, d_i, lay, st);
     });
+}
+
+int ikgpu_targets_from_pose7(int64_t B, int32_t ntasks, const double *pose7, double *targets12, int layout, void *stream) {
+    if (!pose7 || !targets12) return fail(IKGPU_ERR_INVALID, "null argument");
+    if (B < 0 || ntasks < 0) return fail(IKGPU_ERR_INVALID, "negative size");
+    if (layout != IKGPU_SOA && layout != IKGPU_AOS) return fail(IKGPU_ERR_INVALID, "unknown layout");
+    if (B == 0 || ntasks == 0) return IKGPU_OK;
+    const hipError_t e = ikgpu::launch_targets_from_pose7(B, ntasks, pose7, targets12, layout, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "launching the target expansion kernel");
+    return IKGPU_OK;
 }
 
 int ikgpu_evaluate_batch(const ikgpu_problem *p, int64_t B, const double *q, const double *targets, double *e_out,

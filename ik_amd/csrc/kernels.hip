@@ -221,6 +221,31 @@ hipError_t run_fk(const ProblemHost &ph, const DeviceTables &dt, int64_t B, cons
 
 #define IKGPU_FOR_NJ(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
 
+namespace {
+// (x y z qx qy qz qw) -> rotation row-major (9) + translation (3), one thread per (problem, task)
+__global__ __launch_bounds__(256) void targets_from_pose7_kernel(int64_t B, int ntasks, const double *pose7, double *out, int layout) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= B * ntasks) return;
+    const int64_t b = i % B;
+    const int t = static_cast<int>(i / B);
+    double in[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) in[k] = pose7[ikdev::at(layout, B, ntasks * 7, t * 7 + k, b)];
+    double R[9];
+    ikdev::quat_to_R(in, R);   // reads entries 3..6 (qx qy qz qw): the free-flyer's layout
+#pragma unroll
+    for (int k = 0; k < 9; ++k) out[ikdev::at(layout, B, ntasks * 12, t * 12 + k, b)] = R[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out[ikdev::at(layout, B, ntasks * 12, t * 12 + 9 + k, b)] = in[k];
+}
+}  // namespace
+
+hipError_t launch_targets_from_pose7(int64_t B, int ntasks, const double *pose7, double *targets12, int layout, hipStream_t stream) {
+    const int64_t n = B * ntasks;
+    hipLaunchKernelGGL(targets_from_pose7_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, B, ntasks, pose7, targets12, layout);
+    return hipGetLastError();
+}
+
 bool refill_wanted(const ikgpu_dls_params &prm, int64_t B, int64_t resident_waves) {
     if (!(prm.stop_sq_tol >= 0.0) || prm.max_iterations < 1) return false;   // the never-stop visitor: every lane takes the same number of steps
     const char *env = std::getenv("IKGPU_REFILL");
@@ -243,7 +268,6 @@ int64_t refill_resident(int64_t occupancy_waves, int64_t B) {
 }
 
 int64_t refill_grid(const void *kernel, int64_t B) {
-    const int64_t waves = (B + kBlock - 1) / kBlock;
     return refill_resident(persistent_grid(kernel, kBlock, 0, INT64_MAX), B);
 }
 

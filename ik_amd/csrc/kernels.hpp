@@ -96,6 +96,7 @@ bool rtc_generic_static_available(const ProblemHost &gen, bool compile, uint64_t
 hipError_t rtc_launch_generic_static(const ProblemHost &gen, uint64_t key, const BatchIO &io, const ikgpu_dls_params &prm, hipStream_t stream);
 std::string rtc_last_log();   // compiler log (or cache note) of the calling process's last run-time compilation attempt
 hipError_t rtc_launch_chain_hot(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const ikgpu_dls_params &prm, hipStream_t stream);
+hipError_t launch_targets_from_pose7(int64_t B, int ntasks, const double *pose7, double *targets12, int layout, hipStream_t stream);
 int64_t persistent_grid(const void *kernel, int block, size_t lds, int64_t nblocks);
 bool raise_lds_limit(const void *kernel, size_t lds);
 hipError_t launch_dls_chain_hot(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const ikgpu_dls_params &prm,

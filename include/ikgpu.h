@@ -71,6 +71,10 @@ typedef enum {
 } ikgpu_kinematic_type;
 
 typedef enum { IKGPU_SOA = 0, IKGPU_AOS = 1 } ikgpu_layout;
+/* OR-ed into the `layout` argument of the HOST-pointer solve entry points: the targets array holds 7 doubles per task -- translation
+ * (x y z) then quaternion (qx qy qz qw), the order of a free-flyer's configuration -- instead of 12; it is expanded on the device
+ * (ikgpu_targets_from_pose7), so a target costs 56 instead of 96 bytes over PCIe. */
+#define IKGPU_TARGETS_POSE7 0x100
 
 typedef enum { IKGPU_ROOT_FIXED = 0, IKGPU_ROOT_FREEFLYER = 1 } ikgpu_root_joint;
 
@@ -196,8 +200,17 @@ int ikgpu_dls_solve_batch(const ikgpu_problem *p, int64_t B, const double *q0, c
                           const ikgpu_dls_params *params, double *q_out, uint8_t *success, int32_t *iters,
                           int layout /* ikgpu_layout */, void *stream);
 
+/* FrameTask::target (an SE(3), reference ik/ik/frame.hpp:189) given as 7 doubles -- translation (x y z), quaternion (qx qy qz qw;
+ * converted as Eigen's toRotationMatrix does, i.e. as the free-flyer's configuration is read) -- expanded into the 12-double slots
+ * the solve entry points take.  pose7: [ntasks x 7 x B] (IKGPU_SOA) or [B x ntasks x 7] (IKGPU_AOS); targets12 likewise with 12.
+ * DEVICE pointers; asynchronous on `stream`.  Slots of tasks that read a vector only (alignment direction, centre-of-mass point,
+ * posture value: doubles 9..11) take it from the translation part. */
+int ikgpu_targets_from_pose7(int64_t B, int32_t ntasks, const double *pose7, double *targets12, int layout /* ikgpu_layout */, void *stream);
+
 /* Same with HOST pointers: copies in, solves on the device, copies out, synchronises. This is what
- * the single-problem ik::dls() shim calls with B = 1. */
+ * the single-problem ik::dls() shim calls with B = 1.  layout may carry IKGPU_TARGETS_POSE7.  Batches above 1 MiB of buffers
+ * are pipelined in chunks (H2D of chunk k + 1, solve of chunk k, D2H of chunk k - 1 overlap; pinned caller buffers make every
+ * copy asynchronous), through an arena the problem keeps: no allocation and no device-wide synchronisation per call. */
 int ikgpu_dls_solve_batch_host(const ikgpu_problem *p, int64_t B, const double *q0, const double *targets,
                                const ikgpu_dls_params *params, double *q_out, uint8_t *success, int32_t *iters,
                                int layout);

@@ -74,3 +74,40 @@ def test_pipelined_host_entry_matches_the_device_entry(setup, layout, B):
     assert np.array_equal(Q, ref[0].cpu().numpy()) and np.array_equal(ok, ref[1].cpu().numpy()) and np.array_equal(it, ref[2].cpu().numpy())
     Q2, _, _ = ik_amd.dls_batch(problem, q_h, t_h, data, vis, prm, layout=layout)      # the arena is reused
     assert np.array_equal(Q2.T if layout == "aos" else Q2, ref[0].cpu().numpy())
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("B", [100, 40000])
+def test_pose7_targets(setup, layout, B):
+    """Targets as (x y z qx qy qz qw): the device-side expansion (ikgpu_targets_from_pose7) and the host entry's IKGPU_TARGETS_POSE7 flag
+    (small staged path and the chunked pipeline) give what the 12-double targets give."""
+    import ctypes as C
+    from scipy.spatial.transform import Rotation
+    torch, ik_amd, model, problem, data, inputs = setup
+    from ik_amd import capi
+    Q0, T = inputs(B)
+    t12 = T.cpu().numpy()                                            # [1, 12, B]
+    R = t12[0, :9].T.reshape(B, 3, 3)
+    quat = Rotation.from_matrix(R).as_quat()                         # (x y z w), unit
+    pose7 = np.concatenate([t12[0, 9:].T, quat], axis=1)             # [B, 7]
+    p7 = np.ascontiguousarray(pose7.T[None]) if layout == "soa" else np.ascontiguousarray(pose7[:, None, :])
+    lay = capi.SOA if layout == "soa" else capi.AOS
+    # (1) device expansion
+    d7 = torch.from_numpy(p7).cuda()
+    out = torch.empty((1, 12, B) if layout == "soa" else (B, 1, 12), dtype=torch.float64, device="cuda")
+    capi.check(capi.lib().ikgpu_targets_from_pose7(B, 1, d7.data_ptr(), out.data_ptr(), lay, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    ref12 = T if layout == "soa" else T.permute(2, 0, 1).contiguous()
+    assert (out - ref12).abs().max().item() < 1e-14
+    # (2) host entry with the flag against the host entry with the expanded targets
+    q_h = Q0.cpu().numpy() if layout == "soa" else np.ascontiguousarray(Q0.cpu().numpy().T)
+    t_h = out.cpu().numpy()
+    prm = capi.DlsParams(30, 1e-2, 1.0, 1e-4)
+    res = []
+    for tg, flag in ((t_h, 0), (p7, capi.TARGETS_POSE7)):
+        Q = np.empty_like(q_h)
+        ok, it = np.zeros(B, np.uint8), np.zeros(B, np.int32)
+        capi.check(capi.lib().ikgpu_dls_solve_batch_host(data._h, B, q_h.ctypes.data, tg.ctypes.data, C.byref(prm), Q.ctypes.data, ok.ctypes.data, it.ctypes.data, lay | flag))
+        res.append((Q, ok, it))
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
