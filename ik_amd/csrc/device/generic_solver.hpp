@@ -546,35 +546,20 @@ IKD_FN void generic_integrate_clip(const TB &T, const WS &ws, double step_length
             freeflyer_integrate(qb, R1, v, qn);
             IKD_UNROLL
             for (int k = 0; k < 7; ++k) {
-                double lo_ = T.lower[iq + k], hi_ = T.upper[iq + k];
-#if defined(IKD_STATIC_TABLES) && IKD_ON_DEVICE
-                asm volatile("" : "+v"(lo_), "+v"(hi_));   // (see the revolute branch below)
-#endif
-                const double c = dmin(hi_, dmax(qn[k], lo_));
+                const double c = dmin(T.upper[iq + k], dmax(qn[k], T.lower[iq + k]));
                 ws[T.off_q + iq + k] = active ? c : qb[k];
             }
         } else if (T.jtype[j] == GJ_REVOLUTE_UNBOUNDED) {
             const double c0 = ws[T.off_q + iq], s0 = ws[T.off_q + iq + 1];
             double c1, s1;
             unbounded_integrate(c0, s0, step_length * ws[T.off_dq + iv], c1, s1);
-            double lo0 = T.lower[iq], hi0 = T.upper[iq], lo1 = T.lower[iq + 1], hi1 = T.upper[iq + 1];
-#if defined(IKD_STATIC_TABLES) && IKD_ON_DEVICE
-            asm volatile("" : "+v"(lo0), "+v"(hi0), "+v"(lo1), "+v"(hi1));   // (see the revolute branch below)
-#endif
-            c1 = dmin(hi0, dmax(c1, lo0));
-            s1 = dmin(hi1, dmax(s1, lo1));
+            c1 = dmin(T.upper[iq], dmax(c1, T.lower[iq]));
+            s1 = dmin(T.upper[iq + 1], dmax(s1, T.lower[iq + 1]));
             ws[T.off_q + iq] = active ? c1 : c0;
             ws[T.off_q + iq + 1] = active ? s1 : s0;
         } else {
             const double qo = ws[T.off_q + iq];
-            // Run-time specialised build: the limits are compile-time constants there, and gfx950 code generated for
-            // min(C_hi, max(x, C_lo)) with two literal bounds under -fno-signed-zeros -fno-honor-nans came out WRONG for one joint of one
-            // task set (Cassie leg, position task + centre of mass in the foot frame: q[7] landed on its upper limit; correct with either
-            // flag dropped, and with the bounds opaque: tools/dbg_static.py).  The bounds are therefore made opaque to the optimiser.
-            double lo_ = T.lower[iq], hi_ = T.upper[iq];
-#if defined(IKD_STATIC_TABLES) && IKD_ON_DEVICE
-            asm volatile("" : "+v"(lo_), "+v"(hi_));
-#endif
+            const double lo_ = T.lower[iq], hi_ = T.upper[iq];
             const double c = dmin(hi_, dmax(dfma(step_length, ws[T.off_dq + iv], qo), lo_));
             ws[T.off_q + iq] = active ? c : qo;
         }

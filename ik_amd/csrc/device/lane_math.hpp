@@ -99,6 +99,17 @@ IKD_FN double dfma3(double a, double b, double c) {
 #endif
 }
 IKD_FN double dsel(bool c, double a, double b) { return c ? a : b; }
+// A per-lane choice between two ALREADY EVALUATED values.  In the run-time specialised programs (IKD_STATIC_TABLES: thousands of
+// instructions per iteration, up to 512 registers and some spill code) a per-lane `c ? a : b` must not become a divergent branch:
+// the register allocator was seen to put a spill store of a loop-carried value into the flow block of such a branch, where the EXEC
+// mask is partial -- masked-off lanes never wrote their slot and got a stale value back (tools/spill_exec_check.py).
+// There every choice goes through dsel (both arms evaluated, one v_cndmask pair); elsewhere it is the plain conditional operator,
+// which hipcc may turn into a branch around an expensive arm (measured faster in the chain kernels, which do not spill).
+#ifdef IKD_STATIC_TABLES
+#define IKD_CHOOSE(c, a, b) dsel((c), (a), (b))
+#else
+#define IKD_CHOOSE(c, a, b) ((c) ? (a) : (b))
+#endif
 IKD_FN double dmin(double a, double b) { return __builtin_fmin(a, b); }
 IKD_FN double dmax(double a, double b) { return __builtin_fmax(a, b); }
 
@@ -265,7 +276,7 @@ IKD_FN double dacos(double x) {
     const double ax = __builtin_fabs(x);
     const bool small = ax < 0.5;
     // small: z = x^2 ; large: z = (1-|x|)/2
-    const double z = small ? x * x : (1.0 - ax) * 0.5;
+    const double z = IKD_CHOOSE(small, x * x, (1.0 - ax) * 0.5);
     double p = dfma(z, pS5, pS4);
     p = dfma(z, p, pS3);
     p = dfma(z, p, pS2);
@@ -298,9 +309,9 @@ IKD_FN double dacos(double x) {
     const double res_pos = 2.0 * (df + dfma(r, s, c));
     // x <= -0.5: pi - 2*(s + (r*s - pio2_lo))
     const double res_neg = kPi - 2.0 * (s + dfma(r, s, -pio2_lo));
-    const double res_large = (x > 0.0) ? res_pos : res_neg;
-    double res = small ? res_small : res_large;
-    res = (ax >= 1.0) ? ((x > 0.0) ? 0.0 : kPi) : res;
+    const double res_large = IKD_CHOOSE(x > 0.0, res_pos, res_neg);
+    double res = IKD_CHOOSE(small, res_small, res_large);
+    res = IKD_CHOOSE(ax >= 1.0, IKD_CHOOSE(x > 0.0, 0.0, kPi), res);
     return res;
 }
 

@@ -546,17 +546,17 @@ IKD_FN void freeflyer_integrate(const double (&qb)[7], const double (&R1)[9], co
     i0 = (M[8] > mii) ? 2 : i0;
     const bool cx = !cw && i0 == 0, cy = !cw && i0 == 1;
     // t = sqrt(1 + trace)  or  sqrt(1 + M_ii - M_jj - M_kk)
-    const double arg = cw ? trace + 1.0 : (cx ? (M[0] - M[4] - M[8] + 1.0) : (cy ? (M[4] - M[8] - M[0] + 1.0) : (M[8] - M[0] - M[4] + 1.0)));
+    const double arg = IKD_CHOOSE(cw, trace + 1.0, IKD_CHOOSE(cx, M[0] - M[4] - M[8] + 1.0, IKD_CHOOSE(cy, M[4] - M[8] - M[0] + 1.0, M[8] - M[0] - M[4] + 1.0)));
     const double tq = dsqrt(arg);
     const double half_t = 0.5 * tq;
     const double s = 0.5 * drcp(tq);
     const double d21 = M[7] - M[5], d02 = M[2] - M[6], d10 = M[3] - M[1];  // (R21-R12), (R02-R20), (R10-R01)
     const double s01 = M[3] + M[1], s02 = M[6] + M[2], s12 = M[7] + M[5];
     double rq[4];  // x y z w
-    rq[0] = cw ? d21 * s : (cx ? half_t : (cy ? s01 * s : s02 * s));
-    rq[1] = cw ? d02 * s : (cx ? s01 * s : (cy ? half_t : s12 * s));
-    rq[2] = cw ? d10 * s : (cx ? s02 * s : (cy ? s12 * s : half_t));
-    rq[3] = cw ? half_t : (cx ? d21 * s : (cy ? d02 * s : d10 * s));
+    rq[0] = IKD_CHOOSE(cw, d21 * s, IKD_CHOOSE(cx, half_t, IKD_CHOOSE(cy, s01 * s, s02 * s)));
+    rq[1] = IKD_CHOOSE(cw, d02 * s, IKD_CHOOSE(cx, s01 * s, IKD_CHOOSE(cy, half_t, s12 * s)));
+    rq[2] = IKD_CHOOSE(cw, d10 * s, IKD_CHOOSE(cx, s02 * s, IKD_CHOOSE(cy, s12 * s, half_t)));
+    rq[3] = IKD_CHOOSE(cw, half_t, IKD_CHOOSE(cx, d21 * s, IKD_CHOOSE(cy, d02 * s, d10 * s)));
     const double dp = dfma(rq[0], qb[3], dfma(rq[1], qb[4], dfma(rq[2], qb[5], rq[3] * qb[6])));
     const double sg = (dp < 0.0) ? -1.0 : 1.0;
     const double n2 = dfma(rq[0], rq[0], dfma(rq[1], rq[1], dfma(rq[2], rq[2], rq[3] * rq[3])));

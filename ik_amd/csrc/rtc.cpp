@@ -196,7 +196,7 @@ uint64_t source_hash(const std::string &src) {
 
 // Compiles `src` against the embedded device headers, or fetches the code object from the on-disk cache (file name: prefix + the
 // hash of headers, source, flags and hipRTC version).  IKGPU_RTC_DUMP=<dir>: also writes the generated source there.
-void compile_cached(const char *prefix, const std::string &src_in, HotCode &hc) {
+void compile_cached(const char *prefix, const std::string &src_in, HotCode &hc, bool if_convert = false) {
     hc.tried = true;
     std::string src = src_in;
     // (debugging aid: IKGPU_RTC_DEFINES="-DX -DY" is prepended to the source as #define lines and so takes part in the cache key)
@@ -215,7 +215,7 @@ void compile_cached(const char *prefix, const std::string &src_in, HotCode &hc) 
     }
     const RtcApi &api = rtc_api();
     if (!api.ok) { hc.log = "libhiprtc could not be loaded"; return; }
-    const uint64_t h = source_hash(src);
+    const uint64_t h = source_hash(src) ^ (if_convert ? 0x9e3779b97f4a7c15ull : 0ull);
     char name[96];
     std::snprintf(name, sizeof name, "/%s_%016llx", prefix, static_cast<unsigned long long>(h));
     if (const char *dump = std::getenv("IKGPU_RTC_DUMP")) {
@@ -231,6 +231,9 @@ void compile_cached(const char *prefix, const std::string &src_in, HotCode &hc) 
     // (debugging aid: IKGPU_RTC_PLAIN_FLAGS drops the three no-signed-zeros / no-NaN / no-infinity flags; set it together with a
     // fresh IKGPU_CACHE_DIR -- the flags are part of the cache key only in their default form)
     std::vector<const char *> flags(kFlags, kFlags + sizeof kFlags / sizeof kFlags[0]);
+    // the generic program: every two-armed choice whose arms the compiler may evaluate speculatively becomes a select, whatever the
+    // arms cost -- no divergent branch inside the iteration (see IKD_CHOOSE in device/lane_math.hpp)
+    if (if_convert) { flags.push_back("-mllvm"); flags.push_back("-two-entry-phi-node-folding-threshold=100000"); }
     if (const char *m = std::getenv("IKGPU_RTC_PLAIN_FLAGS")) {   // bit k set: drop the k-th of the three flags
         const long mask = std::strtol(m, nullptr, 10);
         std::vector<const char *> keep(kFlags, kFlags + 5);
@@ -467,7 +470,7 @@ bool rtc_generic_static_available(const ProblemHost &gen, bool compile, uint64_t
     if (key_out) *key_out = key;
     std::lock_guard<std::mutex> lock(g_mu);
     HotCode &hc = g_gen_codes[key];
-    if (!hc.tried) compile_cached("generic_static", src, hc);
+    if (!hc.tried) compile_cached("generic_static", src, hc, /*if_convert=*/true);
     g_last_log = hc.log;
     return hc.ok;
 }
