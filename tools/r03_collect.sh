@@ -1,0 +1,18 @@
+#!/usr/bin/env bash
+# Copies round 3's measurement matrix (tools/r03_measure_all.sh) from gpurun_out/ into profiles/ (r03_*) and folds every PMC session
+# into ik_amd/kernel_stats.json (tools/pmc_to_stats.py: one session, one build, stamped).
+set -e
+cd "$(dirname "$0")/.."
+mkdir -p profiles/r03_pmc
+for w in cassie_leg ur5 ur10 ur5_clamp ur10_clamp arm7 ur5_two_tasks cassie_full_body cassie_demo cassie_demo_posture cassie_demo_pinned cassie_demo_pinned_posture cassie_demo_pik; do
+  [ -s gpurun_out/bench_$w.json ] && cp gpurun_out/bench_$w.json profiles/r03_bench_$w.json
+  f=$(ls -t gpurun_out/stats_$w/runc/*_kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" profiles/r03_kernel_stats_$w.csv
+done
+for s in cassie_leg cassie_leg_general ur5 arm7 ur5_two_tasks cassie_full_body cassie_demo cassie_demo_tree cassie_demo_coop cassie_demo_posture cassie_demo_pinned cassie_demo_pinned_tree cassie_demo_pinned_posture cassie_demo_pik; do
+  [ -d gpurun_out/r03_pmc_$s ] && python3 tools/pmc_to_stats.py gpurun_out/r03_pmc_$s profiles/r03_pmc $s | cut -c1-400
+done
+for f in r03_refill_timing_chain.txt r03_refill_timing_tree.txt r03_host_entry.txt r03_chain_builds.txt r03_generic_forms.txt r03_bench_launcher_n1.json r03_bench_launcher_n1_gather_full.json r03_copy_probe.txt; do
+  [ -s gpurun_out/$f ] && cp gpurun_out/$f profiles/$f
+done
+[ -s gpurun_out/parity_counts.json ] && cp gpurun_out/parity_counts.json profiles/r03_parity_counts.json
+ls profiles | grep r03 | wc -l

@@ -1,0 +1,41 @@
+#!/usr/bin/env bash
+# Round 3's measurement matrix, in parts (a gpurun call lasts at most 20 minutes):
+#   tools/r03_measure_all.sh stats     bench line + rocprofv3 --kernel-trace --stats of every bench workload
+#   tools/r03_measure_all.sh pmc1|pmc2 PMC sessions (tools/pmc_session.sh: fresh directories, one build per session), incl. the
+#                                      A/B variants an environment switch selects at problem creation
+#   tools/r03_measure_all.sh misc      refill / host entry / chain builds / generic forms timings, launcher rehearsals, probes
+# Outputs under gpurun_out/; tools/r03_collect.sh folds them into profiles/ and ik_amd/kernel_stats.json.
+part="${1:-stats}"
+steps=()
+case "$part" in
+stats)
+  for w in cassie_leg ur5 ur10 ur5_clamp ur10_clamp arm7 ur5_two_tasks cassie_full_body cassie_demo cassie_demo_posture cassie_demo_pinned cassie_demo_pinned_posture cassie_demo_pik; do
+    steps+=("stats_$w|240|tools/stats_session.sh $w")
+  done ;;
+pmc1)
+  steps+=("pmc_cassie_leg|300|tools/pmc_session.sh cassie_leg r03_pmc_cassie_leg")
+  steps+=("pmc_cassie_leg_general|300|IKGPU_CHAIN_HOT=0 tools/pmc_session.sh cassie_leg r03_pmc_cassie_leg_general")
+  steps+=("pmc_ur5|300|tools/pmc_session.sh ur5 r03_pmc_ur5")
+  steps+=("pmc_arm7|300|tools/pmc_session.sh arm7 r03_pmc_arm7")
+  steps+=("pmc_ur5_two_tasks|300|tools/pmc_session.sh ur5_two_tasks r03_pmc_ur5_two_tasks")
+  steps+=("pmc_cassie_full_body|300|tools/pmc_session.sh cassie_full_body r03_pmc_cassie_full_body")
+  steps+=("pmc_cassie_demo|300|tools/pmc_session.sh cassie_demo r03_pmc_cassie_demo") ;;
+pmc2)
+  steps+=("pmc_cassie_demo_tree|300|IKGPU_TREE_STATIC_ROWS=0 tools/pmc_session.sh cassie_demo r03_pmc_cassie_demo_tree")
+  steps+=("pmc_cassie_demo_coop|400|IKGPU_DLS_KERNEL=generic IKGPU_GENERIC_STATIC=0 tools/pmc_session.sh cassie_demo r03_pmc_cassie_demo_coop")
+  steps+=("pmc_cassie_demo_posture|300|tools/pmc_session.sh cassie_demo_posture r03_pmc_cassie_demo_posture")
+  steps+=("pmc_cassie_demo_pinned|300|tools/pmc_session.sh cassie_demo_pinned r03_pmc_cassie_demo_pinned")
+  steps+=("pmc_cassie_demo_pinned_tree|300|IKGPU_TREE_STATIC_ROWS=0 tools/pmc_session.sh cassie_demo_pinned r03_pmc_cassie_demo_pinned_tree")
+  steps+=("pmc_cassie_demo_pinned_posture|300|tools/pmc_session.sh cassie_demo_pinned_posture r03_pmc_cassie_demo_pinned_posture")
+  steps+=("pmc_cassie_demo_pik|300|tools/pmc_session.sh cassie_demo_pik r03_pmc_cassie_demo_pik") ;;
+misc)
+  steps+=("refill_chain|200|python3 tools/refill_timing.py > gpurun_out/r03_refill_timing_chain.txt 2>&1; grep -v amdgpu.ids gpurun_out/r03_refill_timing_chain.txt | tail -4")
+  steps+=("refill_tree|200|python3 tools/refill_timing.py full_body x > gpurun_out/r03_refill_timing_tree.txt 2>&1; grep -v amdgpu.ids gpurun_out/r03_refill_timing_tree.txt | tail -4")
+  steps+=("host_entry|200|python3 tools/host_entry_timing.py > gpurun_out/r03_host_entry.txt 2>&1; grep -v amdgpu.ids gpurun_out/r03_host_entry.txt | tail -4")
+  steps+=("chain_builds|200|python3 tools/chain_builds_timing.py > gpurun_out/r03_chain_builds.txt 2>&1; grep -v amdgpu.ids gpurun_out/r03_chain_builds.txt")
+  steps+=("generic_forms|400|FORMS=coop,static python3 tools/generic_forms.py shared_joints com_of_the_arm moving_reference_prismatic demo_task_set com_under_feet three_feet_frames feet_frames_beyond_the_register_solve rows_16 nv_30 fixed_two_feet_priorities com_in_foot_frame > gpurun_out/r03_generic_forms.txt 2>&1; grep -v amdgpu.ids gpurun_out/r03_generic_forms.txt")
+  steps+=("launcher|300|python3 bench.py --launcher --no-cpu > gpurun_out/r03_bench_launcher_n1.json; cut -c1-250 gpurun_out/r03_bench_launcher_n1.json")
+  steps+=("launcher_full|300|python3 bench.py --launcher --gather full --no-cpu > gpurun_out/r03_bench_launcher_n1_gather_full.json; cut -c1-250 gpurun_out/r03_bench_launcher_n1_gather_full.json")
+  steps+=("copy_probe|100|tools/copy_probe > gpurun_out/r03_copy_probe.txt; tail -6 gpurun_out/r03_copy_probe.txt") ;;
+esac
+tools/gpu_session.sh "${steps[@]}"
