@@ -38,6 +38,7 @@ def _build(name, B, rows, seed=0):
     out = {}
     for label, val in (("static", str(rows)), ("tree", "0")):
         os.environ["IKGPU_TREE_STATIC_ROWS"] = val
+        os.environ["IKGPU_TREE_STATIC_CONSTRAINED"] = "1"   # (the product leaves constrained tree problems on the tree kernel: it is faster there)
         try:
             ik, O, model, problem, data, om, ot, q0, tg = build(model_name, ff, specs, B, seed=seed)
             if cons:
@@ -45,6 +46,7 @@ def _build(name, B, rows, seed=0):
                 data = ik_amd.dls_data(problem, device=0)
         finally:
             os.environ["IKGPU_TREE_STATIC_ROWS"] = "0"
+            os.environ.pop("IKGPU_TREE_STATIC_CONSTRAINED", None)
         out[label] = (ik, O, model, problem, data, om, ot, q0, tg)
     return out
 

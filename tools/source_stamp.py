@@ -15,7 +15,7 @@ def device_source_sha16():
     h = hashlib.sha256()
     files = sorted(glob.glob(os.path.join(ROOT, "ik_amd", "csrc", "device", "*.hpp")) +
                    glob.glob(os.path.join(ROOT, "ik_amd", "csrc", "*.hip")) +
-                   [os.path.join(ROOT, "ik_amd", "csrc", f) for f in ("kernels.hpp", "generic_tables.hpp", "Makefile")])
+                   [os.path.join(ROOT, "ik_amd", "csrc", f) for f in ("kernels.hpp", "generic_tables.hpp", "Makefile", "rtc.cpp")])   # rtc.cpp: the run-time compiled kernels' source generator and flags
     for f in files:
         h.update(os.path.relpath(f, ROOT).encode())
         h.update(open(f, "rb").read())
