@@ -23,7 +23,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SOLVE = ("dls_", "pik_")
+SOLVE = ("dls_", "pik_", "ikgpu_hot_", "ikgpu_lane_")   # (the last two: kernels compiled at run time, rtc.cpp)
 NOT_SOLVE = ("pass_through",)
 
 
