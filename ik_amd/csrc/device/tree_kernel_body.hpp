@@ -32,9 +32,10 @@ struct TreeKernelArgs {
 // B independent ik::dls() calls (reference ik/ik/dls.cpp:5-78) on a free-flyer model, lane `gid`.
 // post_lane / post_stride: where a posture build keeps the joints outside the chains between iterations -- an LDS column of
 // the lane (row k at post_lane[k * post_stride]) when the kernel has LDS to spare, else (nullptr) the lane's column of q_out.
+// group0: the first problem of this lane's workgroup (wave-uniform; what LaneRows addresses from), or -1: per-lane addressing.
 template <int NJ, int NCH, int SPEC = -1, class Desc, class Park, class AnyFn>
 IKD_FN void dls_tree_body(const TreeKernelArgs<NJ, NCH> &a, const Desc &d, int64_t gid, Park park,
-                          AnyFn any_active, double *post_lane = nullptr, int64_t post_stride = 0) {
+                          AnyFn any_active, double *post_lane = nullptr, int64_t post_stride = 0, int64_t group0 = -1) {
     const bool valid = gid < a.B;
     const int64_t b = valid ? gid : a.B - 1;
     double qb[7], qj0[NJ], qj1[NJ];  // chain 1's angles stay unused (zero) when NCH == 1
@@ -48,8 +49,10 @@ IKD_FN void dls_tree_body(const TreeKernelArgs<NJ, NCH> &a, const Desc &d, int64
         qj0[j] = a.q0[at(a.layout, a.B, a.nq, a.qidx[0][j], b)];
         qj1[j] = NCH > 1 ? a.q0[at(a.layout, a.B, a.nq, a.qidx[NCH - 1][j], b)] : 0.0;
     }
-    const double *tl = a.layout == LAYOUT_SOA ? a.targets + b : a.targets + b * a.ntasks * 12;
-    const int64_t ts = a.layout == LAYOUT_SOA ? a.B : 1;
+    const int64_t g0 = group0 >= 0 ? group0 : b;
+    const int64_t tcol = a.layout == LAYOUT_SOA ? 1 : static_cast<int64_t>(a.ntasks) * 12;   // doubles between consecutive problems
+    const LaneRows tl{reinterpret_cast<const char *>(a.targets + g0 * tcol), static_cast<uint32_t>((b - g0) * tcol * 8),
+                      static_cast<uint32_t>(a.layout == LAYOUT_SOA ? a.B * 8 : 8), group0 >= 0};
 
     int iters;
     bool success;
@@ -66,11 +69,11 @@ IKD_FN void dls_tree_body(const TreeKernelArgs<NJ, NCH> &a, const Desc &d, int64
             ps.q_lane[(ps.by_row ? k : a.prm.post_q[k]) * ps.stride] = a.q0[at(a.layout, a.B, a.nq, a.prm.post_q[k], b)];
     }
     if (kPost && a.prm.post_on && post_lane) {  // every lane (a tail lane shadows the last problem): its own LDS column
-        for (int k = 0; k < a.prm.post_n; ++k) t_out[k * post_stride] = tl[(a.prm.post_slot[k] * 12 + 9) * ts];
+        for (int k = 0; k < a.prm.post_n; ++k) t_out[k * post_stride] = tl(a.prm.post_slot[k] * 12 + 9);
         for (int j = 0; j < NJ; ++j)
-            t_chain[j * post_stride] = a.prm.postc_slot[0][j] >= 0 ? tl[(a.prm.postc_slot[0][j] * 12 + 9) * ts] : 0.0;
+            t_chain[j * post_stride] = a.prm.postc_slot[0][j] >= 0 ? tl(a.prm.postc_slot[0][j] * 12 + 9) : 0.0;
     }
-    tree_dls<NJ, NCH, SPEC>(d, a.prm, qb, qj0, qj1, tl, ts, a.tslot, ps, iters, success, park, any_active);
+    tree_dls<NJ, NCH, SPEC>(d, a.prm, qb, qj0, qj1, tl, a.tslot, ps, iters, success, park, any_active);
     if (kPost && a.prm.post_on && valid && ps.by_row) {
         for (int k = 0; k < a.prm.post_n; ++k) a.q_out[at(a.layout, a.B, a.nq, a.prm.post_q[k], b)] = ps.q_lane[k * ps.stride];
     }
@@ -119,13 +122,14 @@ struct TreeRefill {
             qj1[j] = NCH > 1 ? A.q0[at(A.layout, A.B, A.nq, A.qidx[NCH - 1][j], bb)] : 0.0;
         }
     }
-    __device__ __forceinline__ const double *target_pointer(int64_t bb) const {
-        return a->layout == LAYOUT_SOA ? a->targets + bb : a->targets + bb * a->ntasks * 12;
+    __device__ __forceinline__ LaneRows target_rows(int64_t bb) const {
+        return LaneRows{reinterpret_cast<const char *>(a->layout == LAYOUT_SOA ? a->targets + bb : a->targets + bb * a->ntasks * 12), 0u,
+                        static_cast<uint32_t>(a->layout == LAYOUT_SOA ? a->B * 8 : 8), false};
     }
 
     // done lanes store (q, success, iters) and take the next problem; returns the wave-uniform "some lane still holds a problem"
     template <class ReloadFn>
-    __device__ __forceinline__ bool step(bool done, bool stopped, int iters, double (&qb)[7], double (&qj0)[NJ], double (&qj1)[NJ], const double *&tl,
+    __device__ __forceinline__ bool step(bool done, bool stopped, int iters, double (&qb)[7], double (&qj0)[NJ], double (&qj1)[NJ], LaneRows &tl,
                                          bool &active, ReloadFn reload_targets) {
         const TreeKernelArgs<NJ, NCH> &A = *a;
         const int lane = static_cast<int>(threadIdx.x) & 63;
@@ -166,7 +170,7 @@ struct TreeRefill {
                 if (got) {
                     b = nb;
                     load(b, qb, qj0, qj1);
-                    tl = target_pointer(b);
+                    tl = target_rows(b);
                     reload_targets(tl);
                 }
             }
@@ -185,12 +189,11 @@ __device__ __forceinline__ void dls_tree_refill_body(const TreeKernelArgs<NJ, NC
     const int64_t bs = rf.start ? rf.b : a.B - 1;
     double qb[7], qj0[NJ], qj1[NJ];
     rf.load(bs, qb, qj0, qj1);
-    const double *tl = rf.target_pointer(bs);
-    const int64_t ts = a.layout == LAYOUT_SOA ? a.B : 1;
+    const LaneRows tl = rf.target_rows(bs);
     const PostureState ps{nullptr, 0, false, a.lower, a.upper, false, nullptr, nullptr};
     int iters;
     bool success;
-    tree_dls<NJ, NCH, SPEC>(d, a.prm, qb, qj0, qj1, tl, ts, a.tslot, ps, iters, success, park, [](bool act) { return __any(act) != 0; }, rf);
+    tree_dls<NJ, NCH, SPEC>(d, a.prm, qb, qj0, qj1, tl, a.tslot, ps, iters, success, park, [](bool act) { return __any(act) != 0; }, rf);
     if (lane == 0) {   // the last wave out resets the slot
         __threadfence();
         if (atomicAdd(queue + 1, 1ull) == static_cast<unsigned long long>(nwaves) - 1ull) {

@@ -242,13 +242,67 @@ struct LegFactor {
 // Evaluate one chain task at the current configuration, add its base-block contributions to
 // (Hbb, gb), eliminate its NJ joint unknowns (Schur complement onto the base) and return the factor.
 // FAST: sin / cos by dsincos_fast (the device loops) instead of dsincos (runtime-parameter build), lane_math.hpp.
+// This lane's element of row r of a caller's array of doubles laid out [rows][B] (component-major) or [B][rows] (problem-major):
+//   *(base + r * stride_bytes + off).
+// Lock-step kernels: `base` is the array at the workgroup's first problem (wave-uniform) and `off` the lane's byte offset from
+// there, 32 bits -- a row's address is scalar arithmetic and the load takes the SGPR-base + VGPR-offset form.  (With a 64-bit
+// per-lane pointer per row hipcc hoisted up to 36 row addresses out of the iteration loop, two VGPRs each, and spilled them to
+// scratch memory: every target word then cost a scratch reload AND the load, back to back.)  Refill kernels, whose lanes change
+// problems: `base` is the lane's own pointer, off = 0.
+struct LaneRows {
+    const char *base;
+    uint32_t off;
+    uint32_t stride_bytes;   // bytes between consecutive rows: B * 8 (the tree launchers refuse B >= 2^29) or 8
+    bool uniform;   // `base` is wave-uniform (a literal at every construction site: folds after inlining)
+    IKD_FN double operator()(int r) const {
+        const char *row = base + static_cast<uint64_t>(static_cast<uint32_t>(r)) * stride_bytes;
+#if IKD_ON_DEVICE
+        // pin the row address in an SGPR pair: left to itself hipcc adds `off` to `base` first and is back to one 64-bit VGPR address
+        // per row (the asm hides the pointer's provenance, so its address space is stated: a generic pointer would be a flat_load)
+        if (uniform) {
+            typedef const char __attribute__((address_space(1))) *GlobalBytes;
+            typedef const double __attribute__((address_space(1))) *GlobalDouble;
+            GlobalBytes g = (GlobalBytes)row;
+            asm("" : "+s"(g));
+            // (and the zero-extension of `off` has to sit in the load's own basic block for the SGPR-base + 32-bit-VGPR-offset form
+            // to be selected: hoisted out of the loop as a 64-bit pair it turns every load into a 64-bit vector add + load)
+            uint32_t o = off;
+            asm volatile("" : "+v"(o));
+            return *reinterpret_cast<GlobalDouble>(g + o);
+        }
+#endif
+        return *reinterpret_cast<const double *>(row + off);
+    }
+    // N consecutive rows from row r0: one scalar multiply for the first row, one 64-bit scalar add per further row
+    template <int N>
+    IKD_FN void run(int r0, double (&out)[N]) const {
+#if IKD_ON_DEVICE
+        if (uniform) {
+            typedef const char __attribute__((address_space(1))) *GlobalBytes;
+            typedef const double __attribute__((address_space(1))) *GlobalDouble;
+            GlobalBytes g = (GlobalBytes)(base + static_cast<uint64_t>(static_cast<uint32_t>(r0)) * stride_bytes);
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                asm("" : "+s"(g));
+                uint32_t o = off;
+                asm volatile("" : "+v"(o));
+                out[k] = *reinterpret_cast<GlobalDouble>(g + o);
+                g += stride_bytes;
+            }
+            return;
+        }
+#endif
+#pragma unroll
+        for (int k = 0; k < N; ++k) out[k] = (*this)(r0 + k);
+    }
+};
+
 // Posture rows on the joints of one chain (wave-uniform description; targets per lane).
 struct ChainPosture {
     bool on, prio0;
     const int *slot;        // [NJ] target slot or -1
     const double *w, *m;    // [NJ]
-    const double *targets_lane;
-    int64_t tstride;
+    LaneRows targets;
     const double *t_chain;  // when not null: the lane's LDS column of the chain rows' target values, row a at t_chain[a * t_stride]
     int64_t t_stride;
 };
@@ -435,7 +489,7 @@ IKD_FN void leg_eval_factor(const double (&R1)[9], const double (&p1)[3], PlPtr 
             const int slot = po.slot[a];
             if (slot >= 0) {
                 const double w = po.w[a];
-                const double tgt = po.t_chain ? po.t_chain[a * po.t_stride] : po.targets_lane[(slot * 12 + 9) * po.tstride];
+                const double tgt = po.t_chain ? po.t_chain[a * po.t_stride] : po.targets(slot * 12 + 9);
                 const double ea = (q[a] - tgt) * po.m[a] * w;
                 if (po.prio0) e0sq = dfma(ea, ea, e0sq);
                 F.L[tri(a, a)] = dfma(w, w, F.L[tri(a, a)]);
@@ -713,7 +767,7 @@ struct PostureState {
 // four at a time 0.76 ms; state in the q_out column instead of LDS 0.75 ms; without the fence below 0.77 ms): `apply` takes the step of the previous iteration
 // (deferred to the top of the next one, where next to nothing is live in registers), and the error at the resulting q is
 // added to `e0sq` when the rows sit on priority level 0.
-IKD_FN void posture_outside_pass(const TreeParams &prm, const PostureState &ps, const double *targets_lane, int64_t tstride,
+IKD_FN void posture_outside_pass(const TreeParams &prm, const PostureState &ps, const LaneRows &targets,
                                  bool apply, double &e0sq) {
     constexpr int kChunk = 3;
     const bool prio0 = prm.post_prio == 0;
@@ -724,7 +778,7 @@ IKD_FN void posture_outside_pass(const TreeParams &prm, const PostureState &ps, 
         for (int u = 0; u < kChunk; ++u) {
             const int k = k0 + u < prm.post_n ? k0 + u : k0;  // a short last chunk re-reads its first row; nothing of the repeats is stored or summed
             qv[u] = ps.q_lane[(ps.by_row ? k : prm.post_q[k]) * ps.stride];
-            tv[u] = ps.t_out ? ps.t_out[k * ps.stride] : targets_lane[(prm.post_slot[k] * 12 + 9) * tstride];
+            tv[u] = ps.t_out ? ps.t_out[k * ps.stride] : targets(prm.post_slot[k] * 12 + 9);
         }
 #pragma unroll
         for (int u = 0; u < kChunk; ++u) {
@@ -754,16 +808,22 @@ struct NoRefill {
 
 template <int NJ, int NCH, int SPEC = -1, class Desc, class Park, class AnyFn, class R = NoRefill>
 IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], double (&qj0)[NJ], double (&qj1)[NJ],
-                     const double *targets_lane, int64_t tstride, const int (&tslot)[3], const PostureState &ps, int &iters_out,
+                     const LaneRows &targets_in, const int (&tslot)[3], const PostureState &ps, int &iters_out,
                      bool &success_out, Park park, AnyFn any_active, R refill = R{}) {
     constexpr bool kGeneral = spec_is_general(SPEC);  // the demo's extras exist in the general builds only
     static_assert(!R::on || !(spec_has_posture(SPEC) || spec_has_pik(SPEC)), "lane refill: builds without per-lane state outside q");
     constexpr bool kPik = spec_has_pik(SPEC);  // the orthogonalisation behind PikRow costs the other builds registers
     constexpr bool kPost = spec_has_posture(SPEC);
     constexpr bool kCons = NCH > 1 && spec_has_constraint(SPEC);
+    // device constraint builds (SPEC > 0 with bit kSpecCons: launched only for problems with the constraint on): chain 1 carries the
+    // constrained frame and no task, so the park buffer is free -- chain 0's factor (77 doubles for NJ = 7) waits there while the base
+    // task and the 6 x 6 solve run instead of occupying 154 VGPRs (the posture + constraint build spilled 108 B per lane without it)
+    constexpr bool kConsAlways = false && SPEC > 0 && kCons;
+    constexpr bool kConsRuntimeOff = false;
     // (posture builds: a tail lane shadowing the last problem would re-read that problem's outside joints while their owner
     // updates them -- it sits the loop out instead; nothing of it is stored anyway)
     bool active = kPost ? ps.store : true, success = false;
+    LaneRows targets = targets_in;   // (refill: re-pointed when the lane takes its next problem)
     if constexpr (R::on) active = refill.start;   // (a tail lane of the first round holds no problem)
     const Desc *dp = &d_in;
     int iters = prm.max_iterations;
@@ -773,9 +833,9 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
     double tg0[12], tg1[12], tgP[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) {
-        tg0[k] = kTgRegs ? targets_lane[(tslot[0] * 12 + k) * tstride] : 0.0;
-        tg1[k] = (kTgRegs && NCH > 1) ? targets_lane[(tslot[1] * 12 + k) * tstride] : 0.0;
-        tgP[k] = (kTgRegs && prm.hasP) ? targets_lane[(tslot[2] * 12 + k) * tstride] : 0.0;
+        tg0[k] = kTgRegs ? targets(tslot[0] * 12 + k) : 0.0;
+        tg1[k] = (kTgRegs && NCH > 1) ? targets(tslot[1] * 12 + k) : 0.0;
+        tgP[k] = (kTgRegs && prm.hasP) ? targets(tslot[2] * 12 + k) : 0.0;
     }
     int lit = 0;   // (refill) this lane's own iteration count
 #pragma unroll 1
@@ -788,7 +848,7 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
         const double p1[3] = {qb[0], qb[1], qb[2]};
         double Hbb[21], gb[6], e0sq = 0.0;
         if (kPost && prm.post_on) {
-            posture_outside_pass(prm, ps, targets_lane, tstride, it > 0 && active, e0sq);
+            posture_outside_pass(prm, ps, targets, it > 0 && active, e0sq);
             IKD_SCHED_FENCE();  // keep the chain bodies' loads out of this pass: they would only lengthen live ranges
         }
 #pragma unroll
@@ -801,7 +861,8 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
         PikRow<NJ> pr;
         pr.on = false;
         // (constraint builds: chain 1 carries the constrained frame and no task -- it is walked after the solve)
-        const int ntask_chains = (kCons && prm.cons_on) ? 1 : NCH;
+        const bool cons_on = kCons && (prm.cons_on != 0 || kConsRuntimeOff);
+        const int ntask_chains = cons_on ? 1 : NCH;
 #pragma unroll 1
         for (int c = 0; c < ntask_chains; ++c) {
             const auto &ct = d.chain[c];
@@ -810,7 +871,8 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
 #pragma unroll
             for (int j = 0; j < NJ; ++j) q[j] = (NCH > 1 && c == 1) ? qj1[j] : qj0[j];
 #pragma unroll
-            for (int k = 0; k < 12; ++k) oMt[k] = kTgRegs ? ((NCH > 1 && c == 1) ? tg1[k] : tg0[k]) : targets_lane[(tslot[c] * 12 + k) * tstride];
+            for (int k = 0; k < 12; ++k) oMt[k] = (NCH > 1 && c == 1) ? tg1[k] : tg0[k];
+            if (!kTgRegs) targets.run(tslot[c] * 12, oMt);
             AlignRow al{false, 0, 0.0, {0.0, 0.0, 0.0}, false, false};
             if (kGeneral) {  // the demo's extras exist in the general builds only (SPEC = 0 [+ posture] on the device, -1 = all runtime
                               // in the emulator); hot builds compile none of this
@@ -831,8 +893,9 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
                     }
                 }
                 if (prm.align_chain == c) {
-                    const double tx = targets_lane[(prm.align_slot * 12 + 9) * tstride], ty = targets_lane[(prm.align_slot * 12 + 10) * tstride],
-                                 tz = targets_lane[(prm.align_slot * 12 + 11) * tstride];
+                    double td[3];
+                    targets.run(prm.align_slot * 12 + 9, td);
+                    const double tx = td[0], ty = td[1], tz = td[2];
                     const double inv = drsqrt(dfma(tx, tx, dfma(ty, ty, tz * tz)));
                     al.on = true; al.ax = prm.align_axis; al.w = prm.align_w; al.prio0 = prm.align_prio == 0;
                     al.pik = kPik && prm.pik_on != 0;
@@ -840,16 +903,17 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
                 }
             }
             const ChainPosture po{kPost && prm.post_on != 0, prm.post_prio == 0, prm.postc_slot[c], prm.postc_w[c], prm.postc_m[c],
-                                  targets_lane, tstride, (NCH == 1 && ps.by_row) ? ps.t_chain : nullptr, ps.stride};
+                                  targets, (NCH == 1 && ps.by_row) ? ps.t_chain : nullptr, ps.stride};
             leg_eval_factor<NJ, (SPEC >= 0), kPost, kPik>(R1, p1, ct.pl, ct.fr, ct.w, SPEC >= 0 ? (SPEC & ((2 << NJ) - 1)) : prm.idmask[c],
                                 SPEC >= 0 ? ((SPEC >> kSpecUnit) & 1) != 0 : prm.unit[c] != 0, q, oMt, prm.lam2, prm.prio[c] == 0, al,
                                 po, Hbb, gb, e0sq, F, pr);
-            if (NCH > 1 && c == 0 && ntask_chains > 1) park.store(F);
+            if (NCH > 1 && c == 0 && (kConsAlways || ntask_chains > 1)) park.store(F);
         }
         if (prm.hasP) {
             double oMt[12];
 #pragma unroll
-            for (int k = 0; k < 12; ++k) oMt[k] = kTgRegs ? tgP[k] : targets_lane[(tslot[2] * 12 + k) * tstride];
+            for (int k = 0; k < 12; ++k) oMt[k] = tgP[k];
+            if (!kTgRegs) targets.run(tslot[2] * 12, oMt);
             double Rf[9], pf[3], R1[9];
             quat_to_R(qb, R1);
 #pragma unroll
@@ -868,19 +932,15 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
             accumulate_base(JL, JA, t.e, Hbb, gb);
         }
         // constraint builds with posture rows: a joint of the constrained chain carries no task, so its posture row is its own
-        // 1 x 1 system (as the joints outside the chains, posture_outside_pass); the projection below then acts on that step
-        double dq1pre[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) dq1pre[j] = 0.0;
-        if (kCons && kPost && prm.cons_on && prm.post_on) {
+        // 1 x 1 system (as the joints outside the chains, posture_outside_pass); the projection below then acts on that step.  Here
+        // only the rows' share of the level-0 error (the stop test comes first); the steps are formed next to the projection.
+        if (kCons && kPost && cons_on && prm.post_on && prm.post_prio == 0) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int slot = prm.postc_slot[NCH - 1][j];
                 if (slot >= 0) {   // (wave-uniform)
-                    const double w = prm.postc_w[NCH - 1][j], mw = prm.postc_m[NCH - 1][j] * w;
-                    const double ea = (qj1[j] - targets_lane[(slot * 12 + 9) * tstride]) * mw;
-                    if (prm.post_prio == 0) e0sq = dfma(ea, ea, e0sq);
-                    dq1pre[j] = -(w * ea) * drcp(dfma(w, w, prm.lam2));
+                    const double ea = (qj1[j] - targets(slot * 12 + 9)) * (prm.postc_m[NCH - 1][j] * prm.postc_w[NCH - 1][j]);
+                    e0sq = dfma(ea, ea, e0sq);
                 }
             }
         }
@@ -905,7 +965,7 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
 #pragma unroll 1
         for (int c = ntask_chains - 1; c >= 0; --c) {
             const auto &ct = d.chain[c];
-            if (NCH > 1 && c == 0 && ntask_chains > 1) park.load(F);
+            if (NCH > 1 && c == 0 && (kConsAlways || ntask_chains > 1)) park.load(F);
             double dql[NJ];
             leg_back_substitute<NJ>(F, dqb, dql);
             if (kPik && prm.pik_on && pr.on && c == prm.align_chain) {   // level 1 of ik::pik, see PikRow (wave-uniform)
@@ -931,13 +991,23 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
                 qj0[j] = (NCH > 1 && c == 1) ? qj0[j] : qn;
             }
         }
-        if (kCons && prm.cons_on) {
+        if (cons_on) {
             // the constrained chain: no task moves it, so dq is zero there (or its posture rows' own steps) before the projection
             // N = I - pinv(Jc) Jc, which touches the base columns and this chain's only
             double R1[9], dq1[NJ];
             quat_to_R(qb, R1);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) dq1[j] = dq1pre[j];
+            for (int j = 0; j < NJ; ++j) {
+                dq1[j] = 0.0;
+                if (kPost && prm.post_on) {
+                    const int slot = prm.postc_slot[NCH - 1][j];
+                    if (slot >= 0) {   // (wave-uniform)
+                        const double w = prm.postc_w[NCH - 1][j], mw = prm.postc_m[NCH - 1][j] * w;
+                        const double ea = (qj1[j] - targets(slot * 12 + 9)) * mw;
+                        dq1[j] = -(w * ea) * drcp(dfma(w, w, prm.lam2));
+                    }
+                }
+            }
             const auto &cc = d.chain[NCH - 1];
             constraint_project<NJ, (SPEC >= 0)>(R1, p1, cc.pl, cc.fr, prm.idmask[NCH - 1], qj1, prm.cons_type, dqb, dq1);
 #pragma unroll
@@ -960,12 +1030,12 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
             // max_iterations (the stepped q, dls.cpp:76-77) stores its result and takes the next unsolved problem
             ++lit;
             const bool done = had && (stop_now || lit >= prm.max_iterations);
-            const bool any_left = refill.step(done, stop_now, stop_now ? lit - 1 : prm.max_iterations, qb, qj0, qj1, targets_lane, active, [&](const double *tl) {
+            const bool any_left = refill.step(done, stop_now, stop_now ? lit - 1 : prm.max_iterations, qb, qj0, qj1, targets, active, [&](const LaneRows &tl) {
 #pragma unroll
                 for (int k = 0; k < 12; ++k) {
-                    tg0[k] = kTgRegs ? tl[(tslot[0] * 12 + k) * tstride] : 0.0;
-                    tg1[k] = (kTgRegs && NCH > 1) ? tl[(tslot[1] * 12 + k) * tstride] : 0.0;
-                    tgP[k] = (kTgRegs && prm.hasP) ? tl[(tslot[2] * 12 + k) * tstride] : 0.0;
+                    tg0[k] = kTgRegs ? tl(tslot[0] * 12 + k) : 0.0;
+                    tg1[k] = (kTgRegs && NCH > 1) ? tl(tslot[1] * 12 + k) : 0.0;
+                    tgP[k] = (kTgRegs && prm.hasP) ? tl(tslot[2] * 12 + k) : 0.0;
                 }
             });
             if (done) { lit = 0; success = false; }
@@ -976,7 +1046,7 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
     }
     if (kPost && prm.post_on && prm.max_iterations > 0) {  // the step of the last iteration, for the lanes that never stopped
         double unused = 0.0;
-        posture_outside_pass(prm, ps, targets_lane, tstride, active, unused);
+        posture_outside_pass(prm, ps, targets, active, unused);
     }
     iters_out = iters;
     success_out = success;

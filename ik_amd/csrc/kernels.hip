@@ -408,7 +408,8 @@ __global__ __launch_bounds__(kTreeBlock) void dls_tree_kernel(const TreeKernelAr
     // live in dynamic LDS [row][lane] between iterations; with two chains the LDS is full and they stay in the q_out column
     extern __shared__ double lds_post[];
     double *post_lane = (SPEC > 0 && ikdev::spec_has_posture(SPEC) && NCH == 1) ? lds_post + threadIdx.x : nullptr;
-    ikdev::dls_tree_body<NJ, NCH, SPEC>(a, d, gid, park, [](bool act) { return __any(act) != 0; }, post_lane, kTreeBlock);
+    ikdev::dls_tree_body<NJ, NCH, SPEC>(a, d, gid, park, [](bool act) { return __any(act) != 0; }, post_lane, kTreeBlock,
+                                        static_cast<int64_t>(blockIdx.x) * kTreeBlock);
 }
 
 template <int NJ, int NCH>
@@ -457,6 +458,8 @@ namespace {
 template <int NJ, int NCH>
 hipError_t run_dls_tree(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const ikgpu_dls_params &prm,
                         hipStream_t stream, const double *pik_lambda1) {
+    if (io.B >= (int64_t{1} << 29)) return hipErrorInvalidValue;   // (LaneRows: a row stride of B * 8 bytes in 32 bits; 2^29 problems of
+                                                                   // >= 565 B each exceed the 288 GB of the device anyway)
     TreeKernelArgs<NJ, NCH> a = make_tree_args<NJ, NCH>(ph, dt);
     a.prm.max_iterations = prm.max_iterations;
     a.prm.lam2 = prm.damping * prm.damping;
