@@ -742,6 +742,8 @@ constexpr int kSpecUnitP = 29, kSpecIdP = 28, kSpecPost = 26, kSpecCons = 25, kS
 // Bit kSpecGen: the general extras next to a folded placement mask (bits 0..NJ) -- "general" builds without a mask carry none of it
 // (SPEC = 0, or the pure posture / constraint / pik flags).
 constexpr int kSpecGen = 23;
+// Bit kSpecNever (hot builds): the never-stop visitor -- no stop test, no `active` selects (every lane takes every step)
+constexpr int kSpecNever = 27;
 constexpr int kSpecPostCons = (1 << kSpecPost) | (1 << kSpecCons);   // posture rows next to the constraint (the demo with the stance foot pinned)
 constexpr int kSpecExtras = (1 << kSpecGen) | (1 << kSpecPost) | (1 << kSpecCons) | (1 << kSpecPik);
 constexpr bool spec_has_posture(int spec) { return spec < 0 || (spec & (1 << kSpecPost)) != 0; }
@@ -829,7 +831,11 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
     int iters = prm.max_iterations;
     // hot builds: the three pose targets stay in registers (the general builds re-read them every iteration -- their register budget
     // is spent; here 36 doubles fit, and the loads' L2 round trips leave the loop: full body 0.810 -> 0.800 ms, same-box A/B)
-    constexpr bool kTgRegs = SPEC > 0 && ((SPEC >> kSpecUnit) & 1) != 0;
+#ifndef IKGPU_TREE_TG_REGS
+#define IKGPU_TREE_TG_REGS 1
+#endif
+    constexpr bool kTgRegs = IKGPU_TREE_TG_REGS && SPEC > 0 && ((SPEC >> kSpecUnit) & 1) != 0;
+    constexpr bool kNever = !R::on && SPEC > 0 && ((SPEC >> kSpecNever) & 1) != 0;
     double tg0[12], tg1[12], tgP[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) {
@@ -957,7 +963,7 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
             for (int i = 0; i < 6; ++i) dqb[i] = 0.0;
         }
 
-        const bool stop_now = active && (prm.stop_sq_tol >= 0.0) && (e0sq < prm.stop_sq_tol);
+        const bool stop_now = !kNever && active && (prm.stop_sq_tol >= 0.0) && (e0sq < prm.stop_sq_tol);
         if (stop_now) { success = true; iters = R::on ? lit : it; }
         const bool had = active;   // (refill) the lane held a problem during this iteration
         active = active && !stop_now;
@@ -1041,7 +1047,7 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
             if (done) { lit = 0; success = false; }
             if (!any_left) break;
         } else {
-            if (!any_active(active)) break;
+            if (!kNever && !any_active(active)) break;
         }
     }
     if (kPost && prm.post_on && prm.max_iterations > 0) {  // the step of the last iteration, for the lanes that never stopped

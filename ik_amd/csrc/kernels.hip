@@ -493,7 +493,9 @@ hipError_t run_dls_tree(const ProblemHost &ph, const DeviceTables &dt, const Bat
         hipError_t re = hipSuccess;
         if (launch_tree_refill<NJ, NCH>(ph, dt, io, prm, stream, a, hot, &re)) return re;
     }
-    if (hot) hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, kHot>), grid, dim3(kTreeBlock), 0, stream, a);
+    if (hot && !(prm.stop_sq_tol >= 0.0) && !std::getenv("IKGPU_TREE_NEVER_OFF"))   // the never-stop visitor: its own instantiation, as the hot chain kernel's
+        hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, (kHot | (1 << ikdev::kSpecNever))>), grid, dim3(kTreeBlock), 0, stream, a);
+    else if (hot) hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, kHot>), grid, dim3(kTreeBlock), 0, stream, a);
     else if (mask_only) hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, (kMask != 0 ? kMask : kHot)>), grid, dim3(kTreeBlock), 0, stream, a);
     else if (pik_lambda1)   // two-level ik::pik (tree_takes_two_level_pik): the general build + the level-1 row's projection
         IKGPU_TREE_GENERAL((1 << ikdev::kSpecPik), 0);

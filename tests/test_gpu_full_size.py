@@ -247,3 +247,31 @@ def test_full_body_lane_by_lane(torch_cuda):
     tasks = O.make_tasks([(model.getFrameId(f), 0, 2, 0, None) for f in frames])
     q = _compare(torch, model, problem, data, tasks, q0, T, 0, "cassie full body near")
     assert np.abs(np.linalg.norm(q[:, 3:7], axis=1) - 1.0).max() < 1e-9
+
+
+def test_full_body_never_stop_build_equals_the_stop_capable_build(torch_cuda):
+    """The never-stop visitor has its own instantiation of the hot tree kernel (no stop test, no `active` selects); the arithmetic
+    of a step is the same code, so the stop-capable build run with the same visitor (IKGPU_TREE_NEVER_OFF) returns the same bits."""
+    torch = torch_cuda
+    import ik_amd
+    from ik_amd import workload
+    model = ik_amd.Model.from_urdf_file(urdf_path("cassie"), free_flyer=True)
+    problem = ik_amd.InverseKinematicsProblem(model)
+    for i, f in enumerate(["LeftFootFront", "RightFootFront", "pelvis"]):
+        problem.add_frame_task("t%d" % i, ik_amd.FrameTask.create(model, f, ik_amd.KinematicType.Full))
+    data = ik_amd.dls_data(problem, device=0)
+    n = 20000 + 37
+    q0, qs = workload.freeflyer_workload(model.lowerPositionLimit, model.upperPositionLimit, workload.cassie_nominal(model.names),
+                                         np.arange(n), seed=3, mode="uniform")
+    Q0 = torch.from_numpy(np.ascontiguousarray(q0.T)).cuda()
+    T = ik_amd.task_frames_fk_batch(problem, torch.from_numpy(np.ascontiguousarray(qs.T)).cuda(), data)
+    prm = ik_amd.dls_parameters(max_iterations=25)
+    a = [t.clone() for t in ik_amd.dls_batch(problem, Q0, T, data, ik_amd.never_stop_visitor(), prm)]
+    os.environ["IKGPU_TREE_NEVER_OFF"] = "1"
+    try:
+        b = ik_amd.dls_batch(problem, Q0, T, data, ik_amd.never_stop_visitor(), prm)
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop("IKGPU_TREE_NEVER_OFF", None)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert int(a[2].min()) == 25 and int(a[1].sum()) == 0
