@@ -187,7 +187,7 @@ IKD_FN void generic_fk(const TB &T, const WS &ws) {
 
 // evaluate_problem_data (ik/ik/data.cpp:25-58) into the workspace: q -> oMi, Jw, et, Jt.  Returns ||e[0]||^2.
 template <class TB, class WS>
-IKD_FN double generic_evaluate(const TB &T, const WS &ws, const double *targets_lane, int64_t tstride) {
+IKD_FN double generic_evaluate(const TB &T, const WS &ws, const LaneRows &targets) {
     generic_fk(T, ws);
     if (T.has_com) {  // pinocchio::centerOfMass, backward pass: first moment of every subtree (the subtree masses are constants)
         IKD_UNROLL
@@ -218,9 +218,11 @@ IKD_FN double generic_evaluate(const TB &T, const WS &ws, const double *targets_
             g_se3_mul(oJ, T.t_rpl + 12 * t, oMr);
             const double d[3] = {dfma(ws[T.off_sf], T.inv_total_mass, -oMr[9]), dfma(ws[T.off_sf + 1], T.inv_total_mass, -oMr[10]),
                                  dfma(ws[T.off_sf + 2], T.inv_total_mass, -oMr[11])};
+            double tcom[3];
+            targets.template run<3>(t * 12 + 9, tcom);
             IKD_UNROLL
             for (int r = 0; r < 3; ++r) {
-                const double e = (dfma(oMr[r], d[0], dfma(oMr[3 + r], d[1], oMr[6 + r] * d[2])) - targets_lane[(t * 12 + 9 + r) * tstride]) * w6[r];
+                const double e = (dfma(oMr[r], d[0], dfma(oMr[3 + r], d[1], oMr[6 + r] * d[2])) - tcom[r]) * w6[r];
                 ws[T.off_e + row + r] = e;
                 if (T.t_prio[t] == 0) e0sq = dfma(e, e, e0sq);
             }
@@ -245,7 +247,7 @@ IKD_FN double generic_evaluate(const TB &T, const WS &ws, const double *targets_
             continue;
         }
         if (type == GT_POSTURE_ROW) {  // one row of ik::PostureTask, ik/ik/posture.hpp:51-68 (fjoint = tangent column, rjoint = q index)
-            const double e = (ws[T.off_q + rj] - targets_lane[(t * 12 + 9) * tstride]) * w6[1] * w6[0];
+            const double e = (ws[T.off_q + rj] - targets(t * 12 + 9)) * w6[1] * w6[0];
             ws[T.off_e + row] = e;
             if (T.t_prio[t] == 0) e0sq = dfma(e, e, e0sq);
             IKD_UNROLL
@@ -259,8 +261,7 @@ IKD_FN double generic_evaluate(const TB &T, const WS &ws, const double *targets_
         IKD_UNROLL
         for (int k = 0; k < 12; ++k) oJ[k] = ws[T.off_oMi + 12 * rj + k];
         g_se3_mul(oJ, T.t_rpl + 12 * t, oMr);
-        IKD_UNROLL
-        for (int k = 0; k < 12; ++k) tg[k] = targets_lane[(t * 12 + k) * tstride];
+        targets.template run<12>(t * 12, tg);
         IKD_UNROLL
         for (int r = 0; r < dim; ++r)
             IKD_UNROLL
@@ -345,6 +346,12 @@ IKD_FN double generic_evaluate(const TB &T, const WS &ws, const double *targets_
 
 // Column c of pinocchio::getFrameJacobian(..., LOCAL) for a frame placed at (Rf, pf) in the world, from the world joint
 // Jacobian in the workspace: linear part vl, angular part wl.
+// (per-lane pointer + element stride: the interpreter forms and ik::pik)
+template <class TB, class WS>
+IKD_FN double generic_evaluate(const TB &T, const WS &ws, const double *targets_lane, int64_t tstride) {
+    return generic_evaluate(T, ws, LaneRows{reinterpret_cast<const char *>(targets_lane), 0u, static_cast<uint32_t>(tstride * 8), false});
+}
+
 template <class TB, class WS>
 IKD_FN void local_column(const TB &T, const WS &ws, int c, const double (&Rf)[9], const double (&pf)[3], double (&vl)[3],
                          double (&wl)[3]) {
@@ -568,13 +575,13 @@ IKD_FN void generic_integrate_clip(const TB &T, const WS &ws, double step_length
 
 // One full solve on the workspace (q already stored at off_q).
 template <class TB, class WS, class AnyFn>
-IKD_FN void generic_dls(const TB &T, const LoopParams &prm, const WS &ws, const double *targets_lane,
-                        int64_t tstride, int &iters_out, bool &success_out, AnyFn any_active) {
+IKD_FN void generic_dls(const TB &T, const LoopParams &prm, const WS &ws, const LaneRows &targets,
+                        int &iters_out, bool &success_out, AnyFn any_active) {
     bool active = true, success = false;
     int iters = prm.max_iterations;
     const int M = T.M, nv = T.nv;
     for (int it = 0; it < prm.max_iterations; ++it) {
-        const double e0sq = generic_evaluate(T, ws, targets_lane, tstride);
+        const double e0sq = generic_evaluate(T, ws, targets);
         // JJ = Jt Jt^T + damping^2 I (lower triangle, packed), ik/ik/dls.cpp:39-41
         IKD_UNROLL
         for (int i = 0; i < M; ++i)
@@ -682,17 +689,21 @@ struct GenericKernelArgs {
 
 // ws: the lane's workspace column -- of the HBM workspace (dls_generic_body below) or of the workgroup's LDS (the on-chip form,
 // kernels.hip: word w of lane l at lds[w * 64 + l], conflict-free).
+// group0: the first problem of the lane's workgroup (wave-uniform: the targets are then addressed as SGPR row + lane offset, see
+// LaneRows in tree_solver.hpp; the static lane programs), or -1: per-lane pointers.
 template <class TB, class WS, class AnyFn>
-IKD_FN void dls_generic_body_ws(const GenericKernelArgs &a, const TB &T, int64_t gid, const WS &ws, AnyFn any_active) {
+IKD_FN void dls_generic_body_ws(const GenericKernelArgs &a, const TB &T, int64_t gid, const WS &ws, AnyFn any_active, int64_t group0 = -1) {
     const bool valid = gid < a.B;
     const int64_t b = valid ? gid : a.B - 1;
     IKD_UNROLL
     for (int i = 0; i < T.nq; ++i) ws[T.off_q + i] = a.q0[at(a.layout, a.B, T.nq, i, b)];
-    const double *tl = a.layout == LAYOUT_SOA ? a.targets + b : a.targets + b * T.ntasks * 12;
-    const int64_t ts = a.layout == LAYOUT_SOA ? a.B : 1;
+    const int64_t g0 = group0 >= 0 ? group0 : b;
+    const int64_t tcol = a.layout == LAYOUT_SOA ? 1 : static_cast<int64_t>(T.ntasks) * 12;   // doubles between consecutive problems
+    const LaneRows tl{reinterpret_cast<const char *>(a.targets + g0 * tcol), static_cast<uint32_t>((b - g0) * tcol * 8),
+                      static_cast<uint32_t>(a.layout == LAYOUT_SOA ? a.B * 8 : 8), group0 >= 0};
     int iters;
     bool success;
-    generic_dls(T, a.prm, ws, tl, ts, iters, success, any_active);
+    generic_dls(T, a.prm, ws, tl, iters, success, any_active);
     if (!valid) return;
     IKD_UNROLL
     for (int i = 0; i < T.nq; ++i) a.q_out[at(a.layout, a.B, T.nq, i, b)] = ws[T.off_q + i];

@@ -399,7 +399,8 @@ std::string generic_static_source(const ProblemHost &ph) {
     o += "};\n}  // namespace\n"
          "extern \"C\" __global__ __launch_bounds__(64) void ikgpu_lane_dls(const ikdev::GenericKernelArgs a) {\n"
          "    double w[T::ws_words];\n"
-         "    ikdev::dls_generic_body_ws(a, T{}, static_cast<int64_t>(blockIdx.x) * 64 + threadIdx.x, ikdev::WsReg{w}, [](bool act) { return __any(act) != 0; });\n"
+         "    ikdev::dls_generic_body_ws(a, T{}, static_cast<int64_t>(blockIdx.x) * 64 + threadIdx.x, ikdev::WsReg{w}, [](bool act) { return __any(act) != 0; },\n"
+         "                               T::M > 12 ? static_cast<int64_t>(blockIdx.x) * 64 : int64_t{-1});\n"
          "}\n";
     return o;
 }
