@@ -537,8 +537,13 @@ int ikgpu_problem_precompile(const ikgpu_model *h, const ikgpu_task *tasks, int3
             ikgpu::ProblemHost gen = ikgpu::analyse_problem(h->m, tasks, ntasks, /*force_generic=*/true, constraints, nconstraints);
             if (ikgpu::rtc_generic_static_available(gen, /*compile=*/false, nullptr)) {
                 want = static_name(gen);
-                if (ikgpu::rtc_generic_static_available(gen, /*compile=*/true, &gen.generic_key)) got = want;
+                if (ikgpu::rtc_generic_static_available(gen, /*compile=*/true, &gen.generic_key)) {
+                    got = want;
+                    (void)ikgpu::rtc_generic_static_precompile_refill(gen);
+                }
             }
+        } else if (ph.generic_build == 2) {
+            (void)ikgpu::rtc_generic_static_precompile_refill(ph);
         }
         if (out && cap) {
             std::strncpy(out, got.c_str(), cap - 1);
@@ -600,15 +605,15 @@ int ikgpu_dls_solve_batch(const ikgpu_problem *p, int64_t B, const double *q0, c
         if (ikgpu::visitor_extended(*params)) {
             // a derived visitor (step tolerance / per-level tolerances): the generic lane program implements the family -- the one
             // specialised for this problem when there is one, else its memory-resident per-lane form
-            const hipError_t ev = p->gen.generic_build == 2 ? ikgpu::rtc_launch_generic_static(p->gen, p->gen.generic_key, io, *params, st)
+            const hipError_t ev = p->gen.generic_build == 2 ? ikgpu::rtc_launch_generic_static(p->gen, p->gen.generic_key, io, *params, st, &p->dev.queues)
                                                             : ikgpu::launch_dls_generic(p->gen, p->dev, io, *params, st, /*force_lane=*/true);
             if (ev != hipSuccess) return hip_fail(ev, "launching the generic DLS kernel (derived visitor)");
             return static_cast<int>(IKGPU_OK);
         }
-        hipError_t e = p->dls_on_static_gen                      ? ikgpu::rtc_launch_generic_static(p->gen, p->gen.generic_key, io, *params, st)
+        hipError_t e = p->dls_on_static_gen                      ? ikgpu::rtc_launch_generic_static(p->gen, p->gen.generic_key, io, *params, st, &p->dev.queues)
                        : p->host.kind == ikgpu::KernelKind::Chain  ? ikgpu::launch_dls_chain(p->host, p->dev, io, *params, st)
                        : p->host.kind == ikgpu::KernelKind::Tree ? ikgpu::launch_dls_tree(p->host, p->dev, io, *params, st)
-                       : p->host.generic_build == 2              ? ikgpu::rtc_launch_generic_static(p->host, p->host.generic_key, io, *params, st)
+                       : p->host.generic_build == 2              ? ikgpu::rtc_launch_generic_static(p->host, p->host.generic_key, io, *params, st, &p->dev.queues)
                                                                  : ikgpu::launch_dls_generic(p->host, p->dev, io, *params, st);
         if (e != hipSuccess) return hip_fail(e, "launching the DLS kernel");
         return static_cast<int>(IKGPU_OK);

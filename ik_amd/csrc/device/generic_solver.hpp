@@ -574,13 +574,18 @@ IKD_FN void generic_integrate_clip(const TB &T, const WS &ws, double step_length
 }
 
 // One full solve on the workspace (q already stored at off_q).
-template <class TB, class WS, class AnyFn>
-IKD_FN void generic_dls(const TB &T, const LoopParams &prm, const WS &ws, const LaneRows &targets,
-                        int &iters_out, bool &success_out, AnyFn any_active) {
+// R: the lane-refill hook (GenericRefill below, the static lane programs' stop-rule mode on batches larger than the machine);
+// NoRefill (tree_solver.hpp) is the lock-step loop -- every `if constexpr (R::on)` compiles to nothing there.
+template <class TB, class WS, class AnyFn, class R = NoRefill>
+IKD_FN void generic_dls(const TB &T, const LoopParams &prm, const WS &ws, const LaneRows &targets_in,
+                        int &iters_out, bool &success_out, AnyFn any_active, R refill = R{}) {
     bool active = true, success = false;
+    if constexpr (R::on) active = refill.start;   // (a tail lane of the first round holds no problem)
+    LaneRows targets = targets_in;                 // (refill: re-pointed when the lane takes its next problem)
     int iters = prm.max_iterations;
+    int lit = 0;                                   // (refill) this lane's own iteration count
     const int M = T.M, nv = T.nv;
-    for (int it = 0; it < prm.max_iterations; ++it) {
+    for (int it = 0; R::on || it < prm.max_iterations; ++it) {
         const double e0sq = generic_evaluate(T, ws, targets);
         // JJ = Jt Jt^T + damping^2 I (lower triangle, packed), ik/ik/dls.cpp:39-41
         IKD_UNROLL
@@ -657,10 +662,21 @@ IKD_FN void generic_dls(const TB &T, const LoopParams &prm, const WS &ws, const 
             step_small = s < prm.dq_sq_tol;
         }
         const bool stop_now = active && (err_ok || step_small);
-        if (stop_now) { success = true; iters = it; }
+        if (stop_now) { success = true; iters = R::on ? lit : it; }
+        const bool had = active;   // (refill) the lane held a problem during this iteration
         active = active && !stop_now;
         generic_integrate_clip(T, ws, prm.step_length, active);  // ik/ik/dls.cpp:67-71
-        if (!any_active(active)) break;
+        if constexpr (R::on) {
+            // a lane whose visitor fired (q is the configuration the error was evaluated at, dls.cpp:61-63) or whose count reached
+            // max_iterations (the stepped q, dls.cpp:76-77) stores its result and takes the next unsolved problem
+            ++lit;
+            const bool done = had && (stop_now || lit >= prm.max_iterations);
+            const bool any_left = refill.step(T, done, stop_now, stop_now ? lit - 1 : prm.max_iterations, ws, targets, active);
+            if (done) { lit = 0; success = false; }
+            if (!any_left) break;
+        } else {
+            if (!any_active(active)) break;
+        }
     }
     iters_out = iters;
     success_out = success;
@@ -710,6 +726,92 @@ IKD_FN void dls_generic_body_ws(const GenericKernelArgs &a, const TB &T, int64_t
     if (a.success) a.success[b] = success ? 1 : 0;
     if (a.iters) a.iters[b] = iters;
 }
+
+#if IKD_HIP_LANG
+// Lane refill for the static lane programs (the scheme of chain_kernel_body.hpp chain_refill_loop / tree_kernel_body.hpp TreeRefill):
+// persistent one-wave workgroups; the first nwaves * 64 problems are dealt statically, the rest through `queue` in chunks a wave
+// reserves for itself ([pool_lo, pool_hi)); a lane that is done stores (q, success, iters) and loads the next problem's q0 into its
+// workspace.  The arithmetic of a problem's iterations is the lock-step program's: results are bit-identical.
+struct GenericRefill {
+    static constexpr bool on = true;
+    const GenericKernelArgs *a;
+    unsigned long long *queue;
+    int chunk;
+    int64_t b, first_round, pool_lo, pool_hi;
+    bool exhausted;
+    bool start;
+
+    template <class TB>
+    __device__ __forceinline__ LaneRows target_rows(const TB &T, int64_t bb) const {
+        return LaneRows{reinterpret_cast<const char *>(a->layout == LAYOUT_SOA ? a->targets + bb : a->targets + bb * T.ntasks * 12), 0u,
+                        static_cast<uint32_t>(a->layout == LAYOUT_SOA ? a->B * 8 : 8), false};
+    }
+
+    template <class TB, class WS>
+    __device__ __forceinline__ bool step(const TB &T, bool done, bool stopped, int iters, const WS &ws, LaneRows &tl, bool &active) {
+        const GenericKernelArgs &A = *a;
+        const int lane = static_cast<int>(threadIdx.x) & 63;
+        if (__any(done)) {
+            if (done) {
+                IKD_UNROLL
+                for (int i = 0; i < T.nq; ++i) A.q_out[at(A.layout, A.B, T.nq, i, b)] = ws[T.off_q + i];
+                if (A.success) A.success[b] = stopped ? 1 : 0;
+                if (A.iters) A.iters[b] = iters;
+            }
+            const unsigned long long mask = __ballot(done);
+            const int need = __popcll(mask);
+            const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+            const int64_t avail = pool_hi - pool_lo;
+            int64_t nb = pool_lo + rank;
+            bool got = rank < avail;
+            if (avail < need && !exhausted) {                             // wave-uniform: pull the next chunk
+                unsigned long long v = 0;
+                if (lane == 0) v = atomicAdd(queue, static_cast<unsigned long long>(chunk));
+                const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v)), hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
+                const int64_t nlo = first_round + static_cast<int64_t>((static_cast<unsigned long long>(hi) << 32) | lo);
+                const int64_t nhi = nlo + chunk < A.B ? nlo + chunk : A.B;
+                exhausted = nlo + chunk >= A.B;
+                if (rank >= avail) { nb = nlo + (rank - avail); got = nb < nhi; }
+                pool_lo = nlo + (need - avail);
+                pool_hi = nhi > pool_lo ? nhi : pool_lo;
+            } else {
+                pool_lo += need < avail ? need : avail;
+            }
+            if (done) {
+                active = got;
+                if (got) {
+                    b = nb;
+                    IKD_UNROLL
+                    for (int i = 0; i < T.nq; ++i) ws[T.off_q + i] = A.q0[at(A.layout, A.B, T.nq, i, b)];
+                    tl = target_rows(T, b);
+                }
+            }
+        }
+        return __any(active) != 0;
+    }
+};
+
+template <class TB, class WS>
+__device__ __forceinline__ void dls_generic_refill_body(const GenericKernelArgs &a, const TB &T, int64_t wave, int64_t nwaves, const WS &ws,
+                                                        unsigned long long *queue, int chunk) {
+    const int lane = static_cast<int>(threadIdx.x) & 63;
+    GenericRefill rf{&a, queue, chunk, wave * 64 + lane, nwaves * 64, 0, 0, nwaves * 64 >= a.B, wave * 64 + lane < a.B};
+    const int64_t bs = rf.start ? rf.b : a.B - 1;
+    IKD_UNROLL
+    for (int i = 0; i < T.nq; ++i) ws[T.off_q + i] = a.q0[at(a.layout, a.B, T.nq, i, bs)];
+    int iters;
+    bool success;
+    generic_dls(T, a.prm, ws, rf.target_rows(T, bs), iters, success, [](bool act) { return __any(act) != 0; }, rf);
+    if (lane == 0) {   // the last wave out resets the queue slot for the stream's next launch (kernels.hpp QueuePool)
+        __threadfence();
+        if (atomicAdd(queue + 1, 1ull) == static_cast<unsigned long long>(nwaves) - 1ull) {
+            queue[0] = 0ull;
+            queue[1] = 0ull;
+            __threadfence();
+        }
+    }
+}
+#endif
 
 template <class AnyFn>
 IKD_FN void dls_generic_body(const GenericKernelArgs &a, int64_t gid, AnyFn any_active) {

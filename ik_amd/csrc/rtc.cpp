@@ -369,7 +369,7 @@ std::string dbl_array(const char *name, It begin, int n) {
     return o + "};\n";
 }
 
-std::string generic_static_source(const ProblemHost &ph) {
+std::string generic_static_source(const ProblemHost &ph, bool refill = false) {
     const GenericHost &g = ph.generic;
     const int nj = g.njoints, nt = ph.ntasks;
     const int32_t *I = g.ints.data();
@@ -396,18 +396,29 @@ std::string generic_static_source(const ProblemHost &ph) {
     if (g.has_com) o += dbl_array("j_mass", D + g.o_jmass, nj) + dbl_array("j_lever", D + g.o_jlever, 3 * nj) + dbl_array("j_submass", D + g.o_jsubmass, nj);
     else o += "    static constexpr double j_mass[] = {0.0}, j_lever[] = {0.0}, j_submass[] = {0.0};\n";
     o += "    static constexpr double inv_total_mass = " + hexd(g.inv_total_mass) + ";\n";
-    o += "};\n}  // namespace\n"
-         "extern \"C\" __global__ __launch_bounds__(64) void ikgpu_lane_dls(const ikdev::GenericKernelArgs a) {\n"
-         "    double w[T::ws_words];\n"
-         "    ikdev::dls_generic_body_ws(a, T{}, static_cast<int64_t>(blockIdx.x) * 64 + threadIdx.x, ikdev::WsReg{w}, [](bool act) { return __any(act) != 0; },\n"
-         "                               T::M > 12 ? static_cast<int64_t>(blockIdx.x) * 64 : int64_t{-1});\n"
-         "}\n";
+    o += "};\n}  // namespace\n";
+    if (refill)   // the stop-rule mode on batches larger than the machine (generic_solver.hpp GenericRefill): its own module, compiled when first needed
+        o += "extern \"C\" __global__ __launch_bounds__(64) void ikgpu_lane_dls_refill(const ikdev::GenericKernelArgs a, unsigned long long *queue, int chunk) {\n"
+             "    double w[T::ws_words];\n"
+             "    ikdev::dls_generic_refill_body(a, T{}, static_cast<int64_t>(blockIdx.x), static_cast<int64_t>(gridDim.x), ikdev::WsReg{w}, queue, chunk);\n"
+             "}\n";
+    else
+        o += "extern \"C\" __global__ __launch_bounds__(64) void ikgpu_lane_dls(const ikdev::GenericKernelArgs a) {\n"
+             "    double w[T::ws_words];\n"
+             "    ikdev::dls_generic_body_ws(a, T{}, static_cast<int64_t>(blockIdx.x) * 64 + threadIdx.x, ikdev::WsReg{w}, [](bool act) { return __any(act) != 0; },\n"
+             "                               T::M > 12 ? static_cast<int64_t>(blockIdx.x) * 64 : int64_t{-1});\n"
+             "}\n";
     return o;
 }
 
 struct GenModule {
     hipModule_t mod = nullptr;
     hipFunction_t dls = nullptr;
+    // the refill program: compiled and loaded at the first launch that wants it (or by ikgpu_problem_precompile)
+    bool refill_tried = false;
+    hipModule_t refill_mod = nullptr;
+    hipFunction_t refill = nullptr;
+    int refill_waves_per_cu = 0;
 };
 std::map<uint64_t, HotCode> g_gen_codes;                      // by hash of the generated source
 std::map<std::pair<uint64_t, int>, GenModule> g_gen_modules;   // (hash, device)
@@ -476,23 +487,60 @@ bool rtc_generic_static_available(const ProblemHost &gen, bool compile, uint64_t
     return hc.ok;
 }
 
-hipError_t rtc_launch_generic_static(const ProblemHost &gen, uint64_t key, const BatchIO &io, const ikgpu_dls_params &prm, hipStream_t stream) {
-    GenModule m;
-    {
-        std::lock_guard<std::mutex> lock(g_mu);
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        GenModule &gm = g_gen_modules[std::make_pair(key, dev)];
-        if (!gm.mod) {
-            const HotCode &hc = g_gen_codes[key];
-            if (!hc.ok) return hipErrorInvalidImage;
-            hipError_t e = hipModuleLoadData(&gm.mod, hc.code.data());
-            if (e == hipSuccess) e = hipModuleGetFunction(&gm.dls, gm.mod, "ikgpu_lane_dls");
-            if (e != hipSuccess) { gm = GenModule{}; return e; }
-        }
-        m = gm;
+// (g_mu held) the refill program of the static lane program `key` on the current device, or gm.refill == nullptr
+static void ensure_generic_refill(const ProblemHost &gen, GenModule &gm) {
+    if (gm.refill_tried) return;
+    gm.refill_tried = true;
+    const std::string src = generic_static_source(gen, /*refill=*/true);
+    HotCode &hc = g_gen_codes[source_hash(src)];
+    if (!hc.tried) compile_cached("generic_static_refill", src, hc, /*if_convert=*/true);
+    g_last_log = hc.log;
+    if (!hc.ok) return;
+    if (hipModuleLoadData(&gm.refill_mod, hc.code.data()) != hipSuccess) { gm.refill_mod = nullptr; return; }
+    if (hipModuleGetFunction(&gm.refill, gm.refill_mod, "ikgpu_lane_dls_refill") != hipSuccess) { gm.refill = nullptr; return; }
+    // A program that spills is kept off the refill path: its loop has divergent regions (a done lane stores and reloads), and a
+    // spill store the register allocator places inside one is the hazard tools/spill_exec_check.py describes.  The lock-step
+    // program's loop has none (tools/static_program_check.sh).
+    int local_bytes = 0;
+    if (hipFuncGetAttribute(&local_bytes, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, gm.refill) != hipSuccess || local_bytes > 0) { gm.refill = nullptr; return; }
+    int per_cu = 0;
+    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gm.refill, 64, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    gm.refill_waves_per_cu = per_cu;
+}
+
+static hipError_t generic_module(uint64_t key, GenModule **out) {   // (g_mu held)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    GenModule &gm = g_gen_modules[std::make_pair(key, dev)];
+    if (!gm.mod) {
+        const HotCode &hc = g_gen_codes[key];
+        if (!hc.ok) return hipErrorInvalidImage;
+        hipError_t e = hipModuleLoadData(&gm.mod, hc.code.data());
+        if (e == hipSuccess) e = hipModuleGetFunction(&gm.dls, gm.mod, "ikgpu_lane_dls");
+        if (e != hipSuccess) { gm = GenModule{}; return e; }
     }
-    ikdev::GenericKernelArgs a{};
+    *out = &gm;
+    return hipSuccess;
+}
+
+bool rtc_generic_static_precompile_refill(const ProblemHost &gen) {   // (compiles / fetches the code object; modules load per device at launch)
+    const std::string src = generic_static_source(gen, /*refill=*/true);
+    std::lock_guard<std::mutex> lock(g_mu);
+    HotCode &hc = g_gen_codes[source_hash(src)];
+    if (!hc.tried) compile_cached("generic_static_refill", src, hc, /*if_convert=*/true);
+    g_last_log = hc.log;
+    return hc.ok;
+}
+
+hipError_t rtc_launch_generic_static(const ProblemHost &gen, uint64_t key, const BatchIO &io, const ikgpu_dls_params &prm, hipStream_t stream,
+                                     QueuePool *queues) {
+    struct Args {
+        ikdev::GenericKernelArgs a;
+        unsigned long long *queue;
+        int chunk;
+    } args{};
+    static_assert(sizeof(ikdev::GenericKernelArgs) % 8 == 0, "argument layout");
+    ikdev::GenericKernelArgs &a = args.a;
     a.prm.max_iterations = prm.max_iterations;
     a.prm.lam2 = prm.damping * prm.damping;
     a.prm.step_length = prm.step_length;
@@ -500,9 +548,38 @@ hipError_t rtc_launch_generic_static(const ProblemHost &gen, uint64_t key, const
     fill_visitor(a.prm, prm);
     a.layout = io.layout; a.B = io.B; a.q0 = io.q0; a.targets = io.targets;
     a.q_out = io.q_out; a.success = io.success; a.iters = io.iters;
-    size_t nbytes = sizeof a;
-    void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &nbytes, HIP_LAUNCH_PARAM_END};
-    return hipModuleLaunchKernel(m.dls, static_cast<unsigned>((io.B + 63) / 64), 1, 1, 64, 1, 1, 0, stream, nullptr, config);
+    // stop-rule mode on a batch larger than the machine: lane refill (as the chain and tree kernels; `refill_wanted` is false at or
+    // below one wave per SIMD, so the small-batch path never meets the compiler here)
+    const bool maybe_refill = queues && refill_wanted(prm, io.B, 1024);
+    GenModule m;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        GenModule *gm = nullptr;
+        const hipError_t e = generic_module(key, &gm);
+        if (e != hipSuccess) return e;
+        if (maybe_refill) ensure_generic_refill(gen, *gm);
+        m = *gm;
+    }
+    auto launch = [&](hipFunction_t fn, int64_t grid, size_t nbytes) {
+        void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &nbytes, HIP_LAUNCH_PARAM_END};
+        return hipModuleLaunchKernel(fn, static_cast<unsigned>(grid), 1, 1, 64, 1, 1, 0, stream, nullptr, config);
+    };
+    if (maybe_refill && m.refill) {
+        int cus = 256;
+        {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+        }
+        const int64_t resident = refill_resident(static_cast<int64_t>(m.refill_waves_per_cu) * cus, io.B);
+        if (refill_wanted(prm, io.B, resident)) {
+            hipError_t e = hipSuccess;
+            args.queue = queues->slot_for(stream, &e);
+            if (!args.queue) return e;
+            args.chunk = refill_chunk(io.B, resident);
+            return launch(m.refill, resident, offsetof(Args, chunk) + sizeof(int));
+        }
+    }
+    return launch(m.dls, (io.B + 63) / 64, sizeof(ikdev::GenericKernelArgs));
 }
 
 }  // namespace ikgpu

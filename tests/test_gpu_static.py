@@ -122,3 +122,47 @@ def test_static_generic_program_full_size_properties(torch_cuda, case):
     assert torch.equal(Q[:, :512], Qs)
     lo, hi = torch.from_numpy(model.lowerPositionLimit).cuda(), torch.from_numpy(model.upperPositionLimit).cuda()
     assert (Q >= lo[:, None] - 1e-15).all() and (Q <= hi[:, None] + 1e-15).all()
+
+
+@pytest.mark.parametrize("layout", ["soa", "aos"])
+@pytest.mark.parametrize("case", ["shared_joints", "demo_task_set", "com_of_the_arm"])
+def test_static_program_lane_refill_is_bit_identical_to_lock_step(torch_cuda, monkeypatch, case, layout):
+    """The stop-rule mode of a static lane program on a batch larger than the machine (generic_solver.hpp GenericRefill): a lane that
+    is done stores its result and takes the next problem.  Same bits as the lock-step program -- q, success, iterations -- at sizes
+    around the wave and machine boundaries, forced on at small sizes too (IKGPU_REFILL=1: tail lanes, waves that start empty)."""
+    torch = torch_cuda
+    name, ff, specs, edit = CASES[case]
+    monkeypatch.setenv("IKGPU_DLS_KERNEL", "generic")   # (the demo task set plans onto the tree kernel otherwise)
+    ik, O, model, problem, data, om, ot, q0, tg = build(name, ff, specs, 1024, seed=9, xml_edit=edit)
+    monkeypatch.delenv("IKGPU_DLS_KERNEL")
+    if not data.kernel.endswith(",static>"):
+        pytest.skip("hipRTC unavailable: %s" % data.kernel)
+    p = ik.dls_parameters(max_iterations=24, damping=1e-1, step_length=0.5)
+    vis = ik.inverse_kinematics_visitor(1e-3)
+    for B in (1, 63, 1000, 65536 + 64 * 3 + 5, 3 * 65536 + 17):
+        rep = -(-B // 1024)
+        q = np.tile(q0, (rep, 1))[:B]
+        t = np.tile(tg, (rep, 1, 1))[:B]
+        rng = np.random.default_rng(B)
+        q = q + rng.uniform(-0.05, 0.05, q.shape) * (np.arange(B) % 7 != 0)[:, None]   # a spread of iteration counts, some lanes at their seed
+        if layout == "soa":
+            Q0 = torch.from_numpy(np.ascontiguousarray(q.T)).cuda()
+            T = torch.from_numpy(np.ascontiguousarray(t.transpose(1, 2, 0))).cuda()
+        else:
+            Q0 = torch.from_numpy(np.ascontiguousarray(q)).cuda()
+            T = torch.from_numpy(np.ascontiguousarray(t)).cuda()
+        res = {}
+        for mode in ("0", "1"):
+            os.environ["IKGPU_REFILL"] = mode
+            try:
+                out = ik.dls_batch(problem, Q0, T, data, vis, p, layout=layout)
+                torch.cuda.synchronize()
+            finally:
+                os.environ.pop("IKGPU_REFILL", None)
+            res[mode] = [x.clone() for x in out]
+        for a, b in zip(res["0"], res["1"]):
+            assert torch.equal(a, b), (case, layout, B)
+        it = res["1"][2]
+        assert int(it.max()) <= 24 and int(it.min()) >= 0
+        if B >= 1000:
+            assert it.unique().numel() > 2, "the workload should spread the iteration counts"

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Stop-rule mode of the chain kernels on batches larger than the machine: lock-step against lane refill, by batch size, resident
 waves per CU, target distribution (uniform: ~3 % of the problems never converge; near: all converge) and max_iterations.
-    python tools/refill_timing.py [model frame]"""
+    python tools/refill_timing.py [model frame | full_body x | demo x]     (demo: the reference demo's task set on its static lane program)"""
 import os
 import sys
 import time
@@ -15,8 +15,16 @@ import ik_amd  # noqa: E402
 from ik_amd import workload  # noqa: E402
 
 name, frame = (sys.argv[1], sys.argv[2]) if len(sys.argv) > 2 else ("cassie_fixed", "LeftFootFront")
-FULL_BODY = name == "full_body"
-if FULL_BODY:
+DEMO = name == "demo"
+FULL_BODY = name == "full_body" or DEMO
+if DEMO:
+    model = ik_amd.Model.from_urdf_file(os.path.join(workload.MODELS_DIR, "cassie.kin.urdf"), free_flyer=True)
+    problem = ik_amd.InverseKinematicsProblem(model)
+    problem.add_frame_task("t0", ik_amd.FrameTask.create(model, "LeftFootFront", ik_amd.KinematicType.Position, "pelvis"))
+    problem.add_frame_task("t1", ik_amd.FrameTask.create(model, "pelvis", ik_amd.KinematicType.Full))
+    problem.add_align_axis_task("t2", ik_amd.AlignAxisTask.create(model, "LeftFootFront", ik_amd.AlignAxisType.AxisY, "universe"))
+    nominal = workload.cassie_nominal(model.names)
+elif FULL_BODY:
     model = ik_amd.Model.from_urdf_file(os.path.join(workload.MODELS_DIR, "cassie.kin.urdf"), free_flyer=True)
     problem = ik_amd.InverseKinematicsProblem(model)
     for i, f in enumerate(["LeftFootFront", "RightFootFront", "pelvis"]):
@@ -54,6 +62,13 @@ for build in (("default",) if FULL_BODY else ("default", "general")):
                 q0, qs = workload.chain_workload(model.lowerPositionLimit, model.upperPositionLimit, nominal, np.arange(B), 0, mode)
             Q0 = torch.from_numpy(np.ascontiguousarray(q0.T)).cuda()
             T = ik_amd.task_frames_fk_batch(problem, torch.from_numpy(np.ascontiguousarray(qs.T)).cuda(), data)
+            if DEMO:   # targets in the tasks' reference frames, the alignment row asks for the foot's Y axis at q* (as bench.py)
+                Rp, pp = T[1, :9].reshape(3, 3, B), T[1, 9:]
+                Rf, pf = T[0, :9].reshape(3, 3, B).clone(), T[0, 9:].clone()
+                T[0, :9] = torch.einsum("kib,kjb->ijb", Rp, Rf).reshape(9, B)
+                T[0, 9:] = torch.einsum("kib,kb->ib", Rp, pf - pp)
+                T[2, 9:] = Rf[:, 1, :]
+                T[2, :9] = torch.eye(3, dtype=torch.float64, device="cuda").reshape(9, 1)
             ms50, _ = timed(data, Q0, T, ik_amd.never_stop_visitor(), ik_amd.dls_parameters(max_iterations=50))
             for max_it in (100, 20):
                 prm = ik_amd.dls_parameters(max_iterations=max_it)
