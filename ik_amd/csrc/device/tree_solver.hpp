@@ -909,7 +909,7 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
                 }
             }
             const ChainPosture po{kPost && prm.post_on != 0, prm.post_prio == 0, prm.postc_slot[c], prm.postc_w[c], prm.postc_m[c],
-                                  targets, (NCH == 1 && ps.by_row) ? ps.t_chain : nullptr, ps.stride};
+                                  targets, (ps.by_row && c == 0) ? ps.t_chain : nullptr, ps.stride};
             leg_eval_factor<NJ, (SPEC >= 0), kPost, kPik>(R1, p1, ct.pl, ct.fr, ct.w, SPEC >= 0 ? (SPEC & ((2 << NJ) - 1)) : prm.idmask[c],
                                 SPEC >= 0 ? ((SPEC >> kSpecUnit) & 1) != 0 : prm.unit[c] != 0, q, oMt, prm.lam2, prm.prio[c] == 0, al,
                                 po, Hbb, gb, e0sq, F, pr);

@@ -408,13 +408,22 @@ __global__ __launch_bounds__(kTreeBlock) void dls_tree_kernel(const TreeKernelAr
     // live in dynamic LDS [row][lane] between iterations; with two chains the LDS is full and they stay in the q_out column
     extern __shared__ double lds_post[];
     double *post_lane = (SPEC > 0 && ikdev::spec_has_posture(SPEC) && NCH == 1) ? lds_post + threadIdx.x : nullptr;
+    int64_t post_stride = kTreeBlock;
+    // posture rows next to the constraint: chain 1 carries the constrained frame and no task, so no factor is ever parked -- the park
+    // buffer's rows hold the outside joints instead (2 * post_n + NJ <= kEntries rows, checked by the launcher), [row][lane] per wave
+    if constexpr (SPEC > 0 && NCH > 1 && (SPEC & ikdev::kSpecPostCons) == ikdev::kSpecPostCons) {
+        if (a.prm.cons_on && 2 * a.prm.post_n + NJ <= LdsPark<NJ>::kEntries) {
+            post_lane = &lds_park[threadIdx.x / 64][0][threadIdx.x % 64];
+            post_stride = 64;
+        }
+    }
     // target rows as SGPR row pointer + lane offset (LaneRows) in the builds that spilled hoisted per-lane row addresses to scratch
     // memory without it: two chains with posture rows next to the constraint, and the general builds without a folded
     // placement mask.  Elsewhere the hoisted addresses fit the register file and are free, the scalar row arithmetic is not (same-box
     // A/B: posture build 0.652 -> 0.663 ms, pik 0.576 -> 0.591, pinned foot 0.707 -> 0.714; posture + pinned foot 1.17 -> 0.87-0.94)
     constexpr bool kRows = SPEC >= 0 && ((NCH > 1 && (SPEC & ikdev::kSpecPostCons) == ikdev::kSpecPostCons) ||
                                          (ikdev::spec_is_general(SPEC) && (SPEC & (1 << ikdev::kSpecGen)) == 0));
-    ikdev::dls_tree_body<NJ, NCH, SPEC>(a, d, gid, park, [](bool act) { return __any(act) != 0; }, post_lane, kTreeBlock,
+    ikdev::dls_tree_body<NJ, NCH, SPEC>(a, d, gid, park, [](bool act) { return __any(act) != 0; }, post_lane, post_stride,
                                         kRows ? static_cast<int64_t>(blockIdx.x) * kTreeBlock : int64_t{-1});
 }
 

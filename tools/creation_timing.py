@@ -18,7 +18,7 @@ def child(row):
     import torch
     import ik_amd
     from ik_amd import workload
-    from test_gpu_generic import CASES, build
+    from test_gpu_generic import CASES
 
     def make():
         if row in ("cassie_leg", "arm7_tool"):
@@ -28,8 +28,21 @@ def child(row):
             problem.add_frame_task("t", ik_amd.FrameTask.create(model, frame, ik_amd.KinematicType.Full))
             return ik_amd, problem
         name, ff, specs, edit = CASES[row]
-        ik, _, _, problem, *_ = build(name, ff, specs, 4, seed=21, xml_edit=edit)
-        return ik, problem
+        xml = open(os.path.join(workload.MODELS_DIR, name + ".kin.urdf"), "rb").read()
+        if edit:
+            xml = edit(xml)
+        model = ik_amd.Model.from_urdf_xml(xml, free_flyer=ff)
+        problem = ik_amd.InverseKinematicsProblem(model, max(s[4] for s in specs))
+        for i, (kind, f, r, t, p, w) in enumerate(specs):
+            if kind == "com":
+                task = problem.add_centre_of_mass_task(ik_amd.CentreOfMassTask.create(model, r), p)
+            elif kind == "align":
+                task = problem.add_align_axis_task("t%d" % i, ik_amd.AlignAxisTask.create(model, f, ik_amd.AlignAxisType(t), r), p)
+            else:
+                task = problem.add_frame_task("t%d" % i, ik_amd.FrameTask.create(model, f, ik_amd.KinematicType(t), r), p)
+            if w is not None:
+                task.weighting()[:] = w
+        return ik_amd, problem
 
     torch.cuda.init()
     torch.zeros(1, device="cuda")
