@@ -587,52 +587,135 @@ IKD_FN void generic_dls(const TB &T, const LoopParams &prm, const WS &ws, const 
     const int M = T.M, nv = T.nv;
     for (int it = 0; R::on || it < prm.max_iterations; ++it) {
         const double e0sq = generic_evaluate(T, ws, targets);
-        // JJ = Jt Jt^T + damping^2 I (lower triangle, packed), ik/ik/dls.cpp:39-41
-        IKD_UNROLL
-        for (int i = 0; i < M; ++i)
+#ifdef IKD_STATIC_TABLES
+        if constexpr (TB::elim != 0) {
+            // PostureTask rows eliminated from the linear system (static lane programs of problems with many of them; the cooperative
+            // kernel does the same, coop_solver.hpp).  Each posture row has ONE non-zero entry, so with J_f the other Mf rows and
+            // D = lambda^2 I + (the posture rows' squares on their columns), JtJ + lambda^2 I = D + J_f^T J_f and by Woodbury
+            //   dq = -(D + J_f^T J_f)^-1 J^T e = -(u - D^-1 J_f^T z),   u = D^-1 J^T e,   (I + J_f D^-1 J_f^T) z = J_f u
+            // -- an Mf x Mf system instead of M x M (the reference demo with every line switched on: 13 instead of 29).  J_f is
+            // scaled by D^-1/2 in place so that the system matrix is I + Jt Jt^T.
+            constexpr int Mf = TB::Mf, Mp = TB::Mp, NV = TB::nv;
+            double dh[NV], u[NV], A[Mf * (Mf + 1) / 2], z[Mf];
             IKD_UNROLL
-            for (int j = 0; j <= i; ++j) {
-                double s = (i == j) ? prm.lam2 : 0.0;
+            for (int c = 0; c < NV; ++c) {
+                double d = prm.lam2;
                 IKD_UNROLL
-                for (int c = 0; c < nv; ++c) s = dfma(ws[T.off_J + i * nv + c], ws[T.off_J + j * nv + c], s);
-                ws[T.off_G + tri(i, j)] = s;
+                for (int k = 0; k < Mp; ++k)
+                    if (TB::p_col[k] == c) { const double w = ws[T.off_J + TB::p_row[k] * NV + c]; d = dfma(w, w, d); }
+                dh[c] = drsqrt(d);
             }
-        // Cholesky in place (diagonal holds 1/L_ii), forward and backward substitution: y = JJ^-1 et
-        IKD_UNROLL
-        for (int k = 0; k < M; ++k) {
-            double d = ws[T.off_G + tri(k, k)];
             IKD_UNROLL
-            for (int m = 0; m < k; ++m) { const double l = ws[T.off_G + tri(k, m)]; d = dfma(-l, l, d); }
-            const double inv = drsqrt(d);
-            ws[T.off_G + tri(k, k)] = inv;
-            IKD_UNROLL
-            for (int i = k + 1; i < M; ++i) {
-                double s = ws[T.off_G + tri(i, k)];
+            for (int c = 0; c < NV; ++c) {
+                double sj = 0.0;
                 IKD_UNROLL
-                for (int m = 0; m < k; ++m) s = dfma(-ws[T.off_G + tri(i, m)], ws[T.off_G + tri(k, m)], s);
-                ws[T.off_G + tri(i, k)] = s * inv;
+                for (int r = 0; r < TB::M; ++r) sj = dfma(ws[T.off_J + r * NV + c], ws[T.off_e + r], sj);
+                u[c] = sj * (dh[c] * dh[c]);
             }
-        }
-        IKD_UNROLL
-        for (int k = 0; k < M; ++k) {
-            double s = ws[T.off_e + k];
             IKD_UNROLL
-            for (int m = 0; m < k; ++m) s = dfma(-ws[T.off_G + tri(k, m)], ws[T.off_y + m], s);
-            ws[T.off_y + k] = s * ws[T.off_G + tri(k, k)];
-        }
-        IKD_UNROLL
-        for (int k = M - 1; k >= 0; --k) {
-            double s = ws[T.off_y + k];
+            for (int i = 0; i < Mf; ++i) {
+                double sb = 0.0;
+                IKD_UNROLL
+                for (int c = 0; c < NV; ++c) sb = dfma(ws[T.off_J + TB::f_row[i] * NV + c], u[c], sb);
+                z[i] = sb;
+                IKD_UNROLL
+                for (int c = 0; c < NV; ++c) ws[T.off_J + TB::f_row[i] * NV + c] = ws[T.off_J + TB::f_row[i] * NV + c] * dh[c];
+            }
             IKD_UNROLL
-            for (int m = M - 1; m > k; --m) s = dfma(-ws[T.off_G + tri(m, k)], ws[T.off_y + m], s);  // (the order coop_solver.hpp takes)
-            ws[T.off_y + k] = s * ws[T.off_G + tri(k, k)];
-        }
-        IKD_UNROLL
-        for (int c = 0; c < nv; ++c) {  // dq = -Jt^T y, ik/ik/dls.cpp:52-53 (N = I)
-            double s = 0.0;
+            for (int i = 0; i < Mf; ++i)
+                IKD_UNROLL
+                for (int j = 0; j <= i; ++j) {
+                    double sa = (i == j) ? 1.0 : 0.0;
+                    IKD_UNROLL
+                    for (int c = 0; c < NV; ++c) sa = dfma(ws[T.off_J + TB::f_row[i] * NV + c], ws[T.off_J + TB::f_row[j] * NV + c], sa);
+                    A[tri(i, j)] = sa;
+                }
             IKD_UNROLL
-            for (int r = 0; r < M; ++r) s = dfma(ws[T.off_J + r * nv + c], ws[T.off_y + r], s);
-            ws[T.off_dq + c] = -s;
+            for (int k = 0; k < Mf; ++k) {   // Cholesky in place (diagonal holds 1 / L_kk), as the dense path below
+                double d = A[tri(k, k)];
+                IKD_UNROLL
+                for (int m = 0; m < k; ++m) { const double l = A[tri(k, m)]; d = dfma(-l, l, d); }
+                const double inv = drsqrt(d);
+                A[tri(k, k)] = inv;
+                IKD_UNROLL
+                for (int i = k + 1; i < Mf; ++i) {
+                    double sl = A[tri(i, k)];
+                    IKD_UNROLL
+                    for (int m = 0; m < k; ++m) sl = dfma(-A[tri(i, m)], A[tri(k, m)], sl);
+                    A[tri(i, k)] = sl * inv;
+                }
+            }
+            IKD_UNROLL
+            for (int k = 0; k < Mf; ++k) {
+                double sf = z[k];
+                IKD_UNROLL
+                for (int m = 0; m < k; ++m) sf = dfma(-A[tri(k, m)], z[m], sf);
+                z[k] = sf * A[tri(k, k)];
+            }
+            IKD_UNROLL
+            for (int k = Mf - 1; k >= 0; --k) {
+                double sb = z[k];
+                IKD_UNROLL
+                for (int m = Mf - 1; m > k; --m) sb = dfma(-A[tri(m, k)], z[m], sb);
+                z[k] = sb * A[tri(k, k)];
+            }
+            IKD_UNROLL
+            for (int c = 0; c < NV; ++c) {
+                double sd = 0.0;
+                IKD_UNROLL
+                for (int i = 0; i < Mf; ++i) sd = dfma(ws[T.off_J + TB::f_row[i] * NV + c], z[i], sd);
+                ws[T.off_dq + c] = -(u[c] - dh[c] * sd);
+            }
+        } else
+#endif
+        {
+            // JJ = Jt Jt^T + damping^2 I (lower triangle, packed), ik/ik/dls.cpp:39-41
+            IKD_UNROLL
+            for (int i = 0; i < M; ++i)
+                IKD_UNROLL
+                for (int j = 0; j <= i; ++j) {
+                    double s = (i == j) ? prm.lam2 : 0.0;
+                    IKD_UNROLL
+                    for (int c = 0; c < nv; ++c) s = dfma(ws[T.off_J + i * nv + c], ws[T.off_J + j * nv + c], s);
+                    ws[T.off_G + tri(i, j)] = s;
+                }
+            // Cholesky in place (diagonal holds 1/L_ii), forward and backward substitution: y = JJ^-1 et
+            IKD_UNROLL
+            for (int k = 0; k < M; ++k) {
+                double d = ws[T.off_G + tri(k, k)];
+                IKD_UNROLL
+                for (int m = 0; m < k; ++m) { const double l = ws[T.off_G + tri(k, m)]; d = dfma(-l, l, d); }
+                const double inv = drsqrt(d);
+                ws[T.off_G + tri(k, k)] = inv;
+                IKD_UNROLL
+                for (int i = k + 1; i < M; ++i) {
+                    double s = ws[T.off_G + tri(i, k)];
+                    IKD_UNROLL
+                    for (int m = 0; m < k; ++m) s = dfma(-ws[T.off_G + tri(i, m)], ws[T.off_G + tri(k, m)], s);
+                    ws[T.off_G + tri(i, k)] = s * inv;
+                }
+            }
+            IKD_UNROLL
+            for (int k = 0; k < M; ++k) {
+                double s = ws[T.off_e + k];
+                IKD_UNROLL
+                for (int m = 0; m < k; ++m) s = dfma(-ws[T.off_G + tri(k, m)], ws[T.off_y + m], s);
+                ws[T.off_y + k] = s * ws[T.off_G + tri(k, k)];
+            }
+            IKD_UNROLL
+            for (int k = M - 1; k >= 0; --k) {
+                double s = ws[T.off_y + k];
+                IKD_UNROLL
+                for (int m = M - 1; m > k; --m) s = dfma(-ws[T.off_G + tri(m, k)], ws[T.off_y + m], s);  // (the order coop_solver.hpp takes)
+                ws[T.off_y + k] = s * ws[T.off_G + tri(k, k)];
+            }
+            IKD_UNROLL
+            for (int c = 0; c < nv; ++c) {  // dq = -Jt^T y, ik/ik/dls.cpp:52-53 (N = I)
+                double s = 0.0;
+                IKD_UNROLL
+                for (int r = 0; r < M; ++r) s = dfma(ws[T.off_J + r * nv + c], ws[T.off_y + r], s);
+                ws[T.off_dq + c] = -s;
+            }
         }
         if (T.Mc > 0) {  // dq <- N dq, N = I - pinv(Jc) Jc: the step stays in the null space of the constraints (dls.cpp:26-34,43-53)
             generic_constraint_jacobian(T, ws);

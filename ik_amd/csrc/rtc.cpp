@@ -233,7 +233,14 @@ void compile_cached(const char *prefix, const std::string &src_in, HotCode &hc, 
     std::vector<const char *> flags(kFlags, kFlags + sizeof kFlags / sizeof kFlags[0]);
     // the generic program: every two-armed choice whose arms the compiler may evaluate speculatively becomes a select, whatever the
     // arms cost -- no divergent branch inside the iteration (see IKD_CHOOSE in device/lane_math.hpp)
-    if (if_convert) { flags.push_back("-mllvm"); flags.push_back("-two-entry-phi-node-folding-threshold=100000"); }
+    if (if_convert) {
+        flags.push_back("-mllvm"); flags.push_back("-two-entry-phi-node-folding-threshold=100000");
+        // `#pragma unroll` gives up above 16384 unrolled instructions by default; a loop of a static lane program left rolled indexes the
+        // workspace with a run-time value, which demotes the WHOLE workspace from registers to scratch memory (18.8 KB per lane for
+        // an M = 29 problem, 20 s of compile time, and "LLVM ERROR: Cannot scavenge register in FI elimination" -- an abort of the
+        // host process -- for its sibling without the constraint).  With the threshold lifted: 1.8 KB, 8 s, no error.
+        flags.push_back("-mllvm"); flags.push_back("-pragma-unroll-threshold=4000000");
+    }
     if (const char *m = std::getenv("IKGPU_RTC_PLAIN_FLAGS")) {   // bit k set: drop the k-th of the three flags
         const long mask = std::strtol(m, nullptr, 10);
         std::vector<const char *> keep(kFlags, kFlags + 5);
@@ -369,6 +376,26 @@ std::string dbl_array(const char *name, It begin, int n) {
     return o + "};\n";
 }
 
+#ifndef IKGPU_STATIC_MAX_ROWS
+#define IKGPU_STATIC_MAX_ROWS 24
+#endif
+// Problems whose PostureTask rows the static program eliminates from the linear system (generic_solver.hpp, TB::elim): those beyond
+// what the dense unrolled solve stays compilable at.  Fewer rows keep the dense solve -- the same operations in the same order as the
+// interpreter forms, bit for bit.
+int static_posture_rows(const ProblemHost &ph) {
+    int n = 0;
+    for (const ikgpu_task &t : ph.tasks) n += t.type == IKGPU_POSTURE_ROW ? 1 : 0;
+    return n;
+}
+int static_max_rows() {   // rows of the linear system the unrolled program is taken up to (IKGPU_STATIC_MAX_ROWS: experiments)
+    if (const char *env = std::getenv("IKGPU_STATIC_MAX_ROWS")) { const long v = std::strtol(env, nullptr, 10); if (v >= 1 && v <= 64) return static_cast<int>(v); }
+    return IKGPU_STATIC_MAX_ROWS;
+}
+bool static_elimination(const ProblemHost &ph) {
+    const int np = static_posture_rows(ph);
+    return np > 0 && (np > 8 || ph.rows > static_max_rows());
+}
+
 std::string generic_static_source(const ProblemHost &ph, bool refill = false) {
     const GenericHost &g = ph.generic;
     const int nj = g.njoints, nt = ph.ntasks;
@@ -387,6 +414,18 @@ std::string generic_static_source(const ProblemHost &ph, bool refill = false) {
     scalar("off_G", g.off_G); scalar("off_y", g.off_y); scalar("off_dq", g.off_dq); scalar("ws_words", g.ws_words);
     scalar("nlevels", g.nlevels);
     o += int_array("lvl_row0", I + g.o_lvlrow0, g.nlevels + 1);
+    {   // the rows of the stacked system by kind: PostureTask rows (one non-zero each) are eliminated from the solve when there are many
+        std::vector<int> f_row, p_row, p_col;
+        for (int t = 0; t < nt; ++t) {
+            const int row = I[g.o_trow + t], dim = I[g.o_tdim + t];
+            if (I[g.o_ttype + t] == IKGPU_POSTURE_ROW) { p_row.push_back(row); p_col.push_back(I[g.o_tfjoint + t]); }
+            else for (int r = 0; r < dim; ++r) f_row.push_back(row + r);
+        }
+        std::sort(f_row.begin(), f_row.end());
+        scalar("elim", static_elimination(ph) ? 1 : 0); scalar("Mf", static_cast<long long>(f_row.size())); scalar("Mp", static_cast<long long>(p_row.size()));
+        o += int_array("f_row", f_row.begin(), static_cast<int>(f_row.size())) + int_array("p_row", p_row.begin(), static_cast<int>(p_row.size())) +
+             int_array("p_col", p_col.begin(), static_cast<int>(p_col.size()));
+    }
     const int nc = static_cast<int>(ph.constraints.size());
     scalar("ncons", nc); scalar("Mc", ph.crows); scalar("off_Jc", g.off_Jc);
     o += int_array("c_type", I + g.o_ctype, nc) + int_array("c_fjoint", I + g.o_cfjoint, nc) + int_array("c_rjoint", I + g.o_crjoint, nc);
@@ -462,19 +501,16 @@ hipError_t rtc_launch_chain_hot(const ProblemHost &ph, const DeviceTables &dt, c
 namespace ikgpu {
 
 // What the static program takes: sizes the unrolled program stays compilable at (constraints project by Gram-Schmidt there).  IKGPU_GENERIC_KERNEL (lane / lds / coop: tests, A/B) keeps the other forms.
-#ifndef IKGPU_STATIC_MAX_ROWS
-#define IKGPU_STATIC_MAX_ROWS 24
-#endif
 bool rtc_generic_static_available(const ProblemHost &gen, bool compile, uint64_t *key_out) {
     if (!rtc_enabled() || gen.kind != KernelKind::Generic || gen.crows > 12) return false;
     if (std::getenv("IKGPU_GENERIC_KERNEL")) return false;
     if (const char *env = std::getenv("IKGPU_GENERIC_STATIC")) { if (env[0] == '0') return false; }
     // (measured compile times of the unrolled program: M = 10: 2 s, 15: 9 s, 21: ~20 s, 31: 48 s with 19 KB of scratch per lane;
     // 28 rows of which 16 are posture rows: 440 s -- such problems keep the cooperative kernel)
-    if (gen.rows < 1 || gen.rows > IKGPU_STATIC_MAX_ROWS || gen.nv > 36 || gen.generic.ws_words > 2400) return false;
-    int posture_rows = 0;
-    for (const ikgpu_task &t : gen.tasks) posture_rows += t.type == IKGPU_POSTURE_ROW ? 1 : 0;
-    if (posture_rows > 8) return false;
+    // (with the PostureTask rows eliminated from the solve the caps apply to the rows that are left: the reference demo with every line
+    // switched on -- M = 29, 16 of them posture rows -- is a 13 x 13 system)
+    const int solve_rows = static_elimination(gen) ? gen.rows - static_posture_rows(gen) : gen.rows;
+    if (gen.rows < 1 || solve_rows < 1 || solve_rows > static_max_rows() || gen.rows > 64 || gen.nv > 36 || gen.generic.ws_words > 2400) return false;
     if (!rtc_api().ok) return false;
     if (!compile) return true;
     const std::string src = generic_static_source(gen);
@@ -488,9 +524,15 @@ bool rtc_generic_static_available(const ProblemHost &gen, bool compile, uint64_t
 }
 
 // (g_mu held) the refill program of the static lane program `key` on the current device, or gm.refill == nullptr
+// (programs above 12 rows spill, and a spilling program is kept off the refill path below: do not even compile it)
+static bool refill_program_worth_compiling(const ProblemHost &gen) {
+    return (static_elimination(gen) ? gen.rows - static_posture_rows(gen) : gen.rows) <= 12;
+}
+
 static void ensure_generic_refill(const ProblemHost &gen, GenModule &gm) {
     if (gm.refill_tried) return;
     gm.refill_tried = true;
+    if (!refill_program_worth_compiling(gen)) return;
     const std::string src = generic_static_source(gen, /*refill=*/true);
     HotCode &hc = g_gen_codes[source_hash(src)];
     if (!hc.tried) compile_cached("generic_static_refill", src, hc, /*if_convert=*/true);
@@ -524,6 +566,7 @@ static hipError_t generic_module(uint64_t key, GenModule **out) {   // (g_mu hel
 }
 
 bool rtc_generic_static_precompile_refill(const ProblemHost &gen) {   // (compiles / fetches the code object; modules load per device at launch)
+    if (!refill_program_worth_compiling(gen)) return false;
     const std::string src = generic_static_source(gen, /*refill=*/true);
     std::lock_guard<std::mutex> lock(g_mu);
     HotCode &hc = g_gen_codes[source_hash(src)];

@@ -34,6 +34,8 @@ misc)
   steps+=("refill_static|300|python3 tools/refill_timing.py demo x > gpurun_out/r03_refill_timing_static.txt 2>&1; grep -v amdgpu.ids gpurun_out/r03_refill_timing_static.txt | tail -4")
   steps+=("creation|600|python3 tools/creation_timing.py > gpurun_out/r03_creation_timing.txt 2>&1; grep -v amdgpu.ids gpurun_out/r03_creation_timing.txt")
   steps+=("fullbody_static|400|IKGPU_TREE_STATIC_ROWS=18 python3 bench.py --workload cassie_full_body --no-cpu --timed-only 2>/dev/null | grep '^{' > gpurun_out/r03_bench_cassie_full_body_static.json; cut -c1-400 gpurun_out/r03_bench_cassie_full_body_static.json")
+  steps+=("constraints|600|python3 tools/constraint_timing.py 2>&1 | grep -v amdgpu.ids | grep cholqr > gpurun_out/r03_constraint_timing.txt; cat gpurun_out/r03_constraint_timing.txt")
+  steps+=("rows_31_32|900|IKGPU_STATIC_MAX_ROWS=32 FORMS=coop,static python3 tools/generic_forms.py rows_31 rows_32 2>&1 | grep -v amdgpu.ids > gpurun_out/r03_generic_forms_rows_31_32.txt; cat gpurun_out/r03_generic_forms_rows_31_32.txt")
   steps+=("host_entry|200|python3 tools/host_entry_timing.py > gpurun_out/r03_host_entry.txt 2>&1; grep -v amdgpu.ids gpurun_out/r03_host_entry.txt | tail -4")
   steps+=("chain_builds|200|python3 tools/chain_builds_timing.py > gpurun_out/r03_chain_builds.txt 2>&1; grep -v amdgpu.ids gpurun_out/r03_chain_builds.txt")
   steps+=("generic_forms|400|FORMS=coop,static python3 tools/generic_forms.py shared_joints com_of_the_arm moving_reference_prismatic demo_task_set com_under_feet three_feet_frames feet_frames_beyond_the_register_solve rows_16 nv_30 fixed_two_feet_priorities com_in_foot_frame > gpurun_out/r03_generic_forms.txt 2>&1; grep -v amdgpu.ids gpurun_out/r03_generic_forms.txt")

@@ -37,7 +37,7 @@ for case, (name, ff, specs, cons) in sorted(ROUTED.items()):
 PY
 for f in "$OUT"/src/generic_static_*.hip; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-fast-math -ffp-contract=on -fno-signed-zeros -fno-honor-nans -fno-honor-infinities \
-    -mllvm -two-entry-phi-node-folding-threshold=100000 -Iik_amd/csrc/device -S --cuda-device-only "$f" -o "${f%.hip}.s" 2>/dev/null
+    -mllvm -two-entry-phi-node-folding-threshold=100000 -mllvm -pragma-unroll-threshold=4000000 -Iik_amd/csrc/device -S --cuda-device-only "$f" -o "${f%.hip}.s" 2>/dev/null
   echo "$(basename "$f"): $(grep -E 'TotalNumVgprs' "${f%.hip}.s" | tr -d ';') $(grep -E 'ScratchSize' "${f%.hip}.s" | tr -d ';') saveexec in loop: $(awk '/Loop Header/ {l=1} /s_and_saveexec/ && l {n++} END {print n+0}' "${f%.hip}.s")"
 done
 python3 tools/spill_exec_check.py "$OUT"/src/*.s | grep -v "divergent regions:   [01]," || true
