@@ -90,8 +90,10 @@ int fail(int code, const std::string &msg) {
     return code;
 }
 
-// Tree-kind problems the static generic program is tried for first: few rows (IKGPU_TREE_STATIC_ROWS, default 12; 0 = never) and no
-// constraint -- measured, B = 65536, 50 iterations: the demo's task set (M = 10) 0.40 ms static against 0.51 ms on the tree kernel,
+// Tree-kind problems the static generic program is tried for first: few rows in the system it solves (IKGPU_TREE_STATIC_ROWS, default
+// 12; 0 = never; PostureTask rows do not count when the program eliminates them) and no constraint -- measured, B = 65536, 50
+// iterations: the demo's task set (M = 10) 0.40 ms static against 0.51 ms on the tree kernel, with the posture regulariser on all 16
+// joints (M = 26, a 10 x 10 system) 0.53 against 0.65,
 // but with the right foot pinned 0.78 against 0.71 (the tree kernel projects on the constrained chain's 13 columns only; the static
 // program orthogonalises three dense rows of 22).  IKGPU_TREE_STATIC_CONSTRAINED=1 routes those too (tests).
 bool tree_prefers_static(const ikgpu::ProblemHost &ph) {
@@ -99,7 +101,7 @@ bool tree_prefers_static(const ikgpu::ProblemHost &ph) {
     long rows = 12;
     if (const char *env = std::getenv("IKGPU_TREE_STATIC_ROWS")) rows = std::strtol(env, nullptr, 10);
     if (ph.cons_on && !std::getenv("IKGPU_TREE_STATIC_CONSTRAINED")) return false;
-    return ph.rows <= rows;
+    return ikgpu::rtc_static_solve_rows(ph) <= rows;
 }
 
 std::string static_name(const ikgpu::ProblemHost &gen) {

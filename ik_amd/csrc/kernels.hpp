@@ -95,6 +95,7 @@ bool rtc_chain_hot_available(const ProblemHost &ph, bool compile);
 bool rtc_generic_static_available(const ProblemHost &gen, bool compile, uint64_t *key_out);
 hipError_t rtc_launch_generic_static(const ProblemHost &gen, uint64_t key, const BatchIO &io, const ikgpu_dls_params &prm, hipStream_t stream,
                                      QueuePool *queues = nullptr);   // queues: where the refill program's work-queue slots come from (none: lock-step only)
+int rtc_static_solve_rows(const ProblemHost &ph);   // rows of the linear system the static program solves (PostureTask rows eliminated when there are many)
 bool rtc_generic_static_precompile_refill(const ProblemHost &gen);   // the refill program, ahead of the first large stop-rule batch
 std::string rtc_last_log();   // compiler log (or cache note) of the calling process's last run-time compilation attempt
 hipError_t rtc_launch_chain_hot(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const ikgpu_dls_params &prm, hipStream_t stream);

@@ -464,6 +464,8 @@ std::map<std::pair<uint64_t, int>, GenModule> g_gen_modules;   // (hash, device)
 
 }  // namespace
 
+int rtc_static_solve_rows(const ProblemHost &ph) { return static_elimination(ph) ? ph.rows - static_posture_rows(ph) : ph.rows; }
+
 bool rtc_chain_hot_available(const ProblemHost &ph, bool compile) {
     if (!rtc_enabled() || ph.kind != KernelKind::Chain || !ph.chain_struct.fits || ph.chain.nj < 1 || ph.chain.nj > 7) return false;
     if (!rtc_api().ok) return false;
@@ -509,7 +511,7 @@ bool rtc_generic_static_available(const ProblemHost &gen, bool compile, uint64_t
     // 28 rows of which 16 are posture rows: 440 s -- such problems keep the cooperative kernel)
     // (with the PostureTask rows eliminated from the solve the caps apply to the rows that are left: the reference demo with every line
     // switched on -- M = 29, 16 of them posture rows -- is a 13 x 13 system)
-    const int solve_rows = static_elimination(gen) ? gen.rows - static_posture_rows(gen) : gen.rows;
+    const int solve_rows = rtc_static_solve_rows(gen);
     if (gen.rows < 1 || solve_rows < 1 || solve_rows > static_max_rows() || gen.rows > 64 || gen.nv > 36 || gen.generic.ws_words > 2400) return false;
     if (!rtc_api().ok) return false;
     if (!compile) return true;
@@ -525,9 +527,7 @@ bool rtc_generic_static_available(const ProblemHost &gen, bool compile, uint64_t
 
 // (g_mu held) the refill program of the static lane program `key` on the current device, or gm.refill == nullptr
 // (programs above 12 rows spill, and a spilling program is kept off the refill path below: do not even compile it)
-static bool refill_program_worth_compiling(const ProblemHost &gen) {
-    return (static_elimination(gen) ? gen.rows - static_posture_rows(gen) : gen.rows) <= 12;
-}
+static bool refill_program_worth_compiling(const ProblemHost &gen) { return rtc_static_solve_rows(gen) <= 12; }
 
 static void ensure_generic_refill(const ProblemHost &gen, GenModule &gm) {
     if (gm.refill_tried) return;

@@ -27,6 +27,8 @@ ROUTED = {
     "demo_task_set": ("cassie", True, DEMO, None),
     "demo_right_foot_pinned": ("cassie", True, DEMO, ("RightFootFront", 0)),
     "fixed_two_feet_positions": ("cassie_fixed", False, [("frame", "LeftFootFront", "universe", 0, 0, None), ("frame", "RightFootFront", "universe", 0, 0, None)], None),
+    # posture regulariser on all 16 joints: M = 26, the static program eliminates the posture rows and solves a 10 x 10 system
+    "demo_with_posture": ("cassie", True, DEMO + [("posture", 16, None, None, 1, ([0.05] * 16, [1.0] * 16))], None),
     "pelvis_and_foot": ("cassie", True, [("frame", "pelvis", "universe", 2, 0, None), ("frame", "RightFootFront", "universe", 2, 0, [1.0, 2.0, 0.5, 1.0, 1.0, 3.0])], None),
 }
 
@@ -93,11 +95,15 @@ def test_small_tree_problems_run_on_the_static_program_and_agree_with_the_tree_k
         frac_gpu, frac_ref = (d_gpu_x <= TOL).mean(), (d_ref_x <= TOL).mean()
         assert frac_gpu >= frac_ref - 0.002 and frac_gpu >= 0.99, (name, iters, frac_gpu, frac_ref)
         d = np.abs(Qs.cpu().numpy().T - q_ref).max(axis=1)
-        assert np.median(d) < 1e-12 and (d[(d_ref_x <= 1e-9) & same] <= TOL).mean() >= 0.9995, (name, iters, np.median(d))
+        # (the eliminated-posture program solves the system by another algebraic route -- Woodbury on D + J_f^T J_f -- than the oracle's
+        # dense dual solve: same answer to cond x eps, ~2e-12 rad per step at damping 1e-2, as the tree kernel's primal arrow solve)
+        median_bar = 1e-10 if name == "demo_with_posture" else 1e-12
+        assert np.median(d) < median_bar and (d[(d_ref_x <= 1e-9) & same] <= TOL).mean() >= 0.9995, (name, iters, np.median(d))
         agree = (its == itt)
         assert agree.double().mean().item() > 0.999
         dt = (Qs - Qt).abs().max(dim=0).values[agree]
-        assert (dt <= 1e-8).double().mean().item() >= frac_ref - 0.004, (name, iters, dt.max().item())
+        # (two kernels that each differ from the oracle by their own rounding: the pair agrees a little less often than either does with it)
+        assert (dt <= 1e-8).double().mean().item() >= frac_ref - (0.01 if name == "demo_with_posture" else 0.004), (name, iters, dt.max().item())
     print("%s: %s replaces %s" % (name, data_s.kernel, data_t.kernel))
 
 

@@ -24,6 +24,7 @@ pmc2)
   steps+=("pmc_cassie_demo_tree|300|IKGPU_TREE_STATIC_ROWS=0 tools/pmc_session.sh cassie_demo r03_pmc_cassie_demo_tree")
   steps+=("pmc_cassie_demo_coop|400|IKGPU_DLS_KERNEL=generic IKGPU_GENERIC_STATIC=0 tools/pmc_session.sh cassie_demo r03_pmc_cassie_demo_coop")
   steps+=("pmc_cassie_demo_posture|300|tools/pmc_session.sh cassie_demo_posture r03_pmc_cassie_demo_posture")
+  steps+=("pmc_cassie_demo_posture_tree|300|IKGPU_TREE_STATIC_ROWS=0 tools/pmc_session.sh cassie_demo_posture r03_pmc_cassie_demo_posture_tree")
   steps+=("pmc_cassie_demo_pinned|300|tools/pmc_session.sh cassie_demo_pinned r03_pmc_cassie_demo_pinned")
   steps+=("pmc_cassie_demo_pinned_tree|300|IKGPU_TREE_STATIC_ROWS=0 tools/pmc_session.sh cassie_demo_pinned r03_pmc_cassie_demo_pinned_tree")
   steps+=("pmc_cassie_demo_pinned_posture|300|tools/pmc_session.sh cassie_demo_pinned_posture r03_pmc_cassie_demo_pinned_posture")
