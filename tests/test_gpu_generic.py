@@ -28,7 +28,7 @@ def T4(m12):
     return M
 
 
-def build(name, ff, specs, B, seed=0, xml_edit=None, static=True):
+def build(name, ff, specs, B, seed=0, xml_edit=None, static=True, device=True):
     """specs: (kind 'frame'|'align', frame, reference, type-or-axis, priority, weights).
     static: False keeps a generic problem off the run-time specialised lane program (IKGPU_GENERIC_STATIC=0 when the handle is
     created): the cooperative / per-lane memory-resident forms then run."""
@@ -60,14 +60,14 @@ def build(name, ff, specs, B, seed=0, xml_edit=None, static=True):
     if not static:
         os.environ["IKGPU_GENERIC_STATIC"] = "0"
     try:
-        data = ik_amd.dls_data(problem, device=0)
+        data = ik_amd.dls_data(problem, device=0) if device else None   # (device=False: the problem and the oracle's view of it only)
     finally:
         if not static:
             if prev is None:
                 del os.environ["IKGPU_GENERIC_STATIC"]
             else:
                 os.environ["IKGPU_GENERIC_STATIC"] = prev
-    if not static:
+    if not static and device:
         assert not data.kernel.endswith(",static>"), data.kernel
     om = O.OracleModel(model.flat())
     ordered = problem.ordered_tasks()

@@ -1,0 +1,108 @@
+"""The static lane programs (rtc.cpp generic_static_source: the generic lane program specialised for ONE problem, what a generic
+problem runs on by default) checked WITHOUT a GPU: the generated translation unit is dumped (IKGPU_RTC_DUMP), its __global__ wrapper
+is replaced by a host loop over the lanes, g++ compiles it, and the results are compared with the C oracle -- the same source the
+device compiles, with the host arms of the reciprocal / square-root helpers (lane_math.hpp).  Covers the dense solve, the constraint
+projection and the eliminated-posture solve (TB::elim) of the reference demo with every line switched on."""
+import ctypes as C
+import glob
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+import oracle as O
+from test_gpu_generic import CASES as GENERIC, build
+from test_gpu_constraints import CASES as CONSTRAINED
+
+HOST_DRIVER = r'''
+extern "C" int static_host_solve(long long B, const double *q0, const double *targets, int max_it, double damping, double step, double stop_tol,
+                                 double *q_out, unsigned char *ok, int *iters) {
+    ikdev::GenericKernelArgs a{};
+    a.prm.max_iterations = max_it; a.prm.lam2 = damping * damping; a.prm.step_length = step; a.prm.stop_sq_tol = stop_tol;
+    a.layout = ikdev::LAYOUT_AOS; a.B = B; a.q0 = q0; a.targets = targets; a.q_out = q_out; a.success = ok; a.iters = iters;
+    for (long long gid = 0; gid < B; ++gid) {
+        double w[T::ws_words];
+        ikdev::dls_generic_body_ws(a, T{}, gid, ikdev::WsReg{w}, [](bool act) { return act; });
+    }
+    return T::elim;
+}
+'''
+
+
+def host_program(tmp_path, problem, want_static_name=True):
+    import ik_amd
+    src_dir, cache = tmp_path / "src", tmp_path / "cache"
+    src_dir.mkdir(), cache.mkdir()
+    old = {k: os.environ.get(k) for k in ("IKGPU_RTC_DUMP", "IKGPU_CACHE_DIR", "IKGPU_DLS_KERNEL", "IKGPU_TREE_STATIC_ROWS")}
+    os.environ.update(IKGPU_RTC_DUMP=str(src_dir), IKGPU_CACHE_DIR=str(cache), IKGPU_DLS_KERNEL="generic")
+    try:
+        try:
+            name = ik_amd.precompile(problem)
+        except ik_amd.capi.IkgpuError as e:
+            pytest.skip("run-time compilation unavailable here: %s" % e)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    if not name.endswith(",static>"):
+        pytest.skip("no static program for this problem here: %s" % name)
+    srcs = [f for f in glob.glob(str(src_dir / "generic_static_*.hip")) if "refill" not in os.path.basename(f)]
+    assert len(srcs) == 1, srcs
+    text = open(srcs[0]).read()
+    cut = text.index('extern "C" __global__')
+    host = tmp_path / "program.cpp"
+    host.write_text(text[:cut] + HOST_DRIVER)
+    lib = tmp_path / "program.so"
+    dev = os.path.join(ROOT, "ik_amd", "csrc", "device")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-I" + dev, "-I" + os.path.join(ROOT, "ik_amd", "csrc"),
+                           "-I" + os.path.join(ROOT, "include"), "-o", str(lib), str(host)])
+    L = C.CDLL(str(lib))
+    L.static_host_solve.restype = C.c_int
+    return name, L
+
+
+def solve(L, q0, tg, iters, damping, step, tol):
+    B = q0.shape[0]
+    q0 = np.ascontiguousarray(q0)
+    tg = np.ascontiguousarray(tg)
+    q, ok, it = np.empty_like(q0), np.zeros(B, np.uint8), np.zeros(B, np.int32)
+    p = lambda x: C.c_void_p(x.ctypes.data)
+    elim = L.static_host_solve(C.c_longlong(B), p(q0), p(tg), iters, C.c_double(damping), C.c_double(step), C.c_double(tol), p(q), p(ok), p(it))
+    return q, ok, it, elim
+
+
+@pytest.mark.parametrize("case,elim", [("shared_joints", 0), ("com_of_the_arm", 0), ("demo_task_set", 0), ("demo_everything_on", 1),
+                                       ("demo_everything_on_unconstrained", 1), ("pelvis_with_both_feet_locked", 0)])
+def test_static_program_on_the_host_matches_the_oracle(tmp_path, native_built, case, elim):
+    import ik_amd
+    constrained = case in CONSTRAINED
+    if case == "demo_everything_on_unconstrained":
+        name, ff, specs, _ = CONSTRAINED["demo_everything_on"]
+        cspecs, edit = [], None
+    elif constrained:
+        name, ff, specs, cspecs = CONSTRAINED[case]
+        edit = None
+    else:
+        (name, ff, specs, edit), cspecs = GENERIC[case], []
+    B = 24
+    ik, _, model, problem, _, om, ot, q0, tg = build(name, ff, specs, B, seed=11, xml_edit=edit, device=False)
+    for i, (f, t, r) in enumerate(cspecs):
+        problem.add_frame_constraint("c%d" % i, ik_amd.FrameConstraint.create(model, f, ik_amd.KinematicType(t), r))
+    kernel, L = host_program(tmp_path, problem)
+    oc = O.make_tasks([(model.getFrameId(f), model.getFrameId(r), t, 0, None) for f, t, r in cspecs]) if cspecs else None
+    for iters, damping, step, tol, bar in ((1, 1e-2, 1.0, -1.0, 1e-9), (3, 1e-2, 1.0, -1.0, 1e-8), (40, 1e-1, 0.5, 1e-4, 1e-6)):
+        prm = O.params(iters, damping, step, tol)
+        if oc is not None:
+            q_ref, ok_ref, it_ref = O.dls_batch_constrained(om, ot, oc, tg, q0, prm, 1)
+        else:
+            q_ref, ok_ref, it_ref = O.dls_batch(om, ot, tg, q0, prm, 1)
+        q, ok, it, is_elim = solve(L, q0, tg, iters, damping, step, tol)
+        assert is_elim == elim, (kernel, is_elim)
+        assert np.array_equal(it, it_ref) and np.array_equal(ok, ok_ref), (case, iters, it, it_ref)
+        d = np.abs(q - q_ref).max()
+        assert d <= bar, (case, kernel, iters, d)
