@@ -51,6 +51,12 @@ struct ikgpu_problem {
     // the dense M x M system of a small task set is cheaper than the tree kernel's arrow elimination (the reference demo's own task
     // set, M = 10: 0.39 against 0.51 ms per 65536 problems); `host` stays the tree analysis (stage kernels, two-level ik::pik)
     bool dls_on_static_gen = false;
+    // A derived visitor (ikgpu_dls_params::dq_sq_tol / level_sq_tol) runs on the generic lane program whatever kernel ik::dls itself
+    // uses.  For Chain / Tree problems that program's static build is compiled at the FIRST such solve (most callers never use a
+    // derived visitor, and creation should not pay for it); until it exists -- or where it cannot -- the per-lane interpreter runs.
+    mutable std::once_flag visitor_static_once;
+    mutable uint64_t visitor_static_key = 0;
+    mutable bool visitor_static = false;
     std::string dls_name;    // what ikgpu_problem_kernel reports
     std::string pik_name;    // name of the generic PIK kernel instance
     std::string pik_tree_name;  // ... and of the tree kernel running a two-level ik::pik (when the problem has that shape)
@@ -607,8 +613,14 @@ int ikgpu_dls_solve_batch(const ikgpu_problem *p, int64_t B, const double *q0, c
         if (ikgpu::visitor_extended(*params)) {
             // a derived visitor (step tolerance / per-level tolerances): the generic lane program implements the family -- the one
             // specialised for this problem when there is one, else its memory-resident per-lane form
-            const hipError_t ev = p->gen.generic_build == 2 ? ikgpu::rtc_launch_generic_static(p->gen, p->gen.generic_key, io, *params, st, &p->dev.queues)
-                                                            : ikgpu::launch_dls_generic(p->gen, p->dev, io, *params, st, /*force_lane=*/true);
+            if (p->gen.generic_build != 2)
+                std::call_once(p->visitor_static_once, [&] {
+                    p->visitor_static = ikgpu::rtc_generic_static_available(p->gen, /*compile=*/true, &p->visitor_static_key);
+                });
+            const bool on_static = p->gen.generic_build == 2 || p->visitor_static;
+            const uint64_t key = p->gen.generic_build == 2 ? p->gen.generic_key : p->visitor_static_key;
+            const hipError_t ev = on_static ? ikgpu::rtc_launch_generic_static(p->gen, key, io, *params, st, &p->dev.queues)
+                                            : ikgpu::launch_dls_generic(p->gen, p->dev, io, *params, st, /*force_lane=*/true);
             if (ev != hipSuccess) return hip_fail(ev, "launching the generic DLS kernel (derived visitor)");
             return static_cast<int>(IKGPU_OK);
         }
