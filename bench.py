@@ -122,9 +122,15 @@ def parse_args(argv=None):
                          "solve can move + flags; none = no collective (the default at N = 1)")
     ap.add_argument("--launcher", action="store_true",
                     help="start the ranks through torch.distributed.run even at N = 1 (rehearses the N > 1 launch and RCCL init on one GPU)")
+    ap.add_argument("--stop-rule", action="store_true",
+                    help="time the reference's DEFAULT visitor (||e0||^2 < 1e-4, max_iterations 100) instead of the fixed-iteration metric: "
+                         "with --batch above 65536 the timed kernel is the lane-refill kernel (profiling sessions of that mode)")
     ap.add_argument("--timed-only", action="store_true",
                     help="launch nothing but the warm-up and timed steps (profiling passes: every dispatch is the same launch)")
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    if a.stop_rule and a.iters == 50:
+        a.iters = 100   # the reference's default max_iterations (ik/ik/common.hpp:61)
+    return a
 
 
 def _free_port():
@@ -360,7 +366,7 @@ def main():
     # two buffer sets alternate so that the all-gather of step k overlaps the solve of step k + 1
     rows = np.flatnonzero(data.support) if gather == "compact" else None
     bufs = [ikdist.ShardBuffers(model.nq, total, rank, world, dev, rows=rows) for _ in range(2)]
-    visitor = ik_amd.never_stop_visitor()
+    visitor = ik_amd.inverse_kinematics_visitor() if args.stop_rule else ik_amd.never_stop_visitor()
     if use_pik:
         prm = ik_amd.pik_parameters(max_iterations=args.iters, step_length=1.0)
         solve_batch = ik_amd.pik_batch
@@ -462,7 +468,8 @@ def main():
         value = total * args.steps / elapsed
         bps = bytes_per_solve(w)
         achieved = bps * B / (kernel_ms * 1e-3) / 1e9
-        stats = load_kernel_stats().get(data.kernel, {})
+        kernel_label = data.kernel + (("|default stop rule" + (", lane refill" if B > 65536 and os.environ.get("IKGPU_REFILL") != "0" else ", lock-step")) if args.stop_rule else "")
+        stats = load_kernel_stats().get(kernel_label, {})
         # One build, one counter set: an entry of ik_amd/kernel_stats.json is replayed only when it was measured on THIS tree's device
         # sources (tools/pmc_session.sh records tools/source_stamp.py's hash; tools/pmc_to_stats.py stamps it next to the kernel's symbol)
         sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -486,7 +493,8 @@ def main():
         hbm = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                "traffic": traffic, "traffic_source": replay if traffic else stale, "counter_stamp": stamp, "algorithmic_bytes_per_solve": bps}
         res = {
-            "metric": "IK solves/sec (50-iter %s) at batch=65536" % ("PIK" if use_pik else "DLS"),
+            "metric": ("IK solves/sec (default stop rule, max %d iterations) at batch=%d" % (args.iters, B)) if args.stop_rule else
+                      "IK solves/sec (50-iter %s) at batch=65536" % ("PIK" if use_pik else "DLS"),
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -494,7 +502,7 @@ def main():
                                     "%s, %d fixed DLS iterations, damping 1e-2, step 1.0, reachable targets FK(q*)")
                                    % (w["text"], args.iters),
                        "name": args.workload, "batch_per_gpu": b_max, "global_batch": total, "iterations": args.iters,
-                       "kernel": data.kernel,
+                       "kernel": kernel_label,
                        "parallelism": ("contiguous batch shards x%d + one RCCL all-gather per step (%s payload, %d B per problem)"
                                        % (world, gather, bufs[0].nbytes // max(1, b_max)) if distributed else "single GPU"),
                        "waves_per_simd_per_gpu": waves_per_simd,

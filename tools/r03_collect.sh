@@ -8,7 +8,7 @@ for w in cassie_leg ur5 ur10 ur5_clamp ur10_clamp arm7 ur5_two_tasks cassie_full
   [ -s gpurun_out/bench_$w.json ] && cp gpurun_out/bench_$w.json profiles/r03_bench_$w.json
   f=$(ls -t gpurun_out/stats_$w/runc/*_kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" profiles/r03_kernel_stats_$w.csv
 done
-for s in cassie_leg cassie_leg_general ur5 arm7 ur5_two_tasks cassie_full_body cassie_demo cassie_demo_tree cassie_demo_coop cassie_demo_posture cassie_demo_posture_tree cassie_demo_pinned cassie_demo_pinned_tree cassie_demo_pinned_posture cassie_demo_pik; do
+for s in cassie_leg cassie_leg_refill cassie_leg_lockstep cassie_leg_general ur5 arm7 ur5_two_tasks cassie_full_body cassie_demo cassie_demo_tree cassie_demo_coop cassie_demo_posture cassie_demo_posture_tree cassie_demo_pinned cassie_demo_pinned_tree cassie_demo_pinned_posture cassie_demo_pik; do
   [ -d gpurun_out/r03_pmc_$s ] && python3 tools/pmc_to_stats.py gpurun_out/r03_pmc_$s profiles/r03_pmc $s | cut -c1-400
 done
 for f in r03_refill_timing_chain.txt r03_refill_timing_tree.txt r03_refill_timing_static.txt r03_creation_timing.txt r03_bench_cassie_full_body_static.json r03_constraint_timing.txt r03_generic_forms_rows_31_32.txt r03_host_entry.txt r03_chain_builds.txt r03_generic_forms.txt r03_bench_launcher_n1.json r03_bench_launcher_n1_gather_full.json r03_copy_probe.txt; do

@@ -29,6 +29,9 @@ pmc2)
   steps+=("pmc_cassie_demo_pinned_tree|300|IKGPU_TREE_STATIC_ROWS=0 tools/pmc_session.sh cassie_demo_pinned r03_pmc_cassie_demo_pinned_tree")
   steps+=("pmc_cassie_demo_pinned_posture|300|tools/pmc_session.sh cassie_demo_pinned_posture r03_pmc_cassie_demo_pinned_posture")
   steps+=("pmc_cassie_demo_pik|300|tools/pmc_session.sh cassie_demo_pik r03_pmc_cassie_demo_pik") ;;
+pmc3)   # the default stop rule on config 4's batch: the lane-refill kernel against the lock-step kernel (IKGPU_REFILL=0)
+  steps+=("pmc_cassie_leg_refill|300|tools/pmc_session.sh cassie_leg r03_pmc_cassie_leg_refill --stop-rule --batch 262144")
+  steps+=("pmc_cassie_leg_lockstep|300|IKGPU_REFILL=0 tools/pmc_session.sh cassie_leg r03_pmc_cassie_leg_lockstep --stop-rule --batch 262144") ;;
 misc)
   steps+=("refill_chain|200|python3 tools/refill_timing.py > gpurun_out/r03_refill_timing_chain.txt 2>&1; grep -v amdgpu.ids gpurun_out/r03_refill_timing_chain.txt | tail -4")
   steps+=("refill_tree|200|python3 tools/refill_timing.py full_body x > gpurun_out/r03_refill_timing_tree.txt 2>&1; grep -v amdgpu.ids gpurun_out/r03_refill_timing_tree.txt | tail -4")
