@@ -349,7 +349,7 @@ IKD_FN double generic_evaluate(const TB &T, const WS &ws, const LaneRows &target
 // (per-lane pointer + element stride: the interpreter forms and ik::pik)
 template <class TB, class WS>
 IKD_FN double generic_evaluate(const TB &T, const WS &ws, const double *targets_lane, int64_t tstride) {
-    return generic_evaluate(T, ws, LaneRows{reinterpret_cast<const char *>(targets_lane), 0u, static_cast<uint32_t>(tstride * 8), false});
+    return generic_evaluate(T, ws, LaneRows{reinterpret_cast<const char *>(targets_lane), 0u, tstride * 8, false});
 }
 
 template <class TB, class WS>
@@ -799,7 +799,7 @@ IKD_FN void dls_generic_body_ws(const GenericKernelArgs &a, const TB &T, int64_t
     const int64_t g0 = group0 >= 0 ? group0 : b;
     const int64_t tcol = a.layout == LAYOUT_SOA ? 1 : static_cast<int64_t>(T.ntasks) * 12;   // doubles between consecutive problems
     const LaneRows tl{reinterpret_cast<const char *>(a.targets + g0 * tcol), static_cast<uint32_t>((b - g0) * tcol * 8),
-                      static_cast<uint32_t>(a.layout == LAYOUT_SOA ? a.B * 8 : 8), group0 >= 0};
+                      static_cast<int64_t>(a.layout == LAYOUT_SOA ? a.B * 8 : 8), group0 >= 0};
     int iters;
     bool success;
     generic_dls(T, a.prm, ws, tl, iters, success, any_active);
@@ -827,7 +827,7 @@ struct GenericRefill {
     template <class TB>
     __device__ __forceinline__ LaneRows target_rows(const TB &T, int64_t bb) const {
         return LaneRows{reinterpret_cast<const char *>(a->layout == LAYOUT_SOA ? a->targets + bb : a->targets + bb * T.ntasks * 12), 0u,
-                        static_cast<uint32_t>(a->layout == LAYOUT_SOA ? a->B * 8 : 8), false};
+                        static_cast<int64_t>(a->layout == LAYOUT_SOA ? a->B * 8 : 8), false};
     }
 
     template <class TB, class WS>

@@ -52,7 +52,7 @@ IKD_FN void dls_tree_body(const TreeKernelArgs<NJ, NCH> &a, const Desc &d, int64
     const int64_t g0 = group0 >= 0 ? group0 : b;
     const int64_t tcol = a.layout == LAYOUT_SOA ? 1 : static_cast<int64_t>(a.ntasks) * 12;   // doubles between consecutive problems
     const LaneRows tl{reinterpret_cast<const char *>(a.targets + g0 * tcol), static_cast<uint32_t>((b - g0) * tcol * 8),
-                      static_cast<uint32_t>(a.layout == LAYOUT_SOA ? a.B * 8 : 8), group0 >= 0};
+                      static_cast<int64_t>(a.layout == LAYOUT_SOA ? a.B * 8 : 8), group0 >= 0};
 
     int iters;
     bool success;
@@ -124,7 +124,7 @@ struct TreeRefill {
     }
     __device__ __forceinline__ LaneRows target_rows(int64_t bb) const {
         return LaneRows{reinterpret_cast<const char *>(a->layout == LAYOUT_SOA ? a->targets + bb : a->targets + bb * a->ntasks * 12), 0u,
-                        static_cast<uint32_t>(a->layout == LAYOUT_SOA ? a->B * 8 : 8), false};
+                        static_cast<int64_t>(a->layout == LAYOUT_SOA ? a->B * 8 : 8), false};
     }
 
     // done lanes store (q, success, iters) and take the next problem; returns the wave-uniform "some lane still holds a problem"

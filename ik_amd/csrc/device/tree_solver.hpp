@@ -252,10 +252,10 @@ struct LegFactor {
 struct LaneRows {
     const char *base;
     uint32_t off;
-    uint32_t stride_bytes;   // bytes between consecutive rows: B * 8 (the tree launchers refuse B >= 2^29) or 8
+    int64_t stride_bytes;    // bytes between consecutive rows: B * 8 or 8 (64 bits: 2^29 problems of a small task set fit the device)
     bool uniform;   // `base` is wave-uniform (a literal at every construction site: folds after inlining)
     IKD_FN double operator()(int r) const {
-        const char *row = base + static_cast<uint64_t>(static_cast<uint32_t>(r)) * stride_bytes;
+        const char *row = base + static_cast<int64_t>(r) * stride_bytes;
 #if IKD_ON_DEVICE
         // pin the row address in an SGPR pair: left to itself hipcc adds `off` to `base` first and is back to one 64-bit VGPR address
         // per row (the asm hides the pointer's provenance, so its address space is stated: a generic pointer would be a flat_load)
@@ -280,7 +280,7 @@ struct LaneRows {
         if (uniform) {
             typedef const char __attribute__((address_space(1))) *GlobalBytes;
             typedef const double __attribute__((address_space(1))) *GlobalDouble;
-            GlobalBytes g = (GlobalBytes)(base + static_cast<uint64_t>(static_cast<uint32_t>(r0)) * stride_bytes);
+            GlobalBytes g = (GlobalBytes)(base + static_cast<int64_t>(r0) * stride_bytes);
 #pragma unroll
             for (int k = 0; k < N; ++k) {
                 asm("" : "+s"(g));

@@ -473,8 +473,6 @@ namespace {
 template <int NJ, int NCH>
 hipError_t run_dls_tree(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const ikgpu_dls_params &prm,
                         hipStream_t stream, const double *pik_lambda1) {
-    if (io.B >= (int64_t{1} << 29)) return hipErrorInvalidValue;   // (LaneRows: a row stride of B * 8 bytes in 32 bits; 2^29 problems of
-                                                                   // >= 565 B each exceed the 288 GB of the device anyway)
     TreeKernelArgs<NJ, NCH> a = make_tree_args<NJ, NCH>(ph, dt);
     a.prm.max_iterations = prm.max_iterations;
     a.prm.lam2 = prm.damping * prm.damping;
