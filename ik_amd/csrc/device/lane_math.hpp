@@ -20,6 +20,8 @@ typedef unsigned char uint8_t;
 namespace std {
 template <class A, class B> struct is_same { static constexpr bool value = false; };
 template <class A> struct is_same<A, A> { static constexpr bool value = true; };
+template <bool C, class A, class B> struct conditional { typedef A type; };
+template <class A, class B> struct conditional<false, A, B> { typedef B type; };
 }  // namespace std
 #else
 #include <cmath>

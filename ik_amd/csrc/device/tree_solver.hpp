@@ -19,6 +19,7 @@
 // carry weight zero: zero rows change neither H nor J^T e.
 #pragma once
 #include "chain_solver.hpp"
+#include "chain_hot.hpp"   // ChainStruct: the placement-structure codes
 
 namespace ikdev {
 
@@ -297,6 +298,47 @@ struct LaneRows {
     }
 };
 
+// (R, p) <- (R, p) * placement i of a chain whose placement STRUCTURE is the compile-time code S (chain_hot.hpp ChainStruct: every
+// rotation entry exactly 0 / +1 / -1 or general, every translation component zero or not).  The same expressions as
+// se3_compose_const, with the structural terms written out -- a zero term is not formed, a +-1 factor is an add / subtract -- so no
+// compiler flag is needed for the folding and the result has the bits of the full product on finite data (fma(x, 1, t) = x + t;
+// fma(x, 0, t) = t).  Entries that are structural are never READ (the table sits in LDS: a Cassie leg reads 22 words instead of 96).
+// `i` is the index of an unrolled loop: S::ent / S::tnz fold to constants there.
+IKD_FN void struct_term(bool &has, double &v, double x, unsigned cls, double m) {
+    if (cls == kEntZero) return;
+    if (cls == kEntOne) v = has ? x + v : x;
+    else if (cls == kEntMinusOne) v = has ? v - x : -x;
+    else v = has ? dfma(x, m, v) : x * m;
+    has = true;
+}
+template <class S, class ConstPtr>
+IKD_FN void se3_compose_struct(double (&R)[9], double (&p)[3], ConstPtr c, int i) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const double a = R[3 * r], b = R[3 * r + 1], d = R[3 * r + 2];
+        double t = p[r];
+        if (S::tnz(i, 2)) t = dfma(d, c[11], t);
+        if (S::tnz(i, 1)) t = dfma(b, c[10], t);
+        if (S::tnz(i, 0)) t = dfma(a, c[9], t);
+        p[r] = t;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            bool has = false;
+            double v = 0.0;
+            struct_term(has, v, d, S::ent(i, 6 + k), S::ent(i, 6 + k) == kEntGeneral ? c[6 + k] : 0.0);
+            struct_term(has, v, b, S::ent(i, 3 + k), S::ent(i, 3 + k) == kEntGeneral ? c[3 + k] : 0.0);
+            struct_term(has, v, a, S::ent(i, k), S::ent(i, k) == kEntGeneral ? c[k] : 0.0);
+            R[3 * r + k] = v;
+        }
+    }
+}
+
+// The structure code the hot tree builds are compiled for (NJ = 7: a Cassie leg -- both legs share it, and it is the hot chain
+// kernel's code for the same leg, kernels_hot.hip); the launcher takes the hot build only for chains that carry it.
+constexpr uint64_t kTreeHotCode7[3] = {0x04f0208cce8c7664ull, 0x395959cacad65656ull, 0x000001cacace5656ull};
+template <int NJ> struct TreeHotStruct { typedef void type; };
+template <> struct TreeHotStruct<7> { typedef ChainStruct<kTreeHotCode7[0], kTreeHotCode7[1], kTreeHotCode7[2]> type; };
+
 // Posture rows on the joints of one chain (wave-uniform description; targets per lane).
 struct ChainPosture {
     bool on, prio0;
@@ -307,7 +349,7 @@ struct ChainPosture {
     int64_t t_stride;
 };
 
-template <int NJ, bool FAST = false, bool POST = false, bool PIK = false, class PlPtr, class FrPtr, class WPtr>
+template <int NJ, bool FAST = false, bool POST = false, bool PIK = false, class S = void, class PlPtr, class FrPtr, class WPtr>
 IKD_FN void leg_eval_factor(const double (&R1)[9], const double (&p1)[3], PlPtr pl, FrPtr frame_pl,
                             WPtr w6, int idmask, bool unit, const double (&q)[NJ], const double (&oMt)[12],
                             double lam2, bool prio0, const AlignRow &al, const ChainPosture &po, double (&Hbb)[21],
@@ -320,7 +362,8 @@ IKD_FN void leg_eval_factor(const double (&R1)[9], const double (&p1)[3], PlPtr 
     for (int k = 0; k < 3; ++k) p[k] = p1[k];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        se3_compose_const(R, p, pl[j], (idmask >> j) & 1);
+        if constexpr (std::is_same<S, void>::value) se3_compose_const(R, p, pl[j], (idmask >> j) & 1);
+        else se3_compose_struct<S>(R, p, pl[j], j);
         double s, c;
         if constexpr (FAST) dsincos_fast(q[j], s, c);
         else dsincos(q[j], s, c);
@@ -328,7 +371,8 @@ IKD_FN void leg_eval_factor(const double (&R1)[9], const double (&p1)[3], PlPtr 
         zax[j][0] = R[2]; zax[j][1] = R[5]; zax[j][2] = R[8];
         org[j][0] = p[0]; org[j][1] = p[1]; org[j][2] = p[2];
     }
-    se3_compose_const(R, p, frame_pl, (idmask >> NJ) & 1);
+    if constexpr (std::is_same<S, void>::value) se3_compose_const(R, p, frame_pl, (idmask >> NJ) & 1);
+    else se3_compose_struct<S>(R, p, frame_pl, NJ);
 
     IKD_SCHED_FENCE();
     TaskTerms t;
@@ -813,6 +857,8 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
                      const LaneRows &targets_in, const int (&tslot)[3], const PostureState &ps, int &iters_out,
                      bool &success_out, Park park, AnyFn any_active, R refill = R{}) {
     constexpr bool kGeneral = spec_is_general(SPEC);  // the demo's extras exist in the general builds only
+    // hot builds (every task Full with unit weights, the shape's placement mask): the chains' placement structure is compile-time too
+    typedef typename std::conditional<(SPEC > 0 && ((SPEC >> kSpecUnit) & 1) != 0), typename TreeHotStruct<NJ>::type, void>::type HotS;
     static_assert(!R::on || !(spec_has_posture(SPEC) || spec_has_pik(SPEC)), "lane refill: builds without per-lane state outside q");
     constexpr bool kPik = spec_has_pik(SPEC);  // the orthogonalisation behind PikRow costs the other builds registers
     constexpr bool kPost = spec_has_posture(SPEC);
@@ -910,7 +956,7 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
             }
             const ChainPosture po{kPost && prm.post_on != 0, prm.post_prio == 0, prm.postc_slot[c], prm.postc_w[c], prm.postc_m[c],
                                   targets, (ps.by_row && c == 0) ? ps.t_chain : nullptr, ps.stride};
-            leg_eval_factor<NJ, (SPEC >= 0), kPost, kPik>(R1, p1, ct.pl, ct.fr, ct.w, SPEC >= 0 ? (SPEC & ((2 << NJ) - 1)) : prm.idmask[c],
+            leg_eval_factor<NJ, (SPEC >= 0), kPost, kPik, HotS>(R1, p1, ct.pl, ct.fr, ct.w, SPEC >= 0 ? (SPEC & ((2 << NJ) - 1)) : prm.idmask[c],
                                 SPEC >= 0 ? ((SPEC >> kSpecUnit) & 1) != 0 : prm.unit[c] != 0, q, oMt, prm.lam2, prm.prio[c] == 0, al,
                                 po, Hbb, gb, e0sq, F, pr);
             if (NCH > 1 && c == 0 && (kConsAlways || ntask_chains > 1)) park.store(F);

@@ -470,6 +470,19 @@ bool launch_tree_refill(const ProblemHost &ph, const DeviceTables &dt, const Bat
                         ikdev::TreeKernelArgs<NJ, NCH> a, bool hot, hipError_t *err);
 namespace {
 
+template <int NJ>
+bool tree_hot_structure_matches(const ProblemHost &ph) {
+    if constexpr (std::is_same<typename ikdev::TreeHotStruct<NJ>::type, void>::value) return true;   // no structure folded for this NJ
+    else {
+        for (const ChainHost *c : {&ph.chain, &ph.chainB}) {
+            if (c->nj == 0) continue;
+            const ChainStructure s = chain_structure(*c);
+            if (!s.fits || s.code[0] != ikdev::kTreeHotCode7[0] || s.code[1] != ikdev::kTreeHotCode7[1] || s.code[2] != ikdev::kTreeHotCode7[2]) return false;
+        }
+        return true;
+    }
+}
+
 template <int NJ, int NCH>
 hipError_t run_dls_tree(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const ikgpu_dls_params &prm,
                         hipStream_t stream, const double *pik_lambda1) {
@@ -485,8 +498,10 @@ hipError_t run_dls_tree(const ProblemHost &ph, const DeviceTables &dt, const Bat
     // task sits at a pure translation from the base joint -- all folded at compile time; otherwise the general build
     constexpr int kMask = HotMask<NJ>::value;
     constexpr int kHot = kMask | (1 << ikdev::kSpecUnit) | (1 << ikdev::kSpecUnitP) | (1 << ikdev::kSpecIdP);
+    // (and, where the hot builds fold the chains' placement STRUCTURE -- ikdev::TreeHotStruct, NJ = 7 -- both chains carry that code)
     const bool hot = !ph.tree_extras() && kMask != 0 && (a.prm.idmask[0] & kMask) == kMask && (NCH == 1 || (a.prm.idmask[1] & kMask) == kMask) &&
-                     a.prm.unit[0] && (NCH == 1 || a.prm.unit[1]) && (!a.prm.hasP || (a.prm.unitP && (a.prm.idmaskP & 1)));
+                     a.prm.unit[0] && (NCH == 1 || a.prm.unit[1]) && (!a.prm.hasP || (a.prm.unitP && (a.prm.idmaskP & 1))) &&
+                     tree_hot_structure_matches<NJ>(ph);
     const dim3 grid(static_cast<unsigned>((io.B + kTreeBlock - 1) / kTreeBlock));
     // in between (as for the chain kernels): the placement mask folded, weights / task types / base-frame placement general
     // (A/B on one box, full body: pelvis task weighted 1.07 -> 0.91 ms, feet as Position tasks 0.98 -> 0.83 ms)
