@@ -333,11 +333,11 @@ IKD_FN void se3_compose_struct(double (&R)[9], double (&p)[3], ConstPtr c, int i
     }
 }
 
-// The structure code the hot tree builds are compiled for (NJ = 7: a Cassie leg -- both legs share it, and it is the hot chain
+// The structure code the mask-folded tree builds are compiled for (NJ = 7: a Cassie leg -- both legs share it, and it is the hot chain
 // kernel's code for the same leg, kernels_hot.hip); the launcher takes the hot build only for chains that carry it.
 constexpr uint64_t kTreeHotCode7[3] = {0x04f0208cce8c7664ull, 0x395959cacad65656ull, 0x000001cacace5656ull};
-template <int NJ> struct TreeHotStruct { typedef void type; };
-template <> struct TreeHotStruct<7> { typedef ChainStruct<kTreeHotCode7[0], kTreeHotCode7[1], kTreeHotCode7[2]> type; };
+template <int NJ> struct TreeHotStruct { typedef void type; static constexpr int mask = 0; };
+template <> struct TreeHotStruct<7> { typedef ChainStruct<kTreeHotCode7[0], kTreeHotCode7[1], kTreeHotCode7[2]> type; static constexpr int mask = 0xf8; };   // (mask: the code's identity-rotation placements, kernels.hip HotMask)
 
 // Posture rows on the joints of one chain (wave-uniform description; targets per lane).
 struct ChainPosture {
@@ -857,8 +857,10 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
                      const LaneRows &targets_in, const int (&tslot)[3], const PostureState &ps, int &iters_out,
                      bool &success_out, Park park, AnyFn any_active, R refill = R{}) {
     constexpr bool kGeneral = spec_is_general(SPEC);  // the demo's extras exist in the general builds only
-    // hot builds (every task Full with unit weights, the shape's placement mask): the chains' placement structure is compile-time too
-    typedef typename std::conditional<(SPEC > 0 && ((SPEC >> kSpecUnit) & 1) != 0), typename TreeHotStruct<NJ>::type, void>::type HotS;
+    // builds with the shape's placement mask folded (the hot builds and the general builds next to bit kSpecGen): the launcher takes
+    // them only for chains that carry the shape's whole placement-structure code, which is then compile-time too
+    typedef typename std::conditional<(SPEC > 0 && TreeHotStruct<NJ>::mask != 0 && (SPEC & ((2 << NJ) - 1)) == TreeHotStruct<NJ>::mask),
+                                      typename TreeHotStruct<NJ>::type, void>::type HotS;
     static_assert(!R::on || !(spec_has_posture(SPEC) || spec_has_pik(SPEC)), "lane refill: builds without per-lane state outside q");
     constexpr bool kPik = spec_has_pik(SPEC);  // the orthogonalisation behind PikRow costs the other builds registers
     constexpr bool kPost = spec_has_posture(SPEC);

@@ -505,10 +505,11 @@ hipError_t run_dls_tree(const ProblemHost &ph, const DeviceTables &dt, const Bat
     const dim3 grid(static_cast<unsigned>((io.B + kTreeBlock - 1) / kTreeBlock));
     // in between (as for the chain kernels): the placement mask folded, weights / task types / base-frame placement general
     // (A/B on one box, full body: pelvis task weighted 1.07 -> 0.91 ms, feet as Position tasks 0.98 -> 0.83 ms)
-    const bool mask_only = !hot && !ph.tree_extras() && kMask != 0 && (a.prm.idmask[0] & kMask) == kMask && (NCH == 1 || (a.prm.idmask[1] & kMask) == kMask);
+    const bool structure = tree_hot_structure_matches<NJ>(ph);
+    const bool mask_only = !hot && !ph.tree_extras() && structure && kMask != 0 && (a.prm.idmask[0] & kMask) == kMask && (NCH == 1 || (a.prm.idmask[1] & kMask) == kMask);
     // the general builds (extras: base reference, alignment row, fixed base, posture rows, the constraint, level 1 of ik::pik) exist
     // twice where the shape's mask is known: with it folded (bit kSpecGen next to the mask) and without
-    const bool fold = kMask != 0 && (a.prm.idmask[0] & kMask) == kMask && (NCH == 1 || (a.prm.idmask[1] & kMask) == kMask);
+    const bool fold = structure && kMask != 0 && (a.prm.idmask[0] & kMask) == kMask && (NCH == 1 || (a.prm.idmask[1] & kMask) == kMask);
     const size_t post_lds = NCH == 1 ? sizeof(double) * kTreeBlock * static_cast<size_t>(2 * std::max(1, a.prm.post_n) + NJ) : 0;
 #define IKGPU_TREE_GENERAL(FLAGS, LDS)                                                                                              \
     do {                                                                                                                            \
