@@ -672,7 +672,7 @@ IKD_FN void freeflyer_integrate(const double (&qb)[7], const double (&R1)[9], co
 // block-diagonal mix of them) and orthogonalised by Gram-Schmidt with every projection applied twice.  A row whose remainder
 // falls below Eigen's rank threshold (epsilon x rows x the largest row norm, as the complete orthogonal decomposition behind
 // the reference's pseudo-inverse) is dropped, per lane, by a select.
-template <int NJ, bool FAST, class PlPtr, class FrPtr>
+template <int NJ, bool FAST, class S = void, class PlPtr, class FrPtr>
 IKD_FN void constraint_project(const double (&R1)[9], const double (&p1)[3], PlPtr pl, FrPtr frame_pl, int idmask,
                                const double (&q)[NJ], int type, double (&dqb)[6], double (&dql)[NJ]) {
     constexpr int W = 6 + NJ;
@@ -684,7 +684,8 @@ IKD_FN void constraint_project(const double (&R1)[9], const double (&p1)[3], PlP
     for (int k = 0; k < 3; ++k) p[k] = p1[k];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        se3_compose_const(R, p, pl[j], (idmask >> j) & 1);
+        if constexpr (std::is_same<S, void>::value) se3_compose_const(R, p, pl[j], (idmask >> j) & 1);
+        else se3_compose_struct<S>(R, p, pl[j], j);
         double s, c;
         if constexpr (FAST) dsincos_fast(q[j], s, c);
         else dsincos(q[j], s, c);
@@ -692,7 +693,8 @@ IKD_FN void constraint_project(const double (&R1)[9], const double (&p1)[3], PlP
         zax[j][0] = R[2]; zax[j][1] = R[5]; zax[j][2] = R[8];
         org[j][0] = p[0]; org[j][1] = p[1]; org[j][2] = p[2];
     }
-    se3_compose_const(R, p, frame_pl, (idmask >> NJ) & 1);
+    if constexpr (std::is_same<S, void>::value) se3_compose_const(R, p, frame_pl, (idmask >> NJ) & 1);
+    else se3_compose_struct<S>(R, p, frame_pl, NJ);
     // world rows about the frame origin: rows 0..2 linear velocity, 3..5 angular velocity; columns: base linear 0..2 (body
     // axes R1 e_c), base angular 3..5, chain joints 6..
     double V[6][W];
@@ -1063,7 +1065,7 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
                 }
             }
             const auto &cc = d.chain[NCH - 1];
-            constraint_project<NJ, (SPEC >= 0)>(R1, p1, cc.pl, cc.fr, prm.idmask[NCH - 1], qj1, prm.cons_type, dqb, dq1);
+            constraint_project<NJ, (SPEC >= 0), HotS>(R1, p1, cc.pl, cc.fr, prm.idmask[NCH - 1], qj1, prm.cons_type, dqb, dq1);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const double qc = dmin(cc.hi[j], dmax(dfma(prm.step_length, dq1[j], qj1[j]), cc.lo[j]));
