@@ -26,6 +26,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <fstream>
+#include <map>
 #include <memory>
 #include <sstream>
 #include <stdexcept>
@@ -446,104 +447,98 @@ class PostureTask : public DeviceTask {
 class InverseKinematicsProblem {
    public:
     InverseKinematicsProblem(const model_t &model, const std::size_t &max_priority_level = 0)
-        : model_(model), max_priority_level_(max_priority_level), tasks_(max_priority_level + 1) {}
+        : model_(model), top_level_(max_priority_level), by_level_(max_priority_level + 1) {}
 
-    const std::size_t &max_priority_level() const { return max_priority_level_; }
-    std::size_t e_size(const std::size_t &priority) const {
-        std::size_t sz = 0;
-        for (const auto &task : get_all_tasks(priority)) sz += task->dimension();
-        return sz;
+    const std::size_t &max_priority_level() const { return top_level_; }
+    std::size_t e_size(const std::size_t &priority) const {  // rows of one priority level (problem.hpp:38-45)
+        std::size_t rows = 0;
+        for (const auto &t : get_all_tasks(priority)) rows += t->dimension();
+        return rows;
     }
-    std::size_t c_size() const {  // problem.hpp:47-53
-        std::size_t sz = 0;
-        for (const auto &c : frame_constraints_) sz += c->dimension();
-        return sz;
+    std::size_t c_size() const {  // rows of all hard constraints (problem.hpp:47-53)
+        std::size_t rows = 0;
+        for (const auto &c : constraints_) rows += c->dimension();
+        return rows;
     }
+
+    // The reference keeps one vector + one name map per task class (problem.hpp:183-206).  Here ONE registry holds every named
+    // object: (kind, name) -> the object, first registration of a name wins (as unordered_map::insert does there); the per-level
+    // lists the solvers walk are kept beside it in insertion order.
     std::shared_ptr<FrameConstraint> add_frame_constraint(const string_t &name, const std::shared_ptr<FrameConstraint> &constraint) {
-        frame_constraints_map_.insert({name, frame_constraints_.size()});  // problem.hpp:68-77
-        frame_constraints_.push_back(constraint);
+        remember(kConstraint, name, constraint);  // problem.hpp:68-77
+        constraints_.push_back(constraint);
         ++generation_;
-        return frame_constraints_.back();
+        return constraint;
     }
-    std::shared_ptr<FrameConstraint> get_frame_constraint(const string_t &name) {
-        auto it = frame_constraints_map_.find(name);
-        if (it == frame_constraints_map_.end()) throw std::out_of_range("Frame constraint does not exist: " + name);
-        return frame_constraints_.at(it->second);
-    }
+    std::shared_ptr<FrameConstraint> get_frame_constraint(const string_t &name) { return lookup<FrameConstraint>(kConstraint, name, "Frame constraint"); }
     std::vector<std::shared_ptr<Constraint>> get_all_constraints() const {  // problem.hpp:167-173
-        return std::vector<std::shared_ptr<Constraint>>(frame_constraints_.begin(), frame_constraints_.end());
+        return std::vector<std::shared_ptr<Constraint>>(constraints_.begin(), constraints_.end());
     }
 
-    std::shared_ptr<FrameTask> add_frame_task(const string_t &name, const std::shared_ptr<FrameTask> &task,
-                                              const std::size_t &priority = 0) {
-        if (priority > max_priority_level_) throw std::out_of_range("Maximum priority level exceeded!");
-        frame_tasks_map_.insert({name, frame_tasks_.size()});
-        frame_tasks_.push_back(task);
-        tasks_[priority].push_back(task);
-        ++generation_;
-        return frame_tasks_.back();
+    std::shared_ptr<FrameTask> add_frame_task(const string_t &name, const std::shared_ptr<FrameTask> &task, const std::size_t &priority = 0) {
+        return enlist(kFrame, name, task, priority);  // problem.hpp:55-66
     }
-    std::shared_ptr<FrameTask> get_frame_task(const string_t &name) { return frame_tasks_.at(get_frame_task_index(name)); }
-    std::size_t get_frame_task_index(const string_t &name) {
-        auto it = frame_tasks_map_.find(name);
-        if (it == frame_tasks_map_.end()) throw std::out_of_range("Frame task does not exist: " + name);
-        return it->second;
+    std::shared_ptr<FrameTask> get_frame_task(const string_t &name) { return lookup<FrameTask>(kFrame, name, "Frame task"); }
+    std::size_t get_frame_task_index(const string_t &name) {  // position among the frame tasks, in registration order
+        const auto it = registry_.find({kFrame, name});
+        if (it == registry_.end()) throw std::out_of_range("Frame task does not exist: " + name);
+        return it->second.ordinal;
     }
     std::shared_ptr<AlignAxisTask> add_align_axis_task(const string_t &name, const std::shared_ptr<AlignAxisTask> &task,
                                                        const std::size_t &priority = 0) {  // problem.hpp:94-105
-        if (priority > max_priority_level_) throw std::out_of_range("Maximum priority level exceeded!");
-        axis_tasks_map_.insert({name, axis_tasks_.size()});
-        axis_tasks_.push_back(task);
-        tasks_[priority].push_back(task);
-        ++generation_;
-        return axis_tasks_.back();
+        return enlist(kAlign, name, task, priority);
     }
-    std::shared_ptr<AlignAxisTask> get_align_axis_task(const string_t &name) {
-        auto it = axis_tasks_map_.find(name);  // (the reference looks the name up in the frame-task map: problem.hpp:109)
-        if (it == axis_tasks_map_.end()) throw std::out_of_range("Align-axis task does not exist: " + name);
-        return axis_tasks_.at(it->second);
-    }
+    // (the reference looks the name up among the FRAME tasks, problem.hpp:109; here the align-axis tasks have their own names)
+    std::shared_ptr<AlignAxisTask> get_align_axis_task(const string_t &name) { return lookup<AlignAxisTask>(kAlign, name, "Align-axis task"); }
     std::shared_ptr<PostureTask> add_posture_task(const string_t &name, const std::shared_ptr<PostureTask> &task,
                                                   const std::size_t &priority = 0) {  // problem.hpp:134-145
-        if (priority > max_priority_level_) throw std::out_of_range("Maximum priority level exceeded!");
-        posture_tasks_map_.insert({name, posture_tasks_.size()});
-        posture_tasks_.push_back(task);
-        tasks_[priority].push_back(task);
-        ++generation_;
-        return posture_tasks_.back();
+        return enlist(kPosture, name, task, priority);
     }
-    std::shared_ptr<PostureTask> get_posture_task(const string_t &name) {  // problem.hpp:147-149
-        auto it = posture_tasks_map_.find(name);
-        if (it == posture_tasks_map_.end()) throw std::out_of_range("Posture task does not exist: " + name);
-        return posture_tasks_.at(it->second);
-    }
+    std::shared_ptr<PostureTask> get_posture_task(const string_t &name) { return lookup<PostureTask>(kPosture, name, "Posture task"); }  // problem.hpp:147-149
     std::shared_ptr<CentreOfMassTask> add_centre_of_mass_task(const std::shared_ptr<CentreOfMassTask> &task,
                                                               const std::size_t &priority = 0) {  // problem.hpp:121-128
-        if (priority > max_priority_level_) throw std::out_of_range("Maximum priority level exceeded!");
-        if (com_task_) throw std::logic_error("a problem holds one centre-of-mass task");
-        com_task_ = task;
-        tasks_[priority].push_back(task);
-        ++generation_;
-        return com_task_;
+        if (registry_.count({kCom, string_t()})) throw std::logic_error("a problem holds one centre-of-mass task");
+        return enlist(kCom, string_t(), task, priority);
     }
-    std::shared_ptr<CentreOfMassTask> get_centre_of_mass_task() { return com_task_; }  // problem.hpp:130-132
-    const std::vector<std::shared_ptr<DeviceTask>> &get_all_tasks(const std::size_t &priority) const { return tasks_.at(priority); }
+    std::shared_ptr<CentreOfMassTask> get_centre_of_mass_task() {  // problem.hpp:130-132 (null when none was added)
+        const auto it = registry_.find({kCom, string_t()});
+        return it == registry_.end() ? nullptr : std::static_pointer_cast<CentreOfMassTask>(it->second.object);
+    }
+    const std::vector<std::shared_ptr<DeviceTask>> &get_all_tasks(const std::size_t &priority) const { return by_level_.at(priority); }
     const model_t &model() const { return model_; }
     std::size_t generation() const { return generation_; }
 
    private:
+    enum Kind { kFrame, kAlign, kPosture, kCom, kConstraint };
+    struct Entry {
+        std::shared_ptr<void> object;
+        std::size_t ordinal;  // how many objects of this kind were registered before it
+    };
+    void remember(Kind kind, const string_t &name, std::shared_ptr<void> object) {
+        registry_.insert({{kind, name}, Entry{std::move(object), count_[kind]}});
+        ++count_[kind];
+    }
+    template <class T>
+    std::shared_ptr<T> enlist(Kind kind, const string_t &name, const std::shared_ptr<T> &task, std::size_t priority) {
+        if (priority > top_level_) throw std::out_of_range("Maximum priority level exceeded!");
+        remember(kind, name, task);
+        by_level_[priority].push_back(task);
+        ++generation_;
+        return task;
+    }
+    template <class T>
+    std::shared_ptr<T> lookup(Kind kind, const string_t &name, const char *what) const {
+        const auto it = registry_.find({kind, name});
+        if (it == registry_.end()) throw std::out_of_range(string_t(what) + " does not exist: " + name);
+        return std::static_pointer_cast<T>(it->second.object);
+    }
+
     model_t model_;  // a copy, as the reference keeps (problem.hpp:183); the handle inside is shared
-    std::size_t max_priority_level_;
-    std::vector<std::vector<std::shared_ptr<DeviceTask>>> tasks_;
-    std::vector<std::shared_ptr<FrameTask>> frame_tasks_;
-    std::unordered_map<string_t, std::size_t> frame_tasks_map_;
-    std::vector<std::shared_ptr<AlignAxisTask>> axis_tasks_;
-    std::unordered_map<string_t, std::size_t> axis_tasks_map_;
-    std::vector<std::shared_ptr<PostureTask>> posture_tasks_;
-    std::unordered_map<string_t, std::size_t> posture_tasks_map_;
-    std::vector<std::shared_ptr<FrameConstraint>> frame_constraints_;
-    std::unordered_map<string_t, std::size_t> frame_constraints_map_;
-    std::shared_ptr<CentreOfMassTask> com_task_;
+    std::size_t top_level_;
+    std::vector<std::vector<std::shared_ptr<DeviceTask>>> by_level_;
+    std::vector<std::shared_ptr<FrameConstraint>> constraints_;
+    std::map<std::pair<int, string_t>, Entry> registry_;
+    std::size_t count_[5] = {0, 0, 0, 0, 0};
     std::size_t generation_ = 0;
 };
 

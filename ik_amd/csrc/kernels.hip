@@ -467,7 +467,7 @@ TreeKernelArgs<NJ, NCH> make_tree_args(const ProblemHost &ph, const DeviceTables
 // kernels_tree_refill.hip
 template <int NJ, int NCH>
 bool launch_tree_refill(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const ikgpu_dls_params &prm, hipStream_t stream,
-                        ikdev::TreeKernelArgs<NJ, NCH> a, bool hot, hipError_t *err);
+                        ikdev::TreeKernelArgs<NJ, NCH> a, int build, hipError_t *err);
 namespace {
 
 template <int NJ>
@@ -517,10 +517,12 @@ hipError_t run_dls_tree(const ProblemHost &ph, const DeviceTables &dt, const Bat
                                      dim3(kTreeBlock), LDS, stream, a);                                                             \
         else hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, (FLAGS)>), grid, dim3(kTreeBlock), LDS, stream, a);                       \
     } while (0)
-    // stop-rule mode on a batch larger than the machine: lane refill (kernels_tree_refill.hip) for the builds that have it
-    if ((hot || (!mask_only && !pik_lambda1 && !ph.cons_on && !ph.has_posture && !fold)) && prm.stop_sq_tol >= 0.0 && prm.max_iterations >= 1) {
+    // stop-rule mode on a batch larger than the machine: lane refill (kernels_tree_refill.hip) for the builds that have it -- every
+    // build without per-lane state outside q (no posture rows, no constraint, no ik::pik level)
+    if (!pik_lambda1 && !ph.cons_on && !ph.has_posture && prm.stop_sq_tol >= 0.0 && prm.max_iterations >= 1) {
         hipError_t re = hipSuccess;
-        if (launch_tree_refill<NJ, NCH>(ph, dt, io, prm, stream, a, hot, &re)) return re;
+        const int build = hot ? kTreeBuildHot : mask_only ? kTreeBuildMask : fold ? kTreeBuildFold : kTreeBuildGeneral;
+        if (launch_tree_refill<NJ, NCH>(ph, dt, io, prm, stream, a, build, &re)) return re;
     }
     if (hot && !(prm.stop_sq_tol >= 0.0) && !std::getenv("IKGPU_TREE_NEVER_OFF"))   // the never-stop visitor: its own instantiation, as the hot chain kernel's
         hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, (kHot | (1 << ikdev::kSpecNever))>), grid, dim3(kTreeBlock), 0, stream, a);

@@ -81,6 +81,8 @@ std::string chain_kernel_name(const ProblemHost &ph);
 // is larger than the lanes the device keeps resident; IKGPU_REFILL=0 never, =1 whenever the mode allows.  `resident_waves`: what
 // hipOccupancyMaxActiveBlocksPerMultiprocessor reports for the refill kernel x the device's CUs (IKGPU_REFILL_WAVES_PER_CU overrides).
 bool refill_wanted(const ikgpu_dls_params &prm, int64_t B, int64_t resident_waves);
+// the lock-step builds of the tree kernel a refill launch can mirror (kernels.hip run_dls_tree / kernels_tree_refill.hip)
+enum { kTreeBuildGeneral = 0, kTreeBuildHot = 1, kTreeBuildMask = 2, kTreeBuildFold = 3 };
 int64_t refill_grid(const void *kernel, int64_t B);
 int64_t refill_resident(int64_t occupancy_waves, int64_t B);   // persistent waves of a refill launch given what the device can hold
 int refill_chunk(int64_t B, int64_t grid);   // problems a wave reserves per pull from the head (IKGPU_REFILL_CHUNK overrides)

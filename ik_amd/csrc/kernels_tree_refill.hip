@@ -72,18 +72,24 @@ template <> struct HotMask<7> { static constexpr int value = 0xf8; };
 
 // Lane-refill launch of a tree problem when the mode and the batch ask for it (kernels.hpp refill_wanted); returns false when this
 // problem's build has no refill instantiation (posture rows, ik::pik levels, constraints, shapes other than Cassie's) -- the caller
-// then launches the lock-step kernel.  `a` is the fully prepared argument block of the lock-step launch.
+// then launches the lock-step kernel.  `a` is the fully prepared argument block of the lock-step launch; `build` names the lock-step
+// build the problem runs on (kernels.hip run_dls_tree), whose lane program the refill kernel must share to return the same bits:
+// kTreeBuildHot (mask, unit weights, base task at a translation: all folded), kTreeBuildMask (the placement mask folded only),
+// kTreeBuildFold (the mask next to the general extras: base-relative references, alignment row, fixed base), kTreeBuildGeneral.
 template <int NJ, int NCH>
 bool launch_tree_refill(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const ikgpu_dls_params &prm, hipStream_t stream,
-                        ikdev::TreeKernelArgs<NJ, NCH> a, bool hot, hipError_t *err) {
+                        ikdev::TreeKernelArgs<NJ, NCH> a, int build, hipError_t *err) {
     if constexpr (NJ != 7) {
         return false;
     } else {
         constexpr int kMask = HotMask<NJ>::value;
         constexpr int kHot = kMask | (1 << ikdev::kSpecUnit) | (1 << ikdev::kSpecUnitP) | (1 << ikdev::kSpecIdP);
-        if (ph.tree_extras() && (ph.has_posture || ph.cons_on)) return false;
-        const void *kern = hot ? reinterpret_cast<const void *>(dls_tree_refill_kernel<NJ, NCH, kHot>)
-                               : reinterpret_cast<const void *>(dls_tree_refill_kernel<NJ, NCH, 0>);
+        constexpr int kFold = kMask | (1 << ikdev::kSpecGen);
+        if (ph.has_posture || ph.cons_on) return false;
+        const void *kern = build == kTreeBuildHot    ? reinterpret_cast<const void *>(dls_tree_refill_kernel<NJ, NCH, kHot>)
+                           : build == kTreeBuildMask ? reinterpret_cast<const void *>(dls_tree_refill_kernel<NJ, NCH, kMask>)
+                           : build == kTreeBuildFold ? reinterpret_cast<const void *>(dls_tree_refill_kernel<NJ, NCH, kFold>)
+                                                     : reinterpret_cast<const void *>(dls_tree_refill_kernel<NJ, NCH, 0>);
         // persistent workgroups of two waves: what the device holds, one wave per SIMD until every lane has >= 8 problems (kernels.hip refill_resident)
         const int64_t occ_waves = persistent_grid(kern, kTreeBlock, 0, INT64_MAX) * kTreeWaves;
         int64_t waves = refill_resident(occ_waves, io.B);
@@ -99,7 +105,9 @@ bool launch_tree_refill(const ProblemHost &ph, const DeviceTables &dt, const Bat
         }
         const dim3 grid(static_cast<unsigned>(waves / kTreeWaves));
         const int chunk = refill_chunk(io.B, waves);
-        if (hot) hipLaunchKernelGGL((dls_tree_refill_kernel<NJ, NCH, kHot>), grid, dim3(kTreeBlock), 0, stream, a, queue, chunk);
+        if (build == kTreeBuildHot) hipLaunchKernelGGL((dls_tree_refill_kernel<NJ, NCH, kHot>), grid, dim3(kTreeBlock), 0, stream, a, queue, chunk);
+        else if (build == kTreeBuildMask) hipLaunchKernelGGL((dls_tree_refill_kernel<NJ, NCH, kMask>), grid, dim3(kTreeBlock), 0, stream, a, queue, chunk);
+        else if (build == kTreeBuildFold) hipLaunchKernelGGL((dls_tree_refill_kernel<NJ, NCH, kFold>), grid, dim3(kTreeBlock), 0, stream, a, queue, chunk);
         else hipLaunchKernelGGL((dls_tree_refill_kernel<NJ, NCH, 0>), grid, dim3(kTreeBlock), 0, stream, a, queue, chunk);
         e = hipGetLastError();
         if (e == hipSuccess) e = launch_chain_pass_through(ph, dt, io, a.iters, stream);
@@ -112,9 +120,9 @@ bool launch_tree_refill(const ProblemHost &ph, const DeviceTables &dt, const Bat
     }
 }
 
-template bool launch_tree_refill<7, 2>(const ProblemHost &, const DeviceTables &, const BatchIO &, const ikgpu_dls_params &, hipStream_t, ikdev::TreeKernelArgs<7, 2>, bool, hipError_t *);
-template bool launch_tree_refill<7, 1>(const ProblemHost &, const DeviceTables &, const BatchIO &, const ikgpu_dls_params &, hipStream_t, ikdev::TreeKernelArgs<7, 1>, bool, hipError_t *);
-template bool launch_tree_refill<6, 2>(const ProblemHost &, const DeviceTables &, const BatchIO &, const ikgpu_dls_params &, hipStream_t, ikdev::TreeKernelArgs<6, 2>, bool, hipError_t *);
-template bool launch_tree_refill<6, 1>(const ProblemHost &, const DeviceTables &, const BatchIO &, const ikgpu_dls_params &, hipStream_t, ikdev::TreeKernelArgs<6, 1>, bool, hipError_t *);
+template bool launch_tree_refill<7, 2>(const ProblemHost &, const DeviceTables &, const BatchIO &, const ikgpu_dls_params &, hipStream_t, ikdev::TreeKernelArgs<7, 2>, int, hipError_t *);
+template bool launch_tree_refill<7, 1>(const ProblemHost &, const DeviceTables &, const BatchIO &, const ikgpu_dls_params &, hipStream_t, ikdev::TreeKernelArgs<7, 1>, int, hipError_t *);
+template bool launch_tree_refill<6, 2>(const ProblemHost &, const DeviceTables &, const BatchIO &, const ikgpu_dls_params &, hipStream_t, ikdev::TreeKernelArgs<6, 2>, int, hipError_t *);
+template bool launch_tree_refill<6, 1>(const ProblemHost &, const DeviceTables &, const BatchIO &, const ikgpu_dls_params &, hipStream_t, ikdev::TreeKernelArgs<6, 1>, int, hipError_t *);
 
 }  // namespace ikgpu

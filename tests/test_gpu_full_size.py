@@ -39,6 +39,8 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-6           # rad, north_star
 B = 65536
 ITERS = 50
+SEEDS = [0, 1, 2]    # seed 0 primary, 1 and 2 for repeats.  Every threshold below was set on seed 0 in round 3 and is
+                     # FROZEN: seeds 1 and 2 run against the same constants (counts of all three in profiles/r04_parity_counts.json)
 
 
 @pytest.fixture(scope="module")
@@ -145,7 +147,7 @@ CHAIN_CASES = [
 BUILDS = ["default", "general"]   # default: hot for the fixture robots, hot-rtc for arm7 (general when hipRTC is absent)
 
 
-def _chain_case(torch, name, frame, narrow, mode, build="default"):
+def _chain_case(torch, name, frame, narrow, mode, build="default", seed=0):
     import ik_amd
     import oracle as O
     from ik_amd import workload
@@ -170,22 +172,17 @@ def _chain_case(torch, name, frame, narrow, mode, build="default"):
     want = ",general>" if build == "general" else (",hot-rtc>", ",general>") if name == "arm7" else ",hot>"
     assert data.kernel.endswith(want), (data.kernel, build)
     nominal = workload.UR5_NOMINAL if name.startswith("ur") else np.zeros(model.nq) if name == "arm7" else workload.cassie_nominal(model.names)
-    q0, qs = workload.chain_workload(model.lowerPositionLimit, model.upperPositionLimit, nominal, np.arange(B), 0, mode)
+    q0, qs = workload.chain_workload(model.lowerPositionLimit, model.upperPositionLimit, nominal, np.arange(B), seed, mode)
     T = ik_amd.task_frames_fk_batch(problem, torch.from_numpy(np.ascontiguousarray(qs.T)).cuda(), data)
     tasks = O.make_tasks([(model.getFrameId(frame), 0, 2, 0, None)])
     return xml, model, problem, data, q0, T, tasks
 
 
-@pytest.mark.parametrize("build", BUILDS)
-@pytest.mark.parametrize("name,frame,narrow,mode", [c[:4] for c in CHAIN_CASES])
-def test_step_synchronised_along_the_oracle_trajectory(torch_cuda, name, frame, narrow, mode, build):
-    """All 65536 lanes, all 50 steps, no exclusions: from the oracle's k-th iterate the device's next iterate equals the
-    oracle's to 1e-9 rad (one DLS step: evaluate, solve, integrate, project onto the limits -- reference ik/ik/dls.cpp:14-71).
-    Every tenth step, on the first 8192 lanes: the device's and the double oracle's one-step errors against the _Float128 oracle."""
-    torch = torch_cuda
+def _step_synchronised(torch, model, problem, data, tasks, q0, T, steps, step_bar, label):
+    """From the oracle's k-th iterate the device's next iterate, all lanes, no exclusions; every tenth step (first 8192 lanes) the
+    one-step errors of device and double oracle against the _Float128 oracle, as distributions."""
     import ik_amd
     import oracle as O
-    xml, model, problem, data, q0, T, tasks = _chain_case(torch, name, frame, narrow, mode, build)
     om = O.OracleModel(model.flat())
     tg = T.permute(2, 0, 1).contiguous().cpu().numpy()
     one = O.params(1, 1e-2, 1.0, -1.0)
@@ -195,43 +192,56 @@ def test_step_synchronised_along_the_oracle_trajectory(torch_cuda, name, frame, 
     out = None
     NX = 8192
     worst_ratio = 0.0
-    # far targets drive the made-up arm through near-singular poses (damping 1e-2: condition ~1e4-1e5 on the rounding of J): one step
-    # of either side is good to ~1e-9 there, so that case gets 1e-8; the distribution check against _Float128 below is the sharp one
-    step_bar = 1e-8 if (name, mode) == ("arm7", "uniform") else 1e-9
-    for k in range(ITERS):
+    for k in range(steps):
         q_next, _, _ = O.dls_batch(om, tasks, tg, q, one, cores)
         out = ik_amd.dls_batch(problem, torch.from_numpy(np.ascontiguousarray(q.T)).cuda(), T, data, ik_amd.never_stop_visitor(), p1, out=out)
         q_dev = out[0].cpu().numpy().T
         d = np.abs(q_dev - q_next).max()
         worst = max(worst, d)
-        assert d <= step_bar, (name, mode, narrow, build, k, d)
+        assert d <= step_bar, (label, k, d)
         if k % 10 == 0:
             q_x, _, _ = O.dls_batch(om, tasks, tg[:NX], q[:NX], one, cores, ext="q")
             e_dev, e_orc = np.abs(q_dev[:NX] - q_x).max(axis=1), np.abs(q_next[:NX] - q_x).max(axis=1)
             for pct, factor in ((50, 2.0), (99, 2.0), (100, 5.0)):     # (the maximum of 8192 draws is a noisy statistic)
                 a, b = np.percentile(e_dev, pct), np.percentile(e_orc, pct)
                 worst_ratio = max(worst_ratio, a / (b + 1e-15))
-                assert a <= factor * b + 1e-15, (name, mode, narrow, build, k, pct, a, b)
+                assert a <= factor * b + 1e-15, (label, k, pct, a, b)
         q = q_next
-    print("%s %s narrow=%s [%s]: worst one-step |dq| over %d steps x %d lanes: %.3e rad; one-step error vs _Float128, device / oracle, worst "
-          "percentile ratio %.2f" % (name, mode, narrow, data.kernel, ITERS, B, worst, worst_ratio))
+    print("%s [%s]: worst one-step |dq| over %d steps x %d lanes: %.3e rad; one-step error vs _Float128, device / oracle, worst "
+          "percentile ratio %.2f" % (label, data.kernel, steps, q0.shape[0], worst, worst_ratio))
+    _record("step-synchronised " + label, {"kernel": data.kernel, "steps": steps, "lanes": int(q0.shape[0]), "worst_one_step_abs_dq_rad": float(worst),
+                                           "bar_rad": step_bar, "worst_percentile_ratio_vs_float128": float(worst_ratio)})
 
 
+@pytest.mark.parametrize("seed", SEEDS)
+@pytest.mark.parametrize("build", BUILDS)
+@pytest.mark.parametrize("name,frame,narrow,mode", [c[:4] for c in CHAIN_CASES])
+def test_step_synchronised_along_the_oracle_trajectory(torch_cuda, name, frame, narrow, mode, build, seed):
+    """All 65536 lanes, all 50 steps, no exclusions: from the oracle's k-th iterate the device's next iterate equals the
+    oracle's to 1e-9 rad (one DLS step: evaluate, solve, integrate, project onto the limits -- reference ik/ik/dls.cpp:14-71).
+    Every tenth step, on the first 8192 lanes: the device's and the double oracle's one-step errors against the _Float128 oracle."""
+    torch = torch_cuda
+    xml, model, problem, data, q0, T, tasks = _chain_case(torch, name, frame, narrow, mode, build, seed)
+    # far targets drive the made-up arm through near-singular poses (damping 1e-2: condition ~1e4-1e5 on the rounding of J): one step
+    # of either side is good to ~1e-9 there, so that case gets 1e-8; the distribution check against _Float128 is the sharp one
+    step_bar = 1e-8 if (name, mode) == ("arm7", "uniform") else 1e-9
+    _step_synchronised(torch, model, problem, data, tasks, q0, T, ITERS, step_bar, "%s %s narrow=%s %s [%s] seed %d" % (name, frame, narrow, mode, build, seed))
+
+
+@pytest.mark.parametrize("seed", SEEDS)
 @pytest.mark.parametrize("build", BUILDS)
 @pytest.mark.parametrize("name,frame,narrow,mode,max_excluded,statistical", CHAIN_CASES)
-def test_chain_configs_lane_by_lane(torch_cuda, name, frame, narrow, mode, max_excluded, statistical, build):
+def test_chain_configs_lane_by_lane(torch_cuda, name, frame, narrow, mode, max_excluded, statistical, build, seed):
     torch = torch_cuda
-    xml, model, problem, data, q0, T, tasks = _chain_case(torch, name, frame, narrow, mode, build)
-    q = _compare(torch, model, problem, data, tasks, q0, T, max_excluded, "%s %s narrow=%s %s [%s]" % (name, frame, narrow, mode, build), statistical)
+    xml, model, problem, data, q0, T, tasks = _chain_case(torch, name, frame, narrow, mode, build, seed)
+    q = _compare(torch, model, problem, data, tasks, q0, T, max_excluded, "%s %s narrow=%s %s [%s] seed %d" % (name, frame, narrow, mode, build, seed), statistical)
     lo, hi = model.lowerPositionLimit, model.upperPositionLimit
     assert (q >= lo - 1e-15).all() and (q <= hi + 1e-15).all()
     if narrow:
         assert (np.abs(np.abs(q) - narrow) < 1e-15).any()          # the projection does bind
 
 
-def test_full_body_lane_by_lane(torch_cuda):
-    """Config 3: Cassie full body (free-flyer, nq = 23), SE(3) tasks on both feet and the pelvis."""
-    torch = torch_cuda
+def _full_body(torch, mode, seed):
     import ik_amd
     import oracle as O
     from ik_amd import workload
@@ -241,12 +251,42 @@ def test_full_body_lane_by_lane(torch_cuda):
     for i, f in enumerate(frames):
         problem.add_frame_task("t%d" % i, ik_amd.FrameTask.create(model, f, ik_amd.KinematicType.Full))
     data = ik_amd.dls_data(problem, device=0)
+    assert data.kernel == "dls_tree<NJ=7,chains=2,base_task>"
     q0, qs = workload.freeflyer_workload(model.lowerPositionLimit, model.upperPositionLimit, workload.cassie_nominal(model.names),
-                                         np.arange(B), seed=0, mode="near")
+                                         np.arange(B), seed=seed, mode=mode)
     T = ik_amd.task_frames_fk_batch(problem, torch.from_numpy(np.ascontiguousarray(qs.T)).cuda(), data)
     tasks = O.make_tasks([(model.getFrameId(f), 0, 2, 0, None) for f in frames])
-    q = _compare(torch, model, problem, data, tasks, q0, T, 0, "cassie full body near")
+    return model, problem, data, q0, T, tasks
+
+
+# Config 3's two target distributions: "near" (q* = q0 + U(+-0.15): every lane converges) and "uniform" (joints anywhere
+# in their limits, base moved by U(+-0.1) m / U(+-0.2) rad: the primary distribution; about 6 % of the lanes never converge, and those
+# are where the 50-step map amplifies rounding differences -- the chaotic regime of rule 3, as for the narrowed UR arms).
+FULL_BODY_CASES = [("near", 0, False), ("uniform", 0.12, True)]
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+@pytest.mark.parametrize("mode,max_excluded,statistical", FULL_BODY_CASES)
+def test_full_body_lane_by_lane(torch_cuda, mode, max_excluded, statistical, seed):
+    """Config 3: Cassie full body (free-flyer, nq = 23), SE(3) tasks on both feet and the pelvis; integrate is the SE(3) update of
+    the floating base (reference ik/ik/dls.cpp:67-68)."""
+    torch = torch_cuda
+    model, problem, data, q0, T, tasks = _full_body(torch, mode, seed)
+    q = _compare(torch, model, problem, data, tasks, q0, T, max_excluded, "cassie full body %s seed %d" % (mode, seed), statistical)
     assert np.abs(np.linalg.norm(q[:, 3:7], axis=1) - 1.0).max() < 1e-9
+    lo, hi = model.lowerPositionLimit, model.upperPositionLimit
+    assert (q[:, 7:] >= lo[7:] - 1e-15).all() and (q[:, 7:] <= hi[7:] + 1e-15).all()
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+@pytest.mark.parametrize("mode", ["near", "uniform"])
+def test_full_body_step_synchronised_along_the_oracle_trajectory(torch_cuda, mode, seed):
+    """All 65536 lanes, 20 steps along the ORACLE's trajectory, no exclusions: one full step of the tree kernel -- both chains, the base
+    task, the arrow solve, exp6 of the base twist and the quaternion update, the clamp -- equals the oracle's dense 18 x 18 dual solve
+    and pinocchio-style integrate to 1e-9 rad / m (quaternion entries: 1e-9); the distribution check against _Float128 as for the chains."""
+    torch = torch_cuda
+    model, problem, data, q0, T, tasks = _full_body(torch, mode, seed)
+    _step_synchronised(torch, model, problem, data, tasks, q0, T, 20, 1e-9, "cassie full body %s seed %d" % (mode, seed))
 
 
 def test_full_body_never_stop_build_equals_the_stop_capable_build(torch_cuda):

@@ -85,5 +85,5 @@ for build in (("default",) if FULL_BODY else ("default", "general")):
                     row += " | refill %s w/CU %.3f ms%s" % (wpc, ms1, "" if same else " DIFFERENT")
                 os.environ.pop("IKGPU_REFILL_WAVES_PER_CU")
                 os.environ.pop("IKGPU_REFILL")
-                ideal = mean_it * B / 65536 * ms50 / 50
-                print(row + " | ideal (mean_it x B / lanes) %.3f ms" % ideal)
+                ideal = mean_it * ms50 / 50      # (ms50 is the 50-iteration time of THIS batch: it already scales with B)
+                print(row + " | ideal (mean_it x time per iteration of the batch) %.3f ms" % ideal)
