@@ -29,7 +29,7 @@ SYMBOLS = [
     "ikgpu_dls_solve_batch", "ikgpu_dls_solve_batch_host", "ikgpu_evaluate_batch", "ikgpu_task_frames_fk_batch",
     "ikgpu_pik_params_default", "ikgpu_pik_solve_batch", "ikgpu_pik_solve_batch_host", "ikgpu_pik_kernel",
     "ikgpu_problem_create_constrained", "ikgpu_problem_plan_constrained", "ikgpu_problem_support",
-    "ikgpu_problem_precompile",
+    "ikgpu_problem_precompile", "ikgpu_rtc_worker_compile",
     "ikgpu_shard_range", "ikgpu_shard_slot_layout", "ikgpu_shard_slot_bytes", "ikgpu_shard_group_create", "ikgpu_shard_group_destroy",
     "ikgpu_shard_group_size", "ikgpu_shard_group_problem", "ikgpu_shard_group_uses_rccl", "ikgpu_shard_group_stream",
     "ikgpu_dls_solve_batch_sharded", "ikgpu_shard_group_synchronize", "ikgpu_targets_from_pose7",

@@ -10,14 +10,30 @@
 //  * libhiprtc is opened with dlopen: when it is absent, or IKGPU_RTC=0, or the compilation fails, the problem runs on the general
 //    chain build -- never on a CPU path.
 //  * Code objects are cached in memory (per structure code) and on disk ($IKGPU_CACHE_DIR, else $XDG_CACHE_HOME/ikgpu, else
-//    ~/.cache/ikgpu; keyed by a hash of headers + source + flags + the hipRTC version), modules are loaded per device on first launch.
+//    ~/.cache/ikgpu; keyed by a hash of headers + source + the flags actually passed + the hipRTC version; each file carries a header
+//    -- magic, key, length, checksum -- that is validated on read; the directory must be the caller's own, mode 0700), modules are
+//    loaded per device on first launch.
+//  * THE COMPILER NEVER RUNS IN THE CALLER'S PROCESS.  LLVM can abort() on a program it cannot lower (round 3: "LLVM ERROR: Cannot
+//    scavenge register in FI elimination" took a test process down), and a library whose *_create can kill the robot's control
+//    process is a boundary defect (include/ikgpu.h: "nothing here ever throws").  A cache miss therefore spawns the worker
+//    `ikgpu_precompile --request <file>` (tools/ikgpu_precompile.cpp, installed next to libikgpu.so; posix_spawn, no fork handlers,
+//    no exec of this process), which runs hipRTC and leaves the code object in the cache; a worker that exits non-zero, dies on a
+//    signal or outlives IKGPU_RTC_TIMEOUT_S (default 600) means "this problem runs on its general build / interpreter", nothing
+//    else.  The worker initialises no device.  IKGPU_RTC_INPROCESS=1 restores in-process compilation (debugging).
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
+#include <signal.h>
+#include <spawn.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <cerrno>
 #include <cstddef>
 #include <cstdio>
 #include <cstdlib>
@@ -44,6 +60,8 @@ IKGPU_EMBED(ikgpu_src_chain_kernel_body, "device/chain_kernel_body.hpp")
 IKGPU_EMBED(ikgpu_src_chain_hot, "device/chain_hot.hpp")
 IKGPU_EMBED(ikgpu_src_tree_solver, "device/tree_solver.hpp")
 IKGPU_EMBED(ikgpu_src_generic_solver, "device/generic_solver.hpp")
+
+extern char **environ;   // (the compile worker inherits the caller's environment: IKGPU_CACHE_DIR, IKGPU_RTC_DEFINES, ...)
 
 namespace ikgpu {
 namespace {
@@ -117,6 +135,8 @@ std::string hot_source(int nj, const uint64_t code[3], int values) {
     return buf;
 }
 
+// The on-disk cache directory, or "" when there is none this process may trust: code objects read from it are handed to
+// hipModuleLoadData, so it has to be a directory (not a symlink) owned by the caller that nobody else can write to.
 std::string cache_dir() {
     std::string d;
     if (const char *e = std::getenv("IKGPU_CACHE_DIR")) d = e;
@@ -126,7 +146,9 @@ std::string cache_dir() {
     // mkdir -p (two levels are enough for the defaults)
     const size_t slash = d.rfind('/');
     if (slash != std::string::npos && slash > 0) (void)mkdir(d.substr(0, slash).c_str(), 0755);
-    (void)mkdir(d.c_str(), 0755);
+    (void)mkdir(d.c_str(), 0700);
+    struct stat st;
+    if (lstat(d.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != getuid() || (st.st_mode & (S_IWGRP | S_IWOTH)) != 0) return std::string();
     return d;
 }
 
@@ -142,13 +164,45 @@ bool read_file(const std::string &path, std::vector<char> &out) {
     return ok;
 }
 
-void write_file_atomically(const std::string &path, const std::vector<char> &data) {
+// A cached code object: {magic, key, payload bytes, FNV-1a of the payload} + the payload.  A file that is truncated, belongs to
+// another key or was edited is treated as a miss.
+struct CacheHeader {
+    char magic[8];
+    uint64_t key, bytes, check;
+};
+constexpr char kCacheMagic[8] = {'I', 'K', 'G', 'P', 'U', 'C', 'O', '2'};
+
+bool read_cached_object(const std::string &path, uint64_t key, std::vector<char> &code) {
+    std::vector<char> raw;
+    if (!read_file(path, raw) || raw.size() <= sizeof(CacheHeader)) return false;
+    CacheHeader h;
+    std::memcpy(&h, raw.data(), sizeof h);
+    if (std::memcmp(h.magic, kCacheMagic, sizeof kCacheMagic) != 0 || h.key != key || h.bytes != raw.size() - sizeof h) return false;
+    if (fnv1a(14695981039346656037ull, raw.data() + sizeof h, h.bytes) != h.check) return false;
+    code.assign(raw.begin() + sizeof h, raw.end());
+    return true;
+}
+
+bool write_file_atomically(const std::string &path, const std::vector<char> &data) {
     const std::string tmp = path + ".tmp." + std::to_string(static_cast<long>(getpid()));
     FILE *f = std::fopen(tmp.c_str(), "wb");
-    if (!f) return;
+    if (!f) return false;
     const bool ok = std::fwrite(data.data(), 1, data.size(), f) == data.size();
     std::fclose(f);
-    if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) (void)std::remove(tmp.c_str());
+    if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) { (void)std::remove(tmp.c_str()); return false; }
+    return true;
+}
+
+bool write_cached_object(const std::string &path, uint64_t key, const std::vector<char> &code) {
+    CacheHeader h;
+    std::memcpy(h.magic, kCacheMagic, sizeof kCacheMagic);
+    h.key = key;
+    h.bytes = code.size();
+    h.check = fnv1a(14695981039346656037ull, code.data(), code.size());
+    std::vector<char> raw(sizeof h + code.size());
+    std::memcpy(raw.data(), &h, sizeof h);
+    std::memcpy(raw.data() + sizeof h, code.data(), code.size());
+    return write_file_atomically(path, raw);
 }
 
 typedef std::tuple<int, uint64_t, uint64_t, uint64_t> ShapeKey;
@@ -164,10 +218,13 @@ struct HotModule {
     int refill_waves_per_cu = 0;
 };
 
-std::mutex g_mu;
+// g_mu guards the maps below (held for map access and module loading only, never while a compiler runs); g_compile_mu serialises
+// compilations (a second thread asking for the same program waits for the first instead of spawning a second compiler).
+std::mutex g_mu, g_compile_mu;
 std::map<ShapeKey, HotCode> g_codes;
 std::map<std::pair<ShapeKey, int>, HotModule> g_modules;
 std::string g_last_log;
+std::atomic<bool> g_in_worker{false};   // this process IS the compile worker (ikgpu_rtc_worker_compile): compile here
 
 ShapeKey key_of(const ProblemHost &ph) {
     return ShapeKey(ph.chain.nj, ph.chain_struct.code[0], ph.chain_struct.code[1], ph.chain_struct.code[2]);
@@ -182,6 +239,28 @@ const Hdr kHeaders[] = {{"lane_math.hpp", ikgpu_src_lane_math, ikgpu_src_lane_ma
                         {"generic_solver.hpp", ikgpu_src_generic_solver, ikgpu_src_generic_solver_end}};
 constexpr int kNumHeaders = static_cast<int>(sizeof kHeaders / sizeof kHeaders[0]);
 
+// The flag vector a program is compiled with.  if_convert (the generated lane programs): every two-armed choice whose arms the compiler
+// may evaluate speculatively becomes a select, whatever the arms cost -- no divergent branch inside the iteration (see IKD_CHOOSE in
+// device/lane_math.hpp); and `#pragma unroll` must not give up (16384 unrolled instructions by default): a loop of a static lane
+// program left rolled indexes the workspace with a run-time value, which demotes the WHOLE workspace from registers to scratch
+// memory (18.8 KB per lane for an M = 29 problem, 20 s of compile time, and "LLVM ERROR: Cannot scavenge register in FI
+// elimination" for its sibling without the constraint).  With the threshold lifted: 1.8 KB, 8 s, no error.
+// (debugging aid: IKGPU_RTC_PLAIN_FLAGS, bit k set: drop the k-th of the no-signed-zeros / no-NaN / no-infinity flags.  The -mllvm
+// flags stay, and the vector that results is what the cache key hashes.)
+std::vector<const char *> compile_flags(bool if_convert) {
+    std::vector<const char *> flags(kFlags, kFlags + 5);
+    long mask = 0;
+    if (const char *m = std::getenv("IKGPU_RTC_PLAIN_FLAGS")) mask = std::strtol(m, nullptr, 10);
+    for (int k = 0; k < 3; ++k)
+        if (!((mask >> k) & 1)) flags.push_back(kFlags[5 + k]);
+    if (if_convert) {
+        flags.push_back("-mllvm"); flags.push_back("-two-entry-phi-node-folding-threshold=100000");
+        flags.push_back("-mllvm"); flags.push_back("-pragma-unroll-threshold=4000000");
+    }
+    return flags;
+}
+
+// Identity of a program: the embedded headers, the generated source, the hipRTC version.  (What the in-memory maps are keyed by.)
 uint64_t source_hash(const std::string &src) {
     const RtcApi &api = rtc_api();
     uint64_t h = 14695981039346656037ull;
@@ -194,61 +273,39 @@ uint64_t source_hash(const std::string &src) {
     return fnv1a(h, &vmin, sizeof vmin);
 }
 
-// Compiles `src` against the embedded device headers, or fetches the code object from the on-disk cache (file name: prefix + the
-// hash of headers, source, flags and hipRTC version).  IKGPU_RTC_DUMP=<dir>: also writes the generated source there.
-void compile_cached(const char *prefix, const std::string &src_in, HotCode &hc, bool if_convert = false) {
-    hc.tried = true;
-    std::string src = src_in;
-    // (debugging aid: IKGPU_RTC_DEFINES="-DX -DY" is prepended to the source as #define lines and so takes part in the cache key)
-    if (const char *defs = std::getenv("IKGPU_RTC_DEFINES")) {
-        std::string d(defs), pre;
-        size_t pos = 0;
-        while ((pos = d.find("-D", pos)) != std::string::npos) {
-            size_t end = d.find(' ', pos);
-            if (end == std::string::npos) end = d.size();
-            std::string item = d.substr(pos + 2, end - pos - 2);
-            const size_t eq = item.find('=');
-            pre += "#define " + (eq == std::string::npos ? item + " 1" : item.substr(0, eq) + " " + item.substr(eq + 1)) + "\n";
-            pos = end;
-        }
-        src = pre + src;
+// Identity of a code object on disk: the program + the flag vector it was actually compiled with.
+uint64_t object_key(const std::string &src, const std::vector<const char *> &flags) {
+    uint64_t h = source_hash(src);
+    for (const char *f : flags) { h = fnv1a(h, f, std::strlen(f)); h = fnv1a(h, "\0", 1); }
+    return h;
+}
+
+// IKGPU_RTC_DEFINES="-DX -DY=3" (debugging aid) is prepended to the source as #define lines and so takes part in every key.
+std::string with_defines(const std::string &src) {
+    const char *defs = std::getenv("IKGPU_RTC_DEFINES");
+    if (!defs) return src;
+    std::string d(defs), pre;
+    size_t pos = 0;
+    while ((pos = d.find("-D", pos)) != std::string::npos) {
+        size_t end = d.find(' ', pos);
+        if (end == std::string::npos) end = d.size();
+        std::string item = d.substr(pos + 2, end - pos - 2);
+        const size_t eq = item.find('=');
+        pre += "#define " + (eq == std::string::npos ? item + " 1" : item.substr(0, eq) + " " + item.substr(eq + 1)) + "\n";
+        pos = end;
     }
+    return pre + src;
+}
+
+// hipRTC, in THIS process: only the compile worker (and IKGPU_RTC_INPROCESS=1) gets here.
+void compile_here(const std::string &src, const std::vector<const char *> &flags, HotCode &hc) {
     const RtcApi &api = rtc_api();
-    if (!api.ok) { hc.log = "libhiprtc could not be loaded"; return; }
-    const uint64_t h = source_hash(src) ^ (if_convert ? 0x9e3779b97f4a7c15ull : 0ull);
-    char name[96];
-    std::snprintf(name, sizeof name, "/%s_%016llx", prefix, static_cast<unsigned long long>(h));
-    if (const char *dump = std::getenv("IKGPU_RTC_DUMP")) {
-        std::vector<char> text(src.begin(), src.end());
-        write_file_atomically(std::string(dump) + name + ".hip", text);
-    }
-    const std::string path = cache_dir() + name + ".hsaco";
-    if (read_file(path, hc.code)) { hc.ok = true; hc.log = "cached: " + path; return; }
     hiprtcProgram prog = nullptr;
     const char *hsrc[kNumHeaders], *hname[kNumHeaders];
     for (int i = 0; i < kNumHeaders; ++i) { hsrc[i] = kHeaders[i].begin; hname[i] = kHeaders[i].name; }
     if (api.create(&prog, src.c_str(), "ikgpu_rtc.hip", kNumHeaders, hsrc, hname) != HIPRTC_SUCCESS) { hc.log = "hiprtcCreateProgram failed"; return; }
-    // (debugging aid: IKGPU_RTC_PLAIN_FLAGS drops the three no-signed-zeros / no-NaN / no-infinity flags; set it together with a
-    // fresh IKGPU_CACHE_DIR -- the flags are part of the cache key only in their default form)
-    std::vector<const char *> flags(kFlags, kFlags + sizeof kFlags / sizeof kFlags[0]);
-    // the generic program: every two-armed choice whose arms the compiler may evaluate speculatively becomes a select, whatever the
-    // arms cost -- no divergent branch inside the iteration (see IKD_CHOOSE in device/lane_math.hpp)
-    if (if_convert) {
-        flags.push_back("-mllvm"); flags.push_back("-two-entry-phi-node-folding-threshold=100000");
-        // `#pragma unroll` gives up above 16384 unrolled instructions by default; a loop of a static lane program left rolled indexes the
-        // workspace with a run-time value, which demotes the WHOLE workspace from registers to scratch memory (18.8 KB per lane for
-        // an M = 29 problem, 20 s of compile time, and "LLVM ERROR: Cannot scavenge register in FI elimination" -- an abort of the
-        // host process -- for its sibling without the constraint).  With the threshold lifted: 1.8 KB, 8 s, no error.
-        flags.push_back("-mllvm"); flags.push_back("-pragma-unroll-threshold=4000000");
-    }
-    if (const char *m = std::getenv("IKGPU_RTC_PLAIN_FLAGS")) {   // bit k set: drop the k-th of the three flags
-        const long mask = std::strtol(m, nullptr, 10);
-        std::vector<const char *> keep(kFlags, kFlags + 5);
-        for (int k = 0; k < 3; ++k)
-            if (!((mask >> k) & 1)) keep.push_back(kFlags[5 + k]);
-        flags = keep;
-    }
-    const hiprtcResult rc = api.compile(prog, static_cast<int>(flags.size()), flags.data());
+    std::vector<const char *> f(flags);
+    const hiprtcResult rc = api.compile(prog, static_cast<int>(f.size()), f.data());
     size_t ls = 0;
     if (api.log_size(prog, &ls) == HIPRTC_SUCCESS && ls > 1) {
         hc.log.resize(ls);
@@ -260,36 +317,177 @@ void compile_cached(const char *prefix, const std::string &src_in, HotCode &hc, 
         hc.ok = api.code(prog, hc.code.data()) == HIPRTC_SUCCESS;
     }
     (void)api.destroy(&prog);
-    if (hc.ok) write_file_atomically(path, hc.code);
-    else if (std::getenv("IKGPU_RTC_VERBOSE")) std::fprintf(stderr, "ikgpu: run-time compilation failed:\n%s\n", hc.log.c_str());
 }
 
-// Compiles (or fetches) the code object of this shape.  Called with g_mu held.
+// ---- the compile worker --------------------------------------------------------------------------------------------------------------
+std::string worker_path() {
+    if (const char *e = std::getenv("IKGPU_PRECOMPILE_EXE")) return e;
+    Dl_info info;
+    if (dladdr(reinterpret_cast<const void *>(&rtc_api), &info) == 0 || !info.dli_fname) return std::string();
+    std::string dir(info.dli_fname);
+    const size_t slash = dir.rfind('/');
+    dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
+    return dir + "/ikgpu_precompile";
+}
+
+double now_s() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return static_cast<double>(ts.tv_sec) + 1e-9 * static_cast<double>(ts.tv_nsec);
+}
+
+std::string file_tail(const std::string &path, size_t max_bytes) {
+    std::vector<char> raw;
+    if (!read_file(path, raw)) return std::string();
+    const size_t from = raw.size() > max_bytes ? raw.size() - max_bytes : 0;
+    return std::string(raw.begin() + static_cast<long>(from), raw.end());
+}
+
+// Hands (prefix, source, if_convert) to a fresh `ikgpu_precompile --request <file>` and waits for it.  Returns true when the worker
+// exited 0 (the code object is then in the cache); otherwise `why` says what happened -- exit status, signal, timeout -- with the tail of
+// the worker's stderr.  The child is a NEW program started with posix_spawn: nothing of this process (its GPU context, its threads,
+// its locks) exists in it, and this process is never replaced.
+bool run_worker(const std::string &dir, const char *prefix, const std::string &src, bool if_convert, std::string &why) {
+    const std::string exe = worker_path();
+    if (exe.empty() || access(exe.c_str(), X_OK) != 0) { why = "compile worker not found (" + exe + "; IKGPU_PRECOMPILE_EXE overrides)"; return false; }
+    static std::atomic<unsigned> counter{0};
+    const std::string req = dir + "/request." + std::to_string(static_cast<long>(getpid())) + "." + std::to_string(counter.fetch_add(1)) + ".req";
+    const std::string log = req + ".log";
+    {
+        std::string head = std::string("IKGPU-RTC-REQUEST 1\n") + prefix + "\n" + (if_convert ? "1" : "0") + "\n" + std::to_string(src.size()) + "\n";
+        std::vector<char> body(head.begin(), head.end());
+        body.insert(body.end(), src.begin(), src.end());
+        if (!write_file_atomically(req, body)) { why = "cannot write the compile request " + req; return false; }
+    }
+    posix_spawn_file_actions_t fa;
+    posix_spawn_file_actions_init(&fa);
+    posix_spawn_file_actions_addopen(&fa, 0, "/dev/null", O_RDONLY, 0);
+    posix_spawn_file_actions_addopen(&fa, 1, log.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0600);
+    posix_spawn_file_actions_adddup2(&fa, 1, 2);
+    std::string a0 = exe, a1 = "--request", a2 = req;
+    char *argv[] = {&a0[0], &a1[0], &a2[0], nullptr};
+    pid_t pid = -1;
+    const int rc = posix_spawn(&pid, exe.c_str(), &fa, nullptr, argv, environ);
+    posix_spawn_file_actions_destroy(&fa);
+    if (rc != 0) { why = std::string("posix_spawn(") + exe + "): " + std::strerror(rc); (void)std::remove(req.c_str()); return false; }
+    double limit = 600.0;
+    if (const char *e = std::getenv("IKGPU_RTC_TIMEOUT_S")) { const double v = std::strtod(e, nullptr); if (v > 0.0) limit = v; }
+    const double t0 = now_s();
+    int status = 0;
+    bool reaped = false, timed_out = false;
+    for (;;) {
+        const pid_t r = waitpid(pid, &status, WNOHANG);
+        if (r == pid) { reaped = true; break; }
+        if (r < 0 && errno != EINTR) break;   // ECHILD: the host ignores SIGCHLD and the kernel reaped the child -- the cache decides
+        if (now_s() - t0 > limit) {
+            timed_out = true;
+            (void)kill(pid, SIGKILL);          // exactly the process started above
+            (void)waitpid(pid, &status, 0);
+            break;
+        }
+        const timespec nap{0, 5 * 1000 * 1000};
+        (void)nanosleep(&nap, nullptr);
+    }
+    bool ok = false;
+    char buf[160];
+    if (timed_out) std::snprintf(buf, sizeof buf, "compile worker killed after %.0f s (IKGPU_RTC_TIMEOUT_S)", limit);
+    else if (!reaped) { ok = true; std::snprintf(buf, sizeof buf, "compile worker's exit status unavailable (SIGCHLD ignored by the host)"); }
+    else if (WIFEXITED(status) && WEXITSTATUS(status) == 0) { ok = true; buf[0] = '\0'; }
+    else if (WIFEXITED(status)) std::snprintf(buf, sizeof buf, "compile worker exited with status %d", WEXITSTATUS(status));
+    else if (WIFSIGNALED(status)) std::snprintf(buf, sizeof buf, "compile worker died on signal %d (%s)", WTERMSIG(status), strsignal(WTERMSIG(status)));
+    else std::snprintf(buf, sizeof buf, "compile worker ended abnormally (status 0x%x)", status);
+    why = buf;
+    const std::string tail = file_tail(log, 4000);
+    if (!tail.empty()) why += (why.empty() ? "" : ":\n") + tail;
+    (void)std::remove(req.c_str());
+    (void)std::remove(log.c_str());
+    return ok;
+}
+
+// Fetches the code object of `src_in` from the on-disk cache or has it compiled (file name: prefix + object_key).
+// IKGPU_RTC_DUMP=<dir>: also writes the generated source there.  Called WITHOUT g_mu.
+void compile_cached(const char *prefix, const std::string &src_in, HotCode &hc, bool if_convert = false) {
+    hc.tried = true;
+    const std::string src = with_defines(src_in);
+    const RtcApi &api = rtc_api();
+    if (!api.ok) { hc.log = "libhiprtc could not be loaded"; return; }
+    const std::vector<const char *> flags = compile_flags(if_convert);
+    const uint64_t key = object_key(src, flags);
+    char name[96];
+    std::snprintf(name, sizeof name, "/%s_%016llx", prefix, static_cast<unsigned long long>(key));
+    if (const char *dump = std::getenv("IKGPU_RTC_DUMP")) {
+        std::vector<char> text(src.begin(), src.end());
+        (void)write_file_atomically(std::string(dump) + name + ".hip", text);
+    }
+    const std::string dir = cache_dir();
+    const std::string path = dir.empty() ? std::string() : dir + name + ".hsaco";
+    if (!path.empty() && read_cached_object(path, key, hc.code)) { hc.ok = true; hc.log = "cached: " + path; return; }
+    const char *inproc = std::getenv("IKGPU_RTC_INPROCESS");
+    if (g_in_worker.load() || (inproc && inproc[0] == '1')) {
+        compile_here(src, flags, hc);
+        if (hc.ok && !path.empty()) (void)write_cached_object(path, key, hc.code);
+    } else if (path.empty()) {
+        hc.log = "no cache directory this process may trust (owned by the caller, not group / world writable): the compile worker has nowhere to leave the code object";
+    } else {
+        std::string why;
+        const bool ran = run_worker(dir, prefix, src_in, if_convert, why);
+        hc.ok = ran && read_cached_object(path, key, hc.code);
+        hc.log = hc.ok ? "compiled by the worker: " + path : (why.empty() ? "compile worker left no code object" : why);
+    }
+    if (!hc.ok && std::getenv("IKGPU_RTC_VERBOSE")) std::fprintf(stderr, "ikgpu: run-time compilation failed:\n%s\n", hc.log.c_str());
+}
+
+// The code object of (map, key): compiled at most once per process, without g_mu held while the compiler runs.
+template <class Map, class Key>
+HotCode &ensure_code(Map &map, const Key &key, const char *prefix, const std::string &src, bool if_convert) {
+    std::lock_guard<std::mutex> one_compiler(g_compile_mu);
+    HotCode *hc = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        hc = &map[key];   // (std::map: the node never moves)
+        if (hc->tried) { g_last_log = hc->log; return *hc; }
+    }
+    HotCode fresh;
+    compile_cached(prefix, src, fresh, if_convert);
+    std::lock_guard<std::mutex> lock(g_mu);
+    *hc = std::move(fresh);
+    g_last_log = hc->log;
+    return *hc;
+}
+
+// Compiles (or fetches) the code object of this shape.  Called WITHOUT g_mu.
 HotCode &code_for(const ProblemHost &ph) {
-    HotCode &hc = g_codes[key_of(ph)];
-    if (!hc.tried) compile_cached("chain_hot", hot_source(ph.chain.nj, ph.chain_struct.code, ph.chain_struct.values), hc);
-    return hc;
+    return ensure_code(g_codes, key_of(ph), "chain_hot", hot_source(ph.chain.nj, ph.chain_struct.code, ph.chain_struct.values), false);
 }
 
-// The loaded module of this shape on the current device.  Called with g_mu held.
-HotModule *module_for(const ProblemHost &ph, hipError_t *err) {
+// The loaded module of this shape on the current device (a copy: the map is guarded).  Called WITHOUT g_mu.
+bool module_for(const ProblemHost &ph, HotModule &out, hipError_t *err) {
     int dev = 0;
     (void)hipGetDevice(&dev);
-    HotModule &m = g_modules[std::make_pair(key_of(ph), dev)];
-    if (m.mod) return &m;
-    HotCode &hc = code_for(ph);
-    if (!hc.ok) { *err = hipErrorInvalidImage; return nullptr; }
-    hipError_t e = hipModuleLoadData(&m.mod, hc.code.data());
-    if (e == hipSuccess) e = hipModuleGetFunction(&m.never, m.mod, "ikgpu_hot_never");
-    if (e == hipSuccess) e = hipModuleGetFunction(&m.stop, m.mod, "ikgpu_hot_stop");
-    if (e == hipSuccess) e = hipModuleGetFunction(&m.refill, m.mod, "ikgpu_hot_refill");
-    if (e == hipSuccess) {
-        int per_cu = 0;
-        if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, m.refill, 64, 0) != hipSuccess || per_cu < 1) per_cu = 4;
-        m.refill_waves_per_cu = per_cu;
+    const auto mkey = std::make_pair(key_of(ph), dev);
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        const auto it = g_modules.find(mkey);
+        if (it != g_modules.end() && it->second.mod) { out = it->second; return true; }
     }
-    if (e != hipSuccess) { *err = e; m = HotModule{}; return nullptr; }
-    return &m;
+    HotCode &hc = code_for(ph);
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (!hc.ok) { *err = hipErrorInvalidImage; return false; }
+    HotModule &m = g_modules[mkey];
+    if (!m.mod) {
+        hipError_t e = hipModuleLoadData(&m.mod, hc.code.data());
+        if (e == hipSuccess) e = hipModuleGetFunction(&m.never, m.mod, "ikgpu_hot_never");
+        if (e == hipSuccess) e = hipModuleGetFunction(&m.stop, m.mod, "ikgpu_hot_stop");
+        if (e == hipSuccess) e = hipModuleGetFunction(&m.refill, m.mod, "ikgpu_hot_refill");
+        if (e == hipSuccess) {
+            int per_cu = 0;
+            if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, m.refill, 64, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+            m.refill_waves_per_cu = per_cu;
+        }
+        if (e != hipSuccess) { *err = e; m = HotModule{}; return false; }
+    }
+    out = m;
+    return true;
 }
 
 template <int NJ>
@@ -387,8 +585,16 @@ int static_posture_rows(const ProblemHost &ph) {
     for (const ikgpu_task &t : ph.tasks) n += t.type == IKGPU_POSTURE_ROW ? 1 : 0;
     return n;
 }
-int static_max_rows() {   // rows of the linear system the unrolled program is taken up to (IKGPU_STATIC_MAX_ROWS: experiments)
-    if (const char *env = std::getenv("IKGPU_STATIC_MAX_ROWS")) { const long v = std::strtol(env, nullptr, 10); if (v >= 1 && v <= 64) return static_cast<int>(v); }
+// Rows of the linear system the unrolled program is taken up to.  IKGPU_STATIC_MAX_ROWS can LOWER the built-in cap (tests, A/B);
+// raising it needs IKGPU_UNSAFE=1 next to it (experiments: beyond the cap nothing has been through the compiler -- the compile worker
+// contains a compiler crash, but minutes of compile time and KBs of scratch per lane are what was measured there).
+int static_max_rows() {
+    if (const char *env = std::getenv("IKGPU_STATIC_MAX_ROWS")) {
+        const long v = std::strtol(env, nullptr, 10);
+        const char *unsafe = std::getenv("IKGPU_UNSAFE");
+        const long cap = (unsafe && unsafe[0] == '1') ? 64 : IKGPU_STATIC_MAX_ROWS;
+        if (v >= 1) return static_cast<int>(std::min(v, cap));
+    }
     return IKGPU_STATIC_MAX_ROWS;
 }
 bool static_elimination(const ProblemHost &ph) {
@@ -470,10 +676,7 @@ bool rtc_chain_hot_available(const ProblemHost &ph, bool compile) {
     if (!rtc_enabled() || ph.kind != KernelKind::Chain || !ph.chain_struct.fits || ph.chain.nj < 1 || ph.chain.nj > 7) return false;
     if (!rtc_api().ok) return false;
     if (!compile) return true;
-    std::lock_guard<std::mutex> lock(g_mu);
-    const HotCode &hc = code_for(ph);
-    g_last_log = hc.log;
-    return hc.ok;
+    return code_for(ph).ok;
 }
 
 std::string rtc_last_log() {
@@ -484,11 +687,8 @@ std::string rtc_last_log() {
 hipError_t rtc_launch_chain_hot(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const ikgpu_dls_params &prm, hipStream_t stream) {
     HotModule m;
     {
-        std::lock_guard<std::mutex> lock(g_mu);
         hipError_t e = hipSuccess;
-        HotModule *pm = module_for(ph, &e);
-        if (!pm) return e;
-        m = *pm;
+        if (!module_for(ph, m, &e)) return e;
     }
     switch (ph.chain.nj) {
 #define X(N) case N: return launch_shape<N>(ph, dt, io, prm, stream, m);
@@ -516,27 +716,24 @@ bool rtc_generic_static_available(const ProblemHost &gen, bool compile, uint64_t
     if (!rtc_api().ok) return false;
     if (!compile) return true;
     const std::string src = generic_static_source(gen);
-    const uint64_t key = source_hash(src);
+    const uint64_t key = source_hash(with_defines(src));
     if (key_out) *key_out = key;
-    std::lock_guard<std::mutex> lock(g_mu);
-    HotCode &hc = g_gen_codes[key];
-    if (!hc.tried) compile_cached("generic_static", src, hc, /*if_convert=*/true);
-    g_last_log = hc.log;
-    return hc.ok;
+    return ensure_code(g_gen_codes, key, "generic_static", src, /*if_convert=*/true).ok;
 }
 
-// (g_mu held) the refill program of the static lane program `key` on the current device, or gm.refill == nullptr
-// (programs above 12 rows spill, and a spilling program is kept off the refill path below: do not even compile it)
+// The refill program of a static lane program (programs above 12 rows spill, and a spilling program is kept off the refill path
+// below: do not even compile it).
 static bool refill_program_worth_compiling(const ProblemHost &gen) { return rtc_static_solve_rows(gen) <= 12; }
 
-static void ensure_generic_refill(const ProblemHost &gen, GenModule &gm) {
+static HotCode &refill_code(const ProblemHost &gen) {   // (called WITHOUT g_mu: the compiler may run)
+    const std::string src = generic_static_source(gen, /*refill=*/true);
+    return ensure_code(g_gen_codes, source_hash(with_defines(src)), "generic_static_refill", src, /*if_convert=*/true);
+}
+
+// (g_mu held; `hc` tried) loads the refill program into gm, or leaves gm.refill == nullptr
+static void load_generic_refill(const HotCode &hc, GenModule &gm) {
     if (gm.refill_tried) return;
     gm.refill_tried = true;
-    if (!refill_program_worth_compiling(gen)) return;
-    const std::string src = generic_static_source(gen, /*refill=*/true);
-    HotCode &hc = g_gen_codes[source_hash(src)];
-    if (!hc.tried) compile_cached("generic_static_refill", src, hc, /*if_convert=*/true);
-    g_last_log = hc.log;
     if (!hc.ok) return;
     if (hipModuleLoadData(&gm.refill_mod, hc.code.data()) != hipSuccess) { gm.refill_mod = nullptr; return; }
     if (hipModuleGetFunction(&gm.refill, gm.refill_mod, "ikgpu_lane_dls_refill") != hipSuccess) { gm.refill = nullptr; return; }
@@ -567,12 +764,7 @@ static hipError_t generic_module(uint64_t key, GenModule **out) {   // (g_mu hel
 
 bool rtc_generic_static_precompile_refill(const ProblemHost &gen) {   // (compiles / fetches the code object; modules load per device at launch)
     if (!refill_program_worth_compiling(gen)) return false;
-    const std::string src = generic_static_source(gen, /*refill=*/true);
-    std::lock_guard<std::mutex> lock(g_mu);
-    HotCode &hc = g_gen_codes[source_hash(src)];
-    if (!hc.tried) compile_cached("generic_static_refill", src, hc, /*if_convert=*/true);
-    g_last_log = hc.log;
-    return hc.ok;
+    return refill_code(gen).ok;
 }
 
 hipError_t rtc_launch_generic_static(const ProblemHost &gen, uint64_t key, const BatchIO &io, const ikgpu_dls_params &prm, hipStream_t stream,
@@ -595,13 +787,22 @@ hipError_t rtc_launch_generic_static(const ProblemHost &gen, uint64_t key, const
     // below one wave per SIMD, so the small-batch path never meets the compiler here)
     const bool maybe_refill = queues && refill_wanted(prm, io.B, 1024);
     GenModule m;
-    {
-        std::lock_guard<std::mutex> lock(g_mu);
-        GenModule *gm = nullptr;
-        const hipError_t e = generic_module(key, &gm);
-        if (e != hipSuccess) return e;
-        if (maybe_refill) ensure_generic_refill(gen, *gm);
-        m = *gm;
+    const HotCode *refill_obj = nullptr;
+    for (int pass = 0;; ++pass) {
+        {
+            std::lock_guard<std::mutex> lock(g_mu);
+            GenModule *gm = nullptr;
+            const hipError_t e = generic_module(key, &gm);
+            if (e != hipSuccess) return e;
+            if (pass == 1) {
+                if (refill_obj) load_generic_refill(*refill_obj, *gm);
+                else gm->refill_tried = true;
+            }
+            m = *gm;
+        }
+        if (pass == 1 || !maybe_refill || m.refill_tried) break;
+        // the first large stop-rule batch of this program: its refill twin is compiled (or fetched) now, with no lock held
+        if (refill_program_worth_compiling(gen)) refill_obj = &refill_code(gen);
     }
     auto launch = [&](hipFunction_t fn, int64_t grid, size_t nbytes) {
         void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &nbytes, HIP_LAUNCH_PARAM_END};
@@ -626,3 +827,44 @@ hipError_t rtc_launch_generic_static(const ProblemHost &gen, uint64_t key, const
 }
 
 }  // namespace ikgpu
+
+// ---- the compile worker's entry (include/ikgpu.h ikgpu_rtc_worker_compile; tools/ikgpu_precompile.cpp --request) ---------------------
+// Runs in the process `run_worker` spawned: reads the request, compiles in THIS process, leaves the code object in the cache.  Touches
+// no device.  IKGPU_RTC_WORKER_FAULT = abort | segv | hang | exit (fault injection for tests/test_rtc_containment.py: what the
+// caller's process must survive).
+extern "C" int ikgpu_rtc_worker_compile(const char *request_path) {
+    using namespace ikgpu;
+    if (!request_path) return 2;
+    g_in_worker.store(true);
+    if (const char *f = std::getenv("IKGPU_RTC_WORKER_FAULT")) {
+        std::fprintf(stderr, "ikgpu_precompile: injected fault '%s'\n", f);
+        std::fflush(stderr);
+        if (std::strcmp(f, "abort") == 0) std::abort();
+        if (std::strcmp(f, "segv") == 0) (void)raise(SIGSEGV);
+        if (std::strcmp(f, "hang") == 0) for (;;) (void)pause();
+        if (std::strcmp(f, "exit") == 0) return 3;
+    }
+    std::vector<char> raw;
+    if (!read_file(request_path, raw)) { std::fprintf(stderr, "ikgpu_precompile: cannot read %s\n", request_path); return 2; }
+    const std::string text(raw.begin(), raw.end());
+    size_t pos = 0;
+    auto line = [&]() {
+        const size_t nl = text.find('\n', pos);
+        if (nl == std::string::npos) { pos = text.size(); return std::string(); }
+        std::string l = text.substr(pos, nl - pos);
+        pos = nl + 1;
+        return l;
+    };
+    if (line() != "IKGPU-RTC-REQUEST 1") { std::fprintf(stderr, "ikgpu_precompile: %s is not a compile request\n", request_path); return 2; }
+    const std::string prefix = line();
+    const bool if_convert = line() == "1";
+    const size_t n = static_cast<size_t>(std::strtoull(line().c_str(), nullptr, 10));
+    if (prefix.empty() || prefix.find('/') != std::string::npos || n == 0 || pos + n != text.size()) {
+        std::fprintf(stderr, "ikgpu_precompile: malformed compile request %s\n", request_path);
+        return 2;
+    }
+    HotCode hc;
+    compile_cached(prefix.c_str(), text.substr(pos, n), hc, if_convert);
+    if (!hc.ok) { std::fprintf(stderr, "%s\n", hc.log.c_str()); return 1; }
+    return 0;
+}

@@ -180,6 +180,17 @@ int ikgpu_problem_plan_constrained(const ikgpu_model *m, const ikgpu_task *tasks
  * runs on the general build; the compiler's log is in ikgpu_last_error()). */
 int ikgpu_problem_precompile(const ikgpu_model *m, const ikgpu_task *tasks, int32_t ntasks, const ikgpu_task *constraints,
                              int32_t nconstraints, char *out, size_t cap);
+/* The run-time compiler never runs inside the caller's process (a compiler can abort(); ikgpu_problem_create must not): a cache
+ * miss in ikgpu_problem_create / ikgpu_problem_precompile spawns the program `ikgpu_precompile` that is installed next to
+ * libikgpu.so (tools/ikgpu_precompile.cpp; $IKGPU_PRECOMPILE_EXE overrides the path) as a child process with the request file
+ * below, waits for it (IKGPU_RTC_TIMEOUT_S, default 600), and loads what it left in the cache.  A worker that fails, crashes or
+ * hangs costs the caller nothing but the specialised build: the problem is created on its general kernel.  On a cache hit no
+ * compiler and no child process run at all -- deployments run `ikgpu_precompile --urdf ...` once (or ikgpu_problem_precompile from
+ * a process of their own) and the control process never meets a compiler.
+ * ikgpu_rtc_worker_compile is that child's entry point: it reads one request written by the library (format private to the
+ * library), compiles it in the calling process and stores the code object in the cache; 0 on success.  It initialises no
+ * device.  Nothing else should call it.  No counterpart in the reference (its kernels are compiled with the library). */
+int ikgpu_rtc_worker_compile(const char *request_path);
 int32_t ikgpu_problem_rows(const ikgpu_problem *p);        /* M = sum of task dimensions */
 const char *ikgpu_problem_kernel(const ikgpu_problem *p);  /* name of the chosen specialisation */
 /* Which entries of q a solve can move: support[i] = 1 when q[i] is integrated by the kernel (a joint in the support of some

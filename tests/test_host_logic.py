@@ -339,7 +339,8 @@ def test_chain_build_switches_and_precompile(ik, tmp_path, monkeypatch):
     assert ik.precompile(arm) == "dls_chain<NJ=7,full,hot-rtc>"
     files = os.listdir(tmp_path)
     assert len(files) == 1 and files[0].startswith("chain_hot_") and files[0].endswith(".hsaco")
-    assert open(os.path.join(tmp_path, files[0]), "rb").read(4) == b"\x7fELF"
+    raw = open(os.path.join(tmp_path, files[0]), "rb").read(36)
+    assert raw[:8] == b"IKGPUCO2" and raw[32:36] == b"\x7fELF"      # the cache header (magic, key, length, checksum), then the code object
     weighted = _problem(ik, "arm7", ["tool"])[1]
     weighted.get_frame_task("t0").weighting()[0] = 2.0                                           # the hot program needs unit weights
     assert ik.precompile(weighted) == "dls_chain<NJ=7,full,general>"

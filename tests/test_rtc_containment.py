@@ -1,0 +1,148 @@
+"""The run-time compiler is contained (ik_amd/csrc/rtc.cpp, tools/ikgpu_precompile.cpp): it never runs in the caller's process, so
+nothing it does -- abort(), a segmentation fault, an endless loop -- can take the caller down; the caller gets IKGPU_ERR_UNSUPPORTED
+and its general kernel.  Round 3 lost a test process to "LLVM ERROR: Cannot scavenge register in FI elimination" inside
+ikgpu_problem_create (gpurun_out/abort.log): the two problems of that record -- every line of the reference demo switched on
+(ik_ros/src/cassie.cpp:45-81; M = 29), with and without the pinned foot -- go through ikgpu_problem_precompile here and must come back
+with a clean status.  Host-only: hipRTC cross-compiles gfx950 without a device.  Also: the on-disk cache's integrity checks."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+SCENARIO = r"""
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import ik_amd
+from ik_amd import capi
+from conftest import urdf_path
+
+def demo(everything, constraint):
+    model = ik_amd.Model.from_urdf_file(urdf_path("cassie"), free_flyer=True)
+    p = ik_amd.InverseKinematicsProblem(model)
+    p.add_frame_task("foot", ik_amd.FrameTask.create(model, "LeftFootFront", ik_amd.KinematicType.Position, "pelvis"))
+    p.add_frame_task("pelvis", ik_amd.FrameTask.create(model, "pelvis", ik_amd.KinematicType.Full))
+    p.add_align_axis_task("align", ik_amd.AlignAxisTask.create(model, "LeftFootFront", ik_amd.AlignAxisType.AxisY, "universe"))
+    if everything:
+        t = p.add_posture_task("posture", ik_amd.PostureTask.create(model, 16))
+        t.weighting()[:] = [0.3 + 0.04 * k for k in range(16)]
+        p.add_centre_of_mass_task(ik_amd.CentreOfMassTask.create(model, "universe"))
+    if constraint:
+        p.add_frame_constraint("pin", ik_amd.FrameConstraint.create(model, "RightFootFront", ik_amd.KinematicType.Position, "universe"))
+    return p
+
+def arm():
+    model = ik_amd.Model.from_urdf_file(urdf_path("arm7"))
+    p = ik_amd.InverseKinematicsProblem(model)
+    p.add_frame_task("t", ik_amd.FrameTask.create(model, "tool", ik_amd.KinematicType.Full))
+    return p
+
+def attempt(problem):
+    try:
+        return "OK " + ik_amd.precompile(problem)
+    except capi.IkgpuError as e:
+        return "ERR %d %s" % (e.code, e.message.replace("\n", " | ")[:600])
+
+{body}
+"""
+
+
+def run(body, tmp_path, **env):
+    e = dict(os.environ)
+    e.update({"IKGPU_CACHE_DIR": str(tmp_path), "IKGPU_TREE_STATIC_ROWS": "12"})
+    e.pop("IKGPU_RTC_WORKER_FAULT", None)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-c", SCENARIO.format(root=ROOT, body=body)], env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, "the CALLER died (rc %s):\n%s\n%s" % (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+    return r.stdout.strip().splitlines()
+
+
+def hiprtc_present():
+    return any(os.path.exists(p) for p in ("/opt/rocm/lib/libhiprtc.so", "/opt/rocm/lib/libhiprtc.so.7"))
+
+
+pytestmark = pytest.mark.skipif(not hiprtc_present(), reason="libhiprtc is not installed")
+
+
+def test_the_problems_that_aborted_in_round_3_come_back_with_a_status(native_built, tmp_path):
+    """M = 29 (13 x 13 after the posture rows are eliminated) with the pinned foot and its sibling without: compiled by the worker,
+    a clean IKGPU_OK and the static program's name -- or a clean UNSUPPORTED; never a dead caller."""
+    out = run("print(attempt(demo(True, True))); print(attempt(demo(True, False))); print('alive')", tmp_path)
+    assert out[-1] == "alive"
+    for line in out[:2]:
+        assert line.startswith("OK dls_generic<M=29,") and line.endswith(",static>") or line.startswith("ERR 3 "), line
+    objs = sorted(os.listdir(tmp_path))
+    assert not [f for f in objs if f.endswith(".req") or f.endswith(".log") or ".tmp." in f], objs    # the hand-over files are gone
+    # a second process finds both on disk: no worker is needed any more (a path that cannot be executed proves none is started)
+    again = run("print(attempt(demo(True, True))); print(attempt(demo(True, False)))", tmp_path, IKGPU_PRECOMPILE_EXE="/nonexistent/ikgpu_precompile")
+    assert again == out[:2]
+
+
+@pytest.mark.parametrize("fault,why", [("abort", "signal 6"), ("segv", "signal 11"), ("exit", "status 3"), ("hang", "killed after")])
+def test_a_compiler_that_crashes_or_hangs_costs_the_specialised_build_only(native_built, tmp_path, fault, why):
+    """Fault injection in the worker (IKGPU_RTC_WORKER_FAULT): the caller survives, ikgpu_problem_precompile says UNSUPPORTED and names
+    what happened and the kernel the problem runs on instead; the plan is unchanged, nothing is left in the cache."""
+    body = ("print(attempt(arm())); print(attempt(demo(False, False))); print(ik_amd.plan(arm())); print('alive')")
+    out = run(body, tmp_path, IKGPU_RTC_WORKER_FAULT=fault, IKGPU_RTC_TIMEOUT_S="2")
+    assert out[-1] == "alive"
+    assert out[0].startswith("ERR 3 ") and why in out[0] and "dls_chain<NJ=7,full,general>" in out[0], out[0]
+    assert out[1].startswith("ERR 3 ") and why in out[1] and "dls_tree<NJ=7,chains=1,base_task,base_reference,align_axis>" in out[1], out[1]
+    assert "injected fault" in out[0]                                     # the worker's stderr reaches ikgpu_last_error()
+    assert out[2] == "dls_chain<NJ=7,full,hot-rtc>"                       # (the plan names what WOULD run; precompile reports what does)
+    assert not os.listdir(tmp_path)
+    # the same problems in a fresh process without the fault: compiled
+    ok = run("print(attempt(arm())); print(attempt(demo(False, False)))", tmp_path)
+    assert ok == ["OK dls_chain<NJ=7,full,hot-rtc>", "OK dls_generic<M=10,nv=22,joints=17,static>"]
+
+
+def test_without_the_worker_program_nothing_is_compiled_in_process(native_built, tmp_path):
+    out = run("print(attempt(arm()))", tmp_path, IKGPU_PRECOMPILE_EXE="/nonexistent/ikgpu_precompile")
+    assert out[0].startswith("ERR 3 ") and "compile worker not found" in out[0]
+    out = run("print(attempt(arm()))", tmp_path, IKGPU_PRECOMPILE_EXE="/nonexistent/ikgpu_precompile", IKGPU_RTC_INPROCESS="1")
+    assert out == ["OK dls_chain<NJ=7,full,hot-rtc>"]                     # (the debugging switch)
+
+
+def test_cache_objects_are_validated_and_the_directory_must_be_private(native_built, tmp_path):
+    assert run("print(attempt(arm()))", tmp_path) == ["OK dls_chain<NJ=7,full,hot-rtc>"]
+    (obj,) = [f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]
+    path = os.path.join(str(tmp_path), obj)
+    raw = bytearray(open(path, "rb").read())
+    assert raw[:8] == b"IKGPUCO2" and len(raw) > 1000
+    # a flipped payload byte, a truncated file, a file of another key: each is a miss, and the object is rebuilt
+    for damage in ("flip", "truncate", "rename"):
+        bad = bytearray(raw)
+        if damage == "flip":
+            bad[len(bad) // 2] ^= 0x40
+        elif damage == "truncate":
+            bad = bad[:len(bad) // 2]
+        else:
+            bad[8] ^= 0x01        # (the key field of the header)
+        open(path, "wb").write(bytes(bad))
+        assert run("print(attempt(arm()))", tmp_path) == ["OK dls_chain<NJ=7,full,hot-rtc>"], damage
+        assert open(path, "rb").read() == bytes(raw), damage
+    # a directory someone else could write to is not used at all: with nowhere to receive the object, no specialised build
+    os.chmod(str(tmp_path), 0o777)
+    try:
+        out = run("print(attempt(arm()))", tmp_path)
+        assert out[0].startswith("ERR 3 ") and "no cache directory" in out[0], out
+    finally:
+        os.chmod(str(tmp_path), 0o700)
+    # the flags are part of the key: dropping one (debugging aid) makes a different object instead of poisoning this one
+    assert run("print(attempt(arm()))", tmp_path, IKGPU_RTC_PLAIN_FLAGS="1") == ["OK dls_chain<NJ=7,full,hot-rtc>"]
+    assert len([f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]) == 2
+
+
+def test_the_row_cap_cannot_be_raised_without_the_unsafe_switch(native_built, tmp_path):
+    """IKGPU_STATIC_MAX_ROWS may lower the built-in cap (24 solved rows); raising it needs IKGPU_UNSAFE=1."""
+    body = r'''
+model = ik_amd.Model.from_urdf_file(urdf_path("cassie"), free_flyer=True)
+p = ik_amd.InverseKinematicsProblem(model)
+for i, f in enumerate(["LeftFootFront", "RightFootFront", "LeftFootBack", "RightFootBack", "pelvis"]):
+    p.add_frame_task("t%d" % i, ik_amd.FrameTask.create(model, f, ik_amd.KinematicType.Full, "universe"))
+print(ik_amd.plan(p))
+'''
+    assert run(body, tmp_path, IKGPU_DLS_KERNEL="generic") == ["dls_generic<M=30,nv=22,joints=17>"]
+    assert run(body, tmp_path, IKGPU_DLS_KERNEL="generic", IKGPU_STATIC_MAX_ROWS="32") == ["dls_generic<M=30,nv=22,joints=17>"]
+    assert run(body, tmp_path, IKGPU_DLS_KERNEL="generic", IKGPU_STATIC_MAX_ROWS="32", IKGPU_UNSAFE="1") == ["dls_generic<M=30,nv=22,joints=17,static>"]
