@@ -57,6 +57,13 @@ struct ikgpu_problem {
     mutable std::once_flag visitor_static_once;
     mutable uint64_t visitor_static_key = 0;
     mutable bool visitor_static = false;
+    // ik::pik beyond one level / the tree kernel's two: a compiled lane program (rtc.cpp rtc_pik_static_available), one per
+    // (problem, with / without the secondary step da), compiled at the FIRST ik::pik call that wants it (or by
+    // ikgpu_problem_precompile) -- most problems are only ever handed to ik::dls
+    mutable std::once_flag pik_static_once[2];
+    mutable uint64_t pik_static_key[2] = {0, 0};
+    mutable bool pik_static[2] = {false, false};
+    mutable std::string pik_static_name;
     std::string dls_name;    // what ikgpu_problem_kernel reports
     std::string pik_name;    // name of the generic PIK kernel instance
     std::string pik_tree_name;  // ... and of the tree kernel running a two-level ik::pik (when the problem has that shape)
@@ -188,7 +195,7 @@ int check_pik_params(const ikgpu_problem *p, const ikgpu_pik_params *prm) {
 // IKGPU_PIK_KERNEL=generic keeps every ik::pik call on the PIK kernel (the parity tests compare the two).
 bool pik_is_one_dls_level(const ikgpu_problem *p, const ikgpu_pik_params *prm) {
     const char *force = std::getenv("IKGPU_PIK_KERNEL");
-    if (force && std::strcmp(force, "generic") == 0) return false;
+    if (force && (std::strcmp(force, "generic") == 0 || std::strcmp(force, "static") == 0)) return false;
     return p->gen.generic.nlevels == 1 && !prm->da && prm->lambda[0] > 0.0 && p->host.constraints.empty();
 }
 
@@ -197,10 +204,28 @@ bool pik_is_one_dls_level(const ikgpu_problem *p, const ikgpu_pik_params *prm) {
 // the tree kernel's arrow solve with damping lambda[0], level 1 a rank-one correction on the chain's joints (device/tree_solver.hpp
 // PikRow).  No secondary velocity, lambda > 0 on both levels.
 bool pik_is_two_levels_on_the_tree(const ikgpu_problem *p, const ikgpu_pik_params *prm) {
-    const char *force = std::getenv("IKGPU_PIK_KERNEL");
-    if (force && std::strcmp(force, "generic") == 0) return false;
+    const char *force = std::getenv("IKGPU_PIK_KERNEL");   // generic: the interpreter forms; static: the compiled lane program where there is one
+    if (force && (std::strcmp(force, "generic") == 0 || std::strcmp(force, "static") == 0)) return false;
     return p->gen.generic.nlevels == 2 && prm->num_levels == 2 && !prm->da && prm->lambda[0] > 0.0 && prm->lambda[1] > 0.0 &&
            p->host.constraints.empty() && ikgpu::tree_takes_two_level_pik(p->host);
+}
+
+// ik::pik on its compiled lane program: every level's lambda > 0 (the program factors Jbar Jbar^T + lambda^2 I), the program exists
+// (compiled here on first use).  IKGPU_PIK_KERNEL=generic / IKGPU_PIK_STATIC=0 keep the interpreter forms.
+bool pik_runs_static(const ikgpu_problem *p, const ikgpu_pik_params *prm) {
+    const char *force = std::getenv("IKGPU_PIK_KERNEL");
+    if (force && std::strcmp(force, "generic") == 0) return false;
+    for (int l = 0; l < prm->num_levels; ++l)
+        if (!(prm->lambda[l] > 0.0)) return false;
+    bool has_da = false;
+    if (prm->da)
+        for (int k = 0; k < p->gen.nv; ++k) has_da = has_da || prm->da[k] != 0.0;
+    const int v = has_da ? 1 : 0;
+    if (!ikgpu::rtc_pik_static_available(p->gen, has_da, /*compile=*/false, nullptr)) return false;
+    std::call_once(p->pik_static_once[v], [&] {
+        p->pik_static[v] = ikgpu::rtc_pik_static_available(p->gen, has_da, /*compile=*/true, &p->pik_static_key[v]);
+    });
+    return p->pik_static[v];
 }
 
 // Host-pointer form of a batched solve: copy in, run `launch` on device buffers, synchronise, copy out.
@@ -553,6 +578,11 @@ int ikgpu_problem_precompile(const ikgpu_model *h, const ikgpu_task *tasks, int3
         } else if (ph.generic_build == 2) {
             (void)ikgpu::rtc_generic_static_precompile_refill(ph);
         }
+        {   // a problem with several priority levels may be handed to ik::pik: its compiled lane program (without the secondary step)
+            const ikgpu::ProblemHost gen = ph.kind == ikgpu::KernelKind::Generic
+                                               ? ph : ikgpu::analyse_problem(h->m, tasks, ntasks, /*force_generic=*/true, constraints, nconstraints);
+            if (ikgpu::rtc_pik_static_available(gen, false, /*compile=*/false, nullptr)) (void)ikgpu::rtc_pik_static_available(gen, false, /*compile=*/true, nullptr);
+        }
         if (out && cap) {
             std::strncpy(out, got.c_str(), cap - 1);
             out[cap - 1] = '\0';
@@ -662,7 +692,12 @@ void ikgpu_pik_params_default(ikgpu_pik_params *p, int32_t num_levels) {
 const char *ikgpu_pik_kernel(const ikgpu_problem *p, const ikgpu_pik_params *params) {
     if (!p || !params) return "";
     if (pik_is_one_dls_level(p, params)) return p->dls_name.c_str();
-    return pik_is_two_levels_on_the_tree(p, params) ? p->pik_tree_name.c_str() : p->pik_name.c_str();
+    if (pik_is_two_levels_on_the_tree(p, params)) return p->pik_tree_name.c_str();
+    if (pik_runs_static(p, params)) {
+        if (p->pik_static_name.empty()) p->pik_static_name = p->pik_name.substr(0, p->pik_name.size() - 1) + ",static>";
+        return p->pik_static_name.c_str();
+    }
+    return p->pik_name.c_str();
 }
 
 int ikgpu_pik_solve_batch(const ikgpu_problem *p, int64_t B, const double *q0, const double *targets,
@@ -692,11 +727,16 @@ int ikgpu_pik_solve_batch(const ikgpu_problem *p, int64_t B, const double *q0, c
             return static_cast<int>(IKGPU_OK);
         });
     }
+    const bool on_static = pik_runs_static(p, params);
     return guarded([&] {
         DeviceGuard g(p->device);
         if (!g.ok) return fail(IKGPU_ERR_DEVICE, "hipSetDevice failed");
         ikgpu::BatchIO io{B, q0, targets, q_out, success, iters, layout};
-        const hipError_t e = ikgpu::launch_pik_generic(p->gen, p->dev, io, *params, static_cast<hipStream_t>(stream));
+        bool has_da = false;
+        if (params->da)
+            for (int k = 0; k < p->gen.nv; ++k) has_da = has_da || params->da[k] != 0.0;
+        const hipError_t e = on_static ? ikgpu::rtc_launch_pik_static(p->gen, p->pik_static_key[has_da ? 1 : 0], io, *params, static_cast<hipStream_t>(stream))
+                                       : ikgpu::launch_pik_generic(p->gen, p->dev, io, *params, static_cast<hipStream_t>(stream));
         if (e != hipSuccess) return hip_fail(e, "launching the PIK kernel");
         return static_cast<int>(IKGPU_OK);
     });

@@ -111,6 +111,186 @@ IKD_FN void generic_pik(const GenericTables &T, const PikParams &prm, const Ws &
     success_out = success;
 }
 
+#ifdef IKD_STATIC_TABLES
+// ---- ik::pik as a compiled lane program (rtc.cpp generic_static_source, kernel ikgpu_lane_pik) -----------------------------------
+// The level loop of reference ik/ik/pik.cpp:47-61 with everything a register program needs known at compile time: TB carries the
+// rows of every level (lvl_row0), so every loop below unrolls and the arrays are registers.
+//   * the projector is kept FACTORED, P = I - V^T V, V an orthonormal basis (rows) of the row space of the levels done so far
+//     (pik.cpp:58-61: P -= pinv(Jbar) Jbar -- pinv(Jbar) Jbar is the orthogonal projector onto rowspace(Jbar), and rowspace(Jbar) is
+//     orthogonal to the earlier levels' because Jbar = J_l P): Jbar = J_l - (J_l V^T) V costs rows x |V| x nv instead of rows x nv x nv,
+//     and V has the structural zeros of the Jacobians it came from;
+//   * the damped pseudo-inverse of pik.cpp:5-21, sum_i sigma_i / (sigma_i^2 + lambda^2) v_i u_i^T, is Jbar^T (Jbar Jbar^T +
+//     lambda^2 I)^-1 for lambda > 0: the m_l x m_l dual solve of the DLS program (unrolled Cholesky) -- no SVD, no sweep count that
+//     depends on the data (lambda = 0 stays on the one-sided-Jacobi interpreter above);
+//   * rank decisions as the complete orthogonal decomposition behind the reference's pinv makes them: pivoted Gram-Schmidt (largest
+//     remaining row first, every projection applied twice), a pivot below epsilon x min(rows, cols) x the first one ends the basis;
+//     the rows beyond the rank enter V as zero rows (selects, no branch).
+// HAS_DA: the secondary step dq += P da (pik.cpp:65) -- then the last level's rows enter V too.
+template <bool HAS_DA, class TB, class WS, class AnyFn>
+IKD_FN void static_pik(const TB &T, const PikParams &prm, const WS &ws, const LaneRows &targets, int &iters_out, bool &success_out,
+                       AnyFn any_lane) {
+    constexpr int NV = TB::nv, NL = TB::nlevels, MM = TB::pik_max_rows;
+    constexpr int VR = HAS_DA ? TB::M : TB::pik_basis_rows;   // rows V can hold: every level's but the last one's (all with da)
+    bool active = true, success = false;
+    int iters = prm.max_iterations;
+    for (int it = 0; it < prm.max_iterations; ++it) {
+        const double e0sq = generic_evaluate(T, ws, targets);                 // pik.cpp:41
+        double dq[NV], V[VR > 0 ? VR : 1][NV];
+        IKD_UNROLL
+        for (int c = 0; c < NV; ++c) dq[c] = 0.0;                              // pik.cpp:44-45
+        IKD_UNROLL
+        for (int l = 0; l < NL; ++l) {                                         // pik.cpp:47
+            const int r0 = TB::lvl_row0[l], ml = TB::lvl_row0[l + 1] - TB::lvl_row0[l];
+            const int v0 = r0;                                                 // rows of V before this level (a dropped row is a zero row)
+            const bool keep = HAS_DA || l != TB::pik_last_level;               // the projector left by the last level is only read by `P da`
+            if (ml == 0) continue;
+            double Jb[MM][NV], de[MM], A[MM * (MM + 1) / 2];
+            IKD_UNROLL
+            for (int r = 0; r < ml; ++r) {
+                double s = ws[T.off_e + r0 + r];                               // de = e_l - J_l dq, pik.cpp:49
+                IKD_UNROLL
+                for (int c = 0; c < NV; ++c) s = dfma(-ws[T.off_J + (r0 + r) * NV + c], dq[c], s);
+                de[r] = s;
+                IKD_UNROLL
+                for (int c = 0; c < NV; ++c) Jb[r][c] = ws[T.off_J + (r0 + r) * NV + c];
+                IKD_UNROLL
+                for (int k = 0; k < v0; ++k) {                                 // Jbar = J_l P, pik.cpp:51
+                    double d = 0.0;
+                    IKD_UNROLL
+                    for (int c = 0; c < NV; ++c) d = dfma(ws[T.off_J + (r0 + r) * NV + c], V[k][c], d);
+                    IKD_UNROLL
+                    for (int c = 0; c < NV; ++c) Jb[r][c] = dfma(-d, V[k][c], Jb[r][c]);
+                }
+            }
+            const double lam2 = prm.lam2[l < kMaxPikLevels ? l : kMaxPikLevels - 1];
+            IKD_UNROLL
+            for (int i = 0; i < ml; ++i)
+                IKD_UNROLL
+                for (int j = 0; j <= i; ++j) {
+                    double s = (i == j) ? lam2 : 0.0;
+                    IKD_UNROLL
+                    for (int c = 0; c < NV; ++c) s = dfma(Jb[i][c], Jb[j][c], s);
+                    A[tri(i, j)] = s;
+                }
+            IKD_UNROLL
+            for (int k = 0; k < ml; ++k) {   // Cholesky in place (diagonal holds 1 / L_kk), as generic_dls
+                double d = A[tri(k, k)];
+                IKD_UNROLL
+                for (int m = 0; m < k; ++m) { const double x = A[tri(k, m)]; d = dfma(-x, x, d); }
+                const double inv = drsqrt(d);
+                A[tri(k, k)] = inv;
+                IKD_UNROLL
+                for (int i = k + 1; i < ml; ++i) {
+                    double s = A[tri(i, k)];
+                    IKD_UNROLL
+                    for (int m = 0; m < k; ++m) s = dfma(-A[tri(i, m)], A[tri(k, m)], s);
+                    A[tri(i, k)] = s * inv;
+                }
+            }
+            IKD_UNROLL
+            for (int k = 0; k < ml; ++k) {
+                double s = de[k];
+                IKD_UNROLL
+                for (int m = 0; m < k; ++m) s = dfma(-A[tri(k, m)], de[m], s);
+                de[k] = s * A[tri(k, k)];
+            }
+            IKD_UNROLL
+            for (int k = ml - 1; k >= 0; --k) {
+                double s = de[k];
+                IKD_UNROLL
+                for (int m = ml - 1; m > k; --m) s = dfma(-A[tri(m, k)], de[m], s);
+                de[k] = s * A[tri(k, k)];
+            }
+            IKD_UNROLL
+            for (int c = 0; c < NV; ++c) {                                     // dq -= damp_pseudoinverse(Jbar, lambda_l) de, pik.cpp:54-55
+                double s = dq[c];
+                IKD_UNROLL
+                for (int r = 0; r < ml; ++r) s = dfma(-Jb[r][c], de[r], s);
+                dq[c] = s;
+            }
+            if (keep) {                                                        // P -= pinv(Jbar) Jbar, pik.cpp:58-61
+                // Gram-Schmidt with PIVOTING -- the largest remaining row first, as the column-pivoted QR behind the reference's
+                // complete orthogonal decomposition takes its columns -- and its rank rule: a pivot below epsilon x min(rows, cols)
+                // x the first pivot ends the basis (a Cassie leg's Full task has rank 5: its sixth pivot is rounding noise, 1e-16
+                // of the first, and WITHOUT pivoting up to 7e-16 when the fifth happens to be small -- the threshold is 1.3e-15).
+                // No row moves: the pivot row is picked by selects (a per-lane row index would put Jb into scratch memory).
+                const double thr = 2.220446049250313e-16 * static_cast<double>(ml < NV ? ml : NV);
+                const double thr2 = thr * thr;
+                bool used[MM], live = true;
+                double maxpiv2 = 0.0;
+                IKD_UNROLL
+                for (int r = 0; r < ml; ++r) used[r] = false;
+                IKD_UNROLL
+                for (int k = 0; k < ml; ++k) {
+                    double n2[MM], best = -1.0;
+                    IKD_UNROLL
+                    for (int r = 0; r < ml; ++r) {
+                        double s = 0.0;
+                        IKD_UNROLL
+                        for (int c = 0; c < NV; ++c) s = dfma(Jb[r][c], Jb[r][c], s);
+                        n2[r] = dsel(used[r], -1.0, s);
+                        best = dmax(best, n2[r]);
+                    }
+                    if (k == 0) maxpiv2 = best;
+                    live = live && best > thr2 * maxpiv2 && best > 0.0;
+                    const double inv = dsel(live, drsqrt(dmax(best, 1e-300)), 0.0);
+                    double v[NV];
+                    IKD_UNROLL
+                    for (int c = 0; c < NV; ++c) v[c] = 0.0;
+                    bool found = false;
+                    IKD_UNROLL
+                    for (int r = 0; r < ml; ++r) {
+                        const bool is_p = !found && !used[r] && n2[r] == best;
+                        found = found || is_p;
+                        used[r] = used[r] || is_p;
+                        IKD_UNROLL
+                        for (int c = 0; c < NV; ++c) v[c] = dsel(is_p, Jb[r][c] * inv, v[c]);
+                    }
+                    IKD_UNROLL
+                    for (int c = 0; c < NV; ++c) V[v0 + k][c] = v[c];
+                    IKD_UNROLL
+                    for (int r = 0; r < ml; ++r) {
+                        IKD_UNROLL
+                        for (int pass = 0; pass < 2; ++pass) {
+                            double d = 0.0;
+                            IKD_UNROLL
+                            for (int c = 0; c < NV; ++c) d = dfma(v[c], Jb[r][c], d);
+                            d = dsel(used[r], 0.0, d);
+                            IKD_UNROLL
+                            for (int c = 0; c < NV; ++c) Jb[r][c] = dfma(-d, v[c], Jb[r][c]);
+                        }
+                    }
+                }
+            }
+        }
+        if (HAS_DA) {                                                          // dq += P da, pik.cpp:65
+            double t[NV];
+            IKD_UNROLL
+            for (int c = 0; c < NV; ++c) t[c] = prm.da[c < kMaxPikDa ? c : kMaxPikDa - 1];
+            IKD_UNROLL
+            for (int k = 0; k < VR; ++k) {
+                double d = 0.0;
+                IKD_UNROLL
+                for (int c = 0; c < NV; ++c) d = dfma(V[k][c], prm.da[c < kMaxPikDa ? c : kMaxPikDa - 1], d);
+                IKD_UNROLL
+                for (int c = 0; c < NV; ++c) t[c] = dfma(-d, V[k][c], t[c]);
+            }
+            IKD_UNROLL
+            for (int c = 0; c < NV; ++c) dq[c] += t[c];
+        }
+        IKD_UNROLL
+        for (int c = 0; c < NV; ++c) ws[T.off_dq + c] = dq[c];
+        const bool stop_now = active && (prm.stop_sq_tol >= 0.0) && (e0sq < prm.stop_sq_tol);  // pik.cpp:67-70
+        if (stop_now) { success = true; iters = it; }
+        active = active && !stop_now;
+        generic_integrate_clip(T, ws, prm.step_length, active);               // pik.cpp:73-77
+        if (!any_lane(active)) break;
+    }
+    iters_out = iters;
+    success_out = success;
+}
+#endif  // IKD_STATIC_TABLES
+
 struct PikKernelArgs {
     GenericTables T;
     PikParams prm;
@@ -140,5 +320,27 @@ IKD_FN void pik_generic_body(const PikKernelArgs &a, int64_t gid, AnyFn any_lane
     if (a.success) a.success[b] = success ? 1 : 0;
     if (a.iters) a.iters[b] = iters;
 }
+
+#ifdef IKD_STATIC_TABLES
+// What one lane of the compiled ik::pik program does (kernel ikgpu_lane_pik / ikgpu_lane_pik_da; a.T and a.ws are unused: the
+// tables are TB's constants, the workspace is the caller's local array).
+template <bool HAS_DA, class TB, class WS, class AnyFn>
+IKD_FN void pik_static_body(const PikKernelArgs &a, const TB &T, int64_t gid, const WS &ws, AnyFn any_lane) {
+    const bool valid = gid < a.B;
+    const int64_t b = valid ? gid : a.B - 1;
+    IKD_UNROLL
+    for (int i = 0; i < T.nq; ++i) ws[T.off_q + i] = a.q0[at(a.layout, a.B, T.nq, i, b)];
+    const LaneRows tl{reinterpret_cast<const char *>(a.layout == LAYOUT_SOA ? a.targets + b : a.targets + b * T.ntasks * 12), 0u,
+                      static_cast<int64_t>(a.layout == LAYOUT_SOA ? a.B * 8 : 8), false};
+    int iters;
+    bool success;
+    static_pik<HAS_DA>(T, a.prm, ws, tl, iters, success, any_lane);
+    if (!valid) return;
+    IKD_UNROLL
+    for (int i = 0; i < T.nq; ++i) a.q_out[at(a.layout, a.B, T.nq, i, b)] = ws[T.off_q + i];
+    if (a.success) a.success[b] = success ? 1 : 0;
+    if (a.iters) a.iters[b] = iters;
+}
+#endif
 
 }  // namespace ikdev

@@ -99,6 +99,10 @@ hipError_t rtc_launch_generic_static(const ProblemHost &gen, uint64_t key, const
                                      QueuePool *queues = nullptr);   // queues: where the refill program's work-queue slots come from (none: lock-step only)
 int rtc_static_solve_rows(const ProblemHost &ph);   // rows of the linear system the static program solves (PostureTask rows eliminated when there are many)
 bool rtc_generic_static_precompile_refill(const ProblemHost &gen);   // the refill program, ahead of the first large stop-rule batch
+// ik::pik on a compiled lane program (device/pik_solver.hpp static_pik): available(compile = true) compiles / fetches the program for
+// calls with (with_da) or without a secondary step; launch needs every lambda > 0 (the caller checks).
+bool rtc_pik_static_available(const ProblemHost &gen, bool with_da, bool compile, uint64_t *key_out);
+hipError_t rtc_launch_pik_static(const ProblemHost &gen, uint64_t key, const BatchIO &io, const ikgpu_pik_params &prm, hipStream_t stream);
 std::string rtc_last_log();   // compiler log (or cache note) of the calling process's last run-time compilation attempt
 hipError_t rtc_launch_chain_hot(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const ikgpu_dls_params &prm, hipStream_t stream);
 hipError_t launch_targets_from_pose7(int64_t B, int ntasks, const double *pose7, double *targets12, int layout, hipStream_t stream);

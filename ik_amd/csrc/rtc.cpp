@@ -46,6 +46,7 @@
 
 #include "device/chain_hot.hpp"
 #include "device/generic_solver.hpp"
+#include "device/pik_solver.hpp"
 #include "kernels.hpp"
 
 // The device headers, verbatim.  (Paths are relative to ik_amd/csrc, where the Makefile runs the compiler.)
@@ -60,6 +61,7 @@ IKGPU_EMBED(ikgpu_src_chain_kernel_body, "device/chain_kernel_body.hpp")
 IKGPU_EMBED(ikgpu_src_chain_hot, "device/chain_hot.hpp")
 IKGPU_EMBED(ikgpu_src_tree_solver, "device/tree_solver.hpp")
 IKGPU_EMBED(ikgpu_src_generic_solver, "device/generic_solver.hpp")
+IKGPU_EMBED(ikgpu_src_pik_solver, "device/pik_solver.hpp")
 
 extern char **environ;   // (the compile worker inherits the caller's environment: IKGPU_CACHE_DIR, IKGPU_RTC_DEFINES, ...)
 
@@ -236,7 +238,8 @@ const Hdr kHeaders[] = {{"lane_math.hpp", ikgpu_src_lane_math, ikgpu_src_lane_ma
                         {"chain_kernel_body.hpp", ikgpu_src_chain_kernel_body, ikgpu_src_chain_kernel_body_end},
                         {"chain_hot.hpp", ikgpu_src_chain_hot, ikgpu_src_chain_hot_end},
                         {"tree_solver.hpp", ikgpu_src_tree_solver, ikgpu_src_tree_solver_end},
-                        {"generic_solver.hpp", ikgpu_src_generic_solver, ikgpu_src_generic_solver_end}};
+                        {"generic_solver.hpp", ikgpu_src_generic_solver, ikgpu_src_generic_solver_end},
+                        {"pik_solver.hpp", ikgpu_src_pik_solver, ikgpu_src_pik_solver_end}};
 constexpr int kNumHeaders = static_cast<int>(sizeof kHeaders / sizeof kHeaders[0]);
 
 // The flag vector a program is compiled with.  if_convert (the generated lane programs): every two-armed choice whose arms the compiler
@@ -602,12 +605,17 @@ bool static_elimination(const ProblemHost &ph) {
     return np > 0 && (np > 8 || ph.rows > static_max_rows());
 }
 
-std::string generic_static_source(const ProblemHost &ph, bool refill = false) {
+enum StaticKind { kStaticDls = 0, kStaticDlsRefill = 1, kStaticPik = 2, kStaticPikDa = 3 };
+
+std::string generic_static_source(const ProblemHost &ph, int kind = kStaticDls) {
+    const bool refill = kind == kStaticDlsRefill;
     const GenericHost &g = ph.generic;
     const int nj = g.njoints, nt = ph.ntasks;
     const int32_t *I = g.ints.data();
     const double *D = g.dbls.data();
-    std::string o = "#define IKD_STATIC_TABLES 1\n#include \"chain_kernel_body.hpp\"\n#include \"generic_solver.hpp\"\nnamespace {\nstruct T {\n";
+    std::string o = "#define IKD_STATIC_TABLES 1\n#include \"chain_kernel_body.hpp\"\n#include \"generic_solver.hpp\"\n";
+    if (kind == kStaticPik || kind == kStaticPikDa) o += "#include \"pik_solver.hpp\"\n";
+    o += "namespace {\nstruct T {\n";
     auto scalar = [&](const char *n, long long v) { o += std::string("    static constexpr int ") + n + " = " + std::to_string(v) + ";\n"; };
     scalar("njoints", nj); scalar("nq", ph.nq); scalar("nv", ph.nv); scalar("ntasks", nt); scalar("M", ph.rows);
     o += int_array("jtype", I + g.o_jtype, nj) + int_array("parent", I + g.o_parent, nj) + int_array("idx_q", I + g.o_idx_q, nj) + int_array("idx_v", I + g.o_idx_v, nj);
@@ -641,8 +649,23 @@ std::string generic_static_source(const ProblemHost &ph, bool refill = false) {
     if (g.has_com) o += dbl_array("j_mass", D + g.o_jmass, nj) + dbl_array("j_lever", D + g.o_jlever, 3 * nj) + dbl_array("j_submass", D + g.o_jsubmass, nj);
     else o += "    static constexpr double j_mass[] = {0.0}, j_lever[] = {0.0}, j_submass[] = {0.0};\n";
     o += "    static constexpr double inv_total_mass = " + hexd(g.inv_total_mass) + ";\n";
+    {   // ik::pik (pik_solver.hpp static_pik): the widest level, the last non-empty one, the rows of the levels before it
+        int max_rows = 1, last = 0;
+        for (int l = 0; l < g.nlevels; ++l) {
+            const int ml = I[g.o_lvlrow0 + l + 1] - I[g.o_lvlrow0 + l];
+            max_rows = std::max(max_rows, ml);
+            if (ml > 0) last = l;
+        }
+        scalar("pik_max_rows", max_rows); scalar("pik_last_level", last); scalar("pik_basis_rows", I[g.o_lvlrow0 + last]);
+    }
     o += "};\n}  // namespace\n";
-    if (refill)   // the stop-rule mode on batches larger than the machine (generic_solver.hpp GenericRefill): its own module, compiled when first needed
+    if (kind == kStaticPik || kind == kStaticPikDa)
+        o += std::string("extern \"C\" __global__ __launch_bounds__(64) void ikgpu_lane_pik(const ikdev::PikKernelArgs a) {\n"
+                         "    double w[T::ws_words];\n"
+                         "    ikdev::pik_static_body<") + (kind == kStaticPikDa ? "true" : "false") +
+             ">(a, T{}, static_cast<int64_t>(blockIdx.x) * 64 + threadIdx.x, ikdev::WsReg{w}, [](bool act) { return __any(act) != 0; });\n"
+             "}\n";
+    else if (refill)   // the stop-rule mode on batches larger than the machine (generic_solver.hpp GenericRefill): its own module, compiled when first needed
         o += "extern \"C\" __global__ __launch_bounds__(64) void ikgpu_lane_dls_refill(const ikdev::GenericKernelArgs a, unsigned long long *queue, int chunk) {\n"
              "    double w[T::ws_words];\n"
              "    ikdev::dls_generic_refill_body(a, T{}, static_cast<int64_t>(blockIdx.x), static_cast<int64_t>(gridDim.x), ikdev::WsReg{w}, queue, chunk);\n"
@@ -726,7 +749,7 @@ bool rtc_generic_static_available(const ProblemHost &gen, bool compile, uint64_t
 static bool refill_program_worth_compiling(const ProblemHost &gen) { return rtc_static_solve_rows(gen) <= 12; }
 
 static HotCode &refill_code(const ProblemHost &gen) {   // (called WITHOUT g_mu: the compiler may run)
-    const std::string src = generic_static_source(gen, /*refill=*/true);
+    const std::string src = generic_static_source(gen, kStaticDlsRefill);
     return ensure_code(g_gen_codes, source_hash(with_defines(src)), "generic_static_refill", src, /*if_convert=*/true);
 }
 
@@ -824,6 +847,75 @@ hipError_t rtc_launch_generic_static(const ProblemHost &gen, uint64_t key, const
         }
     }
     return launch(m.dls, (io.B + 63) / 64, sizeof(ikdev::GenericKernelArgs));
+}
+
+}  // namespace ikgpu
+
+namespace ikgpu {
+
+// ---- ik::pik as a compiled lane program (device/pik_solver.hpp static_pik) -------------------------------------------------------------
+// Eligibility: what the DLS program takes (rows, nv, workspace), at least two non-empty levels (one level IS the DLS iteration and
+// runs on the problem's DLS kernel), every level within 12 rows (its dual system is unrolled in registers).  lambda > 0 on every
+// level is a property of the CALL (capi.cpp checks it): lambda = 0 stays on the one-sided-Jacobi interpreter.
+namespace {
+struct PikModule {
+    hipModule_t mod = nullptr;
+    hipFunction_t fn = nullptr;
+};
+std::map<std::pair<uint64_t, int>, PikModule> g_pik_modules;   // (hash, device); guarded by g_mu
+}  // namespace
+
+bool rtc_pik_static_available(const ProblemHost &gen, bool with_da, bool compile, uint64_t *key_out) {
+    if (!rtc_enabled() || gen.kind != KernelKind::Generic || !rtc_api().ok) return false;
+    if (std::getenv("IKGPU_GENERIC_KERNEL")) return false;
+    if (const char *env = std::getenv("IKGPU_PIK_STATIC")) { if (env[0] == '0') return false; }
+    const GenericHost &g = gen.generic;
+    int levels = 0, widest = 0;
+    for (int l = 0; l < g.nlevels; ++l) {
+        const int ml = g.ints[static_cast<size_t>(g.o_lvlrow0 + l + 1)] - g.ints[static_cast<size_t>(g.o_lvlrow0 + l)];
+        levels += ml > 0 ? 1 : 0;
+        widest = std::max(widest, ml);
+    }
+    if (levels < 2 || widest > 12 || gen.rows > static_max_rows() || gen.nv > 36 || g.ws_words > 2400 || gen.crows > 0) return false;
+    if (!compile) return true;
+    const std::string src = generic_static_source(gen, with_da ? kStaticPikDa : kStaticPik);
+    const uint64_t key = source_hash(with_defines(src));
+    if (key_out) *key_out = key;
+    return ensure_code(g_gen_codes, key, with_da ? "pik_static_da" : "pik_static", src, /*if_convert=*/true).ok;
+}
+
+hipError_t rtc_launch_pik_static(const ProblemHost &gen, uint64_t key, const BatchIO &io, const ikgpu_pik_params &prm, hipStream_t stream) {
+    ikdev::PikKernelArgs a{};
+    a.prm.max_iterations = prm.max_iterations;
+    a.prm.step_length = prm.step_length;
+    a.prm.stop_sq_tol = prm.stop_sq_tol;
+    for (int l = 0; l < ikdev::kMaxPikLevels; ++l) a.prm.lam2[l] = l < prm.num_levels ? prm.lambda[l] * prm.lambda[l] : 1.0;
+    a.prm.has_da = 0;
+    if (prm.da)
+        for (int k = 0; k < gen.nv && k < ikdev::kMaxPikDa; ++k) {
+            a.prm.da[k] = prm.da[k];
+            if (prm.da[k] != 0.0) a.prm.has_da = 1;
+        }
+    a.layout = io.layout; a.B = io.B; a.q0 = io.q0; a.targets = io.targets;
+    a.q_out = io.q_out; a.success = io.success; a.iters = io.iters;
+    PikModule m;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        PikModule &pm = g_pik_modules[std::make_pair(key, dev)];
+        if (!pm.mod) {
+            const HotCode &hc = g_gen_codes[key];
+            if (!hc.ok) return hipErrorInvalidImage;
+            hipError_t e = hipModuleLoadData(&pm.mod, hc.code.data());
+            if (e == hipSuccess) e = hipModuleGetFunction(&pm.fn, pm.mod, "ikgpu_lane_pik");
+            if (e != hipSuccess) { pm = PikModule{}; return e; }
+        }
+        m = pm;
+    }
+    size_t nbytes = sizeof a;
+    void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &nbytes, HIP_LAUNCH_PARAM_END};
+    return hipModuleLaunchKernel(m.fn, static_cast<unsigned>((io.B + 63) / 64), 1, 1, 64, 1, 1, 0, stream, nullptr, config);
 }
 
 }  // namespace ikgpu

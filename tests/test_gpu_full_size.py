@@ -136,9 +136,12 @@ def assert_parity(c, label, max_excluded, statistical):
 
 
 def one_step_ratio(e_dev, e_orc):
-    """Per-lane ratio of two one-step errors against the _Float128 oracle; 1e-16 (half an ulp of a unit-size q) keeps an exact hit
-    of either side from dividing by zero."""
-    return (e_dev + 1e-16) / (e_orc + 1e-16)
+    """Per-lane ratio of two one-step errors against the _Float128 oracle.  Both carry a floor of 4 ulp of a unit-size q (2^-50): a
+    converged lane's error IS the rounding of q + dq itself, quantised in ulps, and one side landing exactly on the rounded exact
+    value while the other sits 5 ulp off says nothing about either (round 4, first run: 24 such lanes against 3 at step 30 of a
+    converged batch failed the sign test with the floor at half an ulp)."""
+    f = 2.0 ** -50
+    return (e_dev + f) / (e_orc + f)
 
 
 def _compare(torch, model, problem, data, tasks, q0, targets_dev, max_excluded, label, statistical=False, primal=False):
@@ -284,7 +287,8 @@ def _step_synchronised(torch, model, problem, data, tasks, q0, T, steps, label, 
                 NA, nv, lam2, u = 1024, model.nv, 1e-4, 2.0 ** -53
                 s1 = np.array([np.linalg.svd(O.evaluate(om, tasks, tg[b], q[b])[1], compute_uv=False)[0] for b in range(NA)])
                 step = np.abs(q_x[:NA] - q[:NA]).max(axis=1)
-                bound = (3 * nv + 1) * u * (s1 * s1 + lam2) / lam2 * np.maximum(step, 1e-6)
+                # (+ the rounding of the update itself -- q + dq, the quaternion product, the clamp: 16 ulp of the largest entry of q)
+                bound = (3 * nv + 1) * u * (s1 * s1 + lam2) / lam2 * step + 16.0 * u * np.maximum(1.0, np.abs(q[:NA]).max(axis=1))
                 rec["max_error_over_apriori_bound"].append(float((e_dev[:NA] / bound).max()))
                 assert (e_dev[:NA] <= bound).all(), (label, k, float((e_dev[:NA] / bound).max()))
         q = q_next

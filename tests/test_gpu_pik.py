@@ -41,6 +41,10 @@ PIK_CASES = {
 }
 
 
+def _hiprtc():
+    return any(os.path.exists(p) for p in ("/opt/rocm/lib/libhiprtc.so", "/opt/rocm/lib/libhiprtc.so.7"))
+
+
 def _pik_data(ik_amd, problem, lam, da=None):
     data = ik_amd.pik_data(problem, device=0)
     data.lambda_ = list(lam)
@@ -69,8 +73,10 @@ def test_pik_kernel_matches_oracle(torch_cuda, case):
             assert data.kernel == ik_amd.plan(problem) and data.kernel.startswith("dls_chain<")
         elif case.startswith("demo_two_levels") and da is None:   # two levels in the tree kernel's shape (device/tree_solver.hpp PikRow)
             assert data.kernel.startswith("dls_tree<NJ=7,chains=1") and data.kernel.endswith(",pik_levels=2>"), data.kernel
-        else:
-            assert data.kernel.startswith("pik_generic<")
+        elif case == "demo_three_levels":     # 26 rows: beyond what the compiled lane program takes -- the cooperative interpreter
+            assert data.kernel.startswith("pik_generic<") and not data.kernel.endswith(",static>"), data.kernel
+        else:                                 # every other split: the lane program compiled for the problem (device/pik_solver.hpp static_pik)
+            assert data.kernel.startswith("pik_generic<") and (data.kernel.endswith(",static>") or not _hiprtc()), data.kernel
         p = ik_amd.pik_parameters(max_iterations=iters, step_length=step)
         visitor = ik_amd.inverse_kinematics_visitor(tol)
         Q, ok, it = ik_amd.pik_batch(problem, Q0, T, data, visitor, p)
@@ -99,7 +105,9 @@ def test_cooperative_and_per_lane_pik_kernels_agree(torch_cuda, case, monkeypatc
         data = _pik_data(ik_amd, problem, lam)
         p, v = ik_amd.pik_parameters(max_iterations=iters, step_length=step), ik_amd.inverse_kinematics_visitor(tol)
         monkeypatch.delenv("IKGPU_GENERIC_KERNEL", raising=False)
+        monkeypatch.setenv("IKGPU_PIK_STATIC", "0")                   # (the interpreter forms: the compiled lane program is compared below)
         Qc, okc, itc = ik_amd.pik_batch(problem, Q0, T, data, v, p)
+        assert not data.kernel.endswith(",static>")
         Qc2, _, _ = ik_amd.pik_batch(problem, Q0, T, data, v, p)
         assert torch.equal(Qc, Qc2)                                   # run-to-run bit-identical
         monkeypatch.setenv("IKGPU_GENERIC_KERNEL", "lane")
@@ -109,6 +117,7 @@ def test_cooperative_and_per_lane_pik_kernels_agree(torch_cuda, case, monkeypatc
         assert (d <= 1e-7).double().mean().item() >= 0.995, (case, iters, d.max().item())
     # lambda = 0 is the per-lane program's (the cooperative one factors Jbar Jbar^T + lambda^2 I): same entry point, finite result
     monkeypatch.delenv("IKGPU_GENERIC_KERNEL", raising=False)
+    monkeypatch.delenv("IKGPU_PIK_STATIC", raising=False)
     data = _pik_data(ik_amd, problem, [0.0] * levels)
     Qz, _, _ = ik_amd.pik_batch(problem, Q0, T, data, ik_amd.never_stop_visitor(), ik_amd.pik_parameters(max_iterations=2, step_length=0.5))
     assert torch.isfinite(Qz).double().mean().item() > 0.99
@@ -302,3 +311,55 @@ def test_cpp_api_program_with_pik(torch_cuda):
     assert out["kernel"].startswith("dls_chain<NJ=6")
     assert np.abs(np.array(out["q_first"]) - q1).max() <= TOL and np.abs(np.array(out["q"]) - q2).max() <= TOL
     assert out["success"] == int(ok2) and out["iterations"] == it2
+
+
+@pytest.mark.parametrize("case", ["ur5_pos_then_ori", "ur5_full_then_elbow", "fixed_two_feet", "feet_then_pelvis"])
+def test_compiled_pik_lane_program_against_the_interpreter_and_the_oracle(torch_cuda, case, monkeypatch):
+    """ik::pik for any level split on a lane program compiled for the problem (rtc.cpp, device/pik_solver.hpp static_pik: projector
+    in factored form, each level's damped pseudo-inverse as a dual Cholesky solve, pivoted Gram-Schmidt with the reference's rank
+    rule) -- what a problem with several priority levels runs on by default.  B = 8192 (not a multiple of 64 + a tail), against the
+    oracle's Jacobi-SVD / COD ik::pik and the cooperative interpreter; lambda = 0 on a level falls back to the interpreter."""
+    torch = torch_cuda
+    if not _hiprtc():
+        pytest.skip("libhiprtc is not installed")
+    name, ff, specs, edit, projector_determined = PIK_CASES[case]
+    B = 8192 + 37
+    ik_amd, O, model, problem, _, om, ot, q0, tg = build(name, ff, specs, 512, seed=12, xml_edit=edit)
+    rep = -(-B // 512)
+    rng = np.random.default_rng(3)
+    q0 = (np.tile(q0, (rep, 1))[:B] + rng.uniform(-0.02, 0.02, (B, model.nq)) * (np.arange(B) >= 512)[:, None])
+    if ff:
+        q0[:, 3:7] /= np.linalg.norm(q0[:, 3:7], axis=1, keepdims=True)
+    q0 = np.clip(q0, model.lowerPositionLimit, model.upperPositionLimit)
+    tg = np.tile(tg, (rep, 1, 1))[:B]
+    levels = problem.max_priority_level() + 1
+    Q0 = torch.from_numpy(np.ascontiguousarray(q0.T)).cuda()
+    T = torch.from_numpy(np.ascontiguousarray(tg.transpose(1, 2, 0))).cuda()
+    monkeypatch.delenv("IKGPU_GENERIC_KERNEL", raising=False)
+    for iters, step, tol, lam, da in ((1, 1.0, -1.0, [1.0] * levels, None), (30, 0.5, 1e-8, [0.05, 0.1][:levels], None),
+                                      (50, 1.0, -1.0, [0.1] * levels, None), (6, 1.0, -1.0, [0.1] * levels, 0.01 * np.cos(np.arange(model.nv)))):
+        if da is not None and not projector_determined:
+            continue
+        data = _pik_data(ik_amd, problem, lam, da)
+        assert data.kernel.startswith("pik_generic<") and data.kernel.endswith(",static>"), data.kernel
+        p, v = ik_amd.pik_parameters(max_iterations=iters, step_length=step), ik_amd.inverse_kinematics_visitor(tol)
+        Qs, oks, its = ik_amd.pik_batch(problem, Q0, T, data, v, p)
+        q_ref, ok_ref, it_ref = O.pik_batch(om, ot, tg, q0, O.pik_params(iters, step, tol, lam, None if da is None else list(da)), os.cpu_count() or 1)
+        same = its.cpu().numpy() == it_ref
+        assert same.mean() > 0.999 and np.array_equal(oks.cpu().numpy()[same], ok_ref[same]), (case, iters, same.mean())
+        d = np.abs(Qs.cpu().numpy().T - q_ref).max(axis=1)
+        # (50 full steps at lambda = 0.1 on far targets: the iteration is chaotic on a few problems, as for ik::dls -- tests/test_gpu_generic.py)
+        assert (d[same] <= TOL).mean() >= (0.99 if iters == 50 else 1.0), (case, iters, d[same].max(), (d[same] <= TOL).mean())
+        monkeypatch.setenv("IKGPU_PIK_STATIC", "0")
+        Qc, okc, itc = ik_amd.pik_batch(problem, Q0, T, data, v, p)
+        monkeypatch.delenv("IKGPU_PIK_STATIC")
+        agree = (its == itc)
+        assert agree.double().mean().item() > 0.999
+        dc = (Qs - Qc).abs().amax(dim=0)[agree]
+        assert (dc <= 1e-7).double().mean().item() >= (0.99 if iters == 50 else 0.999), (case, iters, dc.max().item())
+    # AoS gives the same bits; a second call the same bits (no atomics, no races)
+    Qa, oka, ita = ik_amd.pik_batch(problem, torch.from_numpy(q0).cuda(), torch.from_numpy(tg).cuda(), data, v, p, layout="aos")
+    assert torch.equal(Qs.T.contiguous(), Qa) and torch.equal(oks, oka) and torch.equal(its, ita)
+    # lambda = 0 on a level: the one-sided-Jacobi interpreter (the compiled program factors Jbar Jbar^T + lambda^2 I)
+    data0 = _pik_data(ik_amd, problem, [0.0] + [0.1] * (levels - 1))
+    assert not data0.kernel.endswith(",static>")

@@ -106,3 +106,84 @@ def test_static_program_on_the_host_matches_the_oracle(tmp_path, native_built, c
         assert np.array_equal(it, it_ref) and np.array_equal(ok, ok_ref), (case, iters, it, it_ref)
         d = np.abs(q - q_ref).max()
         assert d <= bar, (case, kernel, iters, d)
+
+
+# ---- ik::pik (reference ik/ik/pik.cpp:31-103) on its compiled lane program (device/pik_solver.hpp static_pik) --------------------------
+PIK_DRIVER = r"""
+extern "C" int static_host_pik(long long B, const double *q0, const double *targets, int max_it, double step, double stop_tol, int nl,
+                               const double *lambda, const double *da, double *q_out, unsigned char *ok, int *iters) {
+    ikdev::PikKernelArgs a{};
+    a.prm.max_iterations = max_it; a.prm.step_length = step; a.prm.stop_sq_tol = stop_tol;
+    for (int l = 0; l < ikdev::kMaxPikLevels; ++l) a.prm.lam2[l] = l < nl ? lambda[l] * lambda[l] : 1.0;
+    a.prm.has_da = da != nullptr;
+    if (da) for (int k = 0; k < T::nv; ++k) a.prm.da[k] = da[k];
+    a.layout = ikdev::LAYOUT_AOS; a.B = B; a.q0 = q0; a.targets = targets; a.q_out = q_out; a.success = ok; a.iters = iters;
+    for (long long gid = 0; gid < B; ++gid) {
+        double w[T::ws_words];
+        if (da) ikdev::pik_static_body<true>(a, T{}, gid, ikdev::WsReg{w}, [](bool act) { return act; });
+        else ikdev::pik_static_body<false>(a, T{}, gid, ikdev::WsReg{w}, [](bool act) { return act; });
+    }
+    return T::pik_basis_rows;
+}
+"""
+
+
+def pik_host_program(tmp_path, problem):
+    """ikgpu_problem_precompile also compiles the ik::pik program of a problem with several priority levels; its dumped source with
+    the __global__ wrapper replaced by a host loop."""
+    import ik_amd
+    src_dir, cache = tmp_path / "src", tmp_path / "cache"
+    src_dir.mkdir(), cache.mkdir()
+    old = {k: os.environ.get(k) for k in ("IKGPU_RTC_DUMP", "IKGPU_CACHE_DIR")}
+    os.environ.update(IKGPU_RTC_DUMP=str(src_dir), IKGPU_CACHE_DIR=str(cache))
+    try:
+        try:
+            ik_amd.precompile(problem)
+        except ik_amd.capi.IkgpuError as e:
+            pytest.skip("run-time compilation unavailable here: %s" % e)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    srcs = glob.glob(str(src_dir / "pik_static_*.hip"))
+    if not srcs:
+        pytest.skip("no compiled ik::pik program for this problem here")
+    assert len(srcs) == 1, srcs
+    text = open(srcs[0]).read()
+    host = tmp_path / "pik_program.cpp"
+    host.write_text(text[:text.index('extern "C" __global__')] + PIK_DRIVER)
+    lib = tmp_path / "pik_program.so"
+    dev = os.path.join(ROOT, "ik_amd", "csrc", "device")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-I" + dev, "-I" + os.path.join(ROOT, "ik_amd", "csrc"),
+                           "-I" + os.path.join(ROOT, "include"), "-o", str(lib), str(host)])
+    L = C.CDLL(str(lib))
+    L.static_host_pik.restype = C.c_int
+    return L
+
+
+@pytest.mark.parametrize("case", ["ur5_pos_then_ori", "ur5_full_then_elbow", "fixed_two_feet", "feet_then_pelvis", "demo_two_levels"])
+def test_static_pik_program_on_the_host_matches_the_oracle(tmp_path, native_built, case):
+    """The level loop with the projector in factored form and each level's damped pseudo-inverse as a dual Cholesky solve, against
+    the oracle's ik::pik (Jacobi SVD + complete orthogonal decomposition, oracle/ik_oracle.c iko_pik)."""
+    from test_gpu_pik import PIK_CASES
+    name, ff, specs, edit, projector_determined = PIK_CASES[case]
+    B = 24
+    ik, _, model, problem, _, om, ot, q0, tg = build(name, ff, specs, B, seed=4, xml_edit=edit, device=False)
+    levels = problem.max_priority_level() + 1
+    L = pik_host_program(tmp_path, problem)
+    p = lambda x: C.c_void_p(x.ctypes.data)
+    q0c, tgc = np.ascontiguousarray(q0), np.ascontiguousarray(tg)
+    for iters, step, tol, lam, da in ((1, 1.0, -1.0, [1.0] * levels, None), (4, 1.0, -1.0, [0.1] * levels, None),
+                                      (30, 0.5, 1e-8, [0.05, 0.1, 0.2][:levels], None),
+                                      (6, 1.0, -1.0, [0.1] * levels, 0.01 * np.cos(np.arange(model.nv)))):
+        if da is not None and not projector_determined:
+            continue
+        q, ok, it = np.empty_like(q0c), np.zeros(B, np.uint8), np.zeros(B, np.int32)
+        lam_a = np.asarray(lam, float)
+        L.static_host_pik(C.c_longlong(B), p(q0c), p(tgc), iters, C.c_double(step), C.c_double(tol), levels, p(lam_a),
+                          p(np.ascontiguousarray(da)) if da is not None else None, p(q), p(ok), p(it))
+        q_ref, ok_ref, it_ref = O.pik_batch(om, ot, tg, q0, O.pik_params(iters, step, tol, lam, None if da is None else list(da)), 1)
+        assert np.array_equal(ok, ok_ref) and np.array_equal(it, it_ref), (case, iters)
+        assert np.abs(q - q_ref).max() <= 1e-6, (case, iters, np.abs(q - q_ref).max())
