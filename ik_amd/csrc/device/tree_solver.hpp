@@ -296,6 +296,30 @@ struct LaneRows {
 #pragma unroll
         for (int k = 0; k < N; ++k) out[k] = (*this)(r0 + k);
     }
+    // The same, with the row addresses formed where they are used: `run` leaves the N row pointers loop-invariant, and the compiler
+    // hoists them out of the iteration loop -- 2 SGPRs per row, free while they fit, but a program that reads 45 target words (four
+    // tasks) then spills scalar registers into VGPR lanes (primal_solver.hpp: 80 v_writelane / 64 v_readlane per iteration).
+    template <int N>
+    IKD_FN void run_fresh(int r0, double (&out)[N]) const {
+#if IKD_ON_DEVICE
+        if (uniform) {
+            typedef const char __attribute__((address_space(1))) *GlobalBytes;
+            typedef const double __attribute__((address_space(1))) *GlobalDouble;
+            GlobalBytes g = (GlobalBytes)(base + static_cast<int64_t>(r0) * stride_bytes);
+            asm volatile("" : "+s"(g));
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                asm("" : "+s"(g));
+                uint32_t o = off;
+                asm volatile("" : "+v"(o));
+                out[k] = *reinterpret_cast<GlobalDouble>(g + o);
+                g += stride_bytes;
+            }
+            return;
+        }
+#endif
+        run<N>(r0, out);
+    }
 };
 
 // (R, p) <- (R, p) * placement i of a chain whose placement STRUCTURE is the compile-time code S (chain_hot.hpp ChainStruct: every

@@ -62,6 +62,7 @@ IKGPU_EMBED(ikgpu_src_chain_hot, "device/chain_hot.hpp")
 IKGPU_EMBED(ikgpu_src_tree_solver, "device/tree_solver.hpp")
 IKGPU_EMBED(ikgpu_src_generic_solver, "device/generic_solver.hpp")
 IKGPU_EMBED(ikgpu_src_pik_solver, "device/pik_solver.hpp")
+IKGPU_EMBED(ikgpu_src_primal_solver, "device/primal_solver.hpp")
 
 extern char **environ;   // (the compile worker inherits the caller's environment: IKGPU_CACHE_DIR, IKGPU_RTC_DEFINES, ...)
 
@@ -239,7 +240,8 @@ const Hdr kHeaders[] = {{"lane_math.hpp", ikgpu_src_lane_math, ikgpu_src_lane_ma
                         {"chain_hot.hpp", ikgpu_src_chain_hot, ikgpu_src_chain_hot_end},
                         {"tree_solver.hpp", ikgpu_src_tree_solver, ikgpu_src_tree_solver_end},
                         {"generic_solver.hpp", ikgpu_src_generic_solver, ikgpu_src_generic_solver_end},
-                        {"pik_solver.hpp", ikgpu_src_pik_solver, ikgpu_src_pik_solver_end}};
+                        {"pik_solver.hpp", ikgpu_src_pik_solver, ikgpu_src_pik_solver_end},
+                        {"primal_solver.hpp", ikgpu_src_primal_solver, ikgpu_src_primal_solver_end}};
 constexpr int kNumHeaders = static_cast<int>(sizeof kHeaders / sizeof kHeaders[0]);
 
 // The flag vector a program is compiled with.  if_convert (the generated lane programs): every two-armed choice whose arms the compiler
@@ -605,6 +607,124 @@ bool static_elimination(const ProblemHost &ph) {
     return np > 0 && (np > 8 || ph.rows > static_max_rows());
 }
 
+// ---- the primal, tree-sparse form of the static DLS program (device/primal_solver.hpp) ---------------------------------------------
+// Taken when the dense dual program would outgrow the register file (more than 12 solved rows) and the problem has what the form
+// covers: frame / alignment / posture rows on revolute, prismatic and free-flyer joints, no centre-of-mass task (rows dense over every
+// tangent direction), no constraint.  IKGPU_STATIC_FORM=primal takes it for every such problem, =dual never (tests, A/B).
+struct PrimalPlan {
+    bool ok = false;
+    int max_path = 1, max_pdofs = 1, nnz = 0, lds_words = 0;
+    int max_anc = 1;
+    std::vector<int> t_npath, t_path, t_nrpath, t_rpath, t_anchor, hidx, park_off, anc_n, anc;
+};
+
+constexpr int kPrimalLdsWords = 80;   // 40 KB per one-wave workgroup: four of them fill a CU's 160 KB, one wave per SIMD
+
+PrimalPlan primal_plan(const ProblemHost &ph) {
+    PrimalPlan pl;
+    const GenericHost &g = ph.generic;
+    const int32_t *I = g.ints.data();
+    const int nj = g.njoints, nt = ph.ntasks, nv = ph.nv;
+    if (g.has_com || !ph.constraints.empty() || nv > 36) return pl;
+    auto ndof = [&](int j) { return I[g.o_jtype + j] == ikdev::GJ_FREEFLYER ? 6 : I[g.o_jtype + j] == ikdev::GJ_UNIVERSE ? 0 : 1; };
+    auto path_of = [&](int joint) {   // root -> joint, without the universe
+        std::vector<int> p;
+        for (int j = joint; j > 0; j = I[g.o_parent + j]) p.insert(p.begin(), j);
+        return p;
+    };
+    std::vector<std::vector<int>> paths(static_cast<size_t>(nt)), rpaths(static_cast<size_t>(nt));
+    std::vector<char> coupled(static_cast<size_t>(nv) * nv, 0), act(static_cast<size_t>(nv), 0);
+    pl.t_anchor.assign(static_cast<size_t>(nt), -1);
+    for (int t = 0; t < nt; ++t) {
+        const int type = I[g.o_ttype + t];
+        if (type == IKGPU_CENTRE_OF_MASS) return pl;
+        if (type == IKGPU_POSTURE_ROW) {
+            const int c = I[g.o_tfjoint + t];   // (the row's tangent column)
+            if (c < 0 || c >= nv) return pl;
+            act[static_cast<size_t>(c)] = 1;
+            pl.t_anchor[static_cast<size_t>(t)] = c;
+            continue;
+        }
+        paths[static_cast<size_t>(t)] = path_of(I[g.o_tfjoint + t]);
+        rpaths[static_cast<size_t>(t)] = path_of(I[g.o_trjoint + t]);
+        std::vector<int> dofs;
+        for (int j : paths[static_cast<size_t>(t)]) {
+            // (the elimination order relies on the model's depth-first numbering: a joint's tangent directions follow its parent's)
+            if (I[g.o_parent + j] > 0 && I[g.o_idx_v + j] < I[g.o_idx_v + I[g.o_parent + j]]) return pl;
+            for (int u = 0; u < ndof(j); ++u) dofs.push_back(I[g.o_idx_v + j] + u);
+        }
+        if (dofs.empty()) return pl;   // a frame welded to the universe: nothing to solve for (the dual program handles the row)
+        for (int a : dofs) {
+            act[static_cast<size_t>(a)] = 1;
+            for (int b : dofs) coupled[static_cast<size_t>(a) * nv + b] = 1;
+        }
+        pl.t_anchor[static_cast<size_t>(t)] = *std::max_element(dofs.begin(), dofs.end());
+        pl.max_path = std::max<int>(pl.max_path, static_cast<int>(std::max(paths[static_cast<size_t>(t)].size(), rpaths[static_cast<size_t>(t)].size())));
+        pl.max_pdofs = std::max<int>(pl.max_pdofs, static_cast<int>(dofs.size()));
+    }
+    // the pattern of H and of its factor (no fill: the coupled earlier directions of c are ancestors of c on one task's path, hence
+    // coupled among themselves) -- verified here rather than assumed
+    for (int c = nv - 1; c >= 0; --c)
+        for (int d = 0; d < c; ++d)
+            for (int e = 0; e < d; ++e)
+                if (coupled[static_cast<size_t>(c) * nv + d] && coupled[static_cast<size_t>(c) * nv + e] && !coupled[static_cast<size_t>(d) * nv + e]) return pl;
+    pl.hidx.assign(static_cast<size_t>(nv) * nv, -1);
+    for (int c = 0; c < nv; ++c)
+        for (int d = 0; d <= c; ++d)
+            if ((c == d && act[static_cast<size_t>(c)]) || (c != d && coupled[static_cast<size_t>(c) * nv + d])) pl.hidx[static_cast<size_t>(c) * nv + d] = pl.nnz++;
+    if (pl.nnz > 420) return pl;
+    pl.anc_n.assign(static_cast<size_t>(nv), 0);
+    for (int c = 0; c < nv; ++c)
+        for (int d = 0; d < c; ++d) pl.anc_n[static_cast<size_t>(c)] += pl.hidx[static_cast<size_t>(c) * nv + d] >= 0 ? 1 : 0;
+    pl.max_anc = std::max(1, *std::max_element(pl.anc_n.begin(), pl.anc_n.end()));
+    pl.anc.assign(static_cast<size_t>(nv) * pl.max_anc, 0);
+    for (int c = 0; c < nv; ++c) {
+        int k = 0;
+        for (int d = 0; d < c; ++d)   // ascending
+            if (pl.hidx[static_cast<size_t>(c) * nv + d] >= 0) pl.anc[static_cast<size_t>(c) * pl.max_anc + k++] = d;
+    }
+    // finished columns parked in LDS until the back substitution: in elimination order (deepest first), the root joint's excepted
+    // (they are read back first), while the slab has room
+    int budget = kPrimalLdsWords;
+    if (const char *env = std::getenv("IKGPU_PRIMAL_LDS_WORDS")) budget = std::max(0, std::min(kPrimalLdsWords, std::atoi(env)));
+    pl.lds_words = ph.nq;   // the slab's first words hold q (primal_solver.hpp WsPrimal)
+    if (pl.lds_words > budget) return pl;
+    pl.park_off.assign(static_cast<size_t>(nv), -1);
+    std::vector<int> dof_joint(static_cast<size_t>(nv), 0);
+    for (int j = 1; j < nj; ++j)
+        for (int u = 0; u < ndof(j); ++u) dof_joint[static_cast<size_t>(I[g.o_idx_v + j] + u)] = j;
+    for (int c = nv - 1; c >= 0; --c) {
+        if (!act[static_cast<size_t>(c)] || I[g.o_parent + dof_joint[static_cast<size_t>(c)]] == 0) continue;
+        int words = 2;
+        for (int d = 0; d < c; ++d) words += pl.hidx[static_cast<size_t>(c) * nv + d] >= 0 ? 1 : 0;
+        if (pl.lds_words + words > budget) continue;
+        pl.park_off[static_cast<size_t>(c)] = pl.lds_words;
+        pl.lds_words += words;
+    }
+    pl.t_npath.assign(static_cast<size_t>(nt), 0);
+    pl.t_nrpath.assign(static_cast<size_t>(nt), 0);
+    pl.t_path.assign(static_cast<size_t>(nt) * pl.max_path, 0);
+    pl.t_rpath.assign(static_cast<size_t>(nt) * pl.max_path, 0);
+    for (int t = 0; t < nt; ++t) {
+        pl.t_npath[static_cast<size_t>(t)] = static_cast<int>(paths[static_cast<size_t>(t)].size());
+        pl.t_nrpath[static_cast<size_t>(t)] = static_cast<int>(rpaths[static_cast<size_t>(t)].size());
+        for (size_t k = 0; k < paths[static_cast<size_t>(t)].size(); ++k) pl.t_path[static_cast<size_t>(t) * pl.max_path + k] = paths[static_cast<size_t>(t)][k];
+        for (size_t k = 0; k < rpaths[static_cast<size_t>(t)].size(); ++k) pl.t_rpath[static_cast<size_t>(t) * pl.max_path + k] = rpaths[static_cast<size_t>(t)][k];
+    }
+    pl.ok = true;
+    return pl;
+}
+
+bool static_form_is_primal(const ProblemHost &ph) {
+    const char *form = std::getenv("IKGPU_STATIC_FORM");
+    if (form && std::strcmp(form, "dual") == 0) return false;
+    const bool forced = form && std::strcmp(form, "primal") == 0;
+    const int np = static_posture_rows(ph);
+    const int solve_rows = (np > 0 && (np > 8 || ph.rows > IKGPU_STATIC_MAX_ROWS)) ? ph.rows - np : ph.rows;
+    if (!forced && solve_rows <= 12) return false;
+    return primal_plan(ph).ok;
+}
+
 enum StaticKind { kStaticDls = 0, kStaticDlsRefill = 1, kStaticPik = 2, kStaticPikDa = 3 };
 
 std::string generic_static_source(const ProblemHost &ph, int kind = kStaticDls) {
@@ -613,8 +733,10 @@ std::string generic_static_source(const ProblemHost &ph, int kind = kStaticDls) 
     const int nj = g.njoints, nt = ph.ntasks;
     const int32_t *I = g.ints.data();
     const double *D = g.dbls.data();
+    const bool primal = (kind == kStaticDls || kind == kStaticDlsRefill) && static_form_is_primal(ph);
     std::string o = "#define IKD_STATIC_TABLES 1\n#include \"chain_kernel_body.hpp\"\n#include \"generic_solver.hpp\"\n";
     if (kind == kStaticPik || kind == kStaticPikDa) o += "#include \"pik_solver.hpp\"\n";
+    if (primal) o += "#include \"primal_solver.hpp\"\n";
     o += "namespace {\nstruct T {\n";
     auto scalar = [&](const char *n, long long v) { o += std::string("    static constexpr int ") + n + " = " + std::to_string(v) + ";\n"; };
     scalar("njoints", nj); scalar("nq", ph.nq); scalar("nv", ph.nv); scalar("ntasks", nt); scalar("M", ph.rows);
@@ -658,7 +780,34 @@ std::string generic_static_source(const ProblemHost &ph, int kind = kStaticDls) 
         }
         scalar("pik_max_rows", max_rows); scalar("pik_last_level", last); scalar("pik_basis_rows", I[g.o_lvlrow0 + last]);
     }
+    if (!primal) scalar("primal", 0);
+    if (primal) {
+        const PrimalPlan pl = primal_plan(ph);
+        scalar("primal", 1); scalar("max_path", pl.max_path); scalar("max_pdofs", pl.max_pdofs); scalar("nnz", pl.nnz); scalar("lds_words", std::max(1, pl.lds_words));
+        o += int_array("t_npath", pl.t_npath.begin(), nt) + int_array("t_path", pl.t_path.begin(), nt * pl.max_path);
+        o += int_array("t_nrpath", pl.t_nrpath.begin(), nt) + int_array("t_rpath", pl.t_rpath.begin(), nt * pl.max_path);
+        o += int_array("t_anchor", pl.t_anchor.begin(), nt) + int_array("hidx", pl.hidx.begin(), ph.nv * ph.nv) + int_array("park_off", pl.park_off.begin(), ph.nv);
+        {
+            std::vector<int> anch_n(static_cast<size_t>(ph.nv), 0), anch_t(static_cast<size_t>(ph.nv) * nt, 0);
+            for (int t = 0; t < nt; ++t) {
+                const int c = pl.t_anchor[static_cast<size_t>(t)];
+                if (c >= 0) anch_t[static_cast<size_t>(c) * nt + anch_n[static_cast<size_t>(c)]++] = t;
+            }
+            o += int_array("anch_n", anch_n.begin(), ph.nv) + int_array("anch_t", anch_t.begin(), ph.nv * nt);
+        }
+        scalar("max_anc", pl.max_anc);
+        o += int_array("anc_n", pl.anc_n.begin(), ph.nv) + int_array("anc", pl.anc.begin(), ph.nv * pl.max_anc);
+    }
     o += "};\n}  // namespace\n";
+    if (primal) {   // (lock-step only: a stop-rule batch larger than the machine runs this kernel too)
+        o += "extern \"C\" __global__ __launch_bounds__(64) void ikgpu_lane_dls(const ikdev::GenericKernelArgs a) {\n"
+             "    __shared__ double slab[T::lds_words][64];\n"
+             "    double w[T::ws_words];\n"
+             "    ikdev::dls_primal_body_ws(a, T{}, static_cast<int64_t>(blockIdx.x) * 64 + threadIdx.x, ikdev::WsReg{w}, ikdev::LdsColumn{&slab[0][threadIdx.x], 64},\n"
+             "                              [](bool act) { return __any(act) != 0; }, static_cast<int64_t>(blockIdx.x) * 64);\n"
+             "}\n";
+        return o;
+    }
     if (kind == kStaticPik || kind == kStaticPikDa)
         o += std::string("extern \"C\" __global__ __launch_bounds__(64) void ikgpu_lane_pik(const ikdev::PikKernelArgs a) {\n"
                          "    double w[T::ws_words];\n"
@@ -735,7 +884,9 @@ bool rtc_generic_static_available(const ProblemHost &gen, bool compile, uint64_t
     // (with the PostureTask rows eliminated from the solve the caps apply to the rows that are left: the reference demo with every line
     // switched on -- M = 29, 16 of them posture rows -- is a 13 x 13 system)
     const int solve_rows = rtc_static_solve_rows(gen);
-    if (gen.rows < 1 || solve_rows < 1 || solve_rows > static_max_rows() || gen.rows > 64 || gen.nv > 36 || gen.generic.ws_words > 2400) return false;
+    // (the primal tree-sparse form, primal_solver.hpp, keeps no dense matrix: it is not bound by the dual program's row cap)
+    const bool primal = static_form_is_primal(gen);
+    if (gen.rows < 1 || solve_rows < 1 || (!primal && solve_rows > static_max_rows()) || gen.rows > 64 || gen.nv > 36 || gen.generic.ws_words > 2400) return false;
     if (!rtc_api().ok) return false;
     if (!compile) return true;
     const std::string src = generic_static_source(gen);
@@ -746,7 +897,7 @@ bool rtc_generic_static_available(const ProblemHost &gen, bool compile, uint64_t
 
 // The refill program of a static lane program (programs above 12 rows spill, and a spilling program is kept off the refill path
 // below: do not even compile it).
-static bool refill_program_worth_compiling(const ProblemHost &gen) { return rtc_static_solve_rows(gen) <= 12; }
+static bool refill_program_worth_compiling(const ProblemHost &gen) { return rtc_static_solve_rows(gen) <= 12 && !static_form_is_primal(gen); }
 
 static HotCode &refill_code(const ProblemHost &gen) {   // (called WITHOUT g_mu: the compiler may run)
     const std::string src = generic_static_source(gen, kStaticDlsRefill);
@@ -854,8 +1005,8 @@ hipError_t rtc_launch_generic_static(const ProblemHost &gen, uint64_t key, const
 namespace ikgpu {
 
 // ---- ik::pik as a compiled lane program (device/pik_solver.hpp static_pik) -------------------------------------------------------------
-// Eligibility: what the DLS program takes (rows, nv, workspace), at least two non-empty levels (one level IS the DLS iteration and
-// runs on the problem's DLS kernel), every level within 12 rows (its dual system is unrolled in registers).  lambda > 0 on every
+// Eligibility: what the DLS program takes (rows, nv, workspace), every level within 12 rows (one level without a secondary step IS
+// the DLS iteration and never gets here: capi.cpp routes it to the problem's DLS kernel) (its dual system is unrolled in registers).  lambda > 0 on every
 // level is a property of the CALL (capi.cpp checks it): lambda = 0 stays on the one-sided-Jacobi interpreter.
 namespace {
 struct PikModule {
@@ -876,7 +1027,7 @@ bool rtc_pik_static_available(const ProblemHost &gen, bool with_da, bool compile
         levels += ml > 0 ? 1 : 0;
         widest = std::max(widest, ml);
     }
-    if (levels < 2 || widest > 12 || gen.rows > static_max_rows() || gen.nv > 36 || g.ws_words > 2400 || gen.crows > 0) return false;
+    if (levels < 1 || widest > 12 || gen.rows > static_max_rows() || gen.nv > 36 || g.ws_words > 2400 || gen.crows > 0) return false;
     if (!compile) return true;
     const std::string src = generic_static_source(gen, with_da ? kStaticPikDa : kStaticPik);
     const uint64_t key = source_hash(with_defines(src));

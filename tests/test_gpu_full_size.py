@@ -42,8 +42,9 @@ twin) -- rule S: the device is fed the ORACLE's iterate at each step and must re
       lambda^2 ~ 1.2e5, where the dual solve's dq = J^T y is formed from J's rows and stays in range(J^T).  Measured (device and
       lane emulator agree): median one-step error 4.2e-13 (near) / 2.5e-12 rad (uniform) against the oracle's 1.7e-14 / 2.1e-13 --
       12-25x, at 0.2 u kappa |dq|.  The symmetric rule S3 does not apply; asserted instead, per lane (first 1024), the a-priori bound
-      of a Cholesky solve (Higham, ASNA 2nd ed., Thm 10.4): e_dev <= (3 nv + 1) u kappa_2(H) |dq|, kappa from the oracle's J (measured:
-      <= 0.02 of the bound).
+      of a Cholesky solve (Higham, ASNA 2nd ed., Thm 10.4): e_dev <= (3 nv + 1) u kappa_2(H) |dq| + 30 u / (2 lambda) + 16 u |q|, kappa
+      from the oracle's J; the second term is the forward error of e (FK through 8 joints) times the gain of a damped step, the
+      third the rounding of the update itself -- what is left on a converged lane (measured: <= 0.1 of the bound).
   Rule 3' (config 3, arbitrated lanes of the trajectory test): a chaotic lane multiplies every step's rounding error by the same
       amplification for both sides, so the ratio r there is distributed like the one-step ratio.  The tree kernel's accuracy class
       rho = the median one-step ratio, measured in the test on 8192 lanes against _Float128 (12-25), scales rule 3: a lane fails when
@@ -287,8 +288,11 @@ def _step_synchronised(torch, model, problem, data, tasks, q0, T, steps, label, 
                 NA, nv, lam2, u = 1024, model.nv, 1e-4, 2.0 ** -53
                 s1 = np.array([np.linalg.svd(O.evaluate(om, tasks, tg[b], q[b])[1], compute_uv=False)[0] for b in range(NA)])
                 step = np.abs(q_x[:NA] - q[:NA]).max(axis=1)
-                # (+ the rounding of the update itself -- q + dq, the quaternion product, the clamp: 16 ulp of the largest entry of q)
-                bound = (3 * nv + 1) * u * (s1 * s1 + lam2) / lam2 * step + 16.0 * u * np.maximum(1.0, np.abs(q[:NA]).max(axis=1))
+                # + what does not shrink with the step: the forward error of e itself -- FK through 8 joints, three products each,
+                #   ~ 30 u on entries of size <= 1 (rotations, metres) -- times the gain of the damped step, |J^T (J J^T + lambda^2)^-1| <=
+                #   1 / (2 lambda); + the rounding of the update (q + dq, the quaternion product, the clamp: 16 ulp of q's largest entry)
+                bound = ((3 * nv + 1) * u * (s1 * s1 + lam2) / lam2 * step + 30.0 * u / (2.0 * np.sqrt(lam2))
+                         + 16.0 * u * np.maximum(1.0, np.abs(q[:NA]).max(axis=1)))
                 rec["max_error_over_apriori_bound"].append(float((e_dev[:NA] / bound).max()))
                 assert (e_dev[:NA] <= bound).all(), (label, k, float((e_dev[:NA] / bound).max()))
         q = q_next

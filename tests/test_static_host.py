@@ -18,21 +18,29 @@ from test_gpu_generic import CASES as GENERIC, build
 from test_gpu_constraints import CASES as CONSTRAINED
 
 HOST_DRIVER = r'''
+#include "primal_solver.hpp"
+template <class TB>
+void one_lane(const ikdev::GenericKernelArgs &a, long long gid) {
+    double w[TB::ws_words];
+    if constexpr (TB::primal != 0) {   // the primal tree-sparse form (device/primal_solver.hpp): its LDS slab is a plain array here
+        double slab[TB::lds_words];
+        ikdev::dls_primal_body_ws(a, TB{}, gid, ikdev::WsReg{w}, ikdev::LdsColumn{slab, 1}, [](bool act) { return act; });
+    } else {
+        ikdev::dls_generic_body_ws(a, TB{}, gid, ikdev::WsReg{w}, [](bool act) { return act; });
+    }
+}
 extern "C" int static_host_solve(long long B, const double *q0, const double *targets, int max_it, double damping, double step, double stop_tol,
                                  double *q_out, unsigned char *ok, int *iters) {
     ikdev::GenericKernelArgs a{};
     a.prm.max_iterations = max_it; a.prm.lam2 = damping * damping; a.prm.step_length = step; a.prm.stop_sq_tol = stop_tol;
     a.layout = ikdev::LAYOUT_AOS; a.B = B; a.q0 = q0; a.targets = targets; a.q_out = q_out; a.success = ok; a.iters = iters;
-    for (long long gid = 0; gid < B; ++gid) {
-        double w[T::ws_words];
-        ikdev::dls_generic_body_ws(a, T{}, gid, ikdev::WsReg{w}, [](bool act) { return act; });
-    }
-    return T::elim;
+    for (long long gid = 0; gid < B; ++gid) one_lane<T>(a, gid);
+    return T::elim + 2 * T::primal;
 }
 '''
 
 
-def host_program(tmp_path, problem, want_static_name=True):
+def host_program(tmp_path, problem, want_static_name=True, opt="-O1"):
     import ik_amd
     src_dir, cache = tmp_path / "src", tmp_path / "cache"
     src_dir.mkdir(), cache.mkdir()
@@ -59,7 +67,7 @@ def host_program(tmp_path, problem, want_static_name=True):
     host.write_text(text[:cut] + HOST_DRIVER)
     lib = tmp_path / "program.so"
     dev = os.path.join(ROOT, "ik_amd", "csrc", "device")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-I" + dev, "-I" + os.path.join(ROOT, "ik_amd", "csrc"),
+    subprocess.check_call(["g++", opt, "-std=c++17", "-fPIC", "-shared", "-I" + dev, "-I" + os.path.join(ROOT, "ik_amd", "csrc"),
                            "-I" + os.path.join(ROOT, "include"), "-o", str(lib), str(host)])
     L = C.CDLL(str(lib))
     L.static_host_solve.restype = C.c_int
@@ -103,6 +111,37 @@ def test_static_program_on_the_host_matches_the_oracle(tmp_path, native_built, c
             q_ref, ok_ref, it_ref = O.dls_batch(om, ot, tg, q0, prm, 1)
         q, ok, it, is_elim = solve(L, q0, tg, iters, damping, step, tol)
         assert is_elim == elim, (kernel, is_elim)
+        assert np.array_equal(it, it_ref) and np.array_equal(ok, ok_ref), (case, iters, it, it_ref)
+        d = np.abs(q - q_ref).max()
+        assert d <= bar, (case, kernel, iters, d)
+
+
+# case -> (force the form with IKGPU_STATIC_FORM, expected T::primal)
+PRIMAL_CASES = {
+    "three_feet_frames": (None, 1), "rows_16": (None, 1), "feet_frames_beyond_the_register_solve": (None, 1), "nv_30": (None, 1),
+    # forced onto the form (IKGPU_STATIC_FORM=primal; with 12 solved rows or fewer the dual program is the default):
+    "posture_regulariser": ("primal", 1),       # 12 frame rows + 16 posture rows (diagonal entries of H)
+    "shared_joints": ("primal", 1), "moving_reference_prismatic": ("primal", 1), "fixed_two_feet_priorities": ("primal", 1),
+    "com_under_feet": (None, 0),                # a centre-of-mass task: rows dense over every direction -- the dual program keeps it
+}
+
+
+@pytest.mark.parametrize("case", sorted(PRIMAL_CASES))
+def test_primal_tree_sparse_program_on_the_host_matches_the_oracle(tmp_path, native_built, monkeypatch, case):
+    """The primal, tree-sparse form of the static program (device/primal_solver.hpp: what more than 12 solved rows run on): per-task
+    path FK, blocks accumulated into the no-fill normal matrix, leaf-to-root elimination with parked columns, against the oracle's
+    dense dual solve.  Bars: one step 1e-9 (kappa(H) u ~ 1e-11 of the step), the converging runs 1e-6."""
+    force, want = PRIMAL_CASES[case]
+    name, ff, specs, edit = GENERIC[case]
+    if force:
+        monkeypatch.setenv("IKGPU_STATIC_FORM", force)
+    B = 24
+    ik, _, model, problem, _, om, ot, q0, tg = build(name, ff, specs, B, seed=11, xml_edit=edit, device=False)
+    kernel, L = host_program(tmp_path, problem, opt="-O0")    # (the host compiler spends a minute per program on the inlined loops at -O1)
+    for iters, damping, step, tol, bar in ((1, 1e-2, 1.0, -1.0, 1e-9), (3, 1e-2, 1.0, -1.0, 1e-7), (40, 1e-1, 0.5, 1e-4, 1e-6), (0, 1e-2, 1.0, 1e-4, 0.0)):
+        q_ref, ok_ref, it_ref = O.dls_batch(om, ot, tg, q0, O.params(iters, damping, step, tol), 1)
+        q, ok, it, flags = solve(L, q0, tg, iters, damping, step, tol)
+        assert flags >> 1 == want, (kernel, flags)
         assert np.array_equal(it, it_ref) and np.array_equal(ok, ok_ref), (case, iters, it, it_ref)
         d = np.abs(q - q_ref).max()
         assert d <= bar, (case, kernel, iters, d)
