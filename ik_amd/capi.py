@@ -32,6 +32,7 @@ SYMBOLS = [
     "ikgpu_problem_precompile", "ikgpu_rtc_worker_compile",
     "ikgpu_shard_range", "ikgpu_shard_slot_layout", "ikgpu_shard_slot_bytes", "ikgpu_shard_group_create", "ikgpu_shard_group_destroy",
     "ikgpu_shard_group_size", "ikgpu_shard_group_problem", "ikgpu_shard_group_uses_rccl", "ikgpu_shard_group_stream",
+    "ikgpu_shard_group_last_issue_us",
     "ikgpu_dls_solve_batch_sharded", "ikgpu_shard_group_synchronize", "ikgpu_targets_from_pose7",
 ]
 MAX_PIK_LEVELS, MAX_PIK_DA = 8, 128

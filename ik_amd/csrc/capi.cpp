@@ -2,7 +2,10 @@
 // solve runs the gfx950 kernels (kernels.hip) or fails with a message -- there is no CPU path.
 #include <hip/hip_runtime.h>
 
+#include <time.h>
+
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <exception>
@@ -25,6 +28,24 @@ struct Staging {
     size_t cap = 0;
 };
 constexpr size_t kStageLimit = size_t(1) << 20;  // batches whose buffers total at most 1 MiB take the staged path
+
+// Per-phase wall clock of the pipelined host entry (host_solve below), switched on by IKGPU_HOST_TRACE=<file>: one line per call --
+// total and the time spent waiting for the pipe's mutex, in set-up, enqueueing copies and launches, and in each of the final waits.
+// (Round 3 saw 30-75 ms stalls about once per hundred calls: this is how the phase that carries them is found;
+// tools/host_entry_tails.py reads the file.)
+struct HostTrace {
+    FILE *f = nullptr;
+    bool on = false;
+    HostTrace() {
+        if (const char *path = std::getenv("IKGPU_HOST_TRACE")) { f = std::fopen(path, "a"); on = f != nullptr; }
+    }
+    ~HostTrace() { if (f) std::fclose(f); }
+    static double now() {
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return 1e3 * static_cast<double>(ts.tv_sec) + 1e-6 * static_cast<double>(ts.tv_nsec);
+    }
+};
 
 // Larger batches through the host-pointer entry points: a pipeline the problem keeps -- one device arena (grow-only), three
 // streams, events -- so that a call allocates nothing and never synchronises the device: chunks of problems flow
@@ -288,7 +309,10 @@ int host_solve(const ikgpu_problem *p, int64_t B, const double *q0, const double
         // The pipelined path.  Chunk k lives compactly on the device ([rows][b_k], component-major, or [b_k][rows]); for the
         // component-major layout one 2-D copy per array gathers / scatters the chunk's columns of the caller's [rows][B] arrays.
         // Pinned caller buffers make every copy asynchronous; pageable ones still work (the runtime stages them).
+        static HostTrace trace;
+        const double t_enter = trace.on ? HostTrace::now() : 0.0;
         std::lock_guard<std::mutex> plock(p->pipe.mu);
+        const double t_locked = trace.on ? HostTrace::now() : 0.0;
         HostPipe &pp = p->pipe;
         // Chunks that fill the device: one problem per lane means a launch lasts as long as ONE wave whatever its size, and kernels of
         // different streams were measured NOT to overlap here (B = 65536 in 8 chunks on 8 streams: 0.93 ms; 2 chunks: 0.55 ms; 1 chunk,
@@ -335,6 +359,7 @@ int host_solve(const ikgpu_problem *p, int64_t B, const double *q0, const double
                              : hipMemcpyAsync(static_cast<char *>(host) + off, dev, bytes, hipMemcpyDeviceToHost, st);
         };
         int rc = IKGPU_OK;
+        const double t_setup = trace.on ? HostTrace::now() : 0.0;
         for (int64_t k = 0; k < nchunks && rc == IKGPU_OK && e == hipSuccess; ++k) {
             const int64_t b0 = k * chunk, bk = std::min<int64_t>(chunk, B - b0);
             double *d_q0 = reinterpret_cast<double *>(take(8 * nq * bk)), *d_t = reinterpret_cast<double *>(take(8 * nt * bk));
@@ -358,10 +383,22 @@ int host_solve(const ikgpu_problem *p, int64_t B, const double *q0, const double
             if (iters) step(copy(d_i, nullptr, iters, 1, 4, b0, bk, false, pp.out));
             if (success) step(copy(d_s, nullptr, success, 1, 1, b0, bk, false, pp.out));
         }
-        // the arena is reused by the next call: everything in flight has to land first (also on a failure half way through)
-        hipError_t w = hipStreamSynchronize(pp.in);
-        for (hipStream_t r : pp.run) { const hipError_t x = hipStreamSynchronize(r); if (w == hipSuccess) w = x; }
+        // The arena is reused by the next call: everything in flight has to land first.  When every chunk was enqueued, the copy-out
+        // stream is the LAST link of every chain (in -> run[k] -> out, by events), so one wait on it covers all three; after a failure
+        // half way through every stream that was touched is waited for.  (Round 3 waited for all ten streams, used or not.)
+        const double t_enqueued = trace.on ? HostTrace::now() : 0.0;
+        hipError_t w = hipSuccess;
+        if (rc != IKGPU_OK || e != hipSuccess) {
+            w = hipStreamSynchronize(pp.in);
+            for (int64_t k = 0; k < std::min<int64_t>(nchunks, HostPipe::kRunStreams); ++k) { const hipError_t x = hipStreamSynchronize(pp.run[k]); if (w == hipSuccess) w = x; }
+        }
         { const hipError_t x = hipStreamSynchronize(pp.out); if (w == hipSuccess) w = x; }
+        if (trace.on) {
+            const double t_done = HostTrace::now();
+            std::fprintf(trace.f, "B %lld chunks %lld total_ms %.4f lock %.4f setup %.4f enqueue %.4f wait %.4f\n", static_cast<long long>(B),
+                         static_cast<long long>(nchunks), t_done - t_enter, t_locked - t_enter, t_setup - t_locked, t_enqueued - t_setup, t_done - t_enqueued);
+            std::fflush(trace.f);
+        }
         if (rc != IKGPU_OK) return rc;
         step(w);
         if (e != hipSuccess) return hip_fail(e, "host-pointer solve (pipeline)");
@@ -581,7 +618,9 @@ int ikgpu_problem_precompile(const ikgpu_model *h, const ikgpu_task *tasks, int3
         {   // a problem with several priority levels may be handed to ik::pik: its compiled lane program (without the secondary step)
             const ikgpu::ProblemHost gen = ph.kind == ikgpu::KernelKind::Generic
                                                ? ph : ikgpu::analyse_problem(h->m, tasks, ntasks, /*force_generic=*/true, constraints, nconstraints);
-            if (ikgpu::rtc_pik_static_available(gen, false, /*compile=*/false, nullptr)) (void)ikgpu::rtc_pik_static_available(gen, false, /*compile=*/true, nullptr);
+            // (one level needs the program only for a secondary step, da != 0: compiled at the first such call)
+            if (gen.generic.nlevels >= 2 && ikgpu::rtc_pik_static_available(gen, false, /*compile=*/false, nullptr))
+                (void)ikgpu::rtc_pik_static_available(gen, false, /*compile=*/true, nullptr);
         }
         if (out && cap) {
             std::strncpy(out, got.c_str(), cap - 1);

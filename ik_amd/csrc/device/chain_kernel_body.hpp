@@ -96,7 +96,7 @@ IKD_FN void dls_chain_body(const ChainKernelArgs<NJ> &a, const Desc &d, int64_t 
 // zeroes both, so the next launch on the same stream finds the slot clean (host: QueuePool in kernels.hpp).
 // iterate(q, oMt, have) runs ONE iteration of this lane's problem in place and returns "the visitor stopped it before the step".
 template <int NJ, class IterFn>
-__device__ __forceinline__ void chain_refill_loop(const ChainKernelArgs<NJ> &a, unsigned long long *queue, int chunk, IterFn iterate) {
+__device__ __forceinline__ void chain_refill_loop(const ChainKernelArgs<NJ> &a, unsigned long long *queue, int chunk_and_batch, IterFn iterate) {
     const int lane = static_cast<int>(threadIdx.x) & 63;                 // one wave per workgroup
     const int64_t first_round = static_cast<int64_t>(gridDim.x) * 64;
     int64_t b = static_cast<int64_t>(blockIdx.x) * 64 + lane;
@@ -113,19 +113,27 @@ __device__ __forceinline__ void chain_refill_loop(const ChainKernelArgs<NJ> &a, 
     // saturated the memory-side atomic unit (measured: ~30-70 M same-address atomics/s device-wide, every refill waiting ~30 us).
     int64_t pool_lo = 0, pool_hi = 0;
     bool exhausted = first_round >= a.B;                                 // the head has passed the end of the batch
+    // Refill events are BATCHED: a finished lane stores its result at once and then waits until `batch` lanes of the wave are idle
+    // (or no lane is active any more) -- one ballot, one reserve update and one round trip of loads per event instead of per
+    // iteration.  With targets near the start every lane is done within two or three iterations, an event per iteration cost
+    // as much as the iterations themselves (round 3: refill 1.5-2x slower than lock-step there); with far targets the wave's
+    // stragglers set the pace either way.  chunk_and_batch: chunk | batch << 16 (kernels.hip refill_chunk).
+    const int batch = chunk_and_batch >> 16, chunk = chunk_and_batch & 0xffff;
     while (__any(have)) {
         const bool stop_now = iterate(q, oMt, have) && have;
         ++it;
         const bool done = have && (stop_now || it >= max_it);
-        if (__any(done)) {
-            if (done) {
+        if (done) {
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) a.q_out[at(a.layout, a.B, a.nq, a.qidx[j], b)] = q[j];
-                if (a.success) a.success[b] = stop_now ? 1 : 0;
-                a.iters[b] = stop_now ? it - 1 : max_it;                 // never null here: the pass-through kernel reads it
-            }
-            const unsigned long long mask = __ballot(done);
-            const int need = __popcll(mask);
+            for (int j = 0; j < NJ; ++j) a.q_out[at(a.layout, a.B, a.nq, a.qidx[j], b)] = q[j];
+            if (a.success) a.success[b] = stop_now ? 1 : 0;
+            a.iters[b] = stop_now ? it - 1 : max_it;                     // never null here: the pass-through kernel reads it
+            have = false;
+        }
+        const unsigned long long mask = __ballot(!have);                 // idle lanes: finished (or never had a problem)
+        const int need = __popcll(mask);
+        const bool supply = pool_hi > pool_lo || !exhausted;             // (wave-uniform)
+        if (supply && (need >= batch || need == 64)) {
             const int rank = __popcll(mask & ((1ull << lane) - 1ull));
             const int64_t avail = pool_hi - pool_lo;
             int64_t nb = pool_lo + rank;                                 // ranks below `avail` are served from the reserve
@@ -143,15 +151,13 @@ __device__ __forceinline__ void chain_refill_loop(const ChainKernelArgs<NJ> &a, 
             } else {
                 pool_lo += need < avail ? need : avail;
             }
-            if (done) {
-                have = got;
-                if (got) {
-                    b = nb;
+            if (!have && got) {
+                have = true;
+                b = nb;
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) q[j] = a.q0[at(a.layout, a.B, a.nq, a.qidx[j], b)];
-                    load_target(a, b, oMt);
-                    it = 0;
-                }
+                for (int j = 0; j < NJ; ++j) q[j] = a.q0[at(a.layout, a.B, a.nq, a.qidx[j], b)];
+                load_target(a, b, oMt);
+                it = 0;
             }
         }
     }

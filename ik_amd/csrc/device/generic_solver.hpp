@@ -754,8 +754,10 @@ IKD_FN void generic_dls(const TB &T, const LoopParams &prm, const WS &ws, const 
             // max_iterations (the stepped q, dls.cpp:76-77) stores its result and takes the next unsolved problem
             ++lit;
             const bool done = had && (stop_now || lit >= prm.max_iterations);
+            active = had && !done;   // (a lane that ran out of iterations is as finished as one whose visitor fired)
+            refill.took = false;
             const bool any_left = refill.step(T, done, stop_now, stop_now ? lit - 1 : prm.max_iterations, ws, targets, active);
-            if (done) { lit = 0; success = false; }
+            if (refill.took) { lit = 0; success = false; }
             if (!any_left) break;
         } else {
             if (!any_active(active)) break;
@@ -819,10 +821,11 @@ struct GenericRefill {
     static constexpr bool on = true;
     const GenericKernelArgs *a;
     unsigned long long *queue;
-    int chunk;
+    int chunk, batch;   // problems pulled from the head at a time; idle lanes a refill event waits for
     int64_t b, first_round, pool_lo, pool_hi;
     bool exhausted;
     bool start;
+    bool took;          // (set by step) this lane has just taken a new problem
 
     template <class TB>
     __device__ __forceinline__ LaneRows target_rows(const TB &T, int64_t bb) const {
@@ -834,15 +837,17 @@ struct GenericRefill {
     __device__ __forceinline__ bool step(const TB &T, bool done, bool stopped, int iters, const WS &ws, LaneRows &tl, bool &active) {
         const GenericKernelArgs &A = *a;
         const int lane = static_cast<int>(threadIdx.x) & 63;
-        if (__any(done)) {
-            if (done) {
-                IKD_UNROLL
-                for (int i = 0; i < T.nq; ++i) A.q_out[at(A.layout, A.B, T.nq, i, b)] = ws[T.off_q + i];
-                if (A.success) A.success[b] = stopped ? 1 : 0;
-                if (A.iters) A.iters[b] = iters;
-            }
-            const unsigned long long mask = __ballot(done);
-            const int need = __popcll(mask);
+        if (done) {   // the result leaves at once; the lane then idles until the wave's next refill event (batched: chain_kernel_body.hpp)
+            IKD_UNROLL
+            for (int i = 0; i < T.nq; ++i) A.q_out[at(A.layout, A.B, T.nq, i, b)] = ws[T.off_q + i];
+            if (A.success) A.success[b] = stopped ? 1 : 0;
+            if (A.iters) A.iters[b] = iters;
+            active = false;
+        }
+        const unsigned long long mask = __ballot(!active);
+        const int need = __popcll(mask);
+        const bool supply = pool_hi > pool_lo || !exhausted;          // (wave-uniform)
+        if (supply && (need >= batch || need == 64)) {
             const int rank = __popcll(mask & ((1ull << lane) - 1ull));
             const int64_t avail = pool_hi - pool_lo;
             int64_t nb = pool_lo + rank;
@@ -860,14 +865,13 @@ struct GenericRefill {
             } else {
                 pool_lo += need < avail ? need : avail;
             }
-            if (done) {
-                active = got;
-                if (got) {
-                    b = nb;
-                    IKD_UNROLL
-                    for (int i = 0; i < T.nq; ++i) ws[T.off_q + i] = A.q0[at(A.layout, A.B, T.nq, i, b)];
-                    tl = target_rows(T, b);
-                }
+            if (!active && got) {
+                active = true;
+                took = true;
+                b = nb;
+                IKD_UNROLL
+                for (int i = 0; i < T.nq; ++i) ws[T.off_q + i] = A.q0[at(A.layout, A.B, T.nq, i, b)];
+                tl = target_rows(T, b);
             }
         }
         return __any(active) != 0;
@@ -878,7 +882,7 @@ template <class TB, class WS>
 __device__ __forceinline__ void dls_generic_refill_body(const GenericKernelArgs &a, const TB &T, int64_t wave, int64_t nwaves, const WS &ws,
                                                         unsigned long long *queue, int chunk) {
     const int lane = static_cast<int>(threadIdx.x) & 63;
-    GenericRefill rf{&a, queue, chunk, wave * 64 + lane, nwaves * 64, 0, 0, nwaves * 64 >= a.B, wave * 64 + lane < a.B};
+    GenericRefill rf{&a, queue, chunk & 0xffff, chunk >> 16, wave * 64 + lane, nwaves * 64, 0, 0, nwaves * 64 >= a.B, wave * 64 + lane < a.B, false};
     const int64_t bs = rf.start ? rf.b : a.B - 1;
     IKD_UNROLL
     for (int i = 0; i < T.nq; ++i) ws[T.off_q + i] = a.q0[at(a.layout, a.B, T.nq, i, bs)];

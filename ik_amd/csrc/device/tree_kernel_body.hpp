@@ -106,11 +106,12 @@ struct TreeRefill {
     static constexpr bool on = true;
     const TreeKernelArgs<NJ, NCH> *a;
     unsigned long long *queue;
-    int chunk;
+    int chunk, batch;   // problems pulled from the head at a time; idle lanes a refill event waits for
     bool fixed_base;
     int64_t b, first_round, pool_lo, pool_hi;
     bool exhausted;
     bool start;   // this lane holds a problem of the first (static) round
+    bool took;    // (set by step) this lane has just taken a new problem: its iteration count restarts
 
     __device__ __forceinline__ void load(int64_t bb, double (&qb)[7], double (&qj0)[NJ], double (&qj1)[NJ]) const {
         const TreeKernelArgs<NJ, NCH> &A = *a;
@@ -133,21 +134,23 @@ struct TreeRefill {
                                          bool &active, ReloadFn reload_targets) {
         const TreeKernelArgs<NJ, NCH> &A = *a;
         const int lane = static_cast<int>(threadIdx.x) & 63;
-        if (__any(done)) {
-            if (done) {
+        if (done) {   // the result leaves at once; the lane then idles until the wave's next refill event (batched: chain_kernel_body.hpp)
 #pragma unroll
-                for (int k = 0; k < 7; ++k)
-                    if (!fixed_base) A.q_out[at(A.layout, A.B, A.nq, k, b)] = qb[k];
+            for (int k = 0; k < 7; ++k)
+                if (!fixed_base) A.q_out[at(A.layout, A.B, A.nq, k, b)] = qb[k];
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    A.q_out[at(A.layout, A.B, A.nq, A.qidx[0][j], b)] = qj0[j];
-                    if (NCH > 1) A.q_out[at(A.layout, A.B, A.nq, A.qidx[NCH - 1][j], b)] = qj1[j];
-                }
-                if (A.success) A.success[b] = stopped ? 1 : 0;
-                A.iters[b] = iters;                                       // never null here: the pass-through kernel reads it
+            for (int j = 0; j < NJ; ++j) {
+                A.q_out[at(A.layout, A.B, A.nq, A.qidx[0][j], b)] = qj0[j];
+                if (NCH > 1) A.q_out[at(A.layout, A.B, A.nq, A.qidx[NCH - 1][j], b)] = qj1[j];
             }
-            const unsigned long long mask = __ballot(done);
-            const int need = __popcll(mask);
+            if (A.success) A.success[b] = stopped ? 1 : 0;
+            A.iters[b] = iters;                                       // never null here: the pass-through kernel reads it
+            active = false;
+        }
+        const unsigned long long mask = __ballot(!active);
+        const int need = __popcll(mask);
+        const bool supply = pool_hi > pool_lo || !exhausted;          // (wave-uniform)
+        if (supply && (need >= batch || need == 64)) {
             const int rank = __popcll(mask & ((1ull << lane) - 1ull));
             const int64_t avail = pool_hi - pool_lo;
             int64_t nb = pool_lo + rank;
@@ -165,14 +168,13 @@ struct TreeRefill {
             } else {
                 pool_lo += need < avail ? need : avail;
             }
-            if (done) {
-                active = got;
-                if (got) {
-                    b = nb;
-                    load(b, qb, qj0, qj1);
-                    tl = target_rows(b);
-                    reload_targets(tl);
-                }
+            if (!active && got) {
+                active = true;
+                took = true;
+                b = nb;
+                load(b, qb, qj0, qj1);
+                tl = target_rows(b);
+                reload_targets(tl);
             }
         }
         return __any(active) != 0;
@@ -185,7 +187,7 @@ __device__ __forceinline__ void dls_tree_refill_body(const TreeKernelArgs<NJ, NC
                                                      unsigned long long *queue, int chunk) {
     const int lane = static_cast<int>(threadIdx.x) & 63;
     const bool fixed_base = spec_is_general(SPEC) ? a.prm.fixed_base != 0 : false;
-    TreeRefill<NJ, NCH> rf{&a, queue, chunk, fixed_base, wave * 64 + lane, nwaves * 64, 0, 0, nwaves * 64 >= a.B, wave * 64 + lane < a.B};
+    TreeRefill<NJ, NCH> rf{&a, queue, chunk & 0xffff, chunk >> 16, fixed_base, wave * 64 + lane, nwaves * 64, 0, 0, nwaves * 64 >= a.B, wave * 64 + lane < a.B, false};
     const int64_t bs = rf.start ? rf.b : a.B - 1;
     double qb[7], qj0[NJ], qj1[NJ];
     rf.load(bs, qb, qj0, qj1);

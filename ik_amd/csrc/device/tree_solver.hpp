@@ -1110,6 +1110,8 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
             // max_iterations (the stepped q, dls.cpp:76-77) stores its result and takes the next unsolved problem
             ++lit;
             const bool done = had && (stop_now || lit >= prm.max_iterations);
+            active = had && !done;   // (a lane that ran out of iterations is as finished as one whose visitor fired)
+            refill.took = false;
             const bool any_left = refill.step(done, stop_now, stop_now ? lit - 1 : prm.max_iterations, qb, qj0, qj1, targets, active, [&](const LaneRows &tl) {
 #pragma unroll
                 for (int k = 0; k < 12; ++k) {
@@ -1118,7 +1120,7 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
                     tgP[k] = (kTgRegs && prm.hasP) ? tl(tslot[2] * 12 + k) : 0.0;
                 }
             });
-            if (done) { lit = 0; success = false; }
+            if (refill.took) { lit = 0; success = false; }
             if (!any_left) break;
         } else {
             if (!kNever && !any_active(active)) break;

@@ -276,12 +276,22 @@ int64_t refill_grid(const void *kernel, int64_t B) {
 int refill_chunk(int64_t B, int64_t grid) {
     if (const char *env = std::getenv("IKGPU_REFILL_CHUNK")) {
         const long c = std::strtol(env, nullptr, 10);
-        if (c >= 64) return static_cast<int>(c / 64 * 64);
+        if (c >= 64) return static_cast<int>(std::min<long>(c / 64 * 64, 4096)) | (refill_batch() << 16);
     }
     const int64_t left = B - grid * kBlock;
     int64_t c = left > 0 ? left / (grid * 4) : 0;
     c = (c + 63) / 64 * 64;
-    return static_cast<int>(std::min<int64_t>(std::max<int64_t>(c, 64), 4096));
+    return static_cast<int>(std::min<int64_t>(std::max<int64_t>(c, 64), 4096)) | (refill_batch() << 16);
+}
+
+// Idle lanes a wave waits for before a refill event (1..64; device/chain_kernel_body.hpp chain_refill_loop): a quarter of the wave.
+// IKGPU_REFILL_BATCH overrides (1 = round 3's behaviour: an event whenever a lane finishes).
+int refill_batch() {
+    if (const char *env = std::getenv("IKGPU_REFILL_BATCH")) {
+        const long v = std::strtol(env, nullptr, 10);
+        if (v >= 1 && v <= 64) return static_cast<int>(v);
+    }
+    return 16;
 }
 
 hipError_t launch_chain_pass_through(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const int32_t *iters, hipStream_t stream) {

@@ -85,7 +85,8 @@ bool refill_wanted(const ikgpu_dls_params &prm, int64_t B, int64_t resident_wave
 enum { kTreeBuildGeneral = 0, kTreeBuildHot = 1, kTreeBuildMask = 2, kTreeBuildFold = 3 };
 int64_t refill_grid(const void *kernel, int64_t B);
 int64_t refill_resident(int64_t occupancy_waves, int64_t B);   // persistent waves of a refill launch given what the device can hold
-int refill_chunk(int64_t B, int64_t grid);   // problems a wave reserves per pull from the head (IKGPU_REFILL_CHUNK overrides)
+int refill_chunk(int64_t B, int64_t grid);   // problems a wave reserves per pull from the head (IKGPU_REFILL_CHUNK overrides) | refill_batch() << 16
+int refill_batch();                          // idle lanes a refill event waits for (IKGPU_REFILL_BATCH overrides)
 // After a refill launch: the entries of q outside the chain (q0 clipped when iters > 0, else q0 -- reference ik/ik/dls.cpp:61-71),
 // one thread per problem; `iters` is the launch's own iteration-count array (never null).
 hipError_t launch_chain_pass_through(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const int32_t *iters, hipStream_t stream);

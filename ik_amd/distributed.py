@@ -148,13 +148,23 @@ class ShardGroup:
         from . import api
         n = len(self.devices)
         prm = api._params(visitor, p)
-        out = [torch.zeros((n, self.slot_bytes(total)), dtype=torch.uint8, device="cuda:%d" % d) for d in self.devices]
+        # (torch.empty, not zeros: a fill kernel would run on torch's current stream, which the group's own non-blocking streams do not
+        # wait for -- it could land AFTER the all-gather and wipe gathered slots.  Slot padding is never read by decode().)
+        out = [torch.empty((n, self.slot_bytes(total)), dtype=torch.uint8, device="cuda:%d" % d) for d in self.devices]
+        for d in set(self.devices):
+            torch.cuda.synchronize(d)    # the inputs' producers (and anything else touching these buffers) have completed
         q = (C.c_void_p * n)(*[t.data_ptr() for t in Q0])
         tg = (C.c_void_p * n)(*[t.data_ptr() for t in targets])
         g = (C.c_void_p * n)(*[t.data_ptr() for t in out])
         capi.check(capi.lib().ikgpu_dls_solve_batch_sharded(self._h, int(total), q, tg, C.byref(prm), g))
         capi.check(capi.lib().ikgpu_shard_group_synchronize(self._h))
         return out
+
+    def issue_us(self):
+        """Per rank: microseconds its worker thread spent enqueueing the last solve (the ranks issue in parallel)."""
+        f = capi.lib().ikgpu_shard_group_last_issue_us
+        f.restype = C.c_double
+        return [float(f(self._h, r)) for r in range(len(self.devices))]
 
     def decode(self, gathered, total):
         """gathered [ndev, slot_bytes] (one device's copy) -> lists of (Q [nq, b_r], success [b_r], iterations [b_r]) per rank."""

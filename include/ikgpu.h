@@ -247,7 +247,15 @@ int32_t ikgpu_shard_group_size(const ikgpu_shard_group *g);
 const ikgpu_problem *ikgpu_shard_group_problem(const ikgpu_shard_group *g, int32_t rank);
 int32_t ikgpu_shard_group_uses_rccl(const ikgpu_shard_group *g);
 void *ikgpu_shard_group_stream(const ikgpu_shard_group *g, int32_t rank); /* the hipStream_t rank's work is enqueued on */
-/* One step.  q0[r], targets[r]: DEVICE pointers on device r to rank r's shard, component-major ([nq x b_r], [ntasks x 12 x b_r]);
+/* Wall time (microseconds) rank's worker thread spent ENQUEUEING its shard's launch in the last ikgpu_dls_solve_batch_sharded call
+ * (the launches of the ranks are issued in parallel, one thread per device; the collective follows in one group call).  < 0: no call
+ * yet / bad rank.  A measurement aid for deployments: with kernels of 0.1 ms, serial issue over 8 devices would cost as much as
+ * the solve.  No counterpart in the reference (one process, one device-less solver). */
+double ikgpu_shard_group_last_issue_us(const ikgpu_shard_group *g, int32_t rank);
+/* One step.  (`gathered[r]` is written by work enqueued on rank r's own stream, ikgpu_shard_group_stream(g, r), which does not
+ * synchronise with the null stream: anything the caller enqueued elsewhere on these buffers -- a fill, a previous reader -- must have
+ * completed, or be ordered against that stream, before the call.)
+ * q0[r], targets[r]: DEVICE pointers on device r to rank r's shard, component-major ([nq x b_r], [ntasks x 12 x b_r]);
  * gathered[r]: DEVICE pointer on device r to ndev * ikgpu_shard_slot_bytes(nq, total, ndev) bytes.  Asynchronous: the solve and
  * the collective are enqueued on each rank's own stream (inputs must be complete before the call);
  * ikgpu_shard_group_synchronize waits for all of them. */

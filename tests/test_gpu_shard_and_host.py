@@ -57,6 +57,40 @@ def test_sharded_solve_matches_the_single_device_solve(setup, stop):
     group.close()
 
 
+@pytest.mark.parametrize("ndev", [2, 3, 8])
+def test_group_code_path_with_several_ranks_on_one_device(setup, ndev, monkeypatch):
+    """The whole group code path with MORE THAN ONE rank on the one-GPU box: IKGPU_SHARD_LOOPBACK=1 lets the ranks share device 0
+    and replaces the all-gather by event-ordered device-to-device copies (shard.cpp) -- one worker thread per rank issuing its
+    shard in parallel, uneven shards (total not a multiple of ndev), the slot layout and its decode on EVERY rank's gathered buffer,
+    twice on one group (buffers reused), with and without the stop rule.  What stays untested here is RCCL over more than one
+    device; the one-device communicator runs in the test above."""
+    torch, ik_amd, model, problem, data, inputs = setup
+    from ik_amd import distributed as D
+    monkeypatch.setenv("IKGPU_SHARD_LOOPBACK", "1")
+    total = 30000 + ndev + 1
+    Q0, T = inputs(total)
+    group = D.ShardGroup(problem, [0] * ndev)
+    assert not group.uses_rccl
+    for stop, iters in ((False, 20), (True, 100), (False, 3)):
+        vis = ik_amd.inverse_kinematics_visitor() if stop else ik_amd.never_stop_visitor()
+        prm = ik_amd.dls_parameters(max_iterations=iters)
+        ref = ik_amd.dls_batch(problem, Q0, T, data, vis, prm)
+        q_parts = [Q0[:, lo:hi].contiguous() for lo, hi in (D.shard_range(total, r, ndev) for r in range(ndev))]
+        t_parts = [T[:, :, lo:hi].contiguous() for lo, hi in (D.shard_range(total, r, ndev) for r in range(ndev))]
+        assert sum(q.shape[1] for q in q_parts) == total and len({q.shape[1] for q in q_parts}) == 2    # uneven shards
+        out = group.solve(total, q_parts, t_parts, vis, prm)
+        for d in range(ndev):
+            parts = group.decode(out[d], total)
+            Q = torch.cat([p[0] for p in parts], dim=1)
+            ok = torch.cat([p[1] for p in parts])
+            it = torch.cat([p[2] for p in parts])
+            assert torch.equal(Q, ref[0]) and torch.equal(ok, ref[1]) and torch.equal(it, ref[2]), (ndev, d, stop)
+        us = group.issue_us()
+        assert len(us) == ndev and all(0.0 < x < 5e5 for x in us), us
+    print("ndev %d: per-rank issue time of the last solve %s us" % (ndev, ["%.0f" % x for x in us]))
+    group.close()
+
+
 @pytest.mark.parametrize("layout", ["soa", "aos"])
 @pytest.mark.parametrize("B", [8192, 20000, 65536 + 77])
 def test_pipelined_host_entry_matches_the_device_entry(setup, layout, B):

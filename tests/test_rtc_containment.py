@@ -135,7 +135,8 @@ def test_cache_objects_are_validated_and_the_directory_must_be_private(native_bu
 
 
 def test_the_row_cap_cannot_be_raised_without_the_unsafe_switch(native_built, tmp_path):
-    """IKGPU_STATIC_MAX_ROWS may lower the built-in cap (24 solved rows); raising it needs IKGPU_UNSAFE=1."""
+    """The dense dual program's cap (24 solved rows): IKGPU_STATIC_MAX_ROWS may lower it; raising it needs IKGPU_UNSAFE=1.  (The primal
+    tree-sparse form keeps no dense matrix and is not bound by it: the same 30-row problem gets a static program that way.)"""
     body = r'''
 model = ik_amd.Model.from_urdf_file(urdf_path("cassie"), free_flyer=True)
 p = ik_amd.InverseKinematicsProblem(model)
@@ -143,6 +144,8 @@ for i, f in enumerate(["LeftFootFront", "RightFootFront", "LeftFootBack", "Right
     p.add_frame_task("t%d" % i, ik_amd.FrameTask.create(model, f, ik_amd.KinematicType.Full, "universe"))
 print(ik_amd.plan(p))
 '''
-    assert run(body, tmp_path, IKGPU_DLS_KERNEL="generic") == ["dls_generic<M=30,nv=22,joints=17>"]
-    assert run(body, tmp_path, IKGPU_DLS_KERNEL="generic", IKGPU_STATIC_MAX_ROWS="32") == ["dls_generic<M=30,nv=22,joints=17>"]
-    assert run(body, tmp_path, IKGPU_DLS_KERNEL="generic", IKGPU_STATIC_MAX_ROWS="32", IKGPU_UNSAFE="1") == ["dls_generic<M=30,nv=22,joints=17,static>"]
+    dual = dict(IKGPU_DLS_KERNEL="generic", IKGPU_STATIC_FORM="dual")
+    assert run(body, tmp_path, **dual) == ["dls_generic<M=30,nv=22,joints=17>"]
+    assert run(body, tmp_path, IKGPU_STATIC_MAX_ROWS="32", **dual) == ["dls_generic<M=30,nv=22,joints=17>"]
+    assert run(body, tmp_path, IKGPU_STATIC_MAX_ROWS="32", IKGPU_UNSAFE="1", **dual) == ["dls_generic<M=30,nv=22,joints=17,static>"]
+    assert run(body, tmp_path, IKGPU_STATIC_MAX_ROWS="8", IKGPU_DLS_KERNEL="generic") == ["dls_generic<M=30,nv=22,joints=17,static>"]   # primal form
