@@ -65,14 +65,14 @@ WORKLOADS = {
                           text="UR5 arm, two Position tasks that share joints (tool0 and wrist_1_link; M=6): the generic lane program"),
     # the demo's own task set (reference ik_ros/src/cassie.cpp:45-81): the tree kernel's general build, or (few rows) the generic lane
     # program specialised for it at run time
-    "cassie_demo": dict(urdf="cassie", free_flyer=True, frames=["LeftFootFront", "pelvis", "LeftFootFront"], nq=23,
+    "cassie_demo": dict(urdf="cassie", free_flyer=True, frames=["LeftFootFront", "pelvis", "LeftFootFront"], nq=23, demo_targets=True,
                         tasks=[("frame", "LeftFootFront", 0, "pelvis"), ("frame", "pelvis", 2, "universe"),
                                ("align", "LeftFootFront", 1, "universe")],
                         text="Cassie demo task set (cassie.urdf + free-flyer): LeftFootFront position w.r.t. the pelvis, pelvis "
                              "SE(3) pose, LeftFootFront Y-axis alignment (M=10)"),
     # ... with the posture regulariser the demo declares and leaves commented out (cassie.cpp:63-64,76: all 16 joints, priority 1):
     # the tree kernel's posture build
-    "cassie_demo_posture": dict(urdf="cassie", free_flyer=True, frames=["LeftFootFront", "pelvis", "LeftFootFront"], nq=23,
+    "cassie_demo_posture": dict(urdf="cassie", free_flyer=True, frames=["LeftFootFront", "pelvis", "LeftFootFront"], nq=23, demo_targets=True,
                                 tasks=[("frame", "LeftFootFront", 0, "pelvis"), ("frame", "pelvis", 2, "universe"),
                                        ("align", "LeftFootFront", 1, "universe")],
                                 posture=dict(nj=16, priority=1, weight=0.05),
@@ -80,7 +80,7 @@ WORKLOADS = {
                                      "PostureTask on all 16 joints at priority 1, weight 0.05 (M=26)"),
     # ... with the right foot pinned by a FrameConstraint (the demo's commented-out intent, cassie.cpp:49-51,74-75): the tree kernel's
     # constraint build (reference ik/ik/dls.cpp:26-34,43-53)
-    "cassie_demo_pinned": dict(urdf="cassie", free_flyer=True, frames=["LeftFootFront", "pelvis", "LeftFootFront"], nq=23,
+    "cassie_demo_pinned": dict(urdf="cassie", free_flyer=True, frames=["LeftFootFront", "pelvis", "LeftFootFront"], nq=23, demo_targets=True,
                                tasks=[("frame", "LeftFootFront", 0, "pelvis"), ("frame", "pelvis", 2, "universe"),
                                       ("align", "LeftFootFront", 1, "universe")],
                                constraint=("RightFootFront", 0, "universe"),
@@ -89,14 +89,34 @@ WORKLOADS = {
     # the same tasks through the reference's other solver, ik::pik (reference ik/ik/pik.cpp:31-103): the alignment row at
     # priority 1, solved in the null space of the two pose tasks; damping factor 0.1 per level
     # ... the pinned foot AND the posture regulariser: the demo with every line but the centre of mass switched on
-    "cassie_demo_pinned_posture": dict(urdf="cassie", free_flyer=True, frames=["LeftFootFront", "pelvis", "LeftFootFront"], nq=23,
+    "cassie_demo_pinned_posture": dict(urdf="cassie", free_flyer=True, frames=["LeftFootFront", "pelvis", "LeftFootFront"], nq=23, demo_targets=True,
                                        tasks=[("frame", "LeftFootFront", 0, "pelvis"), ("frame", "pelvis", 2, "universe"),
                                               ("align", "LeftFootFront", 1, "universe")],
                                        posture=dict(nj=16, priority=1, weight=0.05),
                                        constraint=("RightFootFront", 0, "universe"),
                                        text="Cassie demo task set + a PostureTask on all 16 joints (priority 1, weight 0.05) + the right foot's "
                                             "position pinned by a FrameConstraint (M=26, 3 constraint rows)"),
-    "cassie_demo_pik": dict(urdf="cassie", free_flyer=True, frames=["LeftFootFront", "pelvis", "LeftFootFront"], nq=23,
+    # ik::pik with a level split the tree kernel does not take: the lane program compiled for the problem (device/pik_solver.hpp
+    # static_pik; reference ik/ik/pik.cpp:31-103).  Left foot pose first, right foot position in its null space (fixed-base Cassie).
+    "cassie_two_feet_pik": dict(urdf="cassie_fixed", free_flyer=False, frames=["LeftFootFront", "RightFootFront"], nq=16,
+                                tasks=[("frame", "LeftFootFront", 2, "universe"), ("frame", "RightFootFront", 0, "universe")],
+                                prios=[0, 1], solver="pik", lam=[0.1, 0.1],
+                                text="fixed-base Cassie, ik::pik over two levels: LeftFootFront SE(3) pose, then RightFootFront position in its "
+                                     "null space (M = 6 + 3), lambda 0.1 per level"),
+    "ur5_pos_then_ori_pik": dict(urdf="ur5", free_flyer=False, frames=["tool0", "tool0"], nq=6,
+                                 tasks=[("frame", "tool0", 0, "universe"), ("frame", "tool0", 1, "universe")],
+                                 prios=[0, 1], solver="pik", lam=[0.1, 0.1],
+                                 text="UR5 arm, ik::pik over two levels: tool0 position, then tool0 orientation in its null space (M = 3 + 3), "
+                                      "lambda 0.1 per level"),
+    # more than 12 solved rows: the primal, tree-sparse form of the static lane program (device/primal_solver.hpp) -- two frames on
+    # the left foot, the right foot's pose, the pelvis' orientation at priority 1 (tests/test_gpu_generic.py three_feet_frames)
+    "cassie_three_feet": dict(urdf="cassie", free_flyer=True, frames=["LeftFootFront", "LeftFootBack", "RightFootFront", "pelvis"], nq=23,
+                              tasks=[("frame", "LeftFootFront", 0, "universe"), ("frame", "LeftFootBack", 0, "universe"),
+                                     ("frame", "RightFootFront", 2, "universe"), ("frame", "pelvis", 1, "universe")],
+                              prios=[0, 0, 0, 1],
+                              text="Cassie (cassie.urdf + free-flyer), positions of LeftFootFront and LeftFootBack, SE(3) pose of "
+                                   "RightFootFront, pelvis orientation at priority 1 (M = 15): the primal tree-sparse lane program"),
+    "cassie_demo_pik": dict(urdf="cassie", free_flyer=True, frames=["LeftFootFront", "pelvis", "LeftFootFront"], nq=23, demo_targets=True,
                             tasks=[("frame", "LeftFootFront", 0, "pelvis"), ("frame", "pelvis", 2, "universe"),
                                    ("align", "LeftFootFront", 1, "universe")],
                             prios=[0, 0, 1], solver="pik", lam=[0.1, 0.1],
@@ -188,9 +208,9 @@ def make_inputs(name, model, idx):
     from ik_amd import workload
     w = WORKLOADS[name]
     lo, hi = model.lowerPositionLimit, model.upperPositionLimit
-    if name in ("cassie_full_body", "cassie_demo", "cassie_demo_pik", "cassie_demo_posture", "cassie_demo_pinned", "cassie_demo_pinned_posture"):
+    if w["free_flyer"]:
         return workload.freeflyer_workload(lo, hi, workload.cassie_nominal(model.names), idx, seed=0, mode="near")
-    if name in ("ur5", "ur10", "ur5_two_tasks"):
+    if name in ("ur5", "ur10", "ur5_two_tasks", "ur5_pos_then_ori_pik"):
         return workload.chain_workload(lo, hi, workload.UR5_NOMINAL, idx, seed=0, mode="near")
     if name == "arm7":
         return workload.chain_workload(lo, hi, np.zeros(model.nq), idx, seed=0, mode="near")
@@ -346,7 +366,7 @@ def main():
         Q0_d = torch.from_numpy(np.ascontiguousarray(q0_h.T)).to(dev)
         QS = torch.from_numpy(np.ascontiguousarray(qs_h.T)).to(dev)
         tg = ik_amd.task_frames_fk_batch(problem, QS, data)  # FK(q*) on the device: reachable targets
-        if w.get("tasks") and w["urdf"] == "cassie":
+        if w.get("demo_targets"):
             # express each frame target in its reference frame (here: the pelvis, task 1's frame); the alignment row asks for
             # the direction the foot's Y axis has at q* (slot 2 holds the same foot frame): reachable, like the frame targets
             Rp, pp = tg[1, :9].reshape(3, 3, b), tg[1, 9:]
@@ -693,18 +713,42 @@ def end_to_end(torch, ik_amd, problem, data, model, Q0, targets, prm, visitor, B
     def host_call():
         capi.check(L.ikgpu_dls_solve_batch_host(data._h, B, hq0.data_ptr(), htg.data_ptr(), C.byref(cprm), hq.data_ptr(),
                                                 hok.data_ptr(), hit.data_ptr(), capi.SOA))
-    host_call()
-    t = time.perf_counter()
-    for _ in range(reps):
+    import numpy as np
+    for _ in range(5):
         host_call()
-    host_ms = (time.perf_counter() - t) / reps * 1e3
+    calls = 240     # p50 / p99 / max: the reference's caller runs on a 20 ms tick (ik_ros/src/cassie.cpp:148) -- a tail is a missed deadline
+    ts = np.empty(calls)
+    for i in range(calls):
+        t = time.perf_counter()
+        host_call()
+        ts[i] = (time.perf_counter() - t) * 1e3
+    ts.sort()
+    host_ms = float(ts[calls // 2])
+    # ... and ONE problem per call, the reference's own call pattern (a batch of one through the staged small-batch path)
+    one = [x[:, :1].contiguous().cpu().pin_memory() if x.dim() == 2 else x[:, :, :1].contiguous().cpu().pin_memory() for x in (Q0, targets)]
+    oq, ook, oit = torch.empty_like(one[0]).pin_memory(), torch.empty(1, dtype=torch.uint8).pin_memory(), torch.empty(1, dtype=torch.int32).pin_memory()
+
+    def one_call():
+        capi.check(L.ikgpu_dls_solve_batch_host(data._h, 1, one[0].data_ptr(), one[1].data_ptr(), C.byref(cprm), oq.data_ptr(),
+                                                ook.data_ptr(), oit.data_ptr(), capi.SOA))
+    for _ in range(5):
+        one_call()
+    t1 = np.empty(calls)
+    for i in range(calls):
+        t = time.perf_counter()
+        one_call()
+        t1[i] = (time.perf_counter() - t) * 1e3
+    t1.sort()
     total = h2d + krn + d2h
     return {"value": B / (total * 1e-3), "unit": "solves/s", "h2d_ms": h2d, "solve_ms": krn, "d2h_ms": d2h, "total_ms": total,
             "bytes_in": int(hq0.numel() * 8 + htg.numel() * 8), "bytes_out": int(hq.numel() * 8 + 5 * B),
             "h2d_GBps": (hq0.numel() + htg.numel()) * 8 / (h2d * 1e-3) / 1e9, "d2h_GBps": (hq.numel() * 8 + 5 * B) / (d2h * 1e-3) / 1e9,
-            "abi_host_entry_ms": host_ms, "abi_host_entry_value": B / (host_ms * 1e-3),
+            "abi_host_entry_ms": host_ms, "abi_host_entry_p99_ms": float(ts[int(calls * 0.99)]), "abi_host_entry_max_ms": float(ts[-1]),
+            "abi_host_entry_calls": calls, "abi_host_entry_value": B / (host_ms * 1e-3),
+            "abi_host_entry_one_problem_ms": {"p50": float(t1[calls // 2]), "p99": float(t1[int(calls * 0.99)]), "max": float(t1[-1])},
             "what": "pinned host buffers -> H2D -> %d-iteration solve -> D2H, HIP events on the launch stream (PCIe-inclusive; never "
-                    "`value`); abi_host_entry_*: one ikgpu_dls_solve_batch_host call on the same pinned buffers, wall clock" % iters}
+                    "`value`); abi_host_entry_*: ikgpu_dls_solve_batch_host on the same pinned buffers, wall clock per call: median / "
+                    "99th percentile / maximum over %d calls at this batch, and at B = 1 (the reference's own call pattern)" % (iters, calls)}
 
 
 if __name__ == "__main__":

@@ -52,8 +52,8 @@ struct WsPrimal {
 // One frame / alignment task on the path of its frame's joint: FK along the path, the error, the block's columns, accumulated into
 // H (packed by TB::hidx) and g.  The arithmetic of a column is generic_evaluate's (generic_solver.hpp), which cites the reference.
 template <class TB, class WS>
-IKD_FN void primal_frame_task(const TB &T, const WS &ws, const LaneRows &targets, const int t, double (&H)[TB::nnz], double (&g)[TB::nv],
-                              double &e0sq) {
+IKD_FN void primal_frame_task(const TB &T, const WS &ws, const double (&tgt)[12], const int t, double (&H)[TB::nnz], double (&g)[TB::nv],
+                              double &e0sq, double (&Jt)[6][TB::max_pdofs], double (&er)[6]) {
     constexpr int NV = TB::nv, MP = TB::max_path, MD = TB::max_pdofs;
     const int fj = TB::t_fjoint[t], rj = TB::t_rjoint[t], type = TB::t_type[t], row = TB::t_row[t], dim = TB::t_dim[t];
     const auto w6 = TB::t_w + 6 * t;
@@ -145,13 +145,12 @@ IKD_FN void primal_frame_task(const TB &T, const WS &ws, const LaneRows &targets
     const double pf[3] = {oMf[9], oMf[10], oMf[11]};
 
     // the block: rows [row, row + dim), one column per tangent direction of the path; Jt[r][kc], kc counting the path's directions
-    double Jt[6][MD], er[6];
     LogAndJlog lj;
     double galign[3] = {0.0, 0.0, 0.0};
     const bool align = type >= GT_ALIGN_X;
     const int r0 = (type == GT_ORIENTATION) ? 3 : 0;
     if (align) {   // AlignAxisTask, ik/ik/frame.hpp:257-301
-        targets.template run_fresh<3>(t * 12 + 9, galign);
+        galign[0] = tgt[9]; galign[1] = tgt[10]; galign[2] = tgt[11];
         double rMf[12];
         g_se3_inv_mul(oMr, oMf, rMf);
         const int axn = type - GT_ALIGN_X;
@@ -165,7 +164,8 @@ IKD_FN void primal_frame_task(const TB &T, const WS &ws, const LaneRows &targets
         galign[2] = dfma(rxt[0], rMf[2], dfma(rxt[1], rMf[5], rxt[2] * rMf[8]));
         er[0] = (1.0 - dot(r, tn)) * w6[0];
     } else {
-        targets.template run_fresh<12>(t * 12, tg);
+        IKD_UNROLL
+        for (int i = 0; i < 12; ++i) tg[i] = tgt[i];
         double oMt[12], Re[9], pe[3];
         g_se3_mul(oMr, tg, oMt);                        // frame.hpp:48
         IKD_UNROLL
@@ -273,7 +273,9 @@ IKD_FN void primal_frame_task(const TB &T, const WS &ws, const LaneRows &targets
             for (int i = 0; i < 3; ++i) fM[9 + i] = X[9 + i] - dfma(fM[3 * i], P[9], dfma(fM[3 * i + 1], P[10], fM[3 * i + 2] * P[11]));
         }
     }
-    // H += J_t^T J_t, g += J_t^T e_t on the path's directions
+    // H += J_t^T J_t, g += J_t^T e_t on the path's SHARED directions (those other anchors' tasks move too: the base of a humanoid):
+    // their rows collect contributions from several blocks and are accumulated here.  A direction private to this anchor's tasks
+    // forms its row when its turn comes in the sweep (primal_dls), straight from the blocks -- no entry of H is held for it.
     int ka = 0;
     IKD_UNROLL
     for (int k = 0; k < TB::t_npath[t]; ++k) {
@@ -282,25 +284,27 @@ IKD_FN void primal_frame_task(const TB &T, const WS &ws, const LaneRows &targets
         IKD_UNROLL
         for (int u = 0; u < n; ++u) {
             const int ca = TB::idx_v[j] + u;
-            double sg = g[ca];
-            IKD_UNROLL
-            for (int r = 0; r < dim; ++r) sg = dfma(Jt[r][ka], er[r], sg);
-            g[ca] = sg;
-            int kb = 0;
-            IKD_UNROLL
-            for (int k2 = 0; k2 <= k; ++k2) {
-                const int j2 = TB::t_path[t * MP + k2];
-                const int n2 = TB::jtype[j2] == GJ_FREEFLYER ? 6 : 1;
+            if (TB::shared[ca]) {
+                double sg = g[ca];
                 IKD_UNROLL
-                for (int u2 = 0; u2 < n2; ++u2) {
-                    const int cb = TB::idx_v[j2] + u2;
-                    if (cb <= ca) {
-                        double s = H[TB::hidx[ca * NV + cb]];
-                        IKD_UNROLL
-                        for (int r = 0; r < dim; ++r) s = dfma(Jt[r][ka], Jt[r][kb], s);
-                        H[TB::hidx[ca * NV + cb]] = s;
+                for (int r = 0; r < dim; ++r) sg = dfma(Jt[r][ka], er[r], sg);
+                g[ca] = sg;
+                int kb = 0;
+                IKD_UNROLL
+                for (int k2 = 0; k2 <= k; ++k2) {
+                    const int j2 = TB::t_path[t * MP + k2];
+                    const int n2 = TB::jtype[j2] == GJ_FREEFLYER ? 6 : 1;
+                    IKD_UNROLL
+                    for (int u2 = 0; u2 < n2; ++u2) {
+                        const int cb = TB::idx_v[j2] + u2;
+                        if (cb <= ca && TB::shared[cb]) {
+                            double s = H[TB::hidx[ca * NV + cb]];
+                            IKD_UNROLL
+                            for (int r = 0; r < dim; ++r) s = dfma(Jt[r][ka], Jt[r][kb], s);
+                            H[TB::hidx[ca * NV + cb]] = s;
+                        }
+                        ++kb;
                     }
-                    ++kb;
                 }
             }
             ++ka;
@@ -317,6 +321,26 @@ IKD_FN void primal_dls(const TB &T, const LoopParams &prm, const WS &ws, const L
     int iters = prm.max_iterations;
     for (int it = 0; it < prm.max_iterations; ++it) {
         double H[TB::nnz], g[NV], x[NV], e0sq = 0.0;
+        double Jt[TB::ntasks][6][TB::max_pdofs], er[TB::ntasks][6];   // the blocks of the tasks whose private rows are still to come
+        // every task's target, loaded in ONE go at the top of the iteration (one exposed round trip to HBM / L2 per iteration instead of
+        // one per task; the words wait in registers -- 12 per pose -- until their task's turn, the first tasks of the sweep are the
+        // lightest phase).  Re-read every iteration: kept across the loop they would cost their registers for the whole solve.
+        double tgt[TB::ntasks][12];
+        IKD_UNROLL
+        for (int t = 0; t < TB::ntasks; ++t) {
+            if (TB::t_type[t] == GT_POSTURE_ROW) {
+                double tv[1];
+                targets.template run_fresh<1>(t * 12 + 9, tv);
+                tgt[t][9] = tv[0];
+            } else if (TB::t_type[t] >= GT_ALIGN_X) {
+                double tv[3];
+                targets.template run_fresh<3>(t * 12 + 9, tv);
+                tgt[t][9] = tv[0]; tgt[t][10] = tv[1]; tgt[t][11] = tv[2];
+            } else {
+                targets.template run_fresh<12>(t * 12, tgt[t]);
+            }
+        }
+        IKD_SCHED_FENCE();
         IKD_UNROLL
         for (int c = 0; c < NV; ++c) {
             g[c] = 0.0;
@@ -332,48 +356,103 @@ IKD_FN void primal_dls(const TB &T, const LoopParams &prm, const WS &ws, const L
                 const int t = TB::anch_t[c * TB::ntasks + i];
                 if (TB::t_type[t] == GT_POSTURE_ROW) {   // one row of ik::PostureTask, ik/ik/posture.hpp:51-68: a diagonal entry
                     const auto w6 = TB::t_w + 6 * t;
-                    double tv[1];
-                    targets.template run_fresh<1>(t * 12 + 9, tv);
-                    const double e = (ws[T.off_q + TB::t_rjoint[t]] - tv[0]) * w6[1] * w6[0];
+                    const double e = (ws[T.off_q + TB::t_rjoint[t]] - tgt[t][9]) * w6[1] * w6[0];
                     ws[T.off_e + TB::t_row[t]] = e;
                     if (TB::t_prio[t] == 0) e0sq = dfma(e, e, e0sq);
                     H[TB::hidx[c * NV + c]] = dfma(w6[0], w6[0], H[TB::hidx[c * NV + c]]);
                     g[c] = dfma(w6[0], e, g[c]);
                 } else {
                     IKD_SCHED_FENCE();   // one task at a time: nothing of the next task's FK may start while this block is live
-                    primal_frame_task(T, ws, targets, t, H, g, e0sq);
+                    primal_frame_task(T, ws, tgt[t], t, H, g, e0sq, Jt[t], er[t]);
                     IKD_SCHED_FENCE();
                 }
             }
             if (TB::hidx[c * NV + c] < 0) continue;      // a direction no task moves
-            // eliminate direction c: pivot, column (on c's coupled ancestors, TB::anc), rank-one update of their block, forward substitution
             constexpr int MA = TB::max_anc;
-            const double inv = drsqrt(H[TB::hidx[c * NV + c]]);
-            const double y = g[c] * inv;
-            IKD_UNROLL
-            for (int k = 0; k < TB::anc_n[c]; ++k) {
-                const int d = TB::anc[c * MA + k];
-                const double l = H[TB::hidx[c * NV + d]] * inv;
-                H[TB::hidx[c * NV + d]] = l;
-                g[d] = dfma(-l, y, g[d]);
-            }
-            IKD_UNROLL
-            for (int k = 0; k < TB::anc_n[c]; ++k) {
-                const int d = TB::anc[c * MA + k];
+            if (TB::shared[c]) {
+                // a SHARED direction (all of its ancestors are shared too): its row sits complete in H -- the blocks' contributions and
+                // the rank-one updates of every deeper direction.  Pivot, column, rank-one update of the ancestors, forward substitution.
+                const double inv = drsqrt(H[TB::hidx[c * NV + c]]);
+                const double y = g[c] * inv;
                 IKD_UNROLL
-                for (int k2 = 0; k2 <= k; ++k2) {   // (anc is ascending: e <= d)
-                    const int e = TB::anc[c * MA + k2];
-                    H[TB::hidx[d * NV + e]] = dfma(-H[TB::hidx[c * NV + d]], H[TB::hidx[c * NV + e]], H[TB::hidx[d * NV + e]]);
+                for (int k = 0; k < TB::anc_n[c]; ++k) {
+                    const int d = TB::anc[c * MA + k];
+                    const double l = H[TB::hidx[c * NV + d]] * inv;
+                    H[TB::hidx[c * NV + d]] = l;
+                    g[d] = dfma(-l, y, g[d]);
+                }
+                IKD_UNROLL
+                for (int k = 0; k < TB::anc_n[c]; ++k) {
+                    const int d = TB::anc[c * MA + k];
+                    IKD_UNROLL
+                    for (int k2 = 0; k2 <= k; ++k2) {   // (anc is ascending: e <= d)
+                        const int e = TB::anc[c * MA + k2];
+                        H[TB::hidx[d * NV + e]] = dfma(-H[TB::hidx[c * NV + d]], H[TB::hidx[c * NV + e]], H[TB::hidx[d * NV + e]]);
+                    }
+                }
+                H[TB::hidx[c * NV + c]] = inv;
+                g[c] = y;
+            } else {
+                // a direction PRIVATE to one anchor's tasks (a leg joint): its row is formed NOW, left-looking -- from the blocks of that
+                // anchor's tasks (still alive: they die with the anchor's last private direction) minus the columns of the deeper private
+                // directions -- so no entry of H was ever held for it: while a 6 x 13 block is alive the leg's 70 entries are not.
+                double diag = H[TB::hidx[c * NV + c]], gc = g[c], row[MA];   // (lambda^2 and the direction's own PostureTask row)
+                IKD_UNROLL
+                for (int k = 0; k < TB::anc_n[c]; ++k) row[k] = 0.0;
+                IKD_UNROLL
+                for (int t = 0; t < TB::ntasks; ++t) {
+                    if (TB::t_type[t] == GT_POSTURE_ROW || TB::t_anchor[t] != TB::grp[c] || TB::t_kc[t * NV + c] < 0) continue;
+                    const int kc = TB::t_kc[t * NV + c];
+                    IKD_UNROLL
+                    for (int r = 0; r < TB::t_dim[t]; ++r) {
+                        diag = dfma(Jt[t][r][kc], Jt[t][r][kc], diag);
+                        gc = dfma(Jt[t][r][kc], er[t][r], gc);
+                    }
+                    IKD_UNROLL
+                    for (int k = 0; k < TB::anc_n[c]; ++k) {
+                        const int kd = TB::t_kc[t * NV + TB::anc[c * MA + k]];
+                        IKD_UNROLL
+                        for (int r = 0; r < TB::t_dim[t]; ++r) row[k] = dfma(Jt[t][r][kc], Jt[t][r][kd], row[k]);
+                    }
+                }
+                IKD_UNROLL
+                for (int a = NV - 1; a > c; --a) {   // deeper private directions of the same anchor that have c as an ancestor
+                    if (TB::shared[a] || TB::grp[a] != TB::grp[c] || TB::hidx[a * NV + c] < 0) continue;
+                    const double lca = H[TB::hidx[a * NV + c]];
+                    diag = dfma(-lca, lca, diag);
+                    gc = dfma(-lca, g[a], gc);
+                    IKD_UNROLL
+                    for (int k = 0; k < TB::anc_n[c]; ++k) row[k] = dfma(-lca, H[TB::hidx[a * NV + TB::anc[c * MA + k]]], row[k]);
+                }
+                const double inv = drsqrt(diag);
+                const double y = gc * inv;
+                IKD_UNROLL
+                for (int k = 0; k < TB::anc_n[c]; ++k) H[TB::hidx[c * NV + TB::anc[c * MA + k]]] = row[k] * inv;
+                H[TB::hidx[c * NV + c]] = inv;
+                g[c] = y;
+                IKD_UNROLL
+                for (int k = 0; k < TB::anc_n[c]; ++k) {   // right-looking onto the SHARED ancestors (their rows live in H)
+                    const int d = TB::anc[c * MA + k];
+                    if (!TB::shared[d]) continue;
+                    g[d] = dfma(-H[TB::hidx[c * NV + d]], y, g[d]);
+                    IKD_UNROLL
+                    for (int k2 = 0; k2 <= k; ++k2) {
+                        const int e = TB::anc[c * MA + k2];
+                        if (!TB::shared[e]) continue;
+                        H[TB::hidx[d * NV + e]] = dfma(-H[TB::hidx[c * NV + d]], H[TB::hidx[c * NV + e]], H[TB::hidx[d * NV + e]]);
+                    }
                 }
             }
-            H[TB::hidx[c * NV + c]] = inv;
-            g[c] = y;
-            if (TB::park_off[c] >= 0) {   // the finished column waits in LDS for the back substitution
-                const int o = TB::park_off[c];
-                lds[o] = inv;
-                lds[o + 1] = y;
+            // finished columns wait in LDS for the back substitution -- a private direction's once its anchor's last private row is
+            // formed (the rows above read the deeper columns from registers)
+            IKD_UNROLL
+            for (int a = NV - 1; a >= c; --a) {
+                if (TB::park_off[a] < 0 || TB::park_at[a] != c) continue;
+                const int o = TB::park_off[a];
+                lds[o] = H[TB::hidx[a * NV + a]];
+                lds[o + 1] = g[a];
                 IKD_UNROLL
-                for (int k = 0; k < TB::anc_n[c]; ++k) lds[o + 2 + k] = H[TB::hidx[c * NV + TB::anc[c * MA + k]]];
+                for (int k = 0; k < TB::anc_n[a]; ++k) lds[o + 2 + k] = H[TB::hidx[a * NV + TB::anc[a * MA + k]]];
             }
         }
         // back substitution, root first: x_c = (y_c - sum_{d in anc(c)} L_dc x_d) / l_cc;  dq = -x

@@ -615,7 +615,7 @@ struct PrimalPlan {
     bool ok = false;
     int max_path = 1, max_pdofs = 1, nnz = 0, lds_words = 0;
     int max_anc = 1;
-    std::vector<int> t_npath, t_path, t_nrpath, t_rpath, t_anchor, hidx, park_off, anc_n, anc;
+    std::vector<int> t_npath, t_path, t_nrpath, t_rpath, t_anchor, hidx, park_off, anc_n, anc, shared, grp, t_kc, park_at;
 };
 
 constexpr int kPrimalLdsWords = 80;   // 40 KB per one-wave workgroup: four of them fill a CU's 160 KB, one wave per SIMD
@@ -683,6 +683,33 @@ PrimalPlan primal_plan(const ProblemHost &ph) {
         for (int d = 0; d < c; ++d)   // ascending
             if (pl.hidx[static_cast<size_t>(c) * nv + d] >= 0) pl.anc[static_cast<size_t>(c) * pl.max_anc + k++] = d;
     }
+    // shared / private directions (primal_solver.hpp): a direction moved by tasks of two or more anchors keeps its row in H (the blocks
+    // are accumulated into it); one that belongs to a single anchor's tasks forms its row from their blocks when its turn comes
+    pl.shared.assign(static_cast<size_t>(nv), 0);
+    pl.grp.assign(static_cast<size_t>(nv), -1);
+    pl.t_kc.assign(static_cast<size_t>(nt) * nv, -1);
+    {
+        std::vector<std::vector<int>> anchors(static_cast<size_t>(nv));
+        for (int t = 0; t < nt; ++t) {
+            if (I[g.o_ttype + t] == IKGPU_POSTURE_ROW) continue;
+            int kc = 0;
+            for (int j : paths[static_cast<size_t>(t)])
+                for (int u = 0; u < ndof(j); ++u) {
+                    const int c = I[g.o_idx_v + j] + u;
+                    pl.t_kc[static_cast<size_t>(t) * nv + c] = kc++;
+                    std::vector<int> &a = anchors[static_cast<size_t>(c)];
+                    if (std::find(a.begin(), a.end(), pl.t_anchor[static_cast<size_t>(t)]) == a.end()) a.push_back(pl.t_anchor[static_cast<size_t>(t)]);
+                }
+        }
+        for (int c = 0; c < nv; ++c) {
+            pl.shared[static_cast<size_t>(c)] = anchors[static_cast<size_t>(c)].size() > 1 ? 1 : 0;
+            pl.grp[static_cast<size_t>(c)] = anchors[static_cast<size_t>(c)].size() == 1 ? anchors[static_cast<size_t>(c)][0] : (anchors[static_cast<size_t>(c)].empty() ? c : -1);
+        }
+        // (an ancestor of a shared direction is shared: both anchors' paths run through it)
+        for (int c = 0; c < nv; ++c)
+            for (int d = 0; d < c; ++d)
+                if (pl.shared[static_cast<size_t>(c)] && coupled[static_cast<size_t>(c) * nv + d] && !pl.shared[static_cast<size_t>(d)]) return pl;
+    }
     // finished columns parked in LDS until the back substitution: in elimination order (deepest first), the root joint's excepted
     // (they are read back first), while the slab has room
     int budget = kPrimalLdsWords;
@@ -700,6 +727,17 @@ PrimalPlan primal_plan(const ProblemHost &ph) {
         if (pl.lds_words + words > budget) continue;
         pl.park_off[static_cast<size_t>(c)] = pl.lds_words;
         pl.lds_words += words;
+    }
+    // a shared column is parked when it is finished; a private one when the LAST (lowest) private direction of its anchor is, since
+    // the rows of that anchor's private directions read the deeper columns
+    pl.park_at.assign(static_cast<size_t>(nv), -1);
+    for (int c = 0; c < nv; ++c) {
+        if (pl.park_off[static_cast<size_t>(c)] < 0) continue;
+        int at = c;
+        if (!pl.shared[static_cast<size_t>(c)])
+            for (int d = 0; d < c; ++d)
+                if (act[static_cast<size_t>(d)] && !pl.shared[static_cast<size_t>(d)] && pl.grp[static_cast<size_t>(d)] == pl.grp[static_cast<size_t>(c)]) { at = d; break; }
+        pl.park_at[static_cast<size_t>(c)] = at;
     }
     pl.t_npath.assign(static_cast<size_t>(nt), 0);
     pl.t_nrpath.assign(static_cast<size_t>(nt), 0);
@@ -795,6 +833,8 @@ std::string generic_static_source(const ProblemHost &ph, int kind = kStaticDls) 
             }
             o += int_array("anch_n", anch_n.begin(), ph.nv) + int_array("anch_t", anch_t.begin(), ph.nv * nt);
         }
+        o += int_array("shared", pl.shared.begin(), ph.nv) + int_array("grp", pl.grp.begin(), ph.nv) + int_array("t_kc", pl.t_kc.begin(), nt * ph.nv) +
+             int_array("park_at", pl.park_at.begin(), ph.nv);
         scalar("max_anc", pl.max_anc);
         o += int_array("anc_n", pl.anc_n.begin(), ph.nv) + int_array("anc", pl.anc.begin(), ph.nv * pl.max_anc);
     }
