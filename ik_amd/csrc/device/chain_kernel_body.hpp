@@ -29,6 +29,11 @@ struct ChainKernelArgs {
     const double *lower, *upper;  // [nq]
     const uint8_t *q_in_chain;    // [nq]
     double *e_out, *J_out, *oMf_out;  // stage kernels
+    // second phase of a two-phase stop-rule solve (kernels.hip two_phase_*): the refill kernel walks a LIST of problems -- those the
+    // lock-step first phase left unfinished after it0 iterations -- continuing each from its iterate in q_out.  Null: the whole batch.
+    const int32_t *worklist;
+    const unsigned long long *count;   // (device) length of the list
+    int it0;
 };
 
 IKD_FN int64_t at(int layout, int64_t B, int ncomp, int c, int64_t b) {
@@ -99,20 +104,31 @@ template <int NJ, class IterFn>
 __device__ __forceinline__ void chain_refill_loop(const ChainKernelArgs<NJ> &a, unsigned long long *queue, int chunk_and_batch, IterFn iterate) {
     const int lane = static_cast<int>(threadIdx.x) & 63;                 // one wave per workgroup
     const int64_t first_round = static_cast<int64_t>(gridDim.x) * 64;
-    int64_t b = static_cast<int64_t>(blockIdx.x) * 64 + lane;
-    bool have = b < a.B;
-    int64_t bs = have ? b : a.B - 1;                                     // idle lanes shadow a valid problem
+    // work items: the batch's problems, or (second phase) the entries of the worklist; `b` is always a PROBLEM index
+    const bool listed = a.worklist != nullptr;
+    const int64_t nwork = listed ? static_cast<int64_t>(*a.count) : a.B;
+    const double *qsrc = listed ? a.q_out : a.q0;
+    const int it0 = listed ? a.it0 : 0;
+    auto problem = [&](int64_t w) { return listed ? static_cast<int64_t>(a.worklist[w]) : w; };
+    const int64_t w0 = static_cast<int64_t>(blockIdx.x) * 64 + lane;
+    bool have = w0 < nwork;
     double q[NJ], oMt[12];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) q[j] = a.q0[at(a.layout, a.B, a.nq, a.qidx[j], bs)];
-    load_target(a, bs, oMt);
-    int it = 0;
+    int64_t b = 0;
+    int it = it0;
     const int max_it = a.prm.max_iterations;                             // >= 1: the host sends max_iterations == 0 to the lock-step kernel
+    if (nwork > 0) {                                                     // (wave-uniform; an empty list: straight to the slot's bookkeeping)
+        b = problem(have ? w0 : 0);                                      // idle lanes shadow a valid problem
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) q[j] = qsrc[at(a.layout, a.B, a.nq, a.qidx[j], b)];
+        load_target(a, b, oMt);
+    } else {
+        have = false;
+    }
     // The wave's own reserve [pool_lo, pool_hi) of unsolved problems (wave-uniform): finished lanes are served from it, and only when
     // it runs dry does the wave pull `chunk` (>= 64) more from the launch's head.  One atomic per finished LANE-GROUP on one address
     // saturated the memory-side atomic unit (measured: ~30-70 M same-address atomics/s device-wide, every refill waiting ~30 us).
     int64_t pool_lo = 0, pool_hi = 0;
-    bool exhausted = first_round >= a.B;                                 // the head has passed the end of the batch
+    bool exhausted = first_round >= nwork;                               // the head has passed the end of the batch
     // Refill events are BATCHED: a finished lane stores its result at once and then waits until `batch` lanes of the wave are idle
     // (or no lane is active any more) -- one ballot, one reserve update and one round trip of loads per event instead of per
     // iteration.  With targets near the start every lane is done within two or three iterations, an event per iteration cost
@@ -143,8 +159,8 @@ __device__ __forceinline__ void chain_refill_loop(const ChainKernelArgs<NJ> &a, 
                 if (lane == 0) v = atomicAdd(queue, static_cast<unsigned long long>(chunk));
                 const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v)), hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
                 const int64_t nlo = first_round + static_cast<int64_t>((static_cast<unsigned long long>(hi) << 32) | lo);
-                const int64_t nhi = nlo + chunk < a.B ? nlo + chunk : a.B;
-                exhausted = nlo + chunk >= a.B;
+                const int64_t nhi = nlo + chunk < nwork ? nlo + chunk : nwork;
+                exhausted = nlo + chunk >= nwork;
                 if (rank >= avail) { nb = nlo + (rank - avail); got = nb < nhi; }
                 pool_lo = nlo + (need - avail);
                 pool_hi = nhi > pool_lo ? nhi : pool_lo;
@@ -153,11 +169,11 @@ __device__ __forceinline__ void chain_refill_loop(const ChainKernelArgs<NJ> &a, 
             }
             if (!have && got) {
                 have = true;
-                b = nb;
+                b = problem(nb);
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) q[j] = a.q0[at(a.layout, a.B, a.nq, a.qidx[j], b)];
+                for (int j = 0; j < NJ; ++j) q[j] = qsrc[at(a.layout, a.B, a.nq, a.qidx[j], b)];
                 load_target(a, b, oMt);
-                it = 0;
+                it = it0;
             }
         }
     }

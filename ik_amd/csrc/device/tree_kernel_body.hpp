@@ -27,6 +27,11 @@ struct TreeKernelArgs {
     const double *lower, *upper;  // [nq]
     const uint8_t *q_in_chain;    // [nq] 1 where the kernel integrates the entry itself
     double *e_out, *J_out, *oMf_out;  // stage kernel
+    // second phase of a two-phase stop-rule solve (as ChainKernelArgs): the refill kernel walks the list of problems the lock-step first
+    // phase left unfinished after it0 iterations, continuing each from its iterate in q_out.  Null: the whole batch.
+    const int32_t *worklist;
+    const unsigned long long *count;
+    int it0;
 };
 
 // B independent ik::dls() calls (reference ik/ik/dls.cpp:5-78) on a free-flyer model, lane `gid`.
@@ -112,15 +117,19 @@ struct TreeRefill {
     bool exhausted;
     bool start;   // this lane holds a problem of the first (static) round
     bool took;    // (set by step) this lane has just taken a new problem: its iteration count restarts
+    int64_t nwork;   // work items: the batch's problems, or the entries of a->worklist (`b` is always a PROBLEM index)
+    __device__ __forceinline__ int64_t problem(int64_t w) const { return a->worklist ? static_cast<int64_t>(a->worklist[w]) : w; }
+    __device__ __forceinline__ int it0() const { return a->worklist ? a->it0 : 0; }
 
     __device__ __forceinline__ void load(int64_t bb, double (&qb)[7], double (&qj0)[NJ], double (&qj1)[NJ]) const {
         const TreeKernelArgs<NJ, NCH> &A = *a;
+        const double *src = A.worklist ? A.q_out : A.q0;   // (second phase: the first phase's iterate)
 #pragma unroll
-        for (int k = 0; k < 7; ++k) qb[k] = fixed_base ? (k == 6 ? 1.0 : 0.0) : A.q0[at(A.layout, A.B, A.nq, k, bb)];
+        for (int k = 0; k < 7; ++k) qb[k] = fixed_base ? (k == 6 ? 1.0 : 0.0) : src[at(A.layout, A.B, A.nq, k, bb)];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            qj0[j] = A.q0[at(A.layout, A.B, A.nq, A.qidx[0][j], bb)];
-            qj1[j] = NCH > 1 ? A.q0[at(A.layout, A.B, A.nq, A.qidx[NCH - 1][j], bb)] : 0.0;
+            qj0[j] = src[at(A.layout, A.B, A.nq, A.qidx[0][j], bb)];
+            qj1[j] = NCH > 1 ? src[at(A.layout, A.B, A.nq, A.qidx[NCH - 1][j], bb)] : 0.0;
         }
     }
     __device__ __forceinline__ LaneRows target_rows(int64_t bb) const {
@@ -160,8 +169,8 @@ struct TreeRefill {
                 if (lane == 0) v = atomicAdd(queue, static_cast<unsigned long long>(chunk));
                 const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v)), hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
                 const int64_t nlo = first_round + static_cast<int64_t>((static_cast<unsigned long long>(hi) << 32) | lo);
-                const int64_t nhi = nlo + chunk < A.B ? nlo + chunk : A.B;
-                exhausted = nlo + chunk >= A.B;
+                const int64_t nhi = nlo + chunk < nwork ? nlo + chunk : nwork;
+                exhausted = nlo + chunk >= nwork;
                 if (rank >= avail) { nb = nlo + (rank - avail); got = nb < nhi; }
                 pool_lo = nlo + (need - avail);
                 pool_hi = nhi > pool_lo ? nhi : pool_lo;
@@ -171,7 +180,7 @@ struct TreeRefill {
             if (!active && got) {
                 active = true;
                 took = true;
-                b = nb;
+                b = problem(nb);
                 load(b, qb, qj0, qj1);
                 tl = target_rows(b);
                 reload_targets(tl);
@@ -187,15 +196,18 @@ __device__ __forceinline__ void dls_tree_refill_body(const TreeKernelArgs<NJ, NC
                                                      unsigned long long *queue, int chunk) {
     const int lane = static_cast<int>(threadIdx.x) & 63;
     const bool fixed_base = spec_is_general(SPEC) ? a.prm.fixed_base != 0 : false;
-    TreeRefill<NJ, NCH> rf{&a, queue, chunk & 0xffff, chunk >> 16, fixed_base, wave * 64 + lane, nwaves * 64, 0, 0, nwaves * 64 >= a.B, wave * 64 + lane < a.B, false};
-    const int64_t bs = rf.start ? rf.b : a.B - 1;
-    double qb[7], qj0[NJ], qj1[NJ];
-    rf.load(bs, qb, qj0, qj1);
-    const LaneRows tl = rf.target_rows(bs);
-    const PostureState ps{nullptr, 0, false, a.lower, a.upper, false, nullptr, nullptr};
-    int iters;
-    bool success;
-    tree_dls<NJ, NCH, SPEC>(d, a.prm, qb, qj0, qj1, tl, a.tslot, ps, iters, success, park, [](bool act) { return __any(act) != 0; }, rf);
+    const int64_t nwork = a.worklist ? static_cast<int64_t>(*a.count) : a.B;
+    if (nwork > 0) {   // (wave-uniform; an empty worklist: straight to the slot's bookkeeping)
+        TreeRefill<NJ, NCH> rf{&a, queue, chunk & 0xffff, chunk >> 16, fixed_base, 0, nwaves * 64, 0, 0, nwaves * 64 >= nwork, wave * 64 + lane < nwork, false, nwork};
+        rf.b = rf.problem(rf.start ? wave * 64 + lane : 0);   // a tail lane of the first round shadows a valid problem
+        double qb[7], qj0[NJ], qj1[NJ];
+        rf.load(rf.b, qb, qj0, qj1);
+        const LaneRows tl = rf.target_rows(rf.b);
+        const PostureState ps{nullptr, 0, false, a.lower, a.upper, false, nullptr, nullptr};
+        int iters;
+        bool success;
+        tree_dls<NJ, NCH, SPEC>(d, a.prm, qb, qj0, qj1, tl, a.tslot, ps, iters, success, park, [](bool act) { return __any(act) != 0; }, rf);
+    }
     if (lane == 0) {   // the last wave out resets the slot
         __threadfence();
         if (atomicAdd(queue + 1, 1ull) == static_cast<unsigned long long>(nwaves) - 1ull) {

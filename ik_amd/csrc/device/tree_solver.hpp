@@ -918,6 +918,7 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
         tgP[k] = (kTgRegs && prm.hasP) ? targets(tslot[2] * 12 + k) : 0.0;
     }
     int lit = 0;   // (refill) this lane's own iteration count
+    if constexpr (R::on) lit = refill.it0();   // (second phase of a two-phase solve: the iterations the first phase took)
 #pragma unroll 1
     for (int it = 0; R::on || it < prm.max_iterations; ++it) {
         asm volatile("" ::: "memory");  // re-read the table and the targets every iteration (see chain_solver.hpp)
@@ -1120,7 +1121,7 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
                     tgP[k] = (kTgRegs && prm.hasP) ? tl(tslot[2] * 12 + k) : 0.0;
                 }
             });
-            if (refill.took) { lit = 0; success = false; }
+            if (refill.took) { lit = refill.it0(); success = false; }
             if (!any_left) break;
         } else {
             if (!kNever && !any_active(active)) break;

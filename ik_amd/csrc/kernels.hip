@@ -169,8 +169,14 @@ hipError_t run_dls(const ProblemHost &ph, const DeviceTables &dt, const BatchIO 
     do {                                                                                                                        \
         const void *rk = reinterpret_cast<const void *>(dls_chain_refill_kernel<NJ, KT, SM>);                                    \
         const int64_t rgrid = refill_grid(rk, io.B);                                                                            \
-        if (refill_wanted(prm, io.B, rgrid)) return run_refill<NJ>(ph, dt, io, a, stream, [&](unsigned long long *queue, int32_t *it) { \
+        const int mode = stop_rule_mode(prm, io.B, rgrid, stream);                                                              \
+        if (mode == kStopRefill) return run_refill<NJ>(ph, dt, io, a, stream, [&](unsigned long long *queue, int32_t *it) {      \
             a.iters = it;                                                                                                       \
+            hipLaunchKernelGGL((dls_chain_refill_kernel<NJ, KT, SM>), dim3(static_cast<unsigned>(rgrid)), dim3(kBlock), 0, stream, a, queue, refill_chunk(io.B, rgrid)); \
+        });                                                                                                                     \
+        if (mode == kStopTwoPhase) return run_two_phase(dt, io, stream, a, [&] {                                                 \
+            hipLaunchKernelGGL((dls_chain_kernel<NJ, KT, SM>), grid_for(io.B), dim3(kBlock), 0, stream, a);                      \
+        }, [&](unsigned long long *queue) {                                                                                     \
             hipLaunchKernelGGL((dls_chain_refill_kernel<NJ, KT, SM>), dim3(static_cast<unsigned>(rgrid)), dim3(kBlock), 0, stream, a, queue, refill_chunk(io.B, rgrid)); \
         });                                                                                                                     \
         hipLaunchKernelGGL((dls_chain_kernel<NJ, KT, SM>), grid_for(io.B), dim3(kBlock), 0, stream, a);                          \
@@ -252,6 +258,74 @@ bool refill_wanted(const ikgpu_dls_params &prm, int64_t B, int64_t resident_wave
     if (env && env[0] == '0') return false;
     if (env && env[0] == '1') return true;
     return B > resident_waves * kBlock;   // otherwise every problem has its own lane from the start: nothing to refill
+}
+
+int two_phase_iterations() {
+    if (const char *env = std::getenv("IKGPU_TWO_PHASE_ITERS")) {
+        const long v = std::strtol(env, nullptr, 10);
+        if (v >= 1 && v <= 64) return static_cast<int>(v);
+    }
+    return 4;
+}
+
+int stop_rule_mode(const ikgpu_dls_params &prm, int64_t B, int64_t resident_waves, hipStream_t stream) {
+    if (!(prm.stop_sq_tol >= 0.0) || prm.max_iterations < 1) return kStopLockStep;
+    const char *env = std::getenv("IKGPU_REFILL");
+    if (env && env[0] == '0') return kStopLockStep;
+    if (env && env[0] == '1') return kStopRefill;
+    const bool forced = env && env[0] == '2';
+    if (!forced && B <= resident_waves * kBlock) return kStopLockStep;
+    if (prm.max_iterations <= two_phase_iterations()) return forced ? kStopLockStep : kStopRefill;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap == hipStreamCaptureStatusActive) return kStopRefill;
+    return kStopTwoPhase;
+}
+
+namespace {
+// Problems the first phase left unfinished (no success, K iterations taken) -> worklist; one atomic per wave.
+__global__ __launch_bounds__(256) void two_phase_compact_kernel(const uint8_t *success, int64_t B, int32_t *worklist, unsigned long long *count) {
+    const int64_t b = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    const bool open = b < B && success[b] == 0;
+    const unsigned long long mask = __ballot(open);
+    if (mask == 0ull) return;
+    const int lane = static_cast<int>(threadIdx.x) & 63;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(count, static_cast<unsigned long long>(__popcll(mask)));
+    const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(base)), hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(base >> 32));
+    base = (static_cast<unsigned long long>(hi) << 32) | lo;
+    if (open) worklist[base + __popcll(mask & ((1ull << lane) - 1ull))] = static_cast<int32_t>(b);
+}
+}  // namespace
+
+hipError_t two_phase_begin(const BatchIO &io, hipStream_t stream, TwoPhase *tp) {
+    if (io.B > 0x7fffffff) return hipErrorInvalidValue;   // (the worklist holds 32-bit problem indices; larger batches keep the one-phase modes)
+    hipError_t e = hipMallocAsync(&tp->tmp[0], sizeof(int32_t) * static_cast<size_t>(io.B) + 16, stream);
+    if (e != hipSuccess) return e;
+    tp->count = static_cast<unsigned long long *>(tp->tmp[0]);
+    tp->worklist = reinterpret_cast<int32_t *>(static_cast<char *>(tp->tmp[0]) + 16);
+    tp->success = io.success;
+    tp->iters = io.iters;
+    if (!tp->success) {
+        if ((e = hipMallocAsync(&tp->tmp[1], static_cast<size_t>(io.B), stream)) != hipSuccess) return e;
+        tp->success = static_cast<uint8_t *>(tp->tmp[1]);
+    }
+    if (!tp->iters) {
+        if ((e = hipMallocAsync(&tp->tmp[2], sizeof(int32_t) * static_cast<size_t>(io.B), stream)) != hipSuccess) return e;
+        tp->iters = static_cast<int32_t *>(tp->tmp[2]);
+    }
+    return hipMemsetAsync(tp->count, 0, 16, stream);
+}
+
+hipError_t two_phase_compact(const BatchIO &io, const TwoPhase &tp, hipStream_t stream) {
+    hipLaunchKernelGGL(two_phase_compact_kernel, dim3(static_cast<unsigned>((io.B + 255) / 256)), dim3(256), 0, stream, tp.success, io.B, tp.worklist, tp.count);
+    return hipGetLastError();
+}
+
+hipError_t two_phase_end(TwoPhase *tp, hipStream_t stream) {
+    hipError_t e = hipSuccess;
+    for (void *&p : tp->tmp)
+        if (p) { const hipError_t f = hipFreeAsync(p, stream); if (e == hipSuccess) e = f; p = nullptr; }
+    return e;
 }
 
 int64_t refill_resident(int64_t occupancy_waves, int64_t B) {
@@ -477,7 +551,7 @@ TreeKernelArgs<NJ, NCH> make_tree_args(const ProblemHost &ph, const DeviceTables
 // kernels_tree_refill.hip
 template <int NJ, int NCH>
 bool launch_tree_refill(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const ikgpu_dls_params &prm, hipStream_t stream,
-                        ikdev::TreeKernelArgs<NJ, NCH> a, int build, hipError_t *err);
+                        ikdev::TreeKernelArgs<NJ, NCH> a, int build, hipError_t *err, unsigned long long *phase2_queue);
 namespace {
 
 template <int NJ>
@@ -527,14 +601,8 @@ hipError_t run_dls_tree(const ProblemHost &ph, const DeviceTables &dt, const Bat
                                      dim3(kTreeBlock), LDS, stream, a);                                                             \
         else hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, (FLAGS)>), grid, dim3(kTreeBlock), LDS, stream, a);                       \
     } while (0)
-    // stop-rule mode on a batch larger than the machine: lane refill (kernels_tree_refill.hip) for the builds that have it -- every
-    // build without per-lane state outside q (no posture rows, no constraint, no ik::pik level)
-    if (!pik_lambda1 && !ph.cons_on && !ph.has_posture && prm.stop_sq_tol >= 0.0 && prm.max_iterations >= 1) {
-        hipError_t re = hipSuccess;
-        const int build = hot ? kTreeBuildHot : mask_only ? kTreeBuildMask : fold ? kTreeBuildFold : kTreeBuildGeneral;
-        if (launch_tree_refill<NJ, NCH>(ph, dt, io, prm, stream, a, build, &re)) return re;
-    }
-    if (hot && !(prm.stop_sq_tol >= 0.0) && !std::getenv("IKGPU_TREE_NEVER_OFF"))   // the never-stop visitor: its own instantiation, as the hot chain kernel's
+    auto launch_lockstep = [&]() {
+    if (hot && !(a.prm.stop_sq_tol >= 0.0) && !std::getenv("IKGPU_TREE_NEVER_OFF"))   // the never-stop visitor: its own instantiation, as the hot chain kernel's
         hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, (kHot | (1 << ikdev::kSpecNever))>), grid, dim3(kTreeBlock), 0, stream, a);
     else if (hot) hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, kHot>), grid, dim3(kTreeBlock), 0, stream, a);
     else if (mask_only) hipLaunchKernelGGL((dls_tree_kernel<NJ, NCH, (kMask != 0 ? kMask : kHot)>), grid, dim3(kTreeBlock), 0, stream, a);
@@ -545,10 +613,29 @@ hipError_t run_dls_tree(const ProblemHost &ph, const DeviceTables &dt, const Bat
         if constexpr (NCH == 2) {
             if (ph.has_posture) IKGPU_TREE_GENERAL(ikdev::kSpecPostCons, 0);
             else IKGPU_TREE_GENERAL((1 << ikdev::kSpecCons), 0);
-        } else return hipErrorInvalidValue;
+        }
     } else if (ph.has_posture)
         IKGPU_TREE_GENERAL((1 << ikdev::kSpecPost), post_lds);
     else IKGPU_TREE_GENERAL(0, 0);
+    };
+    if constexpr (NCH != 2) {
+        if (ph.cons_on && !pik_lambda1 && !hot && !mask_only) return hipErrorInvalidValue;
+    }
+    // stop-rule mode on a batch larger than the machine: lane refill (kernels_tree_refill.hip) for the builds that have it -- every
+    // build without per-lane state outside q (no posture rows, no constraint, no ik::pik level) -- directly, or as the second phase
+    // after the lock-step kernel's first iterations (kernels.hpp stop_rule_mode)
+    if (!pik_lambda1 && !ph.cons_on && !ph.has_posture && prm.stop_sq_tol >= 0.0 && prm.max_iterations >= 1) {
+        hipError_t re = hipSuccess;
+        const int build = hot ? kTreeBuildHot : mask_only ? kTreeBuildMask : fold ? kTreeBuildFold : kTreeBuildGeneral;
+        if (launch_tree_refill<NJ, NCH>(ph, dt, io, prm, stream, a, build, &re, nullptr)) {
+            if (re != hipErrorNotReady) return re;
+            return run_two_phase(dt, io, stream, a, launch_lockstep, [&](unsigned long long *queue) {
+                hipError_t pe = hipSuccess;
+                (void)launch_tree_refill<NJ, NCH>(ph, dt, io, prm, stream, a, build, &pe, queue);
+            });
+        }
+    }
+    launch_lockstep();
 #undef IKGPU_TREE_GENERAL
     return hipGetLastError();
 }

@@ -81,6 +81,58 @@ std::string chain_kernel_name(const ProblemHost &ph);
 // is larger than the lanes the device keeps resident; IKGPU_REFILL=0 never, =1 whenever the mode allows.  `resident_waves`: what
 // hipOccupancyMaxActiveBlocksPerMultiprocessor reports for the refill kernel x the device's CUs (IKGPU_REFILL_WAVES_PER_CU overrides).
 bool refill_wanted(const ikgpu_dls_params &prm, int64_t B, int64_t resident_waves);
+// How a stop-rule solve of B problems runs (chain and tree kernels).  The kernel cannot know the targets' distribution in advance:
+// with targets near the start every lane stops within 2-3 iterations and lock-step is 1.5-2x faster than persistent refill waves
+// (whose loads are exposed); with far targets a few per cent of the problems run to max_iterations and lock-step is 2-4x slower.
+// TWO PHASES get both: (1) the lock-step kernel for the first K iterations over the whole batch, (2) a compaction of the problems
+// still unfinished into a worklist (device side, no host synchronisation), (3) the refill kernel over the worklist, continuing each
+// problem from its iterate in q_out at iteration K.  Results are the lock-step kernel's bits (a problem's state is its q).
+//   kStopLockStep: B fits the resident lanes, max_iterations < 1, never-stop visitor, or IKGPU_REFILL=0
+//   kStopRefill:   IKGPU_REFILL=1, or (B large and) max_iterations <= K, or the stream is being captured (the worklist is a
+//                  stream-ordered allocation)
+//   kStopTwoPhase: B larger than the resident lanes (default), or IKGPU_REFILL=2
+enum { kStopLockStep = 0, kStopRefill = 1, kStopTwoPhase = 2 };
+int stop_rule_mode(const ikgpu_dls_params &prm, int64_t B, int64_t resident_waves, hipStream_t stream);
+int two_phase_iterations();   // K (IKGPU_TWO_PHASE_ITERS overrides; default 4)
+struct TwoPhase {
+    int32_t *worklist = nullptr;            // [B]
+    unsigned long long *count = nullptr;    // device word
+    uint8_t *success = nullptr;             // the caller's arrays, or stream-ordered temporaries when it passed none
+    int32_t *iters = nullptr;
+    void *tmp[3] = {nullptr, nullptr, nullptr};
+};
+hipError_t two_phase_begin(const BatchIO &io, hipStream_t stream, TwoPhase *tp);               // allocate, zero the count
+hipError_t two_phase_compact(const BatchIO &io, const TwoPhase &tp, hipStream_t stream);       // unfinished problems -> worklist
+hipError_t two_phase_end(TwoPhase *tp, hipStream_t stream);                                    // free (stream-ordered)
+// The three launches of a two-phase solve around a kernel-argument block `a` with the members {prm.max_iterations, success, iters,
+// worklist, count, it0} (ChainKernelArgs / TreeKernelArgs): lockstep() launches the problem's lock-step kernel with `a`,
+// refill(queue) its refill kernel.  The first phase writes every entry of q_out (also those outside the task supports, clipped once a
+// step was taken); the second rewrites the rows a solve moves and the flags of the listed problems only -- no pass-through launch.
+template <class Args, class LockStepFn, class RefillFn>
+hipError_t run_two_phase(const DeviceTables &dt, const BatchIO &io, hipStream_t stream, Args &a, LockStepFn lockstep, RefillFn refill) {
+    hipError_t qe = hipSuccess;
+    unsigned long long *queue = dt.queues.slot_for(stream, &qe);
+    if (!queue) return qe;
+    TwoPhase tp;
+    hipError_t e = two_phase_begin(io, stream, &tp);
+    if (e == hipSuccess) {
+        const int max_it = a.prm.max_iterations;
+        a.success = tp.success; a.iters = tp.iters;
+        a.prm.max_iterations = two_phase_iterations();
+        a.worklist = nullptr; a.count = nullptr; a.it0 = 0;
+        lockstep();
+        e = hipGetLastError();
+        if (e == hipSuccess) e = two_phase_compact(io, tp, stream);
+        if (e == hipSuccess) {
+            a.prm.max_iterations = max_it;
+            a.worklist = tp.worklist; a.count = tp.count; a.it0 = two_phase_iterations();
+            refill(queue);
+            e = hipGetLastError();
+        }
+    }
+    const hipError_t f = two_phase_end(&tp, stream);
+    return e != hipSuccess ? e : f;
+}
 // the lock-step builds of the tree kernel a refill launch can mirror (kernels.hip run_dls_tree / kernels_tree_refill.hip)
 enum { kTreeBuildGeneral = 0, kTreeBuildHot = 1, kTreeBuildMask = 2, kTreeBuildFold = 3 };
 int64_t refill_grid(const void *kernel, int64_t B);

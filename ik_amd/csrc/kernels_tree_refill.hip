@@ -76,9 +76,11 @@ template <> struct HotMask<7> { static constexpr int value = 0xf8; };
 // build the problem runs on (kernels.hip run_dls_tree), whose lane program the refill kernel must share to return the same bits:
 // kTreeBuildHot (mask, unit weights, base task at a translation: all folded), kTreeBuildMask (the placement mask folded only),
 // kTreeBuildFold (the mask next to the general extras: base-relative references, alignment row, fixed base), kTreeBuildGeneral.
+// *err == hipErrorNotReady (returned true): the batch wants the TWO-PHASE solve -- the caller launches its lock-step kernel for the first
+// iterations, compacts, and calls again with phase2_queue set (kernels.hpp run_two_phase).
 template <int NJ, int NCH>
 bool launch_tree_refill(const ProblemHost &ph, const DeviceTables &dt, const BatchIO &io, const ikgpu_dls_params &prm, hipStream_t stream,
-                        ikdev::TreeKernelArgs<NJ, NCH> a, int build, hipError_t *err) {
+                        ikdev::TreeKernelArgs<NJ, NCH> a, int build, hipError_t *err, unsigned long long *phase2_queue) {
     if constexpr (NJ != 7) {
         return false;
     } else {
@@ -94,7 +96,22 @@ bool launch_tree_refill(const ProblemHost &ph, const DeviceTables &dt, const Bat
         const int64_t occ_waves = persistent_grid(kern, kTreeBlock, 0, INT64_MAX) * kTreeWaves;
         int64_t waves = refill_resident(occ_waves, io.B);
         waves = std::max<int64_t>(kTreeWaves, waves / kTreeWaves * kTreeWaves);
-        if (!refill_wanted(prm, io.B, waves)) return false;
+        const dim3 grid(static_cast<unsigned>(waves / kTreeWaves));
+        const int chunk = refill_chunk(io.B, waves);
+        auto launch = [&](unsigned long long *queue) {
+            if (build == kTreeBuildHot) hipLaunchKernelGGL((dls_tree_refill_kernel<NJ, NCH, kHot>), grid, dim3(kTreeBlock), 0, stream, a, queue, chunk);
+            else if (build == kTreeBuildMask) hipLaunchKernelGGL((dls_tree_refill_kernel<NJ, NCH, kMask>), grid, dim3(kTreeBlock), 0, stream, a, queue, chunk);
+            else if (build == kTreeBuildFold) hipLaunchKernelGGL((dls_tree_refill_kernel<NJ, NCH, kFold>), grid, dim3(kTreeBlock), 0, stream, a, queue, chunk);
+            else hipLaunchKernelGGL((dls_tree_refill_kernel<NJ, NCH, 0>), grid, dim3(kTreeBlock), 0, stream, a, queue, chunk);
+            return hipGetLastError();
+        };
+        if (phase2_queue) {   // second phase of a two-phase solve (kernels.hpp run_two_phase): `a` carries the worklist; nothing else to do
+            *err = launch(phase2_queue);
+            return true;
+        }
+        const int mode = stop_rule_mode(prm, io.B, waves, stream);
+        if (mode == kStopLockStep) return false;
+        if (mode == kStopTwoPhase) { *err = hipErrorNotReady; return true; }   // (the caller runs the phases: it owns the lock-step launch)
         hipError_t e = hipSuccess;
         unsigned long long *queue = dt.queues.slot_for(stream, &e);
         if (!queue) { *err = e; return true; }
@@ -103,13 +120,7 @@ bool launch_tree_refill(const ProblemHost &ph, const DeviceTables &dt, const Bat
             if ((e = hipMallocAsync(&tmp, sizeof(int32_t) * static_cast<size_t>(io.B), stream)) != hipSuccess) { *err = e; return true; }
             a.iters = static_cast<int32_t *>(tmp);
         }
-        const dim3 grid(static_cast<unsigned>(waves / kTreeWaves));
-        const int chunk = refill_chunk(io.B, waves);
-        if (build == kTreeBuildHot) hipLaunchKernelGGL((dls_tree_refill_kernel<NJ, NCH, kHot>), grid, dim3(kTreeBlock), 0, stream, a, queue, chunk);
-        else if (build == kTreeBuildMask) hipLaunchKernelGGL((dls_tree_refill_kernel<NJ, NCH, kMask>), grid, dim3(kTreeBlock), 0, stream, a, queue, chunk);
-        else if (build == kTreeBuildFold) hipLaunchKernelGGL((dls_tree_refill_kernel<NJ, NCH, kFold>), grid, dim3(kTreeBlock), 0, stream, a, queue, chunk);
-        else hipLaunchKernelGGL((dls_tree_refill_kernel<NJ, NCH, 0>), grid, dim3(kTreeBlock), 0, stream, a, queue, chunk);
-        e = hipGetLastError();
+        e = launch(queue);
         if (e == hipSuccess) e = launch_chain_pass_through(ph, dt, io, a.iters, stream);
         if (tmp) {
             const hipError_t f = hipFreeAsync(tmp, stream);
@@ -120,9 +131,9 @@ bool launch_tree_refill(const ProblemHost &ph, const DeviceTables &dt, const Bat
     }
 }
 
-template bool launch_tree_refill<7, 2>(const ProblemHost &, const DeviceTables &, const BatchIO &, const ikgpu_dls_params &, hipStream_t, ikdev::TreeKernelArgs<7, 2>, int, hipError_t *);
-template bool launch_tree_refill<7, 1>(const ProblemHost &, const DeviceTables &, const BatchIO &, const ikgpu_dls_params &, hipStream_t, ikdev::TreeKernelArgs<7, 1>, int, hipError_t *);
-template bool launch_tree_refill<6, 2>(const ProblemHost &, const DeviceTables &, const BatchIO &, const ikgpu_dls_params &, hipStream_t, ikdev::TreeKernelArgs<6, 2>, int, hipError_t *);
-template bool launch_tree_refill<6, 1>(const ProblemHost &, const DeviceTables &, const BatchIO &, const ikgpu_dls_params &, hipStream_t, ikdev::TreeKernelArgs<6, 1>, int, hipError_t *);
+template bool launch_tree_refill<7, 2>(const ProblemHost &, const DeviceTables &, const BatchIO &, const ikgpu_dls_params &, hipStream_t, ikdev::TreeKernelArgs<7, 2>, int, hipError_t *, unsigned long long *);
+template bool launch_tree_refill<7, 1>(const ProblemHost &, const DeviceTables &, const BatchIO &, const ikgpu_dls_params &, hipStream_t, ikdev::TreeKernelArgs<7, 1>, int, hipError_t *, unsigned long long *);
+template bool launch_tree_refill<6, 2>(const ProblemHost &, const DeviceTables &, const BatchIO &, const ikgpu_dls_params &, hipStream_t, ikdev::TreeKernelArgs<6, 2>, int, hipError_t *, unsigned long long *);
+template bool launch_tree_refill<6, 1>(const ProblemHost &, const DeviceTables &, const BatchIO &, const ikgpu_dls_params &, hipStream_t, ikdev::TreeKernelArgs<6, 1>, int, hipError_t *, unsigned long long *);
 
 }  // namespace ikgpu

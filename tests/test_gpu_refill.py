@@ -81,10 +81,15 @@ def test_refill_is_bit_identical_to_lock_step_on_a_batch_larger_than_the_machine
     B = 300000 + 17
     model, problem, data, q0, Q0, T = _problem(torch, name, frame, ik_amd.KinematicType(ktype), build, B)
     a = _solve(ik_amd, problem, data, Q0, T, "0")
-    b = _solve(ik_amd, problem, data, Q0, T, None)      # the default policy: B > resident lanes -> refill
+    b = _solve(ik_amd, problem, data, Q0, T, None)      # the default policy: B > resident lanes -> two phases (lock-step, then refill on the unfinished)
     c = _solve(ik_amd, problem, data, Q0, T, "1")
     for x, y, z in zip(a, b, c):
         assert np.array_equal(x, y) and np.array_equal(x, z), (name, build, data.kernel)
+    # ... on targets near the start too (every problem is done in the first phase: the worklist is empty)
+    _, _, _, _, Q0n, Tn = _problem(torch, name, frame, ik_amd.KinematicType(ktype), build, 200000 + 5, mode="near")
+    an, bn = _solve(ik_amd, problem, data, Q0n, Tn, "0"), _solve(ik_amd, problem, data, Q0n, Tn, None)
+    for x, y in zip(an, bn):
+        assert np.array_equal(x, y), (name, build, "near")
     assert 0 < a[1].mean() < 1 or name != "cassie_fixed"     # the workload has both outcomes
     print("%s [%s]: %d problems, success %.4f, mean iterations %.2f" % (name, data.kernel, B, a[1].mean(), a[2].mean()))
 
@@ -97,11 +102,12 @@ def test_refill_forced_at_small_and_ragged_batches(torch_cuda, B, layout):
     model, problem, data, q0, Q0, T = _problem(torch, "cassie_fixed", "LeftFootFront", ik_amd.KinematicType.Full, "default", B)
     if layout == "aos":
         Q0, T = Q0.t().contiguous(), T.permute(2, 0, 1).contiguous()
-    for max_it in (1, 2, 100):
+    for max_it in (1, 2, 5, 100):
         a = _solve(ik_amd, problem, data, Q0, T, "0", max_it=max_it, layout=layout)
         b = _solve(ik_amd, problem, data, Q0, T, "1", max_it=max_it, layout=layout)
-        for x, y in zip(a, b):
-            assert np.array_equal(x, y), (B, layout, max_it)
+        c = _solve(ik_amd, problem, data, Q0, T, "2", max_it=max_it, layout=layout)    # two phases: lock-step for 4 iterations, refill on the rest
+        for x, y, z in zip(a, b, c):
+            assert np.array_equal(x, y) and np.array_equal(x, z), (B, layout, max_it)
 
 
 def test_refill_against_the_oracle_and_iteration_zero_stops(torch_cuda):
@@ -137,11 +143,13 @@ def test_refill_without_the_optional_outputs(torch_cuda):
     ref = _solve(ik_amd, problem, data, Q0, T, "0")
     Q = torch.full_like(Q0, float("nan"))
     prm = capi.DlsParams(100, 1e-2, 1.0, 1e-4)
-    with env(IKGPU_REFILL="1"):
-        capi.check(capi.lib().ikgpu_dls_solve_batch(data._h, B, Q0.data_ptr(), T.data_ptr(), C.byref(prm), Q.data_ptr(), None, None, capi.SOA,
-                                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-    torch.cuda.synchronize()
-    assert np.array_equal(Q.cpu().numpy(), ref[0])
+    for mode in ("1", "2"):
+        Q.fill_(float("nan"))
+        with env(IKGPU_REFILL=mode):
+            capi.check(capi.lib().ikgpu_dls_solve_batch(data._h, B, Q0.data_ptr(), T.data_ptr(), C.byref(prm), Q.data_ptr(), None, None, capi.SOA,
+                                                        C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        assert np.array_equal(Q.cpu().numpy(), ref[0]), mode
 
 
 def _generic_problem(torch, B):

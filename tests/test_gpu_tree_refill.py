@@ -117,7 +117,7 @@ def test_tree_refill_is_bit_identical_to_lock_step_on_a_batch_larger_than_the_ma
     B = 300000 + 17
     ik_amd, O, model, problem, data, om, ot, ospec, q0, tg, Q0, T, damping, step = _problem(torch, case, B, "uniform")
     a = _solve(ik_amd, problem, data, Q0, T, "0", damping, step)
-    b = _solve(ik_amd, problem, data, Q0, T, None, damping, step)      # the default policy: B > resident lanes -> refill
+    b = _solve(ik_amd, problem, data, Q0, T, None, damping, step)      # the default policy: B > resident lanes -> two phases (lock-step, then refill)
     c = _solve(ik_amd, problem, data, Q0, T, "1", damping, step)
     for x, y, z in zip(a, b, c):
         assert np.array_equal(x, y) and np.array_equal(x, z), (case, data.kernel)
@@ -136,11 +136,12 @@ def test_tree_refill_forced_at_small_and_ragged_batches(torch_cuda, case, layout
             q, t = Q0[:, :B].t().contiguous(), T[:, :, :B].permute(2, 0, 1).contiguous()
         else:
             q, t = Q0[:, :B].contiguous(), T[:, :, :B].contiguous()
-        for max_it in ((1, 2, 100) if B <= 1000 else (100,)):
+        for max_it in ((1, 2, 5, 100) if B <= 1000 else (100,)):
             a = _solve(ik_amd, problem, data, q, t, "0", damping, step, max_it=max_it, layout=layout)
             b = _solve(ik_amd, problem, data, q, t, "1", damping, step, max_it=max_it, layout=layout)
-            for x, y in zip(a, b):
-                assert np.array_equal(x, y), (case, B, layout, max_it)
+            c = _solve(ik_amd, problem, data, q, t, "2", damping, step, max_it=max_it, layout=layout)   # two phases (kernels.hpp stop_rule_mode)
+            for x, y, z in zip(a, b, c):
+                assert np.array_equal(x, y) and np.array_equal(x, z), (case, B, layout, max_it)
             assert (a[2] <= max_it).all() and (a[2][a[1] == 0] == max_it).all()
 
 
@@ -154,11 +155,13 @@ def test_tree_refill_without_the_optional_outputs(torch_cuda, case):
     ref = _solve(ik_amd, problem, data, Q0, T, "0", damping, step)
     Q = torch.full_like(Q0, float("nan"))
     prm = capi.DlsParams(100, damping, step, 1e-4)
-    with env(IKGPU_REFILL="1"):
-        capi.check(capi.lib().ikgpu_dls_solve_batch(data._h, B, Q0.data_ptr(), T.data_ptr(), C.byref(prm), Q.data_ptr(), None, None, capi.SOA,
-                                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-    torch.cuda.synchronize()
-    assert np.array_equal(Q.cpu().numpy(), ref[0])
+    for mode in ("1", "2"):
+        Q.fill_(float("nan"))
+        with env(IKGPU_REFILL=mode):
+            capi.check(capi.lib().ikgpu_dls_solve_batch(data._h, B, Q0.data_ptr(), T.data_ptr(), C.byref(prm), Q.data_ptr(), None, None, capi.SOA,
+                                                        C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        assert np.array_equal(Q.cpu().numpy(), ref[0]), mode
 
 
 @pytest.mark.parametrize("case", ["full_body", "full_body_weighted", "demo_task_set", "fixed_two_feet"])

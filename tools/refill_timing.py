@@ -85,5 +85,8 @@ for build in (("default",) if FULL_BODY else ("default", "general")):
                     row += " | refill %s w/CU %.3f ms%s" % (wpc, ms1, "" if same else " DIFFERENT")
                 os.environ.pop("IKGPU_REFILL_WAVES_PER_CU")
                 os.environ.pop("IKGPU_REFILL")
+                ms2, out2 = timed(data, Q0, T, vis, prm)       # the default policy (two phases above the resident batch)
+                same = all(torch.equal(x, y) for x, y in zip(out0, out2))
+                row += " | default policy %.3f ms%s" % (ms2, "" if same else " DIFFERENT")
                 ideal = mean_it * ms50 / 50      # (ms50 is the 50-iteration time of THIS batch: it already scales with B)
                 print(row + " | ideal (mean_it x time per iteration of the batch) %.3f ms" % ideal)
