@@ -203,20 +203,21 @@ def load_model(ik_amd, workload, w):
     return ik_amd.Model.from_urdf_xml(xml, free_flyer=w["free_flyer"]), xml
 
 
-def make_inputs(name, model, idx):
+def make_inputs(name, model, idx, mode=None):
+    """mode: None = the workload's own target distribution; "uniform" / "near" override it (SURVEY.md 8d's two distributions)."""
     import numpy as np
     from ik_amd import workload
     w = WORKLOADS[name]
     lo, hi = model.lowerPositionLimit, model.upperPositionLimit
     if w["free_flyer"]:
-        return workload.freeflyer_workload(lo, hi, workload.cassie_nominal(model.names), idx, seed=0, mode="near")
+        return workload.freeflyer_workload(lo, hi, workload.cassie_nominal(model.names), idx, seed=0, mode=mode or "near")
     if name in ("ur5", "ur10", "ur5_two_tasks", "ur5_pos_then_ori_pik"):
-        return workload.chain_workload(lo, hi, workload.UR5_NOMINAL, idx, seed=0, mode="near")
+        return workload.chain_workload(lo, hi, workload.UR5_NOMINAL, idx, seed=0, mode=mode or "near")
     if name == "arm7":
-        return workload.chain_workload(lo, hi, np.zeros(model.nq), idx, seed=0, mode="near")
+        return workload.chain_workload(lo, hi, np.zeros(model.nq), idx, seed=0, mode=mode or "near")
     if w.get("narrow"):
-        return workload.chain_workload(lo, hi, workload.UR5_NOMINAL, idx, seed=0, mode="uniform")
-    return workload.chain_workload(lo, hi, workload.cassie_nominal(model.names), idx, seed=0, mode="uniform")
+        return workload.chain_workload(lo, hi, workload.UR5_NOMINAL, idx, seed=0, mode=mode or "uniform")
+    return workload.chain_workload(lo, hi, workload.cassie_nominal(model.names), idx, seed=0, mode=mode or "uniform")
 
 
 def task_specs(w):
@@ -359,9 +360,9 @@ def main():
     else:
         data = ik_amd.dls_data(problem, device=local_rank)
 
-    def device_inputs(idx):
+    def device_inputs(idx, mode=None):
         """(q0 host, Q0 device [nq, b], targets device [ntasks, 12, b]) of the problems `idx` of the global synthetic batch."""
-        q0_h, qs_h = make_inputs(args.workload, model, idx)
+        q0_h, qs_h = make_inputs(args.workload, model, idx, mode)
         b = len(idx)
         Q0_d = torch.from_numpy(np.ascontiguousarray(q0_h.T)).to(dev)
         QS = torch.from_numpy(np.ascontiguousarray(qs_h.T)).to(dev)
@@ -572,27 +573,37 @@ def main():
                                         "stop_sq_tol": stop.tolerance, "max_iterations": 100,
                                         "mean_iterations": float(its.double().mean().item()),
                                         "success_rate": float(oks.double().mean().item())}
-            # (i-b) the stop rule on batches larger than the machine: lock-step waves (a wave runs until its last lane stops) against lane
-            # refill (a finished lane takes the next problem: device/chain_kernel_body.hpp); same results bit for bit
+            # (i-b) the stop rule on batches larger than the machine, for BOTH target distributions of SURVEY.md 8d ("uniform": a few per
+            # cent of the problems never converge; "near": every problem is done in 2-3 iterations): lock-step waves (IKGPU_REFILL=0: a
+            # wave runs until its last lane stops), lane refill from the first iteration (=1: a finished lane takes the next problem,
+            # device/chain_kernel_body.hpp) and the library's DEFAULT (no switch: two phases -- lock-step for the first iterations,
+            # then refill over the unfinished problems; kernels.hpp stop_rule_mode).  Same results bit for bit.
             if data.kernel.startswith("dls_chain<") or data.kernel == "dls_tree<NJ=7,chains=2,base_task>":
                 big = []
-                for bb in (CONFIG4_GLOBAL_BATCH, 4 * CONFIG4_GLOBAL_BATCH):
-                    _, Q0_b, tg_b = device_inputs(np.arange(bb))
-                    row = {"batch": bb}
-                    for label, val in (("lock_step", "0"), ("lane_refill", "1")):
-                        os.environ["IKGPU_REFILL"] = val
-                        ms_b, (Qb, okb, itb) = time_solve(Q0_b, tg_b, reps=3, p=prm_stop, vis=stop)
-                        row[label] = {"kernel_ms": ms_b, "value": bb / (ms_b * 1e-3), "unit": "solves/s"}
-                        if label == "lock_step":
-                            keep = (Qb.clone(), okb.clone(), itb.clone())
-                            row["mean_iterations"] = float(itb.double().mean().item())
-                            row["success_rate"] = float(okb.double().mean().item())
-                        else:
-                            row["bit_identical"] = bool(torch.equal(keep[0], Qb) and torch.equal(keep[1], okb) and torch.equal(keep[2], itb))
-                        row[label]["useful_iterations_per_s"] = row["mean_iterations"] * bb / (ms_b * 1e-3)
-                    os.environ.pop("IKGPU_REFILL", None)
-                    big.append(row)
-                    del Q0_b, tg_b
+                for dist_mode in ("uniform", "near"):
+                    for bb in (CONFIG4_GLOBAL_BATCH, 4 * CONFIG4_GLOBAL_BATCH):
+                        _, Q0_b, tg_b = device_inputs(np.arange(bb), dist_mode)
+                        row = {"batch": bb, "targets": dist_mode}
+                        for label, val in (("lock_step", "0"), ("lane_refill", "1"), ("default_policy", None)):
+                            if val is None:
+                                os.environ.pop("IKGPU_REFILL", None)
+                            else:
+                                os.environ["IKGPU_REFILL"] = val
+                            ms_b, (Qb, okb, itb) = time_solve(Q0_b, tg_b, reps=3, p=prm_stop, vis=stop)
+                            row[label] = {"kernel_ms": ms_b, "value": bb / (ms_b * 1e-3), "unit": "solves/s"}
+                            if label == "lock_step":
+                                keep = (Qb.clone(), okb.clone(), itb.clone())
+                                row["mean_iterations"] = float(itb.double().mean().item())
+                                row["success_rate"] = float(okb.double().mean().item())
+                                row["bit_identical"] = True
+                            else:
+                                row["bit_identical"] = bool(row["bit_identical"] and torch.equal(keep[0], Qb) and torch.equal(keep[1], okb) and torch.equal(keep[2], itb))
+                            row[label]["useful_iterations_per_s"] = row["mean_iterations"] * bb / (ms_b * 1e-3)
+                        os.environ.pop("IKGPU_REFILL", None)
+                        best = min(row["lock_step"]["kernel_ms"], row["lane_refill"]["kernel_ms"])
+                        row["default_policy"]["over_the_better_fixed_mode"] = row["default_policy"]["kernel_ms"] / best
+                        big.append(row)
+                        del Q0_b, tg_b
                 res["stop_rule_large_batches"] = big
             # (i-c) the general chain build on the headline inputs: what a chain without a structure-specialised kernel runs on
             if data.kernel.startswith("dls_chain<") and not data.kernel.endswith(",general>"):
