@@ -374,6 +374,7 @@ IKD_FN void hot_chain_body(const ChainKernelArgs<NJ> &a, const Tab &t, int64_t g
     const int stamp_pre_ticks = static_cast<int>(r0 - rs);
     const int stamp_true_iters = iters;
 #endif
+    if (!NEVERSTOP && a.append_count) append_unfinished(a.append_list, a.append_count, valid && !success, b);   // (first phase of a two-phase solve)
     if (!valid) return;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) a.q_out[at(a.layout, a.B, a.nq, a.qidx[j], b)] = q[j];

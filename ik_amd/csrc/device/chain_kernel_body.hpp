@@ -34,7 +34,28 @@ struct ChainKernelArgs {
     const int32_t *worklist;
     const unsigned long long *count;   // (device) length of the list
     int it0;
+    // ... and of its first phase: the lock-step kernel appends the problems it leaves unfinished (append_unfinished below)
+    int32_t *append_list;
+    unsigned long long *append_count;
 };
+
+// First phase of a two-phase solve: the lanes of a wave whose problem is still open after the lock-step iterations append its index to
+// the list -- one atomic per wave.  Called by EVERY lane of the wave (tail lanes with open = false).
+IKD_FN void append_unfinished(int32_t *list, unsigned long long *count, bool open, int64_t b) {
+#if IKD_ON_DEVICE
+    const unsigned long long mask = __ballot(open);
+    if (mask == 0ull) return;
+    const int lane = static_cast<int>(threadIdx.x) & 63;
+    unsigned long long base = 0;
+    if (lane == __ffsll(static_cast<long long>(mask)) - 1) base = atomicAdd(count, static_cast<unsigned long long>(__popcll(mask)));
+    const int src = __ffsll(static_cast<long long>(mask)) - 1;
+    const unsigned lo = __shfl(static_cast<unsigned>(base), src), hi = __shfl(static_cast<unsigned>(base >> 32), src);
+    base = (static_cast<unsigned long long>(hi) << 32) | lo;
+    if (open) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = static_cast<int32_t>(b);
+#else
+    if (open) list[(*count)++] = static_cast<int32_t>(b);
+#endif
+}
 
 IKD_FN int64_t at(int layout, int64_t B, int ncomp, int c, int64_t b) {
     return layout == LAYOUT_SOA ? static_cast<int64_t>(c) * B + b : b * ncomp + c;
@@ -72,6 +93,7 @@ IKD_FN void dls_chain_body(const ChainKernelArgs<NJ> &a, const Desc &d, int64_t 
     bool success;
     chain_dls<NJ, KT, SMASK>(d, a.prm, q, oMt, iters, success, any_active);
 
+    if (a.append_count) append_unfinished(a.append_list, a.append_count, valid && !success, b);   // (wave-uniform test)
     if (!valid) return;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) a.q_out[at(a.layout, a.B, a.nq, a.qidx[j], b)] = q[j];
@@ -183,6 +205,7 @@ __device__ __forceinline__ void chain_refill_loop(const ChainKernelArgs<NJ> &a, 
         if (atomicAdd(queue + 1, 1ull) == static_cast<unsigned long long>(gridDim.x) - 1ull) {
             queue[0] = 0ull;
             queue[1] = 0ull;
+            queue[2] = 0ull;   // (the two-phase worklist's length)
             __threadfence();
         }
     }

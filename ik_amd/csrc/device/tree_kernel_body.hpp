@@ -32,6 +32,8 @@ struct TreeKernelArgs {
     const int32_t *worklist;
     const unsigned long long *count;
     int it0;
+    int32_t *append_list;            // ... and of its first phase (chain_kernel_body.hpp append_unfinished)
+    unsigned long long *append_count;
 };
 
 // B independent ik::dls() calls (reference ik/ik/dls.cpp:5-78) on a free-flyer model, lane `gid`.
@@ -83,6 +85,7 @@ IKD_FN void dls_tree_body(const TreeKernelArgs<NJ, NCH> &a, const Desc &d, int64
         for (int k = 0; k < a.prm.post_n; ++k) a.q_out[at(a.layout, a.B, a.nq, a.prm.post_q[k], b)] = ps.q_lane[k * ps.stride];
     }
 
+    if (a.append_count) append_unfinished(a.append_list, a.append_count, valid && !success, b);   // (wave-uniform test)
     if (!valid) return;
 #pragma unroll
     for (int k = 0; k < 7; ++k)
@@ -213,6 +216,7 @@ __device__ __forceinline__ void dls_tree_refill_body(const TreeKernelArgs<NJ, NC
         if (atomicAdd(queue + 1, 1ull) == static_cast<unsigned long long>(nwaves) - 1ull) {
             queue[0] = 0ull;
             queue[1] = 0ull;
+            queue[2] = 0ull;   // (the two-phase worklist's length)
             __threadfence();
         }
     }

@@ -281,44 +281,23 @@ int stop_rule_mode(const ikgpu_dls_params &prm, int64_t B, int64_t resident_wave
     return kStopTwoPhase;
 }
 
-namespace {
-// Problems the first phase left unfinished (no success, K iterations taken) -> worklist; one atomic per wave.
-__global__ __launch_bounds__(256) void two_phase_compact_kernel(const uint8_t *success, int64_t B, int32_t *worklist, unsigned long long *count) {
-    const int64_t b = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-    const bool open = b < B && success[b] == 0;
-    const unsigned long long mask = __ballot(open);
-    if (mask == 0ull) return;
-    const int lane = static_cast<int>(threadIdx.x) & 63;
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(count, static_cast<unsigned long long>(__popcll(mask)));
-    const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(base)), hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(base >> 32));
-    base = (static_cast<unsigned long long>(hi) << 32) | lo;
-    if (open) worklist[base + __popcll(mask & ((1ull << lane) - 1ull))] = static_cast<int32_t>(b);
-}
-}  // namespace
-
-hipError_t two_phase_begin(const BatchIO &io, hipStream_t stream, TwoPhase *tp) {
-    if (io.B > 0x7fffffff) return hipErrorInvalidValue;   // (the worklist holds 32-bit problem indices; larger batches keep the one-phase modes)
-    hipError_t e = hipMallocAsync(&tp->tmp[0], sizeof(int32_t) * static_cast<size_t>(io.B) + 16, stream);
-    if (e != hipSuccess) return e;
-    tp->count = static_cast<unsigned long long *>(tp->tmp[0]);
-    tp->worklist = reinterpret_cast<int32_t *>(static_cast<char *>(tp->tmp[0]) + 16);
+hipError_t two_phase_begin(const DeviceTables &dt, const BatchIO &io, hipStream_t stream, unsigned long long *queue, TwoPhase *tp) {
+    if (io.B > 0x7fffffff) return hipErrorInvalidValue;   // (the worklist holds 32-bit problem indices)
+    hipError_t e = hipSuccess;
+    tp->worklist = dt.queues.worklist_for(stream, static_cast<size_t>(io.B), &e);
+    if (!tp->worklist) return e;
+    tp->count = queue + 2;
     tp->success = io.success;
     tp->iters = io.iters;
     if (!tp->success) {
-        if ((e = hipMallocAsync(&tp->tmp[1], static_cast<size_t>(io.B), stream)) != hipSuccess) return e;
-        tp->success = static_cast<uint8_t *>(tp->tmp[1]);
+        if ((e = hipMallocAsync(&tp->tmp[0], static_cast<size_t>(io.B), stream)) != hipSuccess) return e;
+        tp->success = static_cast<uint8_t *>(tp->tmp[0]);
     }
     if (!tp->iters) {
-        if ((e = hipMallocAsync(&tp->tmp[2], sizeof(int32_t) * static_cast<size_t>(io.B), stream)) != hipSuccess) return e;
-        tp->iters = static_cast<int32_t *>(tp->tmp[2]);
+        if ((e = hipMallocAsync(&tp->tmp[1], sizeof(int32_t) * static_cast<size_t>(io.B), stream)) != hipSuccess) return e;
+        tp->iters = static_cast<int32_t *>(tp->tmp[1]);
     }
-    return hipMemsetAsync(tp->count, 0, 16, stream);
-}
-
-hipError_t two_phase_compact(const BatchIO &io, const TwoPhase &tp, hipStream_t stream) {
-    hipLaunchKernelGGL(two_phase_compact_kernel, dim3(static_cast<unsigned>((io.B + 255) / 256)), dim3(256), 0, stream, tp.success, io.B, tp.worklist, tp.count);
-    return hipGetLastError();
+    return hipSuccess;
 }
 
 hipError_t two_phase_end(TwoPhase *tp, hipStream_t stream) {
@@ -861,7 +840,7 @@ bool raise_lds_limit(const void *kernel, size_t lds) {
 hipError_t QueuePool::grow() {
     std::lock_guard<std::mutex> lock(mu);
     void *p = nullptr;
-    const size_t bytes = sizeof(unsigned long long) * 2 * kChunkSlots;
+    const size_t bytes = sizeof(unsigned long long) * 4 * kChunkSlots;
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) return e;
     if ((e = hipMemset(p, 0, bytes)) != hipSuccess) { (void)hipFree(p); return e; }
@@ -881,7 +860,7 @@ unsigned long long *QueuePool::slot_for(hipStream_t stream, hipError_t *err) {
             if (it != by_stream.end()) return it->second;
         }
         if (used_in_last < kChunkSlots && !chunks.empty()) {
-            unsigned long long *slot = chunks.back() + 2 * used_in_last++;
+            unsigned long long *slot = chunks.back() + 4 * used_in_last++;
             if (!capturing) by_stream.emplace(stream, slot);
             return slot;
         }
@@ -894,8 +873,24 @@ unsigned long long *QueuePool::slot_for(hipStream_t stream, hipError_t *err) {
     return slot_for(stream, err);
 }
 
+int32_t *QueuePool::worklist_for(hipStream_t stream, size_t n, hipError_t *err) {
+    std::lock_guard<std::mutex> lock(mu);
+    std::pair<int32_t *, size_t> &l = lists[stream];
+    if (l.second < n) {
+        // (the stream's previous solve may still read the old list: wait for it before the buffer goes)
+        if (l.first) { (void)hipStreamSynchronize(stream); (void)hipFree(l.first); l = {nullptr, 0}; }
+        void *p = nullptr;
+        const size_t cap = std::max<size_t>(n, 65536);
+        if ((*err = hipMalloc(&p, cap * sizeof(int32_t))) != hipSuccess) return nullptr;
+        l = {static_cast<int32_t *>(p), cap};
+    }
+    return l.first;
+}
+
 void QueuePool::release() {
     std::lock_guard<std::mutex> lock(mu);
+    for (auto &kv : lists) (void)hipFree(kv.second.first);
+    lists.clear();
     for (unsigned long long *c : chunks) (void)hipFree(c);
     chunks.clear();
     by_stream.clear();

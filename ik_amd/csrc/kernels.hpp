@@ -25,8 +25,13 @@ struct QueuePool {
     int used_in_last = kChunkSlots;
     std::unordered_map<hipStream_t, unsigned long long *> by_stream;
     hipError_t grow();                           // one more zeroed chunk (not during stream capture: hipMalloc / hipMemset are not capturable)
-    // the slot of a launch on `stream`, or nullptr with *err set
+    // the slot of a launch on `stream`, or nullptr with *err set.  A slot is FOUR words: {head, workgroups that have left, length of
+    // the two-phase worklist, spare}; the last workgroup out of a refill launch zeroes the first three.
     unsigned long long *slot_for(hipStream_t stream, hipError_t *err);
+    // the stream's worklist of a two-phase solve (kernels.hpp stop_rule_mode): n 32-bit problem indices, grown on demand and kept (two
+    // solves on one stream are ordered; solves on different streams have their own).  Not during stream capture (hipMalloc).
+    std::unordered_map<hipStream_t, std::pair<int32_t *, size_t>> lists;
+    int32_t *worklist_for(hipStream_t stream, size_t n, hipError_t *err);
     void release();
 };
 
@@ -95,36 +100,38 @@ enum { kStopLockStep = 0, kStopRefill = 1, kStopTwoPhase = 2 };
 int stop_rule_mode(const ikgpu_dls_params &prm, int64_t B, int64_t resident_waves, hipStream_t stream);
 int two_phase_iterations();   // K (IKGPU_TWO_PHASE_ITERS overrides; default 4)
 struct TwoPhase {
-    int32_t *worklist = nullptr;            // [B]
-    unsigned long long *count = nullptr;    // device word
+    int32_t *worklist = nullptr;            // [B] (QueuePool::worklist_for)
+    unsigned long long *count = nullptr;    // word 2 of the launch's queue slot: zero before the solve, zeroed again by the refill kernel's last wave
     uint8_t *success = nullptr;             // the caller's arrays, or stream-ordered temporaries when it passed none
     int32_t *iters = nullptr;
-    void *tmp[3] = {nullptr, nullptr, nullptr};
+    void *tmp[2] = {nullptr, nullptr};
 };
-hipError_t two_phase_begin(const BatchIO &io, hipStream_t stream, TwoPhase *tp);               // allocate, zero the count
-hipError_t two_phase_compact(const BatchIO &io, const TwoPhase &tp, hipStream_t stream);       // unfinished problems -> worklist
-hipError_t two_phase_end(TwoPhase *tp, hipStream_t stream);                                    // free (stream-ordered)
-// The three launches of a two-phase solve around a kernel-argument block `a` with the members {prm.max_iterations, success, iters,
-// worklist, count, it0} (ChainKernelArgs / TreeKernelArgs): lockstep() launches the problem's lock-step kernel with `a`,
-// refill(queue) its refill kernel.  The first phase writes every entry of q_out (also those outside the task supports, clipped once a
-// step was taken); the second rewrites the rows a solve moves and the flags of the listed problems only -- no pass-through launch.
+hipError_t two_phase_begin(const DeviceTables &dt, const BatchIO &io, hipStream_t stream, unsigned long long *queue, TwoPhase *tp);
+hipError_t two_phase_end(TwoPhase *tp, hipStream_t stream);                                    // free the temporaries (stream-ordered)
+// The two launches of a two-phase solve around a kernel-argument block `a` with the members {prm.max_iterations, success, iters,
+// append_list, append_count, worklist, count, it0} (ChainKernelArgs / TreeKernelArgs): lockstep() launches the problem's lock-step
+// kernel with `a` -- it appends the problems it leaves unfinished to the list (one atomic per wave, in its epilogue) -- refill(queue)
+// its refill kernel over that list.  The first phase writes every entry of q_out (also those outside the task supports, clipped once
+// a step was taken); the second rewrites the rows a solve moves and the flags of the listed problems only: no pass-through launch,
+// no compaction launch, no memset (the list's length lives in the queue slot, which the refill kernel's last wave zeroes).
 template <class Args, class LockStepFn, class RefillFn>
 hipError_t run_two_phase(const DeviceTables &dt, const BatchIO &io, hipStream_t stream, Args &a, LockStepFn lockstep, RefillFn refill) {
     hipError_t qe = hipSuccess;
     unsigned long long *queue = dt.queues.slot_for(stream, &qe);
     if (!queue) return qe;
     TwoPhase tp;
-    hipError_t e = two_phase_begin(io, stream, &tp);
+    hipError_t e = two_phase_begin(dt, io, stream, queue, &tp);
     if (e == hipSuccess) {
         const int max_it = a.prm.max_iterations;
         a.success = tp.success; a.iters = tp.iters;
         a.prm.max_iterations = two_phase_iterations();
         a.worklist = nullptr; a.count = nullptr; a.it0 = 0;
+        a.append_list = tp.worklist; a.append_count = tp.count;
         lockstep();
         e = hipGetLastError();
-        if (e == hipSuccess) e = two_phase_compact(io, tp, stream);
         if (e == hipSuccess) {
             a.prm.max_iterations = max_it;
+            a.append_list = nullptr; a.append_count = nullptr;
             a.worklist = tp.worklist; a.count = tp.count; a.it0 = two_phase_iterations();
             refill(queue);
             e = hipGetLastError();
