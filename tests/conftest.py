@@ -25,7 +25,8 @@ def pytest_configure(config):
 def native_built():
     """libikgpu.so and the oracle must exist; build them when this checkout has not been built yet."""
     lib = os.path.join(ROOT, "ik_amd", "libikgpu.so")
-    if not os.path.exists(lib):
+    worker = os.path.join(ROOT, "ik_amd", "ikgpu_precompile")   # the run-time compiler's own process (rtc.cpp): without it nothing is compiled at run time
+    if not os.path.exists(lib) or not os.path.exists(worker):
         subprocess.check_call([sys.executable, os.path.join(ROOT, "__graft_entry__.py")])
     import oracle as O
     O.lib()
