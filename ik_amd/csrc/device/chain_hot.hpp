@@ -289,7 +289,7 @@ IKD_FN void hot_dls(const Tab &t, const LoopParams &prm, double (&q)[NJ], const 
         hot_step<NJ, S>(t, prm, col, y, q, NEVERSTOP || active);
         if (!NEVERSTOP && !any_active(active)) break;
     }
-    iters_out = iters;
+    iters_out = (NEVERSTOP || success) ? iters : iterations_taken(any_active, prm.max_iterations);   // (chain_solver.hpp chain_dls)
     success_out = success;
 }
 
@@ -374,7 +374,8 @@ IKD_FN void hot_chain_body(const ChainKernelArgs<NJ> &a, const Tab &t, int64_t g
     const int stamp_pre_ticks = static_cast<int>(r0 - rs);
     const int stamp_true_iters = iters;
 #endif
-    if (!NEVERSTOP && a.append_count) append_unfinished(a.append_list, a.append_count, valid && !success, b);   // (first phase of a two-phase solve)
+    if (!NEVERSTOP && a.append_count)   // (first phase of a two-phase solve)
+        append_unfinished(a.append_list, a.append_count, valid && !success && iters < a.prm.max_iterations, b);
     if (!valid) return;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) a.q_out[at(a.layout, a.B, a.nq, a.qidx[j], b)] = q[j];
@@ -424,7 +425,7 @@ __device__ __forceinline__ void hot_kernel_entry(const ChainKernelArgs<NJ> &a, c
     const int64_t gid = static_cast<int64_t>(blockIdx.x) * 64 + threadIdx.x;   // one wave64 per workgroup
     HotTable tv;
     hot_park_table<NJ, S>(t, tv);
-    hot_chain_body<NJ, S, NEVERSTOP>(a, tv, gid, [](bool act) { return __any(act) != 0; });
+    hot_chain_body<NJ, S, NEVERSTOP>(a, tv, gid, KeepGoing{a.leave_active, a.leave_after, 0});
 }
 
 template <int NJ, class S>

@@ -30,11 +30,14 @@ struct ChainKernelArgs {
     const uint8_t *q_in_chain;    // [nq]
     double *e_out, *J_out, *oMf_out;  // stage kernels
     // second phase of a two-phase stop-rule solve (kernels.hip two_phase_*): the refill kernel walks a LIST of problems -- those the
-    // lock-step first phase left unfinished after it0 iterations -- continuing each from its iterate in q_out.  Null: the whole batch.
+    // lock-step first phase left unfinished -- continuing each from its iterate in q_out at the iteration count the first phase left
+    // in iters[].  Null: the whole batch.
     const int32_t *worklist;
     const unsigned long long *count;   // (device) length of the list
-    int it0;
-    // ... and of its first phase: the lock-step kernel appends the problems it leaves unfinished (append_unfinished below)
+    // ... and of its first phase: a wave of the lock-step kernel LEAVES its loop once no more than `leave_active` of its lanes are still
+    // iterating (and at least `leave_after` iterations are done; KeepGoing below) and appends the problems it leaves unfinished
+    // (append_unfinished below).  leave_active == 0: an ordinary lock-step solve.
+    int leave_active, leave_after;
     int32_t *append_list;
     unsigned long long *append_count;
 };
@@ -93,7 +96,8 @@ IKD_FN void dls_chain_body(const ChainKernelArgs<NJ> &a, const Desc &d, int64_t 
     bool success;
     chain_dls<NJ, KT, SMASK>(d, a.prm, q, oMt, iters, success, any_active);
 
-    if (a.append_count) append_unfinished(a.append_list, a.append_count, valid && !success, b);   // (wave-uniform test)
+    // (wave-uniform test; a problem that ran out of iterations is finished, not open)
+    if (a.append_count) append_unfinished(a.append_list, a.append_count, valid && !success && iters < a.prm.max_iterations, b);
     if (!valid) return;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) a.q_out[at(a.layout, a.B, a.nq, a.qidx[j], b)] = q[j];
@@ -130,22 +134,23 @@ __device__ __forceinline__ void chain_refill_loop(const ChainKernelArgs<NJ> &a, 
     const bool listed = a.worklist != nullptr;
     const int64_t nwork = listed ? static_cast<int64_t>(*a.count) : a.B;
     const double *qsrc = listed ? a.q_out : a.q0;
-    const int it0 = listed ? a.it0 : 0;
     auto problem = [&](int64_t w) { return listed ? static_cast<int64_t>(a.worklist[w]) : w; };
     const int64_t w0 = static_cast<int64_t>(blockIdx.x) * 64 + lane;
     bool have = w0 < nwork;
     double q[NJ], oMt[12];
     int64_t b = 0;
-    int it = it0;
+    int it = 0;
     const int max_it = a.prm.max_iterations;                             // >= 1: the host sends max_iterations == 0 to the lock-step kernel
-    if (nwork > 0) {                                                     // (wave-uniform; an empty list: straight to the slot's bookkeeping)
-        b = problem(have ? w0 : 0);                                      // idle lanes shadow a valid problem
+    // Waves without a share of the first round never touch the queue: they leave at once, and the slot's bookkeeping below counts the
+    // others only.  (An EMPTY list -- every problem stopped in the first phase -- costs the launch and one load per wave: the slot is
+    // still zero.  A thousand arrivals on one address took ~15 us, a quarter of a near-target solve.)
+    const int64_t working = (nwork + 63) / 64 < static_cast<int64_t>(gridDim.x) ? (nwork + 63) / 64 : static_cast<int64_t>(gridDim.x);
+    if (static_cast<int64_t>(blockIdx.x) >= working) return;
+    b = problem(have ? w0 : 0);                                          // idle lanes shadow a valid problem
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) q[j] = qsrc[at(a.layout, a.B, a.nq, a.qidx[j], b)];
-        load_target(a, b, oMt);
-    } else {
-        have = false;
-    }
+    for (int j = 0; j < NJ; ++j) q[j] = qsrc[at(a.layout, a.B, a.nq, a.qidx[j], b)];
+    load_target(a, b, oMt);
+    if (listed) it = a.iters[b];                                         // (the iterations the first phase took over this problem)
     // The wave's own reserve [pool_lo, pool_hi) of unsolved problems (wave-uniform): finished lanes are served from it, and only when
     // it runs dry does the wave pull `chunk` (>= 64) more from the launch's head.  One atomic per finished LANE-GROUP on one address
     // saturated the memory-side atomic unit (measured: ~30-70 M same-address atomics/s device-wide, every refill waiting ~30 us).
@@ -195,14 +200,14 @@ __device__ __forceinline__ void chain_refill_loop(const ChainKernelArgs<NJ> &a, 
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) q[j] = qsrc[at(a.layout, a.B, a.nq, a.qidx[j], b)];
                 load_target(a, b, oMt);
-                it = it0;
+                it = listed ? a.iters[b] : 0;
             }
         }
     }
     // the last wave out resets the slot (every wave's atomics on queue[0] are ordered before its own arrival on queue[1])
     if (lane == 0) {
         __threadfence();
-        if (atomicAdd(queue + 1, 1ull) == static_cast<unsigned long long>(gridDim.x) - 1ull) {
+        if (atomicAdd(queue + 1, 1ull) == static_cast<unsigned long long>(working) - 1ull) {
             queue[0] = 0ull;
             queue[1] = 0ull;
             queue[2] = 0ull;   // (the two-phase worklist's length)

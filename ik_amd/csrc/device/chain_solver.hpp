@@ -233,6 +233,28 @@ IKD_FN bool chain_iteration(const Desc &d, const LoopParams &prm, double (&q)[NJ
     return stop_now;
 }
 
+// The wave-uniform "keep iterating" test of the lock-step loops (chain_dls, hot_dls, tree_dls call it once per iteration): some lane is
+// still active -- and, in the first phase of a two-phase solve, more than `leave_active` lanes are once `leave_after` iterations are
+// done: the stragglers of a wave are cheaper to finish in compacted waves than with three quarters of this one idle.
+struct KeepGoing {
+    int leave_active, leave_after, n;
+    IKD_FN bool operator()(bool act) {
+        ++n;
+#if IKD_ON_DEVICE
+        const int live = static_cast<int>(__popcll(__ballot(act)));
+        return live > (n >= leave_after ? leave_active : 0);
+#else
+        return act;
+#endif
+    }
+};
+// Iterations a lock-step loop has taken when it ends with this lane unfinished: with a plain "any lane active" test the loop only ends
+// early when every lane is done, so an unfinished lane saw all of them; KeepGoing counts its calls (one per iteration).
+template <class F>
+IKD_FN int iterations_taken(const F &, int max_iterations) { return max_iterations; }
+IKD_FN int iterations_taken(const KeepGoing &k, int) { return k.n; }
+
+
 // One full solve. q: in = q0 (chain joints only), out = result. Returns iterations / success.
 // any_active(bool) must return a wave-uniform "some lane still iterating" (identity on the host).
 template <int NJ, int KT, int SMASK = -1, class Desc, class AnyFn>
@@ -253,7 +275,9 @@ IKD_FN void chain_dls(const Desc &d_in, const LoopParams &prm, double (&q)[NJ], 
         active = active && !stop_now;
         if (!any_active(active)) break;
     }
-    iters_out = iters;
+    // (a lane the loop left unfinished reports the iterations it took: max_iterations, or fewer when the wave left early -- the first
+    // phase of a two-phase solve, chain_kernel_body.hpp KeepGoing)
+    iters_out = success ? iters : iterations_taken(any_active, prm.max_iterations);
     success_out = success;
 }
 

@@ -28,11 +28,11 @@ struct TreeKernelArgs {
     const uint8_t *q_in_chain;    // [nq] 1 where the kernel integrates the entry itself
     double *e_out, *J_out, *oMf_out;  // stage kernel
     // second phase of a two-phase stop-rule solve (as ChainKernelArgs): the refill kernel walks the list of problems the lock-step first
-    // phase left unfinished after it0 iterations, continuing each from its iterate in q_out.  Null: the whole batch.
+    // phase left unfinished, continuing each from its iterate in q_out at the count in iters[].  Null: the whole batch.
     const int32_t *worklist;
     const unsigned long long *count;
-    int it0;
-    int32_t *append_list;            // ... and of its first phase (chain_kernel_body.hpp append_unfinished)
+    int leave_active, leave_after;   // ... and of its first phase (chain_kernel_body.hpp KeepGoing, append_unfinished)
+    int32_t *append_list;
     unsigned long long *append_count;
 };
 
@@ -85,7 +85,7 @@ IKD_FN void dls_tree_body(const TreeKernelArgs<NJ, NCH> &a, const Desc &d, int64
         for (int k = 0; k < a.prm.post_n; ++k) a.q_out[at(a.layout, a.B, a.nq, a.prm.post_q[k], b)] = ps.q_lane[k * ps.stride];
     }
 
-    if (a.append_count) append_unfinished(a.append_list, a.append_count, valid && !success, b);   // (wave-uniform test)
+    if (a.append_count) append_unfinished(a.append_list, a.append_count, valid && !success && iters < a.prm.max_iterations, b);   // (wave-uniform test)
     if (!valid) return;
 #pragma unroll
     for (int k = 0; k < 7; ++k)
@@ -122,7 +122,7 @@ struct TreeRefill {
     bool took;    // (set by step) this lane has just taken a new problem: its iteration count restarts
     int64_t nwork;   // work items: the batch's problems, or the entries of a->worklist (`b` is always a PROBLEM index)
     __device__ __forceinline__ int64_t problem(int64_t w) const { return a->worklist ? static_cast<int64_t>(a->worklist[w]) : w; }
-    __device__ __forceinline__ int it0() const { return a->worklist ? a->it0 : 0; }
+    __device__ __forceinline__ int it0() const { return a->worklist ? a->iters[b] : 0; }   // (of the lane's CURRENT problem)
 
     __device__ __forceinline__ void load(int64_t bb, double (&qb)[7], double (&qj0)[NJ], double (&qj1)[NJ]) const {
         const TreeKernelArgs<NJ, NCH> &A = *a;
@@ -200,7 +200,10 @@ __device__ __forceinline__ void dls_tree_refill_body(const TreeKernelArgs<NJ, NC
     const int lane = static_cast<int>(threadIdx.x) & 63;
     const bool fixed_base = spec_is_general(SPEC) ? a.prm.fixed_base != 0 : false;
     const int64_t nwork = a.worklist ? static_cast<int64_t>(*a.count) : a.B;
-    if (nwork > 0) {   // (wave-uniform; an empty worklist: straight to the slot's bookkeeping)
+    // waves without a share of the first round leave at once and are not counted below (chain_kernel_body.hpp chain_refill_loop)
+    const int64_t working = (nwork + 63) / 64 < nwaves ? (nwork + 63) / 64 : nwaves;
+    if (wave >= working) return;
+    {
         TreeRefill<NJ, NCH> rf{&a, queue, chunk & 0xffff, chunk >> 16, fixed_base, 0, nwaves * 64, 0, 0, nwaves * 64 >= nwork, wave * 64 + lane < nwork, false, nwork};
         rf.b = rf.problem(rf.start ? wave * 64 + lane : 0);   // a tail lane of the first round shadows a valid problem
         double qb[7], qj0[NJ], qj1[NJ];
@@ -213,7 +216,7 @@ __device__ __forceinline__ void dls_tree_refill_body(const TreeKernelArgs<NJ, NC
     }
     if (lane == 0) {   // the last wave out resets the slot
         __threadfence();
-        if (atomicAdd(queue + 1, 1ull) == static_cast<unsigned long long>(nwaves) - 1ull) {
+        if (atomicAdd(queue + 1, 1ull) == static_cast<unsigned long long>(working) - 1ull) {
             queue[0] = 0ull;
             queue[1] = 0ull;
             queue[2] = 0ull;   // (the two-phase worklist's length)

@@ -1131,7 +1131,7 @@ IKD_FN void tree_dls(const Desc &d_in, const TreeParams &prm, double (&qb)[7], d
         double unused = 0.0;
         posture_outside_pass(prm, ps, targets, active, unused);
     }
-    iters_out = iters;
+    iters_out = (R::on || kNever || success) ? iters : iterations_taken(any_active, prm.max_iterations);   // (chain_solver.hpp chain_dls)
     success_out = success;
 }
 

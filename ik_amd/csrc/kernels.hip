@@ -52,11 +52,11 @@ __global__ __launch_bounds__(kBlock) void dls_chain_kernel(const ChainKernelArgs
     // The table competes with the polynomial constants for the 100 SGPRs (31 v_readlane + 39 s_mov per iteration of SGPR
     // spill code), which is why the single-wave case gains nothing from the missing LDS waits.
     typedef const IKD_CONST_AS ChainDesc<NJ> ConstDesc;
-    ikdev::dls_chain_body<NJ, KT, SMASK>(a, *(ConstDesc *)a.desc, gid, [](bool act) { return __any(act) != 0; });
+    ikdev::dls_chain_body<NJ, KT, SMASK>(a, *(ConstDesc *)a.desc, gid, ikdev::KeepGoing{a.leave_active, a.leave_after, 0});
 #else
     __shared__ double lds_desc[sizeof(ChainDesc<NJ>) / sizeof(double)];
     const ChainDesc<NJ> &d = stage_desc<NJ>(a.desc, lds_desc);
-    ikdev::dls_chain_body<NJ, KT, SMASK>(a, d, gid, [](bool act) { return __any(act) != 0; });
+    ikdev::dls_chain_body<NJ, KT, SMASK>(a, d, gid, ikdev::KeepGoing{a.leave_active, a.leave_after, 0});
 #endif
 }
 
@@ -169,12 +169,12 @@ hipError_t run_dls(const ProblemHost &ph, const DeviceTables &dt, const BatchIO 
     do {                                                                                                                        \
         const void *rk = reinterpret_cast<const void *>(dls_chain_refill_kernel<NJ, KT, SM>);                                    \
         const int64_t rgrid = refill_grid(rk, io.B);                                                                            \
-        const int mode = stop_rule_mode(prm, io.B, rgrid, stream);                                                              \
+        const int mode = stop_rule_mode(prm, io.B, rgrid, stream, false);                                                             \
         if (mode == kStopRefill) return run_refill<NJ>(ph, dt, io, a, stream, [&](unsigned long long *queue, int32_t *it) {      \
             a.iters = it;                                                                                                       \
             hipLaunchKernelGGL((dls_chain_refill_kernel<NJ, KT, SM>), dim3(static_cast<unsigned>(rgrid)), dim3(kBlock), 0, stream, a, queue, refill_chunk(io.B, rgrid)); \
         });                                                                                                                     \
-        if (mode == kStopTwoPhase) return run_two_phase(dt, io, stream, a, [&] {                                                 \
+        if (mode == kStopTwoPhase) return run_two_phase(dt, io, stream, a, false, [&] {                                               \
             hipLaunchKernelGGL((dls_chain_kernel<NJ, KT, SM>), grid_for(io.B), dim3(kBlock), 0, stream, a);                      \
         }, [&](unsigned long long *queue) {                                                                                     \
             hipLaunchKernelGGL((dls_chain_refill_kernel<NJ, KT, SM>), dim3(static_cast<unsigned>(rgrid)), dim3(kBlock), 0, stream, a, queue, refill_chunk(io.B, rgrid)); \
@@ -260,22 +260,30 @@ bool refill_wanted(const ikgpu_dls_params &prm, int64_t B, int64_t resident_wave
     return B > resident_waves * kBlock;   // otherwise every problem has its own lane from the start: nothing to refill
 }
 
-int two_phase_iterations() {
+int two_phase_iterations(bool tree) {
     if (const char *env = std::getenv("IKGPU_TWO_PHASE_ITERS")) {
         const long v = std::strtol(env, nullptr, 10);
         if (v >= 1 && v <= 64) return static_cast<int>(v);
     }
-    return 4;
+    return tree ? 4 : 8;
 }
 
-int stop_rule_mode(const ikgpu_dls_params &prm, int64_t B, int64_t resident_waves, hipStream_t stream) {
+int two_phase_active(bool tree) {
+    if (const char *env = std::getenv("IKGPU_TWO_PHASE_ACTIVE")) {
+        const long v = std::strtol(env, nullptr, 10);
+        if (v >= 1 && v <= 63) return static_cast<int>(v);
+    }
+    return tree ? 48 : 32;
+}
+
+int stop_rule_mode(const ikgpu_dls_params &prm, int64_t B, int64_t resident_waves, hipStream_t stream, bool tree) {
     if (!(prm.stop_sq_tol >= 0.0) || prm.max_iterations < 1) return kStopLockStep;
     const char *env = std::getenv("IKGPU_REFILL");
     if (env && env[0] == '0') return kStopLockStep;
     if (env && env[0] == '1') return kStopRefill;
     const bool forced = env && env[0] == '2';
     if (!forced && B <= resident_waves * kBlock) return kStopLockStep;
-    if (prm.max_iterations <= two_phase_iterations()) return forced ? kStopLockStep : kStopRefill;
+    if (prm.max_iterations <= two_phase_iterations(tree)) return forced ? kStopLockStep : kStopRefill;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (stream && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap == hipStreamCaptureStatusActive) return kStopRefill;
     return kStopTwoPhase;
@@ -486,7 +494,7 @@ __global__ __launch_bounds__(kTreeBlock) void dls_tree_kernel(const TreeKernelAr
     // A/B: posture build 0.652 -> 0.663 ms, pik 0.576 -> 0.591, pinned foot 0.707 -> 0.714; posture + pinned foot 1.17 -> 0.87-0.94)
     constexpr bool kRows = SPEC >= 0 && ((NCH > 1 && (SPEC & ikdev::kSpecPostCons) == ikdev::kSpecPostCons) ||
                                          (ikdev::spec_is_general(SPEC) && (SPEC & (1 << ikdev::kSpecGen)) == 0));
-    ikdev::dls_tree_body<NJ, NCH, SPEC>(a, d, gid, park, [](bool act) { return __any(act) != 0; }, post_lane, post_stride,
+    ikdev::dls_tree_body<NJ, NCH, SPEC>(a, d, gid, park, ikdev::KeepGoing{a.leave_active, a.leave_after, 0}, post_lane, post_stride,
                                         kRows ? static_cast<int64_t>(blockIdx.x) * kTreeBlock : int64_t{-1});
 }
 
@@ -608,7 +616,7 @@ hipError_t run_dls_tree(const ProblemHost &ph, const DeviceTables &dt, const Bat
         const int build = hot ? kTreeBuildHot : mask_only ? kTreeBuildMask : fold ? kTreeBuildFold : kTreeBuildGeneral;
         if (launch_tree_refill<NJ, NCH>(ph, dt, io, prm, stream, a, build, &re, nullptr)) {
             if (re != hipErrorNotReady) return re;
-            return run_two_phase(dt, io, stream, a, launch_lockstep, [&](unsigned long long *queue) {
+            return run_two_phase(dt, io, stream, a, true, launch_lockstep, [&](unsigned long long *queue) {
                 hipError_t pe = hipSuccess;
                 (void)launch_tree_refill<NJ, NCH>(ph, dt, io, prm, stream, a, build, &pe, queue);
             });

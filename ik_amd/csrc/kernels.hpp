@@ -89,16 +89,25 @@ bool refill_wanted(const ikgpu_dls_params &prm, int64_t B, int64_t resident_wave
 // How a stop-rule solve of B problems runs (chain and tree kernels).  The kernel cannot know the targets' distribution in advance:
 // with targets near the start every lane stops within 2-3 iterations and lock-step is 1.5-2x faster than persistent refill waves
 // (whose loads are exposed); with far targets a few per cent of the problems run to max_iterations and lock-step is 2-4x slower.
-// TWO PHASES get both: (1) the lock-step kernel for the first K iterations over the whole batch, (2) a compaction of the problems
-// still unfinished into a worklist (device side, no host synchronisation), (3) the refill kernel over the worklist, continuing each
-// problem from its iterate in q_out at iteration K.  Results are the lock-step kernel's bits (a problem's state is its q).
+// TWO PHASES get both: (1) the lock-step kernel over the whole batch, each WAVE leaving its loop once no more than a quarter of its
+// lanes are still iterating (and at least K iterations are done) and appending the problems it leaves open to a worklist (one atomic per
+// wave, no host synchronisation); (2) the refill kernel over the worklist, continuing each problem from its iterate in q_out at the
+// iteration count the first phase left in iters[].  The switch point follows the batch: near targets never reach it (the list stays
+// empty, the second launch finds nothing to do), far targets reach it when the bulk has converged and the stragglers fit the
+// resident lanes.  Results are the lock-step kernel's bits (a problem's state is its q).
 //   kStopLockStep: B fits the resident lanes, max_iterations < 1, never-stop visitor, or IKGPU_REFILL=0
 //   kStopRefill:   IKGPU_REFILL=1, or (B large and) max_iterations <= K, or the stream is being captured (the worklist is a
 //                  stream-ordered allocation)
 //   kStopTwoPhase: B larger than the resident lanes (default), or IKGPU_REFILL=2
 enum { kStopLockStep = 0, kStopRefill = 1, kStopTwoPhase = 2 };
-int stop_rule_mode(const ikgpu_dls_params &prm, int64_t B, int64_t resident_waves, hipStream_t stream);
-int two_phase_iterations();   // K (IKGPU_TWO_PHASE_ITERS overrides; default 4)
+int stop_rule_mode(const ikgpu_dls_params &prm, int64_t B, int64_t resident_waves, hipStream_t stream, bool tree);
+// K: iterations before a wave of the first phase may leave (IKGPU_TWO_PHASE_ITERS overrides), and N: it does so with this many lanes or
+// fewer still iterating (IKGPU_TWO_PHASE_ACTIVE, 1..63).  Defaults by kernel family, from tools/two_phase_probe.py on both target
+// distributions at 262144 and 2^20 problems (profiles/r04_two_phase_probe_*.txt): the chain kernels K = 8, N = 32 (by then a tenth of a
+// uniform batch is open and the list fits the resident lanes twice over; leaving earlier doubles the second phase), the tree kernels
+// K = 4, N = 48 (their first phase runs one wave per SIMD in many rounds: an idle lane there is a lane lost, so they hand over early).
+int two_phase_iterations(bool tree);
+int two_phase_active(bool tree);
 struct TwoPhase {
     int32_t *worklist = nullptr;            // [B] (QueuePool::worklist_for)
     unsigned long long *count = nullptr;    // word 2 of the launch's queue slot: zero before the solve, zeroed again by the refill kernel's last wave
@@ -109,30 +118,29 @@ struct TwoPhase {
 hipError_t two_phase_begin(const DeviceTables &dt, const BatchIO &io, hipStream_t stream, unsigned long long *queue, TwoPhase *tp);
 hipError_t two_phase_end(TwoPhase *tp, hipStream_t stream);                                    // free the temporaries (stream-ordered)
 // The two launches of a two-phase solve around a kernel-argument block `a` with the members {prm.max_iterations, success, iters,
-// append_list, append_count, worklist, count, it0} (ChainKernelArgs / TreeKernelArgs): lockstep() launches the problem's lock-step
+// append_list, append_count, worklist, count, leave_active, leave_after} (ChainKernelArgs / TreeKernelArgs): lockstep() launches the problem's lock-step
 // kernel with `a` -- it appends the problems it leaves unfinished to the list (one atomic per wave, in its epilogue) -- refill(queue)
 // its refill kernel over that list.  The first phase writes every entry of q_out (also those outside the task supports, clipped once
 // a step was taken); the second rewrites the rows a solve moves and the flags of the listed problems only: no pass-through launch,
 // no compaction launch, no memset (the list's length lives in the queue slot, which the refill kernel's last wave zeroes).
 template <class Args, class LockStepFn, class RefillFn>
-hipError_t run_two_phase(const DeviceTables &dt, const BatchIO &io, hipStream_t stream, Args &a, LockStepFn lockstep, RefillFn refill) {
+hipError_t run_two_phase(const DeviceTables &dt, const BatchIO &io, hipStream_t stream, Args &a, bool tree, LockStepFn lockstep, RefillFn refill) {
     hipError_t qe = hipSuccess;
     unsigned long long *queue = dt.queues.slot_for(stream, &qe);
     if (!queue) return qe;
     TwoPhase tp;
     hipError_t e = two_phase_begin(dt, io, stream, queue, &tp);
     if (e == hipSuccess) {
-        const int max_it = a.prm.max_iterations;
         a.success = tp.success; a.iters = tp.iters;
-        a.prm.max_iterations = two_phase_iterations();
-        a.worklist = nullptr; a.count = nullptr; a.it0 = 0;
+        a.worklist = nullptr; a.count = nullptr;
+        a.leave_active = two_phase_active(tree); a.leave_after = two_phase_iterations(tree);
         a.append_list = tp.worklist; a.append_count = tp.count;
         lockstep();
         e = hipGetLastError();
         if (e == hipSuccess) {
-            a.prm.max_iterations = max_it;
+            a.leave_active = 0; a.leave_after = 0;
             a.append_list = nullptr; a.append_count = nullptr;
-            a.worklist = tp.worklist; a.count = tp.count; a.it0 = two_phase_iterations();
+            a.worklist = tp.worklist; a.count = tp.count;
             refill(queue);
             e = hipGetLastError();
         }

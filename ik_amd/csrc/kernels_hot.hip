@@ -122,11 +122,11 @@ hipError_t launch_dls_chain_hot(const ProblemHost &ph, const DeviceTables &dt, c
         else {                                                                                                           \
             const void *rk = reinterpret_cast<const void *>(dls_chain_hot_refill_kernel<N, K0, K1, K2>);                   \
             const int64_t rgrid = refill_grid(rk, io.B);                                                                 \
-            const int mode = stop_rule_mode(prm, io.B, rgrid, stream);                                                   \
+            const int mode = stop_rule_mode(prm, io.B, rgrid, stream, false);                                                  \
             if (mode == kStopRefill) return hot_refill_launch<N>(ph, dt, io, a, stream, [&](unsigned long long *queue) {  \
                 hipLaunchKernelGGL((dls_chain_hot_refill_kernel<N, K0, K1, K2>), dim3(static_cast<unsigned>(rgrid)), dim3(kBlock), 0, stream, a, t, queue, refill_chunk(io.B, rgrid)); \
             });                                                                                                          \
-            if (mode == kStopTwoPhase) return run_two_phase(dt, io, stream, a, [&] {                                      \
+            if (mode == kStopTwoPhase) return run_two_phase(dt, io, stream, a, false, [&] {                                    \
                 hipLaunchKernelGGL((dls_chain_hot_kernel<N, K0, K1, K2, false>), grid, dim3(kBlock), 0, stream, a, t);    \
             }, [&](unsigned long long *queue) {                                                                          \
                 hipLaunchKernelGGL((dls_chain_hot_refill_kernel<N, K0, K1, K2>), dim3(static_cast<unsigned>(rgrid)), dim3(kBlock), 0, stream, a, t, queue, refill_chunk(io.B, rgrid)); \

@@ -109,7 +109,7 @@ bool launch_tree_refill(const ProblemHost &ph, const DeviceTables &dt, const Bat
             *err = launch(phase2_queue);
             return true;
         }
-        const int mode = stop_rule_mode(prm, io.B, waves, stream);
+        const int mode = stop_rule_mode(prm, io.B, waves, stream, true);
         if (mode == kStopLockStep) return false;
         if (mode == kStopTwoPhase) { *err = hipErrorNotReady; return true; }   // (the caller runs the phases: it owns the lock-step launch)
         hipError_t e = hipSuccess;

@@ -530,11 +530,11 @@ hipError_t launch_shape(const ProblemHost &ph, const DeviceTables &dt, const Bat
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
     }
     const int64_t resident = refill_resident(static_cast<int64_t>(m.refill_waves_per_cu) * cus, io.B);
-    const int mode = stop_rule_mode(prm, io.B, resident, stream);
+    const int mode = stop_rule_mode(prm, io.B, resident, stream, false);
     if (mode == kStopLockStep) return launch(m.stop, waves, two);
     if (mode == kStopTwoPhase) {
         hipError_t le = hipSuccess;
-        const hipError_t te = run_two_phase(dt, io, stream, a, [&] { le = launch(m.stop, waves, two); },
+        const hipError_t te = run_two_phase(dt, io, stream, a, false, [&] { le = launch(m.stop, waves, two); },
                                             [&](unsigned long long *queue) {
                                                 args.queue = queue;
                                                 args.chunk = refill_chunk(io.B, resident);

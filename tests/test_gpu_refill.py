@@ -105,9 +105,15 @@ def test_refill_forced_at_small_and_ragged_batches(torch_cuda, B, layout):
     for max_it in (1, 2, 5, 100):
         a = _solve(ik_amd, problem, data, Q0, T, "0", max_it=max_it, layout=layout)
         b = _solve(ik_amd, problem, data, Q0, T, "1", max_it=max_it, layout=layout)
-        c = _solve(ik_amd, problem, data, Q0, T, "2", max_it=max_it, layout=layout)    # two phases: lock-step for 4 iterations, refill on the rest
+        c = _solve(ik_amd, problem, data, Q0, T, "2", max_it=max_it, layout=layout)    # two phases: lock-step until a wave's stragglers are few, refill on those
         for x, y, z in zip(a, b, c):
             assert np.array_equal(x, y) and np.array_equal(x, z), (B, layout, max_it)
+        if max_it == 100:   # the switch point moves the work between the phases, never the bits: hand over at once / early / late
+            for after, active in (("1", "63"), ("2", "48"), ("16", "1")):
+                with env(IKGPU_TWO_PHASE_ITERS=after, IKGPU_TWO_PHASE_ACTIVE=active):
+                    d = _solve(ik_amd, problem, data, Q0, T, "2", max_it=max_it, layout=layout)
+                for x, y in zip(a, d):
+                    assert np.array_equal(x, y), (B, layout, after, active)
 
 
 def test_refill_against_the_oracle_and_iteration_zero_stops(torch_cuda):

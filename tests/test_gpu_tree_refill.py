@@ -143,6 +143,12 @@ def test_tree_refill_forced_at_small_and_ragged_batches(torch_cuda, case, layout
             for x, y, z in zip(a, b, c):
                 assert np.array_equal(x, y) and np.array_equal(x, z), (case, B, layout, max_it)
             assert (a[2] <= max_it).all() and (a[2][a[1] == 0] == max_it).all()
+            if max_it == 100 and B in (65, 65536 + 67):   # the switch point moves the work between the phases, never the bits
+                for after, active in (("1", "63"), ("16", "1")):
+                    with env(IKGPU_TWO_PHASE_ITERS=after, IKGPU_TWO_PHASE_ACTIVE=active):
+                        d = _solve(ik_amd, problem, data, q, t, "2", damping, step, max_it=max_it, layout=layout)
+                    for x, y in zip(a, d):
+                        assert np.array_equal(x, y), (case, B, layout, after, active)
 
 
 @pytest.mark.parametrize("case", ["full_body", "demo_task_set"])

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Where a two-phase stop-rule solve (kernels.hpp run_two_phase) spends its time: the default policy on the Cassie leg by K (lock-step
-iterations before the compaction) and by resident waves of the second phase, next to the two fixed modes.
-    python tools/two_phase_probe.py            the table
+"""The two-phase stop-rule solve (kernels.hpp run_two_phase) by its two switch parameters -- K (iterations before a wave of the first
+phase may leave) and N (it leaves with <= N lanes still iterating) -- next to the two fixed modes, on the Cassie leg or ("tree") the
+full body; every result compared bit for bit with the lock-step kernel's.
+    python tools/two_phase_probe.py [tree]     the table
     rocprofv3 --kernel-trace --stats -d DIR -- python3 tools/two_phase_probe.py trace [uniform|near] [B]
                                                20 default-policy solves only: the per-kernel durations of the two launches"""
 import os
@@ -15,17 +16,29 @@ sys.path.insert(0, ROOT)
 import ik_amd  # noqa: E402
 from ik_amd import workload  # noqa: E402
 
-model = ik_amd.Model.from_urdf_file(os.path.join(workload.MODELS_DIR, "cassie_fixed.kin.urdf"))
-problem = ik_amd.InverseKinematicsProblem(model)
-problem.add_frame_task("t", ik_amd.FrameTask.create(model, "LeftFootFront", ik_amd.KinematicType.Full))
+TREE = "tree" in sys.argv[1:]
+if TREE:
+    sys.argv.remove("tree")
+    model = ik_amd.Model.from_urdf_file(os.path.join(workload.MODELS_DIR, "cassie.kin.urdf"), free_flyer=True)
+    problem = ik_amd.InverseKinematicsProblem(model)
+    for i, f in enumerate(["LeftFootFront", "RightFootFront", "pelvis"]):
+        problem.add_frame_task("t%d" % i, ik_amd.FrameTask.create(model, f, ik_amd.KinematicType.Full))
+else:
+    model = ik_amd.Model.from_urdf_file(os.path.join(workload.MODELS_DIR, "cassie_fixed.kin.urdf"))
+    problem = ik_amd.InverseKinematicsProblem(model)
+    problem.add_frame_task("t", ik_amd.FrameTask.create(model, "LeftFootFront", ik_amd.KinematicType.Full))
 nominal = workload.cassie_nominal(model.names)
 data = ik_amd.dls_data(problem, device=0)
+print("==", data.kernel)
 vis = ik_amd.inverse_kinematics_visitor()
 prm = ik_amd.dls_parameters(max_iterations=100)
 
 
 def inputs(mode, B):
-    q0, qs = workload.chain_workload(model.lowerPositionLimit, model.upperPositionLimit, nominal, np.arange(B), 0, mode)
+    if TREE:
+        q0, qs = workload.freeflyer_workload(model.lowerPositionLimit, model.upperPositionLimit, nominal, np.arange(B), seed=0, mode=mode)
+    else:
+        q0, qs = workload.chain_workload(model.lowerPositionLimit, model.upperPositionLimit, nominal, np.arange(B), 0, mode)
     Q0 = torch.from_numpy(np.ascontiguousarray(q0.T)).cuda()
     T = ik_amd.task_frames_fk_batch(problem, torch.from_numpy(np.ascontiguousarray(qs.T)).cuda(), data)
     return Q0, T
@@ -71,13 +84,30 @@ for mode in ("uniform", "near"):
             ms, out = with_env({"IKGPU_REFILL": "1", "IKGPU_REFILL_WAVES_PER_CU": wpc}, lambda: timed(Q0, T))
             row += " | refill %sw %.3f" % (wpc, ms)
         print(row)
-        for K in ("1", "2", "4", "8", "16"):
-            row = "          two-phase K=%-2s" % K
-            for wpc in (None, "2", "4", "8"):
-                env = {"IKGPU_TWO_PHASE_ITERS": K, "IKGPU_REFILL": "2"}
-                if wpc:
-                    env["IKGPU_REFILL_WAVES_PER_CU"] = wpc
+        # what the switch does to THIS batch, from the lock-step kernel's own iteration counts: a lane is active in iteration n
+        # (1-based) while n <= iters + 1 (its visitor fires in iteration iters + 1) or, unconverged, n <= max_iterations
+        ok, its = out0[1].cpu().numpy().astype(bool), out0[2].cpu().numpy().astype(np.int64)
+        last = np.where(ok, its + 1, prm.max_iterations).reshape(-1, 64)
+        for K, N in ((4, 16), (8, 16), (8, 32), (4, 48)):
+            n = np.arange(1, prm.max_iterations + 1)[None, :, None]
+            live = (last[:, None, :] > n).sum(axis=2)                     # lanes still iterating after n iterations, per wave
+            leave = np.argmax((live <= N) & (n[:, :, 0] >= K), axis=1) + 1   # (the loop also ends at max_iterations: live == 0 there)
+            listed = int(sum(int((last[w] > leave[w]).sum()) for w in range(last.shape[0]) if leave[w] < prm.max_iterations))
+            print("          K=%d N=%d: waves leave after %d..%d iterations (mean %.1f), %d problems listed (%.1f %%), %d of them unconverged"
+                  % (K, N, leave.min(), leave.max(), leave.mean(), listed, 100.0 * listed / B, int((~ok).sum())))
+        for K in ("2", "4", "8"):
+            row = "          two-phase, leave after K=%-2s with <= N active:" % K
+            for act in ("8", "16", "32", "48"):
+                env = {"IKGPU_TWO_PHASE_ITERS": K, "IKGPU_TWO_PHASE_ACTIVE": act, "IKGPU_REFILL": "2"}
                 ms, out = with_env(env, lambda: timed(Q0, T))
                 same = all(torch.equal(x, y) for x, y in zip(out0, out))
-                row += " | %s %.3f%s" % ("policy" if wpc is None else wpc + "w", ms, "" if same else " DIFFERENT")
+                row += " | N=%s %.3f%s" % (act, ms, "" if same else " DIFFERENT")
             print(row)
+        for K, N in (("4", "16"), ("8", "16")):
+            row = "          K=%s N=%s by resident waves per CU of the second phase:" % (K, N)
+            for wpc in ("1", "2", "3", "4", "6"):
+                env = {"IKGPU_TWO_PHASE_ITERS": K, "IKGPU_TWO_PHASE_ACTIVE": N, "IKGPU_REFILL": "2", "IKGPU_REFILL_WAVES_PER_CU": wpc}
+                row += " | %sw %.3f" % (wpc, with_env(env, lambda: timed(Q0, T))[0])
+            print(row)
+        ms, out = timed(Q0, T)
+        print("          default policy %.3f%s" % (ms, "" if all(torch.equal(x, y) for x, y in zip(out0, out)) else " DIFFERENT"))
