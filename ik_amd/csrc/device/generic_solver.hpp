@@ -584,6 +584,7 @@ IKD_FN void generic_dls(const TB &T, const LoopParams &prm, const WS &ws, const 
     LaneRows targets = targets_in;                 // (refill: re-pointed when the lane takes its next problem)
     int iters = prm.max_iterations;
     int lit = 0;                                   // (refill) this lane's own iteration count
+    if constexpr (R::on) lit = refill.it0();       // (second phase of a two-phase solve: the iterations the first phase took)
     const int M = T.M, nv = T.nv;
     for (int it = 0; R::on || it < prm.max_iterations; ++it) {
         const double e0sq = generic_evaluate(T, ws, targets);
@@ -757,13 +758,13 @@ IKD_FN void generic_dls(const TB &T, const LoopParams &prm, const WS &ws, const 
             active = had && !done;   // (a lane that ran out of iterations is as finished as one whose visitor fired)
             refill.took = false;
             const bool any_left = refill.step(T, done, stop_now, stop_now ? lit - 1 : prm.max_iterations, ws, targets, active);
-            if (refill.took) { lit = 0; success = false; }
+            if (refill.took) { lit = refill.it0(); success = false; }
             if (!any_left) break;
         } else {
             if (!any_active(active)) break;
         }
     }
-    iters_out = iters;
+    iters_out = (R::on || success) ? iters : iterations_taken(any_active, prm.max_iterations);   // (chain_solver.hpp chain_dls)
     success_out = success;
 }
 
@@ -786,6 +787,12 @@ struct GenericKernelArgs {
     double *ws;          // [ws_words][ws_stride]
     int64_t ws_stride;   // >= B
     double *e_out, *J_out, *oMf_out;  // stage kernel
+    // the two-phase stop-rule solve of the static lane programs (as ChainKernelArgs: chain_kernel_body.hpp; rtc.cpp rtc_launch_generic_static)
+    const int32_t *worklist;
+    const unsigned long long *count;
+    int leave_active, leave_after;
+    int32_t *append_list;
+    unsigned long long *append_count;
 };
 
 // ws: the lane's workspace column -- of the HBM workspace (dls_generic_body below) or of the workgroup's LDS (the on-chip form,
@@ -805,6 +812,7 @@ IKD_FN void dls_generic_body_ws(const GenericKernelArgs &a, const TB &T, int64_t
     int iters;
     bool success;
     generic_dls(T, a.prm, ws, tl, iters, success, any_active);
+    if (a.append_count) append_unfinished(a.append_list, a.append_count, valid && !success && iters < a.prm.max_iterations, b);   // (wave-uniform test)
     if (!valid) return;
     IKD_UNROLL
     for (int i = 0; i < T.nq; ++i) a.q_out[at(a.layout, a.B, T.nq, i, b)] = ws[T.off_q + i];
@@ -826,6 +834,9 @@ struct GenericRefill {
     bool exhausted;
     bool start;
     bool took;          // (set by step) this lane has just taken a new problem
+    int64_t nwork;      // work items: the batch's problems, or the entries of a->worklist (`b` is always a PROBLEM index)
+    __device__ __forceinline__ int64_t problem(int64_t w) const { return a->worklist ? static_cast<int64_t>(a->worklist[w]) : w; }
+    __device__ __forceinline__ int it0() const { return a->worklist ? a->iters[b] : 0; }   // (of the lane's CURRENT problem)
 
     template <class TB>
     __device__ __forceinline__ LaneRows target_rows(const TB &T, int64_t bb) const {
@@ -857,8 +868,8 @@ struct GenericRefill {
                 if (lane == 0) v = atomicAdd(queue, static_cast<unsigned long long>(chunk));
                 const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v)), hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
                 const int64_t nlo = first_round + static_cast<int64_t>((static_cast<unsigned long long>(hi) << 32) | lo);
-                const int64_t nhi = nlo + chunk < A.B ? nlo + chunk : A.B;
-                exhausted = nlo + chunk >= A.B;
+                const int64_t nhi = nlo + chunk < nwork ? nlo + chunk : nwork;
+                exhausted = nlo + chunk >= nwork;
                 if (rank >= avail) { nb = nlo + (rank - avail); got = nb < nhi; }
                 pool_lo = nlo + (need - avail);
                 pool_hi = nhi > pool_lo ? nhi : pool_lo;
@@ -868,9 +879,10 @@ struct GenericRefill {
             if (!active && got) {
                 active = true;
                 took = true;
-                b = nb;
+                b = problem(nb);
+                const double *src = A.worklist ? A.q_out : A.q0;   // (second phase: the first phase's iterate)
                 IKD_UNROLL
-                for (int i = 0; i < T.nq; ++i) ws[T.off_q + i] = A.q0[at(A.layout, A.B, T.nq, i, b)];
+                for (int i = 0; i < T.nq; ++i) ws[T.off_q + i] = src[at(A.layout, A.B, T.nq, i, b)];
                 tl = target_rows(T, b);
             }
         }
@@ -882,18 +894,24 @@ template <class TB, class WS>
 __device__ __forceinline__ void dls_generic_refill_body(const GenericKernelArgs &a, const TB &T, int64_t wave, int64_t nwaves, const WS &ws,
                                                         unsigned long long *queue, int chunk) {
     const int lane = static_cast<int>(threadIdx.x) & 63;
-    GenericRefill rf{&a, queue, chunk & 0xffff, chunk >> 16, wave * 64 + lane, nwaves * 64, 0, 0, nwaves * 64 >= a.B, wave * 64 + lane < a.B, false};
-    const int64_t bs = rf.start ? rf.b : a.B - 1;
+    const int64_t nwork = a.worklist ? static_cast<int64_t>(*a.count) : a.B;
+    // waves without a share of the first round leave at once and are not counted below (chain_kernel_body.hpp chain_refill_loop)
+    const int64_t working = (nwork + 63) / 64 < nwaves ? (nwork + 63) / 64 : nwaves;
+    if (wave >= working) return;
+    GenericRefill rf{&a, queue, chunk & 0xffff, chunk >> 16, 0, nwaves * 64, 0, 0, nwaves * 64 >= nwork, wave * 64 + lane < nwork, false, nwork};
+    rf.b = rf.problem(rf.start ? wave * 64 + lane : 0);   // a tail lane of the first round shadows a valid problem
+    const double *src = a.worklist ? a.q_out : a.q0;
     IKD_UNROLL
-    for (int i = 0; i < T.nq; ++i) ws[T.off_q + i] = a.q0[at(a.layout, a.B, T.nq, i, bs)];
+    for (int i = 0; i < T.nq; ++i) ws[T.off_q + i] = src[at(a.layout, a.B, T.nq, i, rf.b)];
     int iters;
     bool success;
-    generic_dls(T, a.prm, ws, rf.target_rows(T, bs), iters, success, [](bool act) { return __any(act) != 0; }, rf);
+    generic_dls(T, a.prm, ws, rf.target_rows(T, rf.b), iters, success, [](bool act) { return __any(act) != 0; }, rf);
     if (lane == 0) {   // the last wave out resets the queue slot for the stream's next launch (kernels.hpp QueuePool)
         __threadfence();
-        if (atomicAdd(queue + 1, 1ull) == static_cast<unsigned long long>(nwaves) - 1ull) {
+        if (atomicAdd(queue + 1, 1ull) == static_cast<unsigned long long>(working) - 1ull) {
             queue[0] = 0ull;
             queue[1] = 0ull;
+            queue[2] = 0ull;   // (the two-phase worklist's length)
             __threadfence();
         }
     }

@@ -174,7 +174,7 @@ hipError_t run_dls(const ProblemHost &ph, const DeviceTables &dt, const BatchIO 
             a.iters = it;                                                                                                       \
             hipLaunchKernelGGL((dls_chain_refill_kernel<NJ, KT, SM>), dim3(static_cast<unsigned>(rgrid)), dim3(kBlock), 0, stream, a, queue, refill_chunk(io.B, rgrid)); \
         });                                                                                                                     \
-        if (mode == kStopTwoPhase) return run_two_phase(dt, io, stream, a, false, [&] {                                               \
+        if (mode == kStopTwoPhase) return run_two_phase(dt.queues, io, stream, a, false, [&] {                                               \
             hipLaunchKernelGGL((dls_chain_kernel<NJ, KT, SM>), grid_for(io.B), dim3(kBlock), 0, stream, a);                      \
         }, [&](unsigned long long *queue) {                                                                                     \
             hipLaunchKernelGGL((dls_chain_refill_kernel<NJ, KT, SM>), dim3(static_cast<unsigned>(rgrid)), dim3(kBlock), 0, stream, a, queue, refill_chunk(io.B, rgrid)); \
@@ -256,7 +256,7 @@ bool refill_wanted(const ikgpu_dls_params &prm, int64_t B, int64_t resident_wave
     if (!(prm.stop_sq_tol >= 0.0) || prm.max_iterations < 1) return false;   // the never-stop visitor: every lane takes the same number of steps
     const char *env = std::getenv("IKGPU_REFILL");
     if (env && env[0] == '0') return false;
-    if (env && env[0] == '1') return true;
+    if (env && (env[0] == '1' || env[0] == '2')) return true;
     return B > resident_waves * kBlock;   // otherwise every problem has its own lane from the start: nothing to refill
 }
 
@@ -289,10 +289,10 @@ int stop_rule_mode(const ikgpu_dls_params &prm, int64_t B, int64_t resident_wave
     return kStopTwoPhase;
 }
 
-hipError_t two_phase_begin(const DeviceTables &dt, const BatchIO &io, hipStream_t stream, unsigned long long *queue, TwoPhase *tp) {
+hipError_t two_phase_begin(QueuePool &queues, const BatchIO &io, hipStream_t stream, unsigned long long *queue, TwoPhase *tp) {
     if (io.B > 0x7fffffff) return hipErrorInvalidValue;   // (the worklist holds 32-bit problem indices)
     hipError_t e = hipSuccess;
-    tp->worklist = dt.queues.worklist_for(stream, static_cast<size_t>(io.B), &e);
+    tp->worklist = queues.worklist_for(stream, static_cast<size_t>(io.B), &e);
     if (!tp->worklist) return e;
     tp->count = queue + 2;
     tp->success = io.success;
@@ -616,7 +616,7 @@ hipError_t run_dls_tree(const ProblemHost &ph, const DeviceTables &dt, const Bat
         const int build = hot ? kTreeBuildHot : mask_only ? kTreeBuildMask : fold ? kTreeBuildFold : kTreeBuildGeneral;
         if (launch_tree_refill<NJ, NCH>(ph, dt, io, prm, stream, a, build, &re, nullptr)) {
             if (re != hipErrorNotReady) return re;
-            return run_two_phase(dt, io, stream, a, true, launch_lockstep, [&](unsigned long long *queue) {
+            return run_two_phase(dt.queues, io, stream, a, true, launch_lockstep, [&](unsigned long long *queue) {
                 hipError_t pe = hipSuccess;
                 (void)launch_tree_refill<NJ, NCH>(ph, dt, io, prm, stream, a, build, &pe, queue);
             });

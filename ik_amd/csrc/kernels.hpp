@@ -105,7 +105,8 @@ int stop_rule_mode(const ikgpu_dls_params &prm, int64_t B, int64_t resident_wave
 // fewer still iterating (IKGPU_TWO_PHASE_ACTIVE, 1..63).  Defaults by kernel family, from tools/two_phase_probe.py on both target
 // distributions at 262144 and 2^20 problems (profiles/r04_two_phase_probe_*.txt): the chain kernels K = 8, N = 32 (by then a tenth of a
 // uniform batch is open and the list fits the resident lanes twice over; leaving earlier doubles the second phase), the tree kernels
-// K = 4, N = 48 (their first phase runs one wave per SIMD in many rounds: an idle lane there is a lane lost, so they hand over early).
+// K = 4, N = 48 (their first phase runs one wave per SIMD in many rounds: an idle lane there is a lane lost, so they hand over early);
+// the static lane programs take the tree kernels' (profiles/r04_refill_timing_static.txt).
 int two_phase_iterations(bool tree);
 int two_phase_active(bool tree);
 struct TwoPhase {
@@ -115,7 +116,7 @@ struct TwoPhase {
     int32_t *iters = nullptr;
     void *tmp[2] = {nullptr, nullptr};
 };
-hipError_t two_phase_begin(const DeviceTables &dt, const BatchIO &io, hipStream_t stream, unsigned long long *queue, TwoPhase *tp);
+hipError_t two_phase_begin(QueuePool &queues, const BatchIO &io, hipStream_t stream, unsigned long long *queue, TwoPhase *tp);
 hipError_t two_phase_end(TwoPhase *tp, hipStream_t stream);                                    // free the temporaries (stream-ordered)
 // The two launches of a two-phase solve around a kernel-argument block `a` with the members {prm.max_iterations, success, iters,
 // append_list, append_count, worklist, count, leave_active, leave_after} (ChainKernelArgs / TreeKernelArgs): lockstep() launches the problem's lock-step
@@ -124,12 +125,12 @@ hipError_t two_phase_end(TwoPhase *tp, hipStream_t stream);                     
 // a step was taken); the second rewrites the rows a solve moves and the flags of the listed problems only: no pass-through launch,
 // no compaction launch, no memset (the list's length lives in the queue slot, which the refill kernel's last wave zeroes).
 template <class Args, class LockStepFn, class RefillFn>
-hipError_t run_two_phase(const DeviceTables &dt, const BatchIO &io, hipStream_t stream, Args &a, bool tree, LockStepFn lockstep, RefillFn refill) {
+hipError_t run_two_phase(QueuePool &queues, const BatchIO &io, hipStream_t stream, Args &a, bool tree, LockStepFn lockstep, RefillFn refill) {
     hipError_t qe = hipSuccess;
-    unsigned long long *queue = dt.queues.slot_for(stream, &qe);
+    unsigned long long *queue = queues.slot_for(stream, &qe);
     if (!queue) return qe;
     TwoPhase tp;
-    hipError_t e = two_phase_begin(dt, io, stream, queue, &tp);
+    hipError_t e = two_phase_begin(queues, io, stream, queue, &tp);
     if (e == hipSuccess) {
         a.success = tp.success; a.iters = tp.iters;
         a.worklist = nullptr; a.count = nullptr;

@@ -126,7 +126,7 @@ hipError_t launch_dls_chain_hot(const ProblemHost &ph, const DeviceTables &dt, c
             if (mode == kStopRefill) return hot_refill_launch<N>(ph, dt, io, a, stream, [&](unsigned long long *queue) {  \
                 hipLaunchKernelGGL((dls_chain_hot_refill_kernel<N, K0, K1, K2>), dim3(static_cast<unsigned>(rgrid)), dim3(kBlock), 0, stream, a, t, queue, refill_chunk(io.B, rgrid)); \
             });                                                                                                          \
-            if (mode == kStopTwoPhase) return run_two_phase(dt, io, stream, a, false, [&] {                                    \
+            if (mode == kStopTwoPhase) return run_two_phase(dt.queues, io, stream, a, false, [&] {                                    \
                 hipLaunchKernelGGL((dls_chain_hot_kernel<N, K0, K1, K2, false>), grid, dim3(kBlock), 0, stream, a, t);    \
             }, [&](unsigned long long *queue) {                                                                          \
                 hipLaunchKernelGGL((dls_chain_hot_refill_kernel<N, K0, K1, K2>), dim3(static_cast<unsigned>(rgrid)), dim3(kBlock), 0, stream, a, t, queue, refill_chunk(io.B, rgrid)); \

@@ -534,7 +534,7 @@ hipError_t launch_shape(const ProblemHost &ph, const DeviceTables &dt, const Bat
     if (mode == kStopLockStep) return launch(m.stop, waves, two);
     if (mode == kStopTwoPhase) {
         hipError_t le = hipSuccess;
-        const hipError_t te = run_two_phase(dt, io, stream, a, false, [&] { le = launch(m.stop, waves, two); },
+        const hipError_t te = run_two_phase(dt.queues, io, stream, a, false, [&] { le = launch(m.stop, waves, two); },
                                             [&](unsigned long long *queue) {
                                                 args.queue = queue;
                                                 args.chunk = refill_chunk(io.B, resident);
@@ -874,7 +874,7 @@ std::string generic_static_source(const ProblemHost &ph, int kind = kStaticDls) 
     else
         o += "extern \"C\" __global__ __launch_bounds__(64) void ikgpu_lane_dls(const ikdev::GenericKernelArgs a) {\n"
              "    double w[T::ws_words];\n"
-             "    ikdev::dls_generic_body_ws(a, T{}, static_cast<int64_t>(blockIdx.x) * 64 + threadIdx.x, ikdev::WsReg{w}, [](bool act) { return __any(act) != 0; },\n"
+             "    ikdev::dls_generic_body_ws(a, T{}, static_cast<int64_t>(blockIdx.x) * 64 + threadIdx.x, ikdev::WsReg{w}, ikdev::KeepGoing{a.leave_active, a.leave_after, 0},\n"
              "                               T::M > 12 ? static_cast<int64_t>(blockIdx.x) * 64 : int64_t{-1});\n"
              "}\n";
     return o;
@@ -1041,12 +1041,25 @@ hipError_t rtc_launch_generic_static(const ProblemHost &gen, uint64_t key, const
             if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
         }
         const int64_t resident = refill_resident(static_cast<int64_t>(m.refill_waves_per_cu) * cus, io.B);
-        if (refill_wanted(prm, io.B, resident)) {
+        // (the switch point of the tree kernels: a static lane program is as heavy, one wave per SIMD in many rounds -- kernels.hpp)
+        const int mode = stop_rule_mode(prm, io.B, resident, stream, true);
+        if (mode == kStopRefill) {
             hipError_t e = hipSuccess;
             args.queue = queues->slot_for(stream, &e);
             if (!args.queue) return e;
             args.chunk = refill_chunk(io.B, resident);
             return launch(m.refill, resident, offsetof(Args, chunk) + sizeof(int));
+        }
+        if (mode == kStopTwoPhase) {   // (kernels.hpp run_two_phase: the lock-step program until a wave's stragglers are few, the refill twin on those)
+            hipError_t le = hipSuccess;
+            const hipError_t te = run_two_phase(*queues, io, stream, a, true, [&] { le = launch(m.dls, (io.B + 63) / 64, sizeof(ikdev::GenericKernelArgs)); },
+                                                [&](unsigned long long *queue) {
+                                                    args.queue = queue;
+                                                    args.chunk = refill_chunk(io.B, resident);
+                                                    const hipError_t r = launch(m.refill, resident, offsetof(Args, chunk) + sizeof(int));
+                                                    if (le == hipSuccess) le = r;
+                                                });
+            return le != hipSuccess ? le : te;
         }
     }
     return launch(m.dls, (io.B + 63) / 64, sizeof(ikdev::GenericKernelArgs));

@@ -158,16 +158,23 @@ def test_static_program_lane_refill_is_bit_identical_to_lock_step(torch_cuda, mo
             Q0 = torch.from_numpy(np.ascontiguousarray(q)).cuda()
             T = torch.from_numpy(np.ascontiguousarray(t)).cuda()
         res = {}
-        for mode in ("0", "1"):
-            os.environ["IKGPU_REFILL"] = mode
+        # "2": the two-phase solve (kernels.hpp run_two_phase: the lock-step program until a wave's stragglers are few, the refill twin
+        # on the problems left open), also with the hand-over at once and late; None: the default policy for this batch size
+        for mode, env in (("0", {}), ("1", {}), ("2", {}), ("2 at once", {"IKGPU_TWO_PHASE_ITERS": "1", "IKGPU_TWO_PHASE_ACTIVE": "63"}),
+                          ("2 late", {"IKGPU_TWO_PHASE_ITERS": "12", "IKGPU_TWO_PHASE_ACTIVE": "2"}), (None, {})):
+            if mode is not None:
+                os.environ["IKGPU_REFILL"] = mode[0]
+            os.environ.update(env)
             try:
                 out = ik.dls_batch(problem, Q0, T, data, vis, p, layout=layout)
                 torch.cuda.synchronize()
             finally:
-                os.environ.pop("IKGPU_REFILL", None)
+                for k in ["IKGPU_REFILL"] + list(env):
+                    os.environ.pop(k, None)
             res[mode] = [x.clone() for x in out]
-        for a, b in zip(res["0"], res["1"]):
-            assert torch.equal(a, b), (case, layout, B)
+        for mode in res:
+            for a, b in zip(res["0"], res[mode]):
+                assert torch.equal(a, b), (case, layout, B, mode)
         it = res["1"][2]
         assert int(it.max()) <= 24 and int(it.min()) >= 0
         if B >= 1000:
