@@ -32,8 +32,11 @@ __global__ __launch_bounds__(kBlock) void dls_chain_hot_kernel(const ChainKernel
 // The same program with lane refill (device/chain_kernel_body.hpp chain_refill_loop): the stop-rule mode on batches larger than the machine.
 // Two waves per SIMD asked for (<= 256 registers): a wave that refills waits for its gathered loads (~2 us, most iterations have a
 // lane that finishes) and the other wave of the SIMD computes meanwhile.
+#ifndef IKGPU_HOT_REFILL_WAVES
+#define IKGPU_HOT_REFILL_WAVES 2   // (tools/build_variant.sh onewave -DIKGPU_HOT_REFILL_WAVES=1: the A/B of DESIGN.md section 3.1)
+#endif
 template <int NJ, uint64_t C0, uint64_t C1, uint64_t C2>
-__global__ __launch_bounds__(kBlock, 2) void dls_chain_hot_refill_kernel(const ChainKernelArgs<NJ> a, const HotTable t, unsigned long long *queue, int chunk) {
+__global__ __launch_bounds__(kBlock, IKGPU_HOT_REFILL_WAVES) void dls_chain_hot_refill_kernel(const ChainKernelArgs<NJ> a, const HotTable t, unsigned long long *queue, int chunk) {
     ikdev::hot_refill_entry<NJ, ChainStruct<C0, C1, C2>>(a, t, queue, chunk);
 }
 

@@ -50,6 +50,10 @@ misc)
   steps+=("launcher_full|300|python3 bench.py --launcher --gather full --no-cpu > gpurun_out/r04_bench_launcher_n1_gather_full.json; cut -c1-250 gpurun_out/r04_bench_launcher_n1_gather_full.json")
   steps+=("pik_timing|300|python3 tools/pik_timing.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_pik_timing.txt; cat gpurun_out/r04_pik_timing.txt")
   steps+=("host_tails|200|python3 tools/host_entry_tails.py 400 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_host_entry_tails.txt; cat gpurun_out/r04_host_entry_tails.txt")
+  steps+=("two_phase_chain|300|python3 tools/two_phase_probe.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_two_phase_probe_chain.txt; tail -3 gpurun_out/r04_two_phase_probe_chain.txt")
+  steps+=("two_phase_tree|300|python3 tools/two_phase_probe.py tree 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_two_phase_probe_tree.txt; tail -3 gpurun_out/r04_two_phase_probe_tree.txt")
+  steps+=("refill_batch|600|bash tools/refill_batch_sweep.sh > gpurun_out/r04_refill_batch.txt 2>&1; tail -3 gpurun_out/r04_refill_batch.txt")
+  steps+=("bench_default|300|python3 bench.py > gpurun_out/r04_bench_default.json 2>/dev/null; cut -c1-300 gpurun_out/r04_bench_default.json")
   steps+=("forms_dual|300|IKGPU_STATIC_FORM=dual FORMS=static python3 tools/generic_forms.py three_feet_frames rows_16 feet_frames_beyond_the_register_solve nv_30 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_generic_forms_dual.txt; cat gpurun_out/r04_generic_forms_dual.txt") ;;
 esac
 tools/gpu_session.sh "${steps[@]}"
