@@ -1,9 +1,14 @@
 #!/usr/bin/env python3
-"""ikgpu_dls_solve_batch_host on pinned host buffers, wall clock per call, by batch size and chunk size (IKGPU_HOST_CHUNK)."""
+"""ikgpu_dls_solve_batch_host on pinned host buffers, wall clock per call, by batch size and chunk size (IKGPU_HOST_CHUNK).  A row whose
+slowest call is more than 5 ms above its median prints that call's phases (IKGPU_HOST_TRACE: lock / set-up / enqueue / wait)."""
 import ctypes as C
 import os
 import sys
+import tempfile
 import time
+
+TRACE = os.path.join(tempfile.gettempdir(), "ikgpu_host_trace_%d.txt" % os.getpid())
+os.environ["IKGPU_HOST_TRACE"] = TRACE
 
 import numpy as np
 import torch
@@ -39,6 +44,7 @@ for B in (65536, 262144):
                 capi.check(L.ikgpu_dls_solve_batch_host(data._h, B, hq0.data_ptr(), htg.data_ptr(), C.byref(prm), hq.data_ptr(), hok.data_ptr(), hit.data_ptr(),
                                                         capi.SOA if layout == "soa" else capi.AOS))
             call(); call()
+            open(TRACE, "w").close()
             ts = []
             for _ in range(30):
                 t = time.perf_counter()
@@ -47,4 +53,8 @@ for B in (65536, 262144):
             ts.sort()
             ms = ts[len(ts) // 2]
             same = torch.equal(hq if layout == "soa" else hq.t(), ref[0].cpu())
-            print("B %d %s chunk %-7s: median %.3f ms (min %.3f, max %.3f) = %.3e solves/s%s" % (B, layout, chunk or "default", ms, ts[0], ts[-1], B / ms * 1e3, "" if same else "  DIFFERENT"))
+            print("B %d %s chunk %-7s: median %.3f ms (min %.3f, max %.3f) = %.3e solves/s%s" % (B, layout, chunk or "default", ms, ts[0], ts[-1], B / ms * 1e3, "" if same else "  DIFFERENT"), flush=True)
+            if ts[-1] > ms + 5.0:
+                rec = sorted((ln.split() for ln in open(TRACE) if ln.startswith("B ")), key=lambda w: -float(w[5]))[:1]
+                for w in rec:
+                    print("      slowest traced call: " + " ".join(w), flush=True)
