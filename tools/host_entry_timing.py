@@ -7,6 +7,29 @@ import sys
 import tempfile
 import time
 
+
+
+def throttled_usec():
+    """time this container's cgroup spent throttled by its CPU quota so far (cgroup v2 cpu.stat / v1 cpu.stat), or None"""
+    for path, key, scale in (("/sys/fs/cgroup/cpu.stat", "throttled_usec", 1.0), ("/sys/fs/cgroup/cpu/cpu.stat", "throttled_time", 1e-3)):
+        try:
+            for ln in open(path):
+                w = ln.split()
+                if w and w[0] == key:
+                    return float(w[1]) * scale
+        except OSError:
+            pass
+    return None
+
+
+def run_delay_ms():
+    """time the calling thread has spent RUNNABLE but not running (waiting for a CPU), /proc/thread-self/schedstat field 2"""
+    try:
+        return float(open("/proc/thread-self/schedstat").read().split()[1]) * 1e-6
+    except (OSError, IndexError, ValueError):
+        return None
+
+
 TRACE = os.path.join(tempfile.gettempdir(), "ikgpu_host_trace_%d.txt" % os.getpid())
 os.environ["IKGPU_HOST_TRACE"] = TRACE
 
@@ -45,6 +68,7 @@ for B in (65536, 262144):
                                                         capi.SOA if layout == "soa" else capi.AOS))
             call(); call()
             open(TRACE, "w").close()
+            thr0, rd0 = throttled_usec(), run_delay_ms()
             ts = []
             for _ in range(30):
                 t = time.perf_counter()
@@ -56,5 +80,8 @@ for B in (65536, 262144):
             print("B %d %s chunk %-7s: median %.3f ms (min %.3f, max %.3f) = %.3e solves/s%s" % (B, layout, chunk or "default", ms, ts[0], ts[-1], B / ms * 1e3, "" if same else "  DIFFERENT"), flush=True)
             if ts[-1] > ms + 5.0:
                 rec = sorted((ln.split() for ln in open(TRACE) if ln.startswith("B ")), key=lambda w: -float(w[5]))[:1]
+                thr1, rd1 = throttled_usec(), run_delay_ms()
+                note = ("cgroup CPU throttling during this row %.1f ms" % ((thr1 - thr0) * 1e-3)) if thr0 is not None and thr1 is not None else "no cpu.stat"
+                note += ("; the calling thread waited %.1f ms for a CPU" % (rd1 - rd0)) if rd0 is not None and rd1 is not None else ""
                 for w in rec:
-                    print("      slowest traced call: " + " ".join(w), flush=True)
+                    print("      slowest traced call: " + " ".join(w) + "   (" + note + ")", flush=True)

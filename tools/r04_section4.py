@@ -80,8 +80,14 @@ Secondary figures printed by `bench.py` next to the headline (Cassie leg, `profi
   p99 %(he_p99).3f, max %(he_max).3f at B = 65 536 (%(he_v).3g solves/s)**; one problem per call (the reference's own call pattern): median
   %(one_p50).3f ms, p99 %(one_p99).3f, max %(one_max).3f at 50 iterations.  PCIe-inclusive, never `value`.  By chunking
   (`profiles/r04_host_entry.txt`, best chunk per size): %(he_txt)s.  Per-phase clocks and the tails over 400 calls:
-  `profiles/r04_host_entry_tails.txt` (no 30–75 ms stall was reproduced; the slowest call spends its extra time in
-  the enqueue phase).
+  `profiles/r04_host_entry_tails.txt`.  VERDICT r03 item 6 — the 30–75 ms stalls: they are the container's CPU quota, not a HIP call.
+  `tools/host_entry_timing.py` now prints, for every row with an outlier, the slow call's phases next to the cgroup's throttled time
+  (`cpu.stat`; the box runs under `cpu.max = 16` CPUs of 256) and the calling thread's run-queue delay (`/proc/thread-self/schedstat`):
+  the slow calls of `profiles/r04_host_entry.txt` (16.6, 36.9, 67.2 ms; in `wait` or in `enqueue`, whichever was running) each come with
+  16.2, 36.3, 66.4 ms in which the calling thread was RUNNABLE and had no CPU, in rows where the cgroup was throttled 90–1 010 ms — the
+  harness's own torch CPU operations between the rows (256 OpenMP threads) spend the quota.  A caller that does not burn its quota does
+  not see them: `bench.py`'s 240 calls and the tails tool's 400 have max ≤ 1.1 × median.  What is left that IS the runtime's: one call in
+  ≈ 700 with 8–10 ms in the enqueue phase (no throttling, no run-queue delay).
 * `model_load`: URDF text → device handle %(ml).2f ms for built-in kernels; run-time compiled ones: §3.3 / `profiles/r04_creation_timing.txt`.
 
 `value` is whole-job throughput over the timed region (K launches back to back on one stream, barrier + synchronize on both sides).
