@@ -86,8 +86,9 @@ Secondary figures printed by `bench.py` next to the headline (Cassie leg, `profi
   the slow calls of `profiles/r04_host_entry.txt` (16.6, 36.9, 67.2 ms; in `wait` or in `enqueue`, whichever was running) each come with
   16.2, 36.3, 66.4 ms in which the calling thread was RUNNABLE and had no CPU, in rows where the cgroup was throttled 90–1 010 ms — the
   harness's own torch CPU operations between the rows (256 OpenMP threads) spend the quota.  A caller that does not burn its quota does
-  not see them: `bench.py`'s 240 calls and the tails tool's 400 have max ≤ 1.1 × median.  What is left that IS the runtime's: one call in
-  ≈ 700 with 8–10 ms in the enqueue phase (no throttling, no run-queue delay).
+  not see them: `bench.py`'s 240 calls and the tails tool's 400 have max ≤ 1.2 × median at B = 65 536 (B = 1: p99 1.2 ×, max 1.4 ×) —
+  the item's bar, p99 ≤ 2 × p50, holds at both sizes.  What is left that IS the runtime's: two calls of that file's 720 with 7–9 ms in the
+  enqueue phase (no throttling, no run-queue delay).
 * `model_load`: URDF text → device handle %(ml).2f ms for built-in kernels; run-time compiled ones: §3.3 / `profiles/r04_creation_timing.txt`.
 
 `value` is whole-job throughput over the timed region (K launches back to back on one stream, barrier + synchronize on both sides).
