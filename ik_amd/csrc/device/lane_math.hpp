@@ -481,7 +481,11 @@ IKD_FN void log6_and_jlog6_hot(const double (&Re)[9], const double (&pe)[3], Log
     const double ax = __builtin_fabs(x);
     const bool mid = ax < 0.5;
     const double z = dfma(-0.5, x, 0.5);       // (1 - cos theta)/2 = sin^2(theta/2)
-    const double zc = dfma(0.5, x, 0.5);       // (1 + cos theta)/2 = cos^2(theta/2) = 1 - z
+    // (1 + cos theta)/2 = cos^2(theta/2) = 1 - z, kept off zero: at theta = pi to rounding (trace <= -1: x clamps to -1) an exact 0
+    // would make h = 0 below, and the ONE reciprocal r = 1 / (theta h) would return 1/theta = r h = 0 -- beta, Jlog3's diagonal and the
+    // translation of log6 all wrong, a step off by a radian (found by the step-synchronised parity test on its tenth seed: one lane-step
+    // in 3e7).  With the floor h = 2^-52, r = 1.4e15, r h = 1/pi, and cot = zc / h = 2^-52 stands in for 0.
+    const double zc = dmax(dfma(0.5, x, 0.5), 0x1p-104);
     const double za = mid ? x * x : dfma(-0.5, ax, 0.5);
     double pp_ = dfma3(za, pS5, pS4);
     pp_ = dfma3(za, pp_, pS3);

