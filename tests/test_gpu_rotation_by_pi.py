@@ -22,13 +22,14 @@ def torch_cuda(native_built):
 
 
 def _rotations_just_short_of_pi(rng, n):
-    """R(a, pi - delta), delta in [1e-9, 3e-8]: (1 + cos theta) / 2 = delta^2 / 4 < 2^-54 rounds to zero or one ulp -- the trace lands on
+    """R(a, pi - delta); even lanes delta in [1e-9, 3e-8]: (1 + cos theta) / 2 = delta^2 / 4 < 2^-54 rounds to zero or one ulp -- the trace lands on
     or next to -1 -- while sin(theta) a_i = delta a_i >> 1e-16 keeps the axis' signs (R21 > R12 ...) unambiguous: AT pi exactly log3
     has two values and the oracle itself is discontinuous (its double and _Float128 builds pick different signs)."""
     a = rng.normal(size=(n, 3))
     a = np.sign(a) * np.maximum(np.abs(a), 0.2)                          # no component near zero
     a /= np.linalg.norm(a, axis=1)[:, None]
-    th = np.pi - 10.0 ** rng.uniform(-9.0, -7.5, n)
+    th = np.pi - 10.0 ** np.where(np.arange(n) % 2 == 0, rng.uniform(-9.0, -7.5, n), rng.uniform(-7.5, -1.5, n))   # (odd lanes: the rest of
+    # the band in which log3 takes its theta -> pi formula, pi - 1e-2 < theta, and a little of the regular one)
     K = np.zeros((n, 3, 3))
     K[:, 0, 1], K[:, 0, 2], K[:, 1, 0], K[:, 1, 2], K[:, 2, 0], K[:, 2, 1] = -a[:, 2], a[:, 1], a[:, 2], -a[:, 0], -a[:, 1], a[:, 0]
     return np.eye(3)[None] + np.sin(th)[:, None, None] * K + (1.0 - np.cos(th))[:, None, None] * (K @ K)
