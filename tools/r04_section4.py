@@ -39,6 +39,45 @@ def host_entry_rows():
     return out
 
 
+def host_entry_stalls():
+    """the outlier rows of profiles/r04_host_entry.txt as a sentence: total / phase / run-queue delay / throttled time of each slow call"""
+    p = os.path.join(P, "r04_host_entry.txt")
+    big, small = [], []
+    if os.path.exists(p):
+        for l in open(p):
+            m = re.search(r"slowest traced call: .*total_ms ([\d.]+) lock ([\d.]+) setup ([\d.]+) enqueue ([\d.]+) wait ([\d.]+)\s+\(cgroup CPU throttling during this row ([\d.]+) ms; the calling thread waited ([\d.]+) ms", l)
+            if m:
+                tot, enq, wait, thr, rd = float(m.group(1)), float(m.group(4)), float(m.group(5)), float(m.group(6)), float(m.group(7))
+                (big if rd > 0.5 * tot else small).append((tot, "enqueue" if enq > wait else "wait", rd, thr))
+    out = ""
+    if big:
+        out += "In this run's `profiles/r04_host_entry.txt` the slow calls of " + ", ".join("%.1f" % b[0] for b in big) + " ms (in `" + "` / `".join(b[1] for b in big) + \
+               "`, whichever was running) come with " + ", ".join("%.1f" % b[2] for b in big) + " ms in which the calling thread was RUNNABLE and had no CPU, in rows where the cgroup was throttled " + \
+               ", ".join("%.0f" % b[3] for b in big) + " ms."
+    else:
+        out += "In this run's `profiles/r04_host_entry.txt` no call waited for a CPU."
+    if small:
+        out += "  What is left that IS the runtime's: " + ", ".join("%.1f ms in `%s`" % (x[0], x[1]) for x in small) + " (no throttling, no run-queue delay) among the file's 720 calls."
+    return out
+
+
+def tails_sentence():
+    rows = {}
+    p = os.path.join(P, "r04_host_entry_tails.txt")
+    if os.path.exists(p):
+        for l in open(p):
+            m = re.match(r"B\s+(\d+),\s+(\d+) iterations, (\d+) calls: p50 ([\d.]+) ms\s+p90 [\d.]+\s+p99 ([\d.]+)\s+max ([\d.]+)", l)
+            if m:
+                rows[(int(m.group(1)), int(m.group(2)))] = (int(m.group(3)), float(m.group(4)), float(m.group(5)), float(m.group(6)))
+    out = "`bench.py`'s %d calls at B = 65 536: p99 %.2f ×, max %.2f × the median" % (e2e["abi_host_entry_calls"], e2e["abi_host_entry_p99_ms"] / e2e["abi_host_entry_ms"],
+                                                                                  e2e["abi_host_entry_max_ms"] / e2e["abi_host_entry_ms"])
+    for key, name in (((65536, 50), "B = 65 536"), ((1, 50), "B = 1")):
+        if key in rows:
+            n, p50, p99, mx = rows[key]
+            out += "; the tails tool's %d at %s: p99 %.2f ×, max %.2f ×" % (n, name, p99 / p50, mx / p50)
+    return out
+
+
 he = host_entry_rows()
 best = {}
 for B, chunk, ms, v in he:
@@ -82,13 +121,10 @@ Secondary figures printed by `bench.py` next to the headline (Cassie leg, `profi
   (`profiles/r04_host_entry.txt`, best chunk per size): %(he_txt)s.  Per-phase clocks and the tails over 400 calls:
   `profiles/r04_host_entry_tails.txt`.  VERDICT r03 item 6 — the 30–75 ms stalls: they are the container's CPU quota, not a HIP call.
   `tools/host_entry_timing.py` now prints, for every row with an outlier, the slow call's phases next to the cgroup's throttled time
-  (`cpu.stat`; the box runs under `cpu.max = 16` CPUs of 256) and the calling thread's run-queue delay (`/proc/thread-self/schedstat`):
-  the slow calls of `profiles/r04_host_entry.txt` (16.6, 36.9, 67.2 ms; in `wait` or in `enqueue`, whichever was running) each come with
-  16.2, 36.3, 66.4 ms in which the calling thread was RUNNABLE and had no CPU, in rows where the cgroup was throttled 90–1 010 ms — the
-  harness's own torch CPU operations between the rows (256 OpenMP threads) spend the quota.  A caller that does not burn its quota does
-  not see them: `bench.py`'s 240 calls and the tails tool's 400 have max ≤ 1.2 × median at B = 65 536 (B = 1: p99 1.2 ×, max 1.4 ×) —
-  the item's bar, p99 ≤ 2 × p50, holds at both sizes.  What is left that IS the runtime's: two calls of that file's 720 with 7–9 ms in the
-  enqueue phase (no throttling, no run-queue delay).
+  (`cpu.stat`; the box runs under `cpu.max = 16` CPUs of 256) and the calling thread's run-queue delay (`/proc/thread-self/schedstat`).
+  %(stalls)s
+  The harness's own torch CPU operations between the rows (256 OpenMP threads) spend the quota; a caller that does not burn its quota
+  does not see the stalls: %(tails)s — the item's bar, p99 ≤ 2 × p50, holds at both sizes.
 * `model_load`: URDF text → device handle %(ml).2f ms for built-in kernels; run-time compiled ones: §3.3 / `profiles/r04_creation_timing.txt`.
 
 `value` is whole-job throughput over the timed region (K launches back to back on one stream, barrier + synchronize on both sides).
@@ -101,7 +137,7 @@ CPU variant (`oracle/fast_cpu.cpp`, every thread): %(cpu_fast).3g solves/s — a
 """ % dict(stamp=stamp, table=table, gb_ms=gb["kernel_ms"], gb_v=gb["value"], b4_ms=b4["kernel_ms"], b4_v=b4["value"], ds_ms=ds["kernel_ms"],
            ds_it=ds["mean_iterations"], ds_ok=100 * ds["success_rate"], rows="\n".join(rows), calls=e2e["abi_host_entry_calls"],
            he_ms=e2e["abi_host_entry_ms"], he_p99=e2e["abi_host_entry_p99_ms"], he_max=e2e["abi_host_entry_max_ms"], he_v=e2e["abi_host_entry_value"],
-           one_p50=one["p50"], one_p99=one["p99"], one_max=one["max"], he_txt=he_txt, ml=ml["urdf_to_device_handle_ms"], cores=cpu["cores"],
+           one_p50=one["p50"], one_p99=one["p99"], one_max=one["max"], he_txt=he_txt, stalls=host_entry_stalls(), tails=tails_sentence(), ml=ml["urdf_to_device_handle_ms"], cores=cpu["cores"],
            cpu_v=cpu["value"], cpu_fast=cpu["optimised"]["value"])
 
 path = os.path.join(ROOT, "DESIGN.md")
