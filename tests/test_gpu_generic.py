@@ -35,6 +35,7 @@ def build(name, ff, specs, B, seed=0, xml_edit=None, static=True, device=True):
     import ik_amd
     import oracle as O
     from ik_amd import workload
+    seed += int(os.environ.get("IKGPU_TEST_SEED_OFFSET", "0"))   # other draws of every workload built here, against the same assertions
     xml = open(urdf_path(name), "rb").read()
     if xml_edit:
         xml = xml_edit(xml)
