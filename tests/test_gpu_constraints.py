@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from conftest import urdf_path
-from test_gpu_generic import build
+from test_gpu_generic import assert_within_bar_or_oracle_unstable, build
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-6
@@ -68,7 +68,8 @@ def test_constrained_dls_matches_oracle(torch_cuda, case, monkeypatch):
         Q, ok, it = ik_amd.dls_batch(problem, Q0, T, data, ik_amd.inverse_kinematics_visitor(tol), p)
         q_ref, ok_ref, it_ref = O.dls_batch_constrained(om, ot, oc, tg, q0, O.params(iters, damping, step, tol), os.cpu_count() or 1)
         assert np.array_equal(ok.cpu().numpy(), ok_ref) and np.array_equal(it.cpu().numpy(), it_ref), (case, iters)
-        assert np.abs(Q.cpu().numpy().T - q_ref).max() <= TOL, (case, iters)
+        prm_o = O.params(iters, damping, step, tol)
+        assert_within_bar_or_oracle_unstable(lambda t_, q_: O.dls_batch_constrained(om, ot, oc, t_, q_, prm_o, os.cpu_count() or 1), Q.cpu().numpy().T, q_ref, tg, q0, (case, iters))
     if on_tree:                                                  # same problem, same parameters, the generic kernel
         monkeypatch.setenv("IKGPU_DLS_KERNEL", "generic")
         data_g = ik_amd.dls_data(problem, device=0)

@@ -196,6 +196,28 @@ CHAOTIC_AT_FULL_STEP = {"com_in_foot_frame", "demo_task_set", "demo_with_directi
 FORCED_GENERIC = {"posture_regulariser", "fixed_two_feet_priorities", "posture_first_level"}
 
 
+def assert_within_bar_or_oracle_unstable(solve, q_dev, q_ref, tg, q0, label):
+    """|q_dev - q_ref| <= 1e-6 rad on every lane -- or, for at most one lane in a hundred, a lane the ORACLE cannot answer to 1e-7 either:
+    its own result moves by more than that under 1e-13 perturbations of its inputs (the exclusion rule of tests/test_gpu_full_size.py,
+    decided by the oracle alone: three draws along (1, ..., 1), then sixteen with random signs).  A lane parked on a joint limit for 200
+    small steps amplifies rounding; with the suite's own seeds no case needs this, with IKGPU_TEST_SEED_OFFSET one lane in 500 does
+    (both forms of the kernel then part from the oracle by the same 1e-4 ... 6e-2 while agreeing with it to 1e-12 step by step).
+    solve(targets, q0) runs the oracle with the case's parameters."""
+    from test_gpu_full_size import oracle_sensitivity_more_draws
+    d = np.abs(q_dev - q_ref).max(axis=1)
+    bad = np.flatnonzero(d > TOL)
+    if not bad.size:
+        return
+    assert bad.size <= max(1, q0.shape[0] // 100), (label, bad.size, d.max())
+    sens = np.zeros(bad.size)
+    for dq, dt in ((1e-13, 0.0), (0.0, 1e-13), (-1e-13, -1e-13)):
+        tgp = tg[bad].copy()
+        tgp[:, :, 9:] += dt
+        sens = np.maximum(sens, np.abs(solve(tgp, q0[bad] + dq)[0] - q_ref[bad]).max(axis=1))
+    sens = np.maximum(sens, oracle_sensitivity_more_draws(lambda t_, q_, _e: solve(t_, q_), tg, q0, q_ref, bad))
+    assert (sens > 1e-7).all(), (label, bad, d[bad], sens)
+
+
 @pytest.mark.parametrize("static", [True, False], ids=["static", "coop"])
 @pytest.mark.parametrize("case", sorted(CASES))
 def test_generic_kernel_matches_oracle(torch_cuda, case, static, monkeypatch):
@@ -231,7 +253,8 @@ def test_generic_kernel_matches_oracle(torch_cuda, case, static, monkeypatch):
             assert (d <= TOL).mean() > 0.7, (case, iters, (d <= TOL).mean())
             continue
         assert np.array_equal(ok.cpu().numpy(), ok_ref) and np.array_equal(it.cpu().numpy(), it_ref), (case, iters)
-        assert np.abs(Q.cpu().numpy().T - q_ref).max() <= TOL, (case, iters)
+        prm_o = O.params(iters, damping, step, tol)
+        assert_within_bar_or_oracle_unstable(lambda t_, q_: O.dls_batch(om, ot, t_, q_, prm_o, os.cpu_count() or 1), Q.cpu().numpy().T, q_ref, tg, q0, (case, iters))
     # AoS gives the same bits
     Qa, oka, ita = ik_amd.dls_batch(problem, torch.from_numpy(q0).cuda(), torch.from_numpy(tg).cuda(), data,
                                     ik_amd.inverse_kinematics_visitor(tol), p, layout="aos")
