@@ -21,7 +21,7 @@ def torch_cuda(native_built):
     return torch
 
 
-def _inputs(model, B, seed):
+def _inputs(model, B, seed, turn):
     from ik_amd import workload
     rng = np.random.default_rng(seed)
     q0, _ = workload.freeflyer_workload(model.lowerPositionLimit, model.upperPositionLimit, workload.cassie_nominal(model.names), np.arange(B), seed=seed, mode="near")
@@ -36,7 +36,7 @@ def _inputs(model, B, seed):
     q0[:, :3] += rng.uniform(-0.5, 0.5, (B, 3))
     v = np.zeros((B, model.nv))
     v[:, :3] = rng.uniform(-0.1, 0.1, (B, 3))
-    v[:, 3:6] = rng.uniform(-0.3, 0.3, (B, 3))
+    v[:, 3:6] = rng.uniform(-turn, turn, (B, 3))
     v[:, 6:] = rng.uniform(-0.15, 0.15, (B, model.nv - 6))
     qs = workload.freeflyer_integrate_batch(q0, v)
     qs[:, 7:] = np.clip(qs[:, 7:], model.lowerPositionLimit[7:], model.upperPositionLimit[7:])
@@ -51,8 +51,9 @@ CASES = {
 }
 
 
-@pytest.mark.parametrize("case", list(CASES))
-def test_any_base_orientation_against_the_oracle(torch_cuda, case):
+@pytest.mark.parametrize("turn", [0.3, 3.0], ids=["near", "far"])   # rad: how far the targets are turned from the start pose (far: the first
+@pytest.mark.parametrize("case", list(CASES))                        # steps turn the base by radians -- exp6 and the conversion at large angles)
+def test_any_base_orientation_against_the_oracle(torch_cuda, case, turn):
     torch = torch_cuda
     import ik_amd
     import oracle as O
@@ -69,7 +70,7 @@ def test_any_base_orientation_against_the_oracle(torch_cuda, case):
     finally:
         for k, v in old.items():
             os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
-    q0, qs = _inputs(model, B, seed=21)
+    q0, qs = _inputs(model, B, seed=21, turn=turn)
     om = O.OracleModel(model.flat())
     fids = [model.getFrameId(f) for f in frames]
     tasks = O.make_tasks([(fid, 0, t, 0, None) for fid, t in zip(fids, types)])
@@ -78,7 +79,7 @@ def test_any_base_orientation_against_the_oracle(torch_cuda, case):
     Q0 = torch.from_numpy(np.ascontiguousarray(q0.T)).cuda()
     cores = os.cpu_count() or 1
     worst = {}
-    for iters, bar in ((1, 1e-9), (20, 1e-6)):
+    for iters, bar in ((1, 1e-9), (20, 1e-6)) if turn < 1.0 else ((1, 1e-9), (3, 1e-8)):
         Q, _, _ = ik_amd.dls_batch(problem, Q0, T, data, ik_amd.never_stop_visitor(), ik_amd.dls_parameters(max_iterations=iters))
         q_dev = Q.cpu().numpy().T
         q_ref, _, _ = O.dls_batch(om, tasks, tg, q0, O.params(iters, 1e-2, 1.0, -1.0), cores)
@@ -91,4 +92,4 @@ def test_any_base_orientation_against_the_oracle(torch_cuda, case):
     qf = q_ref[:, 3:7]
     dom = np.argmax(np.abs(qf), axis=1)
     assert all((dom == k).sum() > B // 40 for k in range(4)), np.bincount(dom, minlength=4)
-    print("%s [%s]: max |dq| vs oracle %.2e after 1 step, %.2e after 20; dominant quaternion component counts %s" % (case, data.kernel, worst[1], worst[20], np.bincount(dom, minlength=4)))
+    print("%s %s [%s]: max |dq| vs oracle %s; dominant quaternion component counts %s" % (case, turn, data.kernel, {k: "%.1e" % v for k, v in worst.items()}, np.bincount(dom, minlength=4)))
