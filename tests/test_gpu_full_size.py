@@ -424,19 +424,25 @@ def test_full_body_step_synchronised_along_the_oracle_trajectory(torch_cuda, mod
 
 
 @pytest.mark.parametrize("kernel", ["tree", "static"])
-def test_demo_task_set_step_synchronised_along_the_oracle_trajectory(torch_cuda, kernel, monkeypatch):
+@pytest.mark.parametrize("case", ["demo_task_set", "demo_with_posture", "pelvis_and_foot"])
+def test_demo_task_set_step_synchronised_along_the_oracle_trajectory(torch_cuda, case, kernel, monkeypatch):
     """The reference demo's own task set (ik_ros/src/cassie.cpp:45-81: foot position in the pelvis frame, pelvis pose, foot-axis
-    alignment; M = 10) through rule S at the metric's batch: all 65536 lanes, 11 steps along the oracle's trajectory, on the kernel it
-    runs on by default (the static lane program: the oracle's own dual system, S3) and on the tree kernel's general build (base-relative
-    reference, alignment row; the arrow solve, S3').  The suites of these kernels compare 500 problems; this is 700 000 lane-steps."""
+    alignment; M = 10), the same with its posture regulariser on all 16 joints (M = 26) and a weighted pelvis + foot pair, through rule S
+    at the metric's batch: all 65536 lanes, 11 steps along the oracle's trajectory, on the kernel each runs on by default (the static lane
+    program) and on the tree kernel's general / posture build.  The suites of these kernels compare 500-4000 problems; this is 700 000
+    lane-steps per case.  S3 (ratio statistics) where the kernel solves the oracle's own dual system -- the static programs without
+    eliminated rows; elsewhere (arrow solve; Woodbury on the posture rows) the a-priori ratio is recorded, S1 and S2 asserted."""
     torch = torch_cuda
     from test_gpu_generic import CASES, build
+    from test_gpu_static import ROUTED
     monkeypatch.setenv("IKGPU_TREE_STATIC_ROWS", "0" if kernel == "tree" else "12")
-    name, ff, specs, edit = CASES["demo_task_set"]
-    ik_amd, O, model, problem, data, om, ot, q0, tg = build(name, ff, specs, B, seed=5, xml_edit=edit)
-    assert data.kernel.startswith("dls_tree<NJ=7,chains=1,base_task,base_reference,align_axis>" if kernel == "tree" else "dls_generic<M=10,"), data.kernel
+    name, ff, specs = (CASES[case] if case in CASES else ROUTED[case])[:3]
+    ik_amd, O, model, problem, data, om, ot, q0, tg = build(name, ff, specs, B, seed=5)
+    assert data.kernel.startswith("dls_tree<NJ=7,chains=1,base_task" if kernel == "tree" else "dls_generic<M="), data.kernel
+    assert kernel == "tree" or data.kernel.endswith(",static>"), data.kernel
     T = torch.from_numpy(np.ascontiguousarray(tg.transpose(1, 2, 0))).cuda()
-    _step_synchronised(torch, model, problem, data, ot, q0, T, 11, "cassie demo task set [%s]" % kernel, primal=(kernel == "tree"), assert_apriori=False)
+    other_route = kernel == "tree" or case == "demo_with_posture"
+    _step_synchronised(torch, model, problem, data, ot, q0, T, 11, "cassie %s [%s]" % (case, kernel), primal=other_route, assert_apriori=False)
 
 
 def test_full_body_never_stop_build_equals_the_stop_capable_build(torch_cuda):
