@@ -268,7 +268,7 @@ def _chain_case(torch, name, frame, narrow, mode, build="default", seed=0):
 STEP_BAR = 1e-9      # rad: one DLS step, device against double oracle, every lane
 
 
-def _step_synchronised(torch, model, problem, data, tasks, q0, T, steps, label, primal=False, assert_apriori=True):
+def _step_synchronised(torch, model, problem, data, tasks, q0, T, steps, label, primal=False, assert_apriori=True, oracle_step=None, device_step=None):
     """From the oracle's k-th iterate the device's next iterate, all lanes, no exclusions (see the module docstring: rule S)."""
     import ik_amd
     import oracle as O
@@ -283,9 +283,16 @@ def _step_synchronised(torch, model, problem, data, tasks, q0, T, steps, label, 
     rec = {"kernel": data.kernel, "steps": steps, "lanes": int(q0.shape[0]), "bar_rad": STEP_BAR, "lanes_beyond_bar_arbitrated": 0,
            "worst_ratio_of_arbitrated": 0.0, "median_ratio": [], "frac_ratio_gt_10": [], "frac_ratio_lt_0.1": [], "frac_ratio_gt_100": [],
            "p50_ratio": [], "p99_ratio": [], "max_error_over_apriori_bound": []}
+    # oracle_step(targets, q, ext) / device_step(Q, out): one step of another solver of the family (constrained ik::dls, ik::pik)
+    if oracle_step is None:
+        def oracle_step(t_, q_, ext):
+            return O.dls_batch(om, tasks, t_, q_, one, cores, ext=ext)[0]
+    if device_step is None:
+        def device_step(Q_, out_):
+            return ik_amd.dls_batch(problem, Q_, T, data, ik_amd.never_stop_visitor(), p1, out=out_)
     for k in range(steps):
-        q_next, _, _ = O.dls_batch(om, tasks, tg, q, one, cores)
-        out = ik_amd.dls_batch(problem, torch.from_numpy(np.ascontiguousarray(q.T)).cuda(), T, data, ik_amd.never_stop_visitor(), p1, out=out)
+        q_next = oracle_step(tg, q, None)
+        out = device_step(torch.from_numpy(np.ascontiguousarray(q.T)).cuda(), out)
         q_dev = out[0].cpu().numpy().T
         d = np.abs(q_dev - q_next).max(axis=1)
         worst = max(worst, d.max())
@@ -299,7 +306,7 @@ def _step_synchronised(torch, model, problem, data, tasks, q0, T, steps, label, 
             # the step must be: a device 1e-9 off with the oracle closer than 1.6e-12 to the exact step fails.  A handful only:
             # the bar holds for all but <= 64 of a run's 3.3 million lane-steps.  (Round 4's first form -- oracle off by >= 1e-10 AND
             # device within 100x -- was two constants; seed 15 met a step with the oracle 7e-11 and the device 1.1e-9 off, both builds.)
-            q_x, _, _ = O.dls_batch(om, tasks, tg[over], q[over], one, cores, ext="q")
+            q_x = oracle_step(tg[over], q[over], "q")
             e_dev, e_orc = np.abs(q_dev[over] - q_x).max(axis=1), np.abs(q_next[over] - q_x).max(axis=1)
             rec["lanes_beyond_bar_arbitrated"] += int(over.size)
             assert rec["lanes_beyond_bar_arbitrated"] <= 64, (label, k, rec["lanes_beyond_bar_arbitrated"])
@@ -307,7 +314,7 @@ def _step_synchronised(torch, model, problem, data, tasks, q0, T, steps, label, 
             assert (one_step_ratio(e_dev, e_orc) <= rmax).all(), (label, k, over[:8], e_dev[:8], e_orc[:8], rmax)
             rec["worst_ratio_of_arbitrated"] = max(rec["worst_ratio_of_arbitrated"], float((e_dev / e_orc).max()))
         if k % 10 == 0:
-            q_x, _, _ = O.dls_batch(om, tasks, tg[:NX], q[:NX], one, cores, ext="q")
+            q_x = oracle_step(tg[:NX], q[:NX], "q")
             e_dev, e_orc = np.abs(q_dev[:NX] - q_x).max(axis=1), np.abs(q_next[:NX] - q_x).max(axis=1)
             r = one_step_ratio(e_dev, e_orc)
             n_hi, n_lo = int((r > 10).sum()), int((r < 0.1).sum())
@@ -443,6 +450,50 @@ def test_demo_task_set_step_synchronised_along_the_oracle_trajectory(torch_cuda,
     T = torch.from_numpy(np.ascontiguousarray(tg.transpose(1, 2, 0))).cuda()
     other_route = kernel == "tree" or case == "demo_with_posture"
     _step_synchronised(torch, model, problem, data, ot, q0, T, 11, "cassie %s [%s]" % (case, kernel), primal=other_route, assert_apriori=False)
+
+
+def test_pinned_foot_step_synchronised_along_the_oracle_trajectory(torch_cuda):
+    """The demo with the stance foot pinned by a FrameConstraint (ik_ros/src/cassie.cpp:49-51,74-75; reference ik/ik/dls.cpp:26-34,43-53:
+    dq <- N dq, N = I - pinv(Jc) Jc) on the tree kernel's constraint build, rule S at 65536 lanes x 11 steps against the oracle's
+    constrained step (S1, S2; the projection is another algebraic route than the oracle's: ratios recorded)."""
+    torch = torch_cuda
+    from test_gpu_generic import build
+    from test_gpu_static import ROUTED
+    name, ff, specs, cons = ROUTED["demo_right_foot_pinned"]
+    ik_amd, O, model, problem, data, om, ot, q0, tg = build(name, ff, specs, B, seed=6)
+    problem.add_frame_constraint("c", ik_amd.FrameConstraint.create(model, cons[0], ik_amd.KinematicType(cons[1])))
+    data = ik_amd.dls_data(problem, device=0)
+    assert data.kernel.startswith("dls_tree<NJ=7,chains=1") and "constraint_rows=3" in data.kernel, data.kernel
+    oc = O.make_tasks([(model.getFrameId(cons[0]), 0, cons[1], 0, None)])
+    one, cores = O.params(1, 1e-2, 1.0, -1.0), os.cpu_count() or 1
+    T = torch.from_numpy(np.ascontiguousarray(tg.transpose(1, 2, 0))).cuda()
+    _step_synchronised(torch, model, problem, data, ot, q0, T, 11, "cassie demo, right foot pinned [tree]", primal=True, assert_apriori=False,
+                       oracle_step=lambda t_, q_, ext: O.dls_batch_constrained(om, ot, oc, t_, q_, one, cores, ext=ext)[0])
+
+
+@pytest.mark.parametrize("case,kernel", [("demo_two_levels", "tree"), ("demo_two_levels", "static"), ("fixed_two_feet", "static"), ("ur5_pos_then_ori", "static")])
+def test_pik_step_synchronised_along_the_oracle_trajectory(torch_cuda, case, kernel, monkeypatch):
+    """ik::pik (reference ik/ik/pik.cpp:31-96) through rule S at 65536 lanes x 11 steps: the tree kernel's two-level build and the
+    compiled lane programs (pik_generic<...,static>) against the oracle's SVD / COD iteration (S1, S2; ratios recorded: the damped
+    pseudo-inverse is a dual Cholesky solve here)."""
+    torch = torch_cuda
+    import ik_amd
+    import oracle as O
+    from test_gpu_generic import build
+    from test_gpu_pik import PIK_CASES, _pik_data
+    name, ff, specs, edit = PIK_CASES[case][:4]
+    if kernel == "static":
+        monkeypatch.setenv("IKGPU_PIK_KERNEL", "static")
+    ik_amd, O, model, problem, _, om, ot, q0, tg = build(name, ff, specs, B, seed=7, xml_edit=edit)
+    lam = [0.1] * (problem.max_priority_level() + 1)
+    data = _pik_data(ik_amd, problem, lam, None)
+    assert ("dls_tree<" if kernel == "tree" else ",static>") in data.kernel, data.kernel
+    p1 = ik_amd.pik_parameters(max_iterations=1, step_length=1.0)
+    T = torch.from_numpy(np.ascontiguousarray(tg.transpose(1, 2, 0))).cuda()
+    po, cores = O.pik_params(1, 1.0, -1.0, lam, None), os.cpu_count() or 1
+    _step_synchronised(torch, model, problem, data, ot, q0, T, 11, "pik %s [%s]" % (case, kernel), primal=True, assert_apriori=False,
+                       oracle_step=lambda t_, q_, ext: O.pik_batch(om, ot, t_, q_, po, cores, ext=ext)[0],
+                       device_step=lambda Q_, out_: ik_amd.pik_batch(problem, Q_, T, data, ik_amd.never_stop_visitor(), p1, out=out_))
 
 
 def test_full_body_never_stop_build_equals_the_stop_capable_build(torch_cuda):
