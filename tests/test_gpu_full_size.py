@@ -452,6 +452,24 @@ def test_demo_task_set_step_synchronised_along_the_oracle_trajectory(torch_cuda,
     _step_synchronised(torch, model, problem, data, ot, q0, T, 11, "cassie %s [%s]" % (case, kernel), primal=other_route, assert_apriori=False)
 
 
+@pytest.mark.parametrize("case", ["shared_joints", "moving_reference_prismatic", "com_of_the_arm", "com_under_feet", "three_feet_frames",
+                                  "fixed_two_feet_priorities", "demo_with_direction_in_pelvis_frame", "posture_regulariser"])
+def test_generic_lane_programs_step_synchronised_along_the_oracle_trajectory(torch_cuda, case, monkeypatch):
+    """The other task kinds of the compiled lane programs -- tasks sharing joints, a prismatic joint under a moving reference frame,
+    centre-of-mass rows (ik/ik/centre_of_mass.hpp:33-45), three frames in the primal tree-sparse form, priorities, an alignment
+    direction given in a moving frame, posture rows -- through rule S (S1, S2) at 65536 lanes x 11 steps; their own suite
+    (tests/test_gpu_generic.py) compares 500 problems."""
+    torch = torch_cuda
+    from test_gpu_generic import CASES, FORCED_GENERIC, build
+    if case in FORCED_GENERIC:
+        monkeypatch.setenv("IKGPU_DLS_KERNEL", "generic")
+    name, ff, specs, edit = CASES[case]
+    ik_amd, O, model, problem, data, om, ot, q0, tg = build(name, ff, specs, B, seed=8, xml_edit=edit)
+    assert data.kernel.startswith("dls_generic<") and data.kernel.endswith(",static>"), data.kernel
+    T = torch.from_numpy(np.ascontiguousarray(tg.transpose(1, 2, 0))).cuda()
+    _step_synchronised(torch, model, problem, data, ot, q0, T, 11, "generic %s" % case, primal=True, assert_apriori=False)
+
+
 def test_pinned_foot_step_synchronised_along_the_oracle_trajectory(torch_cuda):
     """The demo with the stance foot pinned by a FrameConstraint (ik_ros/src/cassie.cpp:49-51,74-75; reference ik/ik/dls.cpp:26-34,43-53:
     dq <- N dq, N = I - pinv(Jc) Jc) on the tree kernel's constraint build, rule S at 65536 lanes x 11 steps against the oracle's
