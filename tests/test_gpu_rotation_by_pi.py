@@ -40,8 +40,31 @@ CASES = [("cassie_fixed", False, ["LeftFootFront"], "default"), ("cassie_fixed",
          ("cassie", True, ["LeftFootFront", "RightFootFront", "pelvis"], "default")]
 
 
+def _rotations_by_a_tiny_angle(rng, n):
+    """R(a, theta), theta from 1e-12 to 1e-2 -- across the thresholds below which log3 / Jlog3 / log6 switch to their Taylor forms
+    (pinocchio's TaylorSeriesExpansion<double>::precision<3>() = eps^(1/4) ~ 1.2e-4; SURVEY.md App. A.3) -- and, every eighth lane, the
+    identity: the target IS the frame's orientation."""
+    a = rng.normal(size=(n, 3))
+    a /= np.linalg.norm(a, axis=1)[:, None]
+    th = 10.0 ** rng.uniform(-12.0, -2.0, n)
+    th[::8] = 0.0
+    K = np.zeros((n, 3, 3))
+    K[:, 0, 1], K[:, 0, 2], K[:, 1, 0], K[:, 1, 2], K[:, 2, 0], K[:, 2, 1] = -a[:, 2], a[:, 1], a[:, 2], -a[:, 0], -a[:, 1], a[:, 0]
+    return np.eye(3)[None] + np.sin(th)[:, None, None] * K + (1.0 - np.cos(th))[:, None, None] * (K @ K)
+
+
+@pytest.mark.parametrize("name,free_flyer,frames,build", CASES)
+def test_one_step_towards_a_target_a_tiny_turn_away(torch_cuda, name, free_flyer, frames, build):
+    """The other end of the angle range: the Taylor branches of log3 / Jlog3 / log6 and their thresholds, and theta = 0 exactly."""
+    _one_step(torch_cuda, name, free_flyer, frames, build, _rotations_by_a_tiny_angle, offset=1e-6, bar=1e-9)
+
+
 @pytest.mark.parametrize("name,free_flyer,frames,build", CASES)
 def test_one_step_towards_a_target_just_short_of_half_a_turn_away(torch_cuda, name, free_flyer, frames, build):
+    _one_step(torch_cuda, name, free_flyer, frames, build, _rotations_just_short_of_pi, offset=0.05, bar=1e-6)
+
+
+def _one_step(torch_cuda, name, free_flyer, frames, build, rotations, offset, bar):
     torch = torch_cuda
     import ik_amd
     import oracle as O
@@ -70,8 +93,8 @@ def test_one_step_towards_a_target_just_short_of_half_a_turn_away(torch_cuda, na
     tg = np.empty((B, len(frames), 12))
     for t in range(len(frames)):
         Rf = T0[t, :9].T.reshape(B, 3, 3)
-        tg[:, t, :9] = (Rf @ _rotations_just_short_of_pi(rng, B)).reshape(B, 9)
-        tg[:, t, 9:] = T0[t, 9:].T + rng.uniform(-0.05, 0.05, (B, 3))
+        tg[:, t, :9] = (Rf @ rotations(rng, B)).reshape(B, 9)
+        tg[:, t, 9:] = T0[t, 9:].T + rng.uniform(-offset, offset, (B, 3)) * (np.arange(B) % 16 != 0)[:, None]   # (every sixteenth lane: no offset at all)
     T = torch.from_numpy(np.ascontiguousarray(tg.transpose(1, 2, 0))).cuda()
     out = ik_amd.dls_batch(problem, Q0, T, data, ik_amd.never_stop_visitor(), ik_amd.dls_parameters(max_iterations=1))
     q_dev = out[0].cpu().numpy().T
@@ -88,5 +111,5 @@ def test_one_step_towards_a_target_just_short_of_half_a_turn_away(torch_cuda, na
     q_x, _, _ = O.dls_batch(om, tasks, tg[worst], q0[worst], one, cores, ext="q")
     e_dev, e_orc = np.abs(q_dev[worst] - q_x).max(axis=1), np.abs(q_ref[worst] - q_x).max(axis=1)
     print("%s [%s]: max |dq| vs oracle %.2e; worst lanes: device %.2e, oracle %.2e from the _Float128 step" % (name, data.kernel, d.max(), e_dev.max(), e_orc.max()))
-    assert d.max() < 1e-6, (data.kernel, d.max(), int(np.argmax(d)))
+    assert d.max() < bar, (data.kernel, d.max(), int(np.argmax(d)))
     assert e_dev.max() <= 10.0 * max(e_orc.max(), 1e-9), (data.kernel, e_dev.max(), e_orc.max())
